@@ -1,0 +1,78 @@
+"""Golden-vector case table shared by ``make_golden.py`` (which runs the real reference
+in the build container) and the tests (which regenerate the same seeded weights/inputs
+and compare the oracle / the HIP path against the stored reference outputs).
+
+A case is data only: a config name, a weight seed and a synthetic-proposal spec.
+"""
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_PKG = os.path.join(_ROOT, "vidsgg-big_amd")
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+from bigc_hip import configs  # noqa: E402
+from bigc_hip.synthetic import synthetic_proposal, bigc_state_shapes, seeded_state_dict  # noqa: E402
+
+GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
+
+# name -> dict(cfg, variant, wseed, topk, att_gain, videos=[proposal kwargs...])
+BIGC_CASES = {
+    # G1: tiny dims, every intermediate stored
+    "bigc_tiny": dict(cfg="CONFIG_TINY", variant="vidvrd", wseed=11, topk=3, att_gain=6.0, full=True,
+                      videos=[dict(seed=101, n_trajs=6, len_range=(5, 13), start_range=(0, 6))]),
+    # tiny dims without I3D (the other concat order, models/model_0v10.py:503)
+    "bigc_tiny_noi3d": dict(cfg="CONFIG_TINY_NOI3D", variant="vidvrd", wseed=12, topk=3, att_gain=6.0, full=True,
+                            videos=[dict(seed=102, n_trajs=7, len_range=(5, 13), start_range=(0, 6))]),
+    # G5 edge cases at tiny dims: single tracklet (=> None, no pair), Tmax=5 (conv out 3 < pool 4),
+    # disjoint durations (=> None), empty video (=> None)
+    "bigc_tiny_edges": dict(cfg="CONFIG_TINY", variant="vidvrd", wseed=13, topk=3, att_gain=6.0, full=False,
+                            videos=[dict(seed=201, n_trajs=1, len_range=(9, 10), start_range=(0, 1)),
+                                    dict(seed=202, n_trajs=5, len_range=(5, 6), start_range=(0, 3)),
+                                    dict(seed=203, n_trajs=3, len_range=(5, 6), start_range=(0, 1), disjoint=True),
+                                    dict(seed=204, n_trajs=0),
+                                    dict(seed=205, n_trajs=9, len_range=(5, 40), start_range=(0, 30))]),
+    # G2: full config V, N=64, the benchmark's first video (seed 1234)
+    "bigc_v_n64": dict(cfg="CONFIG_V", variant="vidvrd", wseed=7, topk=10, att_gain=8.0, full=False,
+                       videos=[dict(seed=1234, n_trajs=64)]),
+}
+
+
+def get_cfg(name):
+    if name == "CONFIG_TINY_NOI3D":
+        c = dict(configs.CONFIG_TINY)
+        c.pop("dim_i3d")
+        return c
+    return dict(getattr(configs, name))
+
+
+def feat_width(cfg, variant):
+    if variant == "vidvrd":
+        return cfg["dim_feat"] + (cfg.get("dim_i3d", None) or 0)
+    return cfg["dim_feat"] + (cfg["dim_clsme"] if cfg.get("use_clsme", False) and cfg.get("EntiNameEmb_path") is None else 0)
+
+
+def make_proposal(cfg, variant, spec):
+    spec = dict(spec)
+    disjoint = spec.pop("disjoint", False)
+    p = synthetic_proposal(feat_width=feat_width(cfg, variant), num_enti_cats=cfg["num_enti_cats"], **spec)
+    if disjoint and p.num_proposals > 0:
+        # place the tracklets one after the other so that no two overlap in time
+        t = 0
+        for i in range(p.num_proposals):
+            n = p.bboxes_list[i].shape[0]
+            p.traj_durations[i, 0] = t
+            p.traj_durations[i, 1] = t + n - 1
+            t += n + 2
+        p.video_len = t
+    return p
+
+
+def make_case(name):
+    """-> (cfg, variant, state_dict, [proposals], topk)"""
+    case = BIGC_CASES[name]
+    cfg = get_cfg(case["cfg"])
+    sd = seeded_state_dict(bigc_state_shapes(cfg, case["variant"]), case["wseed"], case.get("att_gain", 1.0))
+    props = [make_proposal(cfg, case["variant"], v) for v in case["videos"]]
+    return cfg, case["variant"], sd, props, case["topk"]

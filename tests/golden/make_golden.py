@@ -1,0 +1,132 @@
+"""Generate the golden fixtures by running the REAL reference (Dawn-LX/VidSGG-BIG at
+/root/reference) in the build container.  Not run by the tests and never on the GPU box.
+
+    python tests/golden/make_golden.py [case ...]
+
+The reference is imported read-only with two stub modules (``cv2``, ``torchvision.ops``)
+because ``utils/utils_func.py:9,12`` imports them at module top although the hot path
+uses neither.  Weights and inputs come from the numpy-seeded
+generators in ``bigc_hip.synthetic`` (the tests regenerate them bit-identically); only
+the reference's OUTPUTS are stored, as ``tests/golden/<case>.npz``.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import cases  # noqa: E402
+
+REFERENCE = "/root/reference"
+
+
+def import_reference():
+    for m in ("cv2", "torchvision", "torchvision.ops"):
+        if m not in sys.modules:
+            sys.modules[m] = types.ModuleType(m)
+    sys.modules["torchvision.ops"].roi_pool = lambda *a, **k: None
+    # the build's own packages are also called models/utils: the reference must win here
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "utils" or k.startswith("utils.")]:
+        del sys.modules[k]
+    sys.path.insert(0, REFERENCE)
+    import models.model_0v10 as m10
+    import models.model_0v7 as m07
+    import models.grd_model_v5 as grd
+    sys.path.remove(REFERENCE)
+    return m10, m07, grd
+
+
+def build_reference_bigc(mod, cfg, sd):
+    d = tempfile.mkdtemp()
+    cfg = dict(cfg)
+    np.save(os.path.join(d, "bias.npy"), sd["bias_matrix"].numpy())
+    cfg["bias_matrix_path"] = os.path.join(d, "bias.npy")
+    if "EntiNameEmb" in sd:
+        np.save(os.path.join(d, "emb.npy"), sd["EntiNameEmb"].numpy())
+        cfg["EntiNameEmb_path"] = os.path.join(d, "emb.npy")
+    model = mod.BIG_C(cfg, is_train=False)
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    model.eval()
+    return model
+
+
+def run_bigc_case(name, m10, m07):
+    case = cases.BIGC_CASES[name]
+    cfg, variant, sd, props, topk = cases.make_case(name)
+    mod = m10 if variant == "vidvrd" else m07
+    model = build_reference_bigc(mod, cfg, sd)
+    out = {"torch_version": np.array(torch.__version__), "n_videos": np.array(len(props))}
+    captured = {}
+
+    def hook(tag):
+        def f(_m, _i, o):
+            captured.setdefault(tag, []).append(o)
+        return f
+
+    handles = [
+        model.fc_bbox2enti.register_forward_hook(hook("fc_bbox2enti")),
+        model.fc_feat2enti.register_forward_hook(hook("fc_feat2enti")),
+        model.conv_feat2enti.register_forward_hook(hook("conv")),
+        model.fc_enti2enco.register_forward_hook(hook("enti2enco")),
+    ]
+    for i, l in enumerate(model.encoder_layers):
+        handles.append(l.register_forward_hook(hook("enc%d" % i)))
+    for i, l in enumerate(model.decoder_layers):
+        handles.append(l.register_forward_hook(hook("dec%d" % i)))
+
+    with torch.no_grad():
+        for v, p in enumerate(props):
+            captured.clear()
+            res = model([p], topk=topk)[0]
+            pre = "v%d_" % v
+            out[pre + "is_none"] = np.array(res is None)
+            if res is not None:
+                out[pre + "quintuples"] = res[0].numpy()
+                out[pre + "scores"] = res[1].numpy()
+                out[pre + "dura_inters"] = res[2].numpy()
+                out[pre + "query_ids"] = res[3].numpy()
+            if p.num_proposals == 0:
+                continue
+            captured.clear()
+            pq, logits, att = model.encode2decode(p)
+            out[pre + "pred_logits"] = logits.numpy()
+            out[pre + "att"] = att.numpy()
+            out[pre + "pred_query"] = pq.numpy()
+            out[pre + "enti2enco"] = captured["enti2enco"][0].numpy()
+            out[pre + "enco_output"] = captured["enc%d" % (cfg["n_enco_layers"] - 1)][0].squeeze(1).numpy()
+            if case.get("full", False):
+                out[pre + "fc_bbox2enti"] = captured["fc_bbox2enti"][0].numpy()
+                out[pre + "fc_feat2enti"] = captured["fc_feat2enti"][0].numpy()
+                out[pre + "conv"] = captured["conv"][0].permute(0, 2, 1).numpy()
+                for i in range(cfg["n_enco_layers"]):
+                    out[pre + "enc%d" % i] = captured["enc%d" % i][0].squeeze(1).numpy()
+                for i in range(cfg["n_deco_layers"]):
+                    q, a = captured["dec%d" % i][0]
+                    out[pre + "dec%d_query" % i] = q.numpy()
+                    out[pre + "dec%d_att" % i] = a.numpy()
+    for h in handles:
+        h.remove()
+    path = os.path.join(cases.GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def main():
+    torch.manual_seed(0)
+    m10, m07, grd = import_reference()
+    names = sys.argv[1:] or list(cases.BIGC_CASES)
+    for n in names:
+        if n in cases.BIGC_CASES:
+            run_bigc_case(n, m10, m07)
+        else:
+            raise SystemExit("unknown case " + n)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,211 @@
+"""Seeded weights and synthetic tracklet proposals for parity tests and the benchmark.
+
+Everything here is generated from ``numpy.random.RandomState`` so that the GPU box
+regenerates bit-identical weights and inputs without the reference being present
+(SURVEY.md section 8c/8d).  The synthetic-video recipe is the one SURVEY.md section 8(d)
+prescribes: per video v (seed ``base_seed + v``) N tracklets, ``L_i = randint(8,64)``,
+``start_i = randint(0,64)``, boxes ``xy~U(0,600)``, ``wh~U(10,110)`` (xyxy), frame
+1280x720, features ``~N(0,1)``, ``cat_ids = randint(1,num_enti_cats)``, scores ``U(0,1)``
+sorted descending (the order ``dataloaders/dataloader_vidvrd.py:40-46`` produces).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+class TrajProposal(object):
+    """Duck-typed stand-in for the reference's per-video tracklet container.
+
+    Attribute names, dtypes and the closed-interval duration convention follow
+    ``dataloaders/dataloader_vidvrd.py:14-77`` (``TrajProposal``): ``num_proposals``,
+    ``video_len``, ``video_wh``, ``traj_durations`` (int64 (N,2), closed),
+    ``bboxes_list`` (N x f32 (L_i,4) xyxy pixels), ``features_list`` (N x f32 (L_i,D)),
+    ``cat_ids`` (int64 (N,)), ``scores`` (f32 (N,)), ``video_name``; ``to(device)`` moves
+    the tensors in place and returns ``self``.
+    """
+
+    def __init__(self, video_name, video_len, video_wh, cat_ids, scores, traj_durations,
+                 bboxes_list, features_list):
+        self.video_name = video_name
+        self.video_len = int(video_len)
+        self.video_wh = tuple(video_wh)
+        self.num_proposals = len(bboxes_list)
+        if self.num_proposals == 0:
+            return
+        self.cat_ids = torch.as_tensor(cat_ids, dtype=torch.long)
+        self.scores = torch.as_tensor(scores, dtype=torch.float32)
+        self.traj_durations = torch.as_tensor(traj_durations, dtype=torch.long)
+        self.bboxes_list = [torch.as_tensor(b, dtype=torch.float32) for b in bboxes_list]
+        self.features_list = [torch.as_tensor(f, dtype=torch.float32) for f in features_list]
+        self.dim_feat = self.features_list[0].shape[1]
+        for i in range(self.num_proposals):
+            n = int(self.traj_durations[i, 1] - self.traj_durations[i, 0] + 1)
+            assert self.bboxes_list[i].shape == (n, 4)
+            assert self.features_list[i].shape[0] == n
+
+    def to(self, device):
+        if self.num_proposals == 0:
+            return self
+        self.cat_ids = self.cat_ids.to(device)
+        self.scores = self.scores.to(device)
+        self.traj_durations = self.traj_durations.to(device)
+        for i in range(self.num_proposals):
+            self.bboxes_list[i] = self.bboxes_list[i].to(device)
+            self.features_list[i] = self.features_list[i].to(device)
+        return self
+
+    def __repr__(self):
+        return "TrajProposal[{},num_proposals={}]".format(self.video_name, self.num_proposals)
+
+
+def synthetic_proposal(seed, n_trajs=64, feat_width=2048 + 832, num_enti_cats=36,
+                       len_range=(8, 64), start_range=(0, 64), video_wh=(1280, 720),
+                       name=None, feat_scale=1.0):
+    """One synthetic video following SURVEY.md section 8(d)."""
+    rs = np.random.RandomState(seed)
+    if n_trajs == 0:
+        return TrajProposal(name or "synth_%d" % seed, 0, video_wh, [], [], [], [], [])
+    lens = rs.randint(len_range[0], len_range[1], size=n_trajs)
+    starts = rs.randint(start_range[0], start_range[1], size=n_trajs)
+    video_len = int((starts + lens).max())
+    duras = np.stack([starts, starts + lens - 1], axis=1).astype(np.int64)
+    cat_ids = rs.randint(1, num_enti_cats, size=n_trajs).astype(np.int64)
+    scores = np.sort(rs.uniform(0, 1, size=n_trajs).astype(np.float32))[::-1].copy()
+    bboxes, feats = [], []
+    for i in range(n_trajs):
+        xy = rs.uniform(0, 600, size=(lens[i], 2))
+        wh = rs.uniform(10, 110, size=(lens[i], 2))
+        bboxes.append(np.concatenate([xy, xy + wh], axis=1).astype(np.float32))
+        feats.append((feat_scale * rs.standard_normal((lens[i], feat_width))).astype(np.float32))
+    return TrajProposal(name or "synth_%d" % seed, video_len, video_wh, cat_ids, scores, duras,
+                        bboxes, feats)
+
+
+# --------------------------------------------------------------------------------------
+# seeded weights
+# --------------------------------------------------------------------------------------
+
+def _mha_shapes(prefix, d):
+    return [
+        (prefix + ".in_proj_weight", (3 * d, d)),
+        (prefix + ".in_proj_bias", (3 * d,)),
+        (prefix + ".out_proj.weight", (d, d)),
+        (prefix + ".out_proj.bias", (d,)),
+    ]
+
+
+def _linear_shapes(prefix, n_out, n_in, bias=True):
+    out = [(prefix + ".weight", (n_out, n_in))]
+    if bias:
+        out.append((prefix + ".bias", (n_out,)))
+    return out
+
+
+def _ln_shapes(prefix, d):
+    return [(prefix + ".weight", (d,)), (prefix + ".bias", (d,))]
+
+
+def bigc_state_shapes(cfg, variant="vidvrd"):
+    """Ordered (key, shape) list of the BIG-C ``state_dict``.
+
+    Key names and shapes are the reference's (``models/model_0v10.py:266-334`` for
+    ``variant="vidvrd"``, ``models/model_0v7.py:265-341`` for ``variant="vidor"``; dump in
+    SURVEY.md section 8b).
+    """
+    de, dp, da, df = cfg["dim_enti"], cfg["dim_pred"], cfg["dim_att"], cfg["dim_ffn"]
+    q = cfg["num_querys"]
+    ne, npred = cfg["num_enti_cats"], cfg["num_pred_cats"]
+    shapes = []
+    if variant == "vidvrd" or cfg.get("EntiNameEmb_path", None) is not None or cfg.get("_with_EntiNameEmb", False):
+        shapes.append(("EntiNameEmb", (ne, cfg["dim_clsme"])))
+    shapes += [("pos_embedding", (q, dp)), ("pred_query_init", (q, dp)),
+               ("bias_matrix", (ne, ne, npred))]
+    shapes += _linear_shapes("fc_feat2enti.0", de, cfg["dim_feat"])
+    shapes += _linear_shapes("fc_feat2enti.2", de, de)
+    shapes += _linear_shapes("fc_bbox2enti.0", de, 8)
+    shapes += _linear_shapes("fc_bbox2enti.2", de, de)
+    shapes += [("conv_feat2enti.weight", (de, 2 * de, 3)), ("conv_feat2enti.bias", (de,))]
+    shapes += _linear_shapes("fc_enti2enco.0", de, de * cfg["enco_pool_len"])
+    shapes += _linear_shapes("fc_enti2enco.2", de, de)
+    if variant == "vidvrd" and cfg.get("dim_i3d", None):
+        shapes += _linear_shapes("fc_i3d.0", de, cfg["dim_i3d"])
+    for i in range(cfg["n_enco_layers"]):
+        p = "encoder_layers.%d" % i
+        shapes += _mha_shapes(p + ".self_attn", de)
+        shapes += _linear_shapes(p + ".linear1", df, de)
+        shapes += _linear_shapes(p + ".linear2", de, df)
+        shapes += _ln_shapes(p + ".norm1", de) + _ln_shapes(p + ".norm2", de)
+    for i in range(cfg["n_deco_layers"]):
+        p = "decoder_layers.%d" % i
+        shapes += _mha_shapes(p + ".self_attn", dp)
+        for r in range(2):
+            shapes += _linear_shapes(p + ".fc_rolewise.%d.0" % r, dp, de)
+            shapes += _linear_shapes(p + ".fc_rolewise.%d.2" % r, dp, dp)
+        shapes += _linear_shapes(p + ".fc_enti2att", da, de)
+        shapes += _linear_shapes(p + ".fc_pred2att", da, dp)
+        shapes += _linear_shapes(p + ".fc2.0", df, dp)
+        shapes += _linear_shapes(p + ".fc2.3", dp, df)
+        shapes += _ln_shapes(p + ".norm1", dp) + _ln_shapes(p + ".norm2", dp) + _ln_shapes(p + ".norm3", dp)
+    if variant == "vidvrd":
+        if cfg.get("dim_i3d", None):
+            k = dp + 2 * cfg["dim_clsme"] + 4 * de
+        else:
+            k = dp + 2 * cfg["dim_clsme"] + 2 * de
+        shapes += _linear_shapes("fc_pred2logits", npred, k)
+    else:
+        k = dp + 2 * de + (2 * cfg["dim_clsme"] if cfg["use_clsme"] else 0)
+        shapes += _linear_shapes("fc_pred2logits.0", df, k)
+        shapes += _linear_shapes("fc_pred2logits.2", npred, df)
+    return shapes
+
+
+def _fill(rs, key, shape, att_gain=1.0):
+    """Seeded value for one state_dict entry (SURVEY.md section 8d weight recipe)."""
+    leaf = key.split(".")[-1]
+    if key in ("pos_embedding", "pred_query_init"):
+        return rs.normal(0.0, 0.1, size=shape)
+    if key == "bias_matrix":
+        return rs.uniform(-7.0, 0.0, size=shape)
+    if key in ("EntiNameEmb", "PredNameEmb"):
+        return rs.normal(0.0, 0.4, size=shape)
+    if ".norm" in key:
+        if leaf == "weight":
+            return 1.0 + rs.normal(0.0, 0.05, size=shape)
+        return rs.normal(0.0, 0.02, size=shape)
+    if len(shape) == 1:
+        return rs.normal(0.0, 0.02, size=shape)
+    recept = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+    fan_out, fan_in = shape[0] * recept, shape[1] * recept
+    std = np.sqrt(2.0 / (fan_in + fan_out))
+    if "fc_enti2att" in key or "fc_pred2att" in key:
+        std *= att_gain
+    return rs.normal(0.0, std, size=shape)
+
+
+def seeded_state_dict(shapes, seed, att_gain=1.0):
+    """numpy-seeded fill of a list of (key, shape): xavier-scaled normal matrices,
+    small biases, LayerNorm weights near one, query/pos embeddings N(0,0.1),
+    ``bias_matrix`` in [-7,0] (the range of log(p+1e-3))."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for key, shape in shapes:
+        sd[key] = torch.from_numpy(np.asarray(_fill(rs, key, shape, att_gain), dtype=np.float32))
+    return sd
+
+
+def sine_pos_emb(length, d_model):
+    """Fixed sine table used as ``pos_embedding`` by the VidOR model.
+
+    Same values as the reference's ``SinePosEmb`` (models/model_0v7.py:229-238):
+    entry (p, i) = sin(p * f_i + ph_i) evaluated in float32, with
+    f_i = 10000^(-i/d) (i even) or -(10000^((1-i)/d)) (i odd) and ph_i = 0 / pi/2.
+    """
+    idx = np.arange(d_model)
+    even = (idx % 2) == 0
+    f = np.where(even, 10000.0 ** (-idx / d_model), -(10000.0 ** ((1 - idx) / d_model)))
+    ph = np.where(even, 0.0, np.pi / 2)
+    f32 = torch.from_numpy(f.astype(np.float32))
+    ph32 = torch.from_numpy(ph.astype(np.float32))
+    pos = torch.arange(length, dtype=torch.float32)
+    return torch.sin(pos[:, None] * f32[None, :] + ph32[None, :])

@@ -1,0 +1,203 @@
+/*
+ * bigc_hip.h -- C ABI of the MI355X-native BIG classification-then-grounding hot path.
+ *
+ * The reference (Dawn-LX/VidSGG-BIG) is pure Python/PyTorch and has no FFI; the drop-in
+ * boundary is therefore the nn.Module forward() of
+ *     models/model_0v10.py:359  BIG_C.forward(proposal_list, gt_graph_list=None, topk=10)
+ *     models/model_0v7.py:362   BIG_C.forward(proposal_list, gt_graph_list=None, topk=3)
+ *     models/grd_model_v5.py:196 DEBUG.forward(video_feature_list, data_list, ...)
+ * and this header is what those forward()s bind (through ctypes).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - the caller owns all buffers (allocated with torch), the library never frees them;
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, nothing
+ *     synchronises the device;
+ *   - every function returns 0 on success or a negative bigc_status; the message of the
+ *     last failure on the calling thread is returned by bigc_last_error();
+ *   - one handle per device and per model; a handle may be used from one thread at a time.
+ *   - all floating point is IEEE fp32 (f32 MFMA, fp32 accumulate); indices are int32 on
+ *     the device side (the Python host converts to the reference's int64 at the boundary).
+ */
+#ifndef BIGC_HIP_H
+#define BIGC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    BIGC_OK = 0,
+    BIGC_ERR_ARG = -1,       /* bad argument / shape violation (the reference raises AssertionError) */
+    BIGC_ERR_MISSING = -2,   /* a parameter named by the model was never set */
+    BIGC_ERR_HIP = -3,       /* a HIP runtime call failed */
+    BIGC_ERR_WORKSPACE = -4  /* workspace too small */
+} bigc_status;
+
+const char* bigc_last_error(void);
+/* "gfx950 f32-mfma <build id>" -- lets the host verify it loaded the HIP build */
+const char* bigc_build_info(void);
+
+/* ------------------------------------------------------------------------------------
+ * Kernel-level entry points (one per hand-written kernel family).  The model-level
+ * functions below are compositions of these; tests call them directly to compare each
+ * kernel with the oracle.
+ * ---------------------------------------------------------------------------------- */
+
+#define BIGC_ACT_NONE 0
+#define BIGC_ACT_RELU 1
+
+/* C[m, n] = act( sum_k A'[m, k] * W[n, k] + bias[n] ) + residual[m, n]
+ *   replaces torch.nn.Linear / F.linear at every call site of the path
+ *   (models/model_0v10.py:446-447,458,113,190-191,212,220,498,504) and, with the
+ *   segmented row gather, nn.Conv1d(k=3,stride=2) as an implicit GEMM (:451).
+ *   A' is A when a_idx == NULL.  Otherwise the K axis is cut in `nseg` segments of
+ *   `seg_len` (K == nseg*seg_len) and row m, segment s of A' is row a_idx[m*nseg+s] of A
+ *   (columns [0, seg_len)), or zeros when that index is negative.
+ *   W is row-major (N, K) with leading dimension ldw (the torch weight layout).
+ *   bias / residual may be NULL. The residual is added AFTER the activation.
+ *   K must be a multiple of 4; lda, ldw multiples of 4; A and W 16-byte aligned. */
+int bigc_linear_f32(void* stream, const float* A, int lda, const int32_t* a_idx, int nseg, int seg_len,
+                    const float* W, int ldw, const float* bias, const float* residual, int ldr,
+                    float* C, int ldc, int M, int N, int K, int act);
+
+/* y[r, :] = LayerNorm(x[r, :]) * gamma + beta over d columns, eps inside the sqrt
+ *   (torch.nn.LayerNorm, models/model_0v10.py:81-82,171-173). d <= 2048, d % 4 == 0. */
+int bigc_layernorm_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y,
+                       int rows, int d, float eps);
+
+/* y[r, :] = x[r, :] + p[r % period, :]   (query + pos_embedding broadcast over the videos of a batch,
+ *   models/model_0v10.py:182,189); x == NULL means zeros (tiles pred_query_init over the batch, :465) */
+int bigc_add_rows_f32(void* stream, const float* x, const float* p, float* y, int rows, int d, int period);
+
+/* Multi-head attention core for ragged sequences (torch.nn.MultiheadAttention after the
+ *   in-projection and before out_proj: softmax(q k^T / sqrt(hd)) v, models/model_0v10.py:109,183;
+ *   models/grd_model_v5.py:105).  Sequence s owns query rows [q_off[s], q_off[s+1]) of q/o and key
+ *   rows [k_off[s], k_off[s+1]) of k/v; head h uses columns [h*hd, (h+1)*hd).
+ *   hd in {8, 16, 32, 64}. */
+int bigc_mha_core_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                      float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
+                      int n_head, int hd);
+
+/* Role attention of the decoder (models/model_0v10.py:193-207):
+ *   s_r[q, n] = p2a[q, r*half:(r+1)*half] . e2a[n, r*half:(r+1)*half] * scale   (r = 0 subject, 1 object)
+ *   att_r = softmax_n(s_r) * softmax_r(s)[r]
+ *   Video v owns query rows [v*nq, (v+1)*nq) of p2a and entity rows [e_off[v], e_off[v+1]) of e2a;
+ *   att is stored per video as (2, nq, N_v) at float offset 2*nq*e_off[v]. */
+int bigc_role_attention_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, float* att,
+                            const int32_t* e_off, int n_vid, int nq, int half, float scale);
+
+/* values[r][v*nq + q, :] = att_v[r, q, :] @ enco[e_off[v]:e_off[v+1], :]   (models/model_0v10.py:211)
+ *   values is (2, n_vid*nq, d) contiguous. */
+int bigc_role_values_f32(void* stream, const float* att, const float* enco, int lde, float* values,
+                         const int32_t* e_off, int n_vid, int nq, int d);
+
+/* Tracklet front-end helpers ------------------------------------------------------- */
+
+/* (R,4) xyxy pixel boxes -> (R,8) [cx,dcx,cy,dcy,w,dw,h,dh], boxes divided by the video's (w,h),
+ *   forward differences inside each tracklet with 0 at the tracklet's last frame
+ *   (models/model_0v10.py:401-420). trk_row_off (NT+1), trk_vid (NT), vid_wh (B,2). */
+int bigc_bbox_feat_f32(void* stream, const float* boxes, const int32_t* trk_row_off, const int32_t* trk_vid,
+                       const float* vid_wh, float* out, int n_trk);
+
+/* Row gather table of the stride-2 k=3 temporal conv over the virtually stretched sequence
+ *   (stretch: models/model_0v10.py:18-46, conv :302,451): for tracklet t, output position j
+ *   (0 <= j < T_o = (Tmax-1)/2+1), tap c in {0,1,2}: stretched frame f = 2j-1+c; entry is -1 when
+ *   f < 0 or f >= Tmax, else trk_row_off[t] + src(f) with src the stretch map.
+ *   conv_idx is (C,3) with C = trk_conv_off[n_trk]. */
+int bigc_conv_index(void* stream, const int32_t* trk_row_off, const int32_t* trk_conv_off, const int32_t* trk_vid,
+                    const int32_t* vid_tmax, int32_t* conv_idx, int n_trk);
+
+/* adaptive_max_pool1d(T_o -> P) per tracklet and channel, stored channel-major (index c*P+p)
+ *   (models/model_0v10.py:456-457). conv (C, d) row-major; pooled (NT, d*P). */
+int bigc_adaptive_maxpool(void* stream, const float* conv, const int32_t* trk_conv_off, float* pooled,
+                          int n_trk, int d, int P);
+
+/* Mean over the Tmax stretched frames of columns [col0, col0+w) of the tracklet's feature rows
+ *   (models/model_0v10.py:470 I3D mean; models/model_0v7.py:473 classeme mean): a weighted mean
+ *   with the stretch repeat counts. out (NT, w). */
+int bigc_stretched_mean(void* stream, const float* feats, int ldf, int col0, int w, const int32_t* trk_row_off,
+                        const int32_t* trk_vid, const int32_t* vid_tmax, float* out, int n_trk);
+
+/* Prediction-head gather (models/model_0v10.py:485-503, models/model_0v7.py:485-508):
+ *   soid[v, r, q] = argmax_n att_v[r, q, n] (first maximum), then per query row the concat
+ *   [query | seg_1[s] | seg_1[o] | seg_2[s] | seg_2[o] | ...] is written to head_in, where segment i
+ *   is a per-tracklet table (src[i], width[i]) indexed by the tracklet (by_cat[i]==0) or a per-category
+ *   table indexed by cat id (by_cat[i]==1); bias_out[row, :] = bias_matrix[cat_s, cat_o, :]. */
+int bigc_head_gather(void* stream, const float* att, const int32_t* e_off, const int32_t* trk_cat, int n_vid, int nq,
+                     const float* query, int dq, int n_seg, const float* const* seg_src_host, const int32_t* seg_width_host,
+                     const int32_t* seg_by_cat_host, const float* bias_matrix, int n_ecat, int n_pcat,
+                     int32_t* soid, float* head_in, int ld_head, float* bias_out);
+
+/* construct_triplet (models/model_0v10.py:707-785), one video per workgroup, index-exact:
+ *   softmax + top-k per query, subject/object from soid, closed-interval overlap filter with the
+ *   diagonal cleared, lexicographic unique of [pred, s_cat, o_cat, s_tid, o_tid] with the first
+ *   highest-probability candidate as representative, background predicate (0) dropped.
+ *   Outputs are padded to cap = nq*topk rows per video; n_out[v] rows are valid (0 => the reference
+ *   returns None).  quint (B,cap,5) i32, scores (B,cap,3) f32, dura (B,cap,2) i32, qid (B,cap) i32. */
+int bigc_construct_triplets(void* stream, const float* logits, int n_pcat, const int32_t* soid, const int32_t* e_off,
+                            const int32_t* trk_dura, const int32_t* trk_cat, const float* trk_score, int n_vid, int nq,
+                            int topk, int32_t* quint, float* scores, int32_t* dura, int32_t* qid, int32_t* n_out);
+
+/* ------------------------------------------------------------------------------------
+ * Model-level API: BIG-C eval forward (a1..a9 of SURVEY.md section 8) over one packed batch.
+ * ---------------------------------------------------------------------------------- */
+
+typedef struct {
+    int32_t variant;        /* 0 = VidVRD model_0v10, 1 = VidOR model_0v7 */
+    int32_t num_enti_cats, num_pred_cats;
+    int32_t dim_feat, dim_extra; /* dim_extra = I3D width (variant 0) or classeme width carried in the features (variant 1), 0 if none */
+    int32_t dim_clsme, dim_enti, dim_pred, dim_att, dim_ffn;
+    int32_t enco_pool_len, n_enco_layers, n_deco_layers, n_att_head, num_querys;
+    int32_t use_clsme;      /* variant 1 only */
+    int32_t has_enti_emb;   /* EntiNameEmb table present (always for variant 0) */
+} bigc_config;
+
+typedef struct bigc_model bigc_model;
+
+int bigc_create(const bigc_config* cfg, bigc_model** out);
+void bigc_destroy(bigc_model* m);
+/* register a parameter by its reference state_dict key; the pointer must stay valid */
+int bigc_set_param(bigc_model* m, const char* key, const float* ptr, int64_t numel);
+/* resolve all keys, build derived device tables (tap-major conv weight); call again after weights change */
+int bigc_finalize(bigc_model* m, void* stream);
+
+/* One packed batch of videos: the device-resident ragged tracklet store. */
+typedef struct {
+    int32_t n_vid, n_trk, n_rows, n_conv;  /* B, NT = sum N_v, R = sum L_i, C = sum N_v*T_o(v) */
+    int32_t max_trk;               /* max_v N_v (<= 512) */
+    const float* feats;            /* (R, dim_feat+dim_extra) */
+    const float* boxes;            /* (R, 4) xyxy pixels */
+    const int32_t* trk_row_off;    /* (NT+1) */
+    const int32_t* trk_conv_off;   /* (NT+1) */
+    const int32_t* trk_vid;        /* (NT) */
+    const int32_t* trk_dura;       /* (NT,2) closed */
+    const int32_t* trk_cat;        /* (NT) */
+    const float* trk_score;        /* (NT) */
+    const int32_t* vid_trk_off;    /* (B+1) */
+    const int32_t* vid_tmax;       /* (B) */
+    const float* vid_wh;           /* (B,2) */
+} bigc_batch;
+
+typedef struct {
+    float* pred_logits;   /* (B*Q, P) */
+    float* att;           /* per video (2,Q,N_v) at float offset 2*Q*vid_trk_off[v]; total 2*Q*NT */
+    float* pred_query;    /* (B*Q, dim_pred) last decoder layer output, may be NULL */
+    float* enti2enco;     /* (NT, dim_enti) may be NULL */
+    float* enco_output;   /* (NT, dim_enti) may be NULL */
+    int32_t* soid;        /* (B,2,Q) */
+    /* construct_triplet outputs, see bigc_construct_triplets; all may be NULL to skip a8 */
+    int32_t* quint; float* scores; int32_t* dura; int32_t* qid; int32_t* n_out;
+} bigc_outputs;
+
+size_t bigc_workspace_bytes(const bigc_model* m, const bigc_batch* b);
+int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
+                 int topk, const bigc_outputs* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIGC_HIP_H */

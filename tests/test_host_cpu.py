@@ -1,0 +1,99 @@
+"""CPU-side checks (no GPU): the C-ABI library builds/loads and exports every symbol the header
+declares, the host packing logic, and the drop-in module surface."""
+import ctypes
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from bigc_hip import _lib
+from bigc_hip.packed import PackedBatch
+from bigc_hip.synthetic import bigc_state_shapes, seeded_state_dict, synthetic_proposal
+from oracle import bigc_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "bigc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bigc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "library does not export " + n
+    # every declared function has a ctypes signature on the Python side too
+    for n in names:
+        assert n in _lib._SIGS, "no ctypes signature for " + n
+    assert b"gfx950" in _lib.load().bigc_build_info()
+
+
+def test_packed_batch_offsets_cpu():
+    props = [synthetic_proposal(1, n_trajs=5, feat_width=12, len_range=(5, 9)),
+             synthetic_proposal(2, n_trajs=3, feat_width=12, len_range=(20, 31))]
+    pk = PackedBatch(props, "cpu")
+    assert pk.n_vid == 2 and pk.n_trk == 8 and pk.max_trk == 5
+    lens = [b.shape[0] for p in props for b in p.bboxes_list]
+    assert pk.n_rows == sum(lens)
+    assert pk.trk_row_off.tolist() == np.concatenate([[0], np.cumsum(lens)]).tolist()
+    tmax = [max(b.shape[0] for b in p.bboxes_list) for p in props]
+    assert pk.vid_tmax.tolist() == tmax
+    t_o = [(tmax[0] - 1) // 2 + 1] * 5 + [(tmax[1] - 1) // 2 + 1] * 3
+    assert pk.trk_conv_off.tolist() == np.concatenate([[0], np.cumsum(t_o)]).tolist()
+    assert pk.n_conv == sum(t_o)
+    assert pk.vid_trk_off.tolist() == [0, 5, 8]
+    assert pk.n_pairs() == 5 * 4 + 3 * 2
+    assert torch.equal(pk.feats[:lens[0]], props[0].features_list[0])
+    assert pk.trk_dura.dtype == torch.int32 and pk.trk_dura.shape == (8, 2)
+
+
+def test_dropin_module_surface():
+    from models import BIG_C_vidvrd, BIG_C_vidor
+    d = tempfile.mkdtemp()
+    for variant, cls, cname in (("vidvrd", BIG_C_vidvrd, "CONFIG_V"), ("vidor", BIG_C_vidor, "CONFIG_O")):
+        cfg = cases.get_cfg(cname)
+        np.save(d + "/b.npy", np.zeros((cfg["num_enti_cats"], cfg["num_enti_cats"], cfg["num_pred_cats"]), np.float32))
+        cfg["bias_matrix_path"] = d + "/b.npy"
+        if variant == "vidvrd":
+            np.save(d + "/e.npy", np.zeros((cfg["num_enti_cats"], cfg["dim_clsme"]), np.float32))
+            cfg["EntiNameEmb_path"] = d + "/e.npy"
+        m = cls(cfg, is_train=False)
+        got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert got == dict(bigc_state_shapes(cfg, variant))
+        if variant == "vidvrd":
+            assert sum(v.numel() for v in m.state_dict().values()) == 27776445
+        # checkpoints saved from the reference's DataParallel wrapper carry a "module." prefix
+        sd = {"module." + k: v for k, v in m.state_dict().items()}
+        m.load_state_dict({k[7:]: v for k, v in sd.items()})
+        # empty videos never reach the device
+        empty = synthetic_proposal(3, n_trajs=0)
+        assert m([empty, empty]) == [None, None]
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libbigc_hip.so")
+    with pytest.raises(_lib.BigcError):
+        _lib.load()
+
+
+def test_oracle_batch_independence():
+    """the oracle treats videos independently: a list call equals per-video calls"""
+    cfg, variant, sd, props, topk = cases.make_case("bigc_tiny_edges")
+    both = O.forward_test(sd, cfg, props, topk, variant)
+    for p, r in zip(props, both):
+        one = O.forward_test(sd, cfg, [p], topk, variant)[0]
+        assert (one is None) == (r is None)
+        if r is not None:
+            assert all(torch.equal(a, b) for a, b in zip(one, r))

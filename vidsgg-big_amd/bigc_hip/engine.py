@@ -1,0 +1,92 @@
+"""Host-side driver of the HIP BIG-C forward: owns the C model handle, keeps the parameter
+table in sync with the torch parameters, allocates outputs/workspace with torch and calls
+``bigc_forward`` on the current HIP stream."""
+import ctypes
+
+import torch
+
+from . import _lib
+from .packed import PackedBatch
+
+
+class BigcEngine(object):
+    def __init__(self, cfg, variant):
+        """``cfg``: the reference's ``model_config`` dict; ``variant``: "vidvrd" | "vidor"."""
+        self.lib = _lib.load()
+        c = _lib.bigc_config()
+        c.variant = 0 if variant == "vidvrd" else 1
+        c.num_enti_cats, c.num_pred_cats = cfg["num_enti_cats"], cfg["num_pred_cats"]
+        c.dim_feat, c.dim_clsme = cfg["dim_feat"], cfg["dim_clsme"]
+        c.dim_enti, c.dim_pred, c.dim_att, c.dim_ffn = cfg["dim_enti"], cfg["dim_pred"], cfg["dim_att"], cfg["dim_ffn"]
+        c.enco_pool_len, c.n_enco_layers, c.n_deco_layers = cfg["enco_pool_len"], cfg["n_enco_layers"], cfg["n_deco_layers"]
+        c.n_att_head, c.num_querys = cfg["n_att_head"], cfg["num_querys"]
+        if variant == "vidvrd":
+            c.dim_extra = cfg.get("dim_i3d", None) or 0
+            c.use_clsme, c.has_enti_emb = 1, 1
+        else:
+            c.use_clsme = 1 if cfg["use_clsme"] else 0
+            c.has_enti_emb = 1 if cfg.get("EntiNameEmb_path", None) is not None else 0
+            c.dim_extra = cfg["dim_clsme"] if (c.use_clsme and not c.has_enti_emb) else 0
+        self.c = c
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.bigc_create(ctypes.byref(c), ctypes.byref(self.handle)))
+        self._sig = None
+        self._keep = None
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and self.handle:
+                self.lib.bigc_destroy(self.handle)
+        except Exception:
+            pass
+
+    def sync_params(self, named_tensors):
+        """(Re-)register the parameter pointers when a tensor moved or was written in place."""
+        items = [(k, t) for k, t in named_tensors]
+        sig = tuple((k, t.data_ptr(), t._version) for k, t in items)
+        if sig == self._sig:
+            return
+        for k, t in items:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \
+                "parameter %s must be a contiguous fp32 tensor on the GPU" % k
+            _lib.check(self.lib.bigc_set_param(self.handle, k.encode(), t.data_ptr(), t.numel()))
+        _lib.check(self.lib.bigc_finalize(self.handle, _lib.current_stream()))
+        self._sig = sig
+        self._keep = [t for _, t in items]
+
+    def forward(self, packed, topk, with_triplets=True, keep_intermediates=False):
+        """Run a1..a8 on a PackedBatch. Returns a dict of device tensors (padded triplet arrays +
+        ``n_out`` counts); nothing here synchronises with the host."""
+        assert isinstance(packed, PackedBatch)
+        c = self.c
+        assert packed.feat_width == c.dim_feat + c.dim_extra, \
+            "feature width %d != dim_feat+extra %d" % (packed.feat_width, c.dim_feat + c.dim_extra)
+        dev = packed.device
+        B, NT, Q, P = packed.n_vid, packed.n_trk, c.num_querys, c.num_pred_cats
+        cap = Q * topk
+        out = {
+            "pred_logits": torch.empty((B * Q, P), dtype=torch.float32, device=dev),
+            "att": torch.empty((2 * Q * NT,), dtype=torch.float32, device=dev),
+            "soid": torch.empty((B, 2, Q), dtype=torch.int32, device=dev),
+        }
+        if keep_intermediates:
+            out["pred_query"] = torch.empty((B * Q, c.dim_pred), dtype=torch.float32, device=dev)
+            out["enti2enco"] = torch.empty((NT, c.dim_enti), dtype=torch.float32, device=dev)
+            out["enco_output"] = torch.empty((NT, c.dim_enti), dtype=torch.float32, device=dev)
+        if with_triplets:
+            out["quint"] = torch.empty((B, cap, 5), dtype=torch.int32, device=dev)
+            out["scores"] = torch.empty((B, cap, 3), dtype=torch.float32, device=dev)
+            out["dura"] = torch.empty((B, cap, 2), dtype=torch.int32, device=dev)
+            out["qid"] = torch.empty((B, cap), dtype=torch.int32, device=dev)
+            out["n_out"] = torch.empty((B,), dtype=torch.int32, device=dev)
+        o = _lib.bigc_outputs()
+        for name, _ in _lib.bigc_outputs._fields_:
+            setattr(o, name, out[name].data_ptr() if name in out else None)
+        b = packed.as_struct()
+        need = self.lib.bigc_workspace_bytes(self.handle, ctypes.byref(b))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _lib.check(self.lib.bigc_forward(self.handle, _lib.current_stream(), ctypes.byref(b), self._ws.data_ptr(),
+                                         self._ws.numel(), int(topk), ctypes.byref(o)))
+        return out

@@ -1,0 +1,318 @@
+// Attention kernels of the BIG hot path on f32 MFMA, one wave per 32-query tile, no LDS.
+//
+//   mha_core        softmax(q k^T / sqrt(hd)) v per (sequence, head)      -- nn.MultiheadAttention core
+//                   (reference: models/model_0v10.py:109,183; models/grd_model_v5.py:105)
+//   role_attention  softmax over entities x softmax over the two roles    -- models/model_0v10.py:193-207
+//   role_values     att_r @ enco_output per (video, role)                 -- models/model_0v10.py:211
+//
+// All three compute the TRANSPOSED score tile S^T = K Q^T (keys on MFMA rows, queries on MFMA
+// columns): a lane then owns one query (column lane&31) and 16 keys in its 16 accumulator
+// registers, so the softmax statistics of a query are an in-register reduction plus one
+// exchange with lane^32, and the probabilities are already laid out as the A operand of the
+// P V product (register r of lanes <32 / >=32 holds keys mfma_row(r,0) / mfma_row(r,1), exactly
+// the two k-slices one v_mfma_f32_32x32x2_f32 consumes).  Sequences are short (N <= 180
+// tracklets, 192 queries, T clips), so the kernels make two passes over the keys -- pass 1 for
+// the row max / sum, pass 2 recomputing the scores, normalising exactly as torch.softmax does
+// (exp(s - max) / sum) and accumulating P V -- instead of rescaling accumulators on line.
+// Operands come straight from L2 (the whole working set of a video is < 1 MB).
+#include "common.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1e30f;
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                       const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
+                                                       const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
+                                                       int n_seq, int n_qt, int n_head, float scale) {
+    constexpr int HALF = HD / 2;
+    constexpr int NTD = (HD + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n_seq * n_qt * n_head) return;
+    const int h = item % n_head;
+    const int qt = (item / n_head) % n_qt;
+    const int s = item / ((long)n_head * n_qt);
+    const int q0 = q_off[s], nq = q_off[s + 1] - q0;
+    const int k0 = k_off[s], nk = k_off[s + 1] - k0;
+    if (qt * 32 >= nq || nk <= 0) return;
+
+    // this lane's query row (clamped), its half of the head dim, pre-scaled
+    const int qrow = min(qt * 32 + l31, nq - 1);
+    float qf[HALF];
+    {
+        const float* qp = q + (size_t)(q0 + qrow) * ldq + h * HD + hi * HALF;
+#pragma unroll
+        for (int i = 0; i < HALF; i += 4) {
+            f32x4 t = *(const f32x4*)(qp + i);
+            qf[i] = t[0] * scale; qf[i + 1] = t[1] * scale; qf[i + 2] = t[2] * scale; qf[i + 3] = t[3] * scale;
+        }
+    }
+    const int n_kt = (nk + 31) / 32;
+
+    auto score_tile = [&](int kt) -> f32x16 {
+        const int krow = min(kt * 32 + l31, nk - 1);
+        const float* kp = k + (size_t)(k0 + krow) * ldk + h * HD + hi * HALF;
+        float kf[HALF];
+#pragma unroll
+        for (int i = 0; i < HALF; i += 4) {
+            f32x4 t = *(const f32x4*)(kp + i);
+            kf[i] = t[0]; kf[i + 1] = t[1]; kf[i + 2] = t[2]; kf[i + 3] = t[3];
+        }
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) acc = mfma32(kf[i], qf[i], acc);
+        return acc;
+    };
+
+    // pass 1: max and sum of exp over this lane's keys, then merge the two half-waves
+    float m = NEG_BIG, l = 0.f;
+    for (int kt = 0; kt < n_kt; ++kt) {
+        f32x16 sc = score_tile(kt);
+        float tm = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = kt * 32 + mfma_row(r, hi) < nk;
+            tm = ok ? fmaxf(tm, sc[r]) : tm;
+        }
+        const float mn = fmaxf(m, tm);
+        float add = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = kt * 32 + mfma_row(r, hi) < nk;
+            add += ok ? expf(sc[r] - mn) : 0.f;
+        }
+        l = l * expf(m - mn) + add;
+        m = mn;
+    }
+    {
+        const float mo = __shfl_xor(m, 32), lo = __shfl_xor(l, 32);
+        const float M = fmaxf(m, mo);
+        l = l * expf(m - M) + lo * expf(mo - M);
+        m = M;
+    }
+    const float inv = 1.f / l;
+
+    // pass 2: P = exp(s - M) / L, out += P V
+    f32x16 out[NTD];
+#pragma unroll
+    for (int t = 0; t < NTD; ++t) out[t] = zero16();
+    for (int kt = 0; kt < n_kt; ++kt) {
+        f32x16 sc = score_tile(kt);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + mfma_row(r, hi);
+            const bool ok = key < nk;
+            const float p = ok ? expf(sc[r] - m) * inv : 0.f;
+            const float* vp = v + (size_t)(k0 + min(key, nk - 1)) * ldv + h * HD;
+#pragma unroll
+            for (int t = 0; t < NTD; ++t) {
+                const int d = t * 32 + l31;
+                const float vv = (d < HD) ? vp[d] : 0.f;
+                out[t] = mfma32(p, vv, out[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTD; ++t) {
+        const int d = t * 32 + l31;
+        if (d >= HD) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = qt * 32 + mfma_row(r, hi);
+            if (row < nq) o[(size_t)(q0 + row) * ldo + h * HD + d] = out[t][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void role_attention_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
+                                                             float* __restrict__ att, const int32_t* __restrict__ e_off,
+                                                             int n_vid, int nq, int n_qt, int half, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n_vid * n_qt) return;
+    const int qt = item % n_qt, vid = item / n_qt;
+    const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
+    if (qt * 32 >= nq || ne <= 0) return;
+    const int qrow = min(qt * 32 + l31, nq - 1);
+    const int hh = half / 2;  // k-range of one half-wave
+    const float* qp = p2a + (size_t)(vid * nq + qrow) * ldp + hi * hh;
+    const int n_et = (ne + 31) / 32;
+
+    auto score_tile = [&](int et, f32x16& s0, f32x16& s1) {
+        const int erow = min(et * 32 + l31, ne - 1);
+        const float* ep = e2a + (size_t)(e0 + erow) * lde + hi * hh;
+        s0 = zero16();
+        s1 = zero16();
+        for (int i = 0; i < hh; i += 4) {
+            const f32x4 a0 = *(const f32x4*)(ep + i), a1 = *(const f32x4*)(ep + half + i);
+            const f32x4 b0 = *(const f32x4*)(qp + i), b1 = *(const f32x4*)(qp + half + i);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s0 = mfma32(a0[c], b0[c], s0);
+                s1 = mfma32(a1[c], b1[c], s1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] *= scale; s1[r] *= scale; }
+    };
+
+    float m0 = NEG_BIG, l0 = 0.f, m1 = NEG_BIG, l1 = 0.f;
+    for (int et = 0; et < n_et; ++et) {
+        f32x16 s0, s1;
+        score_tile(et, s0, s1);
+        float t0 = NEG_BIG, t1 = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = et * 32 + mfma_row(r, hi) < ne;
+            t0 = ok ? fmaxf(t0, s0[r]) : t0;
+            t1 = ok ? fmaxf(t1, s1[r]) : t1;
+        }
+        const float n0 = fmaxf(m0, t0), n1 = fmaxf(m1, t1);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = et * 32 + mfma_row(r, hi) < ne;
+            a0 += ok ? expf(s0[r] - n0) : 0.f;
+            a1 += ok ? expf(s1[r] - n1) : 0.f;
+        }
+        l0 = l0 * expf(m0 - n0) + a0; m0 = n0;
+        l1 = l1 * expf(m1 - n1) + a1; m1 = n1;
+    }
+    {
+        const float mo = __shfl_xor(m0, 32), lo = __shfl_xor(l0, 32);
+        const float M = fmaxf(m0, mo);
+        l0 = l0 * expf(m0 - M) + lo * expf(mo - M); m0 = M;
+    }
+    {
+        const float mo = __shfl_xor(m1, 32), lo = __shfl_xor(l1, 32);
+        const float M = fmaxf(m1, mo);
+        l1 = l1 * expf(m1 - M) + lo * expf(mo - M); m1 = M;
+    }
+    const int qq = qt * 32 + l31;
+    float* base = att + (size_t)2 * nq * e0;
+    for (int et = 0; et < n_et; ++et) {
+        f32x16 s0, s1;
+        score_tile(et, s0, s1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = et * 32 + mfma_row(r, hi);
+            if (n < ne && qq < nq) {
+                const float pe0 = expf(s0[r] - m0) / l0, pe1 = expf(s1[r] - m1) / l1;
+                const float mx = fmaxf(s0[r], s1[r]);
+                const float w0 = expf(s0[r] - mx), w1 = expf(s1[r] - mx);
+                const float ws = w0 + w1;
+                base[((size_t)0 * nq + qq) * ne + n] = pe0 * (w0 / ws);
+                base[((size_t)1 * nq + qq) * ne + n] = pe1 * (w1 / ws);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void role_values_kernel(const float* __restrict__ att, const float* __restrict__ enco, int lde,
+                                                          float* __restrict__ values, const int32_t* __restrict__ e_off,
+                                                          int n_vid, int nq, int n_qt, int d, int n_dc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n_vid * 2 * n_qt * n_dc) return;
+    const int dc = item % n_dc;
+    const int qt = (item / n_dc) % n_qt;
+    const int role = (item / ((long)n_dc * n_qt)) % 2;
+    const int vid = item / ((long)n_dc * n_qt * 2);
+    const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
+    if (qt * 32 >= nq) return;
+    const int qrow = min(qt * 32 + l31, nq - 1);
+    const float* ap = att + (size_t)2 * nq * e0 + ((size_t)role * nq + qrow) * ne;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    const int d0 = dc * 128;
+    for (int n2 = 0; n2 < ne; n2 += 2) {
+        const int n = n2 + hi;
+        const bool ok = n < ne;
+        const float a = ok ? ap[n] : 0.f;
+        const float* ep = enco + (size_t)(e0 + min(n, ne - 1)) * lde + d0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = t * 32 + l31;
+            const float bv = (d0 + col < d) ? ep[col] : 0.f;
+            acc[t] = mfma32(a, bv, acc[t]);
+        }
+    }
+    float* op = values + ((size_t)role * n_vid * nq + (size_t)vid * nq) * d;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = d0 + t * 32 + l31;
+        if (col >= d) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = qt * 32 + mfma_row(r, hi);
+            if (row < nq) op[(size_t)row * d + col] = acc[t][r];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int bigc_mha_core_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                 float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
+                                 int n_head, int hd) {
+    BIGC_CHECK_ARG(q && k && v && o && q_off && k_off, "mha_core: null pointer");
+    BIGC_CHECK_ARG(hd == 8 || hd == 16 || hd == 32 || hd == 64, "mha_core: head_dim %d not in {8,16,32,64}", hd);
+    BIGC_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0, "mha_core: ldq/ldk must be multiples of 4");
+    if (n_seq <= 0 || max_q <= 0) return BIGC_OK;
+    const int n_qt = cdiv(max_q, 32);
+    const long items = (long)n_seq * n_qt * n_head;
+    const int grid = (int)((items + 3) / 4);
+    const float scale = 1.0f / sqrtf((float)hd);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_MHA(HD) hipLaunchKernelGGL(mha_core_kernel<HD>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale)
+    switch (hd) {
+        case 8: LAUNCH_MHA(8); break;
+        case 16: LAUNCH_MHA(16); break;
+        case 32: LAUNCH_MHA(32); break;
+        default: LAUNCH_MHA(64); break;
+    }
+#undef LAUNCH_MHA
+    BIGC_LAUNCH_CHECK("mha_core");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_role_attention_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, float* att,
+                                       const int32_t* e_off, int n_vid, int nq, int half, float scale) {
+    BIGC_CHECK_ARG(p2a && e2a && att && e_off, "role_attention: null pointer");
+    BIGC_CHECK_ARG(half % 8 == 0 && ldp % 4 == 0 && lde % 4 == 0, "role_attention: half=%d must be a multiple of 8", half);
+    if (n_vid <= 0) return BIGC_OK;
+    const int n_qt = cdiv(nq, 32);
+    const int grid = cdiv(n_vid * n_qt, 4);
+    hipLaunchKernelGGL(role_attention_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, att, e_off,
+                       n_vid, nq, n_qt, half, scale);
+    BIGC_LAUNCH_CHECK("role_attention");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_role_values_f32(void* stream, const float* att, const float* enco, int lde, float* values,
+                                    const int32_t* e_off, int n_vid, int nq, int d) {
+    BIGC_CHECK_ARG(att && enco && values && e_off, "role_values: null pointer");
+    if (n_vid <= 0) return BIGC_OK;
+    const int n_qt = cdiv(nq, 32), n_dc = cdiv(d, 128);
+    const long items = (long)n_vid * 2 * n_qt * n_dc;
+    hipLaunchKernelGGL(role_values_kernel, dim3((int)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, att, enco, lde, values,
+                       e_off, n_vid, nq, n_qt, d, n_dc);
+    BIGC_LAUNCH_CHECK("role_values");
+    return BIGC_OK;
+}

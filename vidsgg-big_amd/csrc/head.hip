@@ -1,0 +1,97 @@
+// Prediction-head gather: subject/object argmax over the role attention, then the concat row
+// the predicate classifier consumes and the frequency-bias row it adds
+// (reference: models/model_0v10.py:485-503, models/model_0v7.py:485-508).
+// One workgroup per (video, query) row; pure gather traffic (HBM/L2-bound).
+#include "common.h"
+
+namespace {
+
+struct HeadSegs {
+    int n;
+    const float* src[4];
+    int width[4];
+    int by_cat[4];
+};
+
+// first index of the maximum (torch.argmax on CPU returns the lowest index among equal maxima)
+__device__ __forceinline__ int wave_argmax_first(const float* p, int n, int lane) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const float x = p[i];
+        if (x > bv || (x == bv && i < bi)) { bv = x; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    return bi;
+}
+
+__global__ __launch_bounds__(256) void head_gather_kernel(const float* __restrict__ att, const int32_t* __restrict__ e_off,
+                                                          const int32_t* __restrict__ trk_cat, int nq,
+                                                          const float* __restrict__ query, int dq, HeadSegs segs,
+                                                          const float* __restrict__ bias_matrix, int n_ecat, int n_pcat,
+                                                          int32_t* __restrict__ soid, float* __restrict__ head_in, int ld_head,
+                                                          float* __restrict__ bias_out) {
+    __shared__ int sh_so[2];
+    const int row = blockIdx.x;
+    const int vid = row / nq, qi = row - vid * nq;
+    const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
+    if (ne <= 0) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 2) {
+        const float* p = att + (size_t)2 * nq * e0 + ((size_t)wave * nq + qi) * ne;
+        const int a = wave_argmax_first(p, ne, lane);
+        if (lane == 0) {
+            sh_so[wave] = a;
+            soid[((size_t)vid * 2 + wave) * nq + qi] = a;
+        }
+    }
+    __syncthreads();
+    const int ts = e0 + sh_so[0], to = e0 + sh_so[1];
+    const int cs = trk_cat[ts], co = trk_cat[to];
+    float* hrow = head_in + (size_t)row * ld_head;
+    const float* qrow = query + (size_t)row * dq;
+    for (int i = threadIdx.x; i < dq; i += 256) hrow[i] = qrow[i];
+    int col = dq;
+    for (int s = 0; s < segs.n; ++s) {
+        const int w = segs.width[s];
+        const float* a = segs.src[s] + (size_t)(segs.by_cat[s] ? cs : ts) * w;
+        const float* b = segs.src[s] + (size_t)(segs.by_cat[s] ? co : to) * w;
+        for (int i = threadIdx.x; i < w; i += 256) {
+            hrow[col + i] = a[i];
+            hrow[col + w + i] = b[i];
+        }
+        col += 2 * w;
+    }
+    const float* bm = bias_matrix + ((size_t)cs * n_ecat + co) * n_pcat;
+    for (int i = threadIdx.x; i < n_pcat; i += 256) bias_out[(size_t)row * n_pcat + i] = bm[i];
+}
+
+}  // namespace
+
+extern "C" int bigc_head_gather(void* stream, const float* att, const int32_t* e_off, const int32_t* trk_cat, int n_vid, int nq,
+                                const float* query, int dq, int n_seg, const float* const* seg_src_host, const int32_t* seg_width_host,
+                                const int32_t* seg_by_cat_host, const float* bias_matrix, int n_ecat, int n_pcat,
+                                int32_t* soid, float* head_in, int ld_head, float* bias_out) {
+    BIGC_CHECK_ARG(att && e_off && trk_cat && query && bias_matrix && soid && head_in && bias_out, "head_gather: null pointer");
+    BIGC_CHECK_ARG(n_seg >= 0 && n_seg <= 4, "head_gather: n_seg=%d not in [0,4]", n_seg);
+    if (n_vid <= 0) return BIGC_OK;
+    HeadSegs segs;
+    segs.n = n_seg;
+    int total = dq;
+    for (int i = 0; i < 4; ++i) {
+        segs.src[i] = i < n_seg ? seg_src_host[i] : nullptr;
+        segs.width[i] = i < n_seg ? seg_width_host[i] : 0;
+        segs.by_cat[i] = i < n_seg ? seg_by_cat_host[i] : 0;
+        total += 2 * segs.width[i];
+    }
+    BIGC_CHECK_ARG(total <= ld_head, "head_gather: concat width %d exceeds ld_head %d", total, ld_head);
+    hipLaunchKernelGGL(head_gather_kernel, dim3(n_vid * nq), dim3(256), 0, (hipStream_t)stream, att, e_off, trk_cat, nq, query, dq,
+                       segs, bias_matrix, n_ecat, n_pcat, soid, head_in, ld_head, bias_out);
+    BIGC_LAUNCH_CHECK("head_gather");
+    return BIGC_OK;
+}

@@ -1,0 +1,169 @@
+// f32-MFMA "linear" kernel: C = act(A' W^T + bias) + residual, with an optional segmented
+// row gather on A (plain row gather, or the 3-tap implicit GEMM of the stride-2 temporal conv).
+//
+// Replaces torch.nn.Linear / nn.Conv1d(k3,s2) at every call site of the BIG hot path
+// (reference: models/model_0v10.py:290-309,446-458; models/grd_model_v5.py:171-174).
+//
+// Tiling (gfx950): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave
+// a 64x64 patch = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 acc VGPRs). K is walked in
+// slabs of 32: both operands are K-contiguous in HBM (activations row-major, torch weights
+// (N,K) row-major), so a slab row is one 128-byte line, loaded as 8 x dwordx4 by 8
+// consecutive lanes, staged through a double-buffered LDS image with a 36-float row pitch
+// (ds_read_b128 conflict-free: 16 lanes with distinct row mod 16 cover all 64 banks).
+// A lane reads 4 consecutive k for its row with one ds_read_b128; lanes 0-31 take k..k+3 and
+// lanes 32-63 take k+4..k+7 of each group of 8, which only permutes the order of the K
+// summation (the MFMA pairs k with k+4).
+// Roofline: f32 MFMA 157.3 TFLOP/s; 2*M*N*K flops per launch.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, PITCH = 36;
+
+struct LinearArgs {
+    const float* A; int lda; const int32_t* a_idx; int nseg; int seg_len;
+    const float* W; int ldw; const float* bias; const float* res; int ldr;
+    float* C; int ldc; int M, N, K; int act; int tiles_m, tiles_n;
+};
+
+template <bool GATHER>
+__global__ __launch_bounds__(256, 2) void linear_f32_kernel(const LinearArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2][2][BM * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware tile order: workgroup b lands on XCD b%8 (observed dispatch), so give each XCD
+    // whole M-tiles and walk their N-tiles back to back: the A slab is then re-read from that
+    // XCD's L2 instead of HBM, and W (shared by everyone) stays L2/MALL resident.
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
+    if (tm >= p.tiles_m) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int lr = tid >> 3, lc = (tid & 7) * 4;
+    int arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + lr + 32 * i;
+        arow[i] = (m < p.M) ? m : -1;
+    }
+    f32x4 ra[4], rb[4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int cur_seg = -1;
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK, kc = k0 + lc;
+        const bool kval = kc < p.K;
+        int acol = kc;
+        if (GATHER) {
+            const int seg = k0 / p.seg_len;
+            acol = kc - seg * p.seg_len;
+            if (seg != cur_seg) {
+                cur_seg = seg;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int m = m0 + lr + 32 * i;
+                    arow[i] = (m < p.M) ? p.a_idx[(size_t)m * p.nseg + seg] : -1;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = (arow[i] >= 0 && kval) ? *(const f32x4*)(p.A + (size_t)arow[i] * p.lda + acol) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int n = n0 + lr + 32 * i;
+            rb[i] = (n < p.N && kval) ? *(const f32x4*)(p.W + (size_t)n * p.ldw + kc) : zero4;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(f32x4*)(&smem[buf][0][(lr + 32 * i) * PITCH + lc]) = ra[i];
+            *(f32x4*)(&smem[buf][1][(lr + 32 * i) * PITCH + lc]) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        const float* as = &smem[buf][0][(wm * 64 + l31) * PITCH + 4 * hi];
+        const float* bs = &smem[buf][1][(wn * 64 + l31) * PITCH + 4 * hi];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 a0 = *(const f32x4*)(as + 8 * c);
+            const f32x4 a1 = *(const f32x4*)(as + 32 * PITCH + 8 * c);
+            const f32x4 b0 = *(const f32x4*)(bs + 8 * c);
+            const f32x4 b1 = *(const f32x4*)(bs + 32 * PITCH + 8 * c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[0][0] = mfma32(a0[q], b0[q], acc[0][0]);
+                acc[0][1] = mfma32(a0[q], b1[q], acc[0][1]);
+                acc[1][0] = mfma32(a1[q], b0[q], acc[1][0]);
+                acc[1][1] = mfma32(a1[q], b1[q], acc[1][1]);
+            }
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lanes 0-31 of a register hold 32 consecutive columns of one row (128-byte stores)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mi * 32 + mfma_row(r, hi);
+                if (row >= p.M) continue;
+                float v = acc[mi][ni][r] + bv;
+                if (p.act == BIGC_ACT_RELU) v = fmaxf(v, 0.f);
+                if (p.res) v += p.res[(size_t)row * p.ldr + col];
+                p.C[(size_t)row * p.ldc + col] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int32_t* a_idx, int nseg, int seg_len,
+                               const float* W, int ldw, const float* bias, const float* residual, int ldr,
+                               float* C, int ldc, int M, int N, int K, int act) {
+    BIGC_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear: bad shape M=%d N=%d K=%d", M, N, K);
+    if (M == 0) return BIGC_OK;
+    BIGC_CHECK_ARG(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "linear: K, lda, ldw must be multiples of 4 (K=%d lda=%d ldw=%d)", K, lda, ldw);
+    BIGC_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "linear: A and W must be 16-byte aligned");
+    BIGC_CHECK_ARG(A && W && C, "linear: null pointer");
+    if (a_idx) {
+        BIGC_CHECK_ARG(nseg >= 1 && seg_len > 0 && nseg * seg_len == K, "linear: K=%d != nseg*seg_len=%d*%d", K, nseg, seg_len);
+        BIGC_CHECK_ARG(nseg == 1 || seg_len % BK == 0, "linear: seg_len=%d must be a multiple of %d", seg_len, BK);
+    }
+    LinearArgs p;
+    p.A = A; p.lda = lda; p.a_idx = a_idx; p.nseg = a_idx ? nseg : 1; p.seg_len = a_idx ? seg_len : K;
+    p.W = W; p.ldw = ldw; p.bias = bias; p.res = residual; p.ldr = ldr; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.act = act;
+    p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
+    const int grid = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
+    hipStream_t s = (hipStream_t)stream;
+    if (a_idx) hipLaunchKernelGGL(linear_f32_kernel<true>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(linear_f32_kernel<false>, dim3(grid), dim3(256), 0, s, p);
+    BIGC_LAUNCH_CHECK("linear_f32");
+    return BIGC_OK;
+}

@@ -1,0 +1,396 @@
+// BIG-C eval forward over one packed batch of videos: the composition of the kernels into the
+// reference's op sequence (models/model_0v10.py:434-507 encode2decode + prediction_head,
+// :707-785 construct_triplet; models/model_0v7.py for the VidOR variant).
+//
+// What differs from the reference by design (same results, different execution):
+//   * ragged execution: the front-end MLPs run on the sum(L_i) packed rows; the stretch to Tmax
+//     (models/model_0v10.py:427-428) exists only as the conv gather table and as weights of the
+//     I3D/classeme mean;
+//   * all videos of the batch go through each kernel together (the reference loops per video,
+//     :376), attention kernels take per-video row offsets;
+//   * everything is stream-ordered on the caller's HIP stream, no host synchronisation.
+#include "common.h"
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+int bigc_fill_offsets(hipStream_t s, int32_t* p, int n, int step);
+int bigc_repack_conv_weight(hipStream_t s, const float* w, float* out, int n_out, int n_in, int taps);
+
+namespace {
+
+struct Lin { const float* w = nullptr; const float* b = nullptr; };
+struct LNp { const float* g = nullptr; const float* b = nullptr; };
+struct EncLayer { Lin in_proj, out_proj, l1, l2; LNp n1, n2; };
+struct DecLayer { Lin in_proj, out_proj, role0[2], role1[2], e2a, p2a, f0, f3; LNp n1, n2, n3; };
+
+}  // namespace
+
+struct bigc_model {
+    bigc_config cfg;
+    std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
+    bool finalized = false;
+    // resolved
+    const float *emb = nullptr, *pos = nullptr, *qinit = nullptr, *bias_matrix = nullptr;
+    Lin feat0, feat2, bbox0, bbox2, conv, enco0, enco2, i3d, head0, head2;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+    float* conv_w_tapmajor = nullptr;  // (de, 3*2de), owned
+    int head_k = 0;
+};
+
+namespace {
+
+struct Resolver {
+    bigc_model* m;
+    int err = 0;
+    const float* get(const std::string& key, int64_t numel) {
+        auto it = m->params.find(key);
+        if (it == m->params.end()) {
+            if (!err) err = bigc_fail(BIGC_ERR_MISSING, "parameter '%s' was never set", key.c_str());
+            return nullptr;
+        }
+        if (it->second.second != numel) {
+            if (!err) err = bigc_fail(BIGC_ERR_ARG, "parameter '%s' has %lld elements, expected %lld", key.c_str(),
+                                      (long long)it->second.second, (long long)numel);
+            return nullptr;
+        }
+        return it->second.first;
+    }
+    Lin lin(const std::string& p, int n_out, int n_in) {
+        Lin l;
+        l.w = get(p + ".weight", (int64_t)n_out * n_in);
+        l.b = get(p + ".bias", n_out);
+        return l;
+    }
+    LNp ln(const std::string& p, int d) {
+        LNp l;
+        l.g = get(p + ".weight", d);
+        l.b = get(p + ".bias", d);
+        return l;
+    }
+    Lin mha_in(const std::string& p, int d) {
+        Lin l;
+        l.w = get(p + ".in_proj_weight", (int64_t)3 * d * d);
+        l.b = get(p + ".in_proj_bias", 3 * d);
+        return l;
+    }
+};
+
+struct Arena {
+    char* base; size_t cap; size_t off = 0; bool overflow = false;
+    template <typename T> T* take(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        if (off + bytes > cap) { overflow = true; return nullptr; }
+        T* p = (T*)(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+struct Sizes { size_t R, NT, C, B, Q, BQ; };
+
+// single source of truth for the workspace layout: run with a null base to measure
+struct Work {
+    float *bbox8, *hb, *hv, *enti, *conv, *pooled, *eh, *e2e, *x0, *x1, *qkv, *ao, *t1, *fh;
+    float *query, *qk_in, *qk, *vv, *ao2, *t2, *t3, *p2a, *e2a, *vals, *rh, *enco;
+    float *xmean, *i3dfc, *head_in, *bias_g, *hh;
+    int32_t *conv_idx, *q_off;
+};
+
+bool layout(const bigc_model* m, const Sizes& z, Arena& a, Work& w) {
+    const bigc_config& c = m->cfg;
+    const size_t de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn;
+    w.bbox8 = a.take<float>(z.R * 8);
+    w.hb = a.take<float>(z.R * de);
+    w.hv = a.take<float>(z.R * de);
+    w.enti = a.take<float>(z.R * 2 * de);
+    w.conv_idx = a.take<int32_t>(z.C * 3);
+    w.conv = a.take<float>(z.C * de);
+    w.pooled = a.take<float>(z.NT * de * c.enco_pool_len);
+    w.eh = a.take<float>(z.NT * de);
+    w.e2e = a.take<float>(z.NT * de);
+    w.x0 = a.take<float>(z.NT * de);
+    w.x1 = a.take<float>(z.NT * de);
+    w.enco = a.take<float>(z.NT * de);
+    w.qkv = a.take<float>(z.NT * 3 * de);
+    w.ao = a.take<float>(z.NT * de);
+    w.t1 = a.take<float>(z.NT * de);
+    w.fh = a.take<float>(z.NT * df);
+    w.q_off = a.take<int32_t>(z.B + 1);
+    w.query = a.take<float>(z.BQ * dp);
+    w.qk_in = a.take<float>(z.BQ * dp);
+    w.qk = a.take<float>(z.BQ * 2 * dp);
+    w.vv = a.take<float>(z.BQ * dp);
+    w.ao2 = a.take<float>(z.BQ * dp);
+    w.t2 = a.take<float>(z.BQ * dp);
+    w.t3 = a.take<float>(z.BQ * dp);
+    w.p2a = a.take<float>(z.BQ * da);
+    w.e2a = a.take<float>(z.NT * da);
+    w.vals = a.take<float>(2 * z.BQ * de);
+    w.rh = a.take<float>(z.BQ * (dp > df ? dp : df));
+    w.xmean = a.take<float>(z.NT * (c.dim_extra > 0 ? c.dim_extra : 1));
+    w.i3dfc = a.take<float>(z.NT * de);
+    w.head_in = a.take<float>(z.BQ * (size_t)m->head_k);
+    w.bias_g = a.take<float>(z.BQ * c.num_pred_cats);
+    w.hh = a.take<float>(z.BQ * df);
+    return !a.overflow;
+}
+
+int head_width(const bigc_config& c) {
+    if (c.variant == 0) return c.dim_pred + 2 * c.dim_clsme + (c.dim_extra > 0 ? 4 : 2) * c.dim_enti;
+    return c.dim_pred + 2 * c.dim_enti + (c.use_clsme ? 2 * c.dim_clsme : 0);
+}
+
+Sizes sizes_of(const bigc_model* m, const bigc_batch* b) {
+    Sizes z;
+    z.R = b->n_rows; z.NT = b->n_trk; z.C = b->n_conv; z.B = b->n_vid; z.Q = m->cfg.num_querys; z.BQ = z.B * z.Q;
+    return z;
+}
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != BIGC_OK) return rc_; } while (0)
+
+inline int linear(void* s, const float* A, int lda, const Lin& l, float* C, int ldc, int M, int N, int K, int act,
+                  const float* res = nullptr, int ldr = 0) {
+    return bigc_linear_f32(s, A, lda, nullptr, 1, K, l.w, K, l.b, res, ldr, C, ldc, M, N, K, act);
+}
+
+}  // namespace
+
+extern "C" int bigc_create(const bigc_config* cfg, bigc_model** out) {
+    BIGC_CHECK_ARG(cfg && out, "create: null pointer");
+    BIGC_CHECK_ARG(cfg->variant == 0 || cfg->variant == 1, "create: variant %d", cfg->variant);
+    BIGC_CHECK_ARG(cfg->dim_enti % cfg->n_att_head == 0 && cfg->dim_pred % cfg->n_att_head == 0, "create: dims not divisible by heads");
+    const int hd_e = cfg->dim_enti / cfg->n_att_head, hd_p = cfg->dim_pred / cfg->n_att_head;
+    BIGC_CHECK_ARG((hd_e == 8 || hd_e == 16 || hd_e == 32 || hd_e == 64) && hd_e == hd_p, "create: head_dim %d/%d unsupported", hd_e, hd_p);
+    BIGC_CHECK_ARG(cfg->dim_feat % 4 == 0 && cfg->dim_extra % 4 == 0 && cfg->dim_enti % 16 == 0 && cfg->dim_att % 16 == 0 &&
+                   cfg->dim_clsme % 4 == 0 && cfg->dim_ffn % 4 == 0 && cfg->dim_pred % 4 == 0, "create: dims must be multiples of 4 (enti/att of 16)");
+    BIGC_CHECK_ARG(cfg->num_pred_cats <= 256 && cfg->num_enti_cats <= 256, "create: at most 256 categories");
+    BIGC_CHECK_ARG(cfg->dim_enti == cfg->dim_pred, "create: dim_enti must equal dim_pred (the reference adds role queries to pred queries)");
+    bigc_model* m = new bigc_model();
+    m->cfg = *cfg;
+    m->head_k = head_width(*cfg);
+    *out = m;
+    return BIGC_OK;
+}
+
+extern "C" void bigc_destroy(bigc_model* m) {
+    if (!m) return;
+    if (m->conv_w_tapmajor) (void)hipFree(m->conv_w_tapmajor);
+    delete m;
+}
+
+extern "C" int bigc_set_param(bigc_model* m, const char* key, const float* ptr, int64_t numel) {
+    BIGC_CHECK_ARG(m && key && ptr && numel > 0, "set_param: bad argument");
+    BIGC_CHECK_ARG(((uintptr_t)ptr & 15) == 0, "set_param: '%s' is not 16-byte aligned", key);
+    m->params[key] = std::make_pair(ptr, numel);
+    m->finalized = false;
+    return BIGC_OK;
+}
+
+extern "C" int bigc_finalize(bigc_model* m, void* stream) {
+    BIGC_CHECK_ARG(m, "finalize: null model");
+    const bigc_config& c = m->cfg;
+    Resolver r{m};
+    const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn;
+    if (c.has_enti_emb) m->emb = r.get("EntiNameEmb", (int64_t)c.num_enti_cats * c.dim_clsme);
+    m->pos = r.get("pos_embedding", (int64_t)c.num_querys * dp);
+    m->qinit = r.get("pred_query_init", (int64_t)c.num_querys * dp);
+    m->bias_matrix = r.get("bias_matrix", (int64_t)c.num_enti_cats * c.num_enti_cats * c.num_pred_cats);
+    m->feat0 = r.lin("fc_feat2enti.0", de, c.dim_feat);
+    m->feat2 = r.lin("fc_feat2enti.2", de, de);
+    m->bbox0 = r.lin("fc_bbox2enti.0", de, 8);
+    m->bbox2 = r.lin("fc_bbox2enti.2", de, de);
+    m->conv.w = r.get("conv_feat2enti.weight", (int64_t)de * 2 * de * 3);
+    m->conv.b = r.get("conv_feat2enti.bias", de);
+    m->enco0 = r.lin("fc_enti2enco.0", de, de * c.enco_pool_len);
+    m->enco2 = r.lin("fc_enti2enco.2", de, de);
+    if (c.variant == 0 && c.dim_extra > 0) m->i3d = r.lin("fc_i3d.0", de, c.dim_extra);
+    m->enc.assign(c.n_enco_layers, EncLayer());
+    for (int i = 0; i < c.n_enco_layers; ++i) {
+        const std::string p = "encoder_layers." + std::to_string(i);
+        EncLayer& L = m->enc[i];
+        L.in_proj = r.mha_in(p + ".self_attn", de);
+        L.out_proj = r.lin(p + ".self_attn.out_proj", de, de);
+        L.l1 = r.lin(p + ".linear1", df, de);
+        L.l2 = r.lin(p + ".linear2", de, df);
+        L.n1 = r.ln(p + ".norm1", de);
+        L.n2 = r.ln(p + ".norm2", de);
+    }
+    m->dec.assign(c.n_deco_layers, DecLayer());
+    for (int i = 0; i < c.n_deco_layers; ++i) {
+        const std::string p = "decoder_layers." + std::to_string(i);
+        DecLayer& L = m->dec[i];
+        L.in_proj = r.mha_in(p + ".self_attn", dp);
+        L.out_proj = r.lin(p + ".self_attn.out_proj", dp, dp);
+        L.role0[0] = r.lin(p + ".fc_rolewise.0.0", dp, de);
+        L.role0[1] = r.lin(p + ".fc_rolewise.0.2", dp, dp);
+        L.role1[0] = r.lin(p + ".fc_rolewise.1.0", dp, de);
+        L.role1[1] = r.lin(p + ".fc_rolewise.1.2", dp, dp);
+        L.e2a = r.lin(p + ".fc_enti2att", da, de);
+        L.p2a = r.lin(p + ".fc_pred2att", da, dp);
+        L.f0 = r.lin(p + ".fc2.0", df, dp);
+        L.f3 = r.lin(p + ".fc2.3", dp, df);
+        L.n1 = r.ln(p + ".norm1", dp);
+        L.n2 = r.ln(p + ".norm2", dp);
+        L.n3 = r.ln(p + ".norm3", dp);
+    }
+    if (c.variant == 0) {
+        m->head0 = r.lin("fc_pred2logits", c.num_pred_cats, m->head_k);
+    } else {
+        m->head0 = r.lin("fc_pred2logits.0", df, m->head_k);
+        m->head2 = r.lin("fc_pred2logits.2", c.num_pred_cats, df);
+    }
+    if (r.err) return r.err;
+    if (!m->conv_w_tapmajor) {
+        hipError_t e = hipMalloc((void**)&m->conv_w_tapmajor, sizeof(float) * (size_t)de * 2 * de * 3);
+        if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "finalize: hipMalloc: %s", hipGetErrorString(e));
+    }
+    TRY(bigc_repack_conv_weight((hipStream_t)stream, m->conv.w, m->conv_w_tapmajor, de, 2 * de, 3));
+    m->finalized = true;
+    return BIGC_OK;
+}
+
+extern "C" size_t bigc_workspace_bytes(const bigc_model* m, const bigc_batch* b) {
+    if (!m || !b) return 0;
+    Arena a{nullptr, (size_t)-1};
+    Work w;
+    layout(m, sizes_of(m, b), a, w);
+    return a.off + 256;
+}
+
+extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
+                            int topk, const bigc_outputs* out) {
+    BIGC_CHECK_ARG(m && b && out, "forward: null pointer");
+    BIGC_CHECK_ARG(m->finalized, "forward: call bigc_finalize after setting the parameters");
+    BIGC_CHECK_ARG(b->n_vid > 0 && b->n_trk > 0 && b->n_rows > 0 && b->n_conv > 0, "forward: empty batch");
+    BIGC_CHECK_ARG(b->max_trk > 0 && b->max_trk <= 512, "forward: max_trk=%d must be in [1,512]", b->max_trk);
+    BIGC_CHECK_ARG(out->pred_logits && out->att && out->soid, "forward: pred_logits/att/soid outputs are required");
+    const bigc_config& c = m->cfg;
+    const Sizes z = sizes_of(m, b);
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (!workspace || workspace_bytes < (size_t)(base - (char*)workspace)) return bigc_fail(BIGC_ERR_WORKSPACE, "forward: no workspace");
+    Arena a{base, workspace_bytes - (size_t)(base - (char*)workspace)};
+    Work w;
+    if (!layout(m, z, a, w)) return bigc_fail(BIGC_ERR_WORKSPACE, "forward: workspace of %zu bytes too small, need %zu", workspace_bytes,
+                                              bigc_workspace_bytes(m, b));
+    hipStream_t hs = (hipStream_t)stream;
+    void* s = stream;
+    const int R = b->n_rows, NT = b->n_trk, C = b->n_conv, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
+    const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn;
+    const int D = c.dim_feat + c.dim_extra;
+    const int H = c.n_att_head, hd = de / H;
+    const float eps = 1e-5f;
+
+    // ---- a1/a3: per-frame front-end on the packed rows (models/model_0v10.py:401-420,446-448)
+    TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
+    TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
+    TRY(linear(s, w.hb, de, m->bbox2, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
+    TRY(linear(s, b->feats, D, m->feat0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
+    TRY(linear(s, w.hv, de, m->feat2, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
+
+    // ---- a2/a4: stride-2 temporal conv over the virtual stretch, pool, fc_enti2enco (:450-458)
+    TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
+    TRY(bigc_linear_f32(s, w.enti, 2 * de, w.conv_idx, 3, 2 * de, m->conv_w_tapmajor, 6 * de, m->conv.b, nullptr, 0, w.conv, de,
+                        C, de, 6 * de, BIGC_ACT_NONE));
+    TRY(bigc_adaptive_maxpool(s, w.conv, b->trk_conv_off, w.pooled, NT, de, c.enco_pool_len));
+    float* e2e = out->enti2enco ? out->enti2enco : w.e2e;
+    TRY(linear(s, w.pooled, de * c.enco_pool_len, m->enco0, w.eh, de, NT, de, de * c.enco_pool_len, BIGC_ACT_RELU));
+    TRY(linear(s, w.eh, de, m->enco2, e2e, de, NT, de, de, BIGC_ACT_RELU));
+
+    // ---- a5: encoder, sequence = the tracklets of a video (:459-462, layer :103-117)
+    const float* x = e2e;
+    for (int i = 0; i < c.n_enco_layers; ++i) {
+        const EncLayer& L = m->enc[i];
+        TRY(linear(s, x, de, L.in_proj, w.qkv, 3 * de, NT, 3 * de, de, BIGC_ACT_NONE));
+        TRY(bigc_mha_core_f32(s, w.qkv, 3 * de, w.qkv + de, 3 * de, w.qkv + 2 * de, 3 * de, w.ao, de, b->vid_trk_off, b->vid_trk_off,
+                              B, b->max_trk, H, hd));
+        TRY(linear(s, w.ao, de, L.out_proj, w.t1, de, NT, de, de, BIGC_ACT_NONE, x, de));
+        TRY(bigc_layernorm_f32(s, w.t1, L.n1.g, L.n1.b, w.x1, NT, de, eps));
+        TRY(linear(s, w.x1, de, L.l1, w.fh, df, NT, df, de, BIGC_ACT_RELU));
+        TRY(linear(s, w.fh, df, L.l2, w.t1, de, NT, de, df, BIGC_ACT_NONE, w.x1, de));
+        float* xo = (i == c.n_enco_layers - 1) ? (out->enco_output ? out->enco_output : w.enco) : w.x0;
+        TRY(bigc_layernorm_f32(s, w.t1, L.n2.g, L.n2.b, xo, NT, de, eps));
+        x = xo;
+    }
+    const float* enco = x;
+
+    // ---- a6: role-aware decoder (:464-467, layer :178-225)
+    TRY(bigc_fill_offsets(hs, w.q_off, B + 1, Q));
+    TRY(bigc_add_rows_f32(s, nullptr, m->qinit, w.query, BQ, dp, Q));
+    const float att_scale = 1.0f / sqrtf((float)de);
+    for (int i = 0; i < c.n_deco_layers; ++i) {
+        const DecLayer& L = m->dec[i];
+        TRY(bigc_add_rows_f32(s, w.query, m->pos, w.qk_in, BQ, dp, Q));
+        Lin qkp{L.in_proj.w, L.in_proj.b};
+        Lin vp{L.in_proj.w + (size_t)2 * dp * dp, L.in_proj.b + 2 * dp};
+        TRY(linear(s, w.qk_in, dp, qkp, w.qk, 2 * dp, BQ, 2 * dp, dp, BIGC_ACT_NONE));
+        TRY(linear(s, w.query, dp, vp, w.vv, dp, BQ, dp, dp, BIGC_ACT_NONE));
+        TRY(bigc_mha_core_f32(s, w.qk, 2 * dp, w.qk + dp, 2 * dp, w.vv, dp, w.ao2, dp, w.q_off, w.q_off, B, Q, H, dp / H));
+        TRY(linear(s, w.ao2, dp, L.out_proj, w.t2, dp, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
+        TRY(bigc_layernorm_f32(s, w.t2, L.n1.g, L.n1.b, w.t3, BQ, dp, eps));
+        TRY(bigc_add_rows_f32(s, w.t3, m->pos, w.query, BQ, dp, Q));            // query += pos, kept (:189)
+        TRY(linear(s, enco, de, L.e2a, w.e2a, da, NT, da, de, BIGC_ACT_NONE));
+        TRY(linear(s, w.query, dp, L.p2a, w.p2a, da, BQ, da, dp, BIGC_ACT_NONE));
+        TRY(bigc_role_attention_f32(s, w.p2a, da, w.e2a, da, out->att, b->vid_trk_off, B, Q, da / 2, att_scale));
+        TRY(bigc_role_values_f32(s, out->att, enco, de, w.vals, b->vid_trk_off, B, Q, de));
+        TRY(linear(s, w.vals, de, L.role0[0], w.rh, dp, BQ, dp, de, BIGC_ACT_RELU));
+        TRY(linear(s, w.rh, dp, L.role0[1], w.t2, dp, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
+        TRY(linear(s, w.vals + (size_t)BQ * de, de, L.role1[0], w.rh, dp, BQ, dp, de, BIGC_ACT_RELU));
+        TRY(linear(s, w.rh, dp, L.role1[1], w.t3, dp, BQ, dp, dp, BIGC_ACT_NONE, w.t2, dp));
+        TRY(bigc_layernorm_f32(s, w.t3, L.n2.g, L.n2.b, w.t2, BQ, dp, eps));
+        TRY(linear(s, w.t2, dp, L.f0, w.rh, df, BQ, df, dp, BIGC_ACT_RELU));
+        TRY(linear(s, w.rh, df, L.f3, w.t3, dp, BQ, dp, df, BIGC_ACT_NONE, w.t2, dp));
+        TRY(bigc_layernorm_f32(s, w.t3, L.n3.g, L.n3.b, w.query, BQ, dp, eps));
+    }
+    if (out->pred_query) {
+        hipError_t e = hipMemcpyAsync(out->pred_query, w.query, sizeof(float) * (size_t)BQ * dp, hipMemcpyDeviceToDevice, hs);
+        if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: memcpy: %s", hipGetErrorString(e));
+    }
+
+    // ---- a7: prediction head (:478-507; VidOR models/model_0v7.py:483-513)
+    const float* seg_src[4];
+    int32_t seg_w[4], seg_cat[4];
+    int n_seg = 0;
+    if (c.variant == 0) {
+        if (c.dim_extra > 0) {
+            TRY(bigc_stretched_mean(s, b->feats, D, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, w.xmean, NT));
+            TRY(linear(s, w.xmean, c.dim_extra, m->i3d, w.i3dfc, de, NT, de, c.dim_extra, BIGC_ACT_RELU));
+            seg_src[n_seg] = w.i3dfc; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
+            seg_src[n_seg] = e2e; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
+            seg_src[n_seg] = m->emb; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 1;
+        } else {
+            seg_src[n_seg] = m->emb; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 1;
+            seg_src[n_seg] = e2e; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
+        }
+    } else {
+        if (c.use_clsme) {
+            if (c.has_enti_emb) {
+                seg_src[n_seg] = m->emb; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 1;
+            } else {
+                BIGC_CHECK_ARG(c.dim_extra == c.dim_clsme, "forward: classeme width %d != dim_clsme %d", c.dim_extra, c.dim_clsme);
+                TRY(bigc_stretched_mean(s, b->feats, D, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, w.xmean, NT));
+                seg_src[n_seg] = w.xmean; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 0;
+            }
+        }
+        seg_src[n_seg] = e2e; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
+    }
+    TRY(bigc_head_gather(s, out->att, b->vid_trk_off, b->trk_cat, B, Q, w.query, dp, n_seg, seg_src, seg_w, seg_cat, m->bias_matrix,
+                         c.num_enti_cats, c.num_pred_cats, out->soid, w.head_in, m->head_k, w.bias_g));
+    if (c.variant == 0) {
+        TRY(linear(s, w.head_in, m->head_k, m->head0, out->pred_logits, c.num_pred_cats, BQ, c.num_pred_cats, m->head_k, BIGC_ACT_NONE,
+                   w.bias_g, c.num_pred_cats));
+    } else {
+        TRY(linear(s, w.head_in, m->head_k, m->head0, w.hh, df, BQ, df, m->head_k, BIGC_ACT_RELU));
+        TRY(linear(s, w.hh, df, m->head2, out->pred_logits, c.num_pred_cats, BQ, c.num_pred_cats, df, BIGC_ACT_NONE, w.bias_g,
+                   c.num_pred_cats));
+    }
+
+    // ---- a8: construct_triplet (:707-785)
+    if (out->quint) {
+        BIGC_CHECK_ARG(out->scores && out->dura && out->qid && out->n_out, "forward: all construct_triplet outputs or none");
+        TRY(bigc_construct_triplets(s, out->pred_logits, c.num_pred_cats, out->soid, b->vid_trk_off, b->trk_dura, b->trk_cat, b->trk_score,
+                                    B, Q, topk, out->quint, out->scores, out->dura, out->qid, out->n_out));
+    }
+    return BIGC_OK;
+}

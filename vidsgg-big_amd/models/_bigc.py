@@ -1,0 +1,152 @@
+"""Shared host-side body of the two BIG-C drop-in modules.
+
+The module tree below exists to own parameters under the reference's ``state_dict`` keys
+(reference constructors models/model_0v10.py:241-336 and
+models/model_0v7.py:241-350).  ``nn.Linear`` / ``nn.MultiheadAttention`` / ``nn.LayerNorm``
+are used as parameter containers only: ``forward`` never calls them, all arithmetic runs in
+the HIP library through ``bigc_hip.engine.BigcEngine``.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from bigc_hip.engine import BigcEngine
+from bigc_hip.packed import PackedBatch
+
+
+def _mlp(*dims, final_relu=True):
+    """Sequential whose Linear layers sit at indices 0, 2, ... like the reference's."""
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2 or final_relu:
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+class _EncoderLayerParams(nn.Module):
+    """keys: self_attn.*, linear1, linear2, norm1, norm2 (models/model_0v10.py:72-82)"""
+
+    def __init__(self, d, nhead, d_ffn):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d, nhead, dropout=0.1)
+        self.linear1 = nn.Linear(d, d_ffn)
+        self.linear2 = nn.Linear(d_ffn, d)
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+
+
+class _DecoderLayerParams(nn.Module):
+    """keys: self_attn.*, fc_rolewise.{0,1}.{0,2}, fc_enti2att, fc_pred2att, fc2.{0,3}, norm{1,2,3}
+    (models/model_0v10.py:144-173)"""
+
+    def __init__(self, d_pred, nhead, d_enti, d_att, d_ffn):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_pred, nhead, dropout=0.1)
+        self.fc_rolewise = nn.ModuleList([_mlp(d_enti, d_pred, d_pred, final_relu=False) for _ in range(2)])
+        self.fc_enti2att = nn.Linear(d_enti, d_att)
+        self.fc_pred2att = nn.Linear(d_pred, d_att)
+        self.fc2 = nn.Sequential(nn.Linear(d_pred, d_ffn), nn.ReLU(), nn.Dropout(0.1), nn.Linear(d_ffn, d_pred))
+        self.norm1 = nn.LayerNorm(d_pred)
+        self.norm2 = nn.LayerNorm(d_pred)
+        self.norm3 = nn.LayerNorm(d_pred)
+
+
+class BigcBase(nn.Module):
+    variant = None          # "vidvrd" | "vidor"
+    default_topk = 10
+
+    def __init__(self, config, is_train=True):
+        super().__init__()
+        self.is_train = is_train
+        self.config = dict(config)
+        c = config
+        self.num_pred_cats, self.num_enti_cats = c["num_pred_cats"], c["num_enti_cats"]
+        self.dim_feat, self.dim_clsme = c["dim_feat"], c["dim_clsme"]
+        self.dim_enti, self.dim_pred, self.dim_att, self.dim_ffn = c["dim_enti"], c["dim_pred"], c["dim_att"], c["dim_ffn"]
+        self.enco_pool_len = c["enco_pool_len"]
+        self.n_enco_layers, self.n_deco_layers = c["n_enco_layers"], c["n_deco_layers"]
+        self.n_att_head, self.num_querys = c["n_att_head"], c["num_querys"]
+        self.num_anchors = self.num_querys
+        self.neg_weight = c["neg_weight"]
+        self.loss_factor, self.cost_factor = c["loss_coeff_dict"], c["cost_coeff_dict"]
+        self.positive_vIoU_th = c["positive_vIoU_th"]
+        self._build_embeddings(c)
+        bias = torch.from_numpy(np.load(c["bias_matrix_path"])).float()
+        assert bias.shape == (self.num_enti_cats, self.num_enti_cats, self.num_pred_cats)
+        self.bias_matrix = nn.Parameter(bias, requires_grad=True)
+
+        de = self.dim_enti
+        self.fc_feat2enti = _mlp(self.dim_feat, de, de)
+        self.fc_bbox2enti = _mlp(8, de, de)
+        self.conv_feat2enti = nn.Conv1d(2 * de, de, kernel_size=3, padding=1, stride=2)
+        self.fc_enti2enco = _mlp(de * self.enco_pool_len, de, de)
+        self._build_extra_layers(c)
+        self.encoder_layers = nn.ModuleList(
+            [_EncoderLayerParams(de, self.n_att_head, self.dim_ffn) for _ in range(self.n_enco_layers)])
+        self.decoder_layers = nn.ModuleList(
+            [_DecoderLayerParams(self.dim_pred, self.n_att_head, de, self.dim_att, self.dim_ffn)
+             for _ in range(self.n_deco_layers)])
+        self._build_head(c)
+        self._reset_parameters()
+        self._engine = None
+
+    # ---- hooks for the two variants -----------------------------------------------------
+    def _build_embeddings(self, c):
+        raise NotImplementedError
+
+    def _build_extra_layers(self, c):
+        pass
+
+    def _build_head(self, c):
+        raise NotImplementedError
+
+    def _reset_parameters(self):
+        raise NotImplementedError
+
+    # ---- forward --------------------------------------------------------------------------
+    def forward(self, proposal_list, gt_graph_list=None, topk=None):
+        """Same contract as the reference (models/model_0v10.py:359-388): mode is fixed by
+        ``is_train``; eval returns one entry per video, ``None`` for an empty video or when no
+        subject/object pair overlaps in time, else ``(uniq_quintuples i64 (U,5), uniq_scores f32
+        (U,3), uniq_dura_inters i64 (U,2), uniq_query_ids i64 (U,))`` on the input device."""
+        if topk is None:
+            topk = self.default_topk
+        if self.is_train:
+            assert gt_graph_list is not None
+            raise NotImplementedError("training step of the HIP path is not built yet (SURVEY.md section 8 a10)")
+        self.topk = topk
+        if isinstance(proposal_list, PackedBatch):
+            return self.unpack_results(proposal_list.n_vid, list(range(proposal_list.n_vid)),
+                                       self.forward_packed(proposal_list, topk))
+        keep = [i for i, p in enumerate(proposal_list) if p.num_proposals > 0]
+        if not keep:
+            return [None for _ in proposal_list]
+        device = self.pred_query_init.device
+        packed = PackedBatch([proposal_list[i] for i in keep], device)
+        return self.unpack_results(len(proposal_list), keep, self.forward_packed(packed, topk))
+
+    def engine(self):
+        if self._engine is None:
+            self._engine = BigcEngine(self.config, self.variant)
+        self._engine.sync_params((k, v) for k, v in self.state_dict(keep_vars=True).items())
+        return self._engine
+
+    def forward_packed(self, packed, topk=None, keep_intermediates=False):
+        """HIP forward on a resident PackedBatch -> dict of padded device tensors (no host sync)."""
+        if topk is None:
+            topk = self.default_topk
+        with torch.no_grad():
+            return self.engine().forward(packed, topk, True, keep_intermediates)
+
+    @staticmethod
+    def unpack_results(n_total, keep, out):
+        """Padded device outputs -> the reference's per-video list (one D2H copy of the counts)."""
+        n_out = out["n_out"].cpu().tolist()
+        quint, dura, qid = out["quint"].long(), out["dura"].long(), out["qid"].long()
+        res = [None] * n_total
+        for j, i in enumerate(keep):
+            n = n_out[j]
+            if n > 0:
+                res[i] = (quint[j, :n], out["scores"][j, :n], dura[j, :n], qid[j, :n])
+        return res

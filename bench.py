@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the BIG classification hot path (BIG-C eval forward incl. construct_triplet).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json / SURVEY.md section 8d): tracklet-pairs/sec = videos/s x N(N-1), whole job.
+Workload = BASELINE.json configs[1]: VidVRD-test classification-only, model_0v10 at the exp2
+dimensions (PKU RoI 2048-d + I3D 832-d), synthetic videos of N=64 tracklets (SURVEY.md 8d recipe,
+video v uses numpy RandomState(1234+v)), numpy-seeded weights.  One step = one pass of the HIP
+path over one resident batch of `--videos` videos (default 256) per GPU; inputs are packed in HBM
+before the timed region.  N>1: one process per GPU (torch.distributed / RCCL only for the barrier
+and the max-over-ranks timing -- videos are independent, no data-path collective), weak scaling.
+
+Also printed in the same JSON line:
+  roofline     dominant kernel (linear_f32, the f32-MFMA GEMM family): algorithmic flops of its
+               launches / their summed duration measured with HIP events inside the library on the
+               launch stream during the timed steps, against the 157.3 TFLOP/s f32-MFMA peak
+  cpu_baseline the CPU oracle (oracle/bigc_oracle.py, a torch-CPU restatement of the reference's
+               op sequence: kind "port") timed on the host cores, rank 0 at N=1 only, on a bounded
+               sample of the same videos
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "vidsgg-big_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from bigc_hip import _lib, configs  # noqa: E402
+from bigc_hip.packed import PackedBatch  # noqa: E402
+from bigc_hip.synthetic import bigc_state_shapes, seeded_state_dict, synthetic_proposal  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--videos", type=int, default=256, help="videos per GPU per step")
+    ap.add_argument("--n-trajs", type=int, default=64)
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--cpu-videos", type=int, default=16, help="videos of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-prof", action="store_true", help="do not record HIP events around the kernels")
+    return ap.parse_args()
+
+
+def usable_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota
+    (the GPU boxes report 256 CPUs but run under a 16-core quota; 256 threads there is ~900x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def build_model(cfg, sd, device):
+    from models import BIG_C_vidvrd
+    d = tempfile.mkdtemp()
+    cfg = dict(cfg)
+    np.save(os.path.join(d, "bias.npy"), sd["bias_matrix"].numpy())
+    np.save(os.path.join(d, "emb.npy"), sd["EntiNameEmb"].numpy())
+    cfg["bias_matrix_path"], cfg["EntiNameEmb_path"] = os.path.join(d, "bias.npy"), os.path.join(d, "emb.npy")
+    model = BIG_C_vidvrd(cfg, is_train=False)
+    model.load_state_dict(sd)
+    return model.to(device)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = dict(configs.CONFIG_V)
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 7, att_gain=8.0)
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    # each rank owns its own shard of synthetic videos (weak scaling): seeds 1234 + rank*videos + v
+    base = 1234 + rank * args.videos
+    t0 = time.time()
+    props = [synthetic_proposal(base + v, n_trajs=args.n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"])
+             for v in range(args.videos)]
+    packed = PackedBatch(props, device)
+    cpu_sample = props[:args.cpu_videos] if (rank == 0 and world == 1) else []
+    props = None
+    packed.proposals = None
+    gen_s = time.time() - t0
+    model = build_model(cfg, sd, device)
+    lib = _lib.load()
+    pairs_per_step = packed.n_pairs()
+
+    def step():
+        out = model.forward_packed(packed, args.topk)
+        return out["n_out"].cpu()      # the one D2H copy forward() needs (row counts) -> host sync
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_prof:
+        lib.bigc_prof_reset()
+        lib.bigc_prof_enable(1)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_out = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    lib.bigc_prof_enable(0)
+
+    families = {}
+    if not args.no_prof:
+        _lib.check(lib.bigc_prof_collect())
+        for f in range(lib.bigc_prof_family_count()):
+            ms, n, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
+            lib.bigc_prof_get(f, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+            if n.value:
+                families[lib.bigc_prof_family_name(f).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = pairs_per_step * world * args.steps / elapsed
+    roofline = None
+    if "linear_f32" in families:
+        lin = families["linear_f32"]
+        achieved = lin["flops"] / (lin["ms"] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel="linear_f32_kernel (f32 MFMA 32x32x2)", achieved=round(achieved, 2),
+                        peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                        traffic=None, launches_per_step=lin["launches"] // args.steps,
+                        avg_launch_us=round(1e3 * lin["ms"] / lin["launches"], 2),
+                        gflop_per_step=round(lin["flops"] / args.steps / 1e9, 1),
+                        share_of_step=round(lin["ms"] / args.steps / ms_per_step, 3))
+    cpu_baseline = None
+    if cpu_sample:
+        from oracle import bigc_oracle as O
+        torch.set_num_threads(usable_cores())
+        cpu_pairs, n_done = 0, 0
+        with torch.no_grad():
+            O.forward_test(sd, cfg, cpu_sample[:1], args.topk)          # warm-up
+            t0 = time.perf_counter()
+            for p in cpu_sample:                                         # bounded: stop after ~15 s
+                O.forward_test(sd, cfg, [p], args.topk)
+                cpu_pairs += p.num_proposals * (p.num_proposals - 1)
+                n_done += 1
+                if time.perf_counter() - t0 > 15.0:
+                    break
+            cpu_s = time.perf_counter() - t0
+        cpu_baseline = dict(value=round(cpu_pairs / cpu_s, 1), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                            sample="%d of the same synthetic videos (N=%d), oracle/bigc_oracle.py forward_test incl. "
+                                   "construct_triplet, fp32 torch CPU, %.1f s" % (n_done, args.n_trajs, cpu_s))
+    line = {
+        "metric": "tracklet_pairs_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "VidVRD-test classification-only (BASELINE configs[1]): BIG-C model_0v10 eval forward incl. "
+                               "construct_triplet, exp2 dims (RoI 2048 + I3D 832), %d synthetic videos x N=%d tracklets "
+                               "per GPU per step, topk=%d, fp32 (f32 MFMA)" % (args.videos, args.n_trajs, args.topk),
+                   "videos_per_gpu_per_step": args.videos, "tracklets_per_video": args.n_trajs,
+                   "rows_per_step": packed.n_rows, "pairs_per_gpu_per_step": pairs_per_step, "parallelism": "dp%d" % world},
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
+        "kernel_families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in families.items()},
+        "videos_per_sec": round(args.videos * world * args.steps / elapsed, 1),
+        "triplets_last_step": int(n_out.sum()), "setup_s": round(gen_s, 1),
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,17 @@ const char* bigc_last_error(void);
 /* "gfx950 f32-mfma <build id>" -- lets the host verify it loaded the HIP build */
 const char* bigc_build_info(void);
 
+/* Optional per-kernel-family timing with HIP events recorded on the caller's stream around every
+ * launch (bench.py's roofline figure). Off by default; bigc_prof_collect() must be called after the
+ * stream has been synchronised, it folds the recorded pairs into per-family totals.
+ * bigc_prof_get: ms = summed launch durations, flops/bytes = summed ALGORITHMIC work of those launches. */
+void bigc_prof_enable(int on);
+void bigc_prof_reset(void);
+int bigc_prof_collect(void);
+int bigc_prof_get(int family, double* ms, long long* launches, double* flops, double* bytes);
+int bigc_prof_family_count(void);
+const char* bigc_prof_family_name(int family);
+
 /* ------------------------------------------------------------------------------------
  * Kernel-level entry points (one per hand-written kernel family).  The model-level
  * functions below are compositions of these; tests call them directly to compare each

@@ -42,6 +42,13 @@ class bigc_outputs(ctypes.Structure):
 _SIGS = {
     "bigc_last_error": (c_char_p, []),
     "bigc_build_info": (c_char_p, []),
+    "bigc_prof_enable": (None, [c_int]),
+    "bigc_prof_reset": (None, []),
+    "bigc_prof_collect": (c_int, []),
+    "bigc_prof_get": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_longlong), POINTER(ctypes.c_double),
+                              POINTER(ctypes.c_double)]),
+    "bigc_prof_family_count": (c_int, []),
+    "bigc_prof_family_name": (c_char_p, [c_int]),
     "bigc_linear_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                 c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "bigc_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),

@@ -16,6 +16,7 @@
 // (exp(s - max) / sum) and accumulating P V -- instead of rescaling accumulators on line.
 // Operands come straight from L2 (the whole working set of a video is < 1 MB).
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -280,6 +281,7 @@ extern "C" int bigc_mha_core_f32(void* stream, const float* q, int ldq, const fl
     const int grid = (int)((items + 3) / 4);
     const float scale = 1.0f / sqrtf((float)hd);
     hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(stream, FAM_MHA, 0.0, 0.0);
 #define LAUNCH_MHA(HD) hipLaunchKernelGGL(mha_core_kernel<HD>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale)
     switch (hd) {
         case 8: LAUNCH_MHA(8); break;
@@ -299,6 +301,7 @@ extern "C" int bigc_role_attention_f32(void* stream, const float* p2a, int ldp, 
     if (n_vid <= 0) return BIGC_OK;
     const int n_qt = cdiv(nq, 32);
     const int grid = cdiv(n_vid * n_qt, 4);
+    ProfScope ps(stream, FAM_ROLE_ATT, 0.0, 0.0);
     hipLaunchKernelGGL(role_attention_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, att, e_off,
                        n_vid, nq, n_qt, half, scale);
     BIGC_LAUNCH_CHECK("role_attention");
@@ -311,6 +314,7 @@ extern "C" int bigc_role_values_f32(void* stream, const float* att, const float*
     if (n_vid <= 0) return BIGC_OK;
     const int n_qt = cdiv(nq, 32), n_dc = cdiv(d, 128);
     const long items = (long)n_vid * 2 * n_qt * n_dc;
+    ProfScope ps(stream, FAM_ROLE_VAL, 0.0, 0.0);
     hipLaunchKernelGGL(role_values_kernel, dim3((int)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, att, enco, lde, values,
                        e_off, n_vid, nq, n_qt, d, n_dc);
     BIGC_LAUNCH_CHECK("role_values");

@@ -9,6 +9,7 @@
 // an index map over the packed (sum L_i)-row store: with q,r = divmod(Tmax, L) the stretched frame f
 // reads source frame f/(q+1) when f < r(q+1) and r + (f - r(q+1))/q otherwise.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -118,6 +119,7 @@ extern "C" int bigc_bbox_feat_f32(void* stream, const float* boxes, const int32_
                                   const float* vid_wh, float* out, int n_trk) {
     BIGC_CHECK_ARG(boxes && trk_row_off && trk_vid && vid_wh && out, "bbox_feat: null pointer");
     if (n_trk <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_FRONTEND, 0.0, 0.0);
     hipLaunchKernelGGL(bbox_feat_kernel, dim3(n_trk), dim3(256), 0, (hipStream_t)stream, boxes, trk_row_off, trk_vid, vid_wh, out);
     BIGC_LAUNCH_CHECK("bbox_feat");
     return BIGC_OK;
@@ -127,6 +129,7 @@ extern "C" int bigc_conv_index(void* stream, const int32_t* trk_row_off, const i
                                const int32_t* vid_tmax, int32_t* conv_idx, int n_trk) {
     BIGC_CHECK_ARG(trk_row_off && trk_conv_off && trk_vid && vid_tmax && conv_idx, "conv_index: null pointer");
     if (n_trk <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_FRONTEND, 0.0, 0.0);
     hipLaunchKernelGGL(conv_index_kernel, dim3(n_trk), dim3(256), 0, (hipStream_t)stream, trk_row_off, trk_conv_off, trk_vid, vid_tmax, conv_idx);
     BIGC_LAUNCH_CHECK("conv_index");
     return BIGC_OK;
@@ -136,6 +139,7 @@ extern "C" int bigc_adaptive_maxpool(void* stream, const float* conv, const int3
                                      int n_trk, int d, int P) {
     BIGC_CHECK_ARG(conv && trk_conv_off && pooled && d > 0 && P > 0, "adaptive_maxpool: bad argument");
     if (n_trk <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_FRONTEND, 0.0, 0.0);
     hipLaunchKernelGGL(adaptive_maxpool_kernel, dim3(n_trk), dim3(256), 0, (hipStream_t)stream, conv, trk_conv_off, pooled, d, P);
     BIGC_LAUNCH_CHECK("adaptive_maxpool");
     return BIGC_OK;
@@ -145,6 +149,7 @@ extern "C" int bigc_stretched_mean(void* stream, const float* feats, int ldf, in
                                    const int32_t* trk_vid, const int32_t* vid_tmax, float* out, int n_trk) {
     BIGC_CHECK_ARG(feats && trk_row_off && trk_vid && vid_tmax && out && w > 0, "stretched_mean: bad argument");
     if (n_trk <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_FRONTEND, 0.0, 0.0);
     hipLaunchKernelGGL(stretched_mean_kernel, dim3(n_trk), dim3(256), 0, (hipStream_t)stream, feats, ldf, col0, w, trk_row_off, trk_vid, vid_tmax, out);
     BIGC_LAUNCH_CHECK("stretched_mean");
     return BIGC_OK;

@@ -3,6 +3,7 @@
 // (reference: models/model_0v10.py:485-503, models/model_0v7.py:485-508).
 // One workgroup per (video, query) row; pure gather traffic (HBM/L2-bound).
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -90,6 +91,7 @@ extern "C" int bigc_head_gather(void* stream, const float* att, const int32_t* e
         total += 2 * segs.width[i];
     }
     BIGC_CHECK_ARG(total <= ld_head, "head_gather: concat width %d exceeds ld_head %d", total, ld_head);
+    ProfScope ps(stream, FAM_HEAD_GATHER, 0.0, 8.0 * n_vid * (double)nq * total);
     hipLaunchKernelGGL(head_gather_kernel, dim3(n_vid * nq), dim3(256), 0, (hipStream_t)stream, att, e_off, trk_cat, nq, query, dq,
                        segs, bias_matrix, n_ecat, n_pcat, soid, head_in, ld_head, bias_out);
     BIGC_LAUNCH_CHECK("head_gather");

@@ -15,6 +15,7 @@
 // summation (the MFMA pairs k with k+4).
 // Roofline: f32 MFMA 157.3 TFLOP/s; 2*M*N*K flops per launch.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -162,6 +163,8 @@ extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int3
     p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
     const int grid = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
     hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(stream, FAM_LINEAR, 2.0 * M * (double)N * K,
+                 4.0 * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)));
     if (a_idx) hipLaunchKernelGGL(linear_f32_kernel<true>, dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(linear_f32_kernel<false>, dim3(grid), dim3(256), 0, s, p);
     BIGC_LAUNCH_CHECK("linear_f32");

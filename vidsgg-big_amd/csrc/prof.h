@@ -1,0 +1,15 @@
+// Optional in-library kernel timing with HIP events on the caller's stream (used by bench.py for the
+// roofline figure: algorithmic flops/bytes per launch divided by the measured launch duration).
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum BigcFamily {
+    FAM_LINEAR = 0, FAM_MHA, FAM_ROLE_ATT, FAM_ROLE_VAL, FAM_LAYERNORM, FAM_ADD_ROWS, FAM_FRONTEND,
+    FAM_HEAD_GATHER, FAM_TRIPLETS, FAM_GROUNDING, FAM_COUNT
+};
+
+struct ProfScope {
+    hipStream_t s; int slot;
+    ProfScope(void* stream, int family, double flops, double bytes);
+    ~ProfScope();
+};

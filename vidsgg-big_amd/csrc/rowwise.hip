@@ -2,6 +2,7 @@
 // One wave per row, 16-byte loads, statistics by in-register two-pass + wave reduction.
 // Roofline: HBM (read x once, write y once): 8*d bytes per row.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -86,6 +87,7 @@ extern "C" int bigc_layernorm_f32(void* stream, const float* x, const float* gam
     BIGC_CHECK_ARG(x && gamma && beta && y, "layernorm: null pointer");
     BIGC_CHECK_ARG(d > 0 && d % 4 == 0 && d <= 2048, "layernorm: d=%d must be a multiple of 4 and <= 2048", d);
     if (rows <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_LAYERNORM, 0.0, 8.0 * rows * (double)d);
     hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, rows, d, eps);
     BIGC_LAUNCH_CHECK("layernorm");
     return BIGC_OK;
@@ -96,6 +98,7 @@ extern "C" int bigc_add_rows_f32(void* stream, const float* x, const float* p, f
     BIGC_CHECK_ARG(d > 0 && d % 4 == 0 && period > 0, "add_rows: d=%d must be a multiple of 4", d);
     if (rows <= 0) return BIGC_OK;
     const long n4 = (long)rows * (d / 4);
+    ProfScope ps(stream, FAM_ADD_ROWS, 0.0, (x ? 8.0 : 4.0) * rows * (double)d);
     const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(add_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, p, y, n4, d / 4, period);
     BIGC_LAUNCH_CHECK("add_rows");

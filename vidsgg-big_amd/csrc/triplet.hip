@@ -11,6 +11,7 @@
 //     predicate probability (:761 argmax), groups with predicate 0 (background) are dropped (:771)
 // Integer/byte work, latency-bound: 256 workgroups of 256 threads, everything in LDS.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -187,6 +188,7 @@ extern "C" int bigc_construct_triplets(void* stream, const float* logits, int n_
     BIGC_CHECK_ARG(n_pcat > 0 && n_pcat <= 256, "construct_triplets: num_pred_cats=%d must be <= 256", n_pcat);
     BIGC_CHECK_ARG(topk > 0 && topk <= n_pcat && nq * topk <= SORT_N, "construct_triplets: num_querys*topk=%d must be <= %d", nq * topk, SORT_N);
     if (n_vid <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_TRIPLETS, 0.0, 0.0);
     hipLaunchKernelGGL(construct_triplets_kernel, dim3(n_vid), dim3(256), 0, (hipStream_t)stream, logits, n_pcat, soid, e_off, trk_dura,
                        trk_cat, trk_score, nq, topk, quint, scores, dura, qid, n_out);
     BIGC_LAUNCH_CHECK("construct_triplets");

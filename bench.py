@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--videos", type=int, default=256, help="videos per GPU per step")
     ap.add_argument("--n-trajs", type=int, default=64)
     ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--cpu-videos", type=int, default=16, help="videos of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-videos", type=int, default=256, help="videos of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not record HIP events around the kernels")
     return ap.parse_args()
 

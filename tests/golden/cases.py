@@ -36,6 +36,17 @@ BIGC_CASES = {
     # G2: full config V, N=64, the benchmark's first video (seed 1234)
     "bigc_v_n64": dict(cfg="CONFIG_V", variant="vidvrd", wseed=7, topk=10, att_gain=8.0, full=False,
                        videos=[dict(seed=1234, n_trajs=64)]),
+    # G3: the VidOR model (models/model_0v7.py): classeme carried in the features / category embedding /
+    # no classeme at all, tiny dims with all intermediates; then the exp5 dims with N=32
+    "bigo_tiny_clsme": dict(cfg="CONFIG_TINY_O", variant="vidor", wseed=31, topk=3, att_gain=6.0, full=True,
+                            videos=[dict(seed=501, n_trajs=8, len_range=(5, 30), start_range=(0, 10)),
+                                    dict(seed=502, n_trajs=2, len_range=(5, 6), start_range=(0, 2))]),
+    "bigo_tiny_emb": dict(cfg="CONFIG_TINY_O_EMB", variant="vidor", wseed=32, topk=3, att_gain=6.0, full=False,
+                          videos=[dict(seed=503, n_trajs=11, len_range=(5, 20), start_range=(0, 10))]),
+    "bigo_tiny_noclsme": dict(cfg="CONFIG_TINY_O_NOCLSME", variant="vidor", wseed=33, topk=3, att_gain=6.0, full=False,
+                              videos=[dict(seed=504, n_trajs=7, len_range=(5, 20), start_range=(0, 10))]),
+    "bigo_o_n32": dict(cfg="CONFIG_O", variant="vidor", wseed=34, topk=3, att_gain=8.0, full=False,
+                       videos=[dict(seed=2234, n_trajs=32, len_range=(15, 200), start_range=(0, 100))]),
 }
 
 
@@ -44,13 +55,22 @@ def get_cfg(name):
         c = dict(configs.CONFIG_TINY)
         c.pop("dim_i3d")
         return c
+    if name == "CONFIG_TINY_O_EMB":
+        c = dict(configs.CONFIG_TINY_O)
+        c["_with_EntiNameEmb"] = True       # a category-embedding table instead of per-frame classeme
+        return c
+    if name == "CONFIG_TINY_O_NOCLSME":
+        c = dict(configs.CONFIG_TINY_O)
+        c["use_clsme"] = False
+        return c
     return dict(getattr(configs, name))
 
 
 def feat_width(cfg, variant):
     if variant == "vidvrd":
         return cfg["dim_feat"] + (cfg.get("dim_i3d", None) or 0)
-    return cfg["dim_feat"] + (cfg["dim_clsme"] if cfg.get("use_clsme", False) and cfg.get("EntiNameEmb_path") is None else 0)
+    per_frame_clsme = cfg.get("use_clsme", False) and cfg.get("EntiNameEmb_path") is None and not cfg.get("_with_EntiNameEmb", False)
+    return cfg["dim_feat"] + (cfg["dim_clsme"] if per_frame_clsme else 0)
 
 
 def make_proposal(cfg, variant, spec):

@@ -1,0 +1,71 @@
+"""World-size-2 gloo test (CPU) of the process-per-GPU sharding that replaces the reference's
+DataParallel shim: partition, object gather in batch order, max-over-ranks timing.  The per-video
+work is done by the CPU oracle here (the HIP kernels need a GPU); what is under test is the N>1
+host path itself."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import cases
+from bigc_hip.shard import gather_results, max_over_ranks, shard_indices
+
+
+def test_shard_indices_partition():
+    for bs in range(1, 20):
+        for world in range(1, 9):
+            parts = [shard_indices(bs, r, world) for r in range(world)]
+            flat = sorted(i for p in parts for i in p)
+            assert flat == list(range(bs))
+            if not (bs == 4 and world == 2):
+                assert all(p == list(range(p[0], p[0] + len(p))) for p in parts if p)      # contiguous chunks
+                assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert shard_indices(8, 1, 2) == [4, 5, 6, 7]           # utils/DataParallel.py:80-92
+    assert shard_indices(4, 0, 2) == [0, 3] and shard_indices(4, 1, 2) == [1, 2]   # scatter_42 :95-113
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import bigc_oracle as O
+    cfg, variant, sd, props, topk = cases.make_case("bigc_tiny_edges")
+    mine = shard_indices(len(props), rank, world)
+    local = O.forward_test(sd, cfg, [props[i] for i in mine], topk, variant)
+    dist.barrier()
+    res = gather_results(local, mine, len(props), dist)
+    slow = max_over_ranks(1.0 + rank, dist)
+    if rank == 0:
+        full = O.forward_test(sd, cfg, props, topk, variant)
+        ok = len(res) == len(full)
+        for a, b in zip(res, full):
+            ok = ok and ((a is None) == (b is None))
+            if a is not None:
+                ok = ok and all(torch.equal(x, y) for x, y in zip(a, b))
+        q.put((ok, slow))
+    else:
+        assert res is None
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_process():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, slow = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok
+    assert slow == 2.0

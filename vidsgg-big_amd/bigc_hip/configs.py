@@ -85,6 +85,30 @@ CONFIG_O = dict(
     loss_coeff_dict=dict(classification=1.0, adj_matrix=30.0),
 )
 
+# tiny VidOR-structured configuration (sine pos-embedding, classeme in the features, 2-layer head)
+CONFIG_TINY_O = dict(
+    num_enti_cats=9,
+    num_pred_cats=7,
+    dim_ffn=32,
+    dim_enti=16,
+    dim_pred=16,
+    dim_att=16,
+    dim_feat=24,
+    dim_clsme=12,
+    enco_pool_len=4,
+    n_enco_layers=3,
+    n_deco_layers=2,
+    n_att_head=2,
+    num_querys=10,
+    neg_weight=0.1,
+    positive_vIoU_th=0.5,
+    use_clsme=True,
+    EntiNameEmb_path=None,
+    bias_matrix_path=None,
+    cost_coeff_dict=dict(classification=1.0, adj_matrix=30.0),
+    loss_coeff_dict=dict(classification=1.0, adj_matrix=30.0),
+)
+
 CONFIG_G = dict(
     dim_feat=1024,
     dim_clsme=300,

@@ -1,0 +1,57 @@
+"""One-process-per-GPU replacement of the reference's single-process ``VidSGG_DataParallel``
+(utils/DataParallel.py:45-113): which videos of a batch a rank owns, and how per-video results
+come back together.  Videos are independent, so inference needs no data-path collective; the
+only communication is the object gather of the (small) result tuples on rank 0.
+"""
+import torch
+
+
+def shard_indices(batch_size, rank, world):
+    """Indices of the batch items rank ``rank`` processes.
+
+    Same partition as ``VidSGG_DataParallel.scatter`` (utils/DataParallel.py:68-92): contiguous
+    chunks of ``batch_size // world`` in collator order, with the reference's special interleave
+    for 4 items on 2 devices (``scatter_42`` :95-113: device 0 gets items 0 and 3, device 1 gets 1
+    and 2, pairing the longest with the shortest video of a length-sorted batch).  Unlike the
+    reference (which asserts divisibility, :76) a remainder is spread over the first ranks.
+    """
+    assert 0 <= rank < world
+    if batch_size == 4 and world == 2:
+        return [0, 3] if rank == 0 else [1, 2]
+    base, rem = divmod(batch_size, world)
+    start = rank * base + min(rank, rem)
+    return list(range(start, start + base + (1 if rank < rem else 0)))
+
+
+def gather_results(local_results, local_indices, batch_size, dist=None, dst=0):
+    """Reassemble the per-video results of all ranks in batch order on rank ``dst`` (None elsewhere).
+    Tensors are moved to the CPU before they are pickled."""
+    def to_cpu(r):
+        return None if r is None else tuple(t.cpu() if isinstance(t, torch.Tensor) else t for t in r)
+
+    payload = [(i, to_cpu(r)) for i, r in zip(local_indices, local_results)]
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        gathered = [payload]
+    else:
+        gathered = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+        dist.gather_object(payload, gathered, dst=dst)
+        if dist.get_rank() != dst:
+            return None
+    out = [None] * batch_size
+    seen = set()
+    for part in gathered:
+        for i, r in part:
+            assert i not in seen
+            seen.add(i)
+            out[i] = r
+    assert len(seen) == batch_size, "every batch item must be owned by exactly one rank"
+    return out
+
+
+def max_over_ranks(seconds, dist=None, device=None):
+    """Timing rule of bench.py: the step time of the job is the slowest rank's."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -122,21 +122,44 @@ __global__ __launch_bounds__(256, 2) void linear_f32_kernel(const LinearArgs p) 
     }
 
     // epilogue: lanes 0-31 of a register hold 32 consecutive columns of one row (128-byte stores)
+    // The residual reads use clamped (always valid) addresses so that all 32 loads of a 64x32 half
+    // are issued back to back before the first use (guarded loads serialise: load, wait, add, store).
+    int colv[2];
+    float bv[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        colv[ni] = n0 + wn * 64 + ni * 32 + l31;
+        bv[ni] = p.bias ? p.bias[min(colv[ni], p.N - 1)] : 0.f;
+    }
+    const bool relu = p.act == BIGC_ACT_RELU;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
+        const int rbase = m0 + wm * 64 + mi * 32;
+        f32x16 rv[2];
+        if (p.res) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const float* rp = p.res + min(colv[ni], p.N - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[ni][r] = rp[(size_t)min(rbase + mfma_row(r, hi), p.M - 1) * p.ldr];
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[ni][r] = 0.f;
+        }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const int col = n0 + wn * 64 + ni * 32 + l31;
-            if (col >= p.N) continue;
-            const float bv = p.bias ? p.bias[col] : 0.f;
+            if (colv[ni] >= p.N) continue;
+            float* cp = p.C + colv[ni];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + mi * 32 + mfma_row(r, hi);
-                if (row >= p.M) continue;
-                float v = acc[mi][ni][r] + bv;
-                if (p.act == BIGC_ACT_RELU) v = fmaxf(v, 0.f);
-                if (p.res) v += p.res[(size_t)row * p.ldr + col];
-                p.C[(size_t)row * p.ldc + col] = v;
+                const int row = rbase + mfma_row(r, hi);
+                float v = acc[mi][ni][r] + bv[ni];
+                if (relu) v = fmaxf(v, 0.f);
+                v += rv[ni][r];
+                if (row < p.M) cp[(size_t)row * p.ldc] = v;
             }
         }
     }

@@ -317,19 +317,29 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
 
     // ---- a6: role-aware decoder (:464-467, layer :178-225)
     TRY(bigc_fill_offsets(hs, w.q_off, B + 1, Q));
-    TRY(bigc_add_rows_f32(s, nullptr, m->qinit, w.query, BQ, dp, Q));
+    if (c.n_deco_layers == 0) TRY(bigc_add_rows_f32(s, nullptr, m->qinit, w.query, BQ, dp, Q));
     const float att_scale = 1.0f / sqrtf((float)de);
     for (int i = 0; i < c.n_deco_layers; ++i) {
         const DecLayer& L = m->dec[i];
-        TRY(bigc_add_rows_f32(s, w.query, m->pos, w.qk_in, BQ, dp, Q));
         Lin qkp{L.in_proj.w, L.in_proj.b};
         Lin vp{L.in_proj.w + (size_t)2 * dp * dp, L.in_proj.b + 2 * dp};
-        TRY(linear(s, w.qk_in, dp, qkp, w.qk, 2 * dp, BQ, 2 * dp, dp, BIGC_ACT_NONE));
-        TRY(linear(s, w.query, dp, vp, w.vv, dp, BQ, dp, dp, BIGC_ACT_NONE));
-        TRY(bigc_mha_core_f32(s, w.qk, 2 * dp, w.qk + dp, 2 * dp, w.vv, dp, w.ao2, dp, w.q_off, w.q_off, B, Q, H, dp / H));
-        TRY(linear(s, w.ao2, dp, L.out_proj, w.t2, dp, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
-        TRY(bigc_layernorm_f32(s, w.t2, L.n1.g, L.n1.b, w.t3, BQ, dp, eps));
-        TRY(bigc_add_rows_f32(s, w.t3, m->pos, w.query, BQ, dp, Q));            // query += pos, kept (:189)
+        // The self-attention block of the FIRST layer only sees pred_query_init and pos_embedding
+        // (:465,181-186), which are the same for every video: it is evaluated once on Q rows and the
+        // result (after `query += pos`) is tiled over the batch. Later layers run on all B*Q rows.
+        const int rows = (i == 0) ? Q : BQ, nseq = (i == 0) ? 1 : B;
+        const float* qin = (i == 0) ? m->qinit : w.query;
+        TRY(bigc_add_rows_f32(s, qin, m->pos, w.qk_in, rows, dp, Q));
+        TRY(linear(s, w.qk_in, dp, qkp, w.qk, 2 * dp, rows, 2 * dp, dp, BIGC_ACT_NONE));
+        TRY(linear(s, qin, dp, vp, w.vv, dp, rows, dp, dp, BIGC_ACT_NONE));
+        TRY(bigc_mha_core_f32(s, w.qk, 2 * dp, w.qk + dp, 2 * dp, w.vv, dp, w.ao2, dp, w.q_off, w.q_off, nseq, Q, H, dp / H));
+        TRY(linear(s, w.ao2, dp, L.out_proj, w.t2, dp, rows, dp, dp, BIGC_ACT_NONE, qin, dp));
+        TRY(bigc_layernorm_f32(s, w.t2, L.n1.g, L.n1.b, w.t3, rows, dp, eps));
+        if (i == 0) {
+            TRY(bigc_add_rows_f32(s, w.t3, m->pos, w.qk_in, Q, dp, Q));
+            TRY(bigc_add_rows_f32(s, nullptr, w.qk_in, w.query, BQ, dp, Q));
+        } else {
+            TRY(bigc_add_rows_f32(s, w.t3, m->pos, w.query, BQ, dp, Q));        // query += pos, kept (:189)
+        }
         TRY(linear(s, enco, de, L.e2a, w.e2a, da, NT, da, de, BIGC_ACT_NONE));
         TRY(linear(s, w.query, dp, L.p2a, w.p2a, da, BQ, da, dp, BIGC_ACT_NONE));
         TRY(bigc_role_attention_f32(s, w.p2a, da, w.e2a, da, out->att, b->vid_trk_off, B, Q, da / 2, att_scale));

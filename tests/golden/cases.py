@@ -89,6 +89,45 @@ def make_proposal(cfg, variant, spec):
     return p
 
 
+# ---- grounding scorer (models/grd_model_v5.py) ------------------------------------------------
+# thresholds of experiments/grounding_weights/config_.py:74-80
+GRD_TH = dict(score_th=0.9, tiou_th=0.5, bins_th=0.2, nms_th=0.8)
+GRD_CASES = {
+    # G4 tiny (hidden 64 = 8 heads x 8, 3 bins, T=9, n=5): every intermediate stored
+    "grd_tiny": dict(cfg=dict(dim_feat=32, dim_clsme=300, dim_hidden=64, num_bins=3), wseed=41, gain=4.0, full=True,
+                     videos=[dict(seed=601, T=9, n=5, video_len=70), dict(seed=602, T=33, n=1, video_len=260),
+                             dict(seed=603, T=2, n=4, video_len=16)]),
+    # full dims (config G), n=64 queries x T=120 clips: outputs only
+    "grd_g_n64": dict(cfg=dict(dim_feat=1024, dim_clsme=300, dim_hidden=128, num_bins=10), wseed=42, gain=4.0, full=False,
+                      videos=[dict(seed=604, T=120, n=64, video_len=960)]),
+}
+
+
+def make_grd_inputs(cfg, spec):
+    """Synthetic grounding input of one video: clip features 0.1*N(0,1) (T,dim_feat),
+    n triplet queries [pred, s_cat, o_cat, s_tid, o_tid] with an overlap span inside the video."""
+    import numpy as np
+    import torch
+    rs = np.random.RandomState(spec["seed"])
+    T, n, video_len = spec["T"], spec["n"], spec["video_len"]
+    feat = torch.from_numpy((0.1 * rs.standard_normal((T, cfg["dim_feat"]))).astype(np.float32))
+    quint = np.stack([rs.randint(1, 51, n), rs.randint(1, 81, n), rs.randint(1, 81, n), rs.randint(0, 50, n), rs.randint(0, 50, n)], 1)
+    s = rs.randint(0, video_len // 2, n)
+    e = s + rs.randint(1, video_len // 2, n)
+    dura = np.stack([s, e], 1)
+    return feat, (torch.from_numpy(quint.astype(np.int64)), torch.from_numpy(dura.astype(np.int64)), video_len)
+
+
+def make_grd_case(name):
+    """-> (cfg, state_dict, [(video_feature, (quintuples, dura_inters, video_len)), ...])"""
+    from bigc_hip.synthetic import grd_state_shapes
+    case = GRD_CASES[name]
+    cfg = dict(case["cfg"])
+    cfg["loss_factor"] = dict(classification=1.0, centerness=1.0, regression=1.0)
+    sd = seeded_state_dict(grd_state_shapes(cfg), case["wseed"], case["gain"])
+    return cfg, sd, [make_grd_inputs(cfg, v) for v in case["videos"]]
+
+
 def make_case(name):
     """-> (cfg, variant, state_dict, [proposals], topk)"""
     case = BIGC_CASES[name]

@@ -117,13 +117,57 @@ def run_bigc_case(name, m10, m07):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def run_grd_case(name, grd):
+    case = cases.GRD_CASES[name]
+    cfg, sd, videos = cases.make_grd_case(name)
+    d = tempfile.mkdtemp()
+    rcfg = dict(cfg)
+    np.save(os.path.join(d, "e.npy"), sd["EntiNameEmb"].numpy())
+    np.save(os.path.join(d, "p.npy"), sd["PredNameEmb"].numpy())
+    rcfg["EntiNameEmb_path"], rcfg["PredNameEmb_path"] = os.path.join(d, "e.npy"), os.path.join(d, "p.npy")
+    model = grd.DEBUG(rcfg, is_train=False)
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    model.eval()
+    out = {"torch_version": np.array(torch.__version__), "n_videos": np.array(len(videos))}
+    captured = {}
+
+    def hook(tag):
+        def f(_m, _i, o):
+            captured[tag] = o
+        return f
+
+    for tag in ("video_encoder", "query_encoder", "combined_encoder", "vq_fc"):
+        getattr(model, tag).register_forward_hook(hook(tag))
+    with torch.no_grad():
+        for v, (feat, data) in enumerate(videos):
+            pre = "v%d_" % v
+            pooled, probs, mask = model([feat], [data], with_gt_data=False, **cases.GRD_TH)
+            out[pre + "pooled_se"] = pooled.numpy()
+            out[pre + "bins_probs"] = probs.numpy()
+            out[pre + "bins_mask"] = mask.numpy()
+            words, info = model.prepare_data(data)
+            regrs, conf, cls = model.forward_propagation(feat, words, info)
+            out[pre + "regrs"], out[pre + "conf"], out[pre + "cls"] = regrs.numpy(), conf.numpy(), cls.numpy()
+            if case.get("full", False):
+                out[pre + "video_enc"] = captured["video_encoder"][0].t().numpy()              # (T,d)
+                out[pre + "query_enc"] = captured["query_encoder"].transpose(1, 2).numpy()     # (n,3,d)
+                out[pre + "combined_in"] = captured["vq_fc"].numpy()                           # (n,T,d)
+                out[pre + "combined_enc"] = captured["combined_encoder"].transpose(1, 2).numpy()
+    path = os.path.join(cases.GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def main():
     torch.manual_seed(0)
     m10, m07, grd = import_reference()
-    names = sys.argv[1:] or list(cases.BIGC_CASES)
+    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES))
     for n in names:
         if n in cases.BIGC_CASES:
             run_bigc_case(n, m10, m07)
+        elif n in cases.GRD_CASES:
+            run_grd_case(n, grd)
         else:
             raise SystemExit("unknown case " + n)
 

@@ -160,6 +160,38 @@ def bigc_state_shapes(cfg, variant="vidvrd"):
     return shapes
 
 
+def grd_state_shapes(cfg):
+    """Ordered (key, shape) list of the grounding scorer's ``state_dict``
+    (reference: models/grd_model_v5.py:158-193; the two embedding tables are hard-wired to
+    81 entity / 51 predicate rows there, :162,168)."""
+    d, k, de = cfg["dim_hidden"], cfg["num_bins"], cfg["dim_clsme"]
+    shapes = [("EntiNameEmb", (81, de)), ("PredNameEmb", (51, de))]
+    shapes += _linear_shapes("video_fc", d, cfg["dim_feat"])
+    shapes += _linear_shapes("query_fc", d, de)
+    shapes += _linear_shapes("temp_fc", d, 2)
+    shapes += _linear_shapes("vq_fc", d, 4 * d)
+
+    def dws(prefix, c_out, ksize):
+        return [(prefix + ".depth_wise.weight", (d, 1, ksize)), (prefix + ".depth_wise.bias", (d,)),
+                (prefix + ".point_wise.weight", (c_out, d, 1)), (prefix + ".point_wise.bias", (c_out,))]
+
+    for enc, ksize in (("video_encoder", 7), ("query_encoder", 3), ("combined_encoder", 7)):
+        for i in range(4):
+            shapes += dws("%s.convs.%d" % (enc, i), d, ksize)
+        shapes += _mha_shapes(enc + ".mh_attn", d)
+        shapes += _linear_shapes(enc + ".fc", d, d)
+        shapes += _ln_shapes(enc + ".normb", d)
+        for i in range(4):
+            shapes += _ln_shapes("%s.norm_seq.%d" % (enc, i), d)
+        shapes += _ln_shapes(enc + ".norme", d)
+    shapes.append(("proj2sim.weight", (d, d)))
+    for hname, c_out in (("cls_head", k), ("conf_head", k), ("regr_head", 2 * k)):
+        for i in range(4):
+            shapes += dws("%s.%d.0" % (hname, i), d, 3)
+        shapes += dws("%s.4" % hname, c_out, 3)
+    return shapes
+
+
 def _fill(rs, key, shape, att_gain=1.0):
     """Seeded value for one state_dict entry (SURVEY.md section 8d weight recipe)."""
     leaf = key.split(".")[-1]
@@ -178,7 +210,11 @@ def _fill(rs, key, shape, att_gain=1.0):
     recept = int(np.prod(shape[2:])) if len(shape) > 2 else 1
     fan_out, fan_in = shape[0] * recept, shape[1] * recept
     std = np.sqrt(2.0 / (fan_in + fan_out))
-    if "fc_enti2att" in key or "fc_pred2att" in key:
+    if "depth_wise.weight" in key:
+        # the reference uses kaiming-normal (2/fan_in, models/grd_model_v5.py:47); 0.5/fan_in keeps the
+        # five un-normalised conv stacks of the heads from saturating every sigmoid
+        std = np.sqrt(0.5 / recept)
+    if "fc_enti2att" in key or "fc_pred2att" in key or "_head.4.point_wise.weight" in key or key == "proj2sim.weight":
         std *= att_gain
     return rs.normal(0.0, std, size=shape)
 

@@ -60,6 +60,7 @@ const char* bigc_prof_family_name(int family);
 
 #define BIGC_ACT_NONE 0
 #define BIGC_ACT_RELU 1
+#define BIGC_ACT_SIGMOID 2
 
 /* C[m, n] = act( sum_k A'[m, k] * W[n, k] + bias[n] ) + residual[m, n]
  *   replaces torch.nn.Linear / F.linear at every call site of the path
@@ -207,6 +208,70 @@ typedef struct {
 size_t bigc_workspace_bytes(const bigc_model* m, const bigc_batch* b);
 int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                  int topk, const bigc_outputs* out);
+
+/* ------------------------------------------------------------------------------------
+ * Temporal grounding scorer (models/grd_model_v5.py, class DEBUG), eval path, one video per call
+ * (the reference asserts batch size 1 at test time, :211).
+ * ---------------------------------------------------------------------------------- */
+
+/* depth-wise Conv1d(groups=C, kernel ks, padding ks/2, stride 1) over n_seq sequences of length T stored as
+ *   rows (n_seq*T, d): y[s,t,c] = b[c] + sum_j w[c,j] * x[s, t+j-ks/2, c]  (models/grd_model_v5.py:44,54).
+ *   w is the torch (d,1,ks) weight; d % 4 == 0; ks odd <= 7. */
+int bigc_dwconv_f32(void* stream, const float* x, const float* w, const float* b, float* y, int n_seq, int T, int d, int ks);
+
+/* Video <-> query co-attention and feature fusion (models/grd_model_v5.py:346-365) for n queries of 3 words:
+ *   sim[i,t,l] = proj[t,:] . query[i,l,:]; sim_r = softmax_l, sim_c = softmax_t;
+ *   A = sim_r @ query_i, B = (sim_r sim_c^T) @ video evaluated as sim_r @ (sim_c^T @ video);
+ *   out[i,t,:] = [video[t], A, A*video[t], B*video[t]]  (4d wide).
+ *   video, proj (T,d); query (n*3,d); out (n*T, 4d). T <= 2048, d % 4 == 0, d <= 256. */
+int grd_coattention_f32(void* stream, const float* video, const float* proj, const float* query, float* out, int n, int T, int d);
+
+/* Multi-bin post-processing of the three heads (models/grd_model_v5.py:533-572 with temporal_pooling :697-737
+ *   and temporal_nms :667-695): scores = sigmoid(conf)*sigmoid(cls); per (query, bin) the spans
+ *   [clip[t]-left, clip[t]+right] of the clips scoring above score_th*top whose gIoU with the top clip's span
+ *   exceeds tiou_th are merged, clipped to the subject/object overlap span `info` (or replaced by it when
+ *   disjoint), the overlap span is appended as bin k with probability 1, greedy 1-D NMS (tIoU >= nms_th
+ *   suppresses), at least one bin kept per query, and the overlap bin's probability zeroed when no real bin
+ *   exceeds bins_th.  regrs (n,T,2k) already passed through the sigmoid; conf, cls (n,T,k) logits;
+ *   clip (T) = linspace(0,1,T); info (n,2). Outputs pooled_se (n,k+1,2), bins_probs (n,k+1), bins_mask (n,k+1) u8.
+ *   k <= 16. status[0] is set to 1 if some (query,bin) had an empty pooling set (the reference raises there, :726). */
+int grd_postprocess(void* stream, const float* regrs, const float* conf, const float* cls, const float* clip, const float* info,
+                    int n, int T, int k, float score_th, float tiou_th, float bins_th, float nms_th,
+                    float* pooled_se, float* bins_probs, uint8_t* bins_mask, int32_t* status);
+
+typedef struct {
+    int32_t dim_feat, dim_clsme, dim_hidden, num_bins;
+    int32_t n_enti_emb, n_pred_emb;   /* rows of EntiNameEmb / PredNameEmb (81 / 51 in the reference) */
+} grd_config;
+
+typedef struct grd_model grd_model;
+
+int grd_create(const grd_config* cfg, grd_model** out);
+void grd_destroy(grd_model* m);
+int grd_set_param(grd_model* m, const char* key, const float* ptr, int64_t numel);
+int grd_finalize(grd_model* m, void* stream);
+size_t grd_workspace_bytes(const grd_model* m, int T, int n);
+
+typedef struct {
+    float* pooled_se;     /* (n, k+1, 2) normalised [0,1] */
+    float* bins_probs;    /* (n, k+1) */
+    uint8_t* bins_mask;   /* (n, k+1) */
+    int32_t* status;      /* (1) */
+    float* regrs;         /* (n*T, 2k) optional */
+    float* conf;          /* (n*T, k) optional */
+    float* cls;           /* (n*T, k) optional */
+    float* video_enc;     /* (T, d) optional */
+    float* query_enc;     /* (3n, d) optional */
+    float* combined_enc;  /* (n*T, d) optional */
+} grd_outputs;
+
+/* quint (n,5) int32 [pred, s_cat, o_cat, s_tid, o_tid] and dura (n,2) int32 as produced by bigc_forward;
+ * pos_video (T,d), pos_query (3,d): PosEncoder tables (models/grd_model_v5.py:58-78) evaluated by the host
+ * exactly as the reference does; clip (T) = linspace(0,1,T). */
+int grd_forward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, const int32_t* dura, int n,
+                float video_len, const float* pos_video, const float* pos_query, const float* clip,
+                float score_th, float tiou_th, float bins_th, float nms_th,
+                void* workspace, size_t workspace_bytes, const grd_outputs* out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,186 @@
+"""GPU parity of the grounding scorer (HIP path through the C ABI) against the reference goldens and
+the CPU oracle: network outputs within 1e-4 relative, pooled spans / bin probabilities within 1e-5,
+bin masks exact."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import cases
+from bigc_hip import _lib
+from oracle import grd_oracle as G
+
+DEV = "cuda:0"
+
+
+def S():
+    return _lib.current_stream()
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+def build_model(cfg, sd):
+    from models import DEBUG
+    d = tempfile.mkdtemp()
+    cfg = dict(cfg)
+    np.save(os.path.join(d, "e.npy"), sd["EntiNameEmb"].numpy())
+    np.save(os.path.join(d, "p.npy"), sd["PredNameEmb"].numpy())
+    cfg["EntiNameEmb_path"], cfg["PredNameEmb_path"] = os.path.join(d, "e.npy"), os.path.join(d, "p.npy")
+    m = DEBUG(cfg, is_train=False)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("n_seq,T,d,ks", [(1, 9, 64, 7), (5, 3, 128, 3), (7, 40, 128, 7), (3, 1, 16, 3), (2, 2, 32, 7)])
+def test_dwconv(n_seq, T, d, ks):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n_seq * 100 + T)
+    x = torch.randn(n_seq, T, d, generator=g)
+    w = torch.randn(d, 1, ks, generator=g)
+    b = torch.randn(d, generator=g)
+    want = F.conv1d(x.transpose(1, 2), w, b, padding=ks // 2, groups=d).transpose(1, 2)
+    xd, wd, bd = x.to(DEV).contiguous(), w.to(DEV).contiguous(), b.to(DEV)
+    y = torch.full((n_seq * T, d), float("nan"), device=DEV)
+    _lib.check(lib.bigc_dwconv_f32(S(), xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), n_seq, T, d, ks))
+    torch.cuda.synchronize()
+    assert rel(y.cpu().reshape(n_seq, T, d), want) < 2e-6
+
+
+@pytest.mark.parametrize("n,T,d", [(5, 9, 64), (1, 300, 128), (17, 2, 128), (3, 1000, 128)])
+def test_coattention(n, T, d):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + T)
+    video = torch.randn(T, d, generator=g)
+    proj = torch.randn(T, d, generator=g) * 0.3
+    query = torch.randn(n, 3, d, generator=g)
+    sim = torch.matmul(proj[None].expand(n, -1, -1), query.transpose(1, 2))            # (n,T,3)
+    sr, sc = torch.softmax(sim, 2), torch.softmax(sim, 1)
+    v = video[None].expand(n, -1, -1)
+    a = sr @ query
+    b = (sr @ sc.transpose(1, 2)) @ v
+    want = torch.cat([v, a, a * v, b * v], -1)
+    vd, pd, qd = video.to(DEV), proj.to(DEV), query.to(DEV).contiguous()
+    out = torch.full((n * T, 4 * d), float("nan"), device=DEV)
+    _lib.check(lib.grd_coattention_f32(S(), vd.data_ptr(), pd.data_ptr(), qd.data_ptr(), out.data_ptr(), n, T, d))
+    torch.cuda.synchronize()
+    assert not torch.isnan(out).any()
+    assert rel(out.cpu().reshape(n, T, 4 * d), want) < 1e-5
+
+
+def run_postprocess(regrs, conf, cls, info, k, th):
+    lib = _lib.load()
+    n, T = conf.shape[0], conf.shape[1]
+    rd, cd, ld, idv = [t.to(DEV).contiguous() for t in (regrs, conf, cls, info)]
+    clip = torch.linspace(0, 1, T).to(DEV)
+    pooled = torch.empty(n, k + 1, 2, device=DEV)
+    probs = torch.empty(n, k + 1, device=DEV)
+    mask = torch.empty(n, k + 1, dtype=torch.uint8, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(lib.grd_postprocess(S(), rd.data_ptr(), cd.data_ptr(), ld.data_ptr(), clip.data_ptr(), idv.data_ptr(), n, T, k,
+                                   th["score_th"], th["tiou_th"], th["bins_th"], th["nms_th"], pooled.data_ptr(), probs.data_ptr(),
+                                   mask.data_ptr(), status.data_ptr()))
+    torch.cuda.synchronize()
+    return pooled.cpu(), probs.cpu(), mask.cpu().bool(), int(status.item())
+
+
+@pytest.mark.parametrize("name", list(cases.GRD_CASES))
+def test_postprocess_on_reference_network_outputs(name):
+    """a14-a16 alone, fed with the REFERENCE's regrs/conf/cls: spans to 1e-6, masks exact."""
+    g = np.load(os.path.join(cases.GOLDEN_DIR, name + ".npz"))
+    cfg, sd, videos = cases.make_grd_case(name)
+    for v, (feat, data) in enumerate(videos):
+        pre = "v%d_" % v
+        info = data[1].float() / data[2]
+        pooled, probs, mask, status = run_postprocess(torch.from_numpy(g[pre + "regrs"]), torch.from_numpy(g[pre + "conf"]),
+                                                      torch.from_numpy(g[pre + "cls"]), info, cfg["num_bins"], cases.GRD_TH)
+        assert status == 0
+        assert np.abs(pooled.numpy() - g[pre + "pooled_se"]).max() < 2e-6
+        assert np.abs(probs.numpy() - g[pre + "bins_probs"]).max() < 2e-6
+        assert np.array_equal(mask.numpy(), g[pre + "bins_mask"])
+
+
+def test_postprocess_thresholds_and_nms_vs_oracle():
+    """random heads with other thresholds (heavy NMS suppression, weak bins, disjoint spans)."""
+    rs = np.random.RandomState(3)
+    n, T, k = 40, 25, 10
+    regrs = torch.from_numpy(rs.uniform(0.01, 0.4, (n, T, 2 * k)).astype(np.float32))
+    conf = torch.from_numpy((3 * rs.standard_normal((n, T, k))).astype(np.float32))
+    cls = torch.from_numpy((3 * rs.standard_normal((n, T, k))).astype(np.float32))
+    conf[:5] -= 8.0                                           # weak queries: no real bin above bins_th
+    s = rs.uniform(0, 0.6, n)
+    info = torch.from_numpy(np.stack([s, s + rs.uniform(0.01, 0.4, n)], 1).astype(np.float32))
+    for th in (dict(score_th=0.5, tiou_th=0.3, bins_th=0.3, nms_th=0.4), dict(score_th=0.9, tiou_th=0.5, bins_th=0.2, nms_th=0.8)):
+        pooled, probs, mask, status = run_postprocess(regrs, conf, cls, info, k, th)
+        scores = conf.sigmoid() * cls.sigmoid()
+        want_pool = G.temporal_pooling(regrs, scores, k, th["score_th"], th["tiou_th"])
+        assert np.abs(pooled[:, :k].numpy() - _clip_to(want_pool, info).numpy()).max() < 2e-6
+        # full post-processing through the oracle's own function with a stub network
+        wp, wprob, wmask = _oracle_post(regrs, conf, cls, info, k, th)
+        assert status == 0
+        assert np.abs(pooled.numpy() - wp.numpy()).max() < 2e-6
+        assert np.abs(probs.numpy() - wprob.numpy()).max() < 2e-6
+        assert np.array_equal(mask.numpy(), wmask.numpy())
+
+
+def _clip_to(pooled, info):
+    s = torch.maximum(info[:, None, 0], pooled[:, :, 0])
+    e = torch.minimum(info[:, None, 1], pooled[:, :, 1])
+    ov = s <= e
+    return torch.where(ov[:, :, None], torch.stack([s, e], -1), info[:, None, :].expand(-1, pooled.shape[1], -1))
+
+
+def _oracle_post(regrs, conf, cls, info, k, th):
+    orig = G.forward_propagation
+    G.forward_propagation = lambda sd, vf, we, idura: (regrs, conf, cls)
+    try:
+        return G.forward_test_single(None, None, None, info, k, th["score_th"], th["tiou_th"], th["bins_th"], th["nms_th"])
+    finally:
+        G.forward_propagation = orig
+
+
+@pytest.mark.parametrize("name", list(cases.GRD_CASES))
+def test_grounding_vs_reference_golden(name):
+    g = np.load(os.path.join(cases.GOLDEN_DIR, name + ".npz"))
+    cfg, sd, videos = cases.make_grd_case(name)
+    model = build_model(cfg, sd)
+    k = cfg["num_bins"]
+    for v, (feat, data) in enumerate(videos):
+        pre = "v%d_" % v
+        quint, dura, video_len = data
+        n, T = quint.shape[0], feat.shape[0]
+        raw = model.forward_raw(feat.to(DEV), quint, dura, video_len, keep_intermediates=True, **cases.GRD_TH)
+        torch.cuda.synchronize()
+        if pre + "video_enc" in g.files:
+            assert rel(raw["video_enc"].cpu().numpy(), g[pre + "video_enc"]) < 2e-5
+            assert rel(raw["query_enc"].cpu().numpy().reshape(n, 3, -1), g[pre + "query_enc"]) < 2e-5
+            assert rel(raw["combined_enc"].cpu().numpy().reshape(n, T, -1), g[pre + "combined_enc"]) < 1e-4
+        assert rel(raw["regrs"].cpu().numpy().reshape(n, T, 2 * k), g[pre + "regrs"]) < 1e-4
+        assert rel(raw["conf"].cpu().numpy().reshape(n, T, k), g[pre + "conf"]) < 1e-4
+        assert rel(raw["cls"].cpu().numpy().reshape(n, T, k), g[pre + "cls"]) < 1e-4
+        pooled, probs, mask = model([feat.to(DEV)], [data], with_gt_data=False, **cases.GRD_TH)
+        assert mask.dtype == torch.bool and pooled.shape == (n, k + 1, 2)
+        assert np.abs(pooled.cpu().numpy() - g[pre + "pooled_se"]).max() < 2e-5
+        assert np.abs(probs.cpu().numpy() - g[pre + "bins_probs"]).max() < 2e-5
+        assert np.array_equal(mask.cpu().numpy(), g[pre + "bins_mask"])
+
+
+def test_grounding_empty_and_all_zero_scores():
+    cfg, sd, videos = cases.make_grd_case("grd_tiny")
+    model = build_model(cfg, sd)
+    feat, (quint, dura, vl) = videos[0]
+    assert model([feat.to(DEV)], [(quint[:0], dura[:0], vl)], with_gt_data=False) == (None, None)
+    # all scores exactly zero: the reference dies with an IndexError in temporal_pooling (:726)
+    n, T, k = 2, 5, 3
+    regrs = torch.full((n, T, 2 * k), 0.1)
+    neg = torch.full((n, T, k), -200.0)
+    info = torch.tensor([[0.1, 0.5], [0.2, 0.9]])
+    _, _, _, status = run_postprocess(regrs, neg, neg, info, k, cases.GRD_TH)
+    assert status == 1

@@ -39,6 +39,15 @@ class bigc_outputs(ctypes.Structure):
         "quint", "scores", "dura", "qid", "n_out")]
 
 
+class grd_config(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in ("dim_feat", "dim_clsme", "dim_hidden", "num_bins", "n_enti_emb", "n_pred_emb")]
+
+
+class grd_outputs(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("pooled_se", "bins_probs", "bins_mask", "status", "regrs", "conf", "cls",
+                                        "video_enc", "query_enc", "combined_enc")]
+
+
 _SIGS = {
     "bigc_last_error": (c_char_p, []),
     "bigc_build_info": (c_char_p, []),
@@ -75,6 +84,18 @@ _SIGS = {
     "bigc_workspace_bytes": (c_size_t, [c_void_p, POINTER(bigc_batch)]),
     "bigc_forward": (c_int, [c_void_p, c_void_p, POINTER(bigc_batch), c_void_p, c_size_t, c_int,
                              POINTER(bigc_outputs)]),
+    # grounding scorer
+    "bigc_dwconv_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    "grd_coattention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "grd_postprocess": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "grd_create": (c_int, [POINTER(grd_config), POINTER(c_void_p)]),
+    "grd_destroy": (None, [c_void_p]),
+    "grd_set_param": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    "grd_finalize": (c_int, [c_void_p, c_void_p]),
+    "grd_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "grd_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
+                            c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_size_t, POINTER(grd_outputs)]),
 }
 
 # grounding entry points are appended by bigc_hip._lib_grd when that part of the library exists

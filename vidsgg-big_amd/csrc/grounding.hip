@@ -1,0 +1,582 @@
+// Temporal grounding scorer on the HIP path: eval forward of the reference's ``DEBUG`` model
+// (models/grd_model_v5.py:196-221,310-373,530-576,667-737) for one video.
+//
+// Kernels specific to this stage (the dense layers reuse linear_f32 / mha_core / layernorm / add_rows):
+//   dwconv            depth-wise temporal conv (k=7 / k=3) on (sequence, time, channel) rows   -- HBM-bound
+//   query_input       embedding gather [subject, predicate, object] + normalised overlap span  -- gather
+//   coattention       video<->query similarity, row/column softmax, A and B, 4d feature fusion -- per query in LDS
+//   postprocess       sigmoid scores, per-(query,bin) temporal pooling, overlap clipping, 1-D NMS, masks
+//                     (replaces the reference's two Python loops, :711-733 and :688-692)
+//
+// Layout: every activation is (rows, d) row-major with rows = sequence-major time (n*T for the combined
+// encoder, 3n for the query encoder, T for the video encoder); the reference's (N, d, T) tensors are
+// the transposes, so Conv1d(k=1) is a plain linear and LayerNorm needs no transposes.
+#include "common.h"
+#include "prof.h"
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+int bigc_fill_offsets(hipStream_t s, int32_t* p, int n, int step);
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                     float* __restrict__ y, long total4, int T, int d4, int ks) {
+    const int half = ks / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long row = i / d4;
+        const int c4 = (int)(i - row * d4);
+        const int t = (int)(row % T);
+        f32x4 acc = ((const f32x4*)b)[c4];
+        const float* wp = w + (size_t)c4 * 4 * ks;
+        for (int j = 0; j < ks; ++j) {
+            const int tt = t + j - half;
+            if (tt < 0 || tt >= T) continue;
+            const f32x4 xv = ((const f32x4*)x)[(row + (j - half)) * d4 + c4];
+            acc[0] += wp[j] * xv[0];
+            acc[1] += wp[ks + j] * xv[1];
+            acc[2] += wp[2 * ks + j] * xv[2];
+            acc[3] += wp[3 * ks + j] * xv[3];
+        }
+        ((f32x4*)y)[i] = acc;
+    }
+}
+
+// rows (3n, kq): [emb(300) | s/len | e/len | 0 0]; word order [subject, predicate, object] (:323)
+__global__ __launch_bounds__(256) void query_input_kernel(const float* __restrict__ enti, const float* __restrict__ pred,
+                                                          const int32_t* __restrict__ quint, const int32_t* __restrict__ dura,
+                                                          float video_len, float* __restrict__ out, int n, int de, int kq) {
+    const long total = (long)3 * n * kq;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / kq;
+        const int c = (int)(i - row * kq);
+        const int q = (int)(row / 3), l = (int)(row - 3 * (long)q);
+        float v = 0.f;
+        if (c < de) {
+            const int id = quint[q * 5 + (l == 0 ? 1 : (l == 1 ? 0 : 2))];
+            v = (l == 1 ? pred : enti)[(size_t)id * de + c];
+        } else if (c < de + 2) {
+            v = (float)dura[q * 2 + (c - de)] / video_len;       // uniq_dura_inters.float() / video_len (:324)
+        }
+        out[i] = v;
+    }
+}
+
+// Wq (d, kq) = [query_fc.weight | temp_fc.weight | 0 0], bq = query_fc.bias + temp_fc.bias
+__global__ void build_query_weight_kernel(const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wt,
+                                          const float* __restrict__ bt, float* __restrict__ w_out, float* __restrict__ b_out,
+                                          int d, int de, int kq) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d * kq) {
+        const int r = i / kq, c = i - r * kq;
+        w_out[i] = c < de ? wq[r * de + c] : (c < de + 2 ? wt[r * 2 + (c - de)] : 0.f);
+    }
+    if (i < d) b_out[i] = bq[i] + bt[i];
+}
+
+// info (n,2) = dura / video_len
+__global__ void span_info_kernel(const int32_t* __restrict__ dura, float video_len, float* __restrict__ info, int n2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n2) info[i] = (float)dura[i] / video_len;
+}
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float u = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, u) : v + u;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+// reference: models/grd_model_v5.py:346-365
+__global__ __launch_bounds__(256) void coattention_kernel(const float* __restrict__ video, const float* __restrict__ proj,
+                                                          const float* __restrict__ query, float* __restrict__ out, int T, int d) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* q = lds;                 // 3*d
+    float* s2 = q + 3 * d;          // 3*d
+    float* sim_r = s2 + 3 * d;      // 3*T
+    float* sim_c = sim_r + 3 * T;   // 3*T (raw scores first)
+    float* red = sim_c + 3 * T;     // 4
+    const int i = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < 3 * d; c += 256) q[c] = query[(size_t)i * 3 * d + c];
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) {
+        const f32x4* pr = (const f32x4*)(proj + (size_t)t * d);
+        float s[3] = {0.f, 0.f, 0.f};
+        for (int c4 = 0; c4 < d / 4; ++c4) {
+            const f32x4 p = pr[c4];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const f32x4 qq = *(const f32x4*)(q + l * d + c4 * 4);
+                s[l] += p[0] * qq[0] + p[1] * qq[1] + p[2] * qq[2] + p[3] * qq[3];
+            }
+        }
+        const float m = fmaxf(s[0], fmaxf(s[1], s[2]));
+        const float e0 = expf(s[0] - m), e1 = expf(s[1] - m), e2 = expf(s[2] - m);
+        const float sum = e0 + e1 + e2;
+        sim_r[t] = e0 / sum; sim_r[T + t] = e1 / sum; sim_r[2 * T + t] = e2 / sum;
+        sim_c[t] = s[0]; sim_c[T + t] = s[1]; sim_c[2 * T + t] = s[2];
+    }
+    __syncthreads();
+    for (int l = 0; l < 3; ++l) {
+        float m = -INFINITY;
+        for (int t = tid; t < T; t += 256) m = fmaxf(m, sim_c[l * T + t]);
+        m = block_reduce(m, true, red);
+        float sum = 0.f;
+        for (int t = tid; t < T; t += 256) {
+            const float e = expf(sim_c[l * T + t] - m);
+            sim_c[l * T + t] = e;
+            sum += e;
+        }
+        sum = block_reduce(sum, false, red);
+        for (int t = tid; t < T; t += 256) sim_c[l * T + t] /= sum;
+    }
+    __syncthreads();
+    for (int e = tid; e < 3 * d; e += 256) {            // S2 = sim_c^T @ video  (3, d)
+        const int l = e / d, c = e - l * d;
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) acc += sim_c[l * T + t] * video[(size_t)t * d + c];
+        s2[e] = acc;
+    }
+    __syncthreads();
+    float* ob = out + (size_t)i * T * 4 * d;
+    for (int e = tid; e < T * d; e += 256) {
+        const int t = e / d, c = e - t * d;
+        const float v = video[e];
+        const float r0 = sim_r[t], r1 = sim_r[T + t], r2 = sim_r[2 * T + t];
+        const float a = r0 * q[c] + r1 * q[d + c] + r2 * q[2 * d + c];
+        const float b = r0 * s2[c] + r1 * s2[d + c] + r2 * s2[2 * d + c];
+        float* o = ob + (size_t)t * 4 * d + c;
+        o[0] = v; o[d] = a; o[2 * d] = a * v; o[3 * d] = b * v;
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// reference: models/grd_model_v5.py:533-572, 697-737, 667-695; tIoU utils/utils_func.py:375-390
+__global__ __launch_bounds__(64) void postprocess_kernel(const float* __restrict__ regrs, const float* __restrict__ conf,
+                                                         const float* __restrict__ cls, const float* __restrict__ clip,
+                                                         const float* __restrict__ info, int T, int k, float score_th, float tiou_th,
+                                                         float bins_th, float nms_th, float* __restrict__ pooled_se,
+                                                         float* __restrict__ bins_probs, uint8_t* __restrict__ bins_mask,
+                                                         int32_t* __restrict__ status) {
+    __shared__ float sp_s[17], sp_e[17], prob[17];
+    __shared__ int ovl[17];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const float is = info[2 * i], ie = info[2 * i + 1];
+    const float* cf = conf + (size_t)i * T * k;
+    const float* cl = cls + (size_t)i * T * k;
+    const float* rg = regrs + (size_t)i * T * 2 * k;
+    for (int b = 0; b < k; ++b) {
+        float bv = -INFINITY;
+        int bt = 0x7fffffff;
+        for (int t = lane; t < T; t += 64) {
+            const float sc = sigmoidf_(cf[t * k + b]) * sigmoidf_(cl[t * k + b]);
+            if (sc > bv || (sc == bv && t < bt)) { bv = sc; bt = t; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int ot = __shfl_xor(bt, o);
+            if (ov > bv || (ov == bv && ot < bt)) { bv = ov; bt = ot; }
+        }
+        const float ts = clip[bt] - rg[bt * 2 * k + b], te = clip[bt] + rg[bt * 2 * k + k + b];
+        const float thr = score_th * bv;
+        float ps = INFINITY, pe = -INFINITY;
+        for (int t = lane; t < T; t += 64) {
+            const float sc = sigmoidf_(cf[t * k + b]) * sigmoidf_(cl[t * k + b]);
+            const float st = clip[t] - rg[t * 2 * k + b], en = clip[t] + rg[t * 2 * k + k + b];
+            const float g = (fminf(te, en) - fmaxf(ts, st)) / (fmaxf(te, en) - fminf(ts, st));
+            if (sc > thr && g > tiou_th) { ps = fminf(ps, st); pe = fmaxf(pe, en); }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            ps = fminf(ps, __shfl_xor(ps, o));
+            pe = fmaxf(pe, __shfl_xor(pe, o));
+        }
+        if (lane == 0) {
+            if (ps == INFINITY) { status[0] = 1; ps = ts; pe = te; }
+            const float s = fmaxf(is, ps), e = fminf(ie, pe);
+            const bool ov = s <= e;
+            sp_s[b] = ov ? s : is; sp_e[b] = ov ? e : ie; ovl[b] = ov; prob[b] = bv;
+        }
+    }
+    if (lane == 0) {
+        sp_s[k] = is; sp_e[k] = ie; ovl[k] = 1; prob[k] = 1.0f;
+        const int nb = k + 1;
+        int order[17];
+        for (int a = 0; a < nb; ++a) {                 // stable ascending insertion sort by probability
+            int j = a;
+            while (j > 0 && prob[order[j - 1]] > prob[a]) { order[j] = order[j - 1]; --j; }
+            order[j] = a;
+        }
+        bool alive[17], keep[17];
+        for (int a = 0; a < nb; ++a) { alive[a] = true; keep[a] = false; }
+        for (int pos = nb - 1; pos >= 0; --pos) {
+            const int a = order[pos];
+            if (!alive[a]) continue;
+            keep[a] = true;
+            for (int p2 = pos - 1; p2 >= 0; --p2) {
+                const int c = order[p2];
+                if (!alive[c]) continue;
+                const bool ok = (sp_e[a] >= sp_s[c]) && (sp_e[c] >= sp_s[a]);
+                float t = (fminf(sp_e[a], sp_e[c]) - fmaxf(sp_s[a], sp_s[c])) / (fmaxf(sp_e[a], sp_e[c]) - fminf(sp_s[a], sp_s[c]));
+                if (!ok) t = 0.f;
+                alive[c] = t < nms_th;
+            }
+        }
+        bool any = false, m[17];
+        for (int a = 0; a < nb; ++a) { m[a] = (prob[a] > bins_th) && ovl[a] && keep[a]; any = any || m[a]; }
+        if (!any) {
+            int best = 0;
+            for (int a = 1; a < nb; ++a) if (prob[a] > prob[best]) best = a;
+            m[best] = true;
+        }
+        float mx = -INFINITY;
+        for (int a = 0; a < k; ++a) mx = fmaxf(mx, prob[a]);
+        const float last = (mx <= bins_th) ? 0.0f : prob[k];
+        for (int a = 0; a < nb; ++a) {
+            pooled_se[((size_t)i * nb + a) * 2] = sp_s[a];
+            pooled_se[((size_t)i * nb + a) * 2 + 1] = sp_e[a];
+            bins_probs[(size_t)i * nb + a] = (a == k) ? last : prob[a];
+            bins_mask[(size_t)i * nb + a] = m[a] ? 1 : 0;
+        }
+    }
+}
+
+int grid_for(long n, int cap = 4096) { long g = (n + 255) / 256; return (int)(g < cap ? (g < 1 ? 1 : g) : cap); }
+
+}  // namespace
+
+extern "C" int bigc_dwconv_f32(void* stream, const float* x, const float* w, const float* b, float* y, int n_seq, int T, int d, int ks) {
+    BIGC_CHECK_ARG(x && w && b && y, "dwconv: null pointer");
+    BIGC_CHECK_ARG(d % 4 == 0 && ks % 2 == 1 && ks <= 7 && T > 0, "dwconv: d=%d ks=%d T=%d", d, ks, T);
+    if (n_seq <= 0) return BIGC_OK;
+    const long total4 = (long)n_seq * T * (d / 4);
+    ProfScope ps(stream, FAM_GROUNDING, 0.0, 8.0 * n_seq * (double)T * d);
+    hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, total4, T, d / 4, ks);
+    BIGC_LAUNCH_CHECK("dwconv");
+    return BIGC_OK;
+}
+
+extern "C" int grd_coattention_f32(void* stream, const float* video, const float* proj, const float* query, float* out, int n, int T, int d) {
+    BIGC_CHECK_ARG(video && proj && query && out, "coattention: null pointer");
+    BIGC_CHECK_ARG(T > 0 && T <= 2048 && d % 4 == 0 && d <= 256, "coattention: T=%d (<=2048) d=%d (<=256)", T, d);
+    if (n <= 0) return BIGC_OK;
+    const size_t lds = sizeof(float) * (6 * (size_t)d + 6 * (size_t)T + 4);
+    ProfScope ps(stream, FAM_GROUNDING, 0.0, 16.0 * n * (double)T * d);
+    hipLaunchKernelGGL(coattention_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, video, proj, query, out, T, d);
+    BIGC_LAUNCH_CHECK("coattention");
+    return BIGC_OK;
+}
+
+extern "C" int grd_postprocess(void* stream, const float* regrs, const float* conf, const float* cls, const float* clip, const float* info,
+                               int n, int T, int k, float score_th, float tiou_th, float bins_th, float nms_th,
+                               float* pooled_se, float* bins_probs, uint8_t* bins_mask, int32_t* status) {
+    BIGC_CHECK_ARG(regrs && conf && cls && clip && info && pooled_se && bins_probs && bins_mask && status, "postprocess: null pointer");
+    BIGC_CHECK_ARG(k >= 1 && k <= 16 && T > 0, "postprocess: num_bins=%d must be in [1,16]", k);
+    hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), (hipStream_t)stream);
+    if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "postprocess: memset: %s", hipGetErrorString(e));
+    if (n <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_GROUNDING, 0.0, 0.0);
+    hipLaunchKernelGGL(postprocess_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, regrs, conf, cls, clip, info, T, k, score_th, tiou_th,
+                       bins_th, nms_th, pooled_se, bins_probs, bins_mask, status);
+    BIGC_LAUNCH_CHECK("postprocess");
+    return BIGC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model-level
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Lin { const float* w = nullptr; const float* b = nullptr; };
+struct DW { const float *dw_w = nullptr, *dw_b = nullptr; Lin pw; };
+struct Enc { DW conv[4]; Lin in_proj, out_proj, fc; Lin normb, norm_seq[4], norme; int ks = 7; };
+struct Head { DW layer[5]; int c_out = 0; };
+}  // namespace
+
+struct grd_model {
+    grd_config cfg;
+    std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
+    bool finalized = false;
+    const float *enti = nullptr, *pred = nullptr;
+    Lin video_fc, vq_fc, proj2sim;
+    Enc video_enc, query_enc, comb_enc;
+    Head cls_head, conf_head, regr_head;
+    float* wq = nullptr;   // (d, kq) owned
+    float* bq = nullptr;   // (d) owned
+    int kq = 0;
+};
+
+namespace {
+
+struct GResolver {
+    grd_model* m;
+    int err = 0;
+    const float* get(const std::string& key, int64_t numel) {
+        auto it = m->params.find(key);
+        if (it == m->params.end()) {
+            if (!err) err = bigc_fail(BIGC_ERR_MISSING, "parameter '%s' was never set", key.c_str());
+            return nullptr;
+        }
+        if (it->second.second != numel) {
+            if (!err) err = bigc_fail(BIGC_ERR_ARG, "parameter '%s' has %lld elements, expected %lld", key.c_str(),
+                                      (long long)it->second.second, (long long)numel);
+            return nullptr;
+        }
+        return it->second.first;
+    }
+    Lin lin(const std::string& p, int n_out, int n_in, bool bias = true) {
+        Lin l;
+        l.w = get(p + ".weight", (int64_t)n_out * n_in);
+        if (bias) l.b = get(p + ".bias", n_out);
+        return l;
+    }
+    Lin ln(const std::string& p, int d) {
+        Lin l;
+        l.w = get(p + ".weight", d);
+        l.b = get(p + ".bias", d);
+        return l;
+    }
+    DW dws(const std::string& p, int d, int c_out, int ks) {
+        DW x;
+        x.dw_w = get(p + ".depth_wise.weight", (int64_t)d * ks);
+        x.dw_b = get(p + ".depth_wise.bias", d);
+        x.pw = lin(p + ".point_wise", c_out, d);
+        return x;
+    }
+    Enc enc(const std::string& p, int d, int ks) {
+        Enc e;
+        e.ks = ks;
+        for (int i = 0; i < 4; ++i) e.conv[i] = dws(p + ".convs." + std::to_string(i), d, d, ks);
+        e.in_proj.w = get(p + ".mh_attn.in_proj_weight", (int64_t)3 * d * d);
+        e.in_proj.b = get(p + ".mh_attn.in_proj_bias", 3 * d);
+        e.out_proj = lin(p + ".mh_attn.out_proj", d, d);
+        e.fc = lin(p + ".fc", d, d);
+        e.normb = ln(p + ".normb", d);
+        for (int i = 0; i < 4; ++i) e.norm_seq[i] = ln(p + ".norm_seq." + std::to_string(i), d);
+        e.norme = ln(p + ".norme", d);
+        return e;
+    }
+    Head head(const std::string& p, int d, int c_out) {
+        Head h;
+        h.c_out = c_out;
+        for (int i = 0; i < 4; ++i) h.layer[i] = dws(p + "." + std::to_string(i) + ".0", d, d, 3);
+        h.layer[4] = dws(p + ".4", d, c_out, 3);
+        return h;
+    }
+};
+
+struct GArena {
+    char* base; size_t cap; size_t off = 0; bool overflow = false;
+    template <typename T> T* take(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        if (off + bytes > cap) { overflow = true; return nullptr; }
+        T* p = (T*)(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+struct GWork {
+    float *b0, *b1, *b2, *b3, *qkv, *att, *venc, *qenc, *proj, *qin, *comb, *regrs, *conf, *cls, *info;
+    int32_t* off;
+};
+
+bool glayout(const grd_model* m, int T, int n, GArena& a, GWork& w) {
+    const size_t d = m->cfg.dim_hidden, k = m->cfg.num_bins;
+    size_t rows = (size_t)n * T;
+    if (rows < (size_t)3 * n) rows = (size_t)3 * n;
+    if (rows < (size_t)T) rows = T;
+    w.b0 = a.take<float>(rows * d); w.b1 = a.take<float>(rows * d); w.b2 = a.take<float>(rows * d); w.b3 = a.take<float>(rows * d);
+    w.qkv = a.take<float>(rows * 3 * d);
+    w.att = a.take<float>(rows * d);
+    w.venc = a.take<float>((size_t)T * d);
+    w.qenc = a.take<float>((size_t)3 * n * d);
+    w.proj = a.take<float>((size_t)T * d);
+    w.qin = a.take<float>((size_t)3 * n * m->kq);
+    w.comb = a.take<float>((size_t)n * T * 4 * d);
+    w.regrs = a.take<float>((size_t)n * T * 2 * k);
+    w.conf = a.take<float>((size_t)n * T * k);
+    w.cls = a.take<float>((size_t)n * T * k);
+    w.info = a.take<float>((size_t)2 * n);
+    w.off = a.take<int32_t>(rows + 2);
+    return !a.overflow;
+}
+
+#define GTRY(expr) do { int rc_ = (expr); if (rc_ != BIGC_OK) return rc_; } while (0)
+
+inline int glinear(void* s, const float* A, int lda, const Lin& l, float* C, int ldc, int M, int N, int K, int act,
+                   const float* res = nullptr, int ldr = 0) {
+    return bigc_linear_f32(s, A, lda, nullptr, 1, K, l.w, K, l.b, res, ldr, C, ldc, M, N, K, act);
+}
+
+// QANetEncoderLayer.forward, eval mode (models/grd_model_v5.py:110-137). x (n_seq*T, d) -> out (same shape).
+// Uses w.b0..b3, w.qkv, w.att, w.off; `out` may be one of the caller's buffers but not b0..b3.
+int qanet(void* s, const Enc& E, const float* x, const float* pos, int n_seq, int T, int d, const GWork& w, float* out) {
+    const int rows = n_seq * T;
+    float *res = w.b0, *ln = w.b1, *dw = w.b2, *nxt = w.b3;
+    GTRY(bigc_add_rows_f32(s, x, pos, res, rows, d, T));                       // out = x + pos ; res = out
+    GTRY(bigc_layernorm_f32(s, res, E.normb.w, E.normb.b, ln, rows, d, 1e-5f));
+    for (int i = 0; i < 4; ++i) {
+        GTRY(bigc_dwconv_f32(s, ln, E.conv[i].dw_w, E.conv[i].dw_b, dw, n_seq, T, d, E.ks));
+        GTRY(glinear(s, dw, d, E.conv[i].pw, nxt, d, rows, d, d, BIGC_ACT_RELU, res, d));   // relu(conv) + res
+        float* t = res; res = nxt; nxt = t;
+        GTRY(bigc_layernorm_f32(s, res, E.norm_seq[i].w, E.norm_seq[i].b, ln, rows, d, 1e-5f));
+    }
+    GTRY(glinear(s, ln, d, E.in_proj, w.qkv, 3 * d, rows, 3 * d, d, BIGC_ACT_NONE));
+    GTRY(bigc_fill_offsets((hipStream_t)s, w.off, n_seq + 1, T));
+    GTRY(bigc_mha_core_f32(s, w.qkv, 3 * d, w.qkv + d, 3 * d, w.qkv + 2 * d, 3 * d, w.att, d, w.off, w.off, n_seq, T, 8, d / 8));
+    GTRY(glinear(s, w.att, d, E.out_proj, nxt, d, rows, d, d, BIGC_ACT_NONE, res, d));        // attn + res
+    res = nxt;
+    GTRY(bigc_layernorm_f32(s, res, E.norme.w, E.norme.b, ln, rows, d, 1e-5f));
+    GTRY(glinear(s, ln, d, E.fc, out, d, rows, d, d, BIGC_ACT_RELU, res, d));                 // relu(fc) + res
+    return BIGC_OK;
+}
+
+// 4 x (DWsep k3 + ReLU) + DWsep -> c_out   (models/grd_model_v5.py:182-193)
+int run_head(void* s, const Head& H, const float* x, int n_seq, int T, int d, const GWork& w, float* out, int act) {
+    const int rows = n_seq * T;
+    const float* cur = x;
+    float* pp[2] = {w.b0, w.b1};
+    for (int i = 0; i < 4; ++i) {
+        GTRY(bigc_dwconv_f32(s, cur, H.layer[i].dw_w, H.layer[i].dw_b, w.b2, n_seq, T, d, 3));
+        GTRY(glinear(s, w.b2, d, H.layer[i].pw, pp[i & 1], d, rows, d, d, BIGC_ACT_RELU));
+        cur = pp[i & 1];
+    }
+    GTRY(bigc_dwconv_f32(s, cur, H.layer[4].dw_w, H.layer[4].dw_b, w.b2, n_seq, T, d, 3));
+    GTRY(glinear(s, w.b2, d, H.layer[4].pw, out, H.c_out, rows, H.c_out, d, act));
+    return BIGC_OK;
+}
+
+}  // namespace
+
+extern "C" int grd_create(const grd_config* cfg, grd_model** out) {
+    BIGC_CHECK_ARG(cfg && out, "grd_create: null pointer");
+    const int hd = cfg->dim_hidden / 8;
+    BIGC_CHECK_ARG(cfg->dim_hidden % 8 == 0 && (hd == 8 || hd == 16 || hd == 32 || hd == 64), "grd_create: dim_hidden=%d (8 heads of 8/16/32/64)", cfg->dim_hidden);
+    BIGC_CHECK_ARG(cfg->dim_feat % 4 == 0 && cfg->dim_clsme % 4 == 0 && cfg->num_bins >= 1 && cfg->num_bins <= 16, "grd_create: bad dims");
+    grd_model* m = new grd_model();
+    m->cfg = *cfg;
+    m->kq = cfg->dim_clsme + 4;
+    *out = m;
+    return BIGC_OK;
+}
+
+extern "C" void grd_destroy(grd_model* m) {
+    if (!m) return;
+    if (m->wq) (void)hipFree(m->wq);
+    if (m->bq) (void)hipFree(m->bq);
+    delete m;
+}
+
+extern "C" int grd_set_param(grd_model* m, const char* key, const float* ptr, int64_t numel) {
+    BIGC_CHECK_ARG(m && key && ptr && numel > 0, "grd_set_param: bad argument");
+    BIGC_CHECK_ARG(((uintptr_t)ptr & 15) == 0, "grd_set_param: '%s' is not 16-byte aligned", key);
+    m->params[key] = std::make_pair(ptr, numel);
+    m->finalized = false;
+    return BIGC_OK;
+}
+
+extern "C" int grd_finalize(grd_model* m, void* stream) {
+    BIGC_CHECK_ARG(m, "grd_finalize: null model");
+    const grd_config& c = m->cfg;
+    const int d = c.dim_hidden, k = c.num_bins;
+    GResolver r{m};
+    m->enti = r.get("EntiNameEmb", (int64_t)c.n_enti_emb * c.dim_clsme);
+    m->pred = r.get("PredNameEmb", (int64_t)c.n_pred_emb * c.dim_clsme);
+    m->video_fc = r.lin("video_fc", d, c.dim_feat);
+    Lin qfc = r.lin("query_fc", d, c.dim_clsme);
+    Lin tfc = r.lin("temp_fc", d, 2);
+    m->vq_fc = r.lin("vq_fc", d, 4 * d);
+    m->proj2sim = r.lin("proj2sim", d, d, false);
+    m->video_enc = r.enc("video_encoder", d, 7);
+    m->query_enc = r.enc("query_encoder", d, 3);
+    m->comb_enc = r.enc("combined_encoder", d, 7);
+    m->cls_head = r.head("cls_head", d, k);
+    m->conf_head = r.head("conf_head", d, k);
+    m->regr_head = r.head("regr_head", d, 2 * k);
+    if (r.err) return r.err;
+    if (!m->wq) {
+        if (hipMalloc((void**)&m->wq, sizeof(float) * (size_t)d * m->kq) != hipSuccess || hipMalloc((void**)&m->bq, sizeof(float) * d) != hipSuccess)
+            return bigc_fail(BIGC_ERR_HIP, "grd_finalize: hipMalloc failed");
+    }
+    hipLaunchKernelGGL(build_query_weight_kernel, dim3(cdiv(d * m->kq, 256)), dim3(256), 0, (hipStream_t)stream, qfc.w, qfc.b, tfc.w, tfc.b,
+                       m->wq, m->bq, d, c.dim_clsme, m->kq);
+    BIGC_LAUNCH_CHECK("build_query_weight");
+    m->finalized = true;
+    return BIGC_OK;
+}
+
+extern "C" size_t grd_workspace_bytes(const grd_model* m, int T, int n) {
+    if (!m || T <= 0 || n <= 0) return 0;
+    GArena a{nullptr, (size_t)-1};
+    GWork w;
+    glayout(m, T, n, a, w);
+    return a.off + 256;
+}
+
+extern "C" int grd_forward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, const int32_t* dura, int n,
+                           float video_len, const float* pos_video, const float* pos_query, const float* clip,
+                           float score_th, float tiou_th, float bins_th, float nms_th,
+                           void* workspace, size_t workspace_bytes, const grd_outputs* out) {
+    BIGC_CHECK_ARG(m && video_feat && quint && dura && pos_video && pos_query && clip && out, "grd_forward: null pointer");
+    BIGC_CHECK_ARG(m->finalized, "grd_forward: call grd_finalize after setting the parameters");
+    BIGC_CHECK_ARG(T > 0 && n > 0 && video_len > 0, "grd_forward: T=%d n=%d video_len=%f", T, n, video_len);
+    BIGC_CHECK_ARG(out->pooled_se && out->bins_probs && out->bins_mask && out->status, "grd_forward: required outputs missing");
+    const grd_config& c = m->cfg;
+    const int d = c.dim_hidden, k = c.num_bins;
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (!workspace || workspace_bytes < (size_t)(base - (char*)workspace)) return bigc_fail(BIGC_ERR_WORKSPACE, "grd_forward: no workspace");
+    GArena a{base, workspace_bytes - (size_t)(base - (char*)workspace)};
+    GWork w;
+    if (!glayout(m, T, n, a, w)) return bigc_fail(BIGC_ERR_WORKSPACE, "grd_forward: workspace of %zu bytes too small, need %zu",
+                                                  workspace_bytes, grd_workspace_bytes(m, T, n));
+    void* s = stream;
+    hipStream_t hs = (hipStream_t)stream;
+
+    // a12: prepare_data (:310-328) fused with query_fc + temp_fc (:337-339)
+    hipLaunchKernelGGL(query_input_kernel, dim3(grid_for((long)3 * n * m->kq)), dim3(256), 0, hs, m->enti, m->pred, quint, dura, video_len,
+                       w.qin, n, c.dim_clsme, m->kq);
+    BIGC_LAUNCH_CHECK("query_input");
+    hipLaunchKernelGGL(span_info_kernel, dim3(cdiv(2 * n, 256)), dim3(256), 0, hs, dura, video_len, w.info, 2 * n);
+    BIGC_LAUNCH_CHECK("span_info");
+    Lin qlin{m->wq, m->bq};
+    float* qemb = w.comb;                         // (3n, d) scratch, comb is free until the co-attention
+    GTRY(glinear(s, w.qin, m->kq, qlin, qemb, d, 3 * n, d, m->kq, BIGC_ACT_NONE));
+    float* vemb = w.comb + (size_t)3 * n * d;     // (T, d)
+    GTRY(glinear(s, video_feat, c.dim_feat, m->video_fc, vemb, d, T, d, c.dim_feat, BIGC_ACT_NONE));
+
+    // a13: the two encoders, co-attention, fusion, combined encoder, three heads (:341-372)
+    float* venc = out->video_enc ? out->video_enc : w.venc;
+    float* qenc = out->query_enc ? out->query_enc : w.qenc;
+    GTRY(qanet(s, m->video_enc, vemb, pos_video, 1, T, d, w, venc));
+    GTRY(qanet(s, m->query_enc, qemb, pos_query, n, 3, d, w, qenc));
+    GTRY(glinear(s, venc, d, m->proj2sim, w.proj, d, T, d, d, BIGC_ACT_NONE));
+    GTRY(grd_coattention_f32(s, venc, w.proj, qenc, w.comb, n, T, d));
+    float* cin = w.att;                           // (n*T, d) free between qanet calls
+    GTRY(glinear(s, w.comb, 4 * d, m->vq_fc, cin, d, n * T, d, 4 * d, BIGC_ACT_NONE));
+    float* cenc = out->combined_enc ? out->combined_enc : w.comb;     // comb (n*T*4d) is free again
+    // qanet reads its input into b0 first, and w.att is only rewritten by the attention step, after
+    // the input has been consumed
+    GTRY(qanet(s, m->comb_enc, cin, pos_video, n, T, d, w, cenc));
+    float* regrs = out->regrs ? out->regrs : w.regrs;
+    float* conf = out->conf ? out->conf : w.conf;
+    float* cls = out->cls ? out->cls : w.cls;
+    GTRY(run_head(s, m->regr_head, cenc, n, T, d, w, regrs, BIGC_ACT_SIGMOID));
+    GTRY(run_head(s, m->conf_head, cenc, n, T, d, w, conf, BIGC_ACT_NONE));
+    GTRY(run_head(s, m->cls_head, cenc, n, T, d, w, cls, BIGC_ACT_NONE));
+
+    // a14-a16: pooling, clipping, NMS, masks (:533-572)
+    GTRY(grd_postprocess(s, regrs, conf, cls, clip, w.info, n, T, k, score_th, tiou_th, bins_th, nms_th, out->pooled_se, out->bins_probs,
+                         out->bins_mask, out->status));
+    return BIGC_OK;
+}

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void linear_f32_kernel(const LinearArgs p) 
         colv[ni] = n0 + wn * 64 + ni * 32 + l31;
         bv[ni] = p.bias ? p.bias[min(colv[ni], p.N - 1)] : 0.f;
     }
-    const bool relu = p.act == BIGC_ACT_RELU;
+    const bool relu = p.act == BIGC_ACT_RELU, sigm = p.act == BIGC_ACT_SIGMOID;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int rbase = m0 + wm * 64 + mi * 32;
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void linear_f32_kernel(const LinearArgs p) 
                 const int row = rbase + mfma_row(r, hi);
                 float v = acc[mi][ni][r] + bv[ni];
                 if (relu) v = fmaxf(v, 0.f);
+                if (sigm) v = 1.0f / (1.0f + expf(-v));
                 v += rv[ni][r];
                 if (row < p.M) cp[(size_t)row * p.ldc] = v;
             }

@@ -156,9 +156,17 @@ def main():
     if "linear_f32" in families:
         lin = families["linear_f32"]
         achieved = lin["flops"] / (lin["ms"] * 1e-3) / 1e12
+        # HBM bytes per launch cannot be sampled from inside this process: they come from the committed
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/pmc_traffic.json,
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if the workload differs
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path) and args.videos == 256 and args.n_trajs == 64:
+            traffic = round(json.load(open(pmc_path))["hbm_bytes_per_launch"])
         roofline = dict(bound="mfma", kernel="linear_f32_kernel (f32 MFMA 32x32x2)", achieved=round(achieved, 2),
                         peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                        traffic=None, launches_per_step=lin["launches"] // args.steps,
+                        traffic=traffic, algorithmic_bytes_per_launch=round(lin["bytes"] / lin["launches"]),
+                        launches_per_step=lin["launches"] // args.steps,
                         avg_launch_us=round(1e3 * lin["ms"] / lin["launches"], 2),
                         gflop_per_step=round(lin["flops"] / args.steps / 1e9, 1),
                         share_of_step=round(lin["ms"] / args.steps / ms_per_step, 3))

@@ -16,10 +16,11 @@
 // Roofline: f32 MFMA 157.3 TFLOP/s; 2*M*N*K flops per launch.
 #include "common.h"
 #include "prof.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, PITCH = 36;
+constexpr int BM = 128, BK = 32, PITCH = 36;
 
 struct LinearArgs {
     const float* A; int lda; const int32_t* a_idx; int nseg; int seg_len;
@@ -27,9 +28,15 @@ struct LinearArgs {
     float* C; int ldc; int M, N, K; int act; int tiles_m, tiles_n;
 };
 
-template <bool GATHER>
-__global__ __launch_bounds__(256, 2) void linear_f32_kernel(const LinearArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2][2][BM * PITCH];
+// NT = number of 32-column MFMA tiles per wave: NT=2 -> 128x128 block tile, 2 workgroups per CU;
+// NT=4 -> 128x256 block tile (wave patch 64x128, 128 accumulator VGPRs), one workgroup per CU, i.e. one
+// wave per SIMD issuing 128 MFMAs between barriers (used when N >= 256: halves the barriers per flop
+// and the A re-reads).
+template <bool GATHER, int NT>
+__global__ __launch_bounds__(256, (NT == 4 ? 1 : 2)) void linear_f32_kernel(const LinearArgs p) {
+    constexpr int BNT = 64 * NT;                     // block tile width
+    constexpr int NB = BNT / 32;                     // float4 loads of W per thread per slab
+    __shared__ __attribute__((aligned(16))) float smem[2][(BM + BNT) * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
 
@@ -39,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void linear_f32_kernel(const LinearArgs p) 
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
     if (tm >= p.tiles_m) return;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BNT;
 
     const int lr = tid >> 3, lc = (tid & 7) * 4;
     int arow[4];
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void linear_f32_kernel(const LinearArgs p) 
         int m = m0 + lr + 32 * i;
         arow[i] = (m < p.M) ? m : -1;
     }
-    f32x4 ra[4], rb[4];
+    f32x4 ra[4], rb[NB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     int cur_seg = -1;
 
@@ -64,33 +71,32 @@ __global__ __launch_bounds__(256, 2) void linear_f32_kernel(const LinearArgs p) 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     int m = m0 + lr + 32 * i;
-                    arow[i] = (m < p.M) ? p.a_idx[(size_t)m * p.nseg + seg] : -1;
+                    arow[i] = p.a_idx[(size_t)min(m, p.M - 1) * p.nseg + seg];
+                    if (m >= p.M) arow[i] = -1;
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i)
             ra[i] = (arow[i] >= 0 && kval) ? *(const f32x4*)(p.A + (size_t)arow[i] * p.lda + acol) : zero4;
-        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NB; ++i) {
             int n = n0 + lr + 32 * i;
             rb[i] = (n < p.N && kval) ? *(const f32x4*)(p.W + (size_t)n * p.ldw + kc) : zero4;
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(f32x4*)(&smem[buf][0][(lr + 32 * i) * PITCH + lc]) = ra[i];
-            *(f32x4*)(&smem[buf][1][(lr + 32 * i) * PITCH + lc]) = rb[i];
-        }
+        for (int i = 0; i < 4; ++i) *(f32x4*)(&smem[buf][(lr + 32 * i) * PITCH + lc]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *(f32x4*)(&smem[buf][(BM + lr + 32 * i) * PITCH + lc]) = rb[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
@@ -100,67 +106,71 @@ __global__ __launch_bounds__(256, 2) void linear_f32_kernel(const LinearArgs p) 
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
-        const float* as = &smem[buf][0][(wm * 64 + l31) * PITCH + 4 * hi];
-        const float* bs = &smem[buf][1][(wn * 64 + l31) * PITCH + 4 * hi];
+        const bool more = kt + 1 < nk;
+        if (more) load_tiles(kt + 1);
+        const float* as = &smem[buf][(wm * 64 + l31) * PITCH + 4 * hi];
+        const float* bs = &smem[buf][(BM + wn * 32 * NT + l31) * PITCH + 4 * hi];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const f32x4 a0 = *(const f32x4*)(as + 8 * c);
-            const f32x4 a1 = *(const f32x4*)(as + 32 * PITCH + 8 * c);
-            const f32x4 b0 = *(const f32x4*)(bs + 8 * c);
-            const f32x4 b1 = *(const f32x4*)(bs + 32 * PITCH + 8 * c);
+            f32x4 af[2], bf[NT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[0][0] = mfma32(a0[q], b0[q], acc[0][0]);
-                acc[0][1] = mfma32(a0[q], b1[q], acc[0][1]);
-                acc[1][0] = mfma32(a1[q], b0[q], acc[1][0]);
-                acc[1][1] = mfma32(a1[q], b1[q], acc[1][1]);
-            }
+            for (int mi = 0; mi < 2; ++mi) af[mi] = *(const f32x4*)(as + mi * 32 * PITCH + 8 * c);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) bf[ni] = *(const f32x4*)(bs + ni * 32 * PITCH + 8 * c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma32(af[mi][q], bf[ni][q], acc[mi][ni]);
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        if (more) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
     // epilogue: lanes 0-31 of a register hold 32 consecutive columns of one row (128-byte stores)
-    // The residual reads use clamped (always valid) addresses so that all 32 loads of a 64x32 half
+    // The residual reads use clamped (always valid) addresses so that all loads of a 32-row slice
     // are issued back to back before the first use (guarded loads serialise: load, wait, add, store).
-    int colv[2];
-    float bv[2];
+    int colv[NT];
+    float bv[NT];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        colv[ni] = n0 + wn * 64 + ni * 32 + l31;
+    for (int ni = 0; ni < NT; ++ni) {
+        colv[ni] = n0 + wn * 32 * NT + ni * 32 + l31;
         bv[ni] = p.bias ? p.bias[min(colv[ni], p.N - 1)] : 0.f;
     }
     const bool relu = p.act == BIGC_ACT_RELU, sigm = p.act == BIGC_ACT_SIGMOID;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int rbase = m0 + wm * 64 + mi * 32;
-        f32x16 rv[2];
-        if (p.res) {
+#pragma unroll
+        for (int nh = 0; nh < NT; nh += 2) {
+            f32x16 rv[2];
+            if (p.res) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float* rp = p.res + min(colv[nh + ni], p.N - 1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[ni][r] = rp[(size_t)min(rbase + mfma_row(r, hi), p.M - 1) * p.ldr];
+                }
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[ni][r] = 0.f;
+            }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                const float* rp = p.res + min(colv[ni], p.N - 1);
+                if (colv[nh + ni] >= p.N) continue;
+                float* cp = p.C + colv[nh + ni];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rv[ni][r] = rp[(size_t)min(rbase + mfma_row(r, hi), p.M - 1) * p.ldr];
-            }
-        } else {
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rv[ni][r] = 0.f;
-        }
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            if (colv[ni] >= p.N) continue;
-            float* cp = p.C + colv[ni];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + mfma_row(r, hi);
-                float v = acc[mi][ni][r] + bv[ni];
-                if (relu) v = fmaxf(v, 0.f);
-                if (sigm) v = 1.0f / (1.0f + expf(-v));
-                v += rv[ni][r];
-                if (row < p.M) cp[(size_t)row * p.ldc] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + mfma_row(r, hi);
+                    float v = acc[mi][nh + ni][r] + bv[nh + ni];
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (sigm) v = 1.0f / (1.0f + expf(-v));
+                    v += rv[ni][r];
+                    if (row < p.M) cp[(size_t)row * p.ldc] = v;
+                }
             }
         }
     }
@@ -184,13 +194,22 @@ extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int3
     p.A = A; p.lda = lda; p.a_idx = a_idx; p.nseg = a_idx ? nseg : 1; p.seg_len = a_idx ? seg_len : K;
     p.W = W; p.ldw = ldw; p.bias = bias; p.res = residual; p.ldr = ldr; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K; p.act = act;
-    p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
-    const int grid = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
+    p.tiles_m = cdiv(M, BM); p.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(stream, FAM_LINEAR, 2.0 * M * (double)N * K,
                  4.0 * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)));
-    if (a_idx) hipLaunchKernelGGL(linear_f32_kernel<true>, dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(linear_f32_kernel<false>, dim3(grid), dim3(256), 0, s, p);
+    static const int force_nt = getenv("BIGC_LINEAR_NT") ? atoi(getenv("BIGC_LINEAR_NT")) : 0;
+    // measured on MI355X (benchmarks/linear_shapes.py): NT=2 119 TFLOP/s aggregate, NT=4 112 -> NT=2 by default
+    const int nt = (force_nt == 4) ? 4 : 2;
+    p.tiles_n = cdiv(N, 64 * nt);
+    const int grid = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
+    if (nt == 4) {
+        if (a_idx) hipLaunchKernelGGL((linear_f32_kernel<true, 4>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((linear_f32_kernel<false, 4>), dim3(grid), dim3(256), 0, s, p);
+    } else {
+        if (a_idx) hipLaunchKernelGGL((linear_f32_kernel<true, 2>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((linear_f32_kernel<false, 2>), dim3(grid), dim3(256), 0, s, p);
+    }
     BIGC_LAUNCH_CHECK("linear_f32");
     return BIGC_OK;
 }

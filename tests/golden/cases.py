@@ -128,6 +128,35 @@ def make_grd_case(name):
     return cfg, sd, [make_grd_inputs(cfg, v) for v in case["videos"]]
 
 
+# ---- BIG-C training step (models/model_0v10.py:510-704) -------------------------------------------
+TRAIN_CASES = {
+    # G6 tiny: a batch of two videos, gradients of EVERY parameter stored
+    "bigc_train_tiny": dict(cfg="CONFIG_TINY", variant="vidvrd", wseed=51, att_gain=3.0, full=True,
+                            videos=[dict(seed=701, n_trajs=9, len_range=(6, 25), start_range=(0, 8)),
+                                    dict(seed=702, n_trajs=6, len_range=(5, 12), start_range=(0, 4))],
+                            gts=[dict(seed=711, n_gt_trajs=5, n_preds=4), dict(seed=712, n_gt_trajs=4, n_preds=3)]),
+    "bigo_train_tiny": dict(cfg="CONFIG_TINY_O", variant="vidor", wseed=52, att_gain=3.0, full=True,
+                            videos=[dict(seed=703, n_trajs=8, len_range=(6, 25), start_range=(0, 8))],
+                            gts=[dict(seed=713, n_gt_trajs=5, n_preds=4)]),
+    # exp2 dims, one N=16 video: loss terms, matching, gradient norms of every parameter + a few full gradients
+    "bigc_train_v": dict(cfg="CONFIG_V", variant="vidvrd", wseed=53, att_gain=3.0, full=False,
+                         videos=[dict(seed=704, n_trajs=16)], gts=[dict(seed=714, n_gt_trajs=6, n_preds=5)]),
+}
+TRAIN_FULL_GRADS_V = ["fc_pred2logits.bias", "decoder_layers.5.norm3.weight", "decoder_layers.0.fc_pred2att.bias",
+                      "encoder_layers.0.norm1.weight", "conv_feat2enti.bias", "fc_bbox2enti.0.weight", "pos_embedding"]
+
+
+def make_train_case(name):
+    """-> (cfg, variant, state_dict, [proposals], [gt_graphs])"""
+    from bigc_hip.synthetic import synthetic_gt_graph
+    case = TRAIN_CASES[name]
+    cfg = get_cfg(case["cfg"])
+    sd = seeded_state_dict(bigc_state_shapes(cfg, case["variant"]), case["wseed"], case.get("att_gain", 1.0))
+    props = [make_proposal(cfg, case["variant"], v) for v in case["videos"]]
+    gts = [synthetic_gt_graph(p, num_pred_cats=cfg["num_pred_cats"], **g) for p, g in zip(props, case["gts"])]
+    return cfg, case["variant"], sd, props, gts
+
+
 def make_case(name):
     """-> (cfg, variant, state_dict, [proposals], topk)"""
     case = BIGC_CASES[name]

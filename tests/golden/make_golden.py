@@ -159,15 +159,58 @@ def run_grd_case(name, grd):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def run_train_case(name, m10, m07):
+    """Reference training forward + backward (modules in eval() mode: dropout is not part of the parity
+    contract, ``is_train=True`` selects the training path)."""
+    case = cases.TRAIN_CASES[name]
+    cfg, variant, sd, props, gts = cases.make_train_case(name)
+    mod = m10 if variant == "vidvrd" else m07
+    d = tempfile.mkdtemp()
+    rcfg = dict(cfg)
+    np.save(os.path.join(d, "bias.npy"), sd["bias_matrix"].numpy())
+    rcfg["bias_matrix_path"] = os.path.join(d, "bias.npy")
+    if "EntiNameEmb" in sd:
+        np.save(os.path.join(d, "emb.npy"), sd["EntiNameEmb"].numpy())
+        rcfg["EntiNameEmb_path"] = os.path.join(d, "emb.npy")
+    model = mod.BIG_C(rcfg, is_train=True)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    indices = []
+    orig = model.bipartite_match
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        indices.append(r)
+        return r
+    model.bipartite_match = spy
+    total, terms = model(props, gts)
+    total.backward()
+    out = {"torch_version": np.array(torch.__version__), "total": total.detach().numpy()}
+    for k, v in terms.items():
+        out["loss_" + k] = v.detach().numpy()
+    for i, (iq, ig) in enumerate(indices):
+        out["match%d_query" % i], out["match%d_gt" % i] = np.asarray(iq), np.asarray(ig)
+    for k, p in model.named_parameters():
+        g = p.grad
+        out["gnorm_" + k] = np.array(0.0 if g is None else float(g.norm()))
+        if g is not None and (case.get("full", False) or k in cases.TRAIN_FULL_GRADS_V):
+            out["grad_" + k] = g.numpy()
+    path = os.path.join(cases.GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "total loss", float(total))
+
+
 def main():
     torch.manual_seed(0)
     m10, m07, grd = import_reference()
-    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES))
+    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES))
     for n in names:
         if n in cases.BIGC_CASES:
             run_bigc_case(n, m10, m07)
         elif n in cases.GRD_CASES:
             run_grd_case(n, grd)
+        elif n in cases.TRAIN_CASES:
+            run_train_case(n, m10, m07)
         else:
             raise SystemExit("unknown case " + n)
 

@@ -245,3 +245,66 @@ def sine_pos_emb(length, d_model):
     ph32 = torch.from_numpy(ph.astype(np.float32))
     pos = torch.arange(length, dtype=torch.float32)
     return torch.sin(pos[:, None] * f32[None, :] + ph32[None, :])
+
+
+# --------------------------------------------------------------------------------------
+# synthetic ground truth for the training step
+# --------------------------------------------------------------------------------------
+
+class VideoGraph(object):
+    """Duck-typed stand-in for the reference's GT container (dataloaders/dataloader_vidvrd.py:84-140):
+    ``traj_cat_ids`` i64 (n_traj,), ``traj_durations`` i64 (n_traj,2) closed, ``traj_bboxes`` list of f32
+    (frames,4), ``pred_cat_ids`` i64 (n_pred,), ``pred_durations`` f32 (n_pred,2) closed, ``adj_matrix`` f32
+    (2,n_pred,n_traj), ``num_trajs``, ``num_preds``, ``video_len``, ``max_frames``; ``to(device)`` in place."""
+
+    def __init__(self, video_name, video_len, video_wh, traj_cat_ids, traj_durations, traj_bboxes, pred_cat_ids,
+                 pred_durations, adj_matrix):
+        self.video_name, self.video_len, self.video_wh = video_name, int(video_len), tuple(video_wh)
+        self.traj_cat_ids = torch.as_tensor(traj_cat_ids, dtype=torch.long)
+        self.traj_durations = torch.as_tensor(traj_durations, dtype=torch.long)
+        self.traj_bboxes = [torch.as_tensor(b, dtype=torch.float32) for b in traj_bboxes]
+        self.pred_cat_ids = torch.as_tensor(pred_cat_ids, dtype=torch.long)
+        self.pred_durations = torch.as_tensor(pred_durations, dtype=torch.float32)
+        self.adj_matrix = torch.as_tensor(adj_matrix, dtype=torch.float32)
+        self.num_trajs, self.num_preds = len(self.traj_bboxes), int(self.pred_cat_ids.shape[0])
+        self.n_frames_list = [int(b.shape[0]) for b in self.traj_bboxes]
+        self.max_frames = max(self.n_frames_list)
+
+    def to(self, device):
+        self.traj_cat_ids = self.traj_cat_ids.to(device)
+        self.pred_cat_ids = self.pred_cat_ids.to(device)
+        self.traj_durations = self.traj_durations.to(device)
+        self.pred_durations = self.pred_durations.to(device)
+        self.adj_matrix = self.adj_matrix.to(device)
+        self.traj_bboxes = [b.to(device) for b in self.traj_bboxes]
+        return self
+
+
+def synthetic_gt_graph(proposal, seed, n_gt_trajs=6, n_preds=5, num_pred_cats=133, jitter=6.0):
+    """GT for one synthetic video: ``n_gt_trajs`` of the proposals (boxes jittered by a few pixels so that
+    vIoU with the source proposal is high but not 1, the last one shifted far away so that it matches no
+    proposal above the threshold and takes the best-proposal fallback of models/model_0v10.py:587-590) and
+    ``n_preds`` predicates between temporally overlapping pairs of them."""
+    rs = np.random.RandomState(seed)
+    n = proposal.num_proposals
+    picks = rs.choice(n, size=min(n_gt_trajs, n), replace=False)
+    duras = proposal.traj_durations[picks].clone()
+    boxes = []
+    for j, p in enumerate(picks):
+        b = proposal.bboxes_list[int(p)].clone() + torch.from_numpy(rs.uniform(-jitter, jitter, size=(1, 4)).astype(np.float32))
+        if j == len(picks) - 1:
+            b = b + 400.0
+        boxes.append(b)
+    cats = proposal.cat_ids[picks].clone()
+    pairs = [(a, b) for a in range(len(picks)) for b in range(len(picks)) if a != b and
+             max(int(duras[a, 0]), int(duras[b, 0])) <= min(int(duras[a, 1]), int(duras[b, 1]))]
+    assert pairs, "no overlapping GT pair: choose another seed"
+    sel = [pairs[i] for i in rs.choice(len(pairs), size=min(n_preds, len(pairs)), replace=False)]
+    adj = np.zeros((2, len(sel), len(picks)), dtype=np.float32)
+    pd = []
+    for k, (a, b) in enumerate(sel):
+        adj[0, k, a] = 1.0
+        adj[1, k, b] = 1.0
+        pd.append([max(int(duras[a, 0]), int(duras[b, 0])), min(int(duras[a, 1]), int(duras[b, 1]))])
+    pred_cats = rs.randint(1, num_pred_cats, size=len(sel))
+    return VideoGraph(proposal.video_name, proposal.video_len, proposal.video_wh, cats, duras, boxes, pred_cats, pd, adj)

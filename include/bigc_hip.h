@@ -89,10 +89,11 @@ int bigc_add_rows_f32(void* stream, const float* x, const float* p, float* y, in
  *   in-projection and before out_proj: softmax(q k^T / sqrt(hd)) v, models/model_0v10.py:109,183;
  *   models/grd_model_v5.py:105).  Sequence s owns query rows [q_off[s], q_off[s+1]) of q/o and key
  *   rows [k_off[s], k_off[s+1]) of k/v; head h uses columns [h*hd, (h+1)*hd).
- *   hd in {8, 16, 32, 64}. */
+ *   hd in {8, 16, 32, 64}. lse (total query rows, n_head), optional: log-sum-exp of the scaled scores
+ *   (saved for bigc_mha_bwd_f32). */
 int bigc_mha_core_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                       float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
-                      int n_head, int hd);
+                      int n_head, int hd, float* lse);
 
 /* Role attention of the decoder (models/model_0v10.py:193-207):
  *   s_r[q, n] = p2a[q, r*half:(r+1)*half] . e2a[n, r*half:(r+1)*half] * scale   (r = 0 subject, 1 object)
@@ -208,6 +209,69 @@ typedef struct {
 size_t bigc_workspace_bytes(const bigc_model* m, const bigc_batch* b);
 int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                  int topk, const bigc_outputs* out);
+
+/* ------------------------------------------------------------------------------------
+ * Training step of BIG-C (models/model_0v10.py:510-704; tools/train_vidvrd.py:151-164): forward with saved
+ * activations, Hungarian matching cost, loss + its gradients, and the backward pass.  Replaces torch autograd
+ * over the reference's modules.  Dropout is not applied (parity is defined in eval() mode).
+ * ---------------------------------------------------------------------------------- */
+
+/* out (cols, rows) = in (rows, cols)^T */
+int bigc_transpose_f32(void* stream, const float* in, float* out, int rows, int cols);
+/* dW[n,k] += sum_m dY[m,n] X'[m,k] (X' optionally segment-gathered like bigc_linear_f32) and, if db != NULL,
+ *   db[n] += sum_m dY[m,n]: weight/bias gradient of every nn.Linear / the conv; fp32 atomic accumulation. */
+int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const float* X, int ldx, const int32_t* x_idx, int nseg, int seg_len,
+                       float* dW, int ldw, float* db, int M, int N, int K);
+/* dY *= (Y > 0) with Y the post-ReLU activation; n % 4 == 0 */
+int bigc_relu_bwd_f32(void* stream, float* dY, const float* Y, long n);
+/* y += x; n % 4 == 0 */
+int bigc_axpy_f32(void* stream, float* y, const float* x, long n);
+/* nn.LayerNorm backward: dx (rows,d); dgamma, dbeta accumulated */
+int bigc_layernorm_bwd_f32(void* stream, const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
+                           int rows, int d, float eps);
+/* out[r % period, :] += x[r, :] summed over r (gradients of pos_embedding / pred_query_init, shared by all videos) */
+int bigc_reduce_periodic_f32(void* stream, const float* x, float* out, int rows, int d, int period);
+/* adaptive_max_pool1d backward (first maximum of each window); dconv (C,d) is fully overwritten */
+int bigc_maxpool_bwd_f32(void* stream, const float* conv, const int32_t* trk_conv_off, const float* dpooled, float* dconv, int n_trk, int d, int P);
+/* inverse of bigc_conv_index: G[s, k, :] = sum of the dconv rows whose tap k reads packed row s; G (R, 3, d) */
+int bigc_conv_gather_bwd_f32(void* stream, const float* dconv, const int32_t* trk_row_off, const int32_t* trk_conv_off,
+                             const int32_t* trk_vid, const int32_t* vid_tmax, float* G, int n_trk, int d);
+/* backward of bigc_mha_core_f32 from the saved output o and log-sum-exp lse; delta_scratch (total_q_rows, n_head) */
+int bigc_mha_bwd_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                     const float* dO, int lddo, const float* lse, float* delta_scratch, float* dq, int lddq, float* dk, int lddk,
+                     float* dv, int lddv, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
+                     int n_head, int hd);
+/* d(raw role scores) (same layout as att) from d att; already multiplied by `scale` */
+int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt, float* ds,
+                                const int32_t* e_off, int n_vid, int nq, int half, float scale);
+/* per-video products around the role attention. mode 0: datt = dvals @ enco^T; 1: denco += att^T @ dvals (both roles);
+ *   2: dp2a = ds @ e2a; 3: de2a = ds^T @ p2a. d = dim_enti, half = dim_att/2. */
+int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1, const float* enco_or_e2a,
+                             int ld2, float* out, int ldo, const int32_t* e_off, int n_vid, int nq, int d, int half, int max_trk);
+/* Hungarian cost (models/model_0v10.py:617-636): cost[v,q,g] (B, nq, g_max) = cost_cls * CE + cost_adj * mean BCE;
+ *   g_off (B+1) prefix of GT predicates per video, gt_pred (sum G), gt_adj per video (2, G_v, N_v) at float offset adj_off[v]. */
+int bigc_match_cost(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
+                    const int32_t* gt_pred, const float* gt_adj, const int64_t* adj_off, int n_vid, int nq, int g_max,
+                    float cost_cls, float cost_adj, float* cost);
+/* Loss terms (models/model_0v10.py:648-703) and their gradients. target (B*nq) = matched GT predicate class or 0,
+ *   match_g (B*nq) = matched GT index or -1; n_pos/n_neg/n_adj = element counts of the three means.
+ *   loss_out[3] = {cls_pos, cls_neg, adj}; dlogits (B*nq, ldg) (pad columns untouched), datt like att. */
+int bigc_loss_grad(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
+                   const float* gt_adj, const int64_t* adj_off, const int32_t* target, const int32_t* match_g, int n_vid, int nq,
+                   float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight,
+                   float gs_pos, float gs_neg, float gs_adj, /* upstream gradients of the three loss terms */
+                   float* loss_out, float* dlogits, int ldg, float* datt);
+
+/* gradient destination of a trainable parameter (accumulated; NULL unregisters). Frozen parameters are never registered. */
+int bigc_set_grad(bigc_model* m, const char* key, float* ptr);
+size_t bigc_train_workspace_bytes(const bigc_model* m, const bigc_batch* b);
+/* forward keeping every activation the backward needs inside `workspace` (which must stay untouched until
+ * bigc_train_backward); pred_logits (B*Q, P), att (2*Q*NT) of the last decoder layer */
+int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
+                       float* pred_logits, float* att);
+/* dlogits (B*Q, ldg) with ldg = num_pred_cats rounded up to 4 and zero pad columns; datt (2*Q*NT) */
+int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
+                        const float* dlogits, int ldg, const float* datt);
 
 /* ------------------------------------------------------------------------------------
  * Temporal grounding scorer (models/grd_model_v5.py, class DEBUG), eval path, one video per call

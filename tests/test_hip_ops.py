@@ -163,7 +163,7 @@ def test_mha_core(lib, hd, H, lens):
     o = torch.full((n, d), float("nan"), device=DEV)
     offd = i32(off)
     _lib.check(lib.bigc_mha_core_f32(S(), qd.data_ptr(), 3 * d, qd.data_ptr() + 4 * d, 3 * d, qd.data_ptr() + 8 * d, 3 * d,
-                                     o.data_ptr(), d, offd.data_ptr(), offd.data_ptr(), len(lens), max(lens), H, hd))
+                                     o.data_ptr(), d, offd.data_ptr(), offd.data_ptr(), len(lens), max(lens), H, hd, None))
     torch.cuda.synchronize()
     assert not torch.isnan(o).any()
     assert rel_err(o, want) < 5e-6
@@ -190,7 +190,7 @@ def test_mha_core_cross_lengths(lib):
     o = torch.empty(sum(ql), d, device=DEV)
     qod, kod = i32(qo), i32(ko)
     _lib.check(lib.bigc_mha_core_f32(S(), qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o.data_ptr(), d,
-                                     qod.data_ptr(), kod.data_ptr(), 2, max(ql), H, hd))
+                                     qod.data_ptr(), kod.data_ptr(), 2, max(ql), H, hd, None))
     torch.cuda.synchronize()
     assert rel_err(o, want) < 5e-6
 

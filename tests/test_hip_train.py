@@ -1,0 +1,286 @@
+"""GPU parity of the BIG-C training step on the HIP path: every backward kernel against torch autograd on
+the CPU, then loss terms / Hungarian indices / gradients of the whole step against the real reference's
+stored values (tests/golden/*train*.npz)."""
+import math
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import cases
+from bigc_hip import _lib
+from oracle import bigc_oracle as O
+from oracle import bigc_train_oracle as T
+
+DEV = "cuda:0"
+
+
+def S():
+    return _lib.current_stream()
+
+
+def dev(t):
+    return t.to(DEV).contiguous()
+
+
+def i32(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.int32).to(DEV)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(1e-30, float(b.abs().max())))
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 16, 8), (5000, 512, 512), (777, 133, 3160), (300, 40, 96)])
+def test_linear_dw(M, N, K):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N)
+    dY = torch.randn(M, N, generator=g)
+    X = torch.randn(M, K, generator=g)
+    dW0 = torch.randn(N, K, generator=g)
+    db0 = torch.randn(N, generator=g)
+    dW, db = dev(dW0), dev(db0)
+    a, b = dev(dY), dev(X)
+    _lib.check(lib.bigc_linear_dw_f32(S(), a.data_ptr(), N, b.data_ptr(), K, None, 1, K, dW.data_ptr(), K, db.data_ptr(), M, N, K))
+    torch.cuda.synchronize()
+    assert rel(dW, dW0 + dY.t() @ X) < 1e-5
+    assert rel(db, db0 + dY.sum(0)) < 1e-5
+
+
+def test_linear_dw_gather():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    src = torch.randn(60, 32, generator=g)
+    M, nseg, N = 500, 3, 24
+    idx = torch.randint(-1, 60, (M, nseg), generator=g)
+    dY = torch.randn(M, N, generator=g)
+    A = torch.zeros(M, nseg, 32)
+    for s in range(nseg):
+        ok = idx[:, s] >= 0
+        A[ok, s] = src[idx[ok, s]]
+    want = dY.t() @ A.reshape(M, -1)
+    dW = torch.zeros(N, nseg * 32, device=DEV)
+    a, b, ii = dev(dY), dev(src), i32(idx.numpy())
+    _lib.check(lib.bigc_linear_dw_f32(S(), a.data_ptr(), N, b.data_ptr(), 32, ii.data_ptr(), nseg, 32, dW.data_ptr(), nseg * 32, None, M, N, nseg * 32))
+    torch.cuda.synchronize()
+    assert rel(dW, want) < 1e-5
+
+
+@pytest.mark.parametrize("rows,d", [(5, 16), (3000, 512), (17, 128)])
+def test_layernorm_bwd(rows, d):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.5).requires_grad_(True)
+    w = torch.randn(d, generator=g).requires_grad_(True)
+    b = torch.randn(d, generator=g).requires_grad_(True)
+    dy = torch.randn(rows, d, generator=g)
+    F.layer_norm(x, (d,), w, b, 1e-5).backward(dy)
+    dx = torch.empty(rows, d, device=DEV)
+    dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    xd, wd, dyd = dev(x.detach()), dev(w.detach()), dev(dy)
+    _lib.check(lib.bigc_layernorm_bwd_f32(S(), xd.data_ptr(), wd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, d, 1e-5))
+    torch.cuda.synchronize()
+    assert rel(dx, x.grad) < 2e-5 and rel(dg, w.grad) < 2e-5 and rel(db, b.grad) < 2e-5
+
+
+@pytest.mark.parametrize("hd,H,lens", [(64, 8, [64, 192]), (8, 2, [6, 1, 40]), (16, 8, [33, 70])])
+def test_mha_bwd(hd, H, lens):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(hd + len(lens))
+    d, n = hd * H, sum(lens)
+    qkv = torch.randn(n, 3 * d, generator=g).requires_grad_(True)
+    dO = torch.randn(n, d, generator=g)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    outs = []
+    for s in range(len(lens)):
+        a, b = off[s], off[s + 1]
+        q = qkv[a:b, :d].reshape(-1, H, hd).transpose(0, 1)
+        k = qkv[a:b, d:2 * d].reshape(-1, H, hd).transpose(0, 1)
+        v = qkv[a:b, 2 * d:].reshape(-1, H, hd).transpose(0, 1)
+        outs.append((torch.softmax(q @ k.transpose(1, 2) / math.sqrt(hd), -1) @ v).transpose(0, 1).reshape(-1, d))
+    out = torch.cat(outs)
+    out.backward(dO)
+    qd, dod, offd = dev(qkv.detach()), dev(dO), i32(off)
+    o = torch.empty(n, d, device=DEV)
+    lse = torch.empty(n, H, device=DEV)
+    _lib.check(lib.bigc_mha_core_f32(S(), qd.data_ptr(), 3 * d, qd.data_ptr() + 4 * d, 3 * d, qd.data_ptr() + 8 * d, 3 * d, o.data_ptr(), d,
+                                     offd.data_ptr(), offd.data_ptr(), len(lens), max(lens), H, hd, lse.data_ptr()))
+    dqkv = torch.full((n, 3 * d), float("nan"), device=DEV)
+    delta = torch.empty(n, H, device=DEV)
+    _lib.check(lib.bigc_mha_bwd_f32(S(), qd.data_ptr(), 3 * d, qd.data_ptr() + 4 * d, 3 * d, qd.data_ptr() + 8 * d, 3 * d, o.data_ptr(), d,
+                                    dod.data_ptr(), d, lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), 3 * d, dqkv.data_ptr() + 4 * d, 3 * d,
+                                    dqkv.data_ptr() + 8 * d, 3 * d, offd.data_ptr(), offd.data_ptr(), len(lens), max(lens), max(lens), n, H, hd))
+    torch.cuda.synchronize()
+    assert rel(o, out) < 5e-6
+    assert not torch.isnan(dqkv).any()
+    assert rel(dqkv, qkv.grad) < 2e-5
+
+
+@pytest.mark.parametrize("nq,half,d,ns", [(192, 256, 512, [64, 5]), (12, 8, 16, [6, 9, 140])])
+def test_role_attention_backward_chain(nq, half, d, ns):
+    """d att -> d scores -> d p2a / d e2a, and the values products, against autograd."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(nq + half)
+    B, NT = len(ns), sum(ns)
+    p2a = torch.randn(B * nq, 2 * half, generator=g).requires_grad_(True)
+    e2a = torch.randn(NT, 2 * half, generator=g).requires_grad_(True)
+    enco = torch.randn(NT, d, generator=g).requires_grad_(True)
+    off = np.concatenate([[0], np.cumsum(ns)])
+    scale = 1.0 / math.sqrt(d)
+    gvals = torch.randn(2, B * nq, d, generator=g)
+    gatt_extra = [torch.randn(2, nq, n, generator=g) * 0.1 for n in ns]
+    total = 0
+    atts = []
+    for v in range(B):
+        e, p, x = e2a[off[v]:off[v + 1]], p2a[v * nq:(v + 1) * nq], enco[off[v]:off[v + 1]]
+        s = torch.stack([p[:, :half] @ e[:, :half].t(), p[:, half:] @ e[:, half:].t()], 0) * scale
+        a = torch.softmax(s, 2) * torch.softmax(s, 0)
+        atts.append(a)
+        vals = torch.stack([a[0] @ x, a[1] @ x], 0)
+        total = total + (vals * gvals[:, v * nq:(v + 1) * nq]).sum() + (a * gatt_extra[v]).sum()
+    total.backward()
+    pd, ed, xd, offd, gvd = dev(p2a.detach()), dev(e2a.detach()), dev(enco.detach()), i32(off), dev(gvals)
+    att = torch.empty(2 * nq * NT, device=DEV)
+    _lib.check(lib.bigc_role_attention_f32(S(), pd.data_ptr(), 2 * half, ed.data_ptr(), 2 * half, att.data_ptr(), offd.data_ptr(), B, nq, half, scale))
+    gatt = torch.full((2 * nq * NT,), float("nan"), device=DEV)
+    mt = max(ns)
+    _lib.check(lib.bigc_role_small_gemm_f32(S(), 0, None, gvd.data_ptr(), d, xd.data_ptr(), d, gatt.data_ptr(), 0, offd.data_ptr(), B, nq, d, half, mt))
+    extra = dev(torch.cat([t.reshape(-1) for t in gatt_extra]))
+    _lib.check(lib.bigc_axpy_f32(S(), gatt.data_ptr(), extra.data_ptr(), gatt.numel()))
+    genco = torch.zeros(NT, d, device=DEV)
+    _lib.check(lib.bigc_role_small_gemm_f32(S(), 1, att.data_ptr(), gvd.data_ptr(), d, None, d, genco.data_ptr(), d, offd.data_ptr(), B, nq, d, half, mt))
+    ds = torch.full((2 * nq * NT,), float("nan"), device=DEV)
+    _lib.check(lib.bigc_role_attention_bwd_f32(S(), pd.data_ptr(), 2 * half, ed.data_ptr(), 2 * half, gatt.data_ptr(), ds.data_ptr(), offd.data_ptr(),
+                                               B, nq, half, scale))
+    gp = torch.full((B * nq, 2 * half), float("nan"), device=DEV)
+    ge = torch.full((NT, 2 * half), float("nan"), device=DEV)
+    _lib.check(lib.bigc_role_small_gemm_f32(S(), 2, ds.data_ptr(), None, 0, ed.data_ptr(), 2 * half, gp.data_ptr(), 2 * half, offd.data_ptr(), B, nq, d, half, mt))
+    _lib.check(lib.bigc_role_small_gemm_f32(S(), 3, ds.data_ptr(), pd.data_ptr(), 2 * half, None, 0, ge.data_ptr(), 2 * half, offd.data_ptr(), B, nq, d, half, mt))
+    torch.cuda.synchronize()
+    assert rel(genco, enco.grad) < 2e-5
+    assert rel(gp, p2a.grad) < 5e-5
+    assert rel(ge, e2a.grad) < 5e-5
+
+
+def test_pool_conv_gather_periodic_transpose_relu():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(8)
+    lens_per_vid = [[5, 5, 5], [8, 63, 20, 1], [12, 7]]
+    lens = [l for v in lens_per_vid for l in v]
+    trk_vid = [i for i, v in enumerate(lens_per_vid) for _ in v]
+    row_off = np.concatenate([[0], np.cumsum(lens)])
+    tmax = [max(v) for v in lens_per_vid]
+    nt, d, P = len(lens), 12, 4
+    t_o = [(tmax[v] - 1) // 2 + 1 for v in trk_vid]
+    conv_off = np.concatenate([[0], np.cumsum(t_o)])
+    ro, co, tv, tm = i32(row_off), i32(conv_off), i32(trk_vid), i32(tmax)
+    conv = torch.randn(int(conv_off[-1]), d, generator=g).requires_grad_(True)
+    dpool = torch.randn(nt, d * P, generator=g)
+    for t in range(nt):
+        F.adaptive_max_pool1d(conv[conv_off[t]:conv_off[t + 1]].t()[None], P).reshape(-1).backward(dpool[t], retain_graph=True)
+    dconv = torch.full(conv.shape, float("nan"), device=DEV)
+    cd, dpd = dev(conv.detach()), dev(dpool)
+    _lib.check(lib.bigc_maxpool_bwd_f32(S(), cd.data_ptr(), co.data_ptr(), dpd.data_ptr(), dconv.data_ptr(), nt, d, P))
+    torch.cuda.synchronize()
+    assert rel(dconv, conv.grad) < 1e-6
+    # conv gather backward == scatter-add through the forward gather table
+    idx = torch.empty(int(conv_off[-1]), 3, dtype=torch.int32, device=DEV)
+    _lib.check(lib.bigc_conv_index(S(), ro.data_ptr(), co.data_ptr(), tv.data_ptr(), tm.data_ptr(), idx.data_ptr(), nt))
+    dc = torch.randn(int(conv_off[-1]), d, generator=g)
+    G = torch.full((int(row_off[-1]), 3, d), float("nan"), device=DEV)
+    dcd = dev(dc)
+    _lib.check(lib.bigc_conv_gather_bwd_f32(S(), dcd.data_ptr(), ro.data_ptr(), co.data_ptr(), tv.data_ptr(), tm.data_ptr(), G.data_ptr(), nt, d))
+    torch.cuda.synchronize()
+    want = torch.zeros(int(row_off[-1]), 3, d)
+    ih = idx.cpu().long()
+    for j in range(ih.shape[0]):
+        for k in range(3):
+            if ih[j, k] >= 0:
+                want[ih[j, k], k] += dc[j]
+    assert rel(G, want) < 1e-6
+    # periodic reduction, transpose, relu mask
+    x = torch.randn(36, 16, generator=g)
+    out0 = torch.randn(12, 16, generator=g)
+    o, xd = dev(out0), dev(x)
+    _lib.check(lib.bigc_reduce_periodic_f32(S(), xd.data_ptr(), o.data_ptr(), 36, 16, 12))
+    a = torch.randn(37, 133, generator=g)
+    at, ad = torch.empty(133, 37, device=DEV), dev(a)
+    _lib.check(lib.bigc_transpose_f32(S(), ad.data_ptr(), at.data_ptr(), 37, 133))
+    y = torch.randn(40, 8, generator=g)
+    dy = torch.randn(40, 8, generator=g)
+    dyd, yd = dev(dy), dev(torch.relu(y))
+    _lib.check(lib.bigc_relu_bwd_f32(S(), dyd.data_ptr(), yd.data_ptr(), 320))
+    torch.cuda.synchronize()
+    assert rel(o, out0 + x.reshape(3, 12, 16).sum(0)) < 1e-6
+    assert torch.equal(at.cpu(), a.t())
+    assert torch.equal(dyd.cpu(), dy * (y > 0))
+
+
+def build_train_model(cfg, variant, sd):
+    from models import BIG_C_vidvrd, BIG_C_vidor
+    d = tempfile.mkdtemp()
+    cfg = dict(cfg)
+    np.save(os.path.join(d, "bias.npy"), sd["bias_matrix"].numpy())
+    cfg["bias_matrix_path"] = os.path.join(d, "bias.npy")
+    if "EntiNameEmb" in sd:
+        np.save(os.path.join(d, "emb.npy"), sd["EntiNameEmb"].numpy())
+        cfg["EntiNameEmb_path"] = os.path.join(d, "emb.npy")
+    model = (BIG_C_vidvrd if variant == "vidvrd" else BIG_C_vidor)(cfg, is_train=True)
+    model.load_state_dict(sd, strict=True)
+    return model.to(DEV)
+
+
+@pytest.mark.parametrize("name", list(cases.TRAIN_CASES))
+def test_train_step_vs_reference_golden(name):
+    """loss terms, Hungarian indices and the gradient of every parameter vs the real reference."""
+    g = np.load(os.path.join(cases.GOLDEN_DIR, name + ".npz"))
+    cfg, variant, sd, props, gts = cases.make_train_case(name)
+    model = build_train_model(cfg, variant, sd)
+    total, terms = model(props, gts)
+    assert set(terms) == {"cls_pos", "cls_neg", "adj"}
+    total.backward()
+    torch.cuda.synchronize()
+    assert abs(float(total) - float(g["total"])) < 2e-4 * abs(float(g["total"]))
+    for k, v in terms.items():
+        assert abs(float(v) - float(g["loss_" + k])) < 2e-4 * max(1.0, abs(float(g["loss_" + k]))), k
+    for i, (iq, ig) in enumerate(model.last_match_indices):
+        assert np.array_equal(np.asarray(iq), g["match%d_query" % i]) and np.array_equal(np.asarray(ig), g["match%d_gt" % i])
+    worst = {}
+    for k, p in model.named_parameters():
+        want = float(g["gnorm_" + k])
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        assert p.grad is not None, k
+        got = float(p.grad.norm())
+        worst[k] = abs(got - want) / max(want, 1e-8)
+        if "grad_" + k in g.files:
+            ref = g["grad_" + k]
+            worst[k] = max(worst[k], float(np.abs(p.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-12)))
+    bad = {k: v for k, v in worst.items() if v > 5e-4}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+def test_train_step_then_optimizer_like_the_reference_loop():
+    """tools/train_vidvrd.py:151-164 unchanged: zero_grad, forward, mean, backward, clip, Adam step."""
+    cfg, variant, sd, props, gts = cases.make_train_case("bigc_train_tiny")
+    model = build_train_model(cfg, variant, sd)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(3):
+        _, _, _, _, gts = cases.make_train_case("bigc_train_tiny")     # the forward mutates the GT durations (reference quirk)
+        opt.zero_grad()
+        loss, terms = model(props, gts)
+        loss = loss.mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=5, norm_type=2)
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0]

@@ -63,7 +63,7 @@ _SIGS = {
     "bigc_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
     "bigc_add_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "bigc_mha_core_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
-                                  c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+                                  c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bigc_role_attention_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                         c_int, c_float]),
     "bigc_role_values_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int]),
@@ -84,6 +84,32 @@ _SIGS = {
     "bigc_workspace_bytes": (c_size_t, [c_void_p, POINTER(bigc_batch)]),
     "bigc_forward": (c_int, [c_void_p, c_void_p, POINTER(bigc_batch), c_void_p, c_size_t, c_int,
                              POINTER(bigc_outputs)]),
+    # training step
+    "bigc_transpose_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "bigc_linear_dw_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                   c_int, c_int, c_int]),
+    "bigc_relu_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long]),
+    "bigc_axpy_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long]),
+    "bigc_layernorm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
+    "bigc_reduce_periodic_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "bigc_maxpool_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "bigc_conv_gather_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "bigc_mha_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                 c_int, c_int, c_int, ctypes.c_long, c_int, c_int]),
+    "bigc_role_attention_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                            c_int, c_float]),
+    "bigc_role_small_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                         c_int, c_int, c_int, c_int, c_int]),
+    "bigc_match_cost": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                c_int, c_float, c_float, c_void_p]),
+    "bigc_loss_grad": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
+                               c_void_p, c_void_p, c_int, c_void_p]),
+    "bigc_set_grad": (c_int, [c_void_p, c_char_p, c_void_p]),
+    "bigc_train_workspace_bytes": (c_size_t, [c_void_p, POINTER(bigc_batch)]),
+    "bigc_train_forward": (c_int, [c_void_p, c_void_p, POINTER(bigc_batch), c_void_p, c_size_t, c_void_p, c_void_p]),
+    "bigc_train_backward": (c_int, [c_void_p, c_void_p, POINTER(bigc_batch), c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     # grounding scorer
     "bigc_dwconv_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     "grd_coattention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),

@@ -33,6 +33,8 @@ class BigcEngine(object):
         self._sig = None
         self._keep = None
         self._ws = None
+        self._train_ws = None
+        self.last_flat_grad = None
 
     def __del__(self):
         try:

@@ -34,7 +34,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                        const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
                                                        const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
-                                                       int n_seq, int n_qt, int n_head, float scale) {
+                                                       int n_seq, int n_qt, int n_head, float scale, float* __restrict__ lse) {
     constexpr int HALF = HD / 2;
     constexpr int NTD = (HD + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -103,6 +103,8 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
         m = M;
     }
     const float inv = 1.f / l;
+    // log-sum-exp of the scaled scores, kept for the backward pass (training only)
+    if (lse && hi == 0 && qt * 32 + l31 < nq) lse[(size_t)(q0 + qt * 32 + l31) * n_head + h] = m + logf(l);
 
     // pass 2: P = exp(s - M) / L, out += P V
     f32x16 out[NTD];
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256) void role_values_kernel(const float* __restric
 
 extern "C" int bigc_mha_core_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                  float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
-                                 int n_head, int hd) {
+                                 int n_head, int hd, float* lse) {
     BIGC_CHECK_ARG(q && k && v && o && q_off && k_off, "mha_core: null pointer");
     BIGC_CHECK_ARG(hd == 8 || hd == 16 || hd == 32 || hd == 64, "mha_core: head_dim %d not in {8,16,32,64}", hd);
     BIGC_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0, "mha_core: ldq/ldk must be multiples of 4");
@@ -282,7 +284,7 @@ extern "C" int bigc_mha_core_f32(void* stream, const float* q, int ldq, const fl
     const float scale = 1.0f / sqrtf((float)hd);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(stream, FAM_MHA, 0.0, 0.0);
-#define LAUNCH_MHA(HD) hipLaunchKernelGGL(mha_core_kernel<HD>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale)
+#define LAUNCH_MHA(HD) hipLaunchKernelGGL(mha_core_kernel<HD>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse)
     switch (hd) {
         case 8: LAUNCH_MHA(8); break;
         case 16: LAUNCH_MHA(16); break;

@@ -1,0 +1,450 @@
+// Backward of the attention kernels (attention.hip) on f32 MFMA, same one-wave-per-32-row-tile scheme:
+//   mha_bwd_dq / mha_bwd_dkv   gradients of softmax(q k^T / sqrt(hd)) v, recomputing the probabilities from
+//                              the saved log-sum-exp (torch autograd of nn.MultiheadAttention's core)
+//   role_attention_bwd         d scores of att_r = softmax_n(s_r) * softmax_roles(s)_r  (models/model_0v10.py:201-207)
+//   small_gemm                 the per-video products around it: d att = d vals @ enco^T, d enco += att^T @ d vals,
+//                              d p2a = d s @ e2a, d e2a = d s^T @ p2a                      (:198-201,211)
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1e30f;
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// delta[row, h] = sum_d dO[row, h*hd + d] * O[row, h*hd + d]
+__global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict__ dO, int lddo, const float* __restrict__ O, int ldo,
+                                                        float* __restrict__ delta, long rows, int n_head, int hd) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * n_head; i += (long)gridDim.x * 256) {
+        const long r = i / n_head;
+        const int h = (int)(i - r * n_head);
+        const float* a = dO + r * lddo + h * hd;
+        const float* b = O + r * ldo + h * hd;
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s += a[d] * b[d];
+        delta[i] = s;
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                         const float* __restrict__ v, int ldv, const float* __restrict__ dO, int lddo,
+                                                         const float* __restrict__ lse, const float* __restrict__ delta,
+                                                         float* __restrict__ dq, int lddq, const int32_t* __restrict__ q_off,
+                                                         const int32_t* __restrict__ k_off, int n_seq, int n_qt, int n_head, float scale) {
+    constexpr int HALF = HD / 2;
+    constexpr int NTD = (HD + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n_seq * n_qt * n_head) return;
+    const int h = item % n_head;
+    const int qt = (item / n_head) % n_qt;
+    const int s = item / ((long)n_head * n_qt);
+    const int q0 = q_off[s], nq = q_off[s + 1] - q0;
+    const int k0 = k_off[s], nk = k_off[s + 1] - k0;
+    if (qt * 32 >= nq || nk <= 0) return;
+    const int qrow = min(qt * 32 + l31, nq - 1);
+    const bool qok = qt * 32 + l31 < nq;
+    float qf[HALF], dof[HALF];
+    {
+        const float* qp = q + (size_t)(q0 + qrow) * ldq + h * HD + hi * HALF;
+        const float* gp = dO + (size_t)(q0 + qrow) * lddo + h * HD + hi * HALF;
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) { qf[i] = qp[i] * scale; dof[i] = gp[i]; }
+    }
+    const float my_lse = lse[(size_t)(q0 + qrow) * n_head + h], my_delta = delta[(size_t)(q0 + qrow) * n_head + h];
+    f32x16 acc[NTD];
+#pragma unroll
+    for (int t = 0; t < NTD; ++t) acc[t] = zero16();
+    const int n_kt = (nk + 31) / 32;
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const int krow = min(kt * 32 + l31, nk - 1);
+        const float* kp = k + (size_t)(k0 + krow) * ldk + h * HD + hi * HALF;
+        const float* vp = v + (size_t)(k0 + krow) * ldv + h * HD + hi * HALF;
+        f32x16 sc = zero16(), dp = zero16();
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            sc = mfma32(kp[i], qf[i], sc);
+            dp = mfma32(vp[i], dof[i], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + mfma_row(r, hi);
+            const bool ok = key < nk && qok;
+            const float p = ok ? expf(sc[r] - my_lse) : 0.f;
+            const float ds = p * (dp[r] - my_delta);
+            const float* kr = k + (size_t)(k0 + min(key, nk - 1)) * ldk + h * HD;
+#pragma unroll
+            for (int t = 0; t < NTD; ++t) {
+                const int d = t * 32 + l31;
+                acc[t] = mfma32(ds, d < HD ? kr[d] : 0.f, acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTD; ++t) {
+        const int d = t * 32 + l31;
+        if (d >= HD) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = qt * 32 + mfma_row(r, hi);
+            if (row < nq) dq[(size_t)(q0 + row) * lddq + h * HD + d] = acc[t][r] * scale;
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                          const float* __restrict__ v, int ldv, const float* __restrict__ dO, int lddo,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv,
+                                                          const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
+                                                          int n_seq, int n_kt, int n_head, float scale) {
+    constexpr int HALF = HD / 2;
+    constexpr int NTD = (HD + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n_seq * n_kt * n_head) return;
+    const int h = item % n_head;
+    const int kt = (item / n_head) % n_kt;
+    const int s = item / ((long)n_head * n_kt);
+    const int q0 = q_off[s], nq = q_off[s + 1] - q0;
+    const int k0 = k_off[s], nk = k_off[s + 1] - k0;
+    if (kt * 32 >= nk) return;
+    const int krow = min(kt * 32 + l31, nk - 1);
+    const bool kok = kt * 32 + l31 < nk;
+    float kf[HALF], vf[HALF];
+    {
+        const float* kp = k + (size_t)(k0 + krow) * ldk + h * HD + hi * HALF;
+        const float* vp = v + (size_t)(k0 + krow) * ldv + h * HD + hi * HALF;
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) { kf[i] = kp[i]; vf[i] = vp[i]; }
+    }
+    f32x16 ak[NTD], av[NTD];
+#pragma unroll
+    for (int t = 0; t < NTD; ++t) { ak[t] = zero16(); av[t] = zero16(); }
+    const int n_qt = (nq + 31) / 32;
+    for (int qt = 0; qt < n_qt; ++qt) {
+        const int qrow = min(qt * 32 + l31, nq - 1);
+        const float* qp = q + (size_t)(q0 + qrow) * ldq + h * HD + hi * HALF;
+        const float* gp = dO + (size_t)(q0 + qrow) * lddo + h * HD + hi * HALF;
+        f32x16 sc = zero16(), dp = zero16();
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            sc = mfma32(qp[i] * scale, kf[i], sc);     // rows = queries, cols = keys (this lane's key)
+            dp = mfma32(gp[i], vf[i], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = qt * 32 + mfma_row(r, hi);
+            const int qc = min(qi, nq - 1);
+            const bool ok = qi < nq && kok;
+            const float lr = lse[(size_t)(q0 + qc) * n_head + h], dr = delta[(size_t)(q0 + qc) * n_head + h];
+            const float p = ok ? expf(sc[r] - lr) : 0.f;
+            const float ds = p * (dp[r] - dr);
+            const float* gor = dO + (size_t)(q0 + qc) * lddo + h * HD;
+            const float* qr = q + (size_t)(q0 + qc) * ldq + h * HD;
+#pragma unroll
+            for (int t = 0; t < NTD; ++t) {
+                const int d = t * 32 + l31;
+                av[t] = mfma32(p, d < HD ? gor[d] : 0.f, av[t]);
+                ak[t] = mfma32(ds, d < HD ? qr[d] : 0.f, ak[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTD; ++t) {
+        const int d = t * 32 + l31;
+        if (d >= HD) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = kt * 32 + mfma_row(r, hi);
+            if (row < nk) {
+                dk[(size_t)(k0 + row) * lddk + h * HD + d] = ak[t][r] * scale;
+                dv[(size_t)(k0 + row) * lddv + h * HD + d] = av[t][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// d scores of the role attention, already multiplied by `scale` (= d of the raw dot products).
+__global__ __launch_bounds__(256) void role_attention_bwd_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
+                                                                 const float* __restrict__ datt, float* __restrict__ ds,
+                                                                 const int32_t* __restrict__ e_off, int n_vid, int nq, int n_qt, int half,
+                                                                 float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n_vid * n_qt) return;
+    const int qt = item % n_qt, vid = item / n_qt;
+    const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
+    if (qt * 32 >= nq || ne <= 0) return;
+    const int qq = qt * 32 + l31;
+    const int qrow = min(qq, nq - 1);
+    const int hh = half / 2;
+    const float* qp = p2a + (size_t)(vid * nq + qrow) * ldp + hi * hh;
+    const int n_et = (ne + 31) / 32;
+
+    auto score_tile = [&](int et, f32x16& s0, f32x16& s1) {
+        const int erow = min(et * 32 + l31, ne - 1);
+        const float* ep = e2a + (size_t)(e0 + erow) * lde + hi * hh;
+        s0 = zero16();
+        s1 = zero16();
+        for (int i = 0; i < hh; i += 4) {
+            const f32x4 a0 = *(const f32x4*)(ep + i), a1 = *(const f32x4*)(ep + half + i);
+            const f32x4 b0 = *(const f32x4*)(qp + i), b1 = *(const f32x4*)(qp + half + i);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s0 = mfma32(a0[c], b0[c], s0);
+                s1 = mfma32(a1[c], b1[c], s1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] *= scale; s1[r] *= scale; }
+    };
+
+    // pass 1: softmax-over-entities statistics of both roles
+    float m0 = NEG_BIG, l0 = 0.f, m1 = NEG_BIG, l1 = 0.f;
+    for (int et = 0; et < n_et; ++et) {
+        f32x16 s0, s1;
+        score_tile(et, s0, s1);
+        float t0 = NEG_BIG, t1 = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = et * 32 + mfma_row(r, hi) < ne;
+            t0 = ok ? fmaxf(t0, s0[r]) : t0;
+            t1 = ok ? fmaxf(t1, s1[r]) : t1;
+        }
+        const float n0 = fmaxf(m0, t0), n1 = fmaxf(m1, t1);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = et * 32 + mfma_row(r, hi) < ne;
+            a0 += ok ? expf(s0[r] - n0) : 0.f;
+            a1 += ok ? expf(s1[r] - n1) : 0.f;
+        }
+        l0 = l0 * expf(m0 - n0) + a0; m0 = n0;
+        l1 = l1 * expf(m1 - n1) + a1; m1 = n1;
+    }
+    {
+        float mo = __shfl_xor(m0, 32), lo = __shfl_xor(l0, 32), M = fmaxf(m0, mo);
+        l0 = l0 * expf(m0 - M) + lo * expf(mo - M); m0 = M;
+        mo = __shfl_xor(m1, 32); lo = __shfl_xor(l1, 32); M = fmaxf(m1, mo);
+        l1 = l1 * expf(m1 - M) + lo * expf(mo - M); m1 = M;
+    }
+    const float* gbase = datt + (size_t)2 * nq * e0;
+    float* dbase = ds + (size_t)2 * nq * e0;
+    // pass 2: c_r = sum_n g_r * att_r
+    float c0 = 0.f, c1 = 0.f;
+    for (int et = 0; et < n_et; ++et) {
+        f32x16 s0, s1;
+        score_tile(et, s0, s1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = et * 32 + mfma_row(r, hi);
+            if (n < ne && qq < nq) {
+                const float E0 = expf(s0[r] - m0) / l0, E1 = expf(s1[r] - m1) / l1;
+                const float mx = fmaxf(s0[r], s1[r]);
+                const float w0 = expf(s0[r] - mx), w1 = expf(s1[r] - mx);
+                const float R0 = w0 / (w0 + w1), R1 = w1 / (w0 + w1);
+                c0 += gbase[((size_t)0 * nq + qq) * ne + n] * E0 * R0;
+                c1 += gbase[((size_t)1 * nq + qq) * ne + n] * E1 * R1;
+            }
+        }
+    }
+    c0 += __shfl_xor(c0, 32);
+    c1 += __shfl_xor(c1, 32);
+    // pass 3: ds_r = 2 g_r att_r - E_r c_r - R_r (g_0 att_0 + g_1 att_1)
+    for (int et = 0; et < n_et; ++et) {
+        f32x16 s0, s1;
+        score_tile(et, s0, s1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = et * 32 + mfma_row(r, hi);
+            if (n < ne && qq < nq) {
+                const float E0 = expf(s0[r] - m0) / l0, E1 = expf(s1[r] - m1) / l1;
+                const float mx = fmaxf(s0[r], s1[r]);
+                const float w0 = expf(s0[r] - mx), w1 = expf(s1[r] - mx);
+                const float R0 = w0 / (w0 + w1), R1 = w1 / (w0 + w1);
+                const float ga0 = gbase[((size_t)0 * nq + qq) * ne + n] * E0 * R0;
+                const float ga1 = gbase[((size_t)1 * nq + qq) * ne + n] * E1 * R1;
+                const float both = ga0 + ga1;
+                dbase[((size_t)0 * nq + qq) * ne + n] = (2.f * ga0 - E0 * c0 - R0 * both) * scale;
+                dbase[((size_t)1 * nq + qq) * ne + n] = (2.f * ga1 - E1 * c1 - R1 * both) * scale;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-video small GEMMs C[i,j] (+)= sum_k A[i,k] B[k,j] with arbitrary strides; one wave per
+// (problem, 32-row tile, 128-column chunk).
+enum SmallGemmMode { SG_DATT = 0, SG_DENCO = 1, SG_DP2A = 2, SG_DE2A = 3 };
+
+struct SmallGemmArgs {
+    int mode; int n_vid; int nq; int d; int half;
+    const float* att; const float* dvals; const float* enco; int lde;      // DATT / DENCO
+    const float* ds; const float* p2a; int ldp; const float* e2a; int lda;  // DP2A / DE2A
+    float* out; int ldo; const int32_t* e_off; int max_rows; int n_cc;
+};
+
+__global__ __launch_bounds__(256) void small_gemm_kernel(const SmallGemmArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    // problem enumeration: (video, role) for DATT/DP2A/DE2A, (video) for DENCO (roles are summed inside)
+    const int n_role = p.mode == SG_DENCO ? 1 : 2;
+    const int n_rt = (p.max_rows + 31) / 32;
+    const int n_cc = p.n_cc;       // 128-column chunks (host: from the largest column count over the videos)
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)p.n_vid * n_role * n_rt * n_cc) return;
+    const int cc = item % n_cc;
+    const int rt = (item / n_cc) % n_rt;
+    const int role = (item / ((long)n_cc * n_rt)) % n_role;
+    const int vid = item / ((long)n_cc * n_rt * n_role);
+    const int e0 = p.e_off[vid], ne = p.e_off[vid + 1] - e0;
+    if (ne <= 0) return;
+    const int nq = p.nq;
+    const size_t abase = (size_t)2 * nq * e0;
+
+    // C is m x n, reduction length kdim; element strides of A (i,k), B (k,j) and C rows
+    int m, n, kdim, sa_i, sa_k, sb_k, sb_j, sc_i, n_pass = 1;
+    const float *A, *B;
+    float* C;
+    bool accumulate = false;
+    if (p.mode == SG_DATT) {           // datt[r] (nq x ne) = dvals[r][vid] (nq x d) @ enco_v^T (d x ne)
+        m = nq; n = ne; kdim = p.d;
+        A = p.dvals + ((size_t)role * p.n_vid * nq + (size_t)vid * nq) * p.lde; sa_i = p.lde; sa_k = 1;
+        B = p.enco + (size_t)e0 * p.lde; sb_k = 1; sb_j = p.lde;
+        C = p.out + abase + (size_t)role * nq * ne; sc_i = ne;
+    } else if (p.mode == SG_DENCO) {   // denco_v (ne x d) += sum_r att[r]^T (ne x nq) @ dvals[r][vid] (nq x d)
+        m = ne; n = p.d; kdim = nq; n_pass = 2; accumulate = true;
+        A = p.att + abase; sa_i = 1; sa_k = ne;
+        B = p.dvals + (size_t)vid * nq * p.lde; sb_k = p.lde; sb_j = 1;
+        C = p.out + (size_t)e0 * p.ldo; sc_i = p.ldo;
+    } else if (p.mode == SG_DP2A) {    // dp2a[vid*nq + q, role*half + c] = sum_n ds[r][q][n] e2a[e0+n, role*half + c]
+        m = nq; n = p.half; kdim = ne;
+        A = p.ds + abase + (size_t)role * nq * ne; sa_i = ne; sa_k = 1;
+        B = p.e2a + (size_t)e0 * p.lda + role * p.half; sb_k = p.lda; sb_j = 1;
+        C = p.out + (size_t)vid * nq * p.ldo + role * p.half; sc_i = p.ldo;
+    } else {                           // SG_DE2A: de2a[e0+n, role*half + c] = sum_q ds[r][q][n] p2a[vid*nq + q, role*half + c]
+        m = ne; n = p.half; kdim = nq;
+        A = p.ds + abase + (size_t)role * nq * ne; sa_i = 1; sa_k = ne;
+        B = p.p2a + (size_t)vid * nq * p.ldp + role * p.half; sb_k = p.ldp; sb_j = 1;
+        C = p.out + (size_t)e0 * p.ldo + role * p.half; sc_i = p.ldo;
+    }
+    if (rt * 32 >= m || cc * 128 >= n) return;
+    const int irow = min(rt * 32 + l31, m - 1);
+    const bool iok = rt * 32 + l31 < m;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    const int j0 = cc * 128;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const float* Ap = A + (p.mode == SG_DENCO ? (size_t)pass * nq * ne : 0);
+        const float* Bp = B + (p.mode == SG_DENCO ? (size_t)pass * p.n_vid * nq * p.lde : 0);
+        for (int k2 = 0; k2 < kdim; k2 += 2) {
+            const int kk = k2 + hi;
+            const bool kok = kk < kdim;
+            const float a = (iok && kok) ? Ap[(size_t)irow * sa_i + (size_t)kk * sa_k] : 0.f;
+            const float* bp = Bp + (size_t)min(kk, kdim - 1) * sb_k;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = j0 + t * 32 + l31;
+                const float bv = (kok && j < n) ? bp[(size_t)j * sb_j] : 0.f;
+                acc[t] = mfma32(a, bv, acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = j0 + t * 32 + l31;
+        if (j >= n) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = rt * 32 + mfma_row(r, hi);
+            if (i >= m) continue;
+            float* cp = C + (size_t)i * sc_i + j;
+            *cp = accumulate ? *cp + acc[t][r] : acc[t][r];
+        }
+    }
+}
+
+int grid_for(long n, int cap = 4096) { long g = (n + 255) / 256; return (int)(g < cap ? (g < 1 ? 1 : g) : cap); }
+
+}  // namespace
+
+extern "C" int bigc_mha_bwd_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                const float* o, int ldo, const float* dO, int lddo, const float* lse, float* delta_scratch,
+                                float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                                const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
+                                int n_head, int hd) {
+    BIGC_CHECK_ARG(q && k && v && o && dO && lse && delta_scratch && dq && dk && dv && q_off && k_off, "mha_bwd: null pointer");
+    BIGC_CHECK_ARG(hd == 8 || hd == 16 || hd == 32 || hd == 64, "mha_bwd: head_dim %d", hd);
+    if (n_seq <= 0 || max_q <= 0 || max_k <= 0) return BIGC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const float scale = 1.0f / sqrtf((float)hd);
+    ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
+    hipLaunchKernelGGL(mha_delta_kernel, dim3(grid_for(total_q_rows * n_head)), dim3(256), 0, s, dO, lddo, o, ldo, delta_scratch, total_q_rows, n_head, hd);
+    BIGC_LAUNCH_CHECK("mha_delta");
+    const int n_qt = cdiv(max_q, 32), n_kt = cdiv(max_k, 32);
+    const int gq = (int)(((long)n_seq * n_qt * n_head + 3) / 4), gk = (int)(((long)n_seq * n_kt * n_head + 3) / 4);
+#define LAUNCH_BWD(HD) \
+    hipLaunchKernelGGL(mha_bwd_dq_kernel<HD>, dim3(gq), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dq, lddq, q_off, k_off, n_seq, n_qt, n_head, scale); \
+    hipLaunchKernelGGL(mha_bwd_dkv_kernel<HD>, dim3(gk), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dk, lddk, dv, lddv, q_off, k_off, n_seq, n_kt, n_head, scale)
+    switch (hd) {
+        case 8: LAUNCH_BWD(8); break;
+        case 16: LAUNCH_BWD(16); break;
+        case 32: LAUNCH_BWD(32); break;
+        default: LAUNCH_BWD(64); break;
+    }
+#undef LAUNCH_BWD
+    BIGC_LAUNCH_CHECK("mha_bwd");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt,
+                                           float* ds, const int32_t* e_off, int n_vid, int nq, int half, float scale) {
+    BIGC_CHECK_ARG(p2a && e2a && datt && ds && e_off, "role_attention_bwd: null pointer");
+    if (n_vid <= 0) return BIGC_OK;
+    const int n_qt = cdiv(nq, 32);
+    ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
+    hipLaunchKernelGGL(role_attention_bwd_kernel, dim3(cdiv(n_vid * n_qt, 4)), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, datt, ds,
+                       e_off, n_vid, nq, n_qt, half, scale);
+    BIGC_LAUNCH_CHECK("role_attention_bwd");
+    return BIGC_OK;
+}
+
+// mode 0: datt = dvals @ enco^T; 1: denco += att^T @ dvals; 2: dp2a = ds @ e2a; 3: de2a = ds^T @ p2a
+extern "C" int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1,
+                                        const float* enco_or_e2a, int ld2, float* out, int ldo, const int32_t* e_off, int n_vid, int nq,
+                                        int d, int half, int max_trk) {
+    BIGC_CHECK_ARG(mode >= 0 && mode <= 3 && out && e_off, "role_small_gemm: bad argument");
+    if (n_vid <= 0) return BIGC_OK;
+    SmallGemmArgs p;
+    p.mode = mode; p.n_vid = n_vid; p.nq = nq; p.d = d; p.half = half;
+    p.att = att_or_ds; p.ds = att_or_ds; p.dvals = dvals_or_p2a; p.p2a = dvals_or_p2a; p.ldp = ld1;
+    p.enco = enco_or_e2a; p.e2a = enco_or_e2a; p.lde = (mode <= 1) ? ld2 : 0; p.lda = ld2;
+    if (mode <= 1) p.lde = ld2;
+    p.out = out; p.ldo = ldo; p.e_off = e_off;
+    int rows, cols, n_role;
+    if (mode == SG_DATT) { rows = nq; cols = max_trk; n_role = 2; }
+    else if (mode == SG_DENCO) { rows = max_trk; cols = d; n_role = 1; }
+    else if (mode == SG_DP2A) { rows = nq; cols = half; n_role = 2; }
+    else { rows = max_trk; cols = half; n_role = 2; }
+    p.max_rows = rows;
+    p.n_cc = cdiv(cols, 128);
+    const long items = (long)n_vid * n_role * cdiv(rows, 32) * p.n_cc;
+    ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((int)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    BIGC_LAUNCH_CHECK("role_small_gemm");
+    return BIGC_OK;
+}

@@ -1,0 +1,509 @@
+// Backward kernels of the BIG-C training step (reference: the autograd graph of
+// models/model_0v10.py:434-507 + the loss :642-704).  Dense gradients reuse the f32-MFMA machinery:
+//   dX = dY W          -> linear_f32 on a transposed copy of W (transpose kernel below)
+//   dW += dY^T X       -> linear_dw kernel (same 128x128 MFMA tile, reduction over the rows M, split over
+//                         M across workgroups, fp32 atomic accumulation into the gradient buffer)
+// plus the row-wise / gather backward kernels (ReLU mask, LayerNorm, column sums, max-pool routing,
+// stretched-conv gather-sum, head scatter, periodic reduction for the shared query/pos embeddings).
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int PITCH = 36;
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        if (r < rows && c < cols) tile[j][tx] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = bx + j, c = by + tx;                      // out is (cols, rows)
+        if (r < cols && c < rows) out[(size_t)r * rows + c] = tile[tx][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dW[n,k] += sum_m dY[m,n] * X'[m,k]; X' optionally row-gathered in segments like linear_f32.
+struct DwArgs {
+    const float* dY; int ldy; const float* X; int ldx; const int32_t* x_idx; int nseg; int seg_len;
+    float* dW; int ldw; int M, N, K; int tiles_n, tiles_k, m_chunk;
+};
+
+__global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2][128 * PITCH];   // [dY^T tile | X^T tile], each [128][32(m)+pad]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.x % (p.tiles_n * p.tiles_k), split = blockIdx.x / (p.tiles_n * p.tiles_k);
+    const int tn = tile / p.tiles_k, tk = tile % p.tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int m_begin = split * p.m_chunk, m_end = min(p.M, m_begin + p.m_chunk);
+    if (m_begin >= m_end) return;
+    // staging: thread owns column c = tid&127 of the tile and 16 consecutive m (half mh of the 32-row slab)
+    const int c = tid & 127, mh = tid >> 7;
+    const int ncol = n0 + c, kcol = k0 + c;
+    const bool nval = ncol < p.N, kval = kcol < p.K;
+    int seg = 0, kin = kcol;
+    if (p.x_idx) { seg = min(kcol, p.K - 1) / p.seg_len; kin = kcol - seg * p.seg_len; }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+        float ry[16], rx[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int m = m0 + mh * 16 + j;
+            const bool mv = m < m_end;
+            ry[j] = (mv && nval) ? p.dY[(size_t)m * p.ldy + ncol] : 0.f;
+            float xv = 0.f;
+            if (mv && kval) {
+                if (p.x_idx) {
+                    const int src = p.x_idx[(size_t)m * p.nseg + seg];
+                    xv = src >= 0 ? p.X[(size_t)src * p.ldx + kin] : 0.f;
+                } else {
+                    xv = p.X[(size_t)m * p.ldx + kcol];
+                }
+            }
+            rx[j] = xv;
+        }
+        __syncthreads();   // previous slab fully consumed
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {
+            *(f32x4*)(&smem[0][c * PITCH + mh * 16 + j]) = f32x4{ry[j], ry[j + 1], ry[j + 2], ry[j + 3]};
+            *(f32x4*)(&smem[1][c * PITCH + mh * 16 + j]) = f32x4{rx[j], rx[j + 1], rx[j + 2], rx[j + 3]};
+        }
+        __syncthreads();
+        const float* as = &smem[0][(wm * 64 + l31) * PITCH + 4 * hi];
+        const float* bs = &smem[1][(wn * 64 + l31) * PITCH + 4 * hi];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const f32x4 a0 = *(const f32x4*)(as + 8 * cc), a1 = *(const f32x4*)(as + 32 * PITCH + 8 * cc);
+            const f32x4 b0 = *(const f32x4*)(bs + 8 * cc), b1 = *(const f32x4*)(bs + 32 * PITCH + 8 * cc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[0][0] = mfma32(a0[q], b0[q], acc[0][0]);
+                acc[0][1] = mfma32(a0[q], b1[q], acc[0][1]);
+                acc[1][0] = mfma32(a1[q], b0[q], acc[1][0]);
+                acc[1][1] = mfma32(a1[q], b1[q], acc[1][1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = k0 + wn * 64 + b * 32 + l31;
+            if (col >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm * 64 + a * 32 + mfma_row(r, hi);
+                if (row < p.N) atomicAdd(&p.dW[(size_t)row * p.ldw + col], acc[a][b][r]);
+            }
+        }
+}
+
+// db[n] += sum_m dY[m,n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dY, int ldy, float* __restrict__ db, int M, int N, int rows_per_block) {
+    const int m_begin = blockIdx.y * rows_per_block, m_end = min(M, m_begin + rows_per_block);
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+        float s = 0.f;
+        for (int m = m_begin; m < m_end; ++m) s += dY[(size_t)m * ldy + n];
+        atomicAdd(&db[n], s);
+    }
+}
+
+// dY *= (Y > 0)   (Y = post-ReLU activation)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dY, const float* __restrict__ Y, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 g = ((f32x4*)dY)[i];
+        const f32x4 y = ((const f32x4*)Y)[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) g[c] = y[c] > 0.f ? g[c] : 0.f;
+        ((f32x4*)dY)[i] = g;
+    }
+}
+
+// y += x  (gradient accumulation of two branches)
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+        ((f32x4*)y)[i] = ((f32x4*)y)[i] + ((const f32x4*)x)[i];
+}
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// LayerNorm backward. One wave per row (grid-stride), d <= 2048. dgamma/dbeta accumulated per wave in
+// registers and added atomically once at the end.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ dy, float* __restrict__ dx,
+                                                            float* __restrict__ dg, float* __restrict__ db, int rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int nv = d >> 2;
+    f32x4 ag[8], ab[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ag[j] = f32x4{0, 0, 0, 0}; ab[j] = f32x4{0, 0, 0, 0}; }
+    for (int row = wid; row < rows; row += nw) {
+        const f32x4* xp = (const f32x4*)(x + (size_t)row * d);
+        const f32x4* yp = (const f32x4*)(dy + (size_t)row * d);
+        f32x4 v[8], gy[8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) { v[j] = xp[i]; gy[j] = yp[i]; s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]); }
+        }
+        const float mean = wsum(s) / (float)d;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float t = v[j][c] - mean; ss += t * t; }
+        }
+        const float rstd = 1.0f / sqrtf(wsum(ss) / (float)d + eps);
+        float s1 = 0.f, s2 = 0.f;   // sum(dxhat), sum(dxhat * xhat)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) {
+                const f32x4 gg = ((const f32x4*)g)[i];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float xh = (v[j][c] - mean) * rstd;
+                    const float dxh = gy[j][c] * gg[c];
+                    s1 += dxh; s2 += dxh * xh;
+                    ag[j][c] += gy[j][c] * xh;
+                    ab[j][c] += gy[j][c];
+                    v[j][c] = xh; gy[j][c] = dxh;
+                }
+            }
+        }
+        s1 = wsum(s1) / (float)d; s2 = wsum(s2) / (float)d;
+        f32x4* op = (f32x4*)(dx + (size_t)row * d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) {
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = rstd * (gy[j][c] - s1 - v[j][c] * s2);
+                op[i] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { atomicAdd(&dg[i * 4 + c], ag[j][c]); atomicAdd(&db[i * 4 + c], ab[j][c]); }
+    }
+}
+
+// out[r % period, :] += sum over the rows with that residue (gradients of pos_embedding / pred_query_init)
+__global__ __launch_bounds__(256) void reduce_periodic_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int d, int period) {
+    const int total = period * d;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int pr = e / d, c = e - pr * d;
+        float s = 0.f;
+        for (int r = pr; r < rows; r += period) s += x[(size_t)r * d + c];
+        out[e] += s;
+    }
+}
+
+// adaptive max-pool backward: route d pooled[t, c*P+p] to the FIRST maximum of its window (torch stores the
+// index of the first maximum); windows of one (tracklet, channel) are handled by one thread (they overlap when T_o < P)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ conv, const int32_t* __restrict__ conv_off,
+                                                          const float* __restrict__ dpooled, float* __restrict__ dconv, int d, int P) {
+    const int t = blockIdx.x;
+    const int c0 = conv_off[t], To = conv_off[t + 1] - c0;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        for (int j = 0; j < To; ++j) dconv[(size_t)(c0 + j) * d + c] = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const int s = (p * To) / P, e = ((p + 1) * To + P - 1) / P;
+            float m = conv[(size_t)(c0 + s) * d + c];
+            int am = s;
+            for (int j = s + 1; j < e; ++j) {
+                const float v = conv[(size_t)(c0 + j) * d + c];
+                if (v > m) { m = v; am = j; }
+            }
+            dconv[(size_t)(c0 + am) * d + c] += dpooled[(size_t)t * d * P + (size_t)c * P + p];
+        }
+    }
+}
+
+// G[s, k, :] = sum of dconv rows j whose tap k reads packed source row s (inverse of the conv gather table):
+// stretched frame f (src(f) = i) feeds output j with tap c iff 2j - 1 + c == f.
+__global__ __launch_bounds__(256) void conv_gather_bwd_kernel(const float* __restrict__ dconv, const int32_t* __restrict__ row_off,
+                                                              const int32_t* __restrict__ conv_off, const int32_t* __restrict__ trk_vid,
+                                                              const int32_t* __restrict__ vid_tmax, float* __restrict__ G, int d) {
+    const int t = blockIdx.x;
+    const int r0 = row_off[t], L = row_off[t + 1] - r0;
+    const int c0 = conv_off[t], To = conv_off[t + 1] - c0;
+    const int M = vid_tmax[trk_vid[t]];
+    const int q = M / L, r = M - q * L;
+    for (int e = threadIdx.x; e < L * 3 * d; e += 256) {
+        const int ch = e % d, k = (e / d) % 3, i = e / (3 * d);
+        // stretched frames of source frame i: [fa, fb)
+        const int fa = i < r ? i * (q + 1) : r * (q + 1) + (i - r) * q;
+        const int fb = fa + (i < r ? q + 1 : q);
+        float s = 0.f;
+        for (int f = fa; f < fb; ++f) {
+            const int num = f + 1 - k;
+            if (num < 0 || (num & 1)) continue;
+            const int j = num >> 1;
+            if (j < To) s += dconv[(size_t)(c0 + j) * d + ch];
+        }
+        G[((size_t)(r0 + i) * 3 + k) * d + ch] = s;
+    }
+}
+
+// (n_out, n_in, taps) conv weight -> (n_in, taps*n_out): W'[c, k*n_out + o] = w[o, c, k]  (dX of the implicit GEMM)
+__global__ void repack_conv_weight_bwd_kernel(const float* __restrict__ w, float* __restrict__ out, long total, int n_out, int n_in, int taps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long per_c = (long)taps * n_out;
+    const long c = i / per_c;
+    const int rem = (int)(i - c * per_c);
+    const int k = rem / n_out, o = rem - k * n_out;
+    out[i] = w[((long)o * n_in + c) * taps + k];
+}
+
+// head gather backward (models/model_0v10.py:485-503): d head_in (rows, ld) ->
+//   dquery[row, :dq]; per tracklet sums of the subject/object slices of every segment table that is indexed by
+//   tracklet; d bias_matrix[cs, co, :] += dlogits[row, :]
+struct HeadBwdSegs { int n; float* dst[4]; int width[4]; int col[4]; };
+
+__global__ __launch_bounds__(256) void head_gather_bwd_kernel(const float* __restrict__ dhead, int ld, const int32_t* __restrict__ soid,
+                                                              const int32_t* __restrict__ e_off, const int32_t* __restrict__ trk_vid,
+                                                              int nq, HeadBwdSegs segs) {
+    const int t = blockIdx.x;                    // global tracklet
+    const int v = trk_vid[t];
+    const int lt = t - e_off[v];
+    const int32_t* so = soid + (size_t)v * 2 * nq;
+    for (int s = 0; s < segs.n; ++s) {
+        const int w = segs.width[s];
+        for (int c = threadIdx.x; c < w; c += 256) {
+            float acc = 0.f;
+            for (int qi = 0; qi < nq; ++qi) {
+                const float* row = dhead + (size_t)(v * nq + qi) * ld + segs.col[s];
+                if (so[qi] == lt) acc += row[c];
+                if (so[nq + qi] == lt) acc += row[w + c];
+            }
+            segs.dst[s][(size_t)t * w + c] += acc;
+        }
+    }
+}
+
+// tap-major conv weight gradient (n_out, taps*n_in) -> torch layout (n_out, n_in, taps), accumulated
+__global__ void conv_grad_unpack_kernel(const float* __restrict__ g, float* __restrict__ out, long total, int n_in, int taps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long per_out = (long)n_in * taps;
+    const long o = i / per_out;
+    const int rem = (int)(i - o * per_out);
+    const int c = rem / taps, k = rem - c * taps;
+    out[i] += g[o * per_out + (long)k * n_in + c];
+}
+
+// out (cols, ld_out) = in (rows, cols)^T with the columns [rows, ld_out) zero-filled
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int ld_out) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;      // bx over cols of `in`, by over rows of `in` (padded to ld_out)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        tile[j][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = bx + j, c = by + tx;
+        if (r < cols && c < ld_out) out[(size_t)r * ld_out + c] = tile[tx][j];
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_matrix_bwd_kernel(const float* __restrict__ dlogits, int ldg, const int32_t* __restrict__ soid,
+                                                              const int32_t* __restrict__ e_off, const int32_t* __restrict__ trk_cat,
+                                                              int nq, int n_ecat, int n_pcat, float* __restrict__ dbias) {
+    const int row = blockIdx.x;
+    const int v = row / nq, qi = row - v * nq;
+    const int e0 = e_off[v];
+    if (e_off[v + 1] - e0 <= 0) return;
+    const int cs = trk_cat[e0 + soid[((size_t)v * 2) * nq + qi]], co = trk_cat[e0 + soid[((size_t)v * 2 + 1) * nq + qi]];
+    float* dst = dbias + ((size_t)cs * n_ecat + co) * n_pcat;
+    for (int i = threadIdx.x; i < n_pcat; i += 256) atomicAdd(&dst[i], dlogits[(size_t)row * ldg + i]);
+}
+
+// copy the first dq columns of each row (d head_in -> d query)
+__global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, long rows, int cols4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * cols4; i += (long)gridDim.x * 256) {
+        const long r = i / cols4;
+        const int c = (int)(i - r * cols4);
+        ((f32x4*)(dst + r * ldd))[c] = ((const f32x4*)(src + r * lds_))[c];
+    }
+}
+
+int grid_for(long n, int cap = 4096) { long g = (n + 255) / 256; return (int)(g < cap ? (g < 1 ? 1 : g) : cap); }
+
+}  // namespace
+
+// ---- internal launchers (used by train.hip) + exported entry points for the parity tests --------------
+
+extern "C" int bigc_transpose_f32(void* stream, const float* in, float* out, int rows, int cols) {
+    BIGC_CHECK_ARG(in && out && rows > 0 && cols > 0, "transpose: bad argument");
+    ProfScope ps(stream, FAM_BACKWARD, 0.0, 8.0 * rows * (double)cols);
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
+    BIGC_LAUNCH_CHECK("transpose");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const float* X, int ldx, const int32_t* x_idx, int nseg,
+                                  int seg_len, float* dW, int ldw, float* db, int M, int N, int K) {
+    BIGC_CHECK_ARG(dY && X && dW && M >= 0 && N > 0 && K > 0, "linear_dw: bad argument");
+    if (M == 0) return BIGC_OK;
+    if (x_idx) BIGC_CHECK_ARG(nseg >= 1 && nseg * seg_len == K, "linear_dw: K=%d != nseg*seg_len", K);
+    DwArgs p;
+    p.dY = dY; p.ldy = ldy; p.X = X; p.ldx = ldx; p.x_idx = x_idx; p.nseg = x_idx ? nseg : 1; p.seg_len = x_idx ? seg_len : K;
+    p.dW = dW; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
+    p.tiles_n = cdiv(N, 128); p.tiles_k = cdiv(K, 128);
+    const int tiles = p.tiles_n * p.tiles_k;
+    int splits = cdiv(2048, tiles);
+    const int max_splits = cdiv(M, 256);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.m_chunk = cdiv(cdiv(M, splits), 32) * 32;
+    splits = cdiv(M, p.m_chunk);
+    {
+        ProfScope ps(stream, FAM_LINEAR_DW, 2.0 * M * (double)N * K, 4.0 * ((double)M * N + (double)M * K + (double)N * K));
+        hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
+        BIGC_LAUNCH_CHECK("linear_dw");
+    }
+    if (db) {
+        const int rpb = cdiv(M, 256) > 256 ? cdiv(M, 256) : 256;     // <= 256 row chunks
+        ProfScope ps(stream, FAM_BACKWARD, 0.0, 4.0 * M * (double)N);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dY, ldy, db, M, N, rpb);
+        BIGC_LAUNCH_CHECK("colsum");
+    }
+    return BIGC_OK;
+}
+
+extern "C" int bigc_relu_bwd_f32(void* stream, float* dY, const float* Y, long n) {
+    BIGC_CHECK_ARG(dY && Y && n % 4 == 0, "relu_bwd: bad argument");
+    if (n <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_BACKWARD, 0.0, 12.0 * n);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dY, Y, n / 4);
+    BIGC_LAUNCH_CHECK("relu_bwd");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_axpy_f32(void* stream, float* y, const float* x, long n) {
+    BIGC_CHECK_ARG(y && x && n % 4 == 0, "axpy: bad argument");
+    if (n <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_BACKWARD, 0.0, 12.0 * n);
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, y, x, n / 4);
+    BIGC_LAUNCH_CHECK("axpy");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_layernorm_bwd_f32(void* stream, const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
+                                      float* dbeta, int rows, int d, float eps) {
+    BIGC_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+    BIGC_CHECK_ARG(d > 0 && d % 4 == 0 && d <= 2048, "layernorm_bwd: d=%d", d);
+    if (rows <= 0) return BIGC_OK;
+    const int grid = cdiv(rows, 4) < 512 ? cdiv(rows, 4) : 512;
+    ProfScope ps(stream, FAM_BACKWARD, 0.0, 12.0 * rows * (double)d);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dx, dgamma, dbeta, rows, d, eps);
+    BIGC_LAUNCH_CHECK("layernorm_bwd");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_reduce_periodic_f32(void* stream, const float* x, float* out, int rows, int d, int period) {
+    BIGC_CHECK_ARG(x && out && period > 0, "reduce_periodic: bad argument");
+    if (rows <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_BACKWARD, 0.0, 4.0 * rows * (double)d);
+    hipLaunchKernelGGL(reduce_periodic_kernel, dim3(grid_for((long)period * d)), dim3(256), 0, (hipStream_t)stream, x, out, rows, d, period);
+    BIGC_LAUNCH_CHECK("reduce_periodic");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_maxpool_bwd_f32(void* stream, const float* conv, const int32_t* trk_conv_off, const float* dpooled, float* dconv,
+                                    int n_trk, int d, int P) {
+    BIGC_CHECK_ARG(conv && trk_conv_off && dpooled && dconv, "maxpool_bwd: null pointer");
+    if (n_trk <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_BACKWARD, 0.0, 0.0);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(n_trk), dim3(256), 0, (hipStream_t)stream, conv, trk_conv_off, dpooled, dconv, d, P);
+    BIGC_LAUNCH_CHECK("maxpool_bwd");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_conv_gather_bwd_f32(void* stream, const float* dconv, const int32_t* trk_row_off, const int32_t* trk_conv_off,
+                                        const int32_t* trk_vid, const int32_t* vid_tmax, float* G, int n_trk, int d) {
+    BIGC_CHECK_ARG(dconv && trk_row_off && trk_conv_off && trk_vid && vid_tmax && G, "conv_gather_bwd: null pointer");
+    if (n_trk <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_BACKWARD, 0.0, 0.0);
+    hipLaunchKernelGGL(conv_gather_bwd_kernel, dim3(n_trk), dim3(256), 0, (hipStream_t)stream, dconv, trk_row_off, trk_conv_off, trk_vid, vid_tmax, G, d);
+    BIGC_LAUNCH_CHECK("conv_gather_bwd");
+    return BIGC_OK;
+}
+
+int bigc_repack_conv_weight_bwd(hipStream_t s, const float* w, float* out, int n_out, int n_in, int taps) {
+    const long total = (long)n_out * n_in * taps;
+    hipLaunchKernelGGL(repack_conv_weight_bwd_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, w, out, total, n_out, n_in, taps);
+    BIGC_LAUNCH_CHECK("repack_conv_weight_bwd");
+    return BIGC_OK;
+}
+
+int bigc_head_gather_bwd(hipStream_t s, const float* dhead, int ld, const int32_t* soid, const int32_t* e_off, const int32_t* trk_vid,
+                         int n_trk, int nq, int n_seg, float* const* dst, const int* width, const int* col) {
+    HeadBwdSegs segs;
+    segs.n = n_seg;
+    for (int i = 0; i < 4; ++i) { segs.dst[i] = i < n_seg ? dst[i] : nullptr; segs.width[i] = i < n_seg ? width[i] : 0; segs.col[i] = i < n_seg ? col[i] : 0; }
+    if (n_trk <= 0 || n_seg <= 0) return BIGC_OK;
+    hipLaunchKernelGGL(head_gather_bwd_kernel, dim3(n_trk), dim3(256), 0, s, dhead, ld, soid, e_off, trk_vid, nq, segs);
+    BIGC_LAUNCH_CHECK("head_gather_bwd");
+    return BIGC_OK;
+}
+
+int bigc_bias_matrix_bwd(hipStream_t s, const float* dlogits, int ldg, const int32_t* soid, const int32_t* e_off, const int32_t* trk_cat,
+                         int n_vid, int nq, int n_ecat, int n_pcat, float* dbias) {
+    if (n_vid <= 0) return BIGC_OK;
+    hipLaunchKernelGGL(bias_matrix_bwd_kernel, dim3(n_vid * nq), dim3(256), 0, s, dlogits, ldg, soid, e_off, trk_cat, nq, n_ecat, n_pcat, dbias);
+    BIGC_LAUNCH_CHECK("bias_matrix_bwd");
+    return BIGC_OK;
+}
+
+int bigc_conv_grad_unpack(hipStream_t s, const float* g_tapmajor, float* g_torch, int n_out, int n_in, int taps) {
+    const long total = (long)n_out * n_in * taps;
+    hipLaunchKernelGGL(conv_grad_unpack_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, g_tapmajor, g_torch, total, n_in, taps);
+    BIGC_LAUNCH_CHECK("conv_grad_unpack");
+    return BIGC_OK;
+}
+
+int bigc_transpose_pad(hipStream_t s, const float* in, float* out, int rows, int cols, int ld_out) {
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(cdiv(cols, 32), cdiv(ld_out, 32)), dim3(256), 0, s, in, out, rows, cols, ld_out);
+    BIGC_LAUNCH_CHECK("transpose_pad");
+    return BIGC_OK;
+}
+
+int bigc_copy_cols(hipStream_t s, const float* src, int lds_, float* dst, int ldd, long rows, int cols) {
+    if (rows <= 0) return BIGC_OK;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(rows * (cols / 4))), dim3(256), 0, s, src, lds_, dst, ldd, rows, cols / 4);
+    BIGC_LAUNCH_CHECK("copy_cols");
+    return BIGC_OK;
+}

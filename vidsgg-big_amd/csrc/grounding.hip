@@ -434,7 +434,7 @@ int qanet(void* s, const Enc& E, const float* x, const float* pos, int n_seq, in
     }
     GTRY(glinear(s, ln, d, E.in_proj, w.qkv, 3 * d, rows, 3 * d, d, BIGC_ACT_NONE));
     GTRY(bigc_fill_offsets((hipStream_t)s, w.off, n_seq + 1, T));
-    GTRY(bigc_mha_core_f32(s, w.qkv, 3 * d, w.qkv + d, 3 * d, w.qkv + 2 * d, 3 * d, w.att, d, w.off, w.off, n_seq, T, 8, d / 8));
+    GTRY(bigc_mha_core_f32(s, w.qkv, 3 * d, w.qkv + d, 3 * d, w.qkv + 2 * d, 3 * d, w.att, d, w.off, w.off, n_seq, T, 8, d / 8, nullptr));
     GTRY(glinear(s, w.att, d, E.out_proj, nxt, d, rows, d, d, BIGC_ACT_NONE, res, d));        // attn + res
     res = nxt;
     GTRY(bigc_layernorm_f32(s, res, E.norme.w, E.norme.b, ln, rows, d, 1e-5f));

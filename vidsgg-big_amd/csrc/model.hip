@@ -9,35 +9,7 @@
 //   * all videos of the batch go through each kernel together (the reference loops per video,
 //     :376), attention kernels take per-video row offsets;
 //   * everything is stream-ordered on the caller's HIP stream, no host synchronisation.
-#include "common.h"
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-int bigc_fill_offsets(hipStream_t s, int32_t* p, int n, int step);
-int bigc_repack_conv_weight(hipStream_t s, const float* w, float* out, int n_out, int n_in, int taps);
-
-namespace {
-
-struct Lin { const float* w = nullptr; const float* b = nullptr; };
-struct LNp { const float* g = nullptr; const float* b = nullptr; };
-struct EncLayer { Lin in_proj, out_proj, l1, l2; LNp n1, n2; };
-struct DecLayer { Lin in_proj, out_proj, role0[2], role1[2], e2a, p2a, f0, f3; LNp n1, n2, n3; };
-
-}  // namespace
-
-struct bigc_model {
-    bigc_config cfg;
-    std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
-    bool finalized = false;
-    // resolved
-    const float *emb = nullptr, *pos = nullptr, *qinit = nullptr, *bias_matrix = nullptr;
-    Lin feat0, feat2, bbox0, bbox2, conv, enco0, enco2, i3d, head0, head2;
-    std::vector<EncLayer> enc;
-    std::vector<DecLayer> dec;
-    float* conv_w_tapmajor = nullptr;  // (de, 3*2de), owned
-    int head_k = 0;
-};
+#include "model_internal.h"
 
 namespace {
 
@@ -74,17 +46,6 @@ struct Resolver {
         l.w = get(p + ".in_proj_weight", (int64_t)3 * d * d);
         l.b = get(p + ".in_proj_bias", 3 * d);
         return l;
-    }
-};
-
-struct Arena {
-    char* base; size_t cap; size_t off = 0; bool overflow = false;
-    template <typename T> T* take(size_t n) {
-        size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
-        if (off + bytes > cap) { overflow = true; return nullptr; }
-        T* p = (T*)(base + off);
-        off += bytes;
-        return p;
     }
 };
 
@@ -148,13 +109,6 @@ Sizes sizes_of(const bigc_model* m, const bigc_batch* b) {
     return z;
 }
 
-#define TRY(expr) do { int rc_ = (expr); if (rc_ != BIGC_OK) return rc_; } while (0)
-
-inline int linear(void* s, const float* A, int lda, const Lin& l, float* C, int ldc, int M, int N, int K, int act,
-                  const float* res = nullptr, int ldr = 0) {
-    return bigc_linear_f32(s, A, lda, nullptr, 1, K, l.w, K, l.b, res, ldr, C, ldc, M, N, K, act);
-}
-
 }  // namespace
 
 extern "C" int bigc_create(const bigc_config* cfg, bigc_model** out) {
@@ -177,6 +131,7 @@ extern "C" int bigc_create(const bigc_config* cfg, bigc_model** out) {
 extern "C" void bigc_destroy(bigc_model* m) {
     if (!m) return;
     if (m->conv_w_tapmajor) (void)hipFree(m->conv_w_tapmajor);
+    if (m->conv_w_bwd) (void)hipFree(m->conv_w_bwd);
     delete m;
 }
 
@@ -304,7 +259,7 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         const EncLayer& L = m->enc[i];
         TRY(linear(s, x, de, L.in_proj, w.qkv, 3 * de, NT, 3 * de, de, BIGC_ACT_NONE));
         TRY(bigc_mha_core_f32(s, w.qkv, 3 * de, w.qkv + de, 3 * de, w.qkv + 2 * de, 3 * de, w.ao, de, b->vid_trk_off, b->vid_trk_off,
-                              B, b->max_trk, H, hd));
+                              B, b->max_trk, H, hd, nullptr));
         TRY(linear(s, w.ao, de, L.out_proj, w.t1, de, NT, de, de, BIGC_ACT_NONE, x, de));
         TRY(bigc_layernorm_f32(s, w.t1, L.n1.g, L.n1.b, w.x1, NT, de, eps));
         TRY(linear(s, w.x1, de, L.l1, w.fh, df, NT, df, de, BIGC_ACT_RELU));
@@ -331,7 +286,7 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         TRY(bigc_add_rows_f32(s, qin, m->pos, w.qk_in, rows, dp, Q));
         TRY(linear(s, w.qk_in, dp, qkp, w.qk, 2 * dp, rows, 2 * dp, dp, BIGC_ACT_NONE));
         TRY(linear(s, qin, dp, vp, w.vv, dp, rows, dp, dp, BIGC_ACT_NONE));
-        TRY(bigc_mha_core_f32(s, w.qk, 2 * dp, w.qk + dp, 2 * dp, w.vv, dp, w.ao2, dp, w.q_off, w.q_off, nseq, Q, H, dp / H));
+        TRY(bigc_mha_core_f32(s, w.qk, 2 * dp, w.qk + dp, 2 * dp, w.vv, dp, w.ao2, dp, w.q_off, w.q_off, nseq, Q, H, dp / H, nullptr));
         TRY(linear(s, w.ao2, dp, L.out_proj, w.t2, dp, rows, dp, dp, BIGC_ACT_NONE, qin, dp));
         TRY(bigc_layernorm_f32(s, w.t2, L.n1.g, L.n1.b, w.t3, rows, dp, eps));
         if (i == 0) {

@@ -1,0 +1,47 @@
+// Internal definitions shared by model.hip (eval forward) and train.hip (training forward/backward).
+#pragma once
+#include "common.h"
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+struct Lin { const float* w = nullptr; const float* b = nullptr; };
+struct LNp { const float* g = nullptr; const float* b = nullptr; };
+struct EncLayer { Lin in_proj, out_proj, l1, l2; LNp n1, n2; };
+struct DecLayer { Lin in_proj, out_proj, role0[2], role1[2], e2a, p2a, f0, f3; LNp n1, n2, n3; };
+
+struct bigc_model {
+    bigc_config cfg;
+    std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
+    std::unordered_map<std::string, float*> grads;      // gradient destination of each trainable parameter (training)
+    bool finalized = false;
+    // resolved
+    const float *emb = nullptr, *pos = nullptr, *qinit = nullptr, *bias_matrix = nullptr;
+    Lin feat0, feat2, bbox0, bbox2, conv, enco0, enco2, i3d, head0, head2;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+    float* conv_w_tapmajor = nullptr;  // (de, 3*2de), owned
+    float* conv_w_bwd = nullptr;       // (2de, 3*de), owned (training)
+    int head_k = 0;
+};
+
+struct Arena {
+    char* base; size_t cap; size_t off = 0; bool overflow = false;
+    template <typename T> T* take(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        if (off + bytes > cap) { overflow = true; return nullptr; }
+        T* p = (T*)(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != BIGC_OK) return rc_; } while (0)
+
+inline int linear(void* s, const float* A, int lda, const Lin& l, float* C, int ldc, int M, int N, int K, int act,
+                  const float* res = nullptr, int ldr = 0) {
+    return bigc_linear_f32(s, A, lda, nullptr, 1, K, l.w, K, l.b, res, ldr, C, ldc, M, N, K, act);
+}
+
+int bigc_fill_offsets(hipStream_t s, int32_t* p, int n, int step);
+int bigc_repack_conv_weight(hipStream_t s, const float* w, float* out, int n_out, int n_in, int taps);

@@ -1,0 +1,482 @@
+// BIG-C training step on the HIP path: forward with saved activations and the full backward pass
+// (the autograd graph of the reference's ``_forward_train``: models/model_0v10.py:510-556 through
+// encode2decode :434-475 and prediction_head :478-507; VidOR variant models/model_0v7.py).
+//
+// Dropout is not applied (parity is defined with the reference modules in eval() mode).  All gradients
+// are ACCUMULATED into the destinations registered with bigc_set_grad (one flat buffer on the host side,
+// which is also the message of the per-step RCCL all-reduce).
+#include "model_internal.h"
+#include "prof.h"
+
+// internal launchers defined in backward.hip
+int bigc_repack_conv_weight_bwd(hipStream_t s, const float* w, float* out, int n_out, int n_in, int taps);
+int bigc_head_gather_bwd(hipStream_t s, const float* dhead, int ld, const int32_t* soid, const int32_t* e_off, const int32_t* trk_vid,
+                         int n_trk, int nq, int n_seg, float* const* dst, const int* width, const int* col);
+int bigc_bias_matrix_bwd(hipStream_t s, const float* dlogits, int ldg, const int32_t* soid, const int32_t* e_off, const int32_t* trk_cat,
+                         int n_vid, int nq, int n_ecat, int n_pcat, float* dbias);
+int bigc_copy_cols(hipStream_t s, const float* src, int lds_, float* dst, int ldd, long rows, int cols);
+int bigc_conv_grad_unpack(hipStream_t s, const float* g_tapmajor, float* g_torch, int n_out, int n_in, int taps);
+int bigc_transpose_pad(hipStream_t s, const float* in, float* out, int rows, int cols, int ld_out);
+
+extern "C" int bigc_transpose_f32(void* stream, const float* in, float* out, int rows, int cols);
+extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const float* X, int ldx, const int32_t* x_idx, int nseg,
+                                  int seg_len, float* dW, int ldw, float* db, int M, int N, int K);
+extern "C" int bigc_relu_bwd_f32(void* stream, float* dY, const float* Y, long n);
+extern "C" int bigc_axpy_f32(void* stream, float* y, const float* x, long n);
+extern "C" int bigc_layernorm_bwd_f32(void* stream, const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
+                                      float* dbeta, int rows, int d, float eps);
+extern "C" int bigc_reduce_periodic_f32(void* stream, const float* x, float* out, int rows, int d, int period);
+extern "C" int bigc_maxpool_bwd_f32(void* stream, const float* conv, const int32_t* trk_conv_off, const float* dpooled, float* dconv,
+                                    int n_trk, int d, int P);
+extern "C" int bigc_conv_gather_bwd_f32(void* stream, const float* dconv, const int32_t* trk_row_off, const int32_t* trk_conv_off,
+                                        const int32_t* trk_vid, const int32_t* vid_tmax, float* G, int n_trk, int d);
+extern "C" int bigc_mha_bwd_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                const float* o, int ldo, const float* dO, int lddo, const float* lse, float* delta_scratch,
+                                float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                                const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
+                                int n_head, int hd);
+extern "C" int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt,
+                                           float* ds, const int32_t* e_off, int n_vid, int nq, int half, float scale);
+extern "C" int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1,
+                                        const float* enco_or_e2a, int ld2, float* out, int ldo, const int32_t* e_off, int n_vid, int nq,
+                                        int d, int half, int max_trk);
+
+namespace {
+
+struct EncS { float *qkv, *lse, *ao, *t1, *x1, *fh, *t1b, *out; };
+struct DecS { float *qin, *qk_in, *qk, *vv, *lse, *ao2, *t2, *q2, *e2a, *p2a, *att, *vals, *rh0, *rh1, *t3b, *q3, *f, *t3c, *qout; };
+
+struct TrainWork {
+    // saved by the forward
+    float *bbox8, *hb, *hv, *enti, *conv, *pooled, *eh, *e2e, *xmean, *i3dfc, *head_in, *bias_g, *hh, *t3tmp, *rtmp;
+    int32_t *conv_idx, *q_off, *soid;
+    std::vector<EncS> enc;
+    std::vector<DecS> dec;
+    // backward scratch
+    float *gq, *ga, *gb, *gc, *gqk, *gvals, *gp2a, *ghead, *ghh, *gatt, *ds, *genco, *ge2e, *gx, *gy, *gz, *gqkv, *ge2a, *gi3d,
+          *gpooled, *delta, *gconv, *G, *genti, *gh, *wT, *gconvw;
+};
+
+struct TSizes { size_t R, NT, C, B, Q, BQ; };
+
+int round4(int x) { return (x + 3) & ~3; }
+
+bool train_layout(const bigc_model* m, const TSizes& z, Arena& a, TrainWork& w) {
+    const bigc_config& c = m->cfg;
+    const size_t de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn, H = c.n_att_head;
+    const size_t mx = dp > df ? dp : df;
+    w.bbox8 = a.take<float>(z.R * 8);
+    w.hb = a.take<float>(z.R * de);
+    w.hv = a.take<float>(z.R * de);
+    w.enti = a.take<float>(z.R * 2 * de);
+    w.conv_idx = a.take<int32_t>(z.C * 3);
+    w.conv = a.take<float>(z.C * de);
+    w.pooled = a.take<float>(z.NT * de * c.enco_pool_len);
+    w.eh = a.take<float>(z.NT * de);
+    w.e2e = a.take<float>(z.NT * de);
+    w.enc.assign(c.n_enco_layers, EncS());
+    for (auto& e : w.enc) {
+        e.qkv = a.take<float>(z.NT * 3 * de); e.lse = a.take<float>(z.NT * H); e.ao = a.take<float>(z.NT * de);
+        e.t1 = a.take<float>(z.NT * de); e.x1 = a.take<float>(z.NT * de); e.fh = a.take<float>(z.NT * df);
+        e.t1b = a.take<float>(z.NT * de); e.out = a.take<float>(z.NT * de);
+    }
+    w.q_off = a.take<int32_t>(z.B + 1);
+    w.dec.assign(c.n_deco_layers, DecS());
+    for (auto& d : w.dec) {
+        d.qin = a.take<float>(z.BQ * dp); d.qk_in = a.take<float>(z.BQ * dp); d.qk = a.take<float>(z.BQ * 2 * dp);
+        d.vv = a.take<float>(z.BQ * dp); d.lse = a.take<float>(z.BQ * H); d.ao2 = a.take<float>(z.BQ * dp);
+        d.t2 = a.take<float>(z.BQ * dp); d.q2 = a.take<float>(z.BQ * dp); d.e2a = a.take<float>(z.NT * da);
+        d.p2a = a.take<float>(z.BQ * da); d.att = a.take<float>(2 * z.Q * z.NT); d.vals = a.take<float>(2 * z.BQ * de);
+        d.rh0 = a.take<float>(z.BQ * dp); d.rh1 = a.take<float>(z.BQ * dp); d.t3b = a.take<float>(z.BQ * dp);
+        d.q3 = a.take<float>(z.BQ * dp); d.f = a.take<float>(z.BQ * df); d.t3c = a.take<float>(z.BQ * dp);
+        d.qout = a.take<float>(z.BQ * dp);
+    }
+    w.t3tmp = a.take<float>(z.BQ * dp);
+    w.rtmp = a.take<float>(z.BQ * dp);
+    w.xmean = a.take<float>(z.NT * (c.dim_extra > 0 ? c.dim_extra : 1));
+    w.i3dfc = a.take<float>(z.NT * de);
+    w.head_in = a.take<float>(z.BQ * (size_t)m->head_k);
+    w.bias_g = a.take<float>(z.BQ * c.num_pred_cats);
+    w.hh = a.take<float>(z.BQ * df);
+    w.soid = a.take<int32_t>(z.B * 2 * z.Q);
+    // backward scratch
+    w.gq = a.take<float>(z.BQ * mx); w.ga = a.take<float>(z.BQ * mx); w.gb = a.take<float>(z.BQ * mx); w.gc = a.take<float>(z.BQ * mx);
+    w.gqk = a.take<float>(z.BQ * 2 * dp);
+    w.gvals = a.take<float>(2 * z.BQ * de);
+    w.gp2a = a.take<float>(z.BQ * da);
+    w.ghead = a.take<float>(z.BQ * (size_t)m->head_k);
+    w.ghh = a.take<float>(z.BQ * df);
+    w.gatt = a.take<float>(2 * z.Q * z.NT);
+    w.ds = a.take<float>(2 * z.Q * z.NT);
+    w.genco = a.take<float>(z.NT * de); w.ge2e = a.take<float>(z.NT * de);
+    w.gx = a.take<float>(z.NT * mx); w.gy = a.take<float>(z.NT * mx); w.gz = a.take<float>(z.NT * mx);
+    w.gqkv = a.take<float>(z.NT * 3 * de);
+    w.ge2a = a.take<float>(z.NT * da);
+    w.gi3d = a.take<float>(z.NT * de);
+    w.gpooled = a.take<float>(z.NT * de * c.enco_pool_len);
+    w.delta = a.take<float>((z.BQ > z.NT ? z.BQ : z.NT) * H);
+    w.gconv = a.take<float>(z.C * de);
+    w.G = a.take<float>(z.R * 3 * de);
+    w.genti = a.take<float>(z.R * 2 * de);
+    w.gh = a.take<float>(z.R * de);
+    size_t wmax = (size_t)m->head_k * round4(c.num_pred_cats);
+    const size_t cand[] = {(size_t)de * c.enco_pool_len * de, (size_t)3 * de * de, (size_t)3 * dp * dp, (size_t)df * round4(c.num_pred_cats),
+                           (size_t)df * m->head_k, (size_t)da * de, (size_t)df * dp};
+    for (size_t v : cand) if (v > wmax) wmax = v;
+    w.wT = a.take<float>(wmax);
+    w.gconvw = a.take<float>((size_t)de * 6 * de);
+    return !a.overflow;
+}
+
+TSizes tsizes(const bigc_model* m, const bigc_batch* b) {
+    TSizes z;
+    z.R = b->n_rows; z.NT = b->n_trk; z.C = b->n_conv; z.B = b->n_vid; z.Q = m->cfg.num_querys; z.BQ = z.B * z.Q;
+    return z;
+}
+
+float* grad_of(bigc_model* m, const std::string& key) {
+    auto it = m->grads.find(key);
+    return it == m->grads.end() ? nullptr : it->second;
+}
+
+// Backward helper of y = act(x W^T + b) (+ residual): given dY (already masked for ReLU by the caller)
+//   dW += dY^T X, db += colsum(dY), and (optionally) dX (=|+=) dY W.
+struct Bwd {
+    bigc_model* m; void* s; TrainWork* w;
+    int lin(const std::string& key, const Lin& L, const float* dY, int ldy, const float* X, int ldx, int M, int N, int K,
+            float* dX, int lddx, bool accumulate_dx) {
+        float* gw = grad_of(m, key + ".weight");
+        float* gb = grad_of(m, key + ".bias");
+        if (gw) TRY(bigc_linear_dw_f32(s, dY, ldy, X, ldx, nullptr, 1, K, gw, K, gb, M, N, K));
+        if (dX) TRY(dx(L.w, dY, ldy, M, N, K, dX, lddx, accumulate_dx));
+        return BIGC_OK;
+    }
+    // dX[M,K] (=|+=) dY[M,N] W[N,K] through a transposed, 4-padded copy of W
+    int dx(const float* W, const float* dY, int ldy, int M, int N, int K, float* dX, int lddx, bool accumulate) {
+        const int n4 = round4(N);
+        BIGC_CHECK_ARG(ldy % 4 == 0 && ldy >= n4, "train: dY leading dimension %d must be a multiple of 4 and >= %d", ldy, n4);
+        TRY(bigc_transpose_pad((hipStream_t)s, W, w->wT, N, K, n4));
+        return bigc_linear_f32(s, dY, ldy, nullptr, 1, n4, w->wT, n4, nullptr, accumulate ? dX : nullptr, lddx, dX, lddx, M, K, n4,
+                               BIGC_ACT_NONE);
+    }
+};
+
+}  // namespace
+
+extern "C" int bigc_set_grad(bigc_model* m, const char* key, float* ptr) {
+    BIGC_CHECK_ARG(m && key, "set_grad: bad argument");
+    if (ptr) m->grads[key] = ptr; else m->grads.erase(key);
+    return BIGC_OK;
+}
+
+extern "C" size_t bigc_train_workspace_bytes(const bigc_model* m, const bigc_batch* b) {
+    if (!m || !b) return 0;
+    Arena a{nullptr, (size_t)-1};
+    TrainWork w;
+    train_layout(m, tsizes(m, b), a, w);
+    return a.off + 256;
+}
+
+static int open_arena(const bigc_model* m, const bigc_batch* b, void* workspace, size_t workspace_bytes, TrainWork& w) {
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (!workspace || workspace_bytes < (size_t)(base - (char*)workspace)) return bigc_fail(BIGC_ERR_WORKSPACE, "train: no workspace");
+    Arena a{base, workspace_bytes - (size_t)(base - (char*)workspace)};
+    if (!train_layout(m, tsizes(m, b), a, w))
+        return bigc_fail(BIGC_ERR_WORKSPACE, "train: workspace of %zu bytes too small, need %zu", workspace_bytes, bigc_train_workspace_bytes(m, b));
+    return BIGC_OK;
+}
+
+extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
+                                  float* pred_logits, float* att_out) {
+    BIGC_CHECK_ARG(m && b && pred_logits && att_out, "train_forward: null pointer");
+    BIGC_CHECK_ARG(m->finalized, "train_forward: call bigc_finalize first");
+    BIGC_CHECK_ARG(b->n_vid > 0 && b->n_trk > 0 && b->n_rows > 0 && b->n_conv > 0 && b->max_trk > 0 && b->max_trk <= 512, "train_forward: bad batch");
+    const bigc_config& c = m->cfg;
+    TrainWork w;
+    TRY(open_arena(m, b, workspace, workspace_bytes, w));
+    void* s = stream;
+    hipStream_t hs = (hipStream_t)stream;
+    const int R = b->n_rows, NT = b->n_trk, C = b->n_conv, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
+    const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn, D = c.dim_feat + c.dim_extra, H = c.n_att_head, hd = de / H;
+    const float eps = 1e-5f;
+
+    TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
+    TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
+    TRY(linear(s, w.hb, de, m->bbox2, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
+    TRY(linear(s, b->feats, D, m->feat0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
+    TRY(linear(s, w.hv, de, m->feat2, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
+    TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
+    TRY(bigc_linear_f32(s, w.enti, 2 * de, w.conv_idx, 3, 2 * de, m->conv_w_tapmajor, 6 * de, m->conv.b, nullptr, 0, w.conv, de, C, de,
+                        6 * de, BIGC_ACT_NONE));
+    TRY(bigc_adaptive_maxpool(s, w.conv, b->trk_conv_off, w.pooled, NT, de, c.enco_pool_len));
+    TRY(linear(s, w.pooled, de * c.enco_pool_len, m->enco0, w.eh, de, NT, de, de * c.enco_pool_len, BIGC_ACT_RELU));
+    TRY(linear(s, w.eh, de, m->enco2, w.e2e, de, NT, de, de, BIGC_ACT_RELU));
+
+    const float* x = w.e2e;
+    for (int i = 0; i < c.n_enco_layers; ++i) {
+        const EncLayer& L = m->enc[i];
+        EncS& S = w.enc[i];
+        TRY(linear(s, x, de, L.in_proj, S.qkv, 3 * de, NT, 3 * de, de, BIGC_ACT_NONE));
+        TRY(bigc_mha_core_f32(s, S.qkv, 3 * de, S.qkv + de, 3 * de, S.qkv + 2 * de, 3 * de, S.ao, de, b->vid_trk_off, b->vid_trk_off, B,
+                              b->max_trk, H, hd, S.lse));
+        TRY(linear(s, S.ao, de, L.out_proj, S.t1, de, NT, de, de, BIGC_ACT_NONE, x, de));
+        TRY(bigc_layernorm_f32(s, S.t1, L.n1.g, L.n1.b, S.x1, NT, de, eps));
+        TRY(linear(s, S.x1, de, L.l1, S.fh, df, NT, df, de, BIGC_ACT_RELU));
+        TRY(linear(s, S.fh, df, L.l2, S.t1b, de, NT, de, df, BIGC_ACT_NONE, S.x1, de));
+        TRY(bigc_layernorm_f32(s, S.t1b, L.n2.g, L.n2.b, S.out, NT, de, eps));
+        x = S.out;
+    }
+    const float* enco = x;
+
+    TRY(bigc_fill_offsets(hs, w.q_off, B + 1, Q));
+    const float att_scale = 1.0f / sqrtf((float)de);
+    const float* qprev = nullptr;
+    for (int i = 0; i < c.n_deco_layers; ++i) {
+        const DecLayer& L = m->dec[i];
+        DecS& S = w.dec[i];
+        Lin qkp{L.in_proj.w, L.in_proj.b};
+        Lin vp{L.in_proj.w + (size_t)2 * dp * dp, L.in_proj.b + 2 * dp};
+        const int rows = (i == 0) ? Q : BQ, nseq = (i == 0) ? 1 : B;
+        const float* qin = (i == 0) ? m->qinit : qprev;
+        TRY(bigc_add_rows_f32(s, qin, m->pos, S.qk_in, rows, dp, Q));
+        TRY(linear(s, S.qk_in, dp, qkp, S.qk, 2 * dp, rows, 2 * dp, dp, BIGC_ACT_NONE));
+        TRY(linear(s, qin, dp, vp, S.vv, dp, rows, dp, dp, BIGC_ACT_NONE));
+        TRY(bigc_mha_core_f32(s, S.qk, 2 * dp, S.qk + dp, 2 * dp, S.vv, dp, S.ao2, dp, w.q_off, w.q_off, nseq, Q, H, dp / H, S.lse));
+        TRY(linear(s, S.ao2, dp, L.out_proj, S.t2, dp, rows, dp, dp, BIGC_ACT_NONE, qin, dp));
+        TRY(bigc_layernorm_f32(s, S.t2, L.n1.g, L.n1.b, w.t3tmp, rows, dp, eps));
+        if (i == 0) {
+            TRY(bigc_add_rows_f32(s, w.t3tmp, m->pos, w.rtmp, Q, dp, Q));
+            TRY(bigc_add_rows_f32(s, nullptr, w.rtmp, S.q2, BQ, dp, Q));
+        } else {
+            TRY(bigc_add_rows_f32(s, w.t3tmp, m->pos, S.q2, BQ, dp, Q));
+        }
+        TRY(linear(s, enco, de, L.e2a, S.e2a, da, NT, da, de, BIGC_ACT_NONE));
+        TRY(linear(s, S.q2, dp, L.p2a, S.p2a, da, BQ, da, dp, BIGC_ACT_NONE));
+        TRY(bigc_role_attention_f32(s, S.p2a, da, S.e2a, da, S.att, b->vid_trk_off, B, Q, da / 2, att_scale));
+        TRY(bigc_role_values_f32(s, S.att, enco, de, S.vals, b->vid_trk_off, B, Q, de));
+        TRY(linear(s, S.vals, de, L.role0[0], S.rh0, dp, BQ, dp, de, BIGC_ACT_RELU));
+        TRY(linear(s, S.rh0, dp, L.role0[1], w.rtmp, dp, BQ, dp, dp, BIGC_ACT_NONE, S.q2, dp));
+        TRY(linear(s, S.vals + (size_t)BQ * de, de, L.role1[0], S.rh1, dp, BQ, dp, de, BIGC_ACT_RELU));
+        TRY(linear(s, S.rh1, dp, L.role1[1], S.t3b, dp, BQ, dp, dp, BIGC_ACT_NONE, w.rtmp, dp));
+        TRY(bigc_layernorm_f32(s, S.t3b, L.n2.g, L.n2.b, S.q3, BQ, dp, eps));
+        TRY(linear(s, S.q3, dp, L.f0, S.f, df, BQ, df, dp, BIGC_ACT_RELU));
+        TRY(linear(s, S.f, df, L.f3, S.t3c, dp, BQ, dp, df, BIGC_ACT_NONE, S.q3, dp));
+        TRY(bigc_layernorm_f32(s, S.t3c, L.n3.g, L.n3.b, S.qout, BQ, dp, eps));
+        qprev = S.qout;
+    }
+    const DecS& last = w.dec[c.n_deco_layers - 1];
+
+    const float* seg_src[4];
+    int32_t seg_w[4], seg_cat[4];
+    int n_seg = 0;
+    if (c.variant == 0) {
+        if (c.dim_extra > 0) {
+            TRY(bigc_stretched_mean(s, b->feats, D, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, w.xmean, NT));
+            TRY(linear(s, w.xmean, c.dim_extra, m->i3d, w.i3dfc, de, NT, de, c.dim_extra, BIGC_ACT_RELU));
+            seg_src[n_seg] = w.i3dfc; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
+            seg_src[n_seg] = w.e2e; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
+            seg_src[n_seg] = m->emb; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 1;
+        } else {
+            seg_src[n_seg] = m->emb; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 1;
+            seg_src[n_seg] = w.e2e; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
+        }
+    } else {
+        if (c.use_clsme) {
+            if (c.has_enti_emb) {
+                seg_src[n_seg] = m->emb; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 1;
+            } else {
+                TRY(bigc_stretched_mean(s, b->feats, D, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, w.xmean, NT));
+                seg_src[n_seg] = w.xmean; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 0;
+            }
+        }
+        seg_src[n_seg] = w.e2e; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
+    }
+    TRY(bigc_head_gather(s, last.att, b->vid_trk_off, b->trk_cat, B, Q, last.qout, dp, n_seg, seg_src, seg_w, seg_cat, m->bias_matrix,
+                         c.num_enti_cats, c.num_pred_cats, w.soid, w.head_in, m->head_k, w.bias_g));
+    if (c.variant == 0) {
+        TRY(linear(s, w.head_in, m->head_k, m->head0, pred_logits, c.num_pred_cats, BQ, c.num_pred_cats, m->head_k, BIGC_ACT_NONE, w.bias_g,
+                   c.num_pred_cats));
+    } else {
+        TRY(linear(s, w.head_in, m->head_k, m->head0, w.hh, df, BQ, df, m->head_k, BIGC_ACT_RELU));
+        TRY(linear(s, w.hh, df, m->head2, pred_logits, c.num_pred_cats, BQ, c.num_pred_cats, df, BIGC_ACT_NONE, w.bias_g, c.num_pred_cats));
+    }
+    hipError_t e = hipMemcpyAsync(att_out, last.att, sizeof(float) * (size_t)2 * Q * NT, hipMemcpyDeviceToDevice, hs);
+    if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_forward: memcpy: %s", hipGetErrorString(e));
+    return BIGC_OK;
+}
+
+#define ZERO(ptr, count) do { hipError_t e_ = hipMemsetAsync((ptr), 0, sizeof(float) * (size_t)(count), hs); \
+    if (e_ != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: memset: %s", hipGetErrorString(e_)); } while (0)
+
+extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
+                                   const float* dlogits, int ldg, const float* datt) {
+    BIGC_CHECK_ARG(m && b && dlogits && datt, "train_backward: null pointer");
+    const bigc_config& c = m->cfg;
+    BIGC_CHECK_ARG(ldg == round4(c.num_pred_cats), "train_backward: dlogits must have leading dimension %d (zero padded)", round4(c.num_pred_cats));
+    TrainWork w;
+    TRY(open_arena(m, b, workspace, workspace_bytes, w));
+    void* s = stream;
+    hipStream_t hs = (hipStream_t)stream;
+    const int R = b->n_rows, NT = b->n_trk, C = b->n_conv, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
+    const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn, D = c.dim_feat + c.dim_extra, H = c.n_att_head, hd = de / H;
+    const int P = c.num_pred_cats, HK = m->head_k;
+    const float eps = 1e-5f;
+    Bwd bw{m, s, &w};
+    const float att_scale = 1.0f / sqrtf((float)de);
+
+    // ---- head (models/model_0v10.py:478-507 / model_0v7.py:483-513) ---------------------------------
+    if (float* gbm = grad_of(m, "bias_matrix"))
+        TRY(bigc_bias_matrix_bwd(hs, dlogits, ldg, w.soid, b->vid_trk_off, b->trk_cat, B, Q, c.num_enti_cats, P, gbm));
+    if (c.variant == 0) {
+        TRY(bw.lin("fc_pred2logits", m->head0, dlogits, ldg, w.head_in, HK, BQ, P, HK, w.ghead, HK, false));
+    } else {
+        TRY(bw.lin("fc_pred2logits.2", m->head2, dlogits, ldg, w.hh, df, BQ, P, df, w.ghh, df, false));
+        TRY(bigc_relu_bwd_f32(s, w.ghh, w.hh, (long)BQ * df));
+        TRY(bw.lin("fc_pred2logits.0", m->head0, w.ghh, df, w.head_in, HK, BQ, df, HK, w.ghead, HK, false));
+    }
+    TRY(bigc_copy_cols(hs, w.ghead, HK, w.gq, dp, BQ, dp));                   // d query of the last decoder layer
+    ZERO(w.ge2e, (size_t)NT * de);
+    {
+        float* dst[4]; int width[4], col[4]; int ns = 0; int colp = dp;
+        const bool i3d = c.variant == 0 && c.dim_extra > 0;
+        if (i3d) { ZERO(w.gi3d, (size_t)NT * de); dst[ns] = w.gi3d; width[ns] = de; col[ns++] = colp; colp += 2 * de; }
+        if (c.variant == 0) {
+            if (i3d) { dst[ns] = w.ge2e; width[ns] = de; col[ns++] = colp; }
+            else { colp += 2 * c.dim_clsme; dst[ns] = w.ge2e; width[ns] = de; col[ns++] = colp; }
+        } else {
+            if (c.use_clsme) colp += 2 * c.dim_clsme;
+            dst[ns] = w.ge2e; width[ns] = de; col[ns++] = colp;
+        }
+        TRY(bigc_head_gather_bwd(hs, w.ghead, HK, w.soid, b->vid_trk_off, b->trk_vid, NT, Q, ns, dst, width, col));
+        if (i3d) {
+            TRY(bigc_relu_bwd_f32(s, w.gi3d, w.i3dfc, (long)NT * de));
+            TRY(bw.lin("fc_i3d.0", m->i3d, w.gi3d, de, w.xmean, c.dim_extra, NT, de, c.dim_extra, nullptr, 0, false));
+        }
+    }
+
+    // ---- decoder, last layer first (models/model_0v10.py:178-225) --------------------------------------
+    ZERO(w.genco, (size_t)NT * de);
+    float* gpos = grad_of(m, "pos_embedding");
+    for (int i = c.n_deco_layers - 1; i >= 0; --i) {
+        const DecLayer& L = m->dec[i];
+        DecS& S = w.dec[i];
+        const std::string p = "decoder_layers." + std::to_string(i);
+        // w.gq = d qout
+        TRY(bigc_layernorm_bwd_f32(s, S.t3c, L.n3.g, w.gq, w.ga, grad_of(m, p + ".norm3.weight"), grad_of(m, p + ".norm3.bias"), BQ, dp, eps));
+        // ga = d t3c ; t3c = f W3^T + b + q3
+        TRY(bw.lin(p + ".fc2.3", L.f3, w.ga, dp, S.f, df, BQ, dp, df, w.gb, df, false));       // gb = d f
+        TRY(bigc_relu_bwd_f32(s, w.gb, S.f, (long)BQ * df));
+        TRY(bw.lin(p + ".fc2.0", L.f0, w.gb, df, S.q3, dp, BQ, df, dp, w.ga, dp, true));       // ga = d q3 (residual + ffn path)
+        TRY(bigc_layernorm_bwd_f32(s, S.t3b, L.n2.g, w.ga, w.gb, grad_of(m, p + ".norm2.weight"), grad_of(m, p + ".norm2.bias"), BQ, dp, eps));
+        // gb = d t3b = d(rh1 W^T + b1 + rh0 W^T + b0 + q2)
+        TRY(bw.lin(p + ".fc_rolewise.1.2", L.role1[1], w.gb, dp, S.rh1, dp, BQ, dp, dp, w.gc, dp, false));   // gc = d rh1
+        TRY(bigc_relu_bwd_f32(s, w.gc, S.rh1, (long)BQ * dp));
+        TRY(bw.lin(p + ".fc_rolewise.1.0", L.role1[0], w.gc, dp, S.vals + (size_t)BQ * de, de, BQ, dp, de, w.gvals + (size_t)BQ * de, de, false));
+        TRY(bw.lin(p + ".fc_rolewise.0.2", L.role0[1], w.gb, dp, S.rh0, dp, BQ, dp, dp, w.gc, dp, false));   // gc = d rh0
+        TRY(bigc_relu_bwd_f32(s, w.gc, S.rh0, (long)BQ * dp));
+        TRY(bw.lin(p + ".fc_rolewise.0.0", L.role0[0], w.gc, dp, S.vals, de, BQ, dp, de, w.gvals, de, false));
+        // gb stays = d q2 (residual path); values = att @ enco
+        const float* enco = w.enc[c.n_enco_layers - 1].out;
+        TRY(bigc_role_small_gemm_f32(s, 0, nullptr, w.gvals, de, enco, de, w.gatt, 0, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
+        if (i == c.n_deco_layers - 1) TRY(bigc_axpy_f32(s, w.gatt, datt, (long)2 * Q * NT));
+        TRY(bigc_role_small_gemm_f32(s, 1, S.att, w.gvals, de, nullptr, de, w.genco, de, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
+        TRY(bigc_role_attention_bwd_f32(s, S.p2a, da, S.e2a, da, w.gatt, w.ds, b->vid_trk_off, B, Q, da / 2, att_scale));
+        TRY(bigc_role_small_gemm_f32(s, 2, w.ds, nullptr, 0, S.e2a, da, w.gp2a, da, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
+        TRY(bigc_role_small_gemm_f32(s, 3, w.ds, S.p2a, da, nullptr, 0, w.ge2a, da, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
+        TRY(bw.lin(p + ".fc_pred2att", L.p2a, w.gp2a, da, S.q2, dp, BQ, da, dp, w.gb, dp, true));           // gb = d q2 total
+        TRY(bw.lin(p + ".fc_enti2att", L.e2a, w.ge2a, da, enco, de, NT, da, de, w.genco, de, true));
+        // q2 = LN1(t2) + pos
+        if (gpos) TRY(bigc_reduce_periodic_f32(s, w.gb, gpos, BQ, dp, Q));
+        const int rows = (i == 0) ? Q : BQ, nseq = (i == 0) ? 1 : B;
+        const float* gt3 = w.gb;
+        if (i == 0) {       // the self-attention block was evaluated once on Q rows and tiled: sum the gradient over the videos
+            ZERO(w.gc, (size_t)Q * dp);
+            TRY(bigc_reduce_periodic_f32(s, w.gb, w.gc, BQ, dp, Q));
+            gt3 = w.gc;
+        }
+        TRY(bigc_layernorm_bwd_f32(s, S.t2, L.n1.g, gt3, w.ga, grad_of(m, p + ".norm1.weight"), grad_of(m, p + ".norm1.bias"), rows, dp, eps));
+        // ga = d t2 ; t2 = ao2 Wo^T + b + qin
+        const float* qin = (i == 0) ? m->qinit : w.dec[i - 1].qout;
+        TRY(bw.lin(p + ".self_attn.out_proj", L.out_proj, w.ga, dp, S.ao2, dp, rows, dp, dp, w.gq, dp, false));   // gq = d ao2
+        float* gvv = w.gc;                                    // gb / gc are free again once LayerNorm-1 consumed gt3
+        TRY(bigc_mha_bwd_f32(s, S.qk, 2 * dp, S.qk + dp, 2 * dp, S.vv, dp, S.ao2, dp, w.gq, dp, S.lse, w.delta, w.gqk, 2 * dp, w.gqk + dp,
+                             2 * dp, gvv, dp, w.q_off, w.q_off, nseq, Q, Q, rows, H, dp / H));
+        // in_proj: [q;k] rows from qk_in, v rows from qin
+        {
+            float* gw = grad_of(m, p + ".self_attn.in_proj_weight");
+            float* gbias = grad_of(m, p + ".self_attn.in_proj_bias");
+            if (gw) {
+                TRY(bigc_linear_dw_f32(s, w.gqk, 2 * dp, S.qk_in, dp, nullptr, 1, dp, gw, dp, gbias, rows, 2 * dp, dp));
+                TRY(bigc_linear_dw_f32(s, gvv, dp, qin, dp, nullptr, 1, dp, gw + (size_t)2 * dp * dp, dp, gbias ? gbias + 2 * dp : nullptr, rows, dp, dp));
+            }
+        }
+        // d qin = d t2 (residual) + d vv Wv + d qk_in ; d qk_in = d qk Wqk ; d pos += d qk_in
+        TRY(bw.dx(L.in_proj.w + (size_t)2 * dp * dp, gvv, dp, rows, dp, dp, w.ga, dp, true));
+        TRY(bw.dx(L.in_proj.w, w.gqk, 2 * dp, rows, 2 * dp, dp, w.gq, dp, false));                         // gq = d qk_in
+        if (gpos) TRY(bigc_reduce_periodic_f32(s, w.gq, gpos, rows, dp, Q));
+        TRY(bigc_axpy_f32(s, w.ga, w.gq, (long)rows * dp));                                                  // ga = d qin
+        if (i == 0) {
+            if (float* gqi = grad_of(m, "pred_query_init")) TRY(bigc_reduce_periodic_f32(s, w.ga, gqi, Q, dp, Q));
+        } else {
+            float* t = w.gq; w.gq = w.ga; w.ga = t;                                                          // gq = d qout of layer i-1
+        }
+    }
+
+    // ---- encoder (models/model_0v10.py:103-117) ---------------------------------------------------------
+    float* gx = w.genco;        // d output of the current encoder layer (NT, de); scratch: w.gx, w.gy, w.gz
+    for (int i = c.n_enco_layers - 1; i >= 0; --i) {
+        const EncLayer& L = m->enc[i];
+        EncS& S = w.enc[i];
+        const std::string p = "encoder_layers." + std::to_string(i);
+        const float* xin = (i == 0) ? w.e2e : w.enc[i - 1].out;
+        TRY(bigc_layernorm_bwd_f32(s, S.t1b, L.n2.g, gx, w.gx, grad_of(m, p + ".norm2.weight"), grad_of(m, p + ".norm2.bias"), NT, de, eps));
+        TRY(bw.lin(p + ".linear2", L.l2, w.gx, de, S.fh, df, NT, de, df, w.gy, df, false));          // gy = d fh
+        TRY(bigc_relu_bwd_f32(s, w.gy, S.fh, (long)NT * df));
+        TRY(bw.lin(p + ".linear1", L.l1, w.gy, df, S.x1, de, NT, df, de, w.gx, de, true));           // gx = d x1
+        TRY(bigc_layernorm_bwd_f32(s, S.t1, L.n1.g, w.gx, w.gy, grad_of(m, p + ".norm1.weight"), grad_of(m, p + ".norm1.bias"), NT, de, eps));
+        // gy = d t1 = d(ao Wo^T + b + xin)
+        TRY(bw.lin(p + ".self_attn.out_proj", L.out_proj, w.gy, de, S.ao, de, NT, de, de, w.gz, de, false));   // gz = d ao
+        TRY(bigc_mha_bwd_f32(s, S.qkv, 3 * de, S.qkv + de, 3 * de, S.qkv + 2 * de, 3 * de, S.ao, de, w.gz, de, S.lse, w.delta, w.gqkv, 3 * de,
+                             w.gqkv + de, 3 * de, w.gqkv + 2 * de, 3 * de, b->vid_trk_off, b->vid_trk_off, B, b->max_trk, b->max_trk, NT, H, hd));
+        {
+            float* gw = grad_of(m, p + ".self_attn.in_proj_weight");
+            float* gbias = grad_of(m, p + ".self_attn.in_proj_bias");
+            if (gw) TRY(bigc_linear_dw_f32(s, w.gqkv, 3 * de, xin, de, nullptr, 1, de, gw, de, gbias, NT, 3 * de, de));
+        }
+        TRY(bw.dx(L.in_proj.w, w.gqkv, 3 * de, NT, 3 * de, de, w.gy, de, true));                      // gy = d xin
+        hipError_t e = hipMemcpyAsync(w.genco, w.gy, sizeof(float) * (size_t)NT * de, hipMemcpyDeviceToDevice, hs);
+        if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: memcpy: %s", hipGetErrorString(e));
+    }
+    TRY(bigc_axpy_f32(s, gx, w.ge2e, (long)NT * de));                                                  // + head gather path
+
+    // ---- fc_enti2enco, pool, conv, per-frame MLPs (models/model_0v10.py:446-458) ----------------------
+    TRY(bigc_relu_bwd_f32(s, gx, w.e2e, (long)NT * de));
+    float* geh = w.gx;
+    TRY(bw.lin("fc_enti2enco.2", m->enco2, gx, de, w.eh, de, NT, de, de, geh, de, false));
+    TRY(bigc_relu_bwd_f32(s, geh, w.eh, (long)NT * de));
+    TRY(bw.lin("fc_enti2enco.0", m->enco0, geh, de, w.pooled, de * c.enco_pool_len, NT, de, de * c.enco_pool_len, w.gpooled,
+               de * c.enco_pool_len, false));
+    TRY(bigc_maxpool_bwd_f32(s, w.conv, b->trk_conv_off, w.gpooled, w.gconv, NT, de, c.enco_pool_len));
+    if (float* gcw = grad_of(m, "conv_feat2enti.weight")) {
+        ZERO(w.gconvw, (size_t)de * 6 * de);
+        TRY(bigc_linear_dw_f32(s, w.gconv, de, w.enti, 2 * de, w.conv_idx, 3, 2 * de, w.gconvw, 6 * de, grad_of(m, "conv_feat2enti.bias"),
+                               C, de, 6 * de));
+        TRY(bigc_conv_grad_unpack(hs, w.gconvw, gcw, de, 2 * de, 3));
+    }
+    TRY(bigc_conv_gather_bwd_f32(s, w.gconv, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.G, NT, de));
+    if (!m->conv_w_bwd) {
+        hipError_t e = hipMalloc((void**)&m->conv_w_bwd, sizeof(float) * (size_t)2 * de * 3 * de);
+        if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: hipMalloc: %s", hipGetErrorString(e));
+    }
+    TRY(bigc_repack_conv_weight_bwd(hs, m->conv.w, m->conv_w_bwd, de, 2 * de, 3));
+    TRY(bigc_linear_f32(s, w.G, 3 * de, nullptr, 1, 3 * de, m->conv_w_bwd, 3 * de, nullptr, nullptr, 0, w.genti, 2 * de, R, 2 * de, 3 * de,
+                        BIGC_ACT_NONE));
+    TRY(bigc_relu_bwd_f32(s, w.genti, w.enti, (long)R * 2 * de));
+    TRY(bw.lin("fc_bbox2enti.2", m->bbox2, w.genti, 2 * de, w.hb, de, R, de, de, w.gh, de, false));
+    TRY(bigc_relu_bwd_f32(s, w.gh, w.hb, (long)R * de));
+    TRY(bw.lin("fc_bbox2enti.0", m->bbox0, w.gh, de, w.bbox8, 8, R, de, 8, nullptr, 0, false));
+    TRY(bw.lin("fc_feat2enti.2", m->feat2, w.genti + de, 2 * de, w.hv, de, R, de, de, w.gh, de, false));
+    TRY(bigc_relu_bwd_f32(s, w.gh, w.hv, (long)R * de));
+    TRY(bw.lin("fc_feat2enti.0", m->feat0, w.gh, de, b->feats, D, R, de, c.dim_feat, nullptr, 0, false));
+    return BIGC_OK;
+}

@@ -114,7 +114,7 @@ class BigcBase(nn.Module):
             topk = self.default_topk
         if self.is_train:
             assert gt_graph_list is not None
-            raise NotImplementedError("training step of the HIP path is not built yet (SURVEY.md section 8 a10)")
+            return self._forward_train(proposal_list, gt_graph_list)
         self.topk = topk
         if isinstance(proposal_list, PackedBatch):
             return self.unpack_results(proposal_list.n_vid, list(range(proposal_list.n_vid)),
@@ -125,6 +125,18 @@ class BigcBase(nn.Module):
         device = self.pred_query_init.device
         packed = PackedBatch([proposal_list[i] for i in keep], device)
         return self.unpack_results(len(proposal_list), keep, self.forward_packed(packed, topk))
+
+    def _forward_train(self, proposal_list, gt_graph_list):
+        """Training contract of the reference (models/model_0v10.py:510-556): returns
+        ``(total_loss, {"cls_pos", "cls_neg", "adj"})``; ``total_loss.backward()`` runs the HIP backward and
+        fills ``.grad`` of every trainable parameter. Dropout is not applied on this path."""
+        from bigc_hip.train_step import HipTrainStep
+        assert len(proposal_list) == len(gt_graph_list)
+        assert all(p.num_proposals > 0 for p in proposal_list), "videos without proposals are filtered out before training"
+        packed = PackedBatch(list(proposal_list), self.pred_query_init.device)
+        terms = HipTrainStep.apply(self, packed, list(gt_graph_list), *[p for _, p in self.named_parameters()])
+        loss_dict = {"cls_pos": terms[0], "cls_neg": terms[1], "adj": terms[2]}
+        return terms.sum(), loss_dict
 
     def engine(self):
         if self._engine is None:

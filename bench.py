@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--cpu-videos", type=int, default=256, help="videos of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not record HIP events around the kernels")
+    ap.add_argument("--mode", choices=["eval", "train"], default="eval", help="eval = headline metric; train = training-step throughput")
+    ap.add_argument("--train-videos", type=int, default=8, help="videos per GPU per training step (reference batch size 8)")
     return ap.parse_args()
 
 
@@ -80,8 +82,77 @@ def build_model(cfg, sd, device):
     return model.to(device)
 
 
+def train_main(args):
+    """`--mode train`: the training step of BASELINE configs[4] (BIG-C DP training) on synthetic videos:
+    zero_grad, HIP forward + host Hungarian, HIP backward, one flat-gradient all-reduce over RCCL (N>1),
+    clip_grad_norm_(5), Adam -- the loop body of tools/train_vidvrd.py:151-164. Not the headline metric."""
+    from bigc_hip.shard import allreduce_gradients, max_over_ranks
+    from bigc_hip.synthetic import synthetic_gt_graph
+    from models import BIG_C_vidvrd
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    cfg = dict(configs.CONFIG_V)
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 7, att_gain=3.0)
+    d = tempfile.mkdtemp()
+    np.save(os.path.join(d, "bias.npy"), sd["bias_matrix"].numpy())
+    np.save(os.path.join(d, "emb.npy"), sd["EntiNameEmb"].numpy())
+    cfg["bias_matrix_path"], cfg["EntiNameEmb_path"] = os.path.join(d, "bias.npy"), os.path.join(d, "emb.npy")
+    model = BIG_C_vidvrd(cfg, is_train=True)
+    model.load_state_dict(sd)
+    model = model.to(device)
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    nvid = args.train_videos
+    props = [synthetic_proposal(5000 + rank * nvid + v, n_trajs=args.n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"])
+             for v in range(nvid)]
+    gts = [synthetic_gt_graph(p, 6000 + rank * nvid + v, n_gt_trajs=8, n_preds=10, num_pred_cats=cfg["num_pred_cats"]) for v, p in enumerate(props)]
+    props = [p.to(device) for p in props]            # GT stays on the host: alignment + Hungarian run there, as in the reference
+    gt_duras = [g.traj_durations.clone() for g in gts]
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    pairs = sum(p.num_proposals * (p.num_proposals - 1) for p in props)
+
+    def step():
+        for g, du in zip(gts, gt_duras):
+            g.traj_durations = du.clone()            # the forward decrements them in place (reference quirk, model_0v10.py:567)
+        opt.zero_grad()
+        loss, terms = model(props, gts)
+        loss.mean().backward()
+        allreduce_gradients(model.parameters(), dist)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=5, norm_type=2)
+        opt.step()
+        return float(loss)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, device)
+    if rank == 0:
+        print(json.dumps({"metric": "train_tracklet_pairs_per_sec", "value": round(pairs * world * args.steps / elapsed, 1), "unit": "pairs/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "BIG-C model_0v10 training step (exp2 dims), %d synthetic videos x N=%d per GPU per step, "
+                                                 "forward + Hungarian + backward + flat-gradient all-reduce + clip + Adam" % (nvid, args.n_trajs),
+                                     "parallelism": "dp%d" % world}, "last_loss": round(last, 4)}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.mode == "train":
+        return train_main(args)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

@@ -248,6 +248,13 @@ int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int ldp, const f
  *   2: dp2a = ds @ e2a; 3: de2a = ds^T @ p2a. d = dim_enti, half = dim_att/2. */
 int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1, const float* enco_or_e2a,
                              int ld2, float* out, int ldo, const int32_t* e_off, int n_vid, int nq, int d, int half, int max_trk);
+/* vIoU of every (proposal, GT trajectory) pair (vIoU_ts utils/utils_func.py:437-471 as used by enti_viou_align,
+ *   models/model_0v10.py:569-581): out (B, max_trk, g_max), 0 where the closed durations do not overlap or the pair
+ *   does not exist. GT trajectories are packed like the proposals: gt_boxes (sum frames, 4), gt_row_off (G+1),
+ *   gt_dura (G,2) closed, gt_traj_off (B+1). */
+int bigc_viou_matrix(void* stream, const float* boxes, const int32_t* trk_row_off, const int32_t* trk_dura, const int32_t* e_off,
+                     const float* gt_boxes, const int32_t* gt_row_off, const int32_t* gt_dura, const int32_t* gt_traj_off,
+                     int n_vid, int max_trk, int g_max, float* out);
 /* Hungarian cost (models/model_0v10.py:617-636): cost[v,q,g] (B, nq, g_max) = cost_cls * CE + cost_adj * mean BCE;
  *   g_off (B+1) prefix of GT predicates per video, gt_pred (sum G), gt_adj per video (2, G_v, N_v) at float offset adj_off[v]. */
 int bigc_match_cost(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,

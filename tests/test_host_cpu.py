@@ -97,3 +97,18 @@ def test_oracle_batch_independence():
         assert (one is None) == (r is None)
         if r is not None:
             assert all(torch.equal(a, b) for a, b in zip(one, r))
+
+
+def test_adj_from_viou_matches_oracle_alignment():
+    """host half of the GT alignment (thresholding the vIoU table) against the oracle's restatement of
+    enti_viou_align, fed with the oracle's own vIoU table"""
+    import copy
+    from bigc_hip.train_step import adj_from_viou
+    from oracle import bigc_train_oracle as T
+    for name in ("bigc_train_tiny", "bigo_train_tiny"):
+        cfg, variant, sd, props, gts = cases.make_train_case(name)
+        for p, g in zip(props, gts):
+            want, vi = T.align_gt_to_proposals(p, copy.deepcopy(g), cfg["positive_vIoU_th"])
+            got = adj_from_viou(vi.clone(), g.adj_matrix.clone(), cfg["positive_vIoU_th"])
+            assert torch.equal(got, want)
+            assert want.sum() > 0

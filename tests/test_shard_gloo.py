@@ -11,7 +11,7 @@ import torch
 import torch.multiprocessing as mp
 
 import cases
-from bigc_hip.shard import gather_results, max_over_ranks, shard_indices
+from bigc_hip.shard import allreduce_gradients, gather_results, max_over_ranks, shard_indices
 
 
 def test_shard_indices_partition():
@@ -40,6 +40,13 @@ def _worker(rank, world, port, q):
     dist.barrier()
     res = gather_results(local, mine, len(props), dist)
     slow = max_over_ranks(1.0 + rank, dist)
+    # gradient exchange of the training step: per-rank gradients -> mean over ranks through one flat buffer
+    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2))]
+    ps[0].grad = torch.full((3, 4), float(rank + 1))
+    ps[1].grad = torch.arange(5, dtype=torch.float32) * (rank + 1)
+    flat = allreduce_gradients(ps, dist)                 # ps[2] has no gradient (frozen): skipped
+    assert flat.numel() == 17 and ps[2].grad is None
+    assert torch.equal(ps[0].grad, torch.full((3, 4), 1.5)) and torch.equal(ps[1].grad, torch.arange(5, dtype=torch.float32) * 1.5)
     if rank == 0:
         full = O.forward_test(sd, cfg, props, topk, variant)
         ok = len(res) == len(full)

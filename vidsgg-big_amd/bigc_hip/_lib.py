@@ -101,6 +101,8 @@ _SIGS = {
                                             c_int, c_float]),
     "bigc_role_small_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                          c_int, c_int, c_int, c_int, c_int]),
+    "bigc_viou_matrix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_int, c_void_p]),
     "bigc_match_cost": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                 c_int, c_float, c_float, c_void_p]),
     "bigc_loss_grad": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

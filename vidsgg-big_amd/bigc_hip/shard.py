@@ -55,3 +55,27 @@ def max_over_ranks(seconds, dist=None, device=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def allreduce_gradients(params, dist=None, average=True):
+    """Data-parallel gradient exchange of the training step: ONE all-reduce over a single flat fp32 buffer
+    holding every gradient (RCCL over xGMI on the GPU boxes, gloo in the CPU tests), then the mean over ranks.
+
+    Replaces the reference's single-process ``nn.DataParallel`` reduction (utils/DataParallel.py:65-69, loss
+    ``.mean()`` over replicas at tools/train_vidvrd.py:155): each rank computes the loss means over its own
+    contiguous chunk of the batch (``shard_indices``), so averaging the per-rank gradients reproduces it.
+    Returns the flat reduced buffer (27.8 M floats = 111 MB for the exp2 model)."""
+    params = [p for p in params if p.grad is not None]
+    if not params:
+        return None
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat)
+        if average:
+            flat /= dist.get_world_size()
+    off = 0
+    for p in params:
+        n = p.grad.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+    return flat

@@ -3,7 +3,7 @@ models/model_0v10.py:510-556, and the loop body of tools/train_vidvrd.py:151-164
 
 Split of work, as in the reference:
   * device (HIP library): forward with saved activations, matching cost, loss terms, the whole backward;
-  * host: GT-to-proposal alignment by vIoU (a Python loop in the reference too, :559-604) and the Hungarian
+  * host: thresholding of the (device-computed) vIoU tables into the aligned GT adjacency (:583-602) and the Hungarian
     assignment with ``scipy.optimize.linear_sum_assignment`` on a copy of the cost matrix (:637).
 The result is exposed as a ``torch.autograd.Function`` so that ``loss.backward()``, ``clip_grad_norm_`` and
 ``optimizer.step()`` of the reference's training loop work unchanged.
@@ -18,45 +18,42 @@ from . import _lib
 from .packed import PackedBatch
 
 
-def _viou(boxes_p, boxes_g, lo_p, hi_p, lo_g, hi_g):
-    """Volume IoU of two trajectories on their temporal intersection, relative closed frame ranges
-    (reference: ``vIoU_ts`` utils/utils_func.py:437-471, +1 pixel convention)."""
-    area_p = ((boxes_p[:, 2] - boxes_p[:, 0] + 1) * (boxes_p[:, 3] - boxes_p[:, 1] + 1)).sum()
-    area_g = ((boxes_g[:, 2] - boxes_g[:, 0] + 1) * (boxes_g[:, 3] - boxes_g[:, 1] + 1)).sum()
-    a, b = boxes_p[lo_p:hi_p + 1], boxes_g[lo_g:hi_g + 1]
-    lt = torch.maximum(a[:, :2], b[:, :2])
-    rb = torch.minimum(a[:, 2:], b[:, 2:])
-    wh = (rb - lt + 1).clamp(min=0.0)
-    inter = (wh[:, 0] * wh[:, 1]).sum()
-    return inter / (area_p + area_g - inter)
-
-
-def align_gt_to_proposals(proposal, gt_graph, viou_th):
-    """GT adjacency re-indexed by proposals, (2, n_gt_pred, n_proposals) f32 on the CPU
-    (reference: ``enti_viou_align`` models/model_0v10.py:559-604, including its in-place
-    ``gt_graph.traj_durations[:, 1] -= 1`` at :567)."""
-    adj = gt_graph.adj_matrix.detach().cpu()
-    n_gt_pred = adj.shape[1]
-    n = proposal.num_proposals
-    gt_graph.traj_durations[:, 1] -= 1
-    pd = proposal.traj_durations.cpu()
-    gd = gt_graph.traj_durations.cpu()
-    pb = [b.detach().cpu().float() for b in proposal.bboxes_list]
-    gb = [b.detach().cpu().float() for b in gt_graph.traj_bboxes]
-    s = torch.maximum(pd[:, None, 0], gd[None, :, 0])
-    e = torch.minimum(pd[:, None, 1], gd[None, :, 1])
-    vi = torch.zeros((n, gd.shape[0]), dtype=torch.float32)
-    for p, g in (s <= e).nonzero().tolist():
-        vi[p, g] = _viou(pb[p], gb[g], int(s[p, g] - pd[p, 0]), int(e[p, g] - pd[p, 0]), int(s[p, g] - gd[g, 0]), int(e[p, g] - gd[g, 0]))
+def adj_from_viou(vi, adj, viou_th):
+    """GT adjacency re-indexed by proposals from the vIoU table ``vi`` (n_proposals, n_gt_traj):
+    (2, n_gt_pred, n_proposals) f32 (reference: the tail of ``enti_viou_align`` models/model_0v10.py:583-602).
+    A proposal inherits the adjacency column of its best-overlapping GT trajectory when it passes the vIoU
+    threshold for some GT trajectory, or when it is the best proposal of a GT trajectory nobody else covers."""
     mask = vi > viou_th
     best = vi.argmax(dim=0)
     none = mask.sum(dim=0) == 0
     mask[best[none], none] = True
-    out = torch.zeros((2, n_gt_pred, n), dtype=torch.float32)
-    for p in range(n):
-        if bool(mask[p].any()):
-            out[:, :, p] = adj[:, :, int(vi[p].argmax())]
-    return out
+    has = mask.any(dim=1)
+    pick = vi.argmax(dim=1)
+    return adj[:, :, pick] * has[None, None, :].to(adj.dtype)
+
+
+def align_batch(lib, packed, gt_graph_list, viou_th):
+    """``enti_viou_align`` for every video of the batch: the vIoU tables come from one HIP kernel launch
+    (``bigc_viou_matrix``; the reference loops over pairs in Python, :576-581), the thresholding on the host.
+    Reproduces the reference's in-place ``gt_graph.traj_durations[:, 1] -= 1`` (:567)."""
+    dev = packed.device
+    for g in gt_graph_list:
+        g.traj_durations[:, 1] -= 1
+    n_traj = [len(g.traj_bboxes) for g in gt_graph_list]
+    lens = [int(b.shape[0]) for g in gt_graph_list for b in g.traj_bboxes]
+    gt_boxes = torch.cat([b.detach().float().cpu() for g in gt_graph_list for b in g.traj_bboxes], 0).contiguous().to(dev)
+    gt_row_off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
+    gt_dura = torch.cat([g.traj_durations.detach().cpu() for g in gt_graph_list], 0).to(torch.int32).contiguous().to(dev)
+    gt_traj_off = torch.from_numpy(np.concatenate([[0], np.cumsum(n_traj)]).astype(np.int32)).to(dev)
+    g_max = int(max(n_traj))
+    out = torch.zeros((packed.n_vid, packed.max_trk, g_max), dtype=torch.float32, device=dev)
+    _lib.check(lib.bigc_viou_matrix(_lib.current_stream(), packed.boxes.data_ptr(), packed.trk_row_off.data_ptr(), packed.trk_dura.data_ptr(),
+                                    packed.vid_trk_off.data_ptr(), gt_boxes.data_ptr(), gt_row_off.data_ptr(), gt_dura.data_ptr(),
+                                    gt_traj_off.data_ptr(), packed.n_vid, packed.max_trk, g_max, out.data_ptr()))
+    vi = out.cpu()
+    n_trk = np.diff(packed.vid_trk_off_host)
+    return [adj_from_viou(vi[v, :int(n_trk[v]), :n_traj[v]].clone(), g.adj_matrix.detach().cpu().float(), viou_th)
+            for v, g in enumerate(gt_graph_list)]
 
 
 class TrainContext(object):
@@ -82,7 +79,7 @@ def forward(model, engine, packed, gt_graph_list):
                                       ctx.logits.data_ptr(), ctx.att.data_ptr()))
     # ground truth, aligned to the proposals on the host
     n_trk = np.diff(packed.vid_trk_off_host)
-    adjs = [align_gt_to_proposals(p, g, model.positive_vIoU_th) for p, g in zip(packed.proposals, gt_graph_list)]
+    adjs = align_batch(lib, packed, gt_graph_list, model.positive_vIoU_th)
     n_gt = [int(a.shape[1]) for a in adjs]
     assert min(n_gt) > 0, "every training video needs at least one GT predicate"
     g_off = np.concatenate([[0], np.cumsum(n_gt)])

@@ -126,3 +126,54 @@ extern "C" int bigc_loss_grad(void* stream, const float* logits, int n_pcat, con
     BIGC_LAUNCH_CHECK("loss_grad");
     return BIGC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// vIoU of every (proposal, GT trajectory) pair of a video (reference: ``vIoU_ts`` utils/utils_func.py:437-471
+// called from ``enti_viou_align`` models/model_0v10.py:569-581): intersection volume over the frames both
+// trajectories cover, divided by the union of the two whole volumes; boxes are inclusive pixel rectangles (+1).
+// One wave per pair; 0 where the durations do not overlap.
+namespace {
+__global__ __launch_bounds__(64) void viou_matrix_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ row_off,
+                                                         const int32_t* __restrict__ dura, const int32_t* __restrict__ e_off,
+                                                         const float* __restrict__ gboxes, const int32_t* __restrict__ grow_off,
+                                                         const int32_t* __restrict__ gdura, const int32_t* __restrict__ gt_off,
+                                                         int max_trk, int g_max, float* __restrict__ out) {
+    const int v = blockIdx.z, p = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    const int e0 = e_off[v], ne = e_off[v + 1] - e0;
+    const int g0 = gt_off[v], ng = gt_off[v + 1] - g0;
+    if (p >= ne || g >= ng) return;
+    const int tp = e0 + p, tg = g0 + g;
+    const int ps = dura[2 * tp], pe = dura[2 * tp + 1], gs = gdura[2 * tg], ge = gdura[2 * tg + 1];
+    const int s = max(ps, gs), e = min(pe, ge);
+    float res = 0.f;
+    if (s <= e) {
+        const f32x4* bp = (const f32x4*)boxes + row_off[tp];
+        const f32x4* bg = (const f32x4*)gboxes + grow_off[tg];
+        const int lp = row_off[tp + 1] - row_off[tp], lg = grow_off[tg + 1] - grow_off[tg];
+        float ap = 0.f, ag = 0.f, inter = 0.f;
+        for (int i = lane; i < lp; i += 64) { const f32x4 b = bp[i]; ap += (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f); }
+        for (int i = lane; i < lg; i += 64) { const f32x4 b = bg[i]; ag += (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f); }
+        for (int f = s + lane; f <= e; f += 64) {
+            const f32x4 a = bp[f - ps], b = bg[f - gs];
+            const float w = fmaxf(fminf(a[2], b[2]) - fmaxf(a[0], b[0]) + 1.f, 0.f);
+            const float h = fmaxf(fminf(a[3], b[3]) - fmaxf(a[1], b[1]) + 1.f, 0.f);
+            inter += w * h;
+        }
+        ap = wave_sum(ap); ag = wave_sum(ag); inter = wave_sum(inter);
+        res = inter / (ap + ag - inter);
+    }
+    if (lane == 0) out[((size_t)v * max_trk + p) * g_max + g] = res;
+}
+}  // namespace
+
+extern "C" int bigc_viou_matrix(void* stream, const float* boxes, const int32_t* trk_row_off, const int32_t* trk_dura, const int32_t* e_off,
+                                const float* gt_boxes, const int32_t* gt_row_off, const int32_t* gt_dura, const int32_t* gt_traj_off,
+                                int n_vid, int max_trk, int g_max, float* out) {
+    BIGC_CHECK_ARG(boxes && trk_row_off && trk_dura && e_off && gt_boxes && gt_row_off && gt_dura && gt_traj_off && out, "viou_matrix: null pointer");
+    if (n_vid <= 0 || max_trk <= 0 || g_max <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_LOSS, 0.0, 0.0);
+    hipLaunchKernelGGL(viou_matrix_kernel, dim3(g_max, max_trk, n_vid), dim3(64), 0, (hipStream_t)stream, boxes, trk_row_off, trk_dura, e_off,
+                       gt_boxes, gt_row_off, gt_dura, gt_traj_off, max_trk, g_max, out);
+    BIGC_LAUNCH_CHECK("viou_matrix");
+    return BIGC_OK;
+}

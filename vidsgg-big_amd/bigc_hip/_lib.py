@@ -140,6 +140,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise BigcError("HIP library %s not found: build it with `python __graft_entry__.py` "
                         "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # torch must be imported first: it ships its own libamdhip64 and the process must end up with ONE HIP
+    # runtime (loading ours first binds the library to /opt/rocm's copy, whose device list is then empty)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)

@@ -164,3 +164,52 @@ def make_case(name):
     sd = seeded_state_dict(bigc_state_shapes(cfg, case["variant"]), case["wseed"], case.get("att_gain", 1.0))
     props = [make_proposal(cfg, case["variant"], v) for v in case["videos"]]
     return cfg, case["variant"], sd, props, case["topk"]
+
+
+# ---- evaluator (VidVRDhelperEvalAPIs) ----------------------------------------------------------------
+EVAL_SEEDS = [901, 902, 903]
+
+
+def make_eval_case(seed, n_videos=6):
+    """Seeded groundtruth / prediction relation sets in the evaluator's dict format: some predictions are jittered
+    copies of GT relations (hits with vIoU above / below 0.5), some have a wrong triplet, some duplicate a GT."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    ents = ["e%d" % i for i in range(5)]
+    preds = ["p%d" % i for i in range(4)]
+
+    def traj(n, x0, y0):
+        xy = np.stack([x0 + np.arange(n) * rs.uniform(-2, 2), y0 + np.arange(n) * rs.uniform(-2, 2)], 1)
+        wh = rs.uniform(20, 80, size=(1, 2))
+        return np.concatenate([xy, xy + wh], 1)
+
+    gt, pr = {}, {}
+    for v in range(n_videos):
+        vid = "video_%d" % v
+        g_list, p_list = [], []
+        for _ in range(rs.randint(0, 7) if v else 5):
+            s = int(rs.randint(0, 30))
+            n = int(rs.randint(5, 40))
+            rel = {"triplet": [ents[rs.randint(5)], preds[rs.randint(4)], ents[rs.randint(5)]], "duration": (s, s + n),
+                   "sub_traj": traj(n, rs.uniform(0, 300), rs.uniform(0, 200)).tolist(),
+                   "obj_traj": traj(n, rs.uniform(0, 300), rs.uniform(0, 200)).tolist()}
+            g_list.append(rel)
+            for _ in range(rs.randint(0, 4)):
+                jit = rs.choice([2.0, 10.0, 40.0])
+                shift = int(rs.randint(-3, 4))
+                s2 = max(0, s + shift)
+                n2 = max(1, n - abs(shift))
+                st = (np.asarray(rel["sub_traj"])[:n2] + rs.uniform(-jit, jit, size=(1, 4))).tolist()
+                ot = (np.asarray(rel["obj_traj"])[:n2] + rs.uniform(-jit, jit, size=(1, 4))).tolist()
+                trip = list(rel["triplet"])
+                if rs.uniform() < 0.2:
+                    trip[1] = preds[rs.randint(4)]
+                p_list.append({"triplet": trip, "duration": (s2, s2 + n2), "score": float(rs.uniform()), "sub_traj": st, "obj_traj": ot})
+        for _ in range(rs.randint(0, 6)):
+            n = int(rs.randint(5, 20))
+            p_list.append({"triplet": [ents[rs.randint(5)], preds[rs.randint(4)], ents[rs.randint(5)]], "duration": (0, n),
+                           "score": float(rs.uniform()), "sub_traj": traj(n, 10, 10).tolist(), "obj_traj": traj(n, 200, 100).tolist()})
+        gt[vid] = g_list
+        if v != 2:                     # one video has no prediction entry at all
+            pr[vid] = p_list
+    return gt, pr

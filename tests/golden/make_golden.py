@@ -200,11 +200,36 @@ def run_train_case(name, m10, m07):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "total loss", float(total))
 
 
+def run_evaluator_golden():
+    """metrics of the reference's own evaluator (VidVRDhelperEvalAPIs/visual_relation_detection.py:64-120) on the
+    seeded relation sets of cases.make_eval_case"""
+    sys.path.insert(0, REFERENCE)
+    from VidVRDhelperEvalAPIs.visual_relation_detection import evaluate
+    from VidVRDhelperEvalAPIs.common import viou, voc_ap
+    sys.path.remove(REFERENCE)
+    out = {}
+    for seed in cases.EVAL_SEEDS:
+        gt, pr = cases.make_eval_case(seed)
+        mean_ap, rec, prec = evaluate(gt, pr)
+        out["s%d" % seed] = np.array([mean_ap, rec[50], rec[100], prec[1], prec[5], prec[10]], dtype=np.float64)
+        g0 = gt["video_0"][0]
+        p0 = pr["video_0"][0]
+        out["s%d_viou" % seed] = np.array([viou(p0["sub_traj"], p0["duration"], g0["sub_traj"], g0["duration"]),
+                                           viou(p0["obj_traj"], p0["duration"], g0["obj_traj"], g0["duration"])])
+    out["voc_ap"] = np.array([voc_ap(np.array([0.1, 0.4, 0.4, 0.9]), np.array([1.0, 0.5, 0.66, 0.4]))])
+    path = os.path.join(cases.GOLDEN_DIR, "evaluator.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: v.round(4).tolist() for k, v in out.items()})
+
+
 def main():
     torch.manual_seed(0)
     m10, m07, grd = import_reference()
-    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES))
+    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + ["evaluator"])
     for n in names:
+        if n == "evaluator":
+            run_evaluator_golden()
+            continue
         if n in cases.BIGC_CASES:
             run_bigc_case(n, m10, m07)
         elif n in cases.GRD_CASES:

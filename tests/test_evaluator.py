@@ -1,0 +1,82 @@
+"""The metrics code (bigc_hip/evaluate.py) against numbers produced by the reference's own evaluator
+(tests/golden/evaluator.npz), and Recall@50 parity of the HIP path with the CPU oracle on synthetic GT."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from bigc_hip import evaluate as E
+from bigc_hip.synthetic import bigc_state_shapes, seeded_state_dict, synthetic_gt_graph
+
+
+def test_metrics_match_reference_evaluator():
+    g = np.load(os.path.join(cases.GOLDEN_DIR, "evaluator.npz"))
+    for seed in cases.EVAL_SEEDS:
+        gt, pr = cases.make_eval_case(seed)
+        mean_ap, rec, prec = E.evaluate(gt, pr)
+        got = np.array([mean_ap, rec[50], rec[100], prec[1], prec[5], prec[10]])
+        assert np.allclose(got, g["s%d" % seed], rtol=0, atol=1e-7), (seed, got, g["s%d" % seed])
+        g0, p0 = gt["video_0"][0], pr["video_0"][0]
+        v = [E.viou(p0["sub_traj"], p0["duration"], g0["sub_traj"], g0["duration"]),
+             E.viou(p0["obj_traj"], p0["duration"], g0["obj_traj"], g0["duration"])]
+        assert np.allclose(v, g["s%d_viou" % seed], atol=1e-12)
+    assert abs(E.voc_ap(np.array([0.1, 0.4, 0.4, 0.9]), np.array([1.0, 0.5, 0.66, 0.4])) - float(g["voc_ap"][0])) < 1e-12
+
+
+def _synthetic_eval_set(cfg, n_videos, n_trajs):
+    props, gts = [], {}
+    for v in range(n_videos):
+        p = cases.make_proposal(cfg, "vidvrd", dict(seed=3000 + v, n_trajs=n_trajs, len_range=(8, 40), start_range=(0, 20)))
+        p.video_name = "synth_%d" % v
+        g = synthetic_gt_graph(p, 4000 + v, n_gt_trajs=6, n_preds=8, num_pred_cats=cfg["num_pred_cats"], jitter=0.0)
+        props.append(p)
+        gts[p.video_name] = E.gt_to_eval_format(g)
+    return props, gts
+
+
+def test_result_conversion_and_oracle_metrics_cpu():
+    """to_eval_format on the oracle's outputs: durations / cut trajectories are consistent and the metrics run"""
+    from oracle import bigc_oracle as O
+    cfg = cases.get_cfg("CONFIG_TINY")
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 61, att_gain=6.0)
+    props, gts = _synthetic_eval_set(cfg, 4, 10)
+    pred = {}
+    for p, r in zip(props, O.forward_test(sd, cfg, props, topk=3)):
+        rel = E.to_eval_format(p, r)
+        for x in rel[p.video_name]:
+            assert len(x["sub_traj"]) == len(x["obj_traj"]) == x["duration"][1] - x["duration"][0] > 0
+        pred.update(rel)
+    mean_ap, rec, prec = E.evaluate(gts, pred)
+    assert 0.0 <= rec[50] <= rec[100] <= 1.0 and 0.0 <= mean_ap <= 1.0
+
+
+@pytest.mark.gpu
+def test_recall_at_50_parity_hip_vs_oracle():
+    """BASELINE metric, second half: Recall@50 of the HIP path equals the oracle's on the synthetic-GT set
+    (|R@50(build) - R@50(oracle)| = 0 in fp32 parity mode)."""
+    from models import BIG_C_vidvrd
+    from oracle import bigc_oracle as O
+    cfg = cases.get_cfg("CONFIG_TINY")
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 61, att_gain=6.0)
+    props, gts = _synthetic_eval_set(cfg, 12, 14)
+    d = tempfile.mkdtemp()
+    mcfg = dict(cfg)
+    np.save(d + "/b.npy", sd["bias_matrix"].numpy())
+    np.save(d + "/e.npy", sd["EntiNameEmb"].numpy())
+    mcfg["bias_matrix_path"], mcfg["EntiNameEmb_path"] = d + "/b.npy", d + "/e.npy"
+    model = BIG_C_vidvrd(mcfg, is_train=False)
+    model.load_state_dict(sd)
+    model = model.to("cuda:0")
+    hip, ora = {}, {}
+    for p, r in zip(props, model(props, topk=3)):
+        hip.update(E.to_eval_format(p, r))
+    for p, r in zip(props, O.forward_test(sd, cfg, props, topk=3)):
+        ora.update(E.to_eval_format(p, r))
+    m_h, r_h, p_h = E.evaluate(gts, hip)
+    m_o, r_o, p_o = E.evaluate(gts, ora)
+    assert r_h[50] == r_o[50] and r_h[100] == r_o[100]
+    assert abs(m_h - m_o) < 1e-6 and p_h == p_o
+    assert sum(len(v) for v in hip.values()) == sum(len(v) for v in ora.values()) > 0

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""VidVRD inference + evaluation on the HIP path; same flags as the reference's ``tools/eval_vidvrd.py:170-180``
+(``--cfg_path --ckpt_path --output_dir --cuda --save_tag --use_pku --json_results_path``).
+
+Data: with ``--synthetic N`` the videos and their ground truth are generated (no dataset is needed); otherwise
+the reference's own ``dataloaders.dataloader_vidvrd`` must be importable (put the reference checkout AFTER this
+package on PYTHONPATH) and is used exactly as the reference does (tools/eval_vidvrd.py:91-108)."""
+import argparse
+import json
+import os
+import pickle
+import sys
+import time
+
+import torch
+
+from _common import ensure_table_files, load_checkpoint_into, parse_config_py, synthetic_source
+
+from bigc_hip import evaluate as E
+from models import BIG_C_vidvrd
+
+
+def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_tag="", use_pku=False, json_results_path=None,
+                        synthetic=0, n_trajs=64, batch_videos=64):
+    cfg = parse_config_py(cfg_path)
+    model_config, infer_config = cfg["model_config"], cfg.get("inference_config", {})
+    topk = infer_config.get("topk", 10)
+    output_dir = output_dir or os.path.dirname(os.path.abspath(cfg_path))
+    os.makedirs(output_dir, exist_ok=True)
+    device = torch.device("cuda:%d" % cuda)
+    model_config = ensure_table_files(model_config, output_dir)
+    model = BIG_C_vidvrd(model_config, is_train=False).to(device)
+    if ckpt_path:
+        load_checkpoint_into(model, ckpt_path, device)
+    model.eval()
+    if synthetic:
+        data = synthetic_source(model_config, synthetic, n_trajs, seed=1234)
+    else:
+        from dataloaders.dataloader_vidvrd import Dataset_pku_i3d, Dataset_pku, Dataset   # the reference's own loaders
+        ds_cfg = cfg["test_dataset_config"]
+        ds = (Dataset_pku_i3d if (use_pku and model_config.get("dim_i3d")) else Dataset_pku if use_pku else Dataset)(**ds_cfg)
+        data = [ds[i] for i in range(len(ds))]
+    predictions, groundtruth, raw = {}, {}, {}
+    t0 = time.time()
+    for s in range(0, len(data), batch_videos):
+        chunk = data[s:s + batch_videos]
+        props = [p.to(device) for p, _ in chunk]
+        with torch.no_grad():
+            results = model(props, topk=topk)               # one packed HIP forward for the whole chunk
+        for (p, g), r in zip(chunk, results):
+            predictions.update(E.to_eval_format(p.to(torch.device("cpu")), None if r is None else tuple(t.cpu() for t in r)))
+            raw[p.video_name] = None if r is None else [t.cpu() for t in r]
+            if g is not None:
+                groundtruth[p.video_name] = E.gt_to_eval_format(g)
+    infer_s = time.time() - t0
+    with open(os.path.join(output_dir, "VidVRDtest_infer_result_%s.pkl" % save_tag), "wb") as f:
+        pickle.dump(raw, f)
+    if json_results_path:
+        with open(json_results_path, "w") as f:
+            json.dump(predictions, f)
+    if not groundtruth:
+        gt_json = "datasets/GT_json_for_eval/VidVRDtest_gts.json"      # VidVRDhelperEvalAPIs/visual_relation_detection.py:250-253
+        with open(gt_json) as f:
+            groundtruth = json.load(f)
+    mean_ap, rec, prec = E.evaluate(groundtruth, predictions)
+    print("inference: %d videos in %.2f s" % (len(data), infer_s))
+    print("detection mean AP (used in challenge): {}".format(mean_ap))
+    print("detection recall: {}".format(rec))
+    print("tagging precision: {}".format(prec))
+    return mean_ap, rec, prec
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description="VidVRD eval on the MI355X HIP path")
+    ap.add_argument("--cfg_path", type=str, required=True)
+    ap.add_argument("--ckpt_path", type=str, default=None)
+    ap.add_argument("--output_dir", type=str, default=None)
+    ap.add_argument("--cuda", type=int, default=0)
+    ap.add_argument("--save_tag", type=str, default="")
+    ap.add_argument("--use_pku", action="store_true")
+    ap.add_argument("--json_results_path", type=str, default=None)
+    ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N generated videos instead of a dataset")
+    ap.add_argument("--n_trajs", type=int, default=64)
+    a = ap.parse_args()
+    inference_then_eval(a.cfg_path, a.ckpt_path, a.output_dir, a.cuda, a.save_tag, a.use_pku, a.json_results_path, a.synthetic, a.n_trajs)

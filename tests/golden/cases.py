@@ -213,3 +213,46 @@ def make_eval_case(seed, n_videos=6):
         if v != 2:                     # one video has no prediction entry at all
             pr[vid] = p_list
     return gt, pr
+
+
+# ---- grounding training step (models/grd_model_v5.py:375-527) -----------------------------------------
+GRD_TRAIN_CASES = {
+    "grd_train_tiny": dict(cfg=dict(dim_feat=32, dim_clsme=300, dim_hidden=64, num_bins=3), wseed=81, gain=2.0, rng_seed=4242, full=True,
+                           videos=[dict(seed=801, T=11, n_gt_trajs=5, n_preds=5), dict(seed=802, T=6, n_gt_trajs=4, n_preds=3)]),
+    "grd_train_g": dict(cfg=dict(dim_feat=1024, dim_clsme=300, dim_hidden=128, num_bins=10), wseed=82, gain=2.0, rng_seed=4343, full=False,
+                        videos=[dict(seed=803, T=40, n_gt_trajs=6, n_preds=8)]),
+}
+GRD_TRAIN_FULL_GRADS = ["regr_head.4.point_wise.weight", "combined_encoder.norme.weight", "proj2sim.weight", "temp_fc.weight",
+                        "video_encoder.convs.0.depth_wise.weight", "query_fc.bias", "PredNameEmb"]
+
+
+def make_grd_train_case(name):
+    """-> (cfg, state_dict, [clip features], [gt graphs], rng_seed). GT predicates get random sub-spans of the subject/object
+    overlap as their durations and the first predicate is duplicated with another span (a multi-instance query)."""
+    import numpy as np
+    import torch
+    from bigc_hip.synthetic import grd_state_shapes, synthetic_gt_graph
+    case = GRD_TRAIN_CASES[name]
+    cfg = dict(case["cfg"])
+    cfg["loss_factor"] = dict(classification=1.0, centerness=1.0, regression=1.0)
+    sd = seeded_state_dict(grd_state_shapes(cfg), case["wseed"], case["gain"])
+    feats, gts = [], []
+    for v in case["videos"]:
+        rs = np.random.RandomState(v["seed"])
+        p = synthetic_proposal(v["seed"], n_trajs=10, feat_width=4, num_enti_cats=81, len_range=(30, 64), start_range=(0, 20))
+        g = synthetic_gt_graph(p, v["seed"] + 1, n_gt_trajs=v["n_gt_trajs"], n_preds=v["n_preds"], num_pred_cats=51)
+        pd = g.pred_durations.clone()
+        for k in range(pd.shape[0]):
+            s, e = int(pd[k, 0]), int(pd[k, 1])
+            a = rs.randint(s, e + 1)
+            b = rs.randint(a, e + 1)
+            pd[k, 0], pd[k, 1] = a, b
+        dup = pd[:1].clone()
+        dup[0, 0] = g.pred_durations[0, 0]
+        g.pred_durations = torch.cat([pd, dup], 0)
+        g.pred_cat_ids = torch.cat([g.pred_cat_ids, g.pred_cat_ids[:1]], 0)
+        g.adj_matrix = torch.cat([g.adj_matrix, g.adj_matrix[:, :1, :]], 1)
+        g.num_preds = int(g.pred_cat_ids.shape[0])
+        gts.append(g)
+        feats.append(torch.from_numpy((0.1 * rs.standard_normal((v["T"], cfg["dim_feat"]))).astype(np.float32)))
+    return cfg, sd, feats, gts, case["rng_seed"]

@@ -200,6 +200,35 @@ def run_train_case(name, m10, m07):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "total loss", float(total))
 
 
+def run_grd_train_case(name, grd):
+    """Reference grounding training forward + backward (eval() mode: no dropout; the negative predicates come from the
+    global torch RNG, seeded right before the call)."""
+    case = cases.GRD_TRAIN_CASES[name]
+    cfg, sd, feats, gts, rng_seed = cases.make_grd_train_case(name)
+    d = tempfile.mkdtemp()
+    rcfg = dict(cfg)
+    np.save(os.path.join(d, "e.npy"), sd["EntiNameEmb"].numpy())
+    np.save(os.path.join(d, "p.npy"), sd["PredNameEmb"].numpy())
+    rcfg["EntiNameEmb_path"], rcfg["PredNameEmb_path"] = os.path.join(d, "e.npy"), os.path.join(d, "p.npy")
+    model = grd.DEBUG(rcfg, is_train=True)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    torch.manual_seed(rng_seed)
+    total, terms = model(feats, gts)
+    total.backward()
+    out = {"torch_version": np.array(torch.__version__), "total": total.detach().numpy()}
+    for k, v in terms.items():
+        out["loss_" + k] = v.detach().numpy()
+    for k, p_ in model.named_parameters():
+        g = p_.grad
+        out["gnorm_" + k] = np.array(0.0 if g is None else float(g.norm()))
+        if g is not None and (case.get("full", False) or k in cases.GRD_TRAIN_FULL_GRADS):
+            out["grad_" + k] = g.numpy()
+    path = os.path.join(cases.GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "total", float(total), {k: round(float(v), 4) for k, v in terms.items()})
+
+
 def run_evaluator_golden():
     """metrics of the reference's own evaluator (VidVRDhelperEvalAPIs/visual_relation_detection.py:64-120) on the
     seeded relation sets of cases.make_eval_case"""
@@ -225,7 +254,7 @@ def run_evaluator_golden():
 def main():
     torch.manual_seed(0)
     m10, m07, grd = import_reference()
-    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + ["evaluator"])
+    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + list(cases.GRD_TRAIN_CASES) + ["evaluator"])
     for n in names:
         if n == "evaluator":
             run_evaluator_golden()
@@ -236,6 +265,8 @@ def main():
             run_grd_case(n, grd)
         elif n in cases.TRAIN_CASES:
             run_train_case(n, m10, m07)
+        elif n in cases.GRD_TRAIN_CASES:
+            run_grd_train_case(n, grd)
         else:
             raise SystemExit("unknown case " + n)
 

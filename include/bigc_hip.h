@@ -344,6 +344,36 @@ int grd_forward(grd_model* m, void* stream, const float* video_feat, int T, cons
                 float score_th, float tiou_th, float bins_th, float nms_th,
                 void* workspace, size_t workspace_bytes, const grd_outputs* out);
 
+/* ---- grounding scorer, training step (models/grd_model_v5.py:375-389 DEBUG._forward_train) -------------------------
+ * One video per call, as the reference loops (:379-385); the loss means run over the whole batch (:444-527), so
+ * the host passes the batch-wide element counts to grd_loss_grad.
+ *
+ * grd_set_grad        gradient destination for a parameter key (same keys as grd_set_param; NULL unregisters);
+ *                     gradients are ACCUMULATED (zero them once per step).
+ * grd_train_forward   forward_propagation (:331-373) for the n queries (positives then sampled negatives,
+ *                     prepare_gt_data :253-306) of one video, activations kept in the workspace.
+ *                     regrs (n*T, 2k) post-sigmoid, conf / cls (n*T, k) logits.
+ * grd_loss_grad       the five loss terms (:444-527) over the entries the host derived with map2bins (:391-442):
+ *                     positive entries (query pos_i, bin pos_b, GT predicate pos_j) and negative entries
+ *                     (query neg_i, bin neg_b); labels of get_gt_labels (:224-250) are evaluated on the fly from
+ *                     clip (T) = linspace(0,1,T) and target (n_gt,2) normalised spans.  loss[5] accumulates
+ *                     [pos_cls, neg_cls, pos_ct, neg_ct, regr] (already multiplied by the loss factors) and
+ *                     dregr (n*T, round4(2k)) / dconf, dcls (n*T, round4(k)) accumulate d total / d pre-activation,
+ *                     scaled by gs_host[5] (upstream gradient of each term).  count_* are the denominators of the
+ *                     batch-wide means: positive elements, negative elements, elements with centerness > 0.
+ * grd_train_backward  backward pass from those three gradient arrays through the network. */
+int grd_set_grad(grd_model* m, const char* key, float* ptr);
+size_t grd_train_workspace_bytes(const grd_model* m, int T, int n);
+int grd_train_forward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, const int32_t* dura, int n,
+                      float video_len, const float* pos_video, const float* pos_query, void* workspace, size_t workspace_bytes,
+                      float* regrs, float* conf, float* cls);
+int grd_loss_grad(void* stream, const float* regrs, const float* conf, const float* cls, const float* clip, const float* target,
+                  const int32_t* pos_i, const int32_t* pos_b, const int32_t* pos_j, int n_pos, const int32_t* neg_i,
+                  const int32_t* neg_b, int n_neg, int T, int k, float count_pos, float count_neg, float count_mask,
+                  float f_cls, float f_ct, float f_regr, const float* gs_host, float* loss, float* dregr, float* dconf, float* dcls);
+int grd_train_backward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, int n,
+                       void* workspace, size_t workspace_bytes, const float* dregr, const float* dconf, const float* dcls);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,86 @@
+"""Training step of the grounding scorer on the HIP path against the reference's
+loss terms and gradients (tests/golden/grd_train_*.npz) and, parameter by parameter, against the CPU oracle."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build_model(cfg, sd, is_train=True):
+    from models import DEBUG
+    d = tempfile.mkdtemp()
+    cfg = dict(cfg)
+    np.save(os.path.join(d, "e.npy"), sd["EntiNameEmb"].numpy())
+    np.save(os.path.join(d, "p.npy"), sd["PredNameEmb"].numpy())
+    cfg["EntiNameEmb_path"], cfg["PredNameEmb_path"] = os.path.join(d, "e.npy"), os.path.join(d, "p.npy")
+    m = DEBUG(cfg, is_train=is_train)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV)
+
+
+def hip_step(name, weights=None):
+    cfg, sd, feats, gts, seed = cases.make_grd_train_case(name)
+    model = build_model(cfg, sd)
+    torch.manual_seed(seed)
+    total, terms = model([f.to(DEV) for f in feats], gts)
+    if weights is None:
+        total.backward()
+    else:
+        sum(w * terms[k] for k, w in weights.items()).backward()
+    return model, total, terms
+
+
+@pytest.mark.parametrize("name", list(cases.GRD_TRAIN_CASES))
+def test_grd_train_matches_reference_golden(name):
+    g = np.load(cases.GOLDEN_DIR + "/" + name + ".npz")
+    model, total, terms = hip_step(name)
+    assert abs(float(total) - float(g["total"])) < 1e-4 * abs(float(g["total"]))
+    for k, v in terms.items():
+        assert abs(float(v) - float(g["loss_" + k])) < 1e-4 * max(1.0, abs(float(g["loss_" + k]))), k
+    for k, p in model.named_parameters():
+        want = float(g["gnorm_" + k])
+        got = 0.0 if p.grad is None else float(p.grad.norm())
+        assert abs(got - want) <= 5e-4 * max(want, 1e-6), (k, got, want)
+        if "grad_" + k in g.files:
+            ref = g["grad_" + k]
+            assert np.abs(p.grad.cpu().numpy() - ref).max() <= 5e-4 * max(np.abs(ref).max(), 1e-12), k
+
+
+@pytest.mark.parametrize("weights", [None, dict(pos_cls=2.0, regr=0.5, neg_ct=1.5)])
+def test_grd_train_every_gradient_matches_oracle(weights):
+    from oracle import grd_train_oracle as GT
+    name = "grd_train_tiny"
+    cfg, sd, feats, gts, seed = cases.make_grd_train_case(name)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.manual_seed(seed)
+    total, terms, _ = GT.forward_train(sdg, cfg, feats, gts)
+    (total if weights is None else sum(w * terms[k] for k, w in weights.items())).backward()
+    model, h_total, h_terms = hip_step(name, weights)
+    for k in terms:
+        assert abs(float(h_terms[k]) - float(terms[k])) < 1e-4 * max(1.0, abs(float(terms[k]))), k
+    for k, p in model.named_parameters():
+        ref = sdg[k].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        err = float((p.grad.cpu() - ref).abs().max())
+        assert err <= 5e-4 * max(float(ref.abs().max()), 1e-12), (k, err, float(ref.abs().max()))
+
+
+def test_grd_eval_with_gt_data_uses_the_gt_queries():
+    from bigc_hip.grd_train_step import gt_queries
+    cfg, sd, feats, gts, _ = cases.make_grd_train_case("grd_train_tiny")
+    model = build_model(cfg, sd, is_train=False)
+    feat = feats[0].to(DEV)
+    pooled, probs, mask = model([feat], [gts[0]], with_gt_data=True)
+    quint, dura, _, _ = gt_queries(gts[0], False)
+    pooled2, probs2, mask2 = model([feat], [(quint, dura, gts[0].video_len)], with_gt_data=False)
+    assert pooled.shape[0] == quint.shape[0]
+    assert torch.equal(pooled, pooled2) and torch.equal(probs, probs2) and torch.equal(mask, mask2)

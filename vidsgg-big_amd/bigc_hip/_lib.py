@@ -124,6 +124,13 @@ _SIGS = {
     "grd_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "grd_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                             c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_size_t, POINTER(grd_outputs)]),
+    "grd_set_grad": (c_int, [c_void_p, c_char_p, c_void_p]),
+    "grd_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "grd_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
+                                  c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "grd_loss_grad": (c_int, [c_void_p] + [c_void_p] * 5 + [c_void_p] * 3 + [c_int] + [c_void_p] * 2 + [c_int, c_int, c_int]
+                      + [c_float] * 6 + [c_void_p] * 5),
+    "grd_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
 }
 
 # grounding entry points are appended by bigc_hip._lib_grd when that part of the library exists

@@ -11,13 +11,8 @@
 // Layout: every activation is (rows, d) row-major with rows = sequence-major time (n*T for the combined
 // encoder, 3n for the query encoder, T for the video encoder); the reference's (N, d, T) tensors are
 // the transposes, so Conv1d(k=1) is a plain linear and LayerNorm needs no transposes.
-#include "common.h"
+#include "grounding_internal.h"
 #include "prof.h"
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-int bigc_fill_offsets(hipStream_t s, int32_t* p, int n, int step);
 
 namespace {
 
@@ -256,6 +251,14 @@ int grid_for(long n, int cap = 4096) { long g = (n + 255) / 256; return (int)(g 
 
 }  // namespace
 
+// shared with grounding_train.hip
+int grd_query_input(hipStream_t hs, const float* enti, const float* pred, const int32_t* quint, const int32_t* dura, float video_len,
+                    float* out, int n, int de, int kq) {
+    hipLaunchKernelGGL(query_input_kernel, dim3(grid_for((long)3 * n * kq)), dim3(256), 0, hs, enti, pred, quint, dura, video_len, out, n, de, kq);
+    BIGC_LAUNCH_CHECK("query_input");
+    return BIGC_OK;
+}
+
 extern "C" int bigc_dwconv_f32(void* stream, const float* x, const float* w, const float* b, float* y, int n_seq, int T, int d, int ks) {
     BIGC_CHECK_ARG(x && w && b && y, "dwconv: null pointer");
     BIGC_CHECK_ARG(d % 4 == 0 && ks % 2 == 1 && ks <= 7 && T > 0, "dwconv: d=%d ks=%d T=%d", d, ks, T);
@@ -297,26 +300,6 @@ extern "C" int grd_postprocess(void* stream, const float* regrs, const float* co
 // model-level
 // ------------------------------------------------------------------------------------------------
 namespace {
-struct Lin { const float* w = nullptr; const float* b = nullptr; };
-struct DW { const float *dw_w = nullptr, *dw_b = nullptr; Lin pw; };
-struct Enc { DW conv[4]; Lin in_proj, out_proj, fc; Lin normb, norm_seq[4], norme; int ks = 7; };
-struct Head { DW layer[5]; int c_out = 0; };
-}  // namespace
-
-struct grd_model {
-    grd_config cfg;
-    std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
-    bool finalized = false;
-    const float *enti = nullptr, *pred = nullptr;
-    Lin video_fc, vq_fc, proj2sim;
-    Enc video_enc, query_enc, comb_enc;
-    Head cls_head, conf_head, regr_head;
-    float* wq = nullptr;   // (d, kq) owned
-    float* bq = nullptr;   // (d) owned
-    int kq = 0;
-};
-
-namespace {
 
 struct GResolver {
     grd_model* m;
@@ -356,6 +339,7 @@ struct GResolver {
     Enc enc(const std::string& p, int d, int ks) {
         Enc e;
         e.ks = ks;
+        e.key = p;
         for (int i = 0; i < 4; ++i) e.conv[i] = dws(p + ".convs." + std::to_string(i), d, d, ks);
         e.in_proj.w = get(p + ".mh_attn.in_proj_weight", (int64_t)3 * d * d);
         e.in_proj.b = get(p + ".mh_attn.in_proj_bias", 3 * d);
@@ -369,6 +353,7 @@ struct GResolver {
     Head head(const std::string& p, int d, int c_out) {
         Head h;
         h.c_out = c_out;
+        h.key = p;
         for (int i = 0; i < 4; ++i) h.layer[i] = dws(p + "." + std::to_string(i) + ".0", d, d, 3);
         h.layer[4] = dws(p + ".4", d, c_out, 3);
         return h;
@@ -496,6 +481,7 @@ extern "C" int grd_finalize(grd_model* m, void* stream) {
     m->video_fc = r.lin("video_fc", d, c.dim_feat);
     Lin qfc = r.lin("query_fc", d, c.dim_clsme);
     Lin tfc = r.lin("temp_fc", d, 2);
+    m->query_fc = qfc; m->temp_fc = tfc;
     m->vq_fc = r.lin("vq_fc", d, 4 * d);
     m->proj2sim = r.lin("proj2sim", d, d, false);
     m->video_enc = r.enc("video_encoder", d, 7);

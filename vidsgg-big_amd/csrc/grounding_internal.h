@@ -1,0 +1,21 @@
+// Definitions shared by grounding.hip (eval forward) and grounding_train.hip (training forward / backward).
+#pragma once
+#include "model_internal.h"
+
+struct DW { const float *dw_w = nullptr, *dw_b = nullptr; Lin pw; };
+struct Enc { DW conv[4]; Lin in_proj, out_proj, fc; Lin normb, norm_seq[4], norme; int ks = 7; std::string key; };
+struct Head { DW layer[5]; int c_out = 0; std::string key; };
+
+struct grd_model {
+    grd_config cfg;
+    std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
+    std::unordered_map<std::string, float*> grads;     // gradient destinations (training)
+    bool finalized = false;
+    const float *enti = nullptr, *pred = nullptr;
+    Lin video_fc, vq_fc, proj2sim, query_fc, temp_fc;
+    Enc video_enc, query_enc, comb_enc;
+    Head cls_head, conf_head, regr_head;
+    float* wq = nullptr;   // (d, kq) owned: [query_fc.weight | temp_fc.weight | 0 0]
+    float* bq = nullptr;   // (d) owned: query_fc.bias + temp_fc.bias
+    int kq = 0;
+};

@@ -7,6 +7,7 @@ import torch
 from torch import nn
 
 from bigc_hip.grd_engine import GrdEngine
+from bigc_hip.grd_train_step import LOSS_KEYS, HipGrdTrainStep, gt_queries
 
 
 class _DWSep(nn.Module):
@@ -77,10 +78,15 @@ class DEBUG(nn.Module):
         """Eval contract of the reference (models/grd_model_v5.py:196-221): one video per call,
         ``data_list[0] = (uniq_quintuples (n,5), uniq_dura_inters (n,2), video_len)``; returns
         ``(pooled_se (n,k+1,2) f32, bins_probs (n,k+1) f32, bins_mask (n,k+1) bool)`` or ``(None, None)``."""
-        if self.is_train or with_gt_data:
-            raise NotImplementedError("only the classification-then-grounding eval path (with_gt_data=False) is built on the HIP path")
+        if self.is_train:
+            assert with_gt_data, "training needs the ground-truth graphs as data_list"
+            return self._forward_train(video_feature_list, data_list)
         assert len(video_feature_list) == 1
-        quint, dura, video_len = data_list[0]
+        if with_gt_data:     # grounding stage evaluated alone on the GT queries (models/grd_model_v5.py:198-201)
+            quint, dura, _, _ = gt_queries(data_list[0], False, int(self.PredNameEmb.shape[0]))
+            video_len = data_list[0].video_len
+        else:
+            quint, dura, video_len = data_list[0]
         if quint is None or dura is None or quint.shape[0] == 0:
             return None, None
         out = self.forward_raw(video_feature_list[0], quint, dura, video_len, score_th, tiou_th, bins_th, nms_th)
@@ -88,6 +94,13 @@ class DEBUG(nn.Module):
             # the reference raises at this point: min() of an empty selection (models/grd_model_v5.py:726)
             raise IndexError("temporal pooling selected no clip for some (query, bin): all scores are zero")
         return out["pooled_se"], out["bins_probs"], out["bins_mask"].bool()
+
+    def _forward_train(self, video_feature_list, gt_graph_list):
+        """``(total_loss, loss_dict)`` of the reference (models/grd_model_v5.py:375-389); ``total_loss.backward()`` runs the
+        HIP backward and fills ``.grad`` of every trainable parameter."""
+        feats = [f.to(self.EntiNameEmb.device) for f in video_feature_list]
+        terms = HipGrdTrainStep.apply(self, feats, list(gt_graph_list), *self.parameters())
+        return terms.sum(), {k: terms[i] for i, k in enumerate(LOSS_KEYS)}
 
     def forward_raw(self, video_feature, quint, dura, video_len, score_th, tiou_th, bins_th, nms_th, keep_intermediates=False):
         with torch.no_grad():

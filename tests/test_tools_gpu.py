@@ -31,3 +31,34 @@ def test_train_then_eval_cli_roundtrip():
                "--synthetic", "8", "--n_trajs", "12", "--json_results_path", os.path.join(out_dir, "pred.json")])
     assert "detection mean AP" in log and "detection recall" in log
     assert os.path.exists(os.path.join(out_dir, "pred.json")) and os.path.exists(os.path.join(out_dir, "VidVRDtest_infer_result_t.pkl"))
+
+
+def test_vidor_cli_cls_training_eval_and_grounding():
+    cfg5 = os.path.join(ROOT, "vidsgg-big_amd", "experiments", "exp5", "config_.py")
+    cfgg = os.path.join(ROOT, "vidsgg-big_amd", "experiments", "grounding_weights", "config_.py")
+    out_dir = tempfile.mkdtemp()
+    # BIG-C VidOR classification stage: a few epochs, loss goes down, checkpoint in the reference's format
+    log = run([os.path.join(TOOLS, "train_vidor.py"), "--cfg_path", cfg5, "--output_dir", out_dir, "--save_tag", "c", "--synthetic", "8",
+               "--n_trajs", "10", "--epochs", "10"])
+    losses = [float(l.split("loss=")[1].split(";")[0]) for l in log.splitlines() if "loss=" in l]
+    assert len(losses) >= 2 and losses[-1] < losses[0], losses
+    cls_ckpt = os.path.join(out_dir, "model_epoch_10_c.pth")
+    assert os.path.exists(cls_ckpt)
+    # grounding stage training
+    log = run([os.path.join(TOOLS, "train_vidor.py"), "--train_grounding", "--cfg_path", cfgg, "--output_dir", out_dir, "--save_tag", "g",
+               "--synthetic", "16", "--n_trajs", "8", "--epochs", "10"])
+    losses = [float(l.split("loss=")[1].split(";")[0]) for l in log.splitlines() if "loss=" in l]
+    assert len(losses) >= 2 and losses[-1] < losses[0], losses
+    assert all(k in log for k in ("pos_cls", "neg_cls", "pos_ct", "neg_ct", "regr"))
+    grd_ckpt = os.path.join(out_dir, "model_epoch_10_g.pth")
+    assert os.path.exists(grd_ckpt)
+    # classification-only eval saves the per-video results the grounding stage consumes
+    log = run([os.path.join(TOOLS, "eval_vidor.py"), "--eval_cls_only", "--cfg_path", cfg5, "--ckpt_path", cls_ckpt, "--output_dir", out_dir,
+               "--save_tag", "t", "--synthetic", "6", "--n_trajs", "10"])
+    assert "detection recall" in log
+    pkl = os.path.join(out_dir, "VidORval_infer_results_topk3_t.pkl")
+    assert os.path.exists(pkl)
+    log = run([os.path.join(TOOLS, "eval_vidor.py"), "--cfg_path", cfgg, "--ckpt_path", grd_ckpt, "--cls_stage_result_path", pkl,
+               "--output_dir", out_dir, "--save_tag", "t", "--synthetic", "6", "--n_trajs", "10", "--save_json_results"])
+    assert "detection recall" in log
+    assert os.path.exists(os.path.join(out_dir, "VidORval_predict_relations_aft_grd_t.json"))

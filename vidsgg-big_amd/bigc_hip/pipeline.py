@@ -14,9 +14,10 @@ def combine_with_grounding(cls_result, grounding_out, video_len):
     pooled, probs, mask = grounding_out
     n, nb = probs.shape
     base = scores.mean(dim=-1) if scores.dim() == 2 else scores
-    q = quint[:, None, :].repeat(1, nb, 1)[mask, :].cpu()
-    s = (base.to(probs.device)[:, None] * probs)[mask].cpu()
-    d = torch.round((pooled * video_len)[mask, :]).type(torch.long).cpu()
+    mask_c = mask.cpu()
+    q = quint.cpu()[:, None, :].repeat(1, nb, 1)[mask_c, :]
+    s = (base.to(probs.device)[:, None] * probs).cpu()[mask_c]
+    d = torch.round((pooled * video_len).cpu()[mask_c, :]).type(torch.long)
     return q, s, d
 
 

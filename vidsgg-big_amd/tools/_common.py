@@ -61,3 +61,101 @@ def ensure_table_files(model_config, out_dir, seed=0):
         np.save(path, rs.normal(0, 0.4, size=(ne, cfg["dim_clsme"])).astype(np.float32))
         cfg["EntiNameEmb_path"] = path
     return cfg
+
+
+def synthetic_vidor_source(model_config, n_videos, n_trajs, seed, clip_dim=None, len_range=(15, 120), n_gt_trajs=8, n_preds=10):
+    """VidOR-shaped synthetic videos: RoI feature + 300-d classeme columns when ``use_clsme`` (models/model_0v7.py:331-340),
+    and -- with ``clip_dim`` -- the clip features the grounding stage reads, ``T = ceil(video_len / 8)`` rows
+    (16-frame clips with overlap 0.5, experiments/grounding_weights/config_.py:22)."""
+    from bigc_hip.synthetic import synthetic_gt_graph, synthetic_proposal
+    width = model_config.get("dim_feat", 1024) + (model_config.get("dim_clsme", 300) if model_config.get("use_clsme", True) else 0)
+    out = []
+    for v in range(n_videos):
+        p = synthetic_proposal(seed + v, n_trajs=n_trajs, feat_width=width, num_enti_cats=model_config.get("num_enti_cats", 81),
+                               len_range=len_range, start_range=(0, len_range[1]), name="synthetic_%05d" % v)
+        g = synthetic_gt_graph(p, seed + 100000 + v, n_gt_trajs=n_gt_trajs, n_preds=n_preds, num_pred_cats=model_config.get("num_pred_cats", 51))
+        clip = None
+        if clip_dim:
+            rs = np.random.RandomState(seed + 200000 + v)
+            clip = torch.from_numpy((0.1 * rs.standard_normal((-(-p.video_len // 8), clip_dim))).astype(np.float32))
+        out.append((p, g, clip))
+    return out
+
+
+def ensure_grounding_files(model_config, out_dir, seed=0):
+    """``DEBUG`` loads ``EntiNameEmb_path`` (81,300) and ``PredNameEmb_path`` (51,300) (models/grd_model_v5.py:158-170)."""
+    cfg = dict(model_config)
+    rs = np.random.RandomState(seed)
+    for key, rows in (("EntiNameEmb_path", 81), ("PredNameEmb_path", 51)):
+        if not (cfg.get(key) and os.path.exists(cfg[key])):
+            path = os.path.join(out_dir, "synthetic_" + key[:-5] + ".npy")
+            np.save(path, rs.normal(0, 0.4, size=(rows, cfg["dim_clsme"])).astype(np.float32))
+            cfg[key] = path
+    return cfg
+
+
+def init_process():
+    """One process per GPU: (rank, world, device, dist-or-None) from the torch.distributed.run environment."""
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    return rank, world, device, dist
+
+
+def training_loop(model, data, train_config, output_dir, save_tag, step, rank, world, device, dist, sort_key=None,
+                  from_checkpoint=False, ckpt_path=None, epochs=None):
+    """The reference's epoch / iteration loop (tools/train_vidvrd.py:121-181, tools/train_vidor.py:590-633) for one rank:
+    Adam + MultiStepLR on iteration milestones, ``drop_last`` batches, every rank takes its chunk of each batch
+    (utils/DataParallel.py:80-113), ONE flat gradient all-reduce, ``clip_grad_norm_(5)``, checkpoints in the reference's
+    format with the ``module.`` key prefix.  ``step(model, items)`` -> (loss, terms)."""
+    import random
+    from bigc_hip.shard import allreduce_gradients, shard_indices
+    batch_size, total_epoch = train_config["batch_size"], epochs or train_config["total_epoch"]
+    n_iter = len(data) // batch_size
+    milestones = [int(m * len(data) / batch_size) for m in train_config["epoch_lr_milestones"]]
+    optimizer = torch.optim.Adam(model.parameters(), lr=train_config["initial_lr"])
+    scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma=train_config["lr_decay"])
+    crt_epoch = 0
+    if from_checkpoint:
+        ckpt = load_checkpoint_into(model, ckpt_path, device)
+        optimizer.load_state_dict(ckpt["optim_state_dict"])
+        scheduler.load_state_dict(ckpt["sched_state_dict"])
+        crt_epoch = ckpt["crt_epoch"]
+    it, loss = 0, torch.zeros(())
+    for epoch in range(total_epoch):
+        if epoch < crt_epoch:
+            it += n_iter
+            continue
+        order = list(range(len(data)))
+        random.Random(epoch).shuffle(order)                 # same permutation on every rank
+        for b in range(n_iter):
+            batch = [data[i] for i in order[b * batch_size:(b + 1) * batch_size]]
+            if sort_key is not None:
+                batch = sorted(batch, key=sort_key)
+            mine = [batch[i] for i in shard_indices(len(batch), rank, world)]
+            optimizer.zero_grad()
+            loss, terms = step(model, mine)
+            loss = loss.mean()
+            loss.backward()
+            allreduce_gradients(model.parameters(), dist)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=5, norm_type=2)
+            optimizer.step()
+            scheduler.step()
+            if rank == 0 and it % 10 == 0:
+                print("epoch={},iter={},loss={:.4f}; ".format(epoch, it, float(loss)) +
+                      "".join("{}:{:.4f}; ".format(k, float(v)) for k, v in terms.items()) + "lr={}".format(optimizer.param_groups[0]["lr"]),
+                      flush=True)
+            it += 1
+        if rank == 0 and ((epoch + 1) % 10 == 0 or epoch + 1 == total_epoch):
+            torch.save({"batch_size": batch_size, "crt_epoch": epoch + 1,
+                        "model_state_dict": {"module." + k: v for k, v in model.state_dict().items()},
+                        "optim_state_dict": optimizer.state_dict(), "sched_state_dict": scheduler.state_dict()},
+                       os.path.join(output_dir, "model_epoch_{}_{}.pth".format(epoch + 1, save_tag)))
+    if dist is not None:
+        dist.destroy_process_group()
+    return float(loss)

@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""VidOR inference + evaluation on the HIP path with the flags of the reference's ``tools/eval_vidor.py:285-300``:
+``--eval_cls_only`` runs the BIG-C classification stage (``evaluate_cls_stage`` :21-138) and saves the per-video results
+pickle; without it the grounding stage re-scores those results (``evaluate_combined`` :141-282, needs
+``--cls_stage_result_path``); ``--json_results_path`` only evaluates a saved prediction file.
+``--synthetic N`` generates the videos, clip features and ground truth instead of reading a dataset."""
+import argparse
+import json
+import os
+import pickle
+import time
+
+import torch
+
+from _common import (ensure_grounding_files, ensure_table_files, load_checkpoint_into, parse_config_py, synthetic_vidor_source)
+
+from bigc_hip import evaluate as E
+from bigc_hip.pipeline import combine_with_grounding
+from models import BIG_C_vidor, DEBUG
+
+
+def _load_data(cfg, synthetic, n_trajs, clip_dim):
+    if synthetic:
+        return synthetic_vidor_source(cfg["model_config"] if not clip_dim else {}, synthetic, n_trajs, seed=2468, clip_dim=clip_dim)
+    from dataloaders.dataloader_vidor_v3 import Dataset                 # the reference's loader (tools/eval_vidor.py:11)
+    ds = Dataset(**cfg["test_dataset_config"])
+    items = [ds[i] for i in range(len(ds))]
+    return [(it[1], it[2], it[0]) if len(it) == 3 else (it[0], it[1], None) for it in items]
+
+
+def _report(groundtruth, predictions, output_dir, name, save_json):
+    if save_json:
+        with open(os.path.join(output_dir, name), "w") as f:
+            json.dump(predictions, f)
+    if not groundtruth:
+        with open("datasets/GT_json_for_eval/VidORval_gts.json") as f:      # VidVRDhelperEvalAPIs/visual_relation_detection.py:250-256
+            groundtruth = json.load(f)
+    mean_ap, rec, prec = E.evaluate(groundtruth, predictions)
+    print("detection mean AP (used in challenge): {}".format(mean_ap))
+    print("detection recall: {}".format(rec))
+    print("tagging precision: {}".format(prec))
+    return mean_ap, rec, prec
+
+
+def evaluate_cls_stage(cfg_path, ckpt_path=None, save_tag="", output_dir=None, cuda=0, save_json=False, synthetic=0, n_trajs=32):
+    cfg = parse_config_py(cfg_path)
+    topk = cfg["inference_config"]["topk"]
+    save_tag = "topk{}_{}".format(topk, save_tag)                       # tools/eval_vidor.py:47
+    output_dir = output_dir or os.path.dirname(os.path.abspath(cfg_path))
+    os.makedirs(output_dir, exist_ok=True)
+    device = torch.device("cuda:%d" % cuda)
+    model = BIG_C_vidor(ensure_table_files(cfg["model_config"], output_dir), is_train=False).to(device)
+    if ckpt_path:
+        load_checkpoint_into(model, ckpt_path, device)
+    model.eval()
+    data = _load_data(cfg, synthetic, n_trajs, None)
+    predictions, groundtruth, raw = {}, {}, {}
+    t0 = time.time()
+    for p, g, _ in data:
+        with torch.no_grad():
+            r = model([p.to(device)], topk=topk)[0]
+        cpu = p.to(torch.device("cpu"))
+        raw[p.video_name] = None if r is None else [t.cpu() for t in r]
+        predictions.update(E.to_eval_format(cpu, None if r is None else tuple(t.cpu() for t in r)))
+        if g is not None:
+            groundtruth[p.video_name] = E.gt_to_eval_format(g)
+    print("inference: %d videos in %.2f s" % (len(data), time.time() - t0))
+    path = os.path.join(output_dir, "VidORval_infer_results_{}.pkl".format(save_tag))
+    with open(path, "wb") as f:
+        pickle.dump(raw, f)
+    print("infer_results have been saved at {}".format(path))
+    return _report(groundtruth, predictions, output_dir, "VidORval_predict_relations_{}.json".format(save_tag), save_json)
+
+
+def evaluate_combined(cfg_path, ckpt_path, cls_stage_result_path, save_tag="", output_dir=None, cuda=0, save_json=False, synthetic=0, n_trajs=32):
+    cfg = parse_config_py(cfg_path)
+    ic = cfg["inference_config"]
+    output_dir = output_dir or os.path.dirname(os.path.abspath(cfg_path))
+    os.makedirs(output_dir, exist_ok=True)
+    device = torch.device("cuda:%d" % cuda)
+    model = DEBUG(ensure_grounding_files(cfg["model_config"], output_dir), is_train=False).to(device)
+    if ckpt_path:
+        load_checkpoint_into(model, ckpt_path, device)
+    model.eval()
+    data = _load_data(cfg, synthetic, n_trajs, cfg["model_config"]["dim_feat"])
+    with open(cls_stage_result_path, "rb") as f:
+        cls_results = pickle.load(f)
+    predictions, groundtruth, n_skipped = {}, {}, 0
+    t0 = time.time()
+    for p, g, clip in data:
+        if g is not None:
+            groundtruth[p.video_name] = E.gt_to_eval_format(g)
+        res = cls_results.get(p.video_name)
+        if res is None:
+            continue
+        quint, scores, dura, qid = res
+        try:
+            with torch.no_grad():
+                out = model([clip.to(device)], [(quint.to(device), dura.to(device), p.video_len)], ic["score_th"], ic["tiou_th"],
+                            ic["bins_th"], ic["nms_th"], with_gt_data=False)
+        except IndexError as e:          # the reference stops here (min() of an empty selection, models/grd_model_v5.py:726)
+            print("skipping {}: {}".format(p.video_name, e))
+            n_skipped += 1
+            continue
+        if out[0] is None:
+            continue
+        predictions.update(E.to_eval_format(p.to(torch.device("cpu")), combine_with_grounding(res, out, p.video_len)))
+    print("grounding: %d videos (%d skipped) in %.2f s" % (len(data), n_skipped, time.time() - t0))
+    return _report(groundtruth, predictions, output_dir, "VidORval_predict_relations_aft_grd_{}.json".format(save_tag), save_json)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description="VidOR eval (classification stage / classification + grounding) on the MI355X HIP path")
+    ap.add_argument("--eval_cls_only", action="store_true")
+    ap.add_argument("--cfg_path", type=str)
+    ap.add_argument("--ckpt_path", type=str, default=None)
+    ap.add_argument("--output_dir", type=str, default=None)
+    ap.add_argument("--cuda", type=int, default=0)
+    ap.add_argument("--save_tag", type=str, default="")
+    ap.add_argument("--save_json_results", action="store_true")
+    ap.add_argument("--use_baseline", action="store_true")
+    ap.add_argument("--json_results_path", type=str, default=None)
+    ap.add_argument("--cls_stage_result_path", type=str, default=None)
+    ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N generated videos instead of a dataset")
+    ap.add_argument("--n_trajs", type=int, default=32)
+    a = ap.parse_args()
+    if a.use_baseline:
+        raise SystemExit("--use_baseline (Base_C, models/model_pairwise_baseline.py) is outside the BIG-C hot path built here")
+    if a.json_results_path is not None:
+        with open(a.json_results_path) as f:
+            _report({}, json.load(f), ".", "", False)
+    elif a.eval_cls_only:
+        evaluate_cls_stage(a.cfg_path, a.ckpt_path, a.save_tag, a.output_dir, a.cuda, a.save_json_results, a.synthetic, a.n_trajs)
+    else:
+        evaluate_combined(a.cfg_path, a.ckpt_path, a.cls_stage_result_path, a.save_tag, a.output_dir, a.cuda, a.save_json_results,
+                          a.synthetic, a.n_trajs)

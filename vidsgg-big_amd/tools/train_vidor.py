@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""VidOR training on the HIP path with the flags of the reference's ``tools/train_vidor.py:642-651``
+(``--cfg_path --from_checkpoint --ckpt_path --train_baseline --train_grounding --output_dir --save_tag``):
+BIG-C classification stage by default (``train_cls_stage`` :357-495), the temporal grounding scorer with
+``--train_grounding`` (``train_grounding_stage`` :497-636).  One process per GPU
+(``python -m torch.distributed.run --nproc-per-node N tools/train_vidor.py ...``); see ``_common.training_loop``."""
+import argparse
+import os
+
+import torch
+
+from _common import ensure_grounding_files, ensure_table_files, init_process, parse_config_py, synthetic_vidor_source, training_loop
+
+from models import BIG_C_vidor, DEBUG
+
+
+def _dataset(cfg):
+    from dataloaders.dataloader_vidor import Dataset                  # the reference's loader (tools/train_vidor.py:15)
+    ds = Dataset(**cfg["train_dataset_config"])
+    return [ds[i] for i in range(len(ds))]
+
+
+def train_cls_stage(cfg_path, output_dir=None, save_tag="", from_checkpoint=False, ckpt_path=None, synthetic=0, n_trajs=32, epochs=None):
+    rank, world, device, dist = init_process()
+    cfg = parse_config_py(cfg_path)
+    output_dir = output_dir or os.path.dirname(os.path.abspath(cfg_path))
+    os.makedirs(output_dir, exist_ok=True)
+    model_config = ensure_table_files(cfg["model_config"], output_dir)
+    torch.manual_seed(0)
+    model = BIG_C_vidor(model_config, is_train=True).to(device)
+    data = [(p, g) for p, g, _ in synthetic_vidor_source(model_config, synthetic, n_trajs, seed=8765)] if synthetic else _dataset(cfg)
+    gt_duras = {id(g): g.traj_durations.clone() for _, g in data}
+
+    def step(model, items):
+        gts = [g for _, g in items]
+        for g in gts:
+            g.traj_durations = gt_duras[id(g)].clone()      # the step decrements the GT end frames in place (models/model_0v7.py, as 0v10:567)
+        return model([p.to(device) for p, _ in items], gts)
+
+    return training_loop(model, data, cfg["train_config"], output_dir, save_tag, step, rank, world, device, dist,
+                         sort_key=lambda pg: pg[1].max_frames, from_checkpoint=from_checkpoint, ckpt_path=ckpt_path, epochs=epochs)
+
+
+def train_grounding_stage(cfg_path, output_dir=None, save_tag="", from_checkpoint=False, ckpt_path=None, synthetic=0, n_trajs=16, epochs=None):
+    rank, world, device, dist = init_process()
+    cfg = parse_config_py(cfg_path)
+    output_dir = output_dir or os.path.dirname(os.path.abspath(cfg_path))
+    os.makedirs(output_dir, exist_ok=True)
+    model_config = ensure_grounding_files(cfg["model_config"], output_dir)
+    torch.manual_seed(0)
+    model = DEBUG(model_config, is_train=True).to(device)
+    if synthetic:
+        data = [(clip, p, g) for p, g, clip in synthetic_vidor_source({}, synthetic, n_trajs, seed=9876, clip_dim=model_config["dim_feat"])]
+    else:
+        data = _dataset(cfg)                                 # (video_feature, proposal, gt_graph) with video_feature_dir set
+    torch.manual_seed(1000 + rank)                          # negative predicates are drawn from the global RNG (models/grd_model_v5.py:285-303)
+
+    def step(model, items):
+        return model([f.to(device) for f, _, _ in items], [g for _, _, g in items])
+
+    return training_loop(model, data, cfg["train_config"], output_dir, save_tag, step, rank, world, device, dist,
+                         from_checkpoint=from_checkpoint, ckpt_path=ckpt_path, epochs=epochs)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description="VidOR training (BIG-C or grounding stage) on the MI355X HIP path")
+    ap.add_argument("--cfg_path", type=str, required=True)
+    ap.add_argument("--from_checkpoint", action="store_true")
+    ap.add_argument("--ckpt_path", type=str, default=None)
+    ap.add_argument("--train_baseline", action="store_true")
+    ap.add_argument("--train_grounding", action="store_true")
+    ap.add_argument("--output_dir", type=str, default=None)
+    ap.add_argument("--save_tag", type=str, default="")
+    ap.add_argument("--synthetic", type=int, default=0, help="train on N generated videos instead of a dataset")
+    ap.add_argument("--n_trajs", type=int, default=None)
+    ap.add_argument("--epochs", type=int, default=None)
+    a = ap.parse_args()
+    if a.train_baseline:
+        raise SystemExit("--train_baseline (Base_C, models/model_pairwise_baseline.py) is outside the BIG-C hot path built here")
+    kw = dict(output_dir=a.output_dir, save_tag=a.save_tag, from_checkpoint=a.from_checkpoint, ckpt_path=a.ckpt_path, synthetic=a.synthetic,
+              epochs=a.epochs)
+    if a.n_trajs:
+        kw["n_trajs"] = a.n_trajs
+    (train_grounding_stage if a.train_grounding else train_cls_stage)(a.cfg_path, **kw)

@@ -14,31 +14,35 @@
 // lanes 32-63 take k+4..k+7 of each group of 8, which only permutes the order of the K
 // summation (the MFMA pairs k with k+4).
 // Roofline: f32 MFMA 157.3 TFLOP/s; 2*M*N*K flops per launch.
-#include "common.h"
+#include "linear_internal.h"
 #include "prof.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
-constexpr int BM = 128, BK = 32, PITCH = 36;
-
-struct LinearArgs {
-    const float* A; int lda; const int32_t* a_idx; int nseg; int seg_len;
-    const float* W; int ldw; const float* bias; const float* res; int ldr;
-    float* C; int ldc; int M, N, K; int act; int tiles_m, tiles_n;
-};
+constexpr int BM = 128;
+constexpr int SEG_ALIGN = 32;        // gather segments are multiples of this many columns
 
 // NT = number of 32-column MFMA tiles per wave: NT=2 -> 128x128 block tile, 2 workgroups per CU;
 // NT=4 -> 128x256 block tile (wave patch 64x128, 128 accumulator VGPRs), one workgroup per CU, i.e. one
 // wave per SIMD issuing 128 MFMAs between barriers (used when N >= 256: halves the barriers per flop
 // and the A re-reads).
-template <bool GATHER, int NT>
-__global__ __launch_bounds__(256, (NT == 4 ? 1 : 2)) void linear_f32_kernel(const LinearArgs p) {
+//
+// BK = K-slab depth: 32 (2 workgroups per CU, 73.7 KB of LDS each) or 16 (pitch 20 floats, 40 KB -> 4 workgroups per CU:
+// twice as many independent waves per SIMD to cover each other's barrier waits).
+template <bool GATHER, int NT, int BK, int OCC>
+__global__ __launch_bounds__(256, OCC) void linear_f32_kernel(const LinearArgs p) {
+    constexpr int PITCH = BK + 4;                    // 36 / 20 floats: odd number of 16-byte granules -> conflict-free b128
     constexpr int BNT = 64 * NT;                     // block tile width
-    constexpr int NB = BNT / 32;                     // float4 loads of W per thread per slab
+    constexpr int TPR = BK / 4;                      // threads per slab row (one float4 each)
+    constexpr int RP = 256 / TPR;                    // rows loaded per pass
+    constexpr int NA = BM / RP;                      // float4 loads of A per thread per slab
+    constexpr int NB = BNT / RP;                     // float4 loads of W per thread per slab
     __shared__ __attribute__((aligned(16))) float smem[2][(BM + BNT) * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
+    if (p.run_if && *p.run_if != p.run_id) return;   // range fallback of the split kernel: not needed
 
     // XCD-aware tile order: workgroup b lands on XCD b%8 (observed dispatch), so give each XCD
     // whole M-tiles and walk their N-tiles back to back: the A slab is then re-read from that
@@ -48,14 +52,14 @@ __global__ __launch_bounds__(256, (NT == 4 ? 1 : 2)) void linear_f32_kernel(cons
     if (tm >= p.tiles_m) return;
     const int m0 = tm * BM, n0 = tn * BNT;
 
-    const int lr = tid >> 3, lc = (tid & 7) * 4;
-    int arow[4];
+    const int lr = tid / TPR, lc = (tid % TPR) * 4;
+    int arow[NA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m0 + lr + 32 * i;
+    for (int i = 0; i < NA; ++i) {
+        int m = m0 + lr + RP * i;
         arow[i] = (m < p.M) ? m : -1;
     }
-    f32x4 ra[4], rb[NB];
+    f32x4 ra[NA], rb[NB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     int cur_seg = -1;
 
@@ -69,27 +73,27 @@ __global__ __launch_bounds__(256, (NT == 4 ? 1 : 2)) void linear_f32_kernel(cons
             if (seg != cur_seg) {
                 cur_seg = seg;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int m = m0 + lr + 32 * i;
+                for (int i = 0; i < NA; ++i) {
+                    int m = m0 + lr + RP * i;
                     arow[i] = p.a_idx[(size_t)min(m, p.M - 1) * p.nseg + seg];
                     if (m >= p.M) arow[i] = -1;
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NA; ++i)
             ra[i] = (arow[i] >= 0 && kval) ? *(const f32x4*)(p.A + (size_t)arow[i] * p.lda + acol) : zero4;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            int n = n0 + lr + 32 * i;
+            int n = n0 + lr + RP * i;
             rb[i] = (n < p.N && kval) ? *(const f32x4*)(p.W + (size_t)n * p.ldw + kc) : zero4;
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(f32x4*)(&smem[buf][(lr + 32 * i) * PITCH + lc]) = ra[i];
+        for (int i = 0; i < NA; ++i) *(f32x4*)(&smem[buf][(lr + RP * i) * PITCH + lc]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *(f32x4*)(&smem[buf][(BM + lr + 32 * i) * PITCH + lc]) = rb[i];
+        for (int i = 0; i < NB; ++i) *(f32x4*)(&smem[buf][(BM + lr + RP * i) * PITCH + lc]) = rb[i];
     };
 
     f32x16 acc[2][NT];
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256, (NT == 4 ? 1 : 2)) void linear_f32_kernel(cons
         const float* as = &smem[buf][(wm * 64 + l31) * PITCH + 4 * hi];
         const float* bs = &smem[buf][(BM + wn * 32 * NT + l31) * PITCH + 4 * hi];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < BK / 8; ++c) {
             f32x4 af[2], bf[NT];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) af[mi] = *(const f32x4*)(as + mi * 32 * PITCH + 8 * c);
@@ -188,7 +192,7 @@ extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int3
     BIGC_CHECK_ARG(A && W && C, "linear: null pointer");
     if (a_idx) {
         BIGC_CHECK_ARG(nseg >= 1 && seg_len > 0 && nseg * seg_len == K, "linear: K=%d != nseg*seg_len=%d*%d", K, nseg, seg_len);
-        BIGC_CHECK_ARG(nseg == 1 || seg_len % BK == 0, "linear: seg_len=%d must be a multiple of %d", seg_len, BK);
+        BIGC_CHECK_ARG(nseg == 1 || seg_len % SEG_ALIGN == 0, "linear: seg_len=%d must be a multiple of %d", seg_len, SEG_ALIGN);
     }
     LinearArgs p;
     p.A = A; p.lda = lda; p.a_idx = a_idx; p.nseg = a_idx ? nseg : 1; p.seg_len = a_idx ? seg_len : K;
@@ -196,19 +200,41 @@ extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int3
     p.M = M; p.N = N; p.K = K; p.act = act;
     p.tiles_m = cdiv(M, BM); p.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope ps(stream, FAM_LINEAR, 2.0 * M * (double)N * K,
-                 4.0 * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)));
+    const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1));
     static const int force_nt = getenv("BIGC_LINEAR_NT") ? atoi(getenv("BIGC_LINEAR_NT")) : 0;
+    static const int force_bk = getenv("BIGC_LINEAR_BK") ? atoi(getenv("BIGC_LINEAR_BK")) : 0;
+    static const bool exact_only = getenv("BIGC_LINEAR_EXACT") && atoi(getenv("BIGC_LINEAR_EXACT")) != 0;
+    p.run_if = nullptr; p.run_id = 0; p.Ws = nullptr; p.ldws = 0; p.flag = nullptr;
+    if (!exact_only) {
+        // split-operand f16 MFMA kernel first; the exact f32 kernel below then runs only if an operand left the f16 range
+        static int* range_flag = nullptr;
+        static std::atomic<int> launch_seq{0};
+        if (!range_flag) {
+            if (hipMalloc((void**)&range_flag, sizeof(int)) != hipSuccess || hipMemset(range_flag, 0, sizeof(int)) != hipSuccess)
+                return bigc_fail(BIGC_ERR_HIP, "linear: cannot allocate the range flag");
+        }
+        p.flag = range_flag;
+        p.run_id = ++launch_seq;
+        int rc = bigc_linear_split_launch(s, p, flops, bytes);
+        if (rc != BIGC_OK) return rc;
+        p.run_if = range_flag;
+    }
+    // the f32 kernel is the measured one only when it does the work; as the (normally idle) range fallback it is "aux"
+    ProfScope ps(stream, exact_only ? FAM_LINEAR : FAM_LINEAR_AUX, exact_only ? flops : 0.0, exact_only ? bytes : 0.0);
     // measured on MI355X (benchmarks/linear_shapes.py): NT=2 119 TFLOP/s aggregate, NT=4 112 -> NT=2 by default
     const int nt = (force_nt == 4) ? 4 : 2;
     p.tiles_n = cdiv(N, 64 * nt);
     const int grid = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
     if (nt == 4) {
-        if (a_idx) hipLaunchKernelGGL((linear_f32_kernel<true, 4>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((linear_f32_kernel<false, 4>), dim3(grid), dim3(256), 0, s, p);
+        if (a_idx) hipLaunchKernelGGL((linear_f32_kernel<true, 4, 32, 1>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((linear_f32_kernel<false, 4, 32, 1>), dim3(grid), dim3(256), 0, s, p);
+    } else if (force_bk == 32) {
+        if (a_idx) hipLaunchKernelGGL((linear_f32_kernel<true, 2, 32, 2>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((linear_f32_kernel<false, 2, 32, 2>), dim3(grid), dim3(256), 0, s, p);
     } else {
-        if (a_idx) hipLaunchKernelGGL((linear_f32_kernel<true, 2>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((linear_f32_kernel<false, 2>), dim3(grid), dim3(256), 0, s, p);
+        // K slabs of 16, three workgroups per CU: 122.8 vs 119.2 TFLOP/s aggregate for slabs of 32 with two
+        if (a_idx) hipLaunchKernelGGL((linear_f32_kernel<true, 2, 16, 3>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((linear_f32_kernel<false, 2, 16, 3>), dim3(grid), dim3(256), 0, s, p);
     }
     BIGC_LAUNCH_CHECK("linear_f32");
     return BIGC_OK;

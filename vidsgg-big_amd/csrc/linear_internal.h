@@ -1,0 +1,15 @@
+// Shared by linear.hip (exact f32 MFMA kernel) and linear_split.hip (f16x3 split-operand MFMA kernel).
+#pragma once
+#include "common.h"
+
+struct LinearArgs {
+    const float* A; int lda; const int32_t* a_idx; int nseg; int seg_len;
+    const float* W; int ldw; const float* bias; const float* res; int ldr;
+    float* C; int ldc; int M, N, K; int act; int tiles_m, tiles_n;
+    const int* run_if; int run_id;        // f32 kernel: when run_if != NULL, run only if *run_if == run_id (range fallback)
+    const uint4* Ws; int ldws;            // split kernel: W as [N][ldws] groups of 4 k: {4 x f16 head, 4 x f16 scaled residual}
+    int* flag;                            // split kernel: set to run_id when an operand leaves the f16 range
+};
+
+// launches the split-operand kernel (and its W pre-split pass); returns BIGC_OK or an error code
+int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double bytes);

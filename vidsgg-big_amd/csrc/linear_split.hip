@@ -1,0 +1,268 @@
+// Split-operand "linear" kernel: the same C = act(A' W^T + bias) + residual as linear.hip, with f32 accuracy, on the
+// f16 matrix cores (v_mfma_f32_32x32x16_f16, 16x the rate of the f32 MFMA).
+//
+// Every f32 operand x is split exactly into two f16 numbers, x = h + r * 2^-11 with h = f16(x) (the 11 leading bits) and
+// r = f16((x - float(h)) * 2^11) (the next 11 bits; x - float(h) is exact in f32).  Then
+//     a * w = h_a h_w + 2^-11 (h_a r_w + r_a h_w) + 2^-22 r_a r_w
+// and the last term (<= 2^-22 relative, f32 round-off level) is dropped: three f16 MFMAs per product, accumulated in
+// f32 in TWO accumulators (leading term / correction terms, combined as acc0 + 2^-11 acc1 in the epilogue, so the small
+// terms are not absorbed by the large partial sum).  Products of f16 pairs are exact in f32.
+// Range: f16 holds |x| < 65504; an operand beyond that (or a NaN/Inf) makes a residual non-finite, which the staging
+// code notices and reports through `flag`; the caller then re-runs that launch on the exact f32 kernel (linear.hip,
+// `run_if`).  Tiny operands (|x| < 2^-35) contribute 0, an absolute error below 3e-11 per element.
+//
+// Tiling: 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, wave patch 64x64 = 2x2 MFMA blocks x 2
+// accumulators (128 accumulator registers), K slabs of 32, two workgroups per CU.  LDS holds four f16 planes per slab
+// (A head, A residual, W head, W residual), rows of 64 bytes with the 16-byte chunks XOR-swizzled by (row >> 2) & 3:
+// both the ds_read_b128 fragment reads (lane = row, 8 consecutive k) and the ds_write_b64 stores are conflict-free.
+// W is split once per launch by a small pre-pass into [N][K/4] 16-byte groups {4 heads, 4 residuals} (same footprint
+// as f32), A is split by the staging code on its way from HBM to LDS.
+// Roofline: f16 MFMA dense peak / 3 MFMAs per product.
+#include "linear_internal.h"
+#include "prof.h"
+#include <atomic>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr float RSCALE = 2048.0f, RINV = 1.0f / 2048.0f;
+constexpr float F16_LIMIT = 32768.0f;      // operands at or beyond this magnitude take the exact f32 kernel
+
+union Pack4 { fp16x2 h[2]; uint2 u; };
+
+// four consecutive f32 -> 4 heads + 4 scaled residuals (8 bytes each).  `chk` accumulates the residuals (NaN when an
+// element is NaN/Inf), `amax` the largest magnitude (the round-toward-zero conversion saturates at 65504 instead of
+// overflowing, so the range is checked on the input)
+__device__ __forceinline__ void split4(const f32x4 x, uint2& head, uint2& resid, float& chk, float& amax) {
+    Pack4 h, r;
+    h.h[0] = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
+    h.h[1] = __builtin_amdgcn_cvt_pkrtz(x[2], x[3]);
+    const float r0 = (x[0] - (float)h.h[0][0]) * RSCALE, r1 = (x[1] - (float)h.h[0][1]) * RSCALE;
+    const float r2 = (x[2] - (float)h.h[1][0]) * RSCALE, r3 = (x[3] - (float)h.h[1][1]) * RSCALE;
+    r.h[0] = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    r.h[1] = __builtin_amdgcn_cvt_pkrtz(r2, r3);
+    chk += (r0 + r1) + (r2 + r3);
+    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[0]), __builtin_fabsf(x[1])));
+    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[2]), __builtin_fabsf(x[3])));
+    head = h.u;
+    resid = r.u;
+}
+
+// W (N, K) f32 -> Ws (N, K/4) groups of 16 bytes
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int ldw, uint4* __restrict__ Ws, int N, int K4,
+                                                           int* flag, int run_id) {
+    float chk = 0.f, amax = 0.f;
+    const long total = (long)N * K4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / K4), k4 = (int)(i - (long)n * K4);
+        const f32x4 x = *(const f32x4*)(W + (size_t)n * ldw + 4 * k4);
+        uint2 h, r;
+        split4(x, h, r, chk, amax);
+        Ws[i] = make_uint4(h.x, h.y, r.x, r.y);
+    }
+    if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) atomicMax(flag, run_id);
+}
+
+__device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((row >> 2) & 3); }
+
+template <bool GATHER>
+__global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p) {
+    // [buffer][plane: A head, A resid, W head, W resid][128 rows][64 bytes]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][4][BM * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
+
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
+    if (tm >= p.tiles_m) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int lr = tid >> 3, q = tid & 7, lc = q * 4;
+    int arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + lr + 32 * i;
+        arow[i] = (m < p.M) ? m : -1;
+    }
+    f32x4 ra[4];
+    uint4 rb[4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const uint4 zero4u = make_uint4(0, 0, 0, 0);
+    int cur_seg = -1;
+    float chk = 0.f, amax = 0.f;
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK, kc = k0 + lc;
+        const bool kval = kc < p.K;
+        int acol = kc;
+        if (GATHER) {
+            const int seg = k0 / p.seg_len;
+            acol = kc - seg * p.seg_len;
+            if (seg != cur_seg) {
+                cur_seg = seg;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int m = m0 + lr + 32 * i;
+                    arow[i] = p.a_idx[(size_t)min(m, p.M - 1) * p.nseg + seg];
+                    if (m >= p.M) arow[i] = -1;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ra[i] = (arow[i] >= 0 && kval) ? *(const f32x4*)(p.A + (size_t)arow[i] * p.lda + acol) : zero4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int n = n0 + lr + 32 * i;
+            rb[i] = (n < p.N && kval) ? p.Ws[(size_t)n * p.ldws + (kc >> 2)] : zero4u;
+        }
+    };
+    // this thread's 8 bytes inside a row: chunk q>>1 (swizzled), half q&1
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lr + 32 * i;
+            const int off = row * 64 + swz(q >> 1, row) * 16 + (q & 1) * 8;
+            uint2 h, r;
+            split4(ra[i], h, r, chk, amax);
+            *(uint2*)(&smem[buf][0][off]) = h;
+            *(uint2*)(&smem[buf][1][off]) = r;
+            *(uint2*)(&smem[buf][2][off]) = make_uint2(rb[i].x, rb[i].y);
+            *(uint2*)(&smem[buf][3][off]) = make_uint2(rb[i].z, rb[i].w);
+        }
+    };
+
+    f32x16 acc0[2][2], acc1[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[mi][ni][r] = 0.f; acc1[mi][ni][r] = 0.f; }
+
+    // fragment addresses: lane = row l31 of a 32-row block, k = 16 s + 8 hi .. + 7 -> chunk 2 s + hi
+    int aoff[2][2], boff[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ra_ = wm * 64 + mi * 32 + l31, rb_ = wn * 64 + mi * 32 + l31;
+            aoff[mi][s] = ra_ * 64 + swz(2 * s + hi, ra_) * 16;
+            boff[mi][s] = rb_ * 64 + swz(2 * s + hi, rb_) * 16;
+        }
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tiles(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 a1[2], a2[2], b1[2], b2[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                a1[mi] = *(const f16x8*)(&smem[buf][0][aoff[mi][s]]);
+                a2[mi] = *(const f16x8*)(&smem[buf][1][aoff[mi][s]]);
+                b1[mi] = *(const f16x8*)(&smem[buf][2][boff[mi][s]]);
+                b2[mi] = *(const f16x8*)(&smem[buf][3][boff[mi][s]]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc0[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mi], b1[ni], acc0[mi][ni], 0, 0, 0);
+                    acc1[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mi], b2[ni], acc1[mi][ni], 0, 0, 0);
+                    acc1[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[mi], b1[ni], acc1[mi][ni], 0, 0, 0);
+                }
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) atomicMax(p.flag, p.run_id);
+
+    int colv[2];
+    float bv[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        colv[ni] = n0 + wn * 64 + ni * 32 + l31;
+        bv[ni] = p.bias ? p.bias[min(colv[ni], p.N - 1)] : 0.f;
+    }
+    const bool relu = p.act == BIGC_ACT_RELU, sigm = p.act == BIGC_ACT_SIGMOID;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int rbase = m0 + wm * 64 + mi * 32;
+        f32x16 rv[2];
+        if (p.res) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const float* rp = p.res + min(colv[ni], p.N - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[ni][r] = rp[(size_t)min(rbase + mfma_row(r, hi), p.M - 1) * p.ldr];
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[ni][r] = 0.f;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            if (colv[ni] >= p.N) continue;
+            float* cp = p.C + colv[ni];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + mfma_row(r, hi);
+                float v = (acc0[mi][ni][r] + acc1[mi][ni][r] * RINV) + bv[ni];
+                if (relu) v = fmaxf(v, 0.f);
+                if (sigm) v = 1.0f / (1.0f + expf(-v));
+                v += rv[ni][r];
+                if (row < p.M) cp[(size_t)row * p.ldc] = v;
+            }
+        }
+    }
+}
+
+// per-process scratch for the split weights (stream-ordered reuse: launches of one stream only)
+uint4* g_ws = nullptr;
+size_t g_ws_cap = 0;
+
+}  // namespace
+
+int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double bytes) {
+    const int K4 = (p.K + 3) / 4;
+    const size_t need = (size_t)p.N * K4;
+    if (need > g_ws_cap) {
+        if (g_ws) {
+            if (hipStreamSynchronize(s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_split: sync failed");
+            (void)hipFree(g_ws);
+        }
+        g_ws_cap = need < (1u << 20) ? (1u << 20) : need + need / 2;
+        if (hipMalloc((void**)&g_ws, g_ws_cap * sizeof(uint4)) != hipSuccess) {
+            g_ws = nullptr; g_ws_cap = 0;
+            return bigc_fail(BIGC_ERR_HIP, "linear_split: hipMalloc of the weight scratch failed");
+        }
+    }
+    p.Ws = g_ws; p.ldws = K4;
+    {
+        ProfScope ps((void*)s, FAM_LINEAR_AUX, 0.0, 8.0 * p.N * (double)p.K);
+        long total = (long)p.N * K4;
+        int grid = (int)((total + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(split_weight_kernel, dim3(grid), dim3(256), 0, s, p.W, p.ldw, g_ws, p.N, K4, p.flag, p.run_id);
+        BIGC_LAUNCH_CHECK("split_weight");
+    }
+    p.tiles_n = cdiv(p.N, BN);
+    const int grid = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
+    ProfScope ps((void*)s, FAM_LINEAR, flops, bytes);
+    if (p.a_idx) hipLaunchKernelGGL((linear_split_kernel<true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((linear_split_kernel<false>), dim3(grid), dim3(256), 0, s, p);
+    BIGC_LAUNCH_CHECK("linear_split");
+    return BIGC_OK;
+}

@@ -46,14 +46,14 @@ __device__ __forceinline__ void split4(const f32x4 x, uint2& head, uint2& resid,
     r.h[0] = __builtin_amdgcn_cvt_pkrtz(r0, r1);
     r.h[1] = __builtin_amdgcn_cvt_pkrtz(r2, r3);
     chk += (r0 + r1) + (r2 + r3);
-    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[0]), __builtin_fabsf(x[1])));
-    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[2]), __builtin_fabsf(x[3])));
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(amax) : "v"(amax), "v"(x[0]), "v"(x[1]));
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(amax) : "v"(amax), "v"(x[2]), "v"(x[3]));
     head = h.u;
     resid = r.u;
 }
 
 // W (N, K) f32 -> Ws (N, K/4) groups of 16 bytes
-__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int ldw, uint4* __restrict__ Ws, int N, int K4,
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int ldw, u32x4* __restrict__ Ws, int N, int K4,
                                                            int* flag, int run_id) {
     float chk = 0.f, amax = 0.f;
     const long total = (long)N * K4;
@@ -62,14 +62,14 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
         const f32x4 x = *(const f32x4*)(W + (size_t)n * ldw + 4 * k4);
         uint2 h, r;
         split4(x, h, r, chk, amax);
-        Ws[i] = make_uint4(h.x, h.y, r.x, r.y);
+        Ws[i] = u32x4{h.x, h.y, r.x, r.y};
     }
     if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) atomicMax(flag, run_id);
 }
 
 __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((row >> 2) & 3); }
 
-template <bool GATHER>
+template <bool GATHER, bool KTAIL>
 __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p) {
     // [buffer][plane: A head, A resid, W head, W resid][128 rows][64 bytes]
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][4][BM * 64];
@@ -82,23 +82,30 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int lr = tid >> 3, q = tid & 7, lc = q * 4;
-    int arow[4];
+    // Loads are unconditional (one basic block per K step, so that the scheduler can interleave the split arithmetic
+    // with the MFMAs): rows past M / N are clamped to the last valid row -- their products land in accumulator rows /
+    // columns that are never stored -- and only a ragged last slab (KTAIL) or a gather index of -1 (a zero row) select 0.
+    const float* arow[4];
+    bool azero[4] = {false, false, false, false};
+    const u32x4* wrow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int m = m0 + lr + 32 * i;
-        arow[i] = (m < p.M) ? m : -1;
+        arow[i] = p.A + (size_t)min(m0 + lr + 32 * i, p.M - 1) * p.lda;
+        wrow[i] = p.Ws + (size_t)min(n0 + lr + 32 * i, p.N - 1) * p.ldws;
     }
-    f32x4 ra[4];
-    uint4 rb[4];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const uint4 zero4u = make_uint4(0, 0, 0, 0);
+    // A is prefetched two slabs ahead in two register sets (its rows stream from HBM), W one slab ahead (L2-resident)
+    f32x4 ra0[4], ra1[4];
+    u32x4 rb[4];
     int cur_seg = -1;
     float chk = 0.f, amax = 0.f;
+    const int nk = (p.K + BK - 1) / BK;
 
-    auto load_tiles = [&](int kt) {
-        const int k0 = kt * BK, kc = k0 + lc;
-        const bool kval = kc < p.K;
-        int acol = kc;
+    auto slab_cols = [&](int kt, int& kc, int& acol, bool& kval) {
+        const int k0 = kt * BK;
+        kc = k0 + lc;
+        kval = true;
+        if (KTAIL) { kval = kc < p.K; kc = min(kc, p.K - 4); }
+        acol = kc;
         if (GATHER) {
             const int seg = k0 / p.seg_len;
             acol = kc - seg * p.seg_len;
@@ -106,33 +113,48 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
                 cur_seg = seg;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    int m = m0 + lr + 32 * i;
-                    arow[i] = p.a_idx[(size_t)min(m, p.M - 1) * p.nseg + seg];
-                    if (m >= p.M) arow[i] = -1;
+                    const int src = p.a_idx[(size_t)min(m0 + lr + 32 * i, p.M - 1) * p.nseg + seg];
+                    azero[i] = src < 0;
+                    arow[i] = p.A + (size_t)max(src, 0) * p.lda;
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            ra[i] = (arow[i] >= 0 && kval) ? *(const f32x4*)(p.A + (size_t)arow[i] * p.lda + acol) : zero4;
+    };
+    auto load_a = [&](int kt, f32x4 (&ra)[4]) {
+        int kc, acol; bool kval;
+        slab_cols(kt, kc, acol, kval);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int n = n0 + lr + 32 * i;
-            rb[i] = (n < p.N && kval) ? p.Ws[(size_t)n * p.ldws + (kc >> 2)] : zero4u;
+            ra[i] = *(const f32x4*)(arow[i] + acol);
+            if ((KTAIL && !kval) || (GATHER && azero[i])) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto load_w = [&](int kt) {
+        int kc = kt * BK + lc;
+        bool kval = true;
+        if (KTAIL) { kval = kc < p.K; kc = min(kc, p.K - 4); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rb[i] = wrow[i][kc >> 2];
+            if (KTAIL && !kval) rb[i] = u32x4{0u, 0u, 0u, 0u};
         }
     };
     // this thread's 8 bytes inside a row: chunk q>>1 (swizzled), half q&1
-    auto store_tiles = [&](int buf) {
+    int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = lr + 32 * i;
+        soff[i] = row * 64 + swz(q >> 1, row) * 16 + (q & 1) * 8;
+    }
+    auto store_tiles = [&](int buf, const f32x4 (&ra)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = lr + 32 * i;
-            const int off = row * 64 + swz(q >> 1, row) * 16 + (q & 1) * 8;
             uint2 h, r;
             split4(ra[i], h, r, chk, amax);
-            *(uint2*)(&smem[buf][0][off]) = h;
-            *(uint2*)(&smem[buf][1][off]) = r;
-            *(uint2*)(&smem[buf][2][off]) = make_uint2(rb[i].x, rb[i].y);
-            *(uint2*)(&smem[buf][3][off]) = make_uint2(rb[i].z, rb[i].w);
+            *(uint2*)(&smem[buf][0][soff[i]]) = h;
+            *(uint2*)(&smem[buf][1][soff[i]]) = r;
+            *(uint2*)(&smem[buf][2][soff[i]]) = make_uint2(rb[i][0], rb[i][1]);
+            *(uint2*)(&smem[buf][3][soff[i]]) = make_uint2(rb[i][2], rb[i][3]);
         }
     };
 
@@ -155,14 +177,12 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
             boff[mi][s] = rb_ * 64 + swz(2 * s + hi, rb_) * 16;
         }
 
-    const int nk = (p.K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    // one K step: slab kt is in LDS buffer kt&1, `sp` holds the raw A rows of slab kt+1, `ld` receives slab kt+2
+    // (slabs past the end repeat the last one: loaded and stored into the idle buffer, never read)
+    auto step = [&](int kt, f32x4 (&ld)[4], const f32x4 (&sp)[4]) {
         const int buf = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tiles(kt + 1);
+        load_w(min(kt + 1, nk - 1));
+        load_a(min(kt + 2, nk - 1), ld);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 a1[2], a2[2], b1[2], b2[2];
@@ -182,8 +202,18 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
                     acc1[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[mi], b1[ni], acc1[mi][ni], 0, 0, 0);
                 }
         }
-        if (more) store_tiles(buf ^ 1);
+        store_tiles(buf ^ 1, sp);
         __syncthreads();
+    };
+
+    load_a(0, ra0);
+    load_w(0);
+    load_a(min(1, nk - 1), ra1);
+    store_tiles(0, ra0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, ra0, ra1);
+        if (kt + 1 < nk) step(kt + 1, ra1, ra0);
     }
     if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) atomicMax(p.flag, p.run_id);
 
@@ -230,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
 }
 
 // per-process scratch for the split weights (stream-ordered reuse: launches of one stream only)
-uint4* g_ws = nullptr;
+u32x4* g_ws = nullptr;
 size_t g_ws_cap = 0;
 
 }  // namespace
@@ -244,7 +274,7 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
             (void)hipFree(g_ws);
         }
         g_ws_cap = need < (1u << 20) ? (1u << 20) : need + need / 2;
-        if (hipMalloc((void**)&g_ws, g_ws_cap * sizeof(uint4)) != hipSuccess) {
+        if (hipMalloc((void**)&g_ws, g_ws_cap * sizeof(u32x4)) != hipSuccess) {
             g_ws = nullptr; g_ws_cap = 0;
             return bigc_fail(BIGC_ERR_HIP, "linear_split: hipMalloc of the weight scratch failed");
         }
@@ -261,8 +291,14 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
     p.tiles_n = cdiv(p.N, BN);
     const int grid = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
     ProfScope ps((void*)s, FAM_LINEAR, flops, bytes);
-    if (p.a_idx) hipLaunchKernelGGL((linear_split_kernel<true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((linear_split_kernel<false>), dim3(grid), dim3(256), 0, s, p);
+    const bool ktail = p.K % BK != 0;
+    if (p.a_idx) {
+        if (ktail) hipLaunchKernelGGL((linear_split_kernel<true, true>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((linear_split_kernel<true, false>), dim3(grid), dim3(256), 0, s, p);
+    } else {
+        if (ktail) hipLaunchKernelGGL((linear_split_kernel<false, true>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((linear_split_kernel<false, false>), dim3(grid), dim3(256), 0, s, p);
+    }
     BIGC_LAUNCH_CHECK("linear_split");
     return BIGC_OK;
 }

@@ -498,6 +498,7 @@ extern "C" int grd_finalize(grd_model* m, void* stream) {
     hipLaunchKernelGGL(build_query_weight_kernel, dim3(cdiv(d * m->kq, 256)), dim3(256), 0, (hipStream_t)stream, qfc.w, qfc.b, tfc.w, tfc.b,
                        m->wq, m->bq, d, c.dim_clsme, m->kq);
     BIGC_LAUNCH_CHECK("build_query_weight");
+    m->epoch = bigc_next_weights_epoch();
     m->finalized = true;
     return BIGC_OK;
 }
@@ -514,6 +515,7 @@ extern "C" int grd_forward(grd_model* m, void* stream, const float* video_feat, 
                            float video_len, const float* pos_video, const float* pos_query, const float* clip,
                            float score_th, float tiou_th, float bins_th, float nms_th,
                            void* workspace, size_t workspace_bytes, const grd_outputs* out) {
+    StaticWeights static_weights(m ? m->epoch : 0);
     BIGC_CHECK_ARG(m && video_feat && quint && dura && pos_video && pos_query && clip && out, "grd_forward: null pointer");
     BIGC_CHECK_ARG(m->finalized, "grd_forward: call grd_finalize after setting the parameters");
     BIGC_CHECK_ARG(T > 0 && n > 0 && video_len > 0, "grd_forward: T=%d n=%d video_len=%f", T, n, video_len);

@@ -11,6 +11,7 @@ struct grd_model {
     std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
     std::unordered_map<std::string, float*> grads;     // gradient destinations (training)
     bool finalized = false;
+    unsigned long long epoch = 0;          // drawn at finalize: scope of the cached split weights
     const float *enti = nullptr, *pred = nullptr;
     Lin video_fc, vq_fc, proj2sim, query_fc, temp_fc;
     Enc video_enc, query_enc, comb_enc;

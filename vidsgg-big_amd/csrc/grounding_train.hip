@@ -398,6 +398,7 @@ struct GBwd {
         const int n4 = round4(N);
         BIGC_CHECK_ARG(ldy % 4 == 0 && ldy >= n4, "grd_train: dY leading dimension %d must be a multiple of 4 and >= %d", ldy, n4);
         TRY(bigc_transpose_pad((hipStream_t)s, W, w->wT, N, K, n4));
+        StaticWeights transposed_copy(0);      // w->wT is rewritten for every layer
         return bigc_linear_f32(s, dY, ldy, nullptr, 1, n4, w->wT, n4, nullptr, acc ? dX : nullptr, lddx, dX, lddx, M, K, n4, BIGC_ACT_NONE);
     }
     int lin(const std::string& key, const Lin& L, const float* dY, int ldy, const float* X, int ldx, int M, int N, int K, float* dX, int lddx,
@@ -497,6 +498,7 @@ extern "C" size_t grd_train_workspace_bytes(const grd_model* m, int T, int n) {
 extern "C" int grd_train_forward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, const int32_t* dura, int n,
                                  float video_len, const float* pos_video, const float* pos_query, void* workspace, size_t workspace_bytes,
                                  float* regrs, float* conf, float* cls) {
+    StaticWeights static_weights(m ? m->epoch : 0);
     BIGC_CHECK_ARG(m && video_feat && quint && dura && pos_video && pos_query && regrs && conf && cls, "grd_train_forward: null pointer");
     BIGC_CHECK_ARG(m->finalized && T > 0 && T <= 2048 && n > 0 && video_len > 0, "grd_train_forward: bad argument");
     const grd_config& c = m->cfg;
@@ -546,6 +548,7 @@ extern "C" int grd_loss_grad(void* stream, const float* regrs, const float* conf
 
 extern "C" int grd_train_backward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, int n,
                                   void* workspace, size_t workspace_bytes, const float* dregr, const float* dconf, const float* dcls) {
+    StaticWeights static_weights(m ? m->epoch : 0);
     BIGC_CHECK_ARG(m && video_feat && quint && dregr && dconf && dcls, "grd_train_backward: null pointer");
     const grd_config& c = m->cfg;
     const int d = c.dim_hidden, k = c.num_bins;

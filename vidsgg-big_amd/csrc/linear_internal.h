@@ -11,6 +11,18 @@ struct LinearArgs {
     const int* run_if; int run_id;        // f32 kernel: when run_if != NULL, run only if *run_if == run_id (range fallback)
     const u32x4* Ws; int ldws;            // split kernel: W as [N][ldws] groups of 4 k: {4 x f16 head, 4 x f16 scaled residual}
     int* flag;                            // split kernel: set to run_id when an operand leaves the f16 range
+    const int* wbad;                      // split kernel: non-zero when the (cached) split W holds an out-of-range element
+};
+
+// Weights that stay constant between launches are split once and cached per (pointer, shape) for an "epoch": the model
+// entry points open a StaticWeights scope with the epoch they drew at finalize time; outside such a scope (epoch 0, e.g.
+// the raw bigc_linear_f32 entry point or the transposed weight copies of the backward pass) W is split on every launch.
+extern thread_local unsigned long long bigc_static_weights_epoch;
+unsigned long long bigc_next_weights_epoch();
+struct StaticWeights {
+    unsigned long long prev;
+    explicit StaticWeights(unsigned long long e) : prev(bigc_static_weights_epoch) { bigc_static_weights_epoch = e; }
+    ~StaticWeights() { bigc_static_weights_epoch = prev; }
 };
 
 // launches the split-operand kernel (and its W pre-split pass); returns BIGC_OK or an error code

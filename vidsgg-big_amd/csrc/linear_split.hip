@@ -21,6 +21,8 @@
 #include "linear_internal.h"
 #include "prof.h"
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
 
 namespace {
 
@@ -54,7 +56,7 @@ __device__ __forceinline__ void split4(const f32x4 x, uint2& head, uint2& resid,
 
 // W (N, K) f32 -> Ws (N, K/4) groups of 16 bytes
 __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int ldw, u32x4* __restrict__ Ws, int N, int K4,
-                                                           int* flag, int run_id) {
+                                                           int* bad) {
     float chk = 0.f, amax = 0.f;
     const long total = (long)N * K4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -64,8 +66,10 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
         split4(x, h, r, chk, amax);
         Ws[i] = u32x4{h.x, h.y, r.x, r.y};
     }
-    if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) atomicMax(flag, run_id);
+    if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) *bad = 1;
 }
+
+__global__ void clear_flag_kernel(int* bad) { *bad = 0; }
 
 __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((row >> 2) & 3); }
 
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
         step(kt, ra0, ra1);
         if (kt + 1 < nk) step(kt + 1, ra1, ra0);
     }
-    if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) atomicMax(p.flag, p.run_id);
+    if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT || *p.wbad != 0) atomicMax(p.flag, p.run_id);
 
     int colv[2];
     float bv[2];
@@ -259,34 +263,64 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
     }
 }
 
-// per-process scratch for the split weights (stream-ordered reuse: launches of one stream only)
-u32x4* g_ws = nullptr;
-size_t g_ws_cap = 0;
+// split weights: one allocation per (pointer, shape) = [int bad | pad to 256 B | N x K/4 groups]; re-split in place when the
+// epoch differs (or on every launch at epoch 0, where a single scratch entry is reused in stream order)
+struct WKey {
+    const float* w; int n, k, ldw;
+    bool operator==(const WKey& o) const { return w == o.w && n == o.n && k == o.k && ldw == o.ldw; }
+};
+struct WKeyHash { size_t operator()(const WKey& k) const { return std::hash<const void*>()(k.w) ^ ((size_t)k.n * 1315423911u) ^ ((size_t)k.k << 20) ^ (size_t)k.ldw; } };
+struct WEntry { char* mem = nullptr; size_t cap = 0; unsigned long long epoch = 0; };
+std::unordered_map<WKey, WEntry, WKeyHash> g_cache;
+WEntry g_scratch;
+std::mutex g_cache_mu;
+std::atomic<unsigned long long> g_epoch_seq{0};
+
+int ensure_split(hipStream_t s, const LinearArgs& p, int K4, WEntry& e, bool fresh) {
+    const size_t need = 256 + (size_t)p.N * K4 * sizeof(u32x4);
+    if (need > e.cap) {
+        if (e.mem) {
+            if (hipStreamSynchronize(s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_split: sync failed");
+            (void)hipFree(e.mem);
+        }
+        e.cap = fresh ? need + need / 2 : need;
+        if (hipMalloc((void**)&e.mem, e.cap) != hipSuccess) {
+            e.mem = nullptr; e.cap = 0;
+            return bigc_fail(BIGC_ERR_HIP, "linear_split: hipMalloc of the split weights failed");
+        }
+    }
+    ProfScope ps((void*)s, FAM_LINEAR_AUX, 0.0, 8.0 * p.N * (double)p.K);
+    hipLaunchKernelGGL(clear_flag_kernel, dim3(1), dim3(1), 0, s, (int*)e.mem);
+    long total = (long)p.N * K4;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(split_weight_kernel, dim3(grid), dim3(256), 0, s, p.W, p.ldw, (u32x4*)(e.mem + 256), p.N, K4, (int*)e.mem);
+    BIGC_LAUNCH_CHECK("split_weight");
+    return BIGC_OK;
+}
 
 }  // namespace
 
+thread_local unsigned long long bigc_static_weights_epoch = 0;
+unsigned long long bigc_next_weights_epoch() { return ++g_epoch_seq; }
+
 int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double bytes) {
     const int K4 = (p.K + 3) / 4;
-    const size_t need = (size_t)p.N * K4;
-    if (need > g_ws_cap) {
-        if (g_ws) {
-            if (hipStreamSynchronize(s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_split: sync failed");
-            (void)hipFree(g_ws);
-        }
-        g_ws_cap = need < (1u << 20) ? (1u << 20) : need + need / 2;
-        if (hipMalloc((void**)&g_ws, g_ws_cap * sizeof(u32x4)) != hipSuccess) {
-            g_ws = nullptr; g_ws_cap = 0;
-            return bigc_fail(BIGC_ERR_HIP, "linear_split: hipMalloc of the weight scratch failed");
-        }
-    }
-    p.Ws = g_ws; p.ldws = K4;
     {
-        ProfScope ps((void*)s, FAM_LINEAR_AUX, 0.0, 8.0 * p.N * (double)p.K);
-        long total = (long)p.N * K4;
-        int grid = (int)((total + 255) / 256);
-        if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(split_weight_kernel, dim3(grid), dim3(256), 0, s, p.W, p.ldw, g_ws, p.N, K4, p.flag, p.run_id);
-        BIGC_LAUNCH_CHECK("split_weight");
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        const unsigned long long epoch = bigc_static_weights_epoch;
+        WEntry* e = &g_scratch;
+        bool stale = true;
+        if (epoch != 0) {
+            e = &g_cache[WKey{p.W, p.N, p.K, p.ldw}];
+            stale = e->epoch != epoch;
+        }
+        if (stale) {
+            int rc = ensure_split(s, p, K4, *e, epoch == 0);
+            if (rc != BIGC_OK) return rc;
+            e->epoch = epoch;
+        }
+        p.Ws = (const u32x4*)(e->mem + 256); p.ldws = K4; p.wbad = (const int*)e->mem;
     }
     p.tiles_n = cdiv(p.N, BN);
     const int grid = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;

@@ -202,6 +202,7 @@ extern "C" int bigc_finalize(bigc_model* m, void* stream) {
         if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "finalize: hipMalloc: %s", hipGetErrorString(e));
     }
     TRY(bigc_repack_conv_weight((hipStream_t)stream, m->conv.w, m->conv_w_tapmajor, de, 2 * de, 3));
+    m->epoch = bigc_next_weights_epoch();
     m->finalized = true;
     return BIGC_OK;
 }
@@ -216,6 +217,7 @@ extern "C" size_t bigc_workspace_bytes(const bigc_model* m, const bigc_batch* b)
 
 extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                             int topk, const bigc_outputs* out) {
+    StaticWeights static_weights(m ? m->epoch : 0);
     BIGC_CHECK_ARG(m && b && out, "forward: null pointer");
     BIGC_CHECK_ARG(m->finalized, "forward: call bigc_finalize after setting the parameters");
     BIGC_CHECK_ARG(b->n_vid > 0 && b->n_trk > 0 && b->n_rows > 0 && b->n_conv > 0, "forward: empty batch");

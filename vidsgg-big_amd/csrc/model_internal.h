@@ -1,6 +1,7 @@
 // Internal definitions shared by model.hip (eval forward) and train.hip (training forward/backward).
 #pragma once
 #include "common.h"
+#include "linear_internal.h"
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -15,6 +16,7 @@ struct bigc_model {
     std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
     std::unordered_map<std::string, float*> grads;      // gradient destination of each trainable parameter (training)
     bool finalized = false;
+    unsigned long long epoch = 0;          // drawn at finalize: scope of the cached split weights (linear_internal.h)
     // resolved
     const float *emb = nullptr, *pos = nullptr, *qinit = nullptr, *bias_matrix = nullptr;
     Lin feat0, feat2, bbox0, bbox2, conv, enco0, enco2, i3d, head0, head2;

@@ -156,6 +156,7 @@ struct Bwd {
         const int n4 = round4(N);
         BIGC_CHECK_ARG(ldy % 4 == 0 && ldy >= n4, "train: dY leading dimension %d must be a multiple of 4 and >= %d", ldy, n4);
         TRY(bigc_transpose_pad((hipStream_t)s, W, w->wT, N, K, n4));
+        StaticWeights transposed_copy(0);      // w->wT is rewritten for every layer
         return bigc_linear_f32(s, dY, ldy, nullptr, 1, n4, w->wT, n4, nullptr, accumulate ? dX : nullptr, lddx, dX, lddx, M, K, n4,
                                BIGC_ACT_NONE);
     }
@@ -188,6 +189,7 @@ static int open_arena(const bigc_model* m, const bigc_batch* b, void* workspace,
 
 extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                                   float* pred_logits, float* att_out) {
+    StaticWeights static_weights(m ? m->epoch : 0);
     BIGC_CHECK_ARG(m && b && pred_logits && att_out, "train_forward: null pointer");
     BIGC_CHECK_ARG(m->finalized, "train_forward: call bigc_finalize first");
     BIGC_CHECK_ARG(b->n_vid > 0 && b->n_trk > 0 && b->n_rows > 0 && b->n_conv > 0 && b->max_trk > 0 && b->max_trk <= 512, "train_forward: bad batch");
@@ -310,6 +312,7 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
 
 extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                                    const float* dlogits, int ldg, const float* datt) {
+    StaticWeights static_weights(m ? m->epoch : 0);
     BIGC_CHECK_ARG(m && b && dlogits && datt, "train_backward: null pointer");
     const bigc_config& c = m->cfg;
     BIGC_CHECK_ARG(ldg == round4(c.num_pred_cats), "train_backward: dlogits must have leading dimension %d (zero padded)", round4(c.num_pred_cats));

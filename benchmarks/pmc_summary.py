@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 outputs of benchmarks/profile_bench.sh into the files kept under profiles/.
+
+    python benchmarks/pmc_summary.py gpurun_out/prof_r01d profiles r01
+
+* <tag>_bench_kernel_stats.csv   copy of the --kernel-trace --stats per-kernel summary
+* <tag>_pmc_linear_hbm.csv       per launch of the dominant GEMM kernel in the LAST forward pass: FETCH_SIZE / WRITE_SIZE
+                                 (separate --pmc passes; counter unit KiB; FETCH_SIZE doubled on gfx950 as
+                                 /opt/skills/guides/MI355X_MICROARCH.md prescribes)
+* <tag>_pmc_linear_sq.csv        SQ counters summed over the same launches
+* pmc_traffic.json               HBM bytes per launch (read by bench.py for roofline.traffic)
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+from collections import OrderedDict, defaultdict
+
+KERNEL = "linear_split_kernel"
+
+
+def per_dispatch(path, kernel):
+    """-> OrderedDict dispatch_id -> {counter: value}, and grid sizes, for kernels whose name contains `kernel`"""
+    out, grid = OrderedDict(), {}
+    for r in csv.DictReader(open(path)):
+        if kernel not in r["Kernel_Name"]:
+            continue
+        d = int(r["Dispatch_Id"])
+        out.setdefault(d, defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
+        grid[d] = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
+    return out, grid
+
+
+def last_pass(d, n_passes):
+    ids = sorted(d)
+    per = len(ids) // n_passes
+    return ids[-per:]
+
+
+def main():
+    src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    n_passes = 3                       # bench.py --steps 2 --warmup 1
+    shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_bench_kernel_stats.csv"))
+    fetch, grid = per_dispatch(os.path.join(src, "pmc_FETCH_SIZE", "pmc_counter_collection.csv"), KERNEL)
+    write, _ = per_dispatch(os.path.join(src, "pmc_WRITE_SIZE", "pmc_counter_collection.csv"), KERNEL)
+    fid, wid = last_pass(fetch, n_passes), last_pass(write, n_passes)
+    assert len(fid) == len(wid)
+    tot_f = tot_w = 0.0
+    with open(os.path.join(dst, tag + "_pmc_linear_hbm.csv"), "w") as f:
+        f.write("launch_in_step,grid_workgroups,FETCH_SIZE_KB_raw,fetch_bytes_corrected_x2,WRITE_SIZE_KB,write_bytes\n")
+        for i, (a, b) in enumerate(zip(fid, wid)):
+            fk, wk = fetch[a]["FETCH_SIZE"], write[b]["WRITE_SIZE"]
+            fb, wb = fk * 1024 * 2, wk * 1024
+            tot_f += fb
+            tot_w += wb
+            f.write("%d,%d,%.1f,%d,%.1f,%d\n" % (i, grid[a], fk, fb, wk, wb))
+    json.dump({"kernel": KERNEL, "launches_per_step": len(fid), "fetch_bytes_per_step": tot_f, "write_bytes_per_step": tot_w,
+               "hbm_bytes_per_launch": (tot_f + tot_w) / len(fid),
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 2 --warmup 1 "
+                         "--cpu-videos 0 --no-prof` (benchmarks/profile_bench.sh); the last step's GEMM launches; FETCH_SIZE doubled per "
+                         "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); counter unit KiB"},
+              open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    sums = OrderedDict()
+    for sub in ("pmc_sq1", "pmc_sq2"):
+        p = os.path.join(src, sub, "pmc_counter_collection.csv")
+        if not os.path.exists(p):
+            continue
+        d, _ = per_dispatch(p, KERNEL)
+        for i in last_pass(d, n_passes):
+            for k, v in d[i].items():
+                sums[k] = sums.get(k, 0.0) + v
+    with open(os.path.join(dst, tag + "_pmc_linear_sq.csv"), "w") as f:
+        f.write("counter,sum_over_%d_gemm_launches_of_one_step\n" % len(fid))
+        for k, v in sums.items():
+            f.write("%s,%d\n" % (k, v))
+    print(json.dumps({"fetch_GB": tot_f / 1e9, "write_GB": tot_w / 1e9, "per_launch_MB": (tot_f + tot_w) / len(fid) / 1e6, "sq": sums}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

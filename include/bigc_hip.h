@@ -108,6 +108,12 @@ int bigc_role_attention_f32(void* stream, const float* p2a, int ldp, const float
 int bigc_role_values_f32(void* stream, const float* att, const float* enco, int lde, float* values,
                          const int32_t* e_off, int n_vid, int nq, int d);
 
+/* role attention and its values in one launch for videos of at most 64 entities (max_ent = the largest entity count of
+ * the batch): same results as bigc_role_attention_f32 followed by bigc_role_values_f32; att may be NULL when only the
+ * values are needed (every decoder layer but the last, models/model_0v10.py:467). */
+int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc,
+                        float* att, float* values, const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d, float scale);
+
 /* Tracklet front-end helpers ------------------------------------------------------- */
 
 /* (R,4) xyxy pixel boxes -> (R,8) [cx,dcx,cy,dcy,w,dw,h,dh], boxes divided by the video's (w,h),

@@ -195,7 +195,7 @@ def test_mha_core_cross_lengths(lib):
     assert rel_err(o, want) < 5e-6
 
 
-@pytest.mark.parametrize("nq,half,d,ns", [(192, 256, 512, [64, 1, 180]), (12, 8, 16, [6, 9]), (40, 16, 160, [33])])
+@pytest.mark.parametrize("nq,half,d,ns", [(192, 256, 512, [64, 1, 180]), (12, 8, 16, [6, 9]), (40, 16, 160, [33]), (192, 256, 512, [64, 1, 37]), (70, 64, 96, [5, 32])])
 def test_role_attention_and_values(lib, nq, half, d, ns):
     g = torch.Generator().manual_seed(nq + half)
     B, NT = len(ns), sum(ns)
@@ -224,6 +224,17 @@ def test_role_attention_and_values(lib, nq, half, d, ns):
     assert not torch.isnan(att).any() and not torch.isnan(vals).any()
     assert rel_err(att, att_want) < 1e-5
     assert rel_err(vals, val_want) < 1e-5
+    if max(ns) <= 64 and half % 64 == 0:        # the one-launch variant of the eval path: same results
+        att2 = torch.full((2 * nq * NT,), float("nan"), device=DEV)
+        vals2 = torch.full((2, B * nq, d), float("nan"), device=DEV)
+        _lib.check(lib.bigc_role_fused_f32(S(), pd.data_ptr(), 2 * half, ed.data_ptr(), 2 * half, xd.data_ptr(), d, att2.data_ptr(),
+                                           vals2.data_ptr(), offd.data_ptr(), B, nq, max(ns), half, d, scale))
+        vals3 = torch.full((2, B * nq, d), float("nan"), device=DEV)
+        _lib.check(lib.bigc_role_fused_f32(S(), pd.data_ptr(), 2 * half, ed.data_ptr(), 2 * half, xd.data_ptr(), d, None,
+                                           vals3.data_ptr(), offd.data_ptr(), B, nq, max(ns), half, d, scale))
+        torch.cuda.synchronize()
+        assert rel_err(att2, att_want) < 1e-5 and rel_err(vals2, val_want) < 1e-5
+        assert torch.equal(vals2, vals3)
 
 
 def _ragged(lens_per_vid, tmax_extra=0, seed=0, width=24):

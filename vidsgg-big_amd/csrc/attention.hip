@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
                 const int d = t * 32 + l31;
-                const float vv = (d < HD) ? vp[d] : 0.f;
+                const float vv = vp[d < HD ? d : HD - 1];       // clamped, never predicated (columns >= HD are not stored)
                 out[t] = mfma32(p, vv, out[t]);
             }
         }
@@ -247,14 +247,11 @@ __global__ __launch_bounds__(256) void role_values_kernel(const float* __restric
     for (int n2 = 0; n2 < ne; n2 += 2) {
         const int n = n2 + hi;
         const bool ok = n < ne;
-        const float a = ok ? ap[n] : 0.f;
-        const float* ep = enco + (size_t)(e0 + min(n, ne - 1)) * lde + d0;
+        const float a_raw = ap[min(n, ne - 1)];
+        const float a = ok ? a_raw : 0.f;
+        const float* ep = enco + (size_t)(e0 + min(n, ne - 1)) * lde;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int col = t * 32 + l31;
-            const float bv = (d0 + col < d) ? ep[col] : 0.f;
-            acc[t] = mfma32(a, bv, acc[t]);
-        }
+        for (int t = 0; t < 4; ++t) acc[t] = mfma32(a, ep[min(d0 + t * 32 + l31, d - 1)], acc[t]);   // clamped, never predicated
     }
     float* op = values + ((size_t)role * n_vid * nq + (size_t)vid * nq) * d;
 #pragma unroll
@@ -265,6 +262,143 @@ __global__ __launch_bounds__(256) void role_values_kernel(const float* __restric
         for (int r = 0; r < 16; ++r) {
             const int row = qt * 32 + mfma_row(r, hi);
             if (row < nq) op[(size_t)row * d + col] = acc[t][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// role attention AND its values in one pass (eval path): the scores of a 32-query tile against all entities of the
+// video stay in registers (NET tiles of 32 entities per role), so there is no second scoring pass, and the
+// probabilities feed the att_r @ enco_output MFMAs directly as in mha_core (models/model_0v10.py:193-211).
+template <int NET>
+__global__ __launch_bounds__(256) void role_fused_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
+                                                         const float* __restrict__ enco, int ldenc, float* __restrict__ att,
+                                                         float* __restrict__ values, const int32_t* __restrict__ e_off,
+                                                         int n_vid, int nq, int n_qt, int half, int d, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n_vid * n_qt) return;
+    const int qt = item % n_qt, vid = item / n_qt;
+    const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
+    if (qt * 32 >= nq || ne <= 0) return;
+    const int qrow = min(qt * 32 + l31, nq - 1);
+    const int hh = half / 2;
+    const float* qp = p2a + (size_t)(vid * nq + qrow) * ldp + hi * hh;
+    const float* ep[NET];
+#pragma unroll
+    for (int et = 0; et < NET; ++et) ep[et] = e2a + (size_t)(e0 + min(et * 32 + l31, ne - 1)) * lde + hi * hh;
+
+    f32x16 sc[2][NET];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int et = 0; et < NET; ++et) sc[r][et] = zero16();
+    // A lane streams its own row of each operand along K.  It takes a whole 128-byte line (32 k) per burst of eight
+    // dwordx4 loads, so that a line is consumed while it is still in the L1 (16 bytes per visit re-fetched every line from
+    // L2: the working set of the four waves of a CU is several times the L1); the next burst is requested before the 32
+    // MFMAs of the current one.
+    constexpr int BURST = 32;
+    f32x4 qa[8], ea[8], qb[8], eb[8];
+    const int n_burst = hh / BURST;                 // half % 64 == 0 is checked by the launcher
+    auto fetch = [&](int job, f32x4 (&qv)[8], f32x4 (&ev)[8]) {
+        job = min(job, 2 * NET * n_burst - 1);
+        const int kc = job % n_burst, et = (job / n_burst) % NET, r = job / (n_burst * NET);
+        const float* q_ = qp + r * half + kc * BURST;
+        const float* e_ = ep[0] + r * half + kc * BURST;
+#pragma unroll
+        for (int t = 1; t < NET; ++t) if (et == t) e_ = ep[t] + r * half + kc * BURST;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { qv[j] = *(const f32x4*)(q_ + 4 * j); ev[j] = *(const f32x4*)(e_ + 4 * j); }
+    };
+    auto fma_burst = [&](f32x16& acc, const f32x4 (&qv)[8], const f32x4 (&ev)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = mfma32(ev[j][c], qv[j][c], acc);
+    };
+    fetch(0, qa, ea);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int et = 0; et < NET; ++et) {
+            const int job0 = (r * NET + et) * n_burst;
+            for (int kc = 0; kc < n_burst; kc += 2) {
+                fetch(job0 + kc + 1, qb, eb);
+                fma_burst(sc[r][et], qa, ea);
+                fetch(job0 + kc + 2, qa, ea);
+                if (kc + 1 < n_burst) fma_burst(sc[r][et], qb, eb);
+            }
+        }
+    // softmax over the entities of each role (torch.softmax: exp(s - max) / sum), then over the two roles
+    float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int et = 0; et < NET; ++et)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                sc[r][et][g] *= scale;
+                if (et * 32 + mfma_row(g, hi) < ne) m[r] = fmaxf(m[r], sc[r][et][g]);
+            }
+        m[r] = fmaxf(m[r], __shfl_xor(m[r], 32));
+#pragma unroll
+        for (int et = 0; et < NET; ++et)
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                if (et * 32 + mfma_row(g, hi) < ne) l[r] += expf(sc[r][et][g] - m[r]);
+        l[r] += __shfl_xor(l[r], 32);
+    }
+    const int qq = qt * 32 + l31;
+    float* abase = att ? att + (size_t)2 * nq * e0 : nullptr;
+#pragma unroll
+    for (int et = 0; et < NET; ++et)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int n = et * 32 + mfma_row(g, hi);
+            const float s0 = sc[0][et][g], s1 = sc[1][et][g];
+            const float pe0 = expf(s0 - m[0]) / l[0], pe1 = expf(s1 - m[1]) / l[1];
+            const float mx = fmaxf(s0, s1);
+            const float w0 = expf(s0 - mx), w1 = expf(s1 - mx), ws = w0 + w1;
+            const bool ok = n < ne;
+            const float a0 = ok ? pe0 * (w0 / ws) : 0.f, a1 = ok ? pe1 * (w1 / ws) : 0.f;
+            sc[0][et][g] = a0;
+            sc[1][et][g] = a1;
+            if (abase && ok && qq < nq) {
+                abase[((size_t)0 * nq + qq) * ne + n] = a0;
+                abase[((size_t)1 * nq + qq) * ne + n] = a1;
+            }
+        }
+    // values_r = att_r @ enco_output, 128 output columns at a time
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        float* op = values + ((size_t)r * n_vid * nq + (size_t)vid * nq) * d;
+#pragma unroll 1
+        for (int d0 = 0; d0 < d; d0 += 128) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = zero16();
+#pragma unroll
+            for (int et = 0; et < NET; ++et)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    // unconditional loads from clamped addresses (a predicated load serialises load -> wait -> MFMA);
+                    // columns past d only feed accumulator columns that are never stored
+                    const int n = min(et * 32 + mfma_row(g, hi), ne - 1);
+                    const float* vp = enco + (size_t)(e0 + n) * ldenc;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = mfma32(sc[r][et][g], vp[min(d0 + t * 32 + l31, d - 1)], acc[t]);
+                }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int col = d0 + t * 32 + l31;
+                if (col >= d) continue;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int row = qt * 32 + mfma_row(g, hi);
+                    if (row < nq) op[(size_t)row * d + col] = acc[t][g];
+                }
+            }
         }
     }
 }
@@ -320,5 +454,25 @@ extern "C" int bigc_role_values_f32(void* stream, const float* att, const float*
     hipLaunchKernelGGL(role_values_kernel, dim3((int)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, att, enco, lde, values,
                        e_off, n_vid, nq, n_qt, d, n_dc);
     BIGC_LAUNCH_CHECK("role_values");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc,
+                                   float* att, float* values, const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d,
+                                   float scale) {
+    BIGC_CHECK_ARG(p2a && e2a && enco && values && e_off, "role_fused: null pointer");
+    BIGC_CHECK_ARG(half % 64 == 0 && ldp % 4 == 0 && lde % 4 == 0, "role_fused: half=%d must be a multiple of 64", half);
+    BIGC_CHECK_ARG(max_ent >= 1 && max_ent <= 64, "role_fused: at most 64 entities per video (got %d): use role_attention + role_values", max_ent);
+    if (n_vid <= 0) return BIGC_OK;
+    const int n_qt = cdiv(nq, 32);
+    const int grid = cdiv(n_vid * n_qt, 4);
+    ProfScope ps(stream, FAM_ROLE_ATT, 0.0, 0.0);
+    if (max_ent <= 32)
+        hipLaunchKernelGGL(role_fused_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, enco, ldenc, att, values,
+                           e_off, n_vid, nq, n_qt, half, d, scale);
+    else
+        hipLaunchKernelGGL(role_fused_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, enco, ldenc, att, values,
+                           e_off, n_vid, nq, n_qt, half, d, scale);
+    BIGC_LAUNCH_CHECK("role_fused");
     return BIGC_OK;
 }

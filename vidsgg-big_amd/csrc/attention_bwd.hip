@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
                 const int d = t * 32 + l31;
-                acc[t] = mfma32(ds, d < HD ? kr[d] : 0.f, acc[t]);
+                acc[t] = mfma32(ds, kr[d < HD ? d : HD - 1], acc[t]);
             }
         }
     }
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restric
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
                 const int d = t * 32 + l31;
-                av[t] = mfma32(p, d < HD ? gor[d] : 0.f, av[t]);
-                ak[t] = mfma32(ds, d < HD ? qr[d] : 0.f, ak[t]);
+                av[t] = mfma32(p, gor[d < HD ? d : HD - 1], av[t]);
+                ak[t] = mfma32(ds, qr[d < HD ? d : HD - 1], ak[t]);
             }
         }
     }
@@ -354,13 +354,15 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallGemmArgs p) 
         for (int k2 = 0; k2 < kdim; k2 += 2) {
             const int kk = k2 + hi;
             const bool kok = kk < kdim;
-            const float a = (iok && kok) ? Ap[(size_t)irow * sa_i + (size_t)kk * sa_k] : 0.f;
+            // loads are unconditional from clamped addresses (a predicated load serialises load -> wait -> MFMA): a = 0
+            // cancels the k tail, columns j >= n are never stored
+            const float a_raw = Ap[(size_t)irow * sa_i + (size_t)min(kk, kdim - 1) * sa_k];
+            const float a = (iok && kok) ? a_raw : 0.f;
             const float* bp = Bp + (size_t)min(kk, kdim - 1) * sb_k;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int j = j0 + t * 32 + l31;
-                const float bv = (kok && j < n) ? bp[(size_t)j * sb_j] : 0.f;
-                acc[t] = mfma32(a, bv, acc[t]);
+                const int j = min(j0 + t * 32 + l31, n - 1);
+                acc[t] = mfma32(a, bp[(size_t)j * sb_j], acc[t]);
             }
         }
     }

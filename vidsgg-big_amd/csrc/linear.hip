@@ -42,7 +42,6 @@ __global__ __launch_bounds__(256, OCC) void linear_f32_kernel(const LinearArgs p
     __shared__ __attribute__((aligned(16))) float smem[2][(BM + BNT) * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
-    if (p.run_if && *p.run_if != p.run_id) return;   // range fallback of the split kernel: not needed
 
     // XCD-aware tile order: workgroup b lands on XCD b%8 (observed dispatch), so give each XCD
     // whole M-tiles and walk their N-tiles back to back: the A slab is then re-read from that
@@ -204,23 +203,9 @@ extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int3
     static const int force_nt = getenv("BIGC_LINEAR_NT") ? atoi(getenv("BIGC_LINEAR_NT")) : 0;
     static const int force_bk = getenv("BIGC_LINEAR_BK") ? atoi(getenv("BIGC_LINEAR_BK")) : 0;
     static const bool exact_only = getenv("BIGC_LINEAR_EXACT") && atoi(getenv("BIGC_LINEAR_EXACT")) != 0;
-    p.run_if = nullptr; p.run_id = 0; p.Ws = nullptr; p.ldws = 0; p.flag = nullptr;
-    if (!exact_only) {
-        // split-operand f16 MFMA kernel first; the exact f32 kernel below then runs only if an operand left the f16 range
-        static int* range_flag = nullptr;
-        static std::atomic<int> launch_seq{0};
-        if (!range_flag) {
-            if (hipMalloc((void**)&range_flag, sizeof(int)) != hipSuccess || hipMemset(range_flag, 0, sizeof(int)) != hipSuccess)
-                return bigc_fail(BIGC_ERR_HIP, "linear: cannot allocate the range flag");
-        }
-        p.flag = range_flag;
-        p.run_id = ++launch_seq;
-        int rc = bigc_linear_split_launch(s, p, flops, bytes);
-        if (rc != BIGC_OK) return rc;
-        p.run_if = range_flag;
-    }
-    // the f32 kernel is the measured one only when it does the work; as the (normally idle) range fallback it is "aux"
-    ProfScope ps(stream, exact_only ? FAM_LINEAR : FAM_LINEAR_AUX, exact_only ? flops : 0.0, exact_only ? bytes : 0.0);
+    p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr;
+    if (!exact_only) return bigc_linear_split_launch(s, p, flops, bytes);   // f16 MFMAs on split operands, in-kernel range fallback
+    ProfScope ps(stream, FAM_LINEAR, flops, bytes);
     // measured on MI355X (benchmarks/linear_shapes.py): NT=2 119 TFLOP/s aggregate, NT=4 112 -> NT=2 by default
     const int nt = (force_nt == 4) ? 4 : 2;
     p.tiles_n = cdiv(N, 64 * nt);

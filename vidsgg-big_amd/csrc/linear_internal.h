@@ -8,10 +8,8 @@ struct LinearArgs {
     const float* A; int lda; const int32_t* a_idx; int nseg; int seg_len;
     const float* W; int ldw; const float* bias; const float* res; int ldr;
     float* C; int ldc; int M, N, K; int act; int tiles_m, tiles_n;
-    const int* run_if; int run_id;        // f32 kernel: when run_if != NULL, run only if *run_if == run_id (range fallback)
     const u32x4* Ws; int ldws;            // split kernel: W as [N][ldws] groups of 4 k: {4 x f16 head, 4 x f16 scaled residual}
-    int* flag;                            // split kernel: set to run_id when an operand leaves the f16 range
-    const int* wbad;                      // split kernel: non-zero when the (cached) split W holds an out-of-range element
+    const int* wbad; int wbad_id;         // split kernel: *wbad == wbad_id when the split W holds an out-of-range element
 };
 
 // Weights that stay constant between launches are split once and cached per (pointer, shape) for an "epoch": the model

@@ -7,9 +7,9 @@
 // and the last term (<= 2^-22 relative, f32 round-off level) is dropped: three f16 MFMAs per product, accumulated in
 // f32 in TWO accumulators (leading term / correction terms, combined as acc0 + 2^-11 acc1 in the epilogue, so the small
 // terms are not absorbed by the large partial sum).  Products of f16 pairs are exact in f32.
-// Range: f16 holds |x| < 65504; an operand beyond that (or a NaN/Inf) makes a residual non-finite, which the staging
-// code notices and reports through `flag`; the caller then re-runs that launch on the exact f32 kernel (linear.hip,
-// `run_if`).  Tiny operands (|x| < 2^-35) contribute 0, an absolute error below 3e-11 per element.
+// Range: the staging code tracks max |x| and a NaN-propagating sum of what it splits; when an operand of a tile is
+// >= 32768 in magnitude, NaN or Inf (or the cached split of W says so), the workgroup recomputes its tile at the end on the
+// exact f32 MFMA straight from memory.  Tiny operands (|x| < 2^-35) contribute 0, an absolute error below 3e-11 per element.
 //
 // Tiling: 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, wave patch 64x64 = 2x2 MFMA blocks x 2
 // accumulators (128 accumulator registers), K slabs of 32, two workgroups per CU.  LDS holds four f16 planes per slab
@@ -56,7 +56,7 @@ __device__ __forceinline__ void split4(const f32x4 x, uint2& head, uint2& resid,
 
 // W (N, K) f32 -> Ws (N, K/4) groups of 16 bytes
 __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int ldw, u32x4* __restrict__ Ws, int N, int K4,
-                                                           int* bad) {
+                                                           int* bad, int bad_id) {
     float chk = 0.f, amax = 0.f;
     const long total = (long)N * K4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -66,10 +66,8 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
         split4(x, h, r, chk, amax);
         Ws[i] = u32x4{h.x, h.y, r.x, r.y};
     }
-    if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) *bad = 1;
+    if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) *bad = bad_id;       // ids are unique per split: no clearing needed
 }
-
-__global__ void clear_flag_kernel(int* bad) { *bad = 0; }
 
 __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((row >> 2) & 3); }
 
@@ -219,7 +217,46 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
         step(kt, ra0, ra1);
         if (kt + 1 < nk) step(kt + 1, ra1, ra0);
     }
-    if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT || *p.wbad != 0) atomicMax(p.flag, p.run_id);
+    // Range fallback: when any operand of this tile left the f16 range (or is NaN/Inf), the whole workgroup redoes its
+    // tile on the exact f32 MFMA with operands read straight from memory (slow, rare: |x| >= 32768).
+    if (__syncthreads_or((!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT || *p.wbad == p.wbad_id) ? 1 : 0)) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[mi][ni][r] = 0.f; acc1[mi][ni][r] = 0.f; }
+        // lane (l31, hi) of block mi / ni owns row m / n and the k quads 8c + 4hi .. + 3
+        for (int k8 = 0; k8 < p.K; k8 += 8) {
+            const int kq = k8 + 4 * hi;
+            const bool kok = kq < p.K;
+            const int kcl = min(kq, p.K - 4);
+            f32x4 av[2], wv[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int mrow = min(m0 + wm * 64 + mi * 32 + l31, p.M - 1);
+                const float* src = p.A + (size_t)mrow * p.lda + kcl;
+                bool zero = !kok;
+                if (GATHER) {
+                    const int seg = kcl / p.seg_len;
+                    const int idx = p.a_idx[(size_t)mrow * p.nseg + seg];
+                    zero = zero || idx < 0;
+                    src = p.A + (size_t)max(idx, 0) * p.lda + (kcl - seg * p.seg_len);
+                }
+                av[mi] = *(const f32x4*)src;
+                if (zero) av[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int nrow = min(n0 + wn * 64 + mi * 32 + l31, p.N - 1);
+                wv[mi] = *(const f32x4*)(p.W + (size_t)nrow * p.ldw + kcl);
+                if (!kok) wv[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc0[mi][ni] = mfma32(av[mi][c], wv[ni][c], acc0[mi][ni]);
+        }
+    }
 
     int colv[2];
     float bv[2];
@@ -270,7 +307,7 @@ struct WKey {
     bool operator==(const WKey& o) const { return w == o.w && n == o.n && k == o.k && ldw == o.ldw; }
 };
 struct WKeyHash { size_t operator()(const WKey& k) const { return std::hash<const void*>()(k.w) ^ ((size_t)k.n * 1315423911u) ^ ((size_t)k.k << 20) ^ (size_t)k.ldw; } };
-struct WEntry { char* mem = nullptr; size_t cap = 0; unsigned long long epoch = 0; };
+struct WEntry { char* mem = nullptr; size_t cap = 0; unsigned long long epoch = 0; int bad_id = 0; };
 std::unordered_map<WKey, WEntry, WKeyHash> g_cache;
 WEntry g_scratch;
 std::mutex g_cache_mu;
@@ -284,17 +321,18 @@ int ensure_split(hipStream_t s, const LinearArgs& p, int K4, WEntry& e, bool fre
             (void)hipFree(e.mem);
         }
         e.cap = fresh ? need + need / 2 : need;
-        if (hipMalloc((void**)&e.mem, e.cap) != hipSuccess) {
+        if (hipMalloc((void**)&e.mem, e.cap) != hipSuccess || hipMemsetAsync(e.mem, 0, 256, s) != hipSuccess) {
             e.mem = nullptr; e.cap = 0;
             return bigc_fail(BIGC_ERR_HIP, "linear_split: hipMalloc of the split weights failed");
         }
     }
     ProfScope ps((void*)s, FAM_LINEAR_AUX, 0.0, 8.0 * p.N * (double)p.K);
-    hipLaunchKernelGGL(clear_flag_kernel, dim3(1), dim3(1), 0, s, (int*)e.mem);
+    static std::atomic<int> bad_seq{0};
+    e.bad_id = ++bad_seq;
     long total = (long)p.N * K4;
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(split_weight_kernel, dim3(grid), dim3(256), 0, s, p.W, p.ldw, (u32x4*)(e.mem + 256), p.N, K4, (int*)e.mem);
+    hipLaunchKernelGGL(split_weight_kernel, dim3(grid), dim3(256), 0, s, p.W, p.ldw, (u32x4*)(e.mem + 256), p.N, K4, (int*)e.mem, e.bad_id);
     BIGC_LAUNCH_CHECK("split_weight");
     return BIGC_OK;
 }
@@ -320,7 +358,7 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
             if (rc != BIGC_OK) return rc;
             e->epoch = epoch;
         }
-        p.Ws = (const u32x4*)(e->mem + 256); p.ldws = K4; p.wbad = (const int*)e->mem;
+        p.Ws = (const u32x4*)(e->mem + 256); p.ldws = K4; p.wbad = (const int*)e->mem; p.wbad_id = e->bad_id;
     }
     p.tiles_n = cdiv(p.N, BN);
     const int grid = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;

@@ -299,8 +299,15 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         }
         TRY(linear(s, enco, de, L.e2a, w.e2a, da, NT, da, de, BIGC_ACT_NONE));
         TRY(linear(s, w.query, dp, L.p2a, w.p2a, da, BQ, da, dp, BIGC_ACT_NONE));
-        TRY(bigc_role_attention_f32(s, w.p2a, da, w.e2a, da, out->att, b->vid_trk_off, B, Q, da / 2, att_scale));
-        TRY(bigc_role_values_f32(s, out->att, enco, de, w.vals, b->vid_trk_off, B, Q, de));
+        if (b->max_trk <= 64 && (da / 2) % 64 == 0) {
+            // only the last layer's att is used downstream (:467)
+            const bool last = i + 1 == c.n_deco_layers;
+            TRY(bigc_role_fused_f32(s, w.p2a, da, w.e2a, da, enco, de, last ? out->att : nullptr, w.vals, b->vid_trk_off, B, Q,
+                                    b->max_trk, da / 2, de, att_scale));
+        } else {
+            TRY(bigc_role_attention_f32(s, w.p2a, da, w.e2a, da, out->att, b->vid_trk_off, B, Q, da / 2, att_scale));
+            TRY(bigc_role_values_f32(s, out->att, enco, de, w.vals, b->vid_trk_off, B, Q, de));
+        }
         TRY(linear(s, w.vals, de, L.role0[0], w.rh, dp, BQ, dp, de, BIGC_ACT_RELU));
         TRY(linear(s, w.rh, dp, L.role0[1], w.t2, dp, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
         TRY(linear(s, w.vals + (size_t)BQ * de, de, L.role1[0], w.rh, dp, BQ, dp, de, BIGC_ACT_RELU));

@@ -139,6 +139,140 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Single-pass variant for sequences of at most 32*NKT keys: the transposed score tiles stay in registers, so the scores
+// are computed once (the two-pass kernel above recomputes them for the P V product).
+template <int HD, int NKT>
+__global__ __launch_bounds__(256) void mha_core_sp_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                          const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
+                                                          const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
+                                                          int n_seq, int n_qt, int n_head, float scale, float* __restrict__ lse) {
+    constexpr int HALF = HD / 2;
+    constexpr int NTD = (HD + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n_seq * n_qt * n_head) return;
+    const int h = item % n_head;
+    const int qt = (item / n_head) % n_qt;
+    const int s = item / ((long)n_head * n_qt);
+    const int q0 = q_off[s], nq = q_off[s + 1] - q0;
+    const int k0 = k_off[s], nk = k_off[s + 1] - k0;
+    if (qt * 32 >= nq || nk <= 0) return;
+    const int n_kt = (nk + 31) / 32;            // <= NKT, guaranteed by the launcher
+
+    const int qrow = min(qt * 32 + l31, nq - 1);
+    float qf[HALF];
+    {
+        const float* qp = q + (size_t)(q0 + qrow) * ldq + h * HD + hi * HALF;
+#pragma unroll
+        for (int i = 0; i < HALF; i += 4) {
+            f32x4 t = *(const f32x4*)(qp + i);
+            qf[i] = t[0] * scale; qf[i + 1] = t[1] * scale; qf[i + 2] = t[2] * scale; qf[i + 3] = t[3] * scale;
+        }
+    }
+    f32x16 sc[NKT];
+    float m = NEG_BIG;
+    // the key rows of tile kt+1 are requested before the MFMAs of tile kt
+    f32x4 ka[HALF / 4], kb[HALF / 4];
+    const float* kbase = k + (size_t)k0 * ldk + h * HD + hi * HALF;
+    auto fetch_k = [&](int kt, f32x4 (&kv)[HALF / 4]) {
+        const float* kp = kbase + (size_t)min(min(kt, n_kt - 1) * 32 + l31, nk - 1) * ldk;
+#pragma unroll
+        for (int i = 0; i < HALF / 4; ++i) kv[i] = *(const f32x4*)(kp + 4 * i);
+    };
+    auto score = [&](int kt, const f32x4 (&kv)[HALF / 4]) {
+        sc[kt] = zero16();
+#pragma unroll
+        for (int i = 0; i < HALF / 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sc[kt] = mfma32(kv[i][c], qf[4 * i + c], sc[kt]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (kt * 32 + mfma_row(r, hi) < nk) m = fmaxf(m, sc[kt][r]);
+    };
+    fetch_k(0, ka);
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt += 2) {
+        if (kt < n_kt) {
+            fetch_k(kt + 1, kb);
+            score(kt, ka);
+        } else {
+            sc[kt] = zero16();
+        }
+        if (kt + 1 < NKT) {
+            if (kt + 1 < n_kt) {
+                fetch_k(kt + 2, ka);
+                score(kt + 1, kb);
+            } else {
+                sc[kt + 1] = zero16();
+            }
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = kt < n_kt && kt * 32 + mfma_row(r, hi) < nk;
+            const float e = ok ? expf(sc[kt][r] - m) : 0.f;
+            sc[kt][r] = e;
+            l += e;
+        }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    if (lse && hi == 0 && qt * 32 + l31 < nq) lse[(size_t)(q0 + qt * 32 + l31) * n_head + h] = m + logf(l);
+
+    // P V.  Output column c of d-tile t is head column NTD*c + t, so that a lane fetches its NTD values of a key row with
+    // ONE load (8 bytes for head_dim 64) and stores its outputs the same way; the V values of key tile kt+1 are requested
+    // before the MFMAs of tile kt.
+    typedef float vrow_t __attribute__((ext_vector_type(NTD)));
+    f32x16 out[NTD];
+#pragma unroll
+    for (int t = 0; t < NTD; ++t) out[t] = zero16();
+    const int dcol = (NTD * l31 < HD) ? NTD * l31 : 0;        // lanes past the head width (head_dim < 32) reuse column 0
+    const float* vbase = v + (size_t)k0 * ldv + h * HD + dcol;
+    vrow_t va[16], vb[16];
+    auto fetch_v = [&](int kt, vrow_t (&vv)[16]) {
+        kt = min(kt, n_kt - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = *(const vrow_t*)(vbase + (size_t)min(kt * 32 + mfma_row(r, hi), nk - 1) * ldv);
+    };
+    auto pv_tile = [&](int kt, const vrow_t (&vv)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = sc[kt][r] * inv;
+#pragma unroll
+            for (int t = 0; t < NTD; ++t) out[t] = mfma32(p, vv[r][t], out[t]);
+        }
+    };
+    fetch_v(0, va);
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt += 2) {
+        if (kt < n_kt) {
+            fetch_v(kt + 1, vb);
+            pv_tile(kt, va);
+        }
+        if (kt + 1 < NKT && kt + 1 < n_kt) {
+            fetch_v(kt + 2, va);
+            pv_tile(kt + 1, vb);
+        }
+    }
+    if (NTD * l31 < HD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = qt * 32 + mfma_row(r, hi);
+            if (row < nq) {
+                vrow_t ov;
+#pragma unroll
+                for (int t = 0; t < NTD; ++t) ov[t] = out[t][r];
+                *(vrow_t*)(o + (size_t)(q0 + row) * ldo + h * HD + dcol) = ov;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void role_attention_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
                                                              float* __restrict__ att, const int32_t* __restrict__ e_off,
                                                              int n_vid, int nq, int n_qt, int half, float scale) {
@@ -369,34 +503,34 @@ __global__ __launch_bounds__(256) void role_fused_kernel(const float* __restrict
                 abase[((size_t)1 * nq + qq) * ne + n] = a1;
             }
         }
-    // values_r = att_r @ enco_output, 128 output columns at a time
+    // values_r = att_r @ enco_output, 128 output columns at a time.  Output column c of tile t is column d0 + 4c + t, so a
+    // lane fetches its four values of an entity row with one dwordx4 load and stores its outputs the same way; loads are
+    // unconditional from clamped addresses (a predicated load serialises load -> wait -> MFMA).
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         float* op = values + ((size_t)r * n_vid * nq + (size_t)vid * nq) * d;
 #pragma unroll 1
         for (int d0 = 0; d0 < d; d0 += 128) {
+            const bool cok = d0 + 4 * l31 < d;            // d % 4 == 0 (checked by the launcher)
+            const float* vb = enco + (size_t)e0 * ldenc + (cok ? d0 + 4 * l31 : 0);
             f32x16 acc[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = zero16();
 #pragma unroll
-            for (int et = 0; et < NET; ++et)
+            for (int et = 0; et < NET; ++et) {
+                f32x4 vv[16];
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    // unconditional loads from clamped addresses (a predicated load serialises load -> wait -> MFMA);
-                    // columns past d only feed accumulator columns that are never stored
-                    const int n = min(et * 32 + mfma_row(g, hi), ne - 1);
-                    const float* vp = enco + (size_t)(e0 + n) * ldenc;
+                for (int g = 0; g < 16; ++g) vv[g] = *(const f32x4*)(vb + (size_t)min(et * 32 + mfma_row(g, hi), ne - 1) * ldenc);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = mfma32(sc[r][et][g], vp[min(d0 + t * 32 + l31, d - 1)], acc[t]);
-                }
+                for (int g = 0; g < 16; ++g)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int col = d0 + t * 32 + l31;
-                if (col >= d) continue;
+                    for (int t = 0; t < 4; ++t) acc[t] = mfma32(sc[r][et][g], vv[g][t], acc[t]);
+            }
+            if (cok) {
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int row = qt * 32 + mfma_row(g, hi);
-                    if (row < nq) op[(size_t)row * d + col] = acc[t][g];
+                    if (row < nq) *(f32x4*)(op + (size_t)row * d + d0 + 4 * l31) = f32x4{acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
                 }
             }
         }
@@ -419,12 +553,24 @@ extern "C" int bigc_mha_core_f32(void* stream, const float* q, int ldq, const fl
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(stream, FAM_MHA, 0.0, 0.0);
 #define LAUNCH_MHA(HD) hipLaunchKernelGGL(mha_core_kernel<HD>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse)
+#define LAUNCH_SP(HD, NKT) hipLaunchKernelGGL((mha_core_sp_kernel<HD, NKT>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse)
+    // self-attention (same offsets for queries and keys): the longest key sequence is max_q, known on the host ->
+    // single-pass kernel with the scores in registers when it fits
+    const int nkt = (q_off == k_off) ? n_qt : 1 << 30;
+    if (hd == 64 && nkt <= 2) LAUNCH_SP(64, 2);
+    else if (hd == 64 && nkt <= 6) LAUNCH_SP(64, 6);
+    else if (hd == 16 && nkt <= 2) LAUNCH_SP(16, 2);
+    else if (hd == 16 && nkt <= 8) LAUNCH_SP(16, 8);
+    else if (hd == 8 && nkt <= 2) LAUNCH_SP(8, 2);
+    else if (hd == 32 && nkt <= 6) LAUNCH_SP(32, 6);
+    else
     switch (hd) {
         case 8: LAUNCH_MHA(8); break;
         case 16: LAUNCH_MHA(16); break;
         case 32: LAUNCH_MHA(32); break;
         default: LAUNCH_MHA(64); break;
     }
+#undef LAUNCH_SP
 #undef LAUNCH_MHA
     BIGC_LAUNCH_CHECK("mha_core");
     return BIGC_OK;
@@ -461,7 +607,7 @@ extern "C" int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, cons
                                    float* att, float* values, const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d,
                                    float scale) {
     BIGC_CHECK_ARG(p2a && e2a && enco && values && e_off, "role_fused: null pointer");
-    BIGC_CHECK_ARG(half % 64 == 0 && ldp % 4 == 0 && lde % 4 == 0, "role_fused: half=%d must be a multiple of 64", half);
+    BIGC_CHECK_ARG(half % 64 == 0 && ldp % 4 == 0 && lde % 4 == 0 && d % 4 == 0 && ldenc % 4 == 0, "role_fused: half=%d must be a multiple of 64, d=%d of 4", half, d);
     BIGC_CHECK_ARG(max_ent >= 1 && max_ent <= 64, "role_fused: at most 64 entities per video (got %d): use role_attention + role_values", max_ent);
     if (n_vid <= 0) return BIGC_OK;
     const int n_qt = cdiv(nq, 32);

@@ -380,6 +380,17 @@ int grd_loss_grad(void* stream, const float* regrs, const float* conf, const flo
 int grd_train_backward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, int n,
                        void* workspace, size_t workspace_bytes, const float* dregr, const float* dconf, const float* dcls);
 
+/* ---- tracking-result ingest (dataloaders/dataloader_vidvrd.py:585-700, utils/utils_func.py:273-317) ---------------------
+ * Assembles the feature rows of the kept tracklets from the raw per-box rows of a video's `.npy` (uploaded once):
+ * output row r = columns [col0, col0+width) of raw row src_a[r] followed by columns [col02, col02+width2) of raw2 row
+ * src_a[r] (the I3D file, optional) when src_b[r] == -2 (a negative src_a gives a zero row: box without detection);
+ * otherwise the row numpy.linspace(row src_a[r], row src_b[r], num = step_div[r] + 1, axis=0)[step_i[r]] evaluated in
+ * float64 with numpy's arithmetic (incl. its any-step-zero branch) and rounded to float32, a negative index standing
+ * for the zero vector.  Bit-identical to the reference's host interpolation. */
+int bigc_assemble_rows_f32(void* stream, const float* raw, int ld_raw, int col0, int width, const float* raw2, int ld_raw2,
+                           int col02, int width2, const int32_t* src_a, const int32_t* src_b, const int32_t* step_i,
+                           const int32_t* step_div, float* out, int ld_out, int n_rows);
+
 #ifdef __cplusplus
 }
 #endif

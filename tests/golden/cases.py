@@ -256,3 +256,46 @@ def make_grd_train_case(name):
         gts.append(g)
         feats.append(torch.from_numpy((0.1 * rs.standard_normal((v["T"], cfg["dim_feat"]))).astype(np.float32)))
     return cfg, sd, feats, gts, case["rng_seed"]
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# f2: tracking-result ingest (dataloaders/dataloader_vidvrd.py:479-700).  Synthetic `.npy` contents in the PKU row format
+# [fid, tid, x,y,w,h (tracker), conf, cat, x,y,w,h (detector), feat...] (tracking_results/format_demo.py:9-21).
+# --------------------------------------------------------------------------------------------------------------------
+INGEST_CASES = {
+    "ingest_pku_i3d": dict(seed=901, n_traj=9, dim_box=16, dim_i3d=8, min_frames_th=5, max_proposal=6, with_i3d=True),
+    "ingest_pku": dict(seed=902, n_traj=7, dim_box=12, dim_i3d=0, min_frames_th=4, max_proposal=50, with_i3d=False),
+}
+
+
+def make_ingest_case(name):
+    """-> (track_res (n_box, 12+dim_box) float32, i3d rows (n_box, 12+dim_i3d) float32 or None, case dict).
+    Tracklets with gaps (to be interpolated), undetected boxes (cat <= 0: tracker box only, zero features), mixed
+    categories (majority vote), one short tracklet (filtered) and one all-background tracklet."""
+    import numpy as np
+    case = INGEST_CASES[name]
+    rs = np.random.RandomState(case["seed"])
+    rows = []
+    for t in range(case["n_traj"]):
+        tid = 3 * t + 1                                           # ids need not be consecutive
+        start = rs.randint(0, 20)
+        n = rs.randint(6, 18) if t != 2 else 3                    # tracklet 2 is shorter than min_frames_th
+        fids = start + np.sort(rs.choice(np.arange(n + 6), size=n, replace=False))   # gaps of up to a few frames
+        main_cat = rs.randint(1, 30)
+        for j, fid in enumerate(fids):
+            xy, wh = rs.uniform(0, 500, 2), rs.uniform(20, 120, 2)
+            conf = rs.uniform(0.3, 1.0)
+            cat = main_cat if rs.rand() < 0.8 else rs.randint(1, 30)
+            if t == 4:
+                cat = 0                                            # never detected: background tracklet
+            elif rs.rand() < 0.15:
+                cat = -1                                           # this box has no detection
+            dxy, dwh = xy + rs.uniform(-5, 5, 2), wh + rs.uniform(-5, 5, 2)
+            feat = np.maximum(rs.standard_normal(case["dim_box"]), 0)      # ReLU-like: exact zeros occur
+            rows.append(np.concatenate([[fid, tid], xy, wh, [conf, cat], dxy, dwh, feat]))
+    order = np.argsort([r[0] for r in rows], kind="stable")       # file order: by frame, tracklets interleaved
+    track = np.stack([rows[i] for i in order]).astype(np.float32)
+    i3d = None
+    if case["with_i3d"]:
+        i3d = np.concatenate([track[:, :12], np.maximum(rs.standard_normal((track.shape[0], case["dim_i3d"])), 0)], 1).astype(np.float32)
+    return track, i3d, case

@@ -251,13 +251,49 @@ def run_evaluator_golden():
     print("wrote", path, {k: v.round(4).tolist() for k, v in out.items()})
 
 
+def run_ingest_case(name):
+    """The reference's own ``_get_proposal`` (dataloaders/dataloader_vidvrd.py:485-573 / :585-700) on synthetic tracking
+    results written to a temp dir; the Dataset constructor (annotations, caches) is bypassed with a stand-in ``self``."""
+    import types as _t
+    sys.path.insert(0, REFERENCE)
+    np.float, np.int = float, int                       # the dataloader module predates numpy 1.24 (SURVEY 8c)
+    from dataloaders import dataloader_vidvrd as D
+    import utils.utils_func as U
+    sys.path.remove(REFERENCE)
+    # fill_zeropadding on the 1-D boundary vectors (utils/utils_func.py:283-290) calls np.where on a 0-d array, which numpy 2
+    # rejects; under the numpy the reference targeted it copies element 1 over element 0 of an ALL-ZERO vector, i.e. nothing
+    U.fill_zeropadding = lambda vectors: None
+    track, i3d, case = cases.make_ingest_case(name)
+    d = tempfile.mkdtemp()
+    os.makedirs(d + "/prop"); os.makedirs(d + "/i3d")
+    np.save(d + "/prop/video_x.npy", track)
+    fake = _t.SimpleNamespace(proposal_dir=d + "/prop", i3d_dir=d + "/i3d", dim_boxfeature=case["dim_box"], dim_i3d=case["dim_i3d"],
+                              min_frames_th=case["min_frames_th"], max_proposal=case["max_proposal"])
+    if case["with_i3d"]:
+        np.save(d + "/i3d/video_x.npy", i3d)
+        prop = D.Dataset_pku_i3d._get_proposal(fake, "video_x")
+    else:
+        prop = D.Dataset_pku._get_proposal(fake, "video_x")
+    out = dict(num_proposals=np.array(prop.num_proposals), cat_ids=prop.cat_ids.numpy(), scores=prop.scores.numpy(),
+               traj_durations=prop.traj_durations.numpy(), bboxes=torch.cat(prop.bboxes_list, 0).numpy(),
+               features=torch.cat(prop.features_list, 0).numpy(), lens=np.array([b.shape[0] for b in prop.bboxes_list]),
+               versions=np.array([torch.__version__, np.__version__]))
+    path = os.path.join(cases.GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "proposals", prop.num_proposals, "rows", out["bboxes"].shape[0])
+
+
 def main():
     torch.manual_seed(0)
     m10, m07, grd = import_reference()
-    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + list(cases.GRD_TRAIN_CASES) + ["evaluator"])
+    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + list(cases.GRD_TRAIN_CASES) + ["evaluator"] +
+                             list(cases.INGEST_CASES))
     for n in names:
         if n == "evaluator":
             run_evaluator_golden()
+            continue
+        if n in cases.INGEST_CASES:
+            run_ingest_case(n)
             continue
         if n in cases.BIGC_CASES:
             run_bigc_case(n, m10, m07)

@@ -1,0 +1,64 @@
+"""Tracking-result ingest against the reference's own ``_get_proposal``
+(tests/golden/ingest_*.npz): host bookkeeping on the CPU, feature-row assembly on the GPU, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from bigc_hip import ingest
+
+
+@pytest.mark.parametrize("name", list(cases.INGEST_CASES))
+def test_plan_matches_reference_dataloader(name):
+    g = np.load(cases.GOLDEN_DIR + "/" + name + ".npz")
+    track, i3d, case = cases.make_ingest_case(name)
+    plan = ingest.plan_tracklets(track, case["dim_box"], case["min_frames_th"], case["max_proposal"])
+    assert len(plan["cat_ids"]) == int(g["num_proposals"])
+    assert np.array_equal(np.array(plan["cat_ids"]), g["cat_ids"])
+    assert np.array_equal(plan["scores"].numpy(), g["scores"])                                  # bit-exact
+    assert np.array_equal(np.array(plan["durations"]), g["traj_durations"])
+    assert np.array_equal(np.array([b.shape[0] for b in plan["boxes"]]), g["lens"])
+    assert np.array_equal(torch.cat(plan["boxes"], 0).numpy(), g["bboxes"])                     # bit-exact
+    assert (plan["src_b"] != -2).sum() > 0 and (plan["src_a"] < 0).sum() > 0                    # the case has gaps and undetected boxes
+
+
+def test_empty_and_all_filtered():
+    track, _, case = cases.make_ingest_case("ingest_pku")
+    assert ingest.plan_tracklets(track, case["dim_box"], 1000, 10) is None                      # everything shorter than the threshold
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(cases.INGEST_CASES))
+def test_feature_rows_match_reference_dataloader(name):
+    g = np.load(cases.GOLDEN_DIR + "/" + name + ".npz")
+    track, i3d, case = cases.make_ingest_case(name)
+    p = ingest.load_pku_tracklets("video_x", track, case["dim_box"], case["min_frames_th"], case["max_proposal"], i3d_res=i3d,
+                                  dim_i3d=case["dim_i3d"], device="cuda:0")
+    assert p.num_proposals == int(g["num_proposals"])
+    feats = torch.cat(p.features_list, 0)
+    assert feats.is_cuda and feats.shape == g["features"].shape
+    assert np.array_equal(feats.cpu().numpy(), g["features"])                                    # bit-exact, incl. interpolated rows
+    assert np.array_equal(torch.cat(p.bboxes_list, 0).cpu().numpy(), g["bboxes"])
+    assert np.array_equal(p.traj_durations.cpu().numpy(), g["traj_durations"]) and np.array_equal(p.cat_ids.cpu().numpy(), g["cat_ids"])
+
+
+@pytest.mark.gpu
+def test_ingested_proposal_runs_through_the_model():
+    """the ingest output is directly consumable by the BIG-C forward (features stay device-resident)"""
+    import os
+    import tempfile
+    from bigc_hip.synthetic import bigc_state_shapes, seeded_state_dict
+    from models import BIG_C_vidvrd
+    track, i3d, case = cases.make_ingest_case("ingest_pku_i3d")
+    cfg = cases.get_cfg("CONFIG_TINY")
+    cfg["dim_feat"], cfg["dim_i3d"], cfg["num_enti_cats"] = case["dim_box"], case["dim_i3d"], 36
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 5, att_gain=4.0)
+    d = tempfile.mkdtemp()
+    np.save(d + "/b.npy", sd["bias_matrix"].numpy()); np.save(d + "/e.npy", sd["EntiNameEmb"].numpy())
+    model = BIG_C_vidvrd(dict(cfg, bias_matrix_path=d + "/b.npy", EntiNameEmb_path=d + "/e.npy"), is_train=False)
+    model.load_state_dict(sd)
+    model = model.to("cuda:0")
+    p = ingest.load_pku_tracklets("video_x", track, case["dim_box"], case["min_frames_th"], case["max_proposal"], i3d_res=i3d,
+                                  dim_i3d=case["dim_i3d"], device="cuda:0").to("cuda:0")
+    res = model([p], topk=3)[0]
+    assert res is None or (res[0].shape[1] == 5 and res[0].shape[0] == res[1].shape[0])

@@ -21,7 +21,7 @@ from models import BIG_C_vidvrd
 
 
 def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_tag="", use_pku=False, json_results_path=None,
-                        synthetic=0, n_trajs=64, batch_videos=64):
+                        synthetic=0, n_trajs=64, batch_videos=64, tracking_dir=None, i3d_dir=None):
     cfg = parse_config_py(cfg_path)
     model_config, infer_config = cfg["model_config"], cfg.get("inference_config", {})
     topk = infer_config.get("topk", 10)
@@ -35,6 +35,19 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
     model.eval()
     if synthetic:
         data = synthetic_source(model_config, synthetic, n_trajs, seed=1234)
+    elif tracking_dir:
+        # raw tracking results (one `.npy` of per-box rows per video, PKU format): ingested here, feature rows assembled on the GPU
+        import glob
+        import numpy as np
+        from bigc_hip.ingest import load_pku_tracklets
+        ds_cfg = cfg["test_dataset_config"]
+        data = []
+        for path in sorted(glob.glob(os.path.join(tracking_dir, "*.npy"))):
+            name = os.path.splitext(os.path.basename(path))[0]
+            i3d = np.load(os.path.join(i3d_dir, name + ".npy")) if i3d_dir else None
+            data.append((load_pku_tracklets(name, np.load(path, allow_pickle=True), ds_cfg["dim_boxfeature"], ds_cfg["min_frames_th"],
+                                            ds_cfg["max_proposal"], i3d_res=i3d, dim_i3d=ds_cfg.get("dim_i3d", 0) if i3d_dir else 0,
+                                            device=device), None))
     else:
         from dataloaders.dataloader_vidvrd import Dataset_pku_i3d, Dataset_pku, Dataset   # the reference's own loaders
         ds_cfg = cfg["test_dataset_config"]
@@ -81,5 +94,8 @@ if __name__ == "__main__":
     ap.add_argument("--json_results_path", type=str, default=None)
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N generated videos instead of a dataset")
     ap.add_argument("--n_trajs", type=int, default=64)
+    ap.add_argument("--tracking_dir", type=str, default=None, help="directory of raw per-video tracking-result .npy files (PKU row format)")
+    ap.add_argument("--i3d_dir", type=str, default=None, help="matching directory of per-box I3D feature .npy files")
     a = ap.parse_args()
-    inference_then_eval(a.cfg_path, a.ckpt_path, a.output_dir, a.cuda, a.save_tag, a.use_pku, a.json_results_path, a.synthetic, a.n_trajs)
+    inference_then_eval(a.cfg_path, a.ckpt_path, a.output_dir, a.cuda, a.save_tag, a.use_pku, a.json_results_path, a.synthetic, a.n_trajs,
+                        tracking_dir=a.tracking_dir, i3d_dir=a.i3d_dir)

@@ -132,6 +132,10 @@ def train_main(args):
 
     for _ in range(args.warmup):
         step()
+    lib = _lib.load()
+    if not args.no_prof:
+        lib.bigc_prof_reset()
+        lib.bigc_prof_enable(1)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -140,13 +144,23 @@ def train_main(args):
         last = step()
     torch.cuda.synchronize()
     elapsed = max_over_ranks(time.perf_counter() - t0, dist, device)
+    lib.bigc_prof_enable(0)
+    families = {}
+    if not args.no_prof:
+        _lib.check(lib.bigc_prof_collect())
+        for f in range(lib.bigc_prof_family_count()):
+            ms, n, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
+            lib.bigc_prof_get(f, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+            if n.value:
+                families[lib.bigc_prof_family_name(f).decode()] = round(ms.value / args.steps, 3)
     if rank == 0:
         print(json.dumps({"metric": "train_tracklet_pairs_per_sec", "value": round(pairs * world * args.steps / elapsed, 1), "unit": "pairs/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "BIG-C model_0v10 training step (exp2 dims), %d synthetic videos x N=%d per GPU per step, "
                                                  "forward + Hungarian + backward + flat-gradient all-reduce + clip + Adam" % (nvid, args.n_trajs),
-                                     "parallelism": "dp%d" % world}, "last_loss": round(last, 4)}))
+                                     "parallelism": "dp%d" % world}, "last_loss": round(last, 4),
+                          "kernel_families_ms_per_step": families}))
     if dist is not None:
         dist.destroy_process_group()
 

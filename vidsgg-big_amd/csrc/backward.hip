@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // dW[n,k] += sum_m dY[m,n] * X'[m,k]; X' optionally row-gathered in segments like linear_f32.
 struct DwArgs {
     const float* dY; int ldy; const float* X; int ldx; const int32_t* x_idx; int nseg; int seg_len;
-    float* dW; int ldw; int M, N, K; int tiles_n, tiles_k, m_chunk;
+    float* dW; int ldw; float* db; int M, N, K; int tiles_n, tiles_k, m_chunk;
 };
 
 __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    float bsum = 0.f;                       // column sum of dY (bias gradient), taken by the tk == 0 workgroups
     for (int m0 = m_begin; m0 < m_end; m0 += 32) {
         float ry[16], rx[16];
 #pragma unroll
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
             const int m = m0 + mh * 16 + j;
             const bool mv = m < m_end;
             ry[j] = (mv && nval) ? p.dY[(size_t)m * p.ldy + ncol] : 0.f;
+            bsum += ry[j];
             float xv = 0.f;
             if (mv && kval) {
                 if (p.x_idx) {
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
             }
         }
     }
+    if (p.db && tk == 0 && nval) atomicAdd(&p.db[ncol], bsum);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -111,16 +114,6 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
                 if (row < p.N) atomicAdd(&p.dW[(size_t)row * p.ldw + col], acc[a][b][r]);
             }
         }
-}
-
-// db[n] += sum_m dY[m,n]
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dY, int ldy, float* __restrict__ db, int M, int N, int rows_per_block) {
-    const int m_begin = blockIdx.y * rows_per_block, m_end = min(M, m_begin + rows_per_block);
-    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
-        float s = 0.f;
-        for (int m = m_begin; m < m_end; ++m) s += dY[(size_t)m * ldy + n];
-        atomicAdd(&db[n], s);
-    }
 }
 
 // dY *= (Y > 0)   (Y = post-ReLU activation)
@@ -207,12 +200,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
+    // the four waves of the workgroup are summed through LDS first: one atomic per column and workgroup
+    __shared__ float red[2][4][2048];
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int i = lane + 64 * j;
         if (i < nv)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { atomicAdd(&dg[i * 4 + c], ag[j][c]); atomicAdd(&db[i * 4 + c], ab[j][c]); }
+            for (int c = 0; c < 4; ++c) { red[0][wv][i * 4 + c] = ag[j][c]; red[1][wv][i * 4 + c] = ab[j][c]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        atomicAdd(&dg[c], (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+        atomicAdd(&db[c], (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
     }
 }
 
@@ -380,7 +381,7 @@ extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const 
     if (x_idx) BIGC_CHECK_ARG(nseg >= 1 && nseg * seg_len == K, "linear_dw: K=%d != nseg*seg_len", K);
     DwArgs p;
     p.dY = dY; p.ldy = ldy; p.X = X; p.ldx = ldx; p.x_idx = x_idx; p.nseg = x_idx ? nseg : 1; p.seg_len = x_idx ? seg_len : K;
-    p.dW = dW; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
+    p.dW = dW; p.ldw = ldw; p.db = db; p.M = M; p.N = N; p.K = K;
     p.tiles_n = cdiv(N, 128); p.tiles_k = cdiv(K, 128);
     const int tiles = p.tiles_n * p.tiles_k;
     int splits = cdiv(2048, tiles);
@@ -393,12 +394,6 @@ extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const 
         ProfScope ps(stream, FAM_LINEAR_DW, 2.0 * M * (double)N * K, 4.0 * ((double)M * N + (double)M * K + (double)N * K));
         hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
         BIGC_LAUNCH_CHECK("linear_dw");
-    }
-    if (db) {
-        const int rpb = cdiv(M, 256) > 256 ? cdiv(M, 256) : 256;     // <= 256 row chunks
-        ProfScope ps(stream, FAM_BACKWARD, 0.0, 4.0 * M * (double)N);
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dY, ldy, db, M, N, rpb);
-        BIGC_LAUNCH_CHECK("colsum");
     }
     return BIGC_OK;
 }
@@ -426,7 +421,8 @@ extern "C" int bigc_layernorm_bwd_f32(void* stream, const float* x, const float*
     BIGC_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
     BIGC_CHECK_ARG(d > 0 && d % 4 == 0 && d <= 2048, "layernorm_bwd: d=%d", d);
     if (rows <= 0) return BIGC_OK;
-    const int grid = cdiv(rows, 4) < 512 ? cdiv(rows, 4) : 512;
+    // every wave takes >= 8 rows (its parameter-gradient partials live in registers): few workgroups, few atomics
+    const int grid = cdiv(rows, 32) < 512 ? cdiv(rows, 32) : 512;
     ProfScope ps(stream, FAM_BACKWARD, 0.0, 12.0 * rows * (double)d);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dx, dgamma, dbeta, rows, d, eps);
     BIGC_LAUNCH_CHECK("layernorm_bwd");

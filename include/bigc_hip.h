@@ -380,6 +380,15 @@ int grd_loss_grad(void* stream, const float* regrs, const float* conf, const flo
 int grd_train_backward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, int n,
                        void* workspace, size_t workspace_bytes, const float* dregr, const float* dconf, const float* dcls);
 
+/* ---- Base_C, the explicit pairwise baseline (models/model_pairwise_baseline.py:174-273), eval forward ------------------------
+ * A model created with variant = 2 holds the front-end parameters plus fc_pred2logits.{0,2} and bias_matrix (same keys as
+ * the reference's state_dict).  bigc_pair_forward runs the front-end and scores EVERY ordered tracklet pair (s, o), s != o:
+ * pair p of video v (row-major over the N_v x N_v grid without its diagonal, trajid2pairid :105-112) is row
+ * vid_pair_off[v] + p of pair_logits (n_pairs, num_pred_cats).  enti2enco (n_trk, dim_enti) is optional. */
+size_t bigc_pair_workspace_bytes(const bigc_model* m, const bigc_batch* b, long n_pairs);
+int bigc_pair_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* vid_pair_off, long n_pairs, void* workspace,
+                      size_t workspace_bytes, float* enti2enco, float* pair_logits);
+
 /* ---- tracking-result ingest (dataloaders/dataloader_vidvrd.py:585-700, utils/utils_func.py:273-317) ---------------------
  * Assembles the feature rows of the kept tracklets from the raw per-box rows of a video's `.npy` (uploaded once):
  * output row r = columns [col0, col0+width) of raw row src_a[r] followed by columns [col02, col02+width2) of raw2 row

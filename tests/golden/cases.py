@@ -299,3 +299,39 @@ def make_ingest_case(name):
     if case["with_i3d"]:
         i3d = np.concatenate([track[:, :12], np.maximum(rs.standard_normal((track.shape[0], case["dim_i3d"])), 0)], 1).astype(np.float32)
     return track, i3d, case
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# f3: the explicit pairwise baseline Base_C (models/model_pairwise_baseline.py)
+# --------------------------------------------------------------------------------------------------------------------
+BASEC_CASES = {
+    # tiny dims, classeme columns in the features (EntiNameEmb_path None), all triplets returned
+    "basec_tiny": dict(cfg=dict(num_enti_cats=9, num_pred_cats=7, dim_feat=24, dim_clsme=12, dim_enti=16, dim_ffn=32, enco_pool_len=4,
+                                use_clsme=True, rt_triplets_topk=-1, EntiNameEmb_path=None), wseed=91, topk=3,
+                       videos=[dict(seed=9101, n_trajs=7, len_range=(5, 14), start_range=(0, 8)), dict(seed=9102, n_trajs=1),
+                               dict(seed=9103, n_trajs=0), dict(seed=9104, n_trajs=5, len_range=(4, 9), start_range=(0, 30))]),
+    # category embedding as classeme, top-20 cut
+    "basec_tiny_emb": dict(cfg=dict(num_enti_cats=9, num_pred_cats=7, dim_feat=24, dim_clsme=12, dim_enti=16, dim_ffn=32, enco_pool_len=4,
+                                    use_clsme=True, rt_triplets_topk=20, _with_EntiNameEmb=True), wseed=92, topk=2,
+                           videos=[dict(seed=9201, n_trajs=8, len_range=(5, 14), start_range=(0, 8))]),
+    # exp6 dimensions (VidOR: 81/51 categories, 1024-d RoI + 300-d classeme), N=24
+    "basec_o_n24": dict(cfg=dict(num_enti_cats=81, num_pred_cats=51, dim_feat=1024, dim_clsme=300, dim_enti=512, dim_ffn=512, enco_pool_len=4,
+                                 use_clsme=True, rt_triplets_topk=200, EntiNameEmb_path=None), wseed=93, topk=3,
+                        videos=[dict(seed=9301, n_trajs=24, len_range=(15, 70), start_range=(0, 40))]),
+}
+
+
+def make_basec_case(name):
+    """-> (cfg, state_dict, [proposals], topk)"""
+    from bigc_hip.synthetic import basec_state_shapes
+    case = BASEC_CASES[name]
+    cfg = dict(case["cfg"])
+    sd = seeded_state_dict(basec_state_shapes(cfg), case["wseed"], 1.0)
+    width = cfg["dim_feat"] + (cfg["dim_clsme"] if (cfg["use_clsme"] and not cfg.get("_with_EntiNameEmb")) else 0)
+    props = []
+    for v in case["videos"]:
+        kw = dict(n_trajs=v["n_trajs"], feat_width=width, num_enti_cats=cfg["num_enti_cats"])
+        if "len_range" in v:
+            kw.update(len_range=v["len_range"], start_range=v["start_range"])
+        props.append(synthetic_proposal(v["seed"], **kw))
+    return cfg, sd, props, case["topk"]

@@ -283,17 +283,51 @@ def run_ingest_case(name):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "proposals", prop.num_proposals, "rows", out["bboxes"].shape[0])
 
 
+def run_basec_case(name):
+    """The reference's Base_C (models/model_pairwise_baseline.py) eval forward on the seeded case."""
+    sys.path.insert(0, REFERENCE)
+    from models import model_pairwise_baseline as MB
+    sys.path.remove(REFERENCE)
+    cfg, sd, props, topk = cases.make_basec_case(name)
+    d = tempfile.mkdtemp()
+    rc = dict(cfg)
+    np.save(os.path.join(d, "bias.npy"), sd["bias_matrix"].numpy())
+    rc["bias_matrix_path"] = os.path.join(d, "bias.npy")
+    if "EntiNameEmb" in sd:
+        np.save(os.path.join(d, "emb.npy"), sd["EntiNameEmb"].numpy())
+        rc["EntiNameEmb_path"] = os.path.join(d, "emb.npy")
+    model = MB.Base_C(rc, is_train=False)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    out = {"versions": np.array([torch.__version__, np.__version__])}
+    with torch.no_grad():
+        res = model(props, topk=topk)
+        for i, (p, r) in enumerate(zip(props, res)):
+            out["v%d_none" % i] = np.array(r is None)
+            if p.num_proposals > 1:
+                pair_ids = model.trajid2pairid(p.num_proposals)
+                out["v%d_logits" % i] = model.forward_propagation(p, pair_ids).numpy()
+            if r is not None:
+                out["v%d_quint" % i], out["v%d_scores" % i], out["v%d_dura" % i] = r[0].numpy(), r[1].numpy(), r[2].numpy()
+    path = os.path.join(cases.GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), [None if r is None else tuple(r[0].shape) for r in res])
+
+
 def main():
     torch.manual_seed(0)
     m10, m07, grd = import_reference()
     names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + list(cases.GRD_TRAIN_CASES) + ["evaluator"] +
-                             list(cases.INGEST_CASES))
+                             list(cases.INGEST_CASES) + list(cases.BASEC_CASES))
     for n in names:
         if n == "evaluator":
             run_evaluator_golden()
             continue
         if n in cases.INGEST_CASES:
             run_ingest_case(n)
+            continue
+        if n in cases.BASEC_CASES:
+            run_basec_case(n)
             continue
         if n in cases.BIGC_CASES:
             run_bigc_case(n, m10, m07)

@@ -62,3 +62,11 @@ def test_vidor_cli_cls_training_eval_and_grounding():
                "--output_dir", out_dir, "--save_tag", "t", "--synthetic", "6", "--n_trajs", "10", "--save_json_results"])
     assert "detection recall" in log
     assert os.path.exists(os.path.join(out_dir, "VidORval_predict_relations_aft_grd_t.json"))
+
+
+def test_vidor_cli_pairwise_baseline():
+    cfg6 = os.path.join(ROOT, "vidsgg-big_amd", "experiments", "exp6", "config_.py")
+    out_dir = tempfile.mkdtemp()
+    log = run([os.path.join(TOOLS, "eval_vidor.py"), "--eval_cls_only", "--use_baseline", "--cfg_path", cfg6, "--output_dir", out_dir,
+               "--save_tag", "b", "--synthetic", "4", "--n_trajs", "10"])
+    assert "detection recall" in log and os.path.exists(os.path.join(out_dir, "VidORval_infer_results_topk3_b.pkl"))

@@ -88,6 +88,8 @@ _SIGS = {
     "bigc_workspace_bytes": (c_size_t, [c_void_p, POINTER(bigc_batch)]),
     "bigc_forward": (c_int, [c_void_p, c_void_p, POINTER(bigc_batch), c_void_p, c_size_t, c_int,
                              POINTER(bigc_outputs)]),
+    "bigc_pair_workspace_bytes": (c_size_t, [c_void_p, POINTER(bigc_batch), ctypes.c_long]),
+    "bigc_pair_forward": (c_int, [c_void_p, c_void_p, POINTER(bigc_batch), c_void_p, ctypes.c_long, c_void_p, c_size_t, c_void_p, c_void_p]),
     # training step
     "bigc_transpose_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "bigc_linear_dw_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,

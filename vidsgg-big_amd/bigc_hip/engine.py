@@ -14,12 +14,17 @@ class BigcEngine(object):
         """``cfg``: the reference's ``model_config`` dict; ``variant``: "vidvrd" | "vidor"."""
         self.lib = _lib.load()
         c = _lib.bigc_config()
-        c.variant = 0 if variant == "vidvrd" else 1
+        c.variant = {"vidvrd": 0, "vidor": 1, "pairwise": 2}[variant]
         c.num_enti_cats, c.num_pred_cats = cfg["num_enti_cats"], cfg["num_pred_cats"]
         c.dim_feat, c.dim_clsme = cfg["dim_feat"], cfg["dim_clsme"]
-        c.dim_enti, c.dim_pred, c.dim_att, c.dim_ffn = cfg["dim_enti"], cfg["dim_pred"], cfg["dim_att"], cfg["dim_ffn"]
-        c.enco_pool_len, c.n_enco_layers, c.n_deco_layers = cfg["enco_pool_len"], cfg["n_enco_layers"], cfg["n_deco_layers"]
-        c.n_att_head, c.num_querys = cfg["n_att_head"], cfg["num_querys"]
+        if variant == "pairwise":       # Base_C has no transformer: only the front-end and the pair head (models/model_pairwise_baseline.py:43-71)
+            c.dim_enti = c.dim_pred = c.dim_att = cfg["dim_enti"]
+            c.dim_ffn, c.enco_pool_len, c.n_enco_layers, c.n_deco_layers = cfg["dim_ffn"], cfg["enco_pool_len"], 0, 0
+            c.n_att_head, c.num_querys = cfg["dim_enti"] // 16, 1
+        else:
+            c.dim_enti, c.dim_pred, c.dim_att, c.dim_ffn = cfg["dim_enti"], cfg["dim_pred"], cfg["dim_att"], cfg["dim_ffn"]
+            c.enco_pool_len, c.n_enco_layers, c.n_deco_layers = cfg["enco_pool_len"], cfg["n_enco_layers"], cfg["n_deco_layers"]
+            c.n_att_head, c.num_querys = cfg["n_att_head"], cfg["num_querys"]
         if variant == "vidvrd":
             c.dim_extra = cfg.get("dim_i3d", None) or 0
             c.use_clsme, c.has_enti_emb = 1, 1
@@ -91,4 +96,29 @@ class BigcEngine(object):
             self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         _lib.check(self.lib.bigc_forward(self.handle, _lib.current_stream(), ctypes.byref(b), self._ws.data_ptr(),
                                          self._ws.numel(), int(topk), ctypes.byref(o)))
+        return out
+
+    def pair_forward(self, packed, keep_intermediates=False):
+        """Base_C: logits of every ordered tracklet pair of every video of a PackedBatch.
+        -> dict(pair_logits (n_pairs, P), vid_pair_off host list, optional enti2enco)."""
+        import numpy as np
+        c = self.c
+        assert packed.feat_width == c.dim_feat + c.dim_extra, "feature width %d != dim_feat+extra %d" % (packed.feat_width, c.dim_feat + c.dim_extra)
+        dev = packed.device
+        n = np.diff(packed.vid_trk_off_host).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(n * (n - 1))])
+        n_pairs = int(off[-1])
+        out = {"vid_pair_off": off, "pair_logits": torch.empty((n_pairs, c.num_pred_cats), dtype=torch.float32, device=dev)}
+        if n_pairs == 0:
+            return out
+        if keep_intermediates:
+            out["enti2enco"] = torch.empty((packed.n_trk, c.dim_enti), dtype=torch.float32, device=dev)
+        off_d = torch.from_numpy(off.astype(np.int32)).to(dev)
+        b = packed.as_struct()
+        need = self.lib.bigc_pair_workspace_bytes(self.handle, ctypes.byref(b), n_pairs)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _lib.check(self.lib.bigc_pair_forward(self.handle, _lib.current_stream(), ctypes.byref(b), off_d.data_ptr(), n_pairs, self._ws.data_ptr(),
+                                              self._ws.numel(), _lib.ptr(out.get("enti2enco")), out["pair_logits"].data_ptr()))
+        out["_keepalive"] = off_d
         return out

@@ -160,6 +160,22 @@ def bigc_state_shapes(cfg, variant="vidvrd"):
     return shapes
 
 
+def basec_state_shapes(cfg):
+    """Ordered (key, shape) list of the pairwise baseline's ``state_dict`` (models/model_pairwise_baseline.py:28-71)."""
+    de, df, ne, npred = cfg["dim_enti"], cfg["dim_ffn"], cfg["num_enti_cats"], cfg["num_pred_cats"]
+    shapes = []
+    if cfg.get("EntiNameEmb_path", None) is not None or cfg.get("_with_EntiNameEmb", False):
+        shapes.append(("EntiNameEmb", (ne, cfg["dim_clsme"])))
+    shapes.append(("bias_matrix", (ne, ne, npred)))
+    shapes += _linear_shapes("fc_feat2enti.0", de, cfg["dim_feat"]) + _linear_shapes("fc_feat2enti.2", de, de)
+    shapes += _linear_shapes("fc_bbox2enti.0", de, 8) + _linear_shapes("fc_bbox2enti.2", de, de)
+    shapes += [("conv_feat2enti.weight", (de, 2 * de, 3)), ("conv_feat2enti.bias", (de,))]
+    shapes += _linear_shapes("fc_enti2enco.0", de, de * cfg["enco_pool_len"]) + _linear_shapes("fc_enti2enco.2", de, de)
+    k = 2 * de + (2 * cfg["dim_clsme"] if cfg["use_clsme"] else 0)
+    shapes += _linear_shapes("fc_pred2logits.0", df, k) + _linear_shapes("fc_pred2logits.2", npred, df)
+    return shapes
+
+
 def grd_state_shapes(cfg):
     """Ordered (key, shape) list of the grounding scorer's ``state_dict``
     (reference: models/grd_model_v5.py:158-193; the two embedding tables are hard-wired to

@@ -97,3 +97,88 @@ extern "C" int bigc_head_gather(void* stream, const float* att, const int32_t* e
     BIGC_LAUNCH_CHECK("head_gather");
     return BIGC_OK;
 }
+
+// ---- pairwise baseline (models/model_pairwise_baseline.py:105-112,236-273) -------------------------------------------------
+namespace {
+
+// pair p of video v: row-major (s, o) over the N_v x N_v grid without its diagonal (trajid2pairid, :105-112)
+__device__ __forceinline__ void pair_of(long p, const int32_t* vid_trk_off, const int32_t* vid_pair_off, int n_vid, int& v, int& s, int& o) {
+    int lo = 0, hi = n_vid - 1;
+    while (lo < hi) {                                   // last video whose first pair is <= p
+        const int mid = (lo + hi + 1) >> 1;
+        if ((long)vid_pair_off[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    v = lo;
+    const int n = vid_trk_off[v + 1] - vid_trk_off[v];
+    const int q = (int)(p - vid_pair_off[v]);
+    s = q / (n - 1);
+    const int r = q - s * (n - 1);
+    o = r < s ? r : r + 1;
+}
+
+__global__ __launch_bounds__(256) void pair_hidden_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                          const int32_t* __restrict__ vid_trk_off, const int32_t* __restrict__ vid_pair_off,
+                                                          float* __restrict__ H, int n_vid, long n_pairs, int d4) {
+    const long total = n_pairs * d4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / d4;
+        const int c = (int)(i - p * d4);
+        int v, s, o;
+        pair_of(p, vid_trk_off, vid_pair_off, n_vid, v, s, o);
+        const int t0 = vid_trk_off[v];
+        const f32x4 a = ((const f32x4*)U)[(size_t)(t0 + s) * d4 + c], b = ((const f32x4*)V)[(size_t)(t0 + o) * d4 + c];
+        f32x4 h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h[k] = fmaxf(a[k] + b[k], 0.f);
+        ((f32x4*)H)[i] = h;
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_bias_kernel(const float* __restrict__ bias_matrix, const int32_t* __restrict__ trk_cat,
+                                                        const int32_t* __restrict__ vid_trk_off, const int32_t* __restrict__ vid_pair_off,
+                                                        float* __restrict__ out, int n_vid, long n_pairs, int n_cat, int n_pred) {
+    const long total = n_pairs * n_pred;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / n_pred;
+        const int c = (int)(i - p * n_pred);
+        int v, s, o;
+        pair_of(p, vid_trk_off, vid_pair_off, n_vid, v, s, o);
+        const int t0 = vid_trk_off[v];
+        out[i] = bias_matrix[((size_t)trk_cat[t0 + s] * n_cat + trk_cat[t0 + o]) * n_pred + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                          long total, int d) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / d;
+        out[i] = src[(size_t)idx[r] * d + (i - r * d)];
+    }
+}
+
+int grid_of(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+
+}  // namespace
+
+int bigc_pair_hidden(hipStream_t s, const float* U, const float* V, const int32_t* vid_trk_off, const int32_t* vid_pair_off, float* H,
+                     int n_vid, long n_pairs, int d) {
+    ProfScope ps((void*)s, FAM_HEAD_GATHER, 0.0, 4.0 * n_pairs * (double)d);
+    hipLaunchKernelGGL(pair_hidden_kernel, dim3(grid_of(n_pairs * (d / 4))), dim3(256), 0, s, U, V, vid_trk_off, vid_pair_off, H, n_vid, n_pairs, d / 4);
+    BIGC_LAUNCH_CHECK("pair_hidden");
+    return BIGC_OK;
+}
+
+int bigc_pair_bias(hipStream_t s, const float* bias_matrix, const int32_t* trk_cat, const int32_t* vid_trk_off, const int32_t* vid_pair_off,
+                   float* out, int n_vid, long n_pairs, int n_cat, int n_pred) {
+    ProfScope ps((void*)s, FAM_HEAD_GATHER, 0.0, 8.0 * n_pairs * (double)n_pred);
+    hipLaunchKernelGGL(pair_bias_kernel, dim3(grid_of(n_pairs * n_pred)), dim3(256), 0, s, bias_matrix, trk_cat, vid_trk_off, vid_pair_off, out, n_vid,
+                       n_pairs, n_cat, n_pred);
+    BIGC_LAUNCH_CHECK("pair_bias");
+    return BIGC_OK;
+}
+
+int bigc_gather_rows(hipStream_t s, const float* src, const int32_t* idx, float* out, int n, int d) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_of((long)n * d)), dim3(256), 0, s, src, idx, out, (long)n * d, d);
+    BIGC_LAUNCH_CHECK("gather_rows");
+    return BIGC_OK;
+}

@@ -99,6 +99,7 @@ bool layout(const bigc_model* m, const Sizes& z, Arena& a, Work& w) {
 }
 
 int head_width(const bigc_config& c) {
+    if (c.variant == 2) return 2 * c.dim_enti + (c.use_clsme ? 2 * c.dim_clsme : 0);      // Base_C: [s_clsme, o_clsme, s_feat, o_feat]
     if (c.variant == 0) return c.dim_pred + 2 * c.dim_clsme + (c.dim_extra > 0 ? 4 : 2) * c.dim_enti;
     return c.dim_pred + 2 * c.dim_enti + (c.use_clsme ? 2 * c.dim_clsme : 0);
 }
@@ -109,11 +110,31 @@ Sizes sizes_of(const bigc_model* m, const bigc_batch* b) {
     return z;
 }
 
+// a1-a4: per-frame front-end on the packed rows, stride-2 temporal conv over the virtual stretch, pool, fc_enti2enco
+// (models/model_0v10.py:401-420,446-458; shared by Base_C, models/model_pairwise_baseline.py:176-197)
+int run_frontend(const bigc_model* m, void* s, const bigc_batch* b, const Work& w, float* e2e) {
+    const bigc_config& c = m->cfg;
+    const int R = b->n_rows, NT = b->n_trk, C = b->n_conv;
+    const int de = c.dim_enti, D = c.dim_feat + c.dim_extra;
+    TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
+    TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
+    TRY(linear(s, w.hb, de, m->bbox2, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
+    TRY(linear(s, b->feats, D, m->feat0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
+    TRY(linear(s, w.hv, de, m->feat2, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
+    TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
+    TRY(bigc_linear_f32(s, w.enti, 2 * de, w.conv_idx, 3, 2 * de, m->conv_w_tapmajor, 6 * de, m->conv.b, nullptr, 0, w.conv, de,
+                        C, de, 6 * de, BIGC_ACT_NONE));
+    TRY(bigc_adaptive_maxpool(s, w.conv, b->trk_conv_off, w.pooled, NT, de, c.enco_pool_len));
+    TRY(linear(s, w.pooled, de * c.enco_pool_len, m->enco0, w.eh, de, NT, de, de * c.enco_pool_len, BIGC_ACT_RELU));
+    TRY(linear(s, w.eh, de, m->enco2, e2e, de, NT, de, de, BIGC_ACT_RELU));
+    return BIGC_OK;
+}
+
 }  // namespace
 
 extern "C" int bigc_create(const bigc_config* cfg, bigc_model** out) {
     BIGC_CHECK_ARG(cfg && out, "create: null pointer");
-    BIGC_CHECK_ARG(cfg->variant == 0 || cfg->variant == 1, "create: variant %d", cfg->variant);
+    BIGC_CHECK_ARG(cfg->variant >= 0 && cfg->variant <= 2, "create: variant %d", cfg->variant);
     BIGC_CHECK_ARG(cfg->dim_enti % cfg->n_att_head == 0 && cfg->dim_pred % cfg->n_att_head == 0, "create: dims not divisible by heads");
     const int hd_e = cfg->dim_enti / cfg->n_att_head, hd_p = cfg->dim_pred / cfg->n_att_head;
     BIGC_CHECK_ARG((hd_e == 8 || hd_e == 16 || hd_e == 32 || hd_e == 64) && hd_e == hd_p, "create: head_dim %d/%d unsupported", hd_e, hd_p);
@@ -149,8 +170,10 @@ extern "C" int bigc_finalize(bigc_model* m, void* stream) {
     Resolver r{m};
     const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn;
     if (c.has_enti_emb) m->emb = r.get("EntiNameEmb", (int64_t)c.num_enti_cats * c.dim_clsme);
-    m->pos = r.get("pos_embedding", (int64_t)c.num_querys * dp);
-    m->qinit = r.get("pred_query_init", (int64_t)c.num_querys * dp);
+    if (c.variant != 2) {
+        m->pos = r.get("pos_embedding", (int64_t)c.num_querys * dp);
+        m->qinit = r.get("pred_query_init", (int64_t)c.num_querys * dp);
+    }
     m->bias_matrix = r.get("bias_matrix", (int64_t)c.num_enti_cats * c.num_enti_cats * c.num_pred_cats);
     m->feat0 = r.lin("fc_feat2enti.0", de, c.dim_feat);
     m->feat2 = r.lin("fc_feat2enti.2", de, de);
@@ -220,6 +243,7 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
     StaticWeights static_weights(m ? m->epoch : 0);
     BIGC_CHECK_ARG(m && b && out, "forward: null pointer");
     BIGC_CHECK_ARG(m->finalized, "forward: call bigc_finalize after setting the parameters");
+    BIGC_CHECK_ARG(m->cfg.variant != 2, "forward: the pairwise baseline runs through bigc_pair_forward");
     BIGC_CHECK_ARG(b->n_vid > 0 && b->n_trk > 0 && b->n_rows > 0 && b->n_conv > 0, "forward: empty batch");
     BIGC_CHECK_ARG(b->max_trk > 0 && b->max_trk <= 512, "forward: max_trk=%d must be in [1,512]", b->max_trk);
     BIGC_CHECK_ARG(out->pred_logits && out->att && out->soid, "forward: pred_logits/att/soid outputs are required");
@@ -233,27 +257,14 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
                                               bigc_workspace_bytes(m, b));
     hipStream_t hs = (hipStream_t)stream;
     void* s = stream;
-    const int R = b->n_rows, NT = b->n_trk, C = b->n_conv, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
+    const int NT = b->n_trk, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
     const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn;
     const int D = c.dim_feat + c.dim_extra;
     const int H = c.n_att_head, hd = de / H;
     const float eps = 1e-5f;
 
-    // ---- a1/a3: per-frame front-end on the packed rows (models/model_0v10.py:401-420,446-448)
-    TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
-    TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
-    TRY(linear(s, w.hb, de, m->bbox2, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
-    TRY(linear(s, b->feats, D, m->feat0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
-    TRY(linear(s, w.hv, de, m->feat2, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
-
-    // ---- a2/a4: stride-2 temporal conv over the virtual stretch, pool, fc_enti2enco (:450-458)
-    TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
-    TRY(bigc_linear_f32(s, w.enti, 2 * de, w.conv_idx, 3, 2 * de, m->conv_w_tapmajor, 6 * de, m->conv.b, nullptr, 0, w.conv, de,
-                        C, de, 6 * de, BIGC_ACT_NONE));
-    TRY(bigc_adaptive_maxpool(s, w.conv, b->trk_conv_off, w.pooled, NT, de, c.enco_pool_len));
     float* e2e = out->enti2enco ? out->enti2enco : w.e2e;
-    TRY(linear(s, w.pooled, de * c.enco_pool_len, m->enco0, w.eh, de, NT, de, de * c.enco_pool_len, BIGC_ACT_RELU));
-    TRY(linear(s, w.eh, de, m->enco2, e2e, de, NT, de, de, BIGC_ACT_RELU));
+    TRY(run_frontend(m, s, b, w, e2e));
 
     // ---- a5: encoder, sequence = the tracklets of a video (:459-462, layer :103-117)
     const float* x = e2e;
@@ -366,5 +377,76 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         TRY(bigc_construct_triplets(s, out->pred_logits, c.num_pred_cats, out->soid, b->vid_trk_off, b->trk_dura, b->trk_cat, b->trk_score,
                                     B, Q, topk, out->quint, out->scores, out->dura, out->qid, out->n_out));
     }
+    return BIGC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Base_C, the explicit pairwise baseline (models/model_pairwise_baseline.py:174-197,236-273): front-end as above, then for
+// EVERY ordered pair (s, o), s != o, of a video: logits = W2 relu(W1 [s_clsme, o_clsme, s_feat, o_feat] + b1) + b2 + bias[s_cat, o_cat].
+// The first layer is linear in the concatenation, so it is evaluated per TRACKLET and per role
+//     U[t] = W1[:, s_clsme cols] clsme_t + W1[:, s_feat cols] feat_t + b1,   V[t] = W1[:, o_clsme cols] clsme_t + W1[:, o_feat cols] feat_t
+// (4 GEMMs over N rows instead of one over N(N-1) rows of width 1624) and fused per pair as relu(U[s] + V[o]).
+// ------------------------------------------------------------------------------------------------
+int bigc_pair_hidden(hipStream_t s, const float* U, const float* V, const int32_t* vid_trk_off, const int32_t* vid_pair_off, float* H,
+                     int n_vid, long n_pairs, int d);
+int bigc_pair_bias(hipStream_t s, const float* bias_matrix, const int32_t* trk_cat, const int32_t* vid_trk_off, const int32_t* vid_pair_off,
+                   float* out, int n_vid, long n_pairs, int n_cat, int n_pred);
+int bigc_gather_rows(hipStream_t s, const float* src, const int32_t* idx, float* out, int n, int d);
+
+extern "C" size_t bigc_pair_workspace_bytes(const bigc_model* m, const bigc_batch* b, long n_pairs) {
+    if (!m || !b) return 0;
+    const bigc_config& c = m->cfg;
+    const size_t NT = b->n_trk, df = c.dim_ffn;
+    return bigc_workspace_bytes(m, b) + 4 * (256 + sizeof(float) * (NT * df * 2 + NT * (size_t)c.dim_clsme + (size_t)n_pairs * (df + c.num_pred_cats)));
+}
+
+extern "C" int bigc_pair_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* vid_pair_off, long n_pairs, void* workspace,
+                                 size_t workspace_bytes, float* enti2enco, float* pair_logits) {
+    StaticWeights static_weights(m ? m->epoch : 0);
+    BIGC_CHECK_ARG(m && b && vid_pair_off && pair_logits, "pair_forward: null pointer");
+    BIGC_CHECK_ARG(m->finalized && m->cfg.variant == 2, "pair_forward: needs a finalized pairwise-baseline model");
+    BIGC_CHECK_ARG(b->n_vid > 0 && b->n_trk > 0 && b->n_rows > 0 && b->n_conv > 0 && n_pairs > 0, "pair_forward: empty batch");
+    const bigc_config& c = m->cfg;
+    const Sizes z = sizes_of(m, b);
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (!workspace || workspace_bytes < (size_t)(base - (char*)workspace)) return bigc_fail(BIGC_ERR_WORKSPACE, "pair_forward: no workspace");
+    Arena a{base, workspace_bytes - (size_t)(base - (char*)workspace)};
+    Work w;
+    layout(m, z, a, w);
+    const int NT = b->n_trk, de = c.dim_enti, df = c.dim_ffn, dc = c.use_clsme ? c.dim_clsme : 0, hk = m->head_k, P = c.num_pred_cats;
+    float* U = a.take<float>((size_t)NT * df);
+    float* V = a.take<float>((size_t)NT * df);
+    float* clsme = a.take<float>((size_t)NT * (dc > 0 ? dc : 1));
+    float* H = a.take<float>((size_t)n_pairs * df);
+    float* bias = a.take<float>((size_t)n_pairs * P);
+    if (a.overflow) return bigc_fail(BIGC_ERR_WORKSPACE, "pair_forward: workspace of %zu bytes too small, need %zu", workspace_bytes,
+                                     bigc_pair_workspace_bytes(m, b, n_pairs));
+    hipStream_t hs = (hipStream_t)stream;
+    void* s = stream;
+    float* e2e = enti2enco ? enti2enco : w.e2e;
+    TRY(run_frontend(m, s, b, w, e2e));
+    const float* W1 = m->head0.w;
+    const float* clsme_rows = nullptr;
+    if (dc > 0) {
+        if (c.has_enti_emb) {               // category embedding as classeme (:251-253)
+            TRY(bigc_gather_rows(hs, m->emb, b->trk_cat, clsme, NT, dc));
+        } else {                            // time-mean of the tracklet's classeme columns over the stretched frames (:191)
+            TRY(bigc_stretched_mean(s, b->feats, c.dim_feat + c.dim_extra, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, clsme, NT));
+        }
+        clsme_rows = clsme;
+    }
+    // column blocks of W1 (df, hk): [s_clsme | o_clsme | s_feat | o_feat] (:257), or [s_feat | o_feat] without classemes (:259)
+    if (dc > 0) {
+        TRY(bigc_linear_f32(s, clsme_rows, dc, nullptr, 1, dc, W1, hk, m->head0.b, nullptr, 0, U, df, NT, df, dc, BIGC_ACT_NONE));
+        TRY(bigc_linear_f32(s, e2e, de, nullptr, 1, de, W1 + 2 * dc, hk, nullptr, U, df, U, df, NT, df, de, BIGC_ACT_NONE));
+        TRY(bigc_linear_f32(s, clsme_rows, dc, nullptr, 1, dc, W1 + dc, hk, nullptr, nullptr, 0, V, df, NT, df, dc, BIGC_ACT_NONE));
+        TRY(bigc_linear_f32(s, e2e, de, nullptr, 1, de, W1 + 2 * dc + de, hk, nullptr, V, df, V, df, NT, df, de, BIGC_ACT_NONE));
+    } else {
+        TRY(bigc_linear_f32(s, e2e, de, nullptr, 1, de, W1, hk, m->head0.b, nullptr, 0, U, df, NT, df, de, BIGC_ACT_NONE));
+        TRY(bigc_linear_f32(s, e2e, de, nullptr, 1, de, W1 + de, hk, nullptr, nullptr, 0, V, df, NT, df, de, BIGC_ACT_NONE));
+    }
+    TRY(bigc_pair_hidden(hs, U, V, b->vid_trk_off, vid_pair_off, H, b->n_vid, n_pairs, df));
+    TRY(bigc_pair_bias(hs, m->bias_matrix, b->trk_cat, b->vid_trk_off, vid_pair_off, bias, b->n_vid, n_pairs, c.num_enti_cats, P));
+    TRY(bigc_linear_f32(s, H, df, nullptr, 1, df, m->head2.w, df, m->head2.b, bias, P, pair_logits, P, (int)n_pairs, P, df, BIGC_ACT_NONE));
     return BIGC_OK;
 }

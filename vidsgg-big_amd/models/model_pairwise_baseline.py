@@ -1,0 +1,107 @@
+"""The explicit pairwise baseline on the HIP path: drop-in for the reference's
+``models/model_pairwise_baseline.py:Base_C`` (eval forward).
+The torch modules only own the parameters under the reference's key names; the front-end, the N x N pair fusion and the
+classifier run in the HIP library (``bigc_pair_forward``); the triplet bookkeeping of ``construct_triplet`` (:306-395) is a
+handful of device-side torch index operations on the pair logits."""
+import numpy as np
+import torch
+from torch import nn
+
+from bigc_hip.engine import BigcEngine
+from bigc_hip.packed import PackedBatch
+
+
+class Base_C(nn.Module):
+    def __init__(self, config, is_train=True):
+        super().__init__()
+        self.is_train = is_train
+        self.config = dict(config)
+        c = config
+        self.num_pred_cats, self.num_enti_cats = c["num_pred_cats"], c["num_enti_cats"]
+        self.dim_feat, self.dim_clsme, self.dim_enti, self.dim_ffn = c["dim_feat"], c["dim_clsme"], c["dim_enti"], c["dim_ffn"]
+        self.enco_pool_len, self.use_clsme, self.rt_triplets_topk = c["enco_pool_len"], c["use_clsme"], c["rt_triplets_topk"]
+        self.EntiNameEmb_path = c.get("EntiNameEmb_path", None)
+        if self.EntiNameEmb_path is None:
+            self.EntiNameEmb = None
+        else:
+            emb = torch.from_numpy(np.load(self.EntiNameEmb_path)).float()
+            assert emb.shape == (self.num_enti_cats, self.dim_clsme)
+            self.EntiNameEmb = nn.Parameter(emb, requires_grad=False)
+        bias = torch.from_numpy(np.load(c["bias_matrix_path"])).float()
+        assert bias.shape == (self.num_enti_cats, self.num_enti_cats, self.num_pred_cats)
+        self.bias_matrix = nn.Parameter(bias, requires_grad=True)
+        de = self.dim_enti
+        self.fc_feat2enti = nn.Sequential(nn.Linear(self.dim_feat, de), nn.ReLU(), nn.Linear(de, de), nn.ReLU())
+        self.fc_bbox2enti = nn.Sequential(nn.Linear(8, de), nn.ReLU(), nn.Linear(de, de), nn.ReLU())
+        self.conv_feat2enti = nn.Conv1d(de * 2, de, kernel_size=3, padding=1, stride=2)
+        self.fc_enti2enco = nn.Sequential(nn.Linear(de * self.enco_pool_len, de), nn.ReLU(), nn.Linear(de, de), nn.ReLU())
+        k = 2 * de + (2 * self.dim_clsme if self.use_clsme else 0)
+        self.fc_pred2logits = nn.Sequential(nn.Linear(k, self.dim_ffn), nn.ReLU(), nn.Linear(self.dim_ffn, self.num_pred_cats))
+        for name, p in self.named_parameters():               # models/model_pairwise_baseline.py:76-91
+            if name in ("bias_matrix", "EntiNameEmb"):
+                continue
+            if p.dim() > 1:
+                nn.init.xavier_normal_(p)
+            if "bias" in name:
+                nn.init.zeros_(p)
+        self._engine = None
+
+    def engine(self):
+        if self._engine is None:
+            cfg = dict(self.config)
+            self._engine = BigcEngine(cfg, "pairwise")
+        self._engine.sync_params((k, v) for k, v in self.state_dict(keep_vars=True).items())
+        return self._engine
+
+    def forward(self, proposal_list, pos_id_list=None, label_list=None, topk=10):
+        """Eval contract of the reference (:93-127): one entry per video, ``None`` for an empty video or when no pair
+        overlaps in time, else ``(uniq_quintuples, uniq_scores (U,3), uniq_dura_inters, uniq_query_ids)``."""
+        if self.is_train:
+            raise NotImplementedError("Base_C training (models/model_pairwise_baseline.py:276-303) is not built on the HIP path")
+        self.topk = topk
+        keep = [i for i, p in enumerate(proposal_list) if p.num_proposals > 0]
+        res = [None] * len(proposal_list)
+        if not keep:
+            return res
+        dev = next(self.parameters()).device
+        packed = PackedBatch([proposal_list[i] for i in keep], dev)
+        with torch.no_grad():
+            out = self.engine().pair_forward(packed)
+        off = out["vid_pair_off"]
+        for j, i in enumerate(keep):
+            if off[j + 1] > off[j]:
+                res[i] = self.construct_triplet(proposal_list[i], out["pair_logits"][off[j]:off[j + 1]])
+        return res
+
+    def construct_triplet(self, proposal, pred_logits):
+        """(:306-395) on the device: softmax, per-pair top-k, temporal-overlap filter, lexicographic order of the (unique)
+        quintuples, background removal, optional top ``rt_triplets_topk`` by mean score."""
+        dev = pred_logits.device
+        n, k = proposal.num_proposals, self.topk
+        probs = torch.softmax(pred_logits, dim=-1)
+        scores, cats = torch.topk(probs, k, dim=-1)
+        scores, cats = scores.reshape(-1), cats.reshape(-1)
+        dura = proposal.traj_durations.to(dev)
+        idx = torch.arange(n, device=dev)
+        so = torch.stack(torch.meshgrid(idx, idx, indexing="ij"), -1).reshape(-1, 2)
+        so = so[so[:, 0] != so[:, 1]]                                           # trajid2pairid (:105-112)
+        so = torch.repeat_interleave(so, k, dim=0)
+        s_d, o_d = dura[so[:, 0]], dura[so[:, 1]]
+        start, end = torch.maximum(s_d[:, 0], o_d[:, 0]), torch.minimum(s_d[:, 1], o_d[:, 1])
+        pos = end >= start                                                      # closed intervals (utils/utils_func.py:347-373)
+        if int(pos.sum()) == 0:
+            return None
+        so, scores, cats, start, end = so[pos], scores[pos], cats[pos], start[pos], end[pos]
+        enti_cat, enti_score = proposal.cat_ids.to(dev), proposal.scores.to(dev)
+        quint = torch.cat([cats[:, None], enti_cat[so], so], dim=-1)            # [pred, s_cat, o_cat, s_tid, o_tid]
+        trip = torch.stack([scores, enti_score[so[:, 0]], enti_score[so[:, 1]]], -1)
+        # every (pair, predicate) occurs once: torch.unique(dim=0) only sorts the rows lexicographically (:349-358)
+        key = (((quint[:, 0] * 512 + quint[:, 1]) * 512 + quint[:, 2]) * 1024 + quint[:, 3]) * 1024 + quint[:, 4]
+        order = torch.argsort(key)
+        quint, trip, inters = quint[order], trip[order], torch.stack([start, end], -1)[order]
+        mask = quint[:, 0] != 0
+        quint, trip, inters = quint[mask], trip[mask], inters[mask]
+        if self.rt_triplets_topk > 0:
+            top = trip.mean(dim=-1).argsort(descending=True)[:self.rt_triplets_topk]
+            quint, trip, inters = quint[top], trip[top], inters[top]
+        return quint, trip, inters, torch.empty(size=(trip.shape[0],))

@@ -16,7 +16,7 @@ from _common import (ensure_grounding_files, ensure_table_files, load_checkpoint
 
 from bigc_hip import evaluate as E
 from bigc_hip.pipeline import combine_with_grounding
-from models import BIG_C_vidor, DEBUG
+from models import BIG_C_vidor, Base_C, DEBUG
 
 
 def _load_data(cfg, synthetic, n_trajs, clip_dim):
@@ -42,14 +42,15 @@ def _report(groundtruth, predictions, output_dir, name, save_json):
     return mean_ap, rec, prec
 
 
-def evaluate_cls_stage(cfg_path, ckpt_path=None, save_tag="", output_dir=None, cuda=0, save_json=False, synthetic=0, n_trajs=32):
+def evaluate_cls_stage(cfg_path, ckpt_path=None, save_tag="", output_dir=None, cuda=0, save_json=False, synthetic=0, n_trajs=32,
+                       model_class=BIG_C_vidor):
     cfg = parse_config_py(cfg_path)
     topk = cfg["inference_config"]["topk"]
     save_tag = "topk{}_{}".format(topk, save_tag)                       # tools/eval_vidor.py:47
     output_dir = output_dir or os.path.dirname(os.path.abspath(cfg_path))
     os.makedirs(output_dir, exist_ok=True)
     device = torch.device("cuda:%d" % cuda)
-    model = BIG_C_vidor(ensure_table_files(cfg["model_config"], output_dir), is_train=False).to(device)
+    model = model_class(ensure_table_files(cfg["model_config"], output_dir), is_train=False).to(device)
     if ckpt_path:
         load_checkpoint_into(model, ckpt_path, device)
     model.eval()
@@ -124,13 +125,12 @@ if __name__ == "__main__":
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N generated videos instead of a dataset")
     ap.add_argument("--n_trajs", type=int, default=32)
     a = ap.parse_args()
-    if a.use_baseline:
-        raise SystemExit("--use_baseline (Base_C, models/model_pairwise_baseline.py) is outside the BIG-C hot path built here")
     if a.json_results_path is not None:
         with open(a.json_results_path) as f:
             _report({}, json.load(f), ".", "", False)
     elif a.eval_cls_only:
-        evaluate_cls_stage(a.cfg_path, a.ckpt_path, a.save_tag, a.output_dir, a.cuda, a.save_json_results, a.synthetic, a.n_trajs)
+        evaluate_cls_stage(a.cfg_path, a.ckpt_path, a.save_tag, a.output_dir, a.cuda, a.save_json_results, a.synthetic, a.n_trajs,
+                           model_class=Base_C if a.use_baseline else BIG_C_vidor)        # tools/eval_vidor.py:310
     else:
         evaluate_combined(a.cfg_path, a.ckpt_path, a.cls_stage_result_path, a.save_tag, a.output_dir, a.cuda, a.save_json_results,
                           a.synthetic, a.n_trajs)

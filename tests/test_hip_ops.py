@@ -115,7 +115,7 @@ def test_linear_rejects_bad_shapes(lib):
         _lib.check(lib.bigc_linear_f32(S(), A.data_ptr(), 6, None, 1, 6, W.data_ptr(), 6, None, None, 0, C.data_ptr(), 4, 4, 4, 6, 0))
 
 
-@pytest.mark.parametrize("rows,d", [(1, 16), (7, 128), (1000, 512), (33, 2048)])
+@pytest.mark.parametrize("rows,d", [(1, 16), (7, 128), (1000, 512), (33, 2048), (1001, 128), (49, 64), (35, 256), (3, 512)])
 def test_layernorm(lib, rows, d):
     g = torch.Generator().manual_seed(rows + d)
     x = torch.randn(rows, d, generator=g) * 3 + 1

@@ -58,6 +58,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Specialised form for d = 4 * G * NVL with G (lanes per row) a power of two <= 64: a wave holds 64 / G rows side by side
+// and UNR such groups in flight (all loads of a wave-iteration are issued before the first reduction), statistics by
+// butterfly shuffles inside the G-lane group.  Same arithmetic order per element as the generic kernel.
+template <int G, int NVL, int UNR>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                             float* __restrict__ y, int rows, float eps) {
+    constexpr int RPW = 64 / G;                    // rows per wave pass
+    constexpr int D4 = G * NVL;                    // float4 per row
+    const int lane = threadIdx.x & 63, sub = lane / G, gl = lane % G;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row0 = wave * RPW * UNR + sub;
+    f32x4 v[UNR][NVL];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int row = min(row0 + u * RPW, rows - 1);
+        const f32x4* xp = (const f32x4*)x + (size_t)row * D4;
+#pragma unroll
+        for (int j = 0; j < NVL; ++j) v[u][j] = xp[gl + G * j];
+    }
+    f32x4 gg[NVL], bb[NVL];
+#pragma unroll
+    for (int j = 0; j < NVL; ++j) { gg[j] = ((const f32x4*)g)[gl + G * j]; bb[j] = ((const f32x4*)b)[gl + G * j]; }
+    auto gsum = [](float t) {
+#pragma unroll
+        for (int o = G / 2; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+        return t;
+    };
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NVL; ++j) s += (v[u][j][0] + v[u][j][1]) + (v[u][j][2] + v[u][j][3]);
+        const float mean = gsum(s) / (float)(4 * D4);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NVL; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float t = v[u][j][c] - mean; ss += t * t; }
+        const float rstd = 1.0f / sqrtf(gsum(ss) / (float)(4 * D4) + eps);
+        const int row = row0 + u * RPW;
+        if (row < rows) {
+            f32x4* yp = (f32x4*)y + (size_t)row * D4;
+#pragma unroll
+            for (int j = 0; j < NVL; ++j) {
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = (v[u][j][c] - mean) * rstd * gg[j][c] + bb[j][c];
+                yp[gl + G * j] = o;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ x, const float* __restrict__ p, float* __restrict__ y,
                                                        long n4, int d4, int period) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -88,7 +141,14 @@ extern "C" int bigc_layernorm_f32(void* stream, const float* x, const float* gam
     BIGC_CHECK_ARG(d > 0 && d % 4 == 0 && d <= 2048, "layernorm: d=%d must be a multiple of 4 and <= 2048", d);
     if (rows <= 0) return BIGC_OK;
     ProfScope ps(stream, FAM_LAYERNORM, 0.0, 8.0 * rows * (double)d);
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, rows, d, eps);
+    hipStream_t hs = (hipStream_t)stream;
+#define LN_ROWS(G, NVL, UNR) hipLaunchKernelGGL((layernorm_rows_kernel<G, NVL, UNR>), dim3(cdiv(rows, 4 * (64 / G) * UNR)), dim3(256), 0, hs, x, gamma, beta, y, rows, eps)
+    if (d == 512) LN_ROWS(64, 2, 4);
+    else if (d == 256) LN_ROWS(64, 1, 4);
+    else if (d == 128) LN_ROWS(32, 1, 4);
+    else if (d == 64) LN_ROWS(16, 1, 4);
+    else hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, hs, x, gamma, beta, y, rows, d, eps);
+#undef LN_ROWS
     BIGC_LAUNCH_CHECK("layernorm");
     return BIGC_OK;
 }

@@ -41,7 +41,7 @@ from bigc_hip.synthetic import bigc_state_shapes, seeded_state_dict, synthetic_p
 
 F32_MFMA_PEAK_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 F16_MFMA_PEAK_TFLOPS = 2500.0   # same table, "Peak BF16/FP16 MFMA" dense
-EXACT_F32 = os.environ.get("BIGC_LINEAR_EXACT", "0") not in ("", "0")     # force the exact f32-MFMA GEMM kernel
+EXACT_F32 = os.environ.get("BIGC_LINEAR_EXACT", "0") not in ("", "0")     # run the whole benchmark on the exact f32-MFMA GEMM kernel
 
 
 def parse():
@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-prof", action="store_true", help="do not record HIP events around the kernels")
     ap.add_argument("--mode", choices=["eval", "train"], default="eval", help="eval = headline metric; train = training-step throughput")
     ap.add_argument("--train-videos", type=int, default=8, help="videos per GPU per training step (reference batch size 8)")
+    ap.add_argument("--exact-steps", type=int, default=3, help="extra steps timed with the exact f32-MFMA GEMM kernel, reported beside (0 = skip)")
     return ap.parse_args()
 
 
@@ -234,6 +235,31 @@ def main():
             if n.value:
                 families[lib.bigc_prof_family_name(f).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
 
+    # the same step with every GEMM on the exact f32 MFMA kernel, outside the timed region, for comparison
+    exact_leg = None
+    if args.exact_steps > 0 and not EXACT_F32 and rank == 0:
+        ref_out = model.forward_packed(packed, args.topk)
+        lib.bigc_linear_set_exact(1)
+        ex_out = model.forward_packed(packed, args.topk)          # also the warm-up of this mode
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.exact_steps):
+            step()
+        torch.cuda.synchronize()
+        ex_elapsed = time.perf_counter() - t0
+        lib.bigc_linear_set_exact(0)
+        # padded arrays: compare the valid rows of every video
+        n_a, n_b = ref_out["n_out"].cpu(), ex_out["n_out"].cpu()
+        cap = ref_out["quint"].shape[1]
+        valid = (torch.arange(cap)[None, :] < torch.minimum(n_a, n_b)[:, None]).to(device)
+        same_rows = ((ref_out["quint"] == ex_out["quint"]).all(-1) & (ref_out["dura"] == ex_out["dura"]).all(-1)) & valid
+        same = bool(torch.equal(n_a, n_b)) and int(same_rows.sum()) == int(valid.sum())
+        exact_leg = dict(value=round(pairs_per_step * args.exact_steps / ex_elapsed, 1), unit="pairs/s (this GPU)",
+                         ms_per_step=round(1e3 * ex_elapsed / args.exact_steps, 3), steps=args.exact_steps,
+                         triplet_indices_identical_to_default_mode=bool(same),
+                         identical_triplet_rows="%d of %d" % (int(same_rows.sum()), int(n_b.sum())),
+                         max_logit_diff_rel_between_modes=float(((ref_out["pred_logits"] - ex_out["pred_logits"]).abs().max() / ex_out["pred_logits"].abs().max()).item()))
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -300,7 +326,7 @@ def main():
                                   "GEMMs on f16 MFMAs with exactly split f32 operands, f32-level error; attention on the f32 MFMA"),
                    "videos_per_gpu_per_step": args.videos, "tracklets_per_video": args.n_trajs,
                    "rows_per_step": packed.n_rows, "pairs_per_gpu_per_step": pairs_per_step, "parallelism": "dp%d" % world},
-        "roofline": roofline, "cpu_baseline": cpu_baseline,
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "exact_f32_gemm_mode": exact_leg,
         "kernel_families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in families.items()},
         "videos_per_sec": round(args.videos * world * args.steps / elapsed, 1),
         "triplets_last_step": int(n_out.sum()), "setup_s": round(gen_s, 1),

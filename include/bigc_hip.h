@@ -76,6 +76,12 @@ int bigc_linear_f32(void* stream, const float* A, int lda, const int32_t* a_idx,
                     const float* W, int ldw, const float* bias, const float* residual, int ldr,
                     float* C, int ldc, int M, int N, int K, int act);
 
+/* GEMM arithmetic of bigc_linear_f32 (process-wide): 0 = f16 matrix cores on exactly split f32 operands (default; f32-level
+ * error, see csrc/linear_split.hip), 1 = the exact f32 MFMA kernel.  Initial value from the environment variable
+ * BIGC_LINEAR_EXACT.  bigc_linear_set_exact returns the previous mode. */
+int bigc_linear_set_exact(int exact);
+int bigc_linear_get_exact(void);
+
 /* y[r, :] = LayerNorm(x[r, :]) * gamma + beta over d columns, eps inside the sqrt
  *   (torch.nn.LayerNorm, models/model_0v10.py:81-82,171-173). d <= 2048, d % 4 == 0. */
 int bigc_layernorm_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y,

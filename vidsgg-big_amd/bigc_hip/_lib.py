@@ -60,6 +60,8 @@ _SIGS = {
     "bigc_prof_family_name": (c_char_p, [c_int]),
     "bigc_linear_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                 c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "bigc_linear_set_exact": (c_int, [c_int]),
+    "bigc_linear_get_exact": (c_int, []),
     "bigc_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
     "bigc_add_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "bigc_mha_core_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,

@@ -181,6 +181,11 @@ __global__ __launch_bounds__(256, OCC) void linear_f32_kernel(const LinearArgs p
 
 }  // namespace
 
+// 0: split-operand f16 MFMA kernel (default), 1: exact f32 MFMA kernel; initialised from BIGC_LINEAR_EXACT
+static std::atomic<int> g_exact_mode{(getenv("BIGC_LINEAR_EXACT") && atoi(getenv("BIGC_LINEAR_EXACT")) != 0) ? 1 : 0};
+extern "C" int bigc_linear_set_exact(int exact) { return g_exact_mode.exchange(exact ? 1 : 0); }
+extern "C" int bigc_linear_get_exact(void) { return g_exact_mode.load(); }
+
 extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int32_t* a_idx, int nseg, int seg_len,
                                const float* W, int ldw, const float* bias, const float* residual, int ldr,
                                float* C, int ldc, int M, int N, int K, int act) {
@@ -202,7 +207,7 @@ extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int3
     const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1));
     static const int force_nt = getenv("BIGC_LINEAR_NT") ? atoi(getenv("BIGC_LINEAR_NT")) : 0;
     static const int force_bk = getenv("BIGC_LINEAR_BK") ? atoi(getenv("BIGC_LINEAR_BK")) : 0;
-    static const bool exact_only = getenv("BIGC_LINEAR_EXACT") && atoi(getenv("BIGC_LINEAR_EXACT")) != 0;
+    const bool exact_only = g_exact_mode.load() != 0;
     p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr;
     if (!exact_only) return bigc_linear_split_launch(s, p, flops, bytes);   // f16 MFMAs on split operands, in-kernel range fallback
     ProfScope ps(stream, FAM_LINEAR, flops, bytes);

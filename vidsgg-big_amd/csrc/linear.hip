@@ -208,7 +208,7 @@ extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int3
     static const int force_nt = getenv("BIGC_LINEAR_NT") ? atoi(getenv("BIGC_LINEAR_NT")) : 0;
     static const int force_bk = getenv("BIGC_LINEAR_BK") ? atoi(getenv("BIGC_LINEAR_BK")) : 0;
     const bool exact_only = g_exact_mode.load() != 0;
-    p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr;
+    p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr; p.zero_row = nullptr;
     if (!exact_only) return bigc_linear_split_launch(s, p, flops, bytes);   // f16 MFMAs on split operands, in-kernel range fallback
     ProfScope ps(stream, FAM_LINEAR, flops, bytes);
     // measured on MI355X (benchmarks/linear_shapes.py): NT=2 119 TFLOP/s aggregate, NT=4 112 -> NT=2 by default

@@ -9,6 +9,7 @@ struct LinearArgs {
     const float* W; int ldw; const float* bias; const float* res; int ldr;
     float* C; int ldc; int M, N, K; int act; int tiles_m, tiles_n;
     const u32x4* Ws; int ldws;            // split kernel: W as [N][ldws] groups of 4 k: {4 x f16 head, 4 x f16 scaled residual}
+    const float* zero_row;                // split kernel, gather mode: seg_len zeros standing for the row index -1
     const int* wbad; int wbad_id;         // split kernel: *wbad == wbad_id when the split W holds an out-of-range element
 };
 

@@ -88,7 +88,6 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
     // with the MFMAs): rows past M / N are clamped to the last valid row -- their products land in accumulator rows /
     // columns that are never stored -- and only a ragged last slab (KTAIL) or a gather index of -1 (a zero row) select 0.
     const float* arow[4];
-    bool azero[4] = {false, false, false, false};
     const u32x4* wrow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -116,8 +115,7 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int src = p.a_idx[(size_t)min(m0 + lr + 32 * i, p.M - 1) * p.nseg + seg];
-                    azero[i] = src < 0;
-                    arow[i] = p.A + (size_t)max(src, 0) * p.lda;
+                    arow[i] = src >= 0 ? p.A + (size_t)src * p.lda : p.zero_row;      // index -1: a row of zeros, no select needed
                 }
             }
         }
@@ -128,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             ra[i] = *(const f32x4*)(arow[i] + acol);
-            if ((KTAIL && !kval) || (GATHER && azero[i])) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (KTAIL && !kval) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto load_w = [&](int kt) {
@@ -359,6 +357,19 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
             e->epoch = epoch;
         }
         p.Ws = (const u32x4*)(e->mem + 256); p.ldws = K4; p.wbad = (const int*)e->mem; p.wbad_id = e->bad_id;
+    }
+    if (p.a_idx) {
+        static float* zero_row = nullptr;
+        static int zero_cap = 0;
+        if (p.seg_len > zero_cap) {
+            if (zero_row) { if (hipStreamSynchronize(s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_split: sync failed"); (void)hipFree(zero_row); }
+            zero_cap = p.seg_len < 4096 ? 4096 : p.seg_len;
+            if (hipMalloc((void**)&zero_row, sizeof(float) * zero_cap) != hipSuccess || hipMemsetAsync(zero_row, 0, sizeof(float) * zero_cap, s) != hipSuccess) {
+                zero_row = nullptr; zero_cap = 0;
+                return bigc_fail(BIGC_ERR_HIP, "linear_split: cannot allocate the zero row");
+            }
+        }
+        p.zero_row = zero_row;
     }
     p.tiles_n = cdiv(p.N, BN);
     const int grid = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;

@@ -1,0 +1,13 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_stage
+rm -rf $O; mkdir -p $O
+cd $R
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stage -- python3 benchmarks/stage_bench.py --workload grounding > $O/stdout.log 2>&1
+python3 - <<'PY'
+import csv,os
+p=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/prof_stage/stats/stage_kernel_stats.csv"
+rows=list(csv.DictReader(open(p)))
+for r in rows[:22]:
+    print("%-100s %6s %10.3f ms %9.1f us %5s%%" % (r['Name'][:100], r['Calls'], float(r['TotalDurationNs'])/1e6, float(r['AverageNs'])/1e3, r['Percentage']))
+PY

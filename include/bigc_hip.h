@@ -386,6 +386,26 @@ int grd_loss_grad(void* stream, const float* regrs, const float* conf, const flo
 int grd_train_backward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, int n,
                        void* workspace, size_t workspace_bytes, const float* dregr, const float* dconf, const float* dcls);
 
+/* ---- dropout of the training paths --------------------------------------------------------------------------------------
+ * The reference trains with nn.Dropout / attention dropout p = 0.1 in its transformer layers (models/model_0v10.py:75-84,
+ * 109-114,151,164-169).  Masks here are counter-based: element idx of site `site` is kept iff hash(seed, site, idx) >=
+ * p * 2^32 (common.h: drop_keep), kept values scaled by 1/(1-p); forward and backward regenerate the same mask.
+ * torch's Philox stream cannot be reproduced, so parity with the reference is defined with dropout off.
+ *   bigc_set_dropout      p and per-step seed used by bigc_train_forward / bigc_train_backward (0 = off)
+ *   bigc_dropout_f32      in place on the logical (rows, n) matrix x with leading dimension ld, idx = r * n + c
+ *   bigc_mha_core_drop_f32 / bigc_mha_bwd_drop_f32   attention core with dropout on the probabilities,
+ *                         idx = ((global query row * n_head + head) << 12) + key index inside the sequence */
+int bigc_set_dropout(bigc_model* m, float p, uint32_t seed);
+int bigc_dropout_f32(void* stream, float* x, long rows, int n, int ld, float p, uint32_t seed, uint32_t site);
+int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                           float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
+                           int n_head, int hd, float* lse, float drop_p, uint32_t drop_seed, uint32_t drop_site);
+int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                          const float* o, int ldo, const float* dO, int lddo, const float* lse, float* delta_scratch,
+                          float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                          const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
+                          int n_head, int hd, float drop_p, uint32_t drop_seed, uint32_t drop_site);
+
 /* ---- Base_C, the explicit pairwise baseline (models/model_pairwise_baseline.py:174-273), eval forward ------------------------
  * A model created with variant = 2 holds the front-end parameters plus fc_pred2logits.{0,2} and bias_matrix (same keys as
  * the reference's state_dict).  bigc_pair_forward runs the front-end and scores EVERY ordered tracklet pair (s, o), s != o:

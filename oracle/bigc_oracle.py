@@ -90,7 +90,7 @@ def layer_norm(x, sd, prefix):
     return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
 
 
-def mha(xq, xk, xv, sd, prefix, nhead):
+def mha(xq, xk, xv, sd, prefix, nhead, drop=None, site=0, row0=0):
     """``nn.MultiheadAttention`` forward for one unbatched sequence, eval mode.
 
     xq (Lq,d), xk/xv (Lk,d); packed in_proj [q;k;v], scale 1/sqrt(head_dim), softmax
@@ -103,22 +103,34 @@ def mha(xq, xk, xv, sd, prefix, nhead):
     k = F.linear(xk, w[d:2 * d], b[d:2 * d]).reshape(-1, nhead, hd).transpose(0, 1)
     v = F.linear(xv, w[2 * d:], b[2 * d:]).reshape(-1, nhead, hd).transpose(0, 1)
     att = torch.softmax(torch.matmul(q, k.transpose(1, 2)) / math.sqrt(hd), dim=-1)
+    if drop is not None:                                   # nn.MultiheadAttention(dropout=0.1) in training mode
+        att = drop.att(site, att, row0)
     o = torch.matmul(att, v).transpose(0, 1).reshape(-1, d)
     return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
 
 
-def encoder_layer(x, sd, p, nhead):
+def encoder_layer(x, sd, p, nhead, drop=None, layer=0, row0=0):
     """Post-norm transformer encoder layer over the N tracklets of one video
-    (models/model_0v10.py:103-117)."""
-    x = layer_norm(x + mha(x, x, x, sd, p + ".self_attn", nhead), sd, p + ".norm1")
-    y = linear(linear(x, sd, p + ".linear1", relu=True), sd, p + ".linear2")
+    (models/model_0v10.py:103-117).  ``drop`` (oracle.dropout_ref.Dropper) applies the training-mode dropouts of :109-114
+    at sites 16*layer + {0 attention, 1 dropout1, 2 ffn, 3 dropout2}; ``row0`` = global index of the video's first tracklet."""
+    a = mha(x, x, x, sd, p + ".self_attn", nhead, drop, 16 * layer, row0)
+    if drop is not None:
+        a = drop.rows(16 * layer + 1, a, row0)
+    x = layer_norm(x + a, sd, p + ".norm1")
+    h = linear(x, sd, p + ".linear1", relu=True)
+    if drop is not None:
+        h = drop.rows(16 * layer + 2, h, row0)
+    y = linear(h, sd, p + ".linear2")
+    if drop is not None:
+        y = drop.rows(16 * layer + 3, y, row0)
     return layer_norm(x + y, sd, p + ".norm2")
 
 
-def decoder_layer(query, pos, enco, sd, p, nhead, dim_enti, dim_att):
-    """Role-aware decoder layer (models/model_0v10.py:178-225). Returns (query, att (2,Q,N))."""
+def decoder_layer(query, pos, enco, sd, p, nhead, dim_enti, dim_att, drop=None, layer=0, row0=0, att_row0=0):
+    """Role-aware decoder layer (models/model_0v10.py:178-225). Returns (query, att (2,Q,N)).  ``drop``: training-mode dropouts at
+    sites 4096 + 16*layer + {0 self-attention probabilities (query rows from ``att_row0``), 1 fc2's Dropout (rows from ``row0``)}."""
     qk = query + pos
-    query = layer_norm(query + mha(qk, qk, query, sd, p + ".self_attn", nhead), sd, p + ".norm1")
+    query = layer_norm(query + mha(qk, qk, query, sd, p + ".self_attn", nhead, drop, 4096 + 16 * layer, att_row0), sd, p + ".norm1")
     query = query + pos                                   # persistent (:189)
     e2a = linear(enco, sd, p + ".fc_enti2att")
     p2a = linear(query, sd, p + ".fc_pred2att")
@@ -134,7 +146,10 @@ def decoder_layer(query, pos, enco, sd, p, nhead, dim_enti, dim_att):
         fr = p + ".fc_rolewise.%d" % r
         role = role + linear(linear(vals, sd, fr + ".0", relu=True), sd, fr + ".2")
     query = layer_norm(query + role, sd, p + ".norm2")
-    y = linear(linear(query, sd, p + ".fc2.0", relu=True), sd, p + ".fc2.3")
+    h = linear(query, sd, p + ".fc2.0", relu=True)
+    if drop is not None:
+        h = drop.rows(4096 + 16 * layer + 1, h, row0)
+    y = linear(h, sd, p + ".fc2.3")
     query = layer_norm(query + y, sd, p + ".norm3")
     return query, att
 
@@ -143,7 +158,7 @@ def decoder_layer(query, pos, enco, sd, p, nhead, dim_enti, dim_att):
 # a3..a7: encode2decode
 # --------------------------------------------------------------------------------------
 
-def encode2decode(sd, cfg, proposal, variant="vidvrd", keep=False):
+def encode2decode(sd, cfg, proposal, variant="vidvrd", keep=False, drop=None, trk0=0, vid=0):
     """models/model_0v10.py:434-475 / models/model_0v7.py:434-481. Returns dict with at
     least ``pred_logits`` (Q,P) and ``att`` (2,Q,N); with ``keep`` every intermediate."""
     out = {}
@@ -162,13 +177,17 @@ def encode2decode(sd, cfg, proposal, variant="vidvrd", keep=False):
     x = enti2enco
     enc_states = []
     for i in range(cfg["n_enco_layers"]):
-        x = encoder_layer(x, sd, "encoder_layers.%d" % i, nhead)
+        x = encoder_layer(x, sd, "encoder_layers.%d" % i, nhead, drop, i, trk0)
         enc_states.append(x)
     enco = x
     query, pos = sd["pred_query_init"], sd["pos_embedding"]
     dec_states, att = [], None
     for i in range(cfg["n_deco_layers"]):
-        query, att = decoder_layer(query, pos, enco, sd, "decoder_layers.%d" % i, nhead, de, cfg["dim_att"])
+        # the HIP path evaluates the first layer's self-attention block once for the whole batch (rows 0..Q-1): its attention
+        # masks are shared by the videos; later layers index the batch's query rows vid*Q + q
+        nq = query.shape[0]
+        query, att = decoder_layer(query, pos, enco, sd, "decoder_layers.%d" % i, nhead, de, cfg["dim_att"], drop, i, vid * nq,
+                                   0 if i == 0 else vid * nq)
         dec_states.append((query, att))
 
     # prediction head (models/model_0v10.py:478-507, models/model_0v7.py:483-513)

@@ -233,7 +233,7 @@ def build_train_model(cfg, variant, sd):
         cfg["EntiNameEmb_path"] = os.path.join(d, "emb.npy")
     model = (BIG_C_vidvrd if variant == "vidvrd" else BIG_C_vidor)(cfg, is_train=True)
     model.load_state_dict(sd, strict=True)
-    return model.to(DEV)
+    return model.to(DEV).eval()        # parity with the reference is defined with dropout off (is_train selects the training PATH)
 
 
 @pytest.mark.parametrize("name", list(cases.TRAIN_CASES))

@@ -117,6 +117,13 @@ _SIGS = {
                                c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
                                c_void_p, c_void_p, c_int, c_void_p]),
     "bigc_set_grad": (c_int, [c_void_p, c_char_p, c_void_p]),
+    "bigc_set_dropout": (c_int, [c_void_p, c_float, ctypes.c_uint32]),
+    "bigc_dropout_f32": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32]),
+    "bigc_mha_core_drop_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                       c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, ctypes.c_uint32, ctypes.c_uint32]),
+    "bigc_mha_bwd_drop_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                      c_int, c_int, c_int, ctypes.c_long, c_int, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32]),
     "bigc_train_workspace_bytes": (c_size_t, [c_void_p, POINTER(bigc_batch)]),
     "bigc_train_forward": (c_int, [c_void_p, c_void_p, POINTER(bigc_batch), c_void_p, c_size_t, c_void_p, c_void_p]),
     "bigc_train_backward": (c_int, [c_void_p, c_void_p, POINTER(bigc_batch), c_void_p, c_size_t, c_void_p, c_int, c_void_p]),

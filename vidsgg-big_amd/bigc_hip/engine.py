@@ -62,6 +62,10 @@ class BigcEngine(object):
         self._sig = sig
         self._keep = [t for _, t in items]
 
+    def set_dropout(self, p, seed):
+        """Training-mode dropout of the transformer layers (0 = off); masks are a pure function of (seed, site, index)."""
+        _lib.check(self.lib.bigc_set_dropout(self.handle, float(p), int(seed)))
+
     def forward(self, packed, topk, with_triplets=True, keep_intermediates=False):
         """Run a1..a8 on a PackedBatch. Returns a dict of device tensors (padded triplet arrays +
         ``n_out`` counts); nothing here synchronises with the host."""

@@ -155,8 +155,14 @@ class HipTrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, packed, gt_graph_list, *params):
         engine = model.engine()
+        # dropout follows the module's training flag like the reference's nn.Dropout / nn.MultiheadAttention(dropout=0.1)
+        # (models/model_0v10.py:320,326); the per-step seed comes from the global torch RNG
+        drop_p = float(getattr(model, "dropout_p", 0.1)) if model.training else 0.0
+        drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0
+        engine.set_dropout(drop_p, drop_seed)
         with torch.no_grad():
             terms, tctx = forward(model, engine, packed, gt_graph_list)
+        tctx.dropout = (drop_p, drop_seed)
         ctx.model, ctx.engine, ctx.tctx = model, engine, tctx
         model.last_match_indices = tctx.indices
         return terms
@@ -165,6 +171,7 @@ class HipTrainStep(torch.autograd.Function):
     def backward(ctx, grad_terms):
         model = ctx.model
         named = list(model.named_parameters())
+        ctx.engine.set_dropout(*ctx.tctx.dropout)          # the masks of THIS step's forward
         with torch.no_grad():
             grads = backward(model, ctx.engine, ctx.tctx, grad_terms, named)
         return (None, None, None) + tuple(grads)

@@ -34,7 +34,8 @@ template <int HD>
 __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                        const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
                                                        const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
-                                                       int n_seq, int n_qt, int n_head, float scale, float* __restrict__ lse) {
+                                                       int n_seq, int n_qt, int n_head, float scale, float* __restrict__ lse,
+                                                       const DropSpec drop) {
     constexpr int HALF = HD / 2;
     constexpr int NTD = (HD + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
         for (int r = 0; r < 16; ++r) {
             const int key = kt * 32 + mfma_row(r, hi);
             const bool ok = key < nk;
-            const float p = ok ? expf(sc[r] - m) * inv : 0.f;
+            float p = ok ? expf(sc[r] - m) * inv : 0.f;
+            if (drop.thresh) p = drop_keep(drop, drop_att_idx(q0 + qrow, n_head, h, key)) ? p * drop.scale : 0.f;
             const float* vp = v + (size_t)(k0 + min(key, nk - 1)) * ldv + h * HD;
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
@@ -145,7 +147,8 @@ template <int HD, int NKT>
 __global__ __launch_bounds__(256) void mha_core_sp_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                           const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
                                                           const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
-                                                          int n_seq, int n_qt, int n_head, float scale, float* __restrict__ lse) {
+                                                          int n_seq, int n_qt, int n_head, float scale, float* __restrict__ lse,
+                                                          const DropSpec drop) {
     constexpr int HALF = HD / 2;
     constexpr int NTD = (HD + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -241,7 +244,8 @@ __global__ __launch_bounds__(256) void mha_core_sp_kernel(const float* __restric
     auto pv_tile = [&](int kt, const vrow_t (&vv)[16]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = sc[kt][r] * inv;
+            float p = sc[kt][r] * inv;
+            if (drop.thresh) p = drop_keep(drop, drop_att_idx(q0 + qrow, n_head, h, kt * 32 + mfma_row(r, hi))) ? p * drop.scale : 0.f;
 #pragma unroll
             for (int t = 0; t < NTD; ++t) out[t] = mfma32(p, vv[r][t], out[t]);
         }
@@ -539,9 +543,20 @@ __global__ __launch_bounds__(256) void role_fused_kernel(const float* __restrict
 
 }  // namespace
 
+extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                      float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
+                                      int n_head, int hd, float* lse, float drop_p, uint32_t drop_seed, uint32_t drop_site);
+
 extern "C" int bigc_mha_core_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                  float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
                                  int n_head, int hd, float* lse) {
+    return bigc_mha_core_drop_f32(stream, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, max_q, n_head, hd, lse, 0.f, 0, 0);
+}
+
+extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                      float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
+                                      int n_head, int hd, float* lse, float drop_p, uint32_t drop_seed, uint32_t drop_site) {
+    const DropSpec drop = make_drop(drop_p, drop_seed, drop_site);
     BIGC_CHECK_ARG(q && k && v && o && q_off && k_off, "mha_core: null pointer");
     BIGC_CHECK_ARG(hd == 8 || hd == 16 || hd == 32 || hd == 64, "mha_core: head_dim %d not in {8,16,32,64}", hd);
     BIGC_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0, "mha_core: ldq/ldk must be multiples of 4");
@@ -552,8 +567,8 @@ extern "C" int bigc_mha_core_f32(void* stream, const float* q, int ldq, const fl
     const float scale = 1.0f / sqrtf((float)hd);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(stream, FAM_MHA, 0.0, 0.0);
-#define LAUNCH_MHA(HD) hipLaunchKernelGGL(mha_core_kernel<HD>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse)
-#define LAUNCH_SP(HD, NKT) hipLaunchKernelGGL((mha_core_sp_kernel<HD, NKT>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse)
+#define LAUNCH_MHA(HD) hipLaunchKernelGGL(mha_core_kernel<HD>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop)
+#define LAUNCH_SP(HD, NKT) hipLaunchKernelGGL((mha_core_sp_kernel<HD, NKT>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop)
     // self-attention (same offsets for queries and keys): the longest key sequence is max_q, known on the host ->
     // single-pass kernel with the scores in registers when it fits
     const int nkt = (q_off == k_off) ? n_qt : 1 << 30;

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
                                                          const float* __restrict__ v, int ldv, const float* __restrict__ dO, int lddo,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          float* __restrict__ dq, int lddq, const int32_t* __restrict__ q_off,
-                                                         const int32_t* __restrict__ k_off, int n_seq, int n_qt, int n_head, float scale) {
+                                                         const int32_t* __restrict__ k_off, int n_seq, int n_qt, int n_head, float scale,
+                                                         const DropSpec drop) {
     constexpr int HALF = HD / 2;
     constexpr int NTD = (HD + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,7 +80,9 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
             const int key = kt * 32 + mfma_row(r, hi);
             const bool ok = key < nk && qok;
             const float p = ok ? expf(sc[r] - my_lse) : 0.f;
-            const float ds = p * (dp[r] - my_delta);
+            float dpr = dp[r];                                   // d of the (dropped) probability
+            if (drop.thresh) dpr = drop_keep(drop, drop_att_idx(q0 + qrow, n_head, h, key)) ? dpr * drop.scale : 0.f;
+            const float ds = p * (dpr - my_delta);
             const float* kr = k + (size_t)(k0 + min(key, nk - 1)) * ldk + h * HD;
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restric
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv,
                                                           const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
-                                                          int n_seq, int n_kt, int n_head, float scale) {
+                                                          int n_seq, int n_kt, int n_head, float scale, const DropSpec drop) {
     constexpr int HALF = HD / 2;
     constexpr int NTD = (HD + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -149,13 +152,19 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restric
             const bool ok = qi < nq && kok;
             const float lr = lse[(size_t)(q0 + qc) * n_head + h], dr = delta[(size_t)(q0 + qc) * n_head + h];
             const float p = ok ? expf(sc[r] - lr) : 0.f;
-            const float ds = p * (dp[r] - dr);
+            float pd = p, dpr = dp[r];                           // dropped probability (for dV) and d of it (for dS)
+            if (drop.thresh) {
+                const bool keep = drop_keep(drop, drop_att_idx(q0 + qc, n_head, h, kt * 32 + l31));
+                pd = keep ? p * drop.scale : 0.f;
+                dpr = keep ? dpr * drop.scale : 0.f;
+            }
+            const float ds = p * (dpr - dr);
             const float* gor = dO + (size_t)(q0 + qc) * lddo + h * HD;
             const float* qr = q + (size_t)(q0 + qc) * ldq + h * HD;
 #pragma unroll
             for (int t = 0; t < NTD; ++t) {
                 const int d = t * 32 + l31;
-                av[t] = mfma32(p, gor[d < HD ? d : HD - 1], av[t]);
+                av[t] = mfma32(pd, gor[d < HD ? d : HD - 1], av[t]);
                 ak[t] = mfma32(ds, qr[d < HD ? d : HD - 1], ak[t]);
             }
         }
@@ -384,11 +393,27 @@ int grid_for(long n, int cap = 4096) { long g = (n + 255) / 256; return (int)(g 
 
 }  // namespace
 
+extern "C" int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                     const float* o, int ldo, const float* dO, int lddo, const float* lse, float* delta_scratch,
+                                     float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                                     const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
+                                     int n_head, int hd, float drop_p, uint32_t drop_seed, uint32_t drop_site);
+
 extern "C" int bigc_mha_bwd_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                 const float* o, int ldo, const float* dO, int lddo, const float* lse, float* delta_scratch,
                                 float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                                 const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
                                 int n_head, int hd) {
+    return bigc_mha_bwd_drop_f32(stream, q, ldq, k, ldk, v, ldv, o, ldo, dO, lddo, lse, delta_scratch, dq, lddq, dk, lddk, dv, lddv, q_off, k_off,
+                                 n_seq, max_q, max_k, total_q_rows, n_head, hd, 0.f, 0, 0);
+}
+
+extern "C" int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                     const float* o, int ldo, const float* dO, int lddo, const float* lse, float* delta_scratch,
+                                     float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                                     const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
+                                     int n_head, int hd, float drop_p, uint32_t drop_seed, uint32_t drop_site) {
+    const DropSpec drop = make_drop(drop_p, drop_seed, drop_site);
     BIGC_CHECK_ARG(q && k && v && o && dO && lse && delta_scratch && dq && dk && dv && q_off && k_off, "mha_bwd: null pointer");
     BIGC_CHECK_ARG(hd == 8 || hd == 16 || hd == 32 || hd == 64, "mha_bwd: head_dim %d", hd);
     if (n_seq <= 0 || max_q <= 0 || max_k <= 0) return BIGC_OK;
@@ -400,8 +425,8 @@ extern "C" int bigc_mha_bwd_f32(void* stream, const float* q, int ldq, const flo
     const int n_qt = cdiv(max_q, 32), n_kt = cdiv(max_k, 32);
     const int gq = (int)(((long)n_seq * n_qt * n_head + 3) / 4), gk = (int)(((long)n_seq * n_kt * n_head + 3) / 4);
 #define LAUNCH_BWD(HD) \
-    hipLaunchKernelGGL(mha_bwd_dq_kernel<HD>, dim3(gq), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dq, lddq, q_off, k_off, n_seq, n_qt, n_head, scale); \
-    hipLaunchKernelGGL(mha_bwd_dkv_kernel<HD>, dim3(gk), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dk, lddk, dv, lddv, q_off, k_off, n_seq, n_kt, n_head, scale)
+    hipLaunchKernelGGL(mha_bwd_dq_kernel<HD>, dim3(gq), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dq, lddq, q_off, k_off, n_seq, n_qt, n_head, scale, drop); \
+    hipLaunchKernelGGL(mha_bwd_dkv_kernel<HD>, dim3(gk), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dk, lddk, dv, lddv, q_off, k_off, n_seq, n_kt, n_head, scale, drop)
     switch (hd) {
         case 8: LAUNCH_BWD(8); break;
         case 16: LAUNCH_BWD(16); break;

@@ -360,6 +360,25 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict_
     }
 }
 
+// in place: x[r, c] = keep(r * n + c) ? x[r, c] / (1 - p) : 0  over the logical (rows, n) matrix with leading dimension ld
+__global__ __launch_bounds__(256) void dropout_kernel(float* __restrict__ x, long rows, int n, int ld, const DropSpec drop) {
+    const long total = rows * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / n;
+        const int c = (int)(i - r * n);
+        float* p = x + r * ld + c;
+        *p = drop_keep(drop, (unsigned long long)i) ? *p * drop.scale : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n4, float a) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 v = ((f32x4*)x)[i];
+        v[0] *= a; v[1] *= a; v[2] *= a; v[3] *= a;
+        ((f32x4*)x)[i] = v;
+    }
+}
+
 int grid_for(long n, int cap = 4096) { long g = (n + 255) / 256; return (int)(g < cap ? (g < 1 ? 1 : g) : cap); }
 
 }  // namespace
@@ -395,6 +414,21 @@ extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const 
         hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
         BIGC_LAUNCH_CHECK("linear_dw");
     }
+    return BIGC_OK;
+}
+
+extern "C" int bigc_dropout_f32(void* stream, float* x, long rows, int n, int ld, float p, uint32_t seed, uint32_t site) {
+    BIGC_CHECK_ARG(x && n > 0 && ld >= n && p >= 0.f && p < 1.f, "dropout: bad argument");
+    if (rows <= 0 || !(p > 0.f)) return BIGC_OK;
+    ProfScope ps(stream, FAM_BACKWARD, 0.0, 8.0 * rows * (double)n);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * n)), dim3(256), 0, (hipStream_t)stream, x, rows, n, ld, make_drop(p, seed, site));
+    BIGC_LAUNCH_CHECK("dropout");
+    return BIGC_OK;
+}
+
+int bigc_scale_f32(hipStream_t s, float* x, long n, float a) {
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, n / 4, a);
+    BIGC_LAUNCH_CHECK("scale");
     return BIGC_OK;
 }
 

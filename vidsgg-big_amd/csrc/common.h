@@ -22,3 +22,30 @@ int bigc_fail(int code, const char* fmt, ...);
     if (e_ != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e_)); } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- dropout (training paths) ---------------------------------------------------------------------------------------------
+// Counter-based masks: element `idx` of dropout site `site` is kept iff hash(seed, site, idx) >= p * 2^32; kept values are
+// scaled by 1 / (1 - p).  The forward and the backward regenerate the same mask, nothing is stored.
+// (torch's Philox stream cannot be reproduced outside torch; parity with the reference is defined with dropout off,
+// tests/test_hip_dropout.py checks this generator against an identical numpy implementation.)
+struct DropSpec { uint32_t thresh; float scale; uint32_t seed; uint32_t site; };
+
+static inline DropSpec make_drop(float p, uint32_t seed, uint32_t site) {
+    DropSpec d;
+    if (!(p > 0.f)) { d.thresh = 0; d.scale = 1.f; d.seed = 0; d.site = 0; return d; }
+    double t = (double)p * 4294967296.0;
+    d.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    d.scale = 1.0f / (1.0f - p);
+    d.seed = seed; d.site = site;
+    return d;
+}
+
+__device__ __forceinline__ bool drop_keep(const DropSpec& d, unsigned long long idx) {
+    uint32_t x = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u ^ d.seed * 0xC2B2AE3Du ^ d.site * 0x27D4EB2Fu;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x >= d.thresh;
+}
+// index of an attention probability: (global query row, head, key index inside the sequence)
+__device__ __forceinline__ unsigned long long drop_att_idx(int q_row, int n_head, int h, int key) {
+    return (((unsigned long long)q_row * (unsigned)n_head + (unsigned)h) << 12) + (unsigned)key;
+}

@@ -16,6 +16,7 @@ struct bigc_model {
     std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
     std::unordered_map<std::string, float*> grads;      // gradient destination of each trainable parameter (training)
     bool finalized = false;
+    float drop_p = 0.f; unsigned int drop_seed = 0;   // training-mode dropout (bigc_set_dropout); 0 = off
     unsigned long long epoch = 0;          // drawn at finalize: scope of the cached split weights (linear_internal.h)
     // resolved
     const float *emb = nullptr, *pos = nullptr, *qinit = nullptr, *bias_matrix = nullptr;

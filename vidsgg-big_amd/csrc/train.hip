@@ -41,6 +41,21 @@ extern "C" int bigc_role_small_gemm_f32(void* stream, int mode, const float* att
                                         const float* enco_or_e2a, int ld2, float* out, int ldo, const int32_t* e_off, int n_vid, int nq,
                                         int d, int half, int max_trk);
 
+extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                      float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
+                                      int n_head, int hd, float* lse, float drop_p, uint32_t drop_seed, uint32_t drop_site);
+extern "C" int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                     const float* o, int ldo, const float* dO, int lddo, const float* lse, float* delta_scratch,
+                                     float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                                     const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
+                                     int n_head, int hd, float drop_p, uint32_t drop_seed, uint32_t drop_site);
+extern "C" int bigc_dropout_f32(void* stream, float* x, long rows, int n, int ld, float p, uint32_t seed, uint32_t site);
+int bigc_scale_f32(hipStream_t s, float* x, long n, float a);
+
+// dropout sites of the reference's transformer layers (models/model_0v10.py:75-84,109-114 encoder; :151,164-169 decoder)
+static inline uint32_t enc_site(int layer, int which) { return 16u * layer + which; }          // 0 attention, 1 dropout1, 2 ffn, 3 dropout2
+static inline uint32_t dec_site(int layer, int which) { return 4096u + 16u * layer + which; }  // 0 attention, 1 fc2 dropout
+
 namespace {
 
 struct EncS { float *qkv, *lse, *ao, *t1, *x1, *fh, *t1b, *out; };
@@ -164,6 +179,12 @@ struct Bwd {
 
 }  // namespace
 
+extern "C" int bigc_set_dropout(bigc_model* m, float p, uint32_t seed) {
+    BIGC_CHECK_ARG(m && p >= 0.f && p < 1.f, "set_dropout: p must be in [0, 1)");
+    m->drop_p = p; m->drop_seed = seed;
+    return BIGC_OK;
+}
+
 extern "C" int bigc_set_grad(bigc_model* m, const char* key, float* ptr) {
     BIGC_CHECK_ARG(m && key, "set_grad: bad argument");
     if (ptr) m->grads[key] = ptr; else m->grads.erase(key);
@@ -201,6 +222,7 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
     const int R = b->n_rows, NT = b->n_trk, C = b->n_conv, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
     const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn, D = c.dim_feat + c.dim_extra, H = c.n_att_head, hd = de / H;
     const float eps = 1e-5f;
+    const float dp_ = m->drop_p; const uint32_t ds_ = m->drop_seed;      // training-mode dropout (0 = off)
 
     TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
     TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
@@ -219,12 +241,25 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
         const EncLayer& L = m->enc[i];
         EncS& S = w.enc[i];
         TRY(linear(s, x, de, L.in_proj, S.qkv, 3 * de, NT, 3 * de, de, BIGC_ACT_NONE));
-        TRY(bigc_mha_core_f32(s, S.qkv, 3 * de, S.qkv + de, 3 * de, S.qkv + 2 * de, 3 * de, S.ao, de, b->vid_trk_off, b->vid_trk_off, B,
-                              b->max_trk, H, hd, S.lse));
-        TRY(linear(s, S.ao, de, L.out_proj, S.t1, de, NT, de, de, BIGC_ACT_NONE, x, de));
+        TRY(bigc_mha_core_drop_f32(s, S.qkv, 3 * de, S.qkv + de, 3 * de, S.qkv + 2 * de, 3 * de, S.ao, de, b->vid_trk_off, b->vid_trk_off, B,
+                                   b->max_trk, H, hd, S.lse, dp_, ds_, enc_site(i, 0)));
+        if (dp_ > 0.f) {            // src + dropout1(out_proj(attn)) (:111)
+            TRY(linear(s, S.ao, de, L.out_proj, S.t1, de, NT, de, de, BIGC_ACT_NONE));
+            TRY(bigc_dropout_f32(s, S.t1, NT, de, de, dp_, ds_, enc_site(i, 1)));
+            TRY(bigc_axpy_f32(s, S.t1, x, (long)NT * de));
+        } else {
+            TRY(linear(s, S.ao, de, L.out_proj, S.t1, de, NT, de, de, BIGC_ACT_NONE, x, de));
+        }
         TRY(bigc_layernorm_f32(s, S.t1, L.n1.g, L.n1.b, S.x1, NT, de, eps));
         TRY(linear(s, S.x1, de, L.l1, S.fh, df, NT, df, de, BIGC_ACT_RELU));
-        TRY(linear(s, S.fh, df, L.l2, S.t1b, de, NT, de, df, BIGC_ACT_NONE, S.x1, de));
+        if (dp_ > 0.f) {            // linear2(dropout(relu(linear1))) then src + dropout2(.) (:113-114)
+            TRY(bigc_dropout_f32(s, S.fh, NT, df, df, dp_, ds_, enc_site(i, 2)));
+            TRY(linear(s, S.fh, df, L.l2, S.t1b, de, NT, de, df, BIGC_ACT_NONE));
+            TRY(bigc_dropout_f32(s, S.t1b, NT, de, de, dp_, ds_, enc_site(i, 3)));
+            TRY(bigc_axpy_f32(s, S.t1b, S.x1, (long)NT * de));
+        } else {
+            TRY(linear(s, S.fh, df, L.l2, S.t1b, de, NT, de, df, BIGC_ACT_NONE, S.x1, de));
+        }
         TRY(bigc_layernorm_f32(s, S.t1b, L.n2.g, L.n2.b, S.out, NT, de, eps));
         x = S.out;
     }
@@ -243,7 +278,8 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
         TRY(bigc_add_rows_f32(s, qin, m->pos, S.qk_in, rows, dp, Q));
         TRY(linear(s, S.qk_in, dp, qkp, S.qk, 2 * dp, rows, 2 * dp, dp, BIGC_ACT_NONE));
         TRY(linear(s, qin, dp, vp, S.vv, dp, rows, dp, dp, BIGC_ACT_NONE));
-        TRY(bigc_mha_core_f32(s, S.qk, 2 * dp, S.qk + dp, 2 * dp, S.vv, dp, S.ao2, dp, w.q_off, w.q_off, nseq, Q, H, dp / H, S.lse));
+        TRY(bigc_mha_core_drop_f32(s, S.qk, 2 * dp, S.qk + dp, 2 * dp, S.vv, dp, S.ao2, dp, w.q_off, w.q_off, nseq, Q, H, dp / H, S.lse, dp_, ds_,
+                                   dec_site(i, 0)));
         TRY(linear(s, S.ao2, dp, L.out_proj, S.t2, dp, rows, dp, dp, BIGC_ACT_NONE, qin, dp));
         TRY(bigc_layernorm_f32(s, S.t2, L.n1.g, L.n1.b, w.t3tmp, rows, dp, eps));
         if (i == 0) {
@@ -262,6 +298,7 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
         TRY(linear(s, S.rh1, dp, L.role1[1], S.t3b, dp, BQ, dp, dp, BIGC_ACT_NONE, w.rtmp, dp));
         TRY(bigc_layernorm_f32(s, S.t3b, L.n2.g, L.n2.b, S.q3, BQ, dp, eps));
         TRY(linear(s, S.q3, dp, L.f0, S.f, df, BQ, df, dp, BIGC_ACT_RELU));
+        if (dp_ > 0.f) TRY(bigc_dropout_f32(s, S.f, BQ, df, df, dp_, ds_, dec_site(i, 1)));            // fc2's Dropout (:167)
         TRY(linear(s, S.f, df, L.f3, S.t3c, dp, BQ, dp, df, BIGC_ACT_NONE, S.q3, dp));
         TRY(bigc_layernorm_f32(s, S.t3c, L.n3.g, L.n3.b, S.qout, BQ, dp, eps));
         qprev = S.qout;
@@ -324,6 +361,7 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
     const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn, D = c.dim_feat + c.dim_extra, H = c.n_att_head, hd = de / H;
     const int P = c.num_pred_cats, HK = m->head_k;
     const float eps = 1e-5f;
+    const float dp_ = m->drop_p; const uint32_t ds_ = m->drop_seed;      // training-mode dropout (0 = off)
     Bwd bw{m, s, &w};
     const float att_scale = 1.0f / sqrtf((float)de);
 
@@ -368,7 +406,8 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
         TRY(bigc_layernorm_bwd_f32(s, S.t3c, L.n3.g, w.gq, w.ga, grad_of(m, p + ".norm3.weight"), grad_of(m, p + ".norm3.bias"), BQ, dp, eps));
         // ga = d t3c ; t3c = f W3^T + b + q3
         TRY(bw.lin(p + ".fc2.3", L.f3, w.ga, dp, S.f, df, BQ, dp, df, w.gb, df, false));       // gb = d f
-        TRY(bigc_relu_bwd_f32(s, w.gb, S.f, (long)BQ * df));
+        TRY(bigc_relu_bwd_f32(s, w.gb, S.f, (long)BQ * df));            // S.f is post-dropout: zero where dropped
+        if (dp_ > 0.f) TRY(bigc_scale_f32(hs, w.gb, (long)BQ * df, 1.0f / (1.0f - dp_)));
         TRY(bw.lin(p + ".fc2.0", L.f0, w.gb, df, S.q3, dp, BQ, df, dp, w.ga, dp, true));       // ga = d q3 (residual + ffn path)
         TRY(bigc_layernorm_bwd_f32(s, S.t3b, L.n2.g, w.ga, w.gb, grad_of(m, p + ".norm2.weight"), grad_of(m, p + ".norm2.bias"), BQ, dp, eps));
         // gb = d t3b = d(rh1 W^T + b1 + rh0 W^T + b0 + q2)
@@ -402,8 +441,8 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
         const float* qin = (i == 0) ? m->qinit : w.dec[i - 1].qout;
         TRY(bw.lin(p + ".self_attn.out_proj", L.out_proj, w.ga, dp, S.ao2, dp, rows, dp, dp, w.gq, dp, false));   // gq = d ao2
         float* gvv = w.gc;                                    // gb / gc are free again once LayerNorm-1 consumed gt3
-        TRY(bigc_mha_bwd_f32(s, S.qk, 2 * dp, S.qk + dp, 2 * dp, S.vv, dp, S.ao2, dp, w.gq, dp, S.lse, w.delta, w.gqk, 2 * dp, w.gqk + dp,
-                             2 * dp, gvv, dp, w.q_off, w.q_off, nseq, Q, Q, rows, H, dp / H));
+        TRY(bigc_mha_bwd_drop_f32(s, S.qk, 2 * dp, S.qk + dp, 2 * dp, S.vv, dp, S.ao2, dp, w.gq, dp, S.lse, w.delta, w.gqk, 2 * dp, w.gqk + dp,
+                                  2 * dp, gvv, dp, w.q_off, w.q_off, nseq, Q, Q, rows, H, dp / H, dp_, ds_, dec_site(i, 0)));
         // in_proj: [q;k] rows from qk_in, v rows from qin
         {
             float* gw = grad_of(m, p + ".self_attn.in_proj_weight");
@@ -433,14 +472,30 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
         const std::string p = "encoder_layers." + std::to_string(i);
         const float* xin = (i == 0) ? w.e2e : w.enc[i - 1].out;
         TRY(bigc_layernorm_bwd_f32(s, S.t1b, L.n2.g, gx, w.gx, grad_of(m, p + ".norm2.weight"), grad_of(m, p + ".norm2.bias"), NT, de, eps));
-        TRY(bw.lin(p + ".linear2", L.l2, w.gx, de, S.fh, df, NT, de, df, w.gy, df, false));          // gy = d fh
+        const float* g_l2 = w.gx;                                    // d of linear2's (pre-dropout) output
+        if (dp_ > 0.f) {
+            hipError_t e2 = hipMemcpyAsync(w.gz, w.gx, sizeof(float) * (size_t)NT * de, hipMemcpyDeviceToDevice, hs);
+            if (e2 != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: memcpy: %s", hipGetErrorString(e2));
+            TRY(bigc_dropout_f32(s, w.gz, NT, de, de, dp_, ds_, enc_site(i, 3)));
+            g_l2 = w.gz;
+        }
+        TRY(bw.lin(p + ".linear2", L.l2, g_l2, de, S.fh, df, NT, de, df, w.gy, df, false));          // gy = d fh
         TRY(bigc_relu_bwd_f32(s, w.gy, S.fh, (long)NT * df));
+        if (dp_ > 0.f) TRY(bigc_scale_f32(hs, w.gy, (long)NT * df, 1.0f / (1.0f - dp_)));
         TRY(bw.lin(p + ".linear1", L.l1, w.gy, df, S.x1, de, NT, df, de, w.gx, de, true));           // gx = d x1
         TRY(bigc_layernorm_bwd_f32(s, S.t1, L.n1.g, w.gx, w.gy, grad_of(m, p + ".norm1.weight"), grad_of(m, p + ".norm1.bias"), NT, de, eps));
         // gy = d t1 = d(ao Wo^T + b + xin)
-        TRY(bw.lin(p + ".self_attn.out_proj", L.out_proj, w.gy, de, S.ao, de, NT, de, de, w.gz, de, false));   // gz = d ao
-        TRY(bigc_mha_bwd_f32(s, S.qkv, 3 * de, S.qkv + de, 3 * de, S.qkv + 2 * de, 3 * de, S.ao, de, w.gz, de, S.lse, w.delta, w.gqkv, 3 * de,
-                             w.gqkv + de, 3 * de, w.gqkv + 2 * de, 3 * de, b->vid_trk_off, b->vid_trk_off, B, b->max_trk, b->max_trk, NT, H, hd));
+        const float* g_op = w.gy;                                    // d of out_proj's (pre-dropout) output
+        if (dp_ > 0.f) {
+            hipError_t e2 = hipMemcpyAsync(w.gx, w.gy, sizeof(float) * (size_t)NT * de, hipMemcpyDeviceToDevice, hs);
+            if (e2 != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: memcpy: %s", hipGetErrorString(e2));
+            TRY(bigc_dropout_f32(s, w.gx, NT, de, de, dp_, ds_, enc_site(i, 1)));
+            g_op = w.gx;
+        }
+        TRY(bw.lin(p + ".self_attn.out_proj", L.out_proj, g_op, de, S.ao, de, NT, de, de, w.gz, de, false));   // gz = d ao
+        TRY(bigc_mha_bwd_drop_f32(s, S.qkv, 3 * de, S.qkv + de, 3 * de, S.qkv + 2 * de, 3 * de, S.ao, de, w.gz, de, S.lse, w.delta, w.gqkv, 3 * de,
+                                  w.gqkv + de, 3 * de, w.gqkv + 2 * de, 3 * de, b->vid_trk_off, b->vid_trk_off, B, b->max_trk, b->max_trk, NT, H, hd,
+                                  dp_, ds_, enc_site(i, 0)));
         {
             float* gw = grad_of(m, p + ".self_attn.in_proj_weight");
             float* gbias = grad_of(m, p + ".self_attn.in_proj_bias");

@@ -129,7 +129,8 @@ class BigcBase(nn.Module):
     def _forward_train(self, proposal_list, gt_graph_list):
         """Training contract of the reference (models/model_0v10.py:510-556): returns
         ``(total_loss, {"cls_pos", "cls_neg", "adj"})``; ``total_loss.backward()`` runs the HIP backward and
-        fills ``.grad`` of every trainable parameter. Dropout is not applied on this path."""
+        fills ``.grad`` of every trainable parameter. In ``.train()`` mode (the default, as in the reference's training scripts) the
+        transformer layers apply dropout p=0.1 with counter-based masks; ``.eval()`` switches it off (parity tests)."""
         from bigc_hip.train_step import HipTrainStep
         assert len(proposal_list) == len(gt_graph_list)
         assert all(p.num_proposals > 0 for p in proposal_list), "videos without proposals are filtered out before training"

@@ -375,6 +375,9 @@ int grd_forward(grd_model* m, void* stream, const float* video_feat, int T, cons
  *                     batch-wide means: positive elements, negative elements, elements with centerness > 0.
  * grd_train_backward  backward pass from those three gradient arrays through the network. */
 int grd_set_grad(grd_model* m, const char* key, float* ptr);
+/* training-mode dropout of the three QANet layers (models/grd_model_v5.py:123-136; base p = 0.1, 0.05 after conv block 1),
+ * counter-based masks as bigc_set_dropout; the host passes a different seed for every video of a batch. 0 = off. */
+int grd_set_dropout(grd_model* m, float p, uint32_t seed);
 size_t grd_train_workspace_bytes(const grd_model* m, int T, int n);
 int grd_train_forward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, const int32_t* dura, int n,
                       float video_len, const float* pos_video, const float* pos_query, void* workspace, size_t workspace_bytes,

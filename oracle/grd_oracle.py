@@ -44,23 +44,42 @@ def _ln_ct(x, sd, p):
     return layer_norm(x.transpose(1, 2), sd, p).transpose(1, 2)
 
 
-def qanet_layer(x, sd, p, num_conv=4, nhead=8):
-    """QANetEncoderLayer.forward in eval mode (dropouts inactive), x (N,d,T)  (:110-137)"""
+def qanet_layer(x, sd, p, num_conv=4, nhead=8, drop=None, base=0, p_base=0.1):
+    """QANetEncoderLayer.forward, x (N,d,T)  (:110-137).  Without ``drop`` the dropouts are inactive (eval mode); with an
+    ``oracle.dropout_ref.Dropper`` they are applied as the HIP path does: sites base + {0,1: after conv blocks 1 and 3 with
+    p = p_base (i+1)/num_conv (:123-125), 2: attention probabilities, 3: after the attention residual (:130), 4: output (:136)},
+    element index = (n T + t) d + c."""
     d, T = x.shape[1], x.shape[2]
+
+    def dropped(t_ndT, site, prob):
+        if drop is None:
+            return t_ndT
+        saved = drop.p
+        drop.p = prob
+        y = drop.rows(site, t_ndT.transpose(1, 2).reshape(-1, d), 0).reshape(-1, T, d).transpose(1, 2)
+        drop.p = saved
+        return y
+
     out = x + pos_table(T, d)[None]
     res = out
     out = _ln_ct(out, sd, p + ".normb")
     for i in range(num_conv):
         out = torch.relu(dwsep(out, sd, p + ".convs.%d" % i)) + res
+        if (i + 1) % 2 == 0:
+            out = dropped(out, base + i // 2, p_base * (i + 1) / num_conv)
         res = out
         out = _ln_ct(out, sd, p + ".norm_seq.%d" % i)
     seq = out.permute(2, 0, 1)                          # (T,N,d): attention over time, batch N
-    att = torch.stack([mha(seq[:, n], seq[:, n], seq[:, n], sd, p + ".mh_attn", nhead) for n in range(seq.shape[1])], 1)
-    out = att.permute(1, 2, 0) + res
+    if drop is not None:
+        saved, drop.p = drop.p, p_base
+    att = torch.stack([mha(seq[:, n], seq[:, n], seq[:, n], sd, p + ".mh_attn", nhead, drop, base + 2, n * T) for n in range(seq.shape[1])], 1)
+    if drop is not None:
+        drop.p = saved
+    out = dropped(att.permute(1, 2, 0) + res, base + 3, p_base)
     res = out
     out = layer_norm(out.transpose(1, 2), sd, p + ".norme")
     out = torch.relu(F.linear(out, sd[p + ".fc.weight"], sd[p + ".fc.bias"])).transpose(1, 2)
-    return out + res
+    return dropped(out + res, base + 4, p_base)
 
 
 def prepare_data(sd, quintuples, dura_inters, video_len):
@@ -78,15 +97,15 @@ def head(x, sd, p, sigmoid=False):
     return torch.sigmoid(x) if sigmoid else x
 
 
-def forward_propagation(sd, video_feature, words_emb, inter_dura, keep=False):
+def forward_propagation(sd, video_feature, words_emb, inter_dura, keep=False, drop=None):
     """(:331-373) -> regrs (n,T,2k), conf_logits (n,T,k), cls_logits (n,T,k)"""
     n = words_emb.shape[0]
     video = F.linear(video_feature, sd["video_fc.weight"], sd["video_fc.bias"]).t()[None]       # (1,d,T)
     words = F.linear(words_emb, sd["query_fc.weight"], sd["query_fc.bias"]).permute(0, 2, 1)     # (n,d,3)
     temporal = F.linear(inter_dura, sd["temp_fc.weight"], sd["temp_fc.bias"])                    # (n,d)
     query = words + temporal[:, :, None]
-    video = qanet_layer(video, sd, "video_encoder")
-    query = qanet_layer(query, sd, "query_encoder")
+    video = qanet_layer(video, sd, "video_encoder", drop=drop, base=0x100)
+    query = qanet_layer(query, sd, "query_encoder", drop=drop, base=0x200)
     vt = video.transpose(1, 2)                                                                    # (1,T,d)
     sim = torch.matmul(F.linear(vt, sd["proj2sim.weight"]).expand(n, -1, -1), query)               # (n,T,3)
     sim_r = torch.softmax(sim, dim=2)
@@ -97,7 +116,7 @@ def forward_propagation(sd, video_feature, words_emb, inter_dura, keep=False):
     mat_b = torch.matmul(sim_rc, v)
     comb = torch.cat([v, mat_a, mat_a * v, mat_b * v], -1)
     comb = F.linear(comb, sd["vq_fc.weight"], sd["vq_fc.bias"]).transpose(1, 2)                   # (n,d,T)
-    enc = qanet_layer(comb, sd, "combined_encoder")
+    enc = qanet_layer(comb, sd, "combined_encoder", drop=drop, base=0x300)
     regrs = head(enc, sd, "regr_head", sigmoid=True).transpose(1, 2)
     conf = head(enc, sd, "conf_head").transpose(1, 2)
     cls = head(enc, sd, "cls_head").transpose(1, 2)

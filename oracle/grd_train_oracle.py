@@ -113,13 +113,13 @@ def loss_terms(mapped, labels, index_maps, loss_factor):
             "neg_ct": neg_ct * f["centerness"], "regr": regr * f["regression"]}
 
 
-def forward_train(sd, cfg, video_feature_list, gt_graph_list):
+def forward_train(sd, cfg, video_feature_list, gt_graph_list, drops=None):
     """(:375-389) -> (total, terms, per-video query descriptions)"""
     k = cfg["num_bins"]
     mapped, labels, maps, queries = [], [], [], []
     for feat, g in zip(video_feature_list, gt_graph_list):
         words, info, target, index_map, tags, spans = prepare_gt_queries(sd, g, True)
-        regrs, conf, cls = G.forward_propagation(sd, feat, words, info)
+        regrs, conf, cls = G.forward_propagation(sd, feat, words, info, drop=None if drops is None else drops[len(mapped)])
         lab = gt_labels(target, regrs.shape[1], k)
         mapped.append(map_to_bins(regrs, conf, cls, lab[-1], index_map, k))
         labels.append(lab)

@@ -22,7 +22,7 @@ def build_model(cfg, sd, is_train=True):
     cfg["EntiNameEmb_path"], cfg["PredNameEmb_path"] = os.path.join(d, "e.npy"), os.path.join(d, "p.npy")
     m = DEBUG(cfg, is_train=is_train)
     m.load_state_dict(sd, strict=True)
-    return m.to(DEV)
+    return m.to(DEV).eval()        # parity with the reference is defined with dropout off (is_train selects the training PATH)
 
 
 def hip_step(name, weights=None):
@@ -84,3 +84,45 @@ def test_grd_eval_with_gt_data_uses_the_gt_queries():
     pooled2, probs2, mask2 = model([feat], [(quint, dura, gts[0].video_len)], with_gt_data=False)
     assert pooled.shape[0] == quint.shape[0]
     assert torch.equal(pooled, pooled2) and torch.equal(probs, probs2) and torch.equal(mask, mask2)
+
+
+def test_grd_train_with_dropout_matches_oracle_with_same_masks():
+    """training-mode dropout of the QANet layers: HIP step vs the oracle applying identical counter-based masks"""
+    from oracle import dropout_ref as DR
+    from oracle import grd_train_oracle as GT
+    name = "grd_train_tiny"
+    cfg, sd, feats, gts, seed = cases.make_grd_train_case(name)
+    model = build_model(cfg, sd).train()
+    torch.manual_seed(seed)
+    total, terms = model([f.to(DEV) for f in feats], gts)
+    total.backward()
+    # replay the global RNG: per video, the negatives are drawn first, then the dropout seed
+    import bigc_hip.grd_train_step as GS
+    torch.manual_seed(seed)
+    seeds = []
+    for g in cases.make_grd_train_case(name)[3]:
+        GS.gt_queries(g, True, 51)
+        seeds.append(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.manual_seed(seed)
+    drops = [DR.Dropper(0.1, s) for s in seeds]
+    # the oracle draws the negatives of video i itself; consume the dropout-seed draw after each video as the HIP host does
+    orig = GT.prepare_gt_queries
+
+    def patched(sd_, g, train=True, n_pred_cats=51):
+        out = orig(sd_, g, train, n_pred_cats)
+        torch.randint(0, 2 ** 31 - 1, (1,))          # consume what the HIP host drew for the dropout seed
+        return out
+    GT.prepare_gt_queries = patched
+    try:
+        o_total, o_terms, _ = GT.forward_train(sdg, cfg, feats, cases.make_grd_train_case(name)[3], drops=drops)
+    finally:
+        GT.prepare_gt_queries = orig
+    o_total.backward()
+    assert abs(float(total) - float(o_total)) < 2e-4 * abs(float(o_total))
+    for k, p in model.named_parameters():
+        ref = sdg[k].grad
+        if ref is None:
+            continue
+        err = float((p.grad.cpu() - ref).abs().max())
+        assert err <= 1e-3 * max(float(ref.abs().max()), 1e-12), (k, err, float(ref.abs().max()))

@@ -140,6 +140,7 @@ _SIGS = {
     "grd_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                             c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_size_t, POINTER(grd_outputs)]),
     "grd_set_grad": (c_int, [c_void_p, c_char_p, c_void_p]),
+    "grd_set_dropout": (c_int, [c_void_p, c_float, ctypes.c_uint32]),
     "grd_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "grd_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                                   c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),

@@ -89,6 +89,9 @@ def forward(model, engine, video_feature_list, gt_graph_list):
     ldc, ldr = (k + 3) // 4 * 4, (2 * k + 3) // 4 * 4
     stream = _lib.current_stream()
     vids = []
+    # dropout follows the module's training flag (models/grd_model_v5.py:125,130,136 use training=self.training); one seed per
+    # video, drawn from the global torch RNG right after that video's negative predicates
+    drop_p = float(getattr(model, "dropout_p", 0.1)) if model.training else 0.0
     for feat, g in zip(video_feature_list, gt_graph_list):
         assert feat.is_cuda and feat.dtype == torch.float32
         dev = feat.device
@@ -111,6 +114,8 @@ def forward(model, engine, video_feature_list, gt_graph_list):
         need = lib.grd_train_workspace_bytes(engine.handle, v.T, v.n)
         v.ws = torch.empty((need,), dtype=torch.uint8, device=dev)             # activations live until the backward
         v.pos_v, v.pos_q, v.clip = engine.tables(v.T, dev)
+        v.drop = (drop_p, int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0)
+        _lib.check(lib.grd_set_dropout(engine.handle, v.drop[0], v.drop[1]))
         _lib.check(lib.grd_train_forward(engine.handle, stream, v.feat.data_ptr(), v.T, v.quint.data_ptr(), v.dura.data_ptr(), v.n,
                                          v.video_len, v.pos_v.data_ptr(), v.pos_q.data_ptr(), v.ws.data_ptr(), v.ws.numel(),
                                          v.regrs.data_ptr(), v.conf.data_ptr(), v.cls.data_ptr()))
@@ -158,6 +163,7 @@ def backward(model, engine, ctx, grad_terms, named_params):
             _lib.check(engine.lib.grd_set_grad(engine.handle, k.encode(), None))
     stream = _lib.current_stream()
     for v in ctx.vids:
+        _lib.check(engine.lib.grd_set_dropout(engine.handle, v.drop[0], v.drop[1]))       # the masks of this video's forward
         _lib.check(engine.lib.grd_train_backward(engine.handle, stream, v.feat.data_ptr(), v.T, v.quint.data_ptr(), v.n, v.ws.data_ptr(),
                                                  v.ws.numel(), v.dregr.data_ptr(), v.dconf.data_ptr(), v.dcls.data_ptr()))
     engine.last_flat_grad = flat

@@ -11,6 +11,7 @@ struct grd_model {
     std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
     std::unordered_map<std::string, float*> grads;     // gradient destinations (training)
     bool finalized = false;
+    float drop_p = 0.f; unsigned int drop_seed = 0;   // training-mode dropout of the QANet layers (grd_set_dropout); 0 = off
     unsigned long long epoch = 0;          // drawn at finalize: scope of the cached split weights
     const float *enti = nullptr, *pred = nullptr;
     Lin video_fc, vq_fc, proj2sim, query_fc, temp_fc;

@@ -23,7 +23,21 @@ extern "C" int bigc_mha_bwd_f32(void* stream, const float* q, int ldq, const flo
                                 const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
                                 int n_head, int hd);
 
+extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                      float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
+                                      int n_head, int hd, float* lse, float drop_p, uint32_t drop_seed, uint32_t drop_site);
+extern "C" int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                     const float* o, int ldo, const float* dO, int lddo, const float* lse, float* delta_scratch,
+                                     float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                                     const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
+                                     int n_head, int hd, float drop_p, uint32_t drop_seed, uint32_t drop_site);
+extern "C" int bigc_dropout_f32(void* stream, float* x, long rows, int n, int ld, float p, uint32_t seed, uint32_t site);
+
 namespace {
+
+// dropout sites of a QANet layer (models/grd_model_v5.py:123-136): base + {0,1: after conv blocks 1 and 3 (p = 0.05, 0.1),
+// 2: attention probabilities, 3: after the attention residual, 4: layer output}; bases 0x100 video, 0x200 query, 0x300 combined
+struct QDrop { float p; uint32_t seed; uint32_t base; };
 
 int grid_for(long n, int cap = 4096) { long g = (n + 255) / 256; return (int)(g < cap ? (g < 1 ? 1 : g) : cap); }
 int round4(int x) { return (x + 3) & ~3; }
@@ -352,7 +366,7 @@ float* gof_or(grd_model* m, const std::string& key, float* fallback) {
 }
 
 // QANetEncoderLayer forward keeping what the backward needs (models/grd_model_v5.py:110-137)
-int qanet_fwd(void* s, const Enc& E, const float* x, const float* pos, int d, EncSave& S, int32_t* off, float* out) {
+int qanet_fwd(void* s, const Enc& E, const float* x, const float* pos, int d, EncSave& S, int32_t* off, float* out, const QDrop& dr) {
     const int rows = S.n_seq * S.T;
     TRY(bigc_add_rows_f32(s, x, pos, S.a, rows, d, S.T));
     TRY(bigc_layernorm_f32(s, S.a, E.normb.w, E.normb.b, S.ln[0], rows, d, 1e-5f));
@@ -363,18 +377,22 @@ int qanet_fwd(void* s, const Enc& E, const float* x, const float* pos, int d, En
         hipError_t e = hipMemcpyAsync(S.c[i], S.r[i], sizeof(float) * (size_t)rows * d, hipMemcpyDeviceToDevice, (hipStream_t)s);
         if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "qanet_fwd: memcpy");
         TRY(bigc_axpy_f32(s, S.c[i], res, (long)rows * d));
+        if (dr.p > 0.f && (i + 1) % 2 == 0) TRY(bigc_dropout_f32(s, S.c[i], rows, d, d, dr.p * (i + 1) / 4, dr.seed, dr.base + i / 2));
         res = S.c[i];
         TRY(bigc_layernorm_f32(s, S.c[i], E.norm_seq[i].w, E.norm_seq[i].b, S.ln[i + 1], rows, d, 1e-5f));
     }
     TRY(linear(s, S.ln[4], d, E.in_proj, S.qkv, 3 * d, rows, 3 * d, d, BIGC_ACT_NONE));
     TRY(bigc_fill_offsets((hipStream_t)s, off, S.n_seq + 1, S.T));
-    TRY(bigc_mha_core_f32(s, S.qkv, 3 * d, S.qkv + d, 3 * d, S.qkv + 2 * d, 3 * d, S.att, d, off, off, S.n_seq, S.T, 8, d / 8, S.lse));
+    TRY(bigc_mha_core_drop_f32(s, S.qkv, 3 * d, S.qkv + d, 3 * d, S.qkv + 2 * d, 3 * d, S.att, d, off, off, S.n_seq, S.T, 8, d / 8, S.lse, dr.p,
+                               dr.seed, dr.base + 2));
     TRY(linear(s, S.att, d, E.out_proj, S.o, d, rows, d, d, BIGC_ACT_NONE, res, d));
+    if (dr.p > 0.f) TRY(bigc_dropout_f32(s, S.o, rows, d, d, dr.p, dr.seed, dr.base + 3));
     TRY(bigc_layernorm_f32(s, S.o, E.norme.w, E.norme.b, S.l5, rows, d, 1e-5f));
     TRY(linear(s, S.l5, d, E.fc, S.r5, d, rows, d, d, BIGC_ACT_RELU));
     hipError_t e = hipMemcpyAsync(out, S.r5, sizeof(float) * (size_t)rows * d, hipMemcpyDeviceToDevice, (hipStream_t)s);
     if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "qanet_fwd: memcpy");
     TRY(bigc_axpy_f32(s, out, S.o, (long)rows * d));
+    if (dr.p > 0.f) TRY(bigc_dropout_f32(s, out, rows, d, d, dr.p, dr.seed, dr.base + 4));
     return BIGC_OK;
 }
 
@@ -430,21 +448,23 @@ struct GBwd {
 };
 
 // backward of qanet_fwd: g_out (rows,d) is consumed (overwritten); result d x is left in w.g0
-int qanet_bwd(GBwd& B, const Enc& E, int d, EncSave& S, float* g_out) {
+int qanet_bwd(GBwd& B, const Enc& E, int d, EncSave& S, float* g_out, const QDrop& dr) {
     void* s = B.s; GTW& w = *B.w; grd_model* m = B.m;
     const int rows = S.n_seq * S.T;
     const std::string& p = E.key;
-    // out = r5 + o
+    // out = dropout(r5 + o)
+    if (dr.p > 0.f) TRY(bigc_dropout_f32(s, g_out, rows, d, d, dr.p, dr.seed, dr.base + 4));
     hipError_t e = hipMemcpyAsync(w.g1, g_out, sizeof(float) * (size_t)rows * d, hipMemcpyDeviceToDevice, (hipStream_t)s);   // g1 = d r5
     if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "qanet_bwd: memcpy");
     TRY(bigc_relu_bwd_f32(s, w.g1, S.r5, (long)rows * d));
     TRY(B.lin(p + ".fc", E.fc, w.g1, d, S.l5, d, rows, d, d, w.g2, d, false));                      // g2 = d l5
     TRY(bigc_layernorm_bwd_f32(s, S.o, E.norme.w, w.g2, w.g1, gof_or(m, p + ".norme.weight", w.dump), gof_or(m, p + ".norme.bias", w.dump + d), rows, d, 1e-5f));
-    TRY(bigc_axpy_f32(s, g_out, w.g1, (long)rows * d));                                             // g_out = d o
+    TRY(bigc_axpy_f32(s, g_out, w.g1, (long)rows * d));                                             // g_out = d o (after its dropout)
+    if (dr.p > 0.f) TRY(bigc_dropout_f32(s, g_out, rows, d, d, dr.p, dr.seed, dr.base + 3));       // -> d (attn + res)
     TRY(B.lin(p + ".mh_attn.out_proj", E.out_proj, g_out, d, S.att, d, rows, d, d, w.g1, d, false));  // g1 = d att ; g_out also = d c3
     TRY(bigc_fill_offsets((hipStream_t)s, w.off, S.n_seq + 1, S.T));
-    TRY(bigc_mha_bwd_f32(s, S.qkv, 3 * d, S.qkv + d, 3 * d, S.qkv + 2 * d, 3 * d, S.att, d, w.g1, d, S.lse, w.delta, w.gqkv, 3 * d, w.gqkv + d,
-                         3 * d, w.gqkv + 2 * d, 3 * d, w.off, w.off, S.n_seq, S.T, S.T, rows, 8, d / 8));
+    TRY(bigc_mha_bwd_drop_f32(s, S.qkv, 3 * d, S.qkv + d, 3 * d, S.qkv + 2 * d, 3 * d, S.att, d, w.g1, d, S.lse, w.delta, w.gqkv, 3 * d, w.gqkv + d,
+                              3 * d, w.gqkv + 2 * d, 3 * d, w.off, w.off, S.n_seq, S.T, S.T, rows, 8, d / 8, dr.p, dr.seed, dr.base + 2));
     if (float* gw = gof(m, p + ".mh_attn.in_proj_weight"))
         TRY(bigc_linear_dw_f32(s, w.gqkv, 3 * d, S.ln[4], d, nullptr, 1, d, gw, d, gof(m, p + ".mh_attn.in_proj_bias"), rows, 3 * d, d));
     TRY(B.dx(E.in_proj.w, w.gqkv, 3 * d, rows, 3 * d, d, w.g2, d, false));                          // g2 = d ln[4]
@@ -453,6 +473,7 @@ int qanet_bwd(GBwd& B, const Enc& E, int d, EncSave& S, float* g_out) {
         const std::string pn = p + ".norm_seq." + std::to_string(i);
         TRY(bigc_layernorm_bwd_f32(s, S.c[i], E.norm_seq[i].w, w.g2, w.g1, gof_or(m, pn + ".weight", w.dump), gof_or(m, pn + ".bias", w.dump + d), rows, d, 1e-5f));
         TRY(bigc_axpy_f32(s, g_out, w.g1, (long)rows * d));                                         // g_out = d c[i]
+        if (dr.p > 0.f && (i + 1) % 2 == 0) TRY(bigc_dropout_f32(s, g_out, rows, d, d, dr.p * (i + 1) / 4, dr.seed, dr.base + i / 2));
         e = hipMemcpyAsync(w.g1, g_out, sizeof(float) * (size_t)rows * d, hipMemcpyDeviceToDevice, (hipStream_t)s);   // g1 = d r[i]
         if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "qanet_bwd: memcpy");
         TRY(bigc_relu_bwd_f32(s, w.g1, S.r[i], (long)rows * d));
@@ -480,6 +501,12 @@ int head_bwd(GBwd& B, const Head& H, const float* x, const float* dY, int ldy, i
 }
 
 }  // namespace
+
+extern "C" int grd_set_dropout(grd_model* m, float p, uint32_t seed) {
+    BIGC_CHECK_ARG(m && p >= 0.f && p < 1.f, "grd_set_dropout: p must be in [0, 1)");
+    m->drop_p = p; m->drop_seed = seed;
+    return BIGC_OK;
+}
 
 extern "C" int grd_set_grad(grd_model* m, const char* key, float* ptr) {
     BIGC_CHECK_ARG(m && key, "grd_set_grad: bad argument");
@@ -510,12 +537,13 @@ extern "C" int grd_train_forward(grd_model* m, void* stream, const float* video_
     Lin qlin{m->wq, m->bq};
     TRY(linear(s, w.qin, m->kq, qlin, w.qemb, d, 3 * n, d, m->kq, BIGC_ACT_NONE));
     TRY(linear(s, video_feat, c.dim_feat, m->video_fc, w.vemb, d, T, d, c.dim_feat, BIGC_ACT_NONE));
-    TRY(qanet_fwd(s, m->video_enc, w.vemb, pos_video, d, w.ev, w.off, w.venc));
-    TRY(qanet_fwd(s, m->query_enc, w.qemb, pos_query, d, w.eq, w.off, w.qenc));
+    const QDrop dv{m->drop_p, m->drop_seed, 0x100}, dq{m->drop_p, m->drop_seed, 0x200}, dc{m->drop_p, m->drop_seed, 0x300};
+    TRY(qanet_fwd(s, m->video_enc, w.vemb, pos_video, d, w.ev, w.off, w.venc, dv));
+    TRY(qanet_fwd(s, m->query_enc, w.qemb, pos_query, d, w.eq, w.off, w.qenc, dq));
     TRY(linear(s, w.venc, d, m->proj2sim, w.proj, d, T, d, d, BIGC_ACT_NONE));
     TRY(grd_coattention_f32(s, w.venc, w.proj, w.qenc, w.comb, n, T, d));
     TRY(linear(s, w.comb, 4 * d, m->vq_fc, w.cin, d, n * T, d, 4 * d, BIGC_ACT_NONE));
-    TRY(qanet_fwd(s, m->comb_enc, w.cin, pos_video, d, w.ec, w.off, w.cenc));
+    TRY(qanet_fwd(s, m->comb_enc, w.cin, pos_video, d, w.ec, w.off, w.cenc, dc));
     TRY(head_fwd(s, m->regr_head, w.cenc, n, T, d, w.hr, regrs, BIGC_ACT_SIGMOID));
     TRY(head_fwd(s, m->conf_head, w.cenc, n, T, d, w.hc, conf, BIGC_ACT_NONE));
     TRY(head_fwd(s, m->cls_head, w.cenc, n, T, d, w.hl, cls, BIGC_ACT_NONE));
@@ -566,7 +594,8 @@ extern "C" int grd_train_backward(grd_model* m, void* stream, const float* video
     TRY(head_bwd(B, m->conf_head, w.cenc, dconf, round4(k), n, T, d, w.hc, g_enc));
     TRY(head_bwd(B, m->cls_head, w.cenc, dcls, round4(k), n, T, d, w.hl, g_enc));
     // combined encoder
-    TRY(qanet_bwd(B, m->comb_enc, d, w.ec, g_enc));                                   // w.g0 = d cin
+    const QDrop dv{m->drop_p, m->drop_seed, 0x100}, dq{m->drop_p, m->drop_seed, 0x200}, dc{m->drop_p, m->drop_seed, 0x300};
+    TRY(qanet_bwd(B, m->comb_enc, d, w.ec, g_enc, dc));                                   // w.g0 = d cin
     TRY(B.lin("vq_fc", m->vq_fc, w.g0, d, w.comb, 4 * d, rc, d, 4 * d, w.gcomb, 4 * d, false));    // gcomb = d comb (n*T, 4d)
     // co-attention
     GZERO(w.gvenc, (size_t)T * d);
@@ -579,10 +608,10 @@ extern "C" int grd_train_backward(grd_model* m, void* stream, const float* video
     }
     TRY(B.lin("proj2sim", m->proj2sim, w.gproj, d, w.venc, d, T, d, d, w.gvenc, d, true, false));
     // video branch
-    TRY(qanet_bwd(B, m->video_enc, d, w.ev, w.gvenc));                                 // w.g0 = d vemb
+    TRY(qanet_bwd(B, m->video_enc, d, w.ev, w.gvenc, dv));                                 // w.g0 = d vemb
     TRY(B.lin("video_fc", m->video_fc, w.g0, d, video_feat, c.dim_feat, T, d, c.dim_feat, nullptr, 0, false));
     // query branch
-    TRY(qanet_bwd(B, m->query_enc, d, w.eq, w.gqenc));                                 // w.g0 = d qemb (3n, d)
+    TRY(qanet_bwd(B, m->query_enc, d, w.eq, w.gqenc, dq));                                 // w.g0 = d qemb (3n, d)
     {
         // the fused input layer [query_fc | temp_fc]: weight gradients split by column range, biases both = column sums
         float* gq = gof(m, "query_fc.weight");

@@ -11,8 +11,8 @@
 // >= 32768 in magnitude, NaN or Inf (or the cached split of W says so), the workgroup recomputes its tile at the end on the
 // exact f32 MFMA straight from memory.  Tiny operands (|x| < 2^-35) contribute 0, an absolute error below 3e-11 per element.
 //
-// Tiling: 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, wave patch 64x64 = 2x2 MFMA blocks x 2
-// accumulators (128 accumulator registers), K slabs of 32, two workgroups per CU.  LDS holds four f16 planes per slab
+// Tiling: 128x256 output tile per 512-thread workgroup (8 waves as 2x4; 128x128 with 4 waves for narrow outputs), wave patch
+// 64x64 = 2x2 MFMA blocks x 2 accumulators (128 accumulator registers), K slabs of 32, two waves per SIMD.  LDS holds four f16 planes per slab
 // (A head, A residual, W head, W residual), rows of 64 bytes with the 16-byte chunks XOR-swizzled by (row >> 2) & 3:
 // both the ds_read_b128 fragment reads (lane = row, 8 consecutive k) and the ds_write_b64 stores are conflict-free.
 // W is split once per launch by a small pre-pass into [N][K/4] 16-byte groups {4 heads, 4 residuals} (same footprint
@@ -21,6 +21,7 @@
 #include "linear_internal.h"
 #include "prof.h"
 #include <atomic>
+#include <stdlib.h>
 #include <mutex>
 #include <unordered_map>
 
@@ -30,7 +31,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BK = 32;
 constexpr float RSCALE = 2048.0f, RINV = 1.0f / 2048.0f;
 constexpr float F16_LIMIT = 32768.0f;      // operands at or beyond this magnitude take the exact f32 kernel
 
@@ -71,32 +72,37 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
 
 __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((row >> 2) & 3); }
 
-template <bool GATHER, bool KTAIL>
-__global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p) {
-    // [buffer][plane: A head, A resid, W head, W resid][128 rows][64 bytes]
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][4][BM * 64];
+// WN = wave columns: 2 -> 128x128 tile, 256 threads, two workgroups per CU; 4 -> 128x256 tile, 512 threads (one workgroup
+// per CU, same two waves per SIMD): the A slab is split once for eight waves instead of four.
+template <bool GATHER, bool KTAIL, int WN>
+__global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void linear_split_kernel(const LinearArgs p) {
+    constexpr int NTH = 128 * WN, BNT = 64 * WN;     // threads, tile width
+    constexpr int RPP = NTH / 8;                     // rows staged per pass (8 threads x 16 bytes per 32-k row)
+    constexpr int NA = BM / RPP, NB = BNT / RPP;     // passes over the A / W rows
+    constexpr int PA = BM * 64, PW = BNT * 64;       // bytes of an A / W plane
+    // [buffer][A head | A resid | W head | W resid], rows of 64 bytes
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2 * PA + 2 * PW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN, hi = lane >> 5, l31 = lane & 31;
 
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
     if (tm >= p.tiles_m) return;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BNT;
 
     const int lr = tid >> 3, q = tid & 7, lc = q * 4;
     // Loads are unconditional (one basic block per K step, so that the scheduler can interleave the split arithmetic
     // with the MFMAs): rows past M / N are clamped to the last valid row -- their products land in accumulator rows /
     // columns that are never stored -- and only a ragged last slab (KTAIL) or a gather index of -1 (a zero row) select 0.
-    const float* arow[4];
-    const u32x4* wrow[4];
+    const float* arow[NA];
+    const u32x4* wrow[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        arow[i] = p.A + (size_t)min(m0 + lr + 32 * i, p.M - 1) * p.lda;
-        wrow[i] = p.Ws + (size_t)min(n0 + lr + 32 * i, p.N - 1) * p.ldws;
-    }
+    for (int i = 0; i < NA; ++i) arow[i] = p.A + (size_t)min(m0 + lr + RPP * i, p.M - 1) * p.lda;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) wrow[i] = p.Ws + (size_t)min(n0 + lr + RPP * i, p.N - 1) * p.ldws;
     // A is prefetched two slabs ahead in two register sets (its rows stream from HBM), W one slab ahead (L2-resident)
-    f32x4 ra0[4], ra1[4];
-    u32x4 rb[4];
+    f32x4 ra0[NA], ra1[NA];
+    u32x4 rb[NB];
     int cur_seg = -1;
     float chk = 0.f, amax = 0.f;
     const int nk = (p.K + BK - 1) / BK;
@@ -113,18 +119,18 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
             if (seg != cur_seg) {
                 cur_seg = seg;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int src = p.a_idx[(size_t)min(m0 + lr + 32 * i, p.M - 1) * p.nseg + seg];
+                for (int i = 0; i < NA; ++i) {
+                    const int src = p.a_idx[(size_t)min(m0 + lr + RPP * i, p.M - 1) * p.nseg + seg];
                     arow[i] = src >= 0 ? p.A + (size_t)src * p.lda : p.zero_row;      // index -1: a row of zeros, no select needed
                 }
             }
         }
     };
-    auto load_a = [&](int kt, f32x4 (&ra)[4]) {
+    auto load_a = [&](int kt, f32x4 (&ra)[NA]) {
         int kc, acol; bool kval;
         slab_cols(kt, kc, acol, kval);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             ra[i] = *(const f32x4*)(arow[i] + acol);
             if (KTAIL && !kval) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -134,27 +140,30 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
         bool kval = true;
         if (KTAIL) { kval = kc < p.K; kc = min(kc, p.K - 4); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NB; ++i) {
             rb[i] = wrow[i][kc >> 2];
             if (KTAIL && !kval) rb[i] = u32x4{0u, 0u, 0u, 0u};
         }
     };
     // this thread's 8 bytes inside a row: chunk q>>1 (swizzled), half q&1
-    int soff[4];
+    int soff[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = lr + 32 * i;
+    for (int i = 0; i < NB; ++i) {
+        const int row = lr + RPP * i;
         soff[i] = row * 64 + swz(q >> 1, row) * 16 + (q & 1) * 8;
     }
-    auto store_tiles = [&](int buf, const f32x4 (&ra)[4]) {
+    auto store_tiles = [&](int buf, const f32x4 (&ra)[NA]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             uint2 h, r;
             split4(ra[i], h, r, chk, amax);
-            *(uint2*)(&smem[buf][0][soff[i]]) = h;
-            *(uint2*)(&smem[buf][1][soff[i]]) = r;
-            *(uint2*)(&smem[buf][2][soff[i]]) = make_uint2(rb[i][0], rb[i][1]);
-            *(uint2*)(&smem[buf][3][soff[i]]) = make_uint2(rb[i][2], rb[i][3]);
+            *(uint2*)(&smem[buf][soff[i]]) = h;
+            *(uint2*)(&smem[buf][PA + soff[i]]) = r;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            *(uint2*)(&smem[buf][2 * PA + soff[i]]) = make_uint2(rb[i][0], rb[i][1]);
+            *(uint2*)(&smem[buf][2 * PA + PW + soff[i]]) = make_uint2(rb[i][2], rb[i][3]);
         }
     };
 
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
 
     // one K step: slab kt is in LDS buffer kt&1, `sp` holds the raw A rows of slab kt+1, `ld` receives slab kt+2
     // (slabs past the end repeat the last one: loaded and stored into the idle buffer, never read)
-    auto step = [&](int kt, f32x4 (&ld)[4], const f32x4 (&sp)[4]) {
+    auto step = [&](int kt, f32x4 (&ld)[NA], const f32x4 (&sp)[NA]) {
         const int buf = kt & 1;
         load_w(min(kt + 1, nk - 1));
         load_a(min(kt + 2, nk - 1), ld);
@@ -188,10 +197,10 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const LinearArgs p
             f16x8 a1[2], a2[2], b1[2], b2[2];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
-                a1[mi] = *(const f16x8*)(&smem[buf][0][aoff[mi][s]]);
-                a2[mi] = *(const f16x8*)(&smem[buf][1][aoff[mi][s]]);
-                b1[mi] = *(const f16x8*)(&smem[buf][2][boff[mi][s]]);
-                b2[mi] = *(const f16x8*)(&smem[buf][3][boff[mi][s]]);
+                a1[mi] = *(const f16x8*)(&smem[buf][aoff[mi][s]]);
+                a2[mi] = *(const f16x8*)(&smem[buf][PA + aoff[mi][s]]);
+                b1[mi] = *(const f16x8*)(&smem[buf][2 * PA + boff[mi][s]]);
+                b2[mi] = *(const f16x8*)(&smem[buf][2 * PA + PW + boff[mi][s]]);
             }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
@@ -371,17 +380,24 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
         }
         p.zero_row = zero_row;
     }
-    p.tiles_n = cdiv(p.N, BN);
-    const int grid = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
     ProfScope ps((void*)s, FAM_LINEAR, flops, bytes);
     const bool ktail = p.K % BK != 0;
-    if (p.a_idx) {
-        if (ktail) hipLaunchKernelGGL((linear_split_kernel<true, true>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((linear_split_kernel<true, false>), dim3(grid), dim3(256), 0, s, p);
+    static const int force_wn = getenv("BIGC_SPLIT_WN") ? atoi(getenv("BIGC_SPLIT_WN")) : 0;
+    // 128x256 tiles (eight waves share one split of the A slab) unless the last column tile would be mostly empty:
+    // 277 vs 260 TFLOP/s over the benchmark step's GEMMs (benchmarks/linear_shapes.py)
+    const int rem = p.N % 256;
+    const int wn = force_wn ? (force_wn == 4 ? 4 : 2) : ((p.N > 192 && (rem == 0 || rem > 128)) ? 4 : 2);
+    p.tiles_n = cdiv(p.N, 64 * wn);
+    const int grid2 = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
+#define LAUNCH_SPLIT(G, T, W) hipLaunchKernelGGL((linear_split_kernel<G, T, W>), dim3(grid2), dim3(128 * W), 0, s, p)
+    if (wn == 4) {
+        if (p.a_idx) { if (ktail) LAUNCH_SPLIT(true, true, 4); else LAUNCH_SPLIT(true, false, 4); }
+        else { if (ktail) LAUNCH_SPLIT(false, true, 4); else LAUNCH_SPLIT(false, false, 4); }
     } else {
-        if (ktail) hipLaunchKernelGGL((linear_split_kernel<false, true>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((linear_split_kernel<false, false>), dim3(grid), dim3(256), 0, s, p);
+        if (p.a_idx) { if (ktail) LAUNCH_SPLIT(true, true, 2); else LAUNCH_SPLIT(true, false, 2); }
+        else { if (ktail) LAUNCH_SPLIT(false, true, 2); else LAUNCH_SPLIT(false, false, 2); }
     }
+#undef LAUNCH_SPLIT
     BIGC_LAUNCH_CHECK("linear_split");
     return BIGC_OK;
 }

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Accuracy of the HIP path's predicate logits on the benchmark model (exp2 dims, seeded weights with sharp attention):
+"""(A checker script, not a pytest module: `python tests/accuracy_vs_fp64.py [n_videos]` on a GPU box.)
+Accuracy of the HIP path's predicate logits on the benchmark model (exp2 dims, seeded weights with sharp attention):
 split-operand GEMM mode and exact-f32 GEMM mode against a float64 evaluation of the CPU oracle, with the float32 CPU oracle
 (= the reference's arithmetic) alongside.  Error = max |x - x64| / max |x64| over all queries of a video."""
 import copy
@@ -10,7 +11,7 @@ import tempfile
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # tests/ -> repo root
 for p in (os.path.join(ROOT, "vidsgg-big_amd"), ROOT):
     sys.path.insert(0, p)
 from bigc_hip import _lib, configs  # noqa: E402

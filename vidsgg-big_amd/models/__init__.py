@@ -1,5 +1,13 @@
-"""Drop-in names of the reference's ``models/__init__.py:1-4`` for the HIP hot path."""
-from .model_0v10 import BIG_C as BIG_C_vidvrd
-from .model_0v7 import BIG_C as BIG_C_vidor
-from .grd_model_v5 import DEBUG
-from .model_pairwise_baseline import Base_C
+"""Public model names of the HIP hot path; they match what the reference's tools import from its ``models`` package
+(BIG-C for VidVRD and VidOR, the pairwise baseline, the grounding scorer)."""
+from . import grd_model_v5 as _grounding
+from . import model_0v7 as _vidor
+from . import model_0v10 as _vidvrd
+from . import model_pairwise_baseline as _pairwise
+
+BIG_C_vidvrd = _vidvrd.BIG_C
+BIG_C_vidor = _vidor.BIG_C
+Base_C = _pairwise.Base_C
+DEBUG = _grounding.DEBUG
+
+__all__ = ["BIG_C_vidvrd", "BIG_C_vidor", "Base_C", "DEBUG"]

@@ -17,7 +17,9 @@
 // both the ds_read_b128 fragment reads (lane = row, 8 consecutive k) and the ds_write_b64 stores are conflict-free.
 // W is split once per launch by a small pre-pass into [N][K/4] 16-byte groups {4 heads, 4 residuals} (same footprint
 // as f32), A is split by the staging code on its way from HBM to LDS.
-// Tried and rejected: persistent workgroups walking the tile list (275.4 vs 273.8 TFLOP/s on the step's shapes, +1 spill).
+// Tried and rejected: persistent workgroups walking the tile list (275.4 vs 273.8 TFLOP/s on the step's shapes, +1 spill);
+// the same with the slab pipeline running across tile boundaries (next tile's first slabs fetched during the epilogue):
+// correct, but the prefetch registers stay live across the epilogue and the kernel spills 200-300 VGPRs (10x slower).
 // Roofline: f16 MFMA dense peak / 3 MFMAs per product.
 #include "linear_internal.h"
 #include "prof.h"

@@ -16,8 +16,10 @@
  *   - every function returns 0 on success or a negative bigc_status; the message of the
  *     last failure on the calling thread is returned by bigc_last_error();
  *   - one handle per device and per model; a handle may be used from one thread at a time.
- *   - all floating point is IEEE fp32 (f32 MFMA, fp32 accumulate); indices are int32 on
- *     the device side (the Python host converts to the reference's int64 at the boundary).
+ *   - all tensors are IEEE fp32 and every accumulation is fp32; GEMMs run on the f16 matrix cores with
+ *     exactly split f32 operands (f32-level error, bigc_linear_set_exact(1) selects the f32 MFMA kernel),
+ *     attention on the f32 MFMA; indices are int32 on the device side (the Python host converts to the
+ *     reference's int64 at the boundary).
  */
 #ifndef BIGC_HIP_H
 #define BIGC_HIP_H
@@ -38,7 +40,7 @@ typedef enum {
 } bigc_status;
 
 const char* bigc_last_error(void);
-/* "gfx950 f32-mfma <build id>" -- lets the host verify it loaded the HIP build */
+/* "bigc_hip gfx950 ... <build id>" -- lets the host verify it loaded the HIP build */
 const char* bigc_build_info(void);
 
 /* Optional per-kernel-family timing with HIP events recorded on the caller's stream around every

@@ -16,7 +16,7 @@ int bigc_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* bigc_last_error(void) { return g_err; }
-extern "C" const char* bigc_build_info(void) { return "bigc_hip gfx950 f32-mfma " __DATE__ " " __TIME__; }
+extern "C" const char* bigc_build_info(void) { return "bigc_hip gfx950 split-f16x3/f32-mfma " __DATE__ " " __TIME__; }
 
 // ---- profiling ------------------------------------------------------------------------------
 namespace {

@@ -371,6 +371,7 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
         p.Ws = (const u32x4*)(e->mem + 256); p.ldws = K4; p.wbad = (const int*)e->mem; p.wbad_id = e->bad_id;
     }
     if (p.a_idx) {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
         static float* zero_row = nullptr;
         static int zero_cap = 0;
         if (p.seg_len > zero_cap) {

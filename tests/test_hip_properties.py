@@ -1,0 +1,161 @@
+"""Size-independent properties of the HIP path at the BASELINE workload's FULL dimensions (exp2: RoI 2048 + I3D 832, 2 encoder /
+6 decoder layers, 192 queries, 133 predicates; videos of N=64 tracklets from the benchmark recipe), where the CPU oracle is
+too slow to be the checker: determinism, independence of a video's result from its batch, permutation equivariance,
+structural invariants of the triplets recomputed on the host from the inputs, subset relation between top-k settings,
+agreement of the two GEMM modes on every triplet index, linearity of the GEMM."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from bigc_hip import _lib, configs
+from bigc_hip.packed import PackedBatch
+from bigc_hip.synthetic import bigc_state_shapes, seeded_state_dict, synthetic_proposal
+from test_hip_bigc import build_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N_VID = 12
+
+
+@pytest.fixture(scope="module")
+def setup():
+    cfg = dict(configs.CONFIG_V)
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 7, att_gain=8.0)
+    model = build_model(cfg, "vidvrd", sd)
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    make = lambda: [synthetic_proposal(1234 + v, n_trajs=64, feat_width=width, num_enti_cats=cfg["num_enti_cats"]) for v in range(N_VID)]
+    return cfg, model, make
+
+
+def as_np(res):
+    return None if res is None else [t.cpu().numpy() for t in res]
+
+
+def same(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_deterministic_batch_independent_and_permutation_equivariant(setup):
+    cfg, model, make = setup
+    props = [p.to(DEV) for p in make()]
+    r1 = [as_np(r) for r in model(props, topk=10)]
+    r2 = [as_np(r) for r in model(props, topk=10)]
+    assert all(same(a, b) for a, b in zip(r1, r2))                                   # run to run: bit-identical
+    rev = [as_np(r) for r in model(props[::-1], topk=10)][::-1]
+    assert all(same(a, b) for a, b in zip(r1, rev))                                  # order of the videos in the batch
+    for i in (0, 5, N_VID - 1):                                                      # a video alone == the same video in the batch
+        alone = as_np(model([props[i]], topk=10)[0])
+        assert same(r1[i], alone)
+    dup = [as_np(r) for r in model([props[3], props[3]], topk=10)]
+    assert same(dup[0], dup[1]) and same(dup[0], r1[3])
+    assert sum(r is not None for r in r1) == N_VID
+
+
+def test_triplet_invariants_recomputed_on_the_host(setup):
+    cfg, model, make = setup
+    host = make()
+    res = model([p.to(DEV) for p in make()], topk=10)
+    for p, r in zip(host, res):
+        q, s, d, qid = as_np(r)
+        assert q.shape[0] == s.shape[0] == d.shape[0] == qid.shape[0] > 0
+        assert (q[:, 0] > 0).all() and (q[:, 0] < cfg["num_pred_cats"]).all()        # background predicate removed
+        assert (q[:, 3] != q[:, 4]).all()                                            # subject != object
+        cats, sc, du = p.cat_ids.numpy(), p.scores.numpy(), p.traj_durations.numpy()
+        assert np.array_equal(q[:, 1], cats[q[:, 3]]) and np.array_equal(q[:, 2], cats[q[:, 4]])
+        assert np.array_equal(s[:, 1], sc[q[:, 3]]) and np.array_equal(s[:, 2], sc[q[:, 4]])
+        assert ((s[:, 0] > 0) & (s[:, 0] <= 1)).all()
+        lo = np.maximum(du[q[:, 3], 0], du[q[:, 4], 0])
+        hi = np.minimum(du[q[:, 3], 1], du[q[:, 4], 1])
+        assert np.array_equal(d[:, 0], lo) and np.array_equal(d[:, 1], hi) and (lo <= hi).all()   # closed-interval overlap
+        key = [tuple(x) for x in q]
+        assert len(set(key)) == len(key) and key == sorted(key)                      # unique, lexicographic (torch.unique(dim=0))
+        assert ((qid >= 0) & (qid < cfg["num_querys"])).all()
+
+
+def test_topk_subset_and_gemm_modes_agree(setup):
+    cfg, model, make = setup
+    props = [p.to(DEV) for p in make()]
+    r10 = [as_np(r) for r in model(props, topk=10)]
+    r3 = [as_np(r) for r in model(props, topk=3)]
+    for a, b in zip(r3, r10):
+        big = set(tuple(x) for x in b[0])
+        assert all(tuple(x) in big for x in a[0])                                    # top-3 candidates are among the top-10
+    lib = _lib.load()
+    prev = lib.bigc_linear_set_exact(1)
+    try:
+        rex = [as_np(r) for r in model(props, topk=10)]
+    finally:
+        lib.bigc_linear_set_exact(prev)
+    for a, b in zip(r10, rex):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert np.abs(a[1] - b[1]).max() < 5e-5
+
+
+def test_gemm_linearity_at_full_size():
+    """C(A1 + A2) = C(A1) + C(A2) - bias for the largest GEMM of the step (M = 579295, K = 2048, N = 512)"""
+    lib = _lib.load()
+    M, N, K = 579295, 512, 2048
+    g = torch.Generator(device=DEV).manual_seed(5)
+    A1 = torch.randn(M, K, device=DEV, generator=g)
+    A2 = torch.randn(M, K, device=DEV, generator=g) * 0.5
+    W = torch.randn(N, K, device=DEV, generator=g) * 0.02
+    b = torch.randn(N, device=DEV, generator=g)
+
+    def run(A):
+        C = torch.empty(M, N, device=DEV)
+        _lib.check(lib.bigc_linear_f32(_lib.current_stream(), A.data_ptr(), K, None, 1, K, W.data_ptr(), K, b.data_ptr(), None, N, C.data_ptr(), N,
+                                       M, N, K, 0))
+        return C
+    c1, c2 = run(A1), run(A2)
+    A1 += A2
+    c12 = run(A1)
+    err = (c12 - (c1 + c2 - b[None, :])).abs().max().item()
+    assert err < 2e-5 * c12.abs().max().item()
+
+
+def test_grounding_full_dims_invariants_and_batch_independence():
+    """config G (1024-d clips, hidden 128, 10 bins) at n = 200 queries, T = 150 clips: determinism, a query's result does not
+    depend on the other queries of the call, and the structural invariants of the pooled spans / masks."""
+    from bigc_hip.synthetic import grd_state_shapes
+    from test_hip_grounding import build_model as build_grd
+    cfg = dict(configs.CONFIG_G)
+    sd = seeded_state_dict(grd_state_shapes(cfg), 12, 4.0)
+    model = build_grd(cfg, sd)
+    rs = np.random.RandomState(3)
+    n, T, vl = 200, 150, 1200
+    feat = torch.from_numpy((0.1 * rs.standard_normal((T, cfg["dim_feat"]))).astype(np.float32)).to(DEV)
+    quint = torch.from_numpy(np.stack([rs.randint(1, 51, n), rs.randint(1, 81, n), rs.randint(1, 81, n), rs.randint(0, 64, n), rs.randint(0, 64, n)], 1))
+    start = rs.randint(0, vl - 100, n)
+    dura = torch.from_numpy(np.stack([start, start + rs.randint(20, 100, n)], 1))
+    th = dict(score_th=0.9, tiou_th=0.5, bins_th=0.2, nms_th=0.8)
+    a = model([feat], [(quint, dura, vl)], with_gt_data=False, **th)
+    b = model([feat], [(quint, dura, vl)], with_gt_data=False, **th)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    sub = model([feat], [(quint[40:90], dura[40:90], vl)], with_gt_data=False, **th)
+    assert torch.equal(sub[2], a[2][40:90]) and torch.equal(sub[0], a[0][40:90]) and torch.equal(sub[1], a[1][40:90])
+    pooled, probs, mask = (t.cpu().numpy() for t in a)
+    k = cfg["num_bins"]
+    assert pooled.shape == (n, k + 1, 2) and probs.shape == (n, k + 1) and mask.shape == (n, k + 1)
+    assert (pooled >= 0).all() and (pooled <= 1).all() and (pooled[:, :, 0] <= pooled[:, :, 1]).all()
+    assert (probs >= 0).all() and (probs <= 1).all()
+    assert mask.any(axis=1).all()                                                    # at least one bin kept per query (:561-564)
+    inter = dura.numpy() / vl
+    assert np.abs(pooled[:, k, 0] - inter[:, 0]).max() < 1e-6 and np.abs(pooled[:, k, 1] - inter[:, 1]).max() < 1e-6   # bin k+1 = overlap span
+
+
+def test_training_gradients_are_linear_in_the_upstream_gradient():
+    """d(c * loss) = c * d(loss) through the whole HIP backward, at tiny dims (structure, not size, matters here)"""
+    from test_hip_train import build_train_model
+    cfg, variant, sd, props, gts = cases.make_train_case("bigc_train_tiny")
+    grads = []
+    for c in (1.0, 3.0):
+        model = build_train_model(cfg, variant, sd)
+        cfg2, _, _, props2, gts2 = cases.make_train_case("bigc_train_tiny")
+        total, _ = model([p.to(DEV) for p in props2], gts2)
+        (c * total).backward()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    for k in grads[0]:
+        assert torch.allclose(grads[1][k], 3.0 * grads[0][k], rtol=2e-4, atol=1e-6 * float(grads[1][k].abs().max())), k   # fp32 atomics: summation order varies

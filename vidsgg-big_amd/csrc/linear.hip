@@ -1,8 +1,8 @@
-// f32-MFMA "linear" kernel: C = act(A' W^T + bias) + residual, with an optional segmented
-// row gather on A (plain row gather, or the 3-tap implicit GEMM of the stride-2 temporal conv).
-//
-// Replaces torch.nn.Linear / nn.Conv1d(k3,s2) at every call site of the BIG hot path
-// (reference: models/model_0v10.py:290-309,446-458; models/grd_model_v5.py:171-174).
+// The "linear" entry point: C = act(A' W^T + bias) + residual, with an optional segmented row gather on A (plain row
+// gather, or the 3-tap implicit GEMM of the stride-2 temporal conv).  Replaces torch.nn.Linear / nn.Conv1d(k3,s2) at every
+// call site of the BIG hot path (reference: models/model_0v10.py:290-309,446-458; models/grd_model_v5.py:171-174).
+// By default the work goes to the split-operand f16 MFMA kernel (linear_split.hip); this file holds the dispatch and the
+// EXACT f32-MFMA kernel (bigc_linear_set_exact(1) / BIGC_LINEAR_EXACT=1):
 //
 // Tiling (gfx950): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave
 // a 64x64 patch = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 acc VGPRs). K is walked in

@@ -66,6 +66,23 @@ __global__ __launch_bounds__(256) void adaptive_maxpool_kernel(const float* __re
                                                                float* __restrict__ pooled, int d, int P) {
     const int t = blockIdx.x;
     const int c0 = conv_off[t], To = conv_off[t + 1] - c0;
+    if ((d & 3) == 0) {
+        // one dwordx4 column group per thread; the windows of adaptive pooling overlap by at most one row
+        for (int c = threadIdx.x * 4; c < d; c += 1024) {
+            for (int p = 0; p < P; ++p) {
+                const int s = (p * To) / P, e = ((p + 1) * To + P - 1) / P;
+                f32x4 m = *(const f32x4*)(conv + (size_t)(c0 + s) * d + c);
+                for (int j = s + 1; j < e; ++j) {
+                    const f32x4 x = *(const f32x4*)(conv + (size_t)(c0 + j) * d + c);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], x[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pooled[(size_t)t * d * P + (size_t)(c + k) * P + p] = m[k];
+            }
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < d; c += 256) {
         for (int p = 0; p < P; ++p) {
             const int s = (p * To) / P, e = ((p + 1) * To + P - 1) / P;
@@ -84,6 +101,34 @@ __global__ __launch_bounds__(256) void stretched_mean_kernel(const float* __rest
     const int r0 = row_off[t], L = row_off[t + 1] - r0;
     const int M = vid_tmax[trk_vid[t]];
     const int q = M / L, r = M - q * L;
+    const float inv = 1.0f / (float)M;
+    if ((w & 3) == 0 && (ldf & 3) == 0 && (col0 & 3) == 0) {
+        // one dwordx4 column group per thread, four rows in flight (HBM-bound: the tracklet's rows are read once)
+        for (int c = threadIdx.x * 4; c < w; c += 1024) {
+            const float* p = feats + (size_t)r0 * ldf + col0 + c;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            int i = 0;
+            for (; i + 4 <= L; i += 4) {
+                f32x4 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = *(const f32x4*)(p + (size_t)(i + u) * ldf);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float wt = (i + u < r) ? (float)(q + 1) : (float)q;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[k] += wt * x[u][k];
+                }
+            }
+            for (; i < L; ++i) {
+                const f32x4 x = *(const f32x4*)(p + (size_t)i * ldf);
+                const float wt = (i < r) ? (float)(q + 1) : (float)q;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += wt * x[k];
+            }
+            *(f32x4*)(out + (size_t)t * w + c) = f32x4{s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv};
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < w; c += 256) {
         const float* p = feats + (size_t)r0 * ldf + col0 + c;
         float s = 0.f;
@@ -91,7 +136,7 @@ __global__ __launch_bounds__(256) void stretched_mean_kernel(const float* __rest
             const float x = p[(size_t)i * ldf];
             s += (i < r ? (float)(q + 1) : (float)q) * x;
         }
-        out[(size_t)t * w + c] = s / (float)M;
+        out[(size_t)t * w + c] = s * inv;
     }
 }
 

@@ -141,29 +141,32 @@ __device__ __forceinline__ float wsum(float v) {
 
 // LayerNorm backward. One wave per row (grid-stride), d <= 2048. dgamma/dbeta accumulated per wave in
 // registers and added atomically once at the end.
+// NVL = float4 per lane (d <= 256 * NVL): the per-lane arrays are exactly as long as the row needs (a fixed length of 8
+// spilled 688 bytes per lane at d = 512)
+template <int NVL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                             const float* __restrict__ dy, float* __restrict__ dx,
                                                             float* __restrict__ dg, float* __restrict__ db, int rows, int d, float eps) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const int nv = d >> 2;
-    f32x4 ag[8], ab[8];
+    f32x4 ag[NVL], ab[NVL];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { ag[j] = f32x4{0, 0, 0, 0}; ab[j] = f32x4{0, 0, 0, 0}; }
+    for (int j = 0; j < NVL; ++j) { ag[j] = f32x4{0, 0, 0, 0}; ab[j] = f32x4{0, 0, 0, 0}; }
     for (int row = wid; row < rows; row += nw) {
         const f32x4* xp = (const f32x4*)(x + (size_t)row * d);
         const f32x4* yp = (const f32x4*)(dy + (size_t)row * d);
-        f32x4 v[8], gy[8];
+        f32x4 v[NVL], gy[NVL];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NVL; ++j) {
             const int i = lane + 64 * j;
             if (i < nv) { v[j] = xp[i]; gy[j] = yp[i]; s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]); }
         }
         const float mean = wsum(s) / (float)d;
         float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NVL; ++j) {
             const int i = lane + 64 * j;
             if (i < nv)
 #pragma unroll
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const float rstd = 1.0f / sqrtf(wsum(ss) / (float)d + eps);
         float s1 = 0.f, s2 = 0.f;   // sum(dxhat), sum(dxhat * xhat)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NVL; ++j) {
             const int i = lane + 64 * j;
             if (i < nv) {
                 const f32x4 gg = ((const f32x4*)g)[i];
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s1 = wsum(s1) / (float)d; s2 = wsum(s2) / (float)d;
         f32x4* op = (f32x4*)(dx + (size_t)row * d);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NVL; ++j) {
             const int i = lane + 64 * j;
             if (i < nv) {
                 f32x4 o;
@@ -201,10 +204,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
     }
     // the four waves of the workgroup are summed through LDS first: one atomic per column and workgroup
-    __shared__ float red[2][4][2048];
+    __shared__ float red[2][4][256 * NVL];
     const int wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NVL; ++j) {
         const int i = lane + 64 * j;
         if (i < nv)
 #pragma unroll
@@ -458,7 +461,12 @@ extern "C" int bigc_layernorm_bwd_f32(void* stream, const float* x, const float*
     // every wave takes >= 8 rows (its parameter-gradient partials live in registers): few workgroups, few atomics
     const int grid = cdiv(rows, 32) < 512 ? cdiv(rows, 32) : 512;
     ProfScope ps(stream, FAM_BACKWARD, 0.0, 12.0 * rows * (double)d);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dx, dgamma, dbeta, rows, d, eps);
+#define LN_BWD(NVL) hipLaunchKernelGGL(layernorm_bwd_kernel<NVL>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dx, dgamma, dbeta, rows, d, eps)
+    if (d <= 256) LN_BWD(1);
+    else if (d <= 512) LN_BWD(2);
+    else if (d <= 1024) LN_BWD(4);
+    else LN_BWD(8);
+#undef LN_BWD
     BIGC_LAUNCH_CHECK("layernorm_bwd");
     return BIGC_OK;
 }

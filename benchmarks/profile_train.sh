@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_train
 rm -rf $O; mkdir -p $O
 cd $R
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o train -- python3 bench.py --mode train --no-prof > $O/stdout.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o train -- python3 bench.py --mode train --no-prof --train-videos ${TV:-8} > $O/stdout.log 2>&1
 python3 - <<'PY'
 import csv,os
 p=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/prof_train/stats/train_kernel_stats.csv"

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 struct DwArgs {
     const float* dY; int ldy; const float* X; int ldx; const int32_t* x_idx; int nseg; int seg_len;
     float* dW; int ldw; float* db; int M, N, K; int tiles_n, tiles_k, m_chunk;
+    float* partial;        // when the M range is split: (splits, tiles_n*128, tiles_k*128) partial products, summed by a second kernel
 };
 
 __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
@@ -111,9 +112,204 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = n0 + wm * 64 + a * 32 + mfma_row(r, hi);
-                if (row < p.N) atomicAdd(&p.dW[(size_t)row * p.ldw + col], acc[a][b][r]);
+                if (row >= p.N) continue;
+                if (p.partial) p.partial[((size_t)split * p.tiles_n * 128 + row) * ((size_t)p.tiles_k * 128) + col] = acc[a][b][r];
+                else p.dW[(size_t)row * p.ldw + col] += acc[a][b][r];      // one workgroup per tile: a single writer per element
             }
         }
+}
+
+// The same product on the f16 matrix cores with exactly split f32 operands (see linear_split.hip): both operands are
+// activations here, so both are split by the staging code (columns of dY and X, 16 consecutive m per thread) into the four f16
+// planes [n or k][32 m] of a slab -- the layout and the MFMA loop of the forward kernel with m as the contraction index.
+// Slab s+1 is fetched into registers while slab s is multiplied.  Out-of-range / non-finite operands: the workgroup redoes its
+// (tile, M range) on the exact f32 MFMA.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 hp16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int dw_swz(int chunk, int row) { return chunk ^ ((row >> 2) & 3); }
+
+// 16 consecutive-m values of one column -> 32 bytes of heads + 32 bytes of scaled residuals, written into the column's LDS row
+__device__ __forceinline__ void dw_split16(const float (&x)[16], unsigned char* head_row, unsigned char* resid_row, int row, int mh,
+                                           float& chk, float& amax) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {               // two 16-byte chunks of 8 m each
+        union { hp16x2 h[4]; uint4 u; } hh, rr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = x[8 * g + 2 * j], b = x[8 * g + 2 * j + 1];
+            hh.h[j] = __builtin_amdgcn_cvt_pkrtz(a, b);
+            const float ra = (a - (float)hh.h[j][0]) * 2048.0f, rb = (b - (float)hh.h[j][1]) * 2048.0f;
+            rr.h[j] = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+            chk += ra + rb;
+            asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(amax) : "v"(amax), "v"(a), "v"(b));
+        }
+        const int off = row * 64 + dw_swz(2 * mh + g, row) * 16;
+        *(uint4*)(head_row + off) = hh.u;
+        *(uint4*)(resid_row + off) = rr.u;
+    }
+}
+
+template <bool GATHER>
+__global__ __launch_bounds__(256, 2) void linear_dw_split_kernel(const DwArgs p) {
+    // [buffer][dY^T head | dY^T resid | X^T head | X^T resid][128 rows][64 bytes = 32 m]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][4][128 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.x % (p.tiles_n * p.tiles_k), split = blockIdx.x / (p.tiles_n * p.tiles_k);
+    const int tn = tile / p.tiles_k, tk = tile % p.tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int m_begin = split * p.m_chunk, m_end = min(p.M, m_begin + p.m_chunk);
+    if (m_begin >= m_end) return;
+    const int c = tid & 127, mh = tid >> 7;
+    const int ncol = min(n0 + c, p.N - 1), kcol = min(k0 + c, p.K - 1);       // clamped: surplus rows of dW are never stored
+    const bool nval = n0 + c < p.N;
+    int seg = 0, kin = kcol;
+    if (GATHER) { seg = kcol / p.seg_len; kin = kcol - seg * p.seg_len; }
+
+    f32x16 acc0[2][2], acc1[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[a][b][r] = 0.f; acc1[a][b][r] = 0.f; }
+    int aoff[2][2], boff[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ra_ = wm * 64 + mi * 32 + l31, rb_ = wn * 64 + mi * 32 + l31;
+            aoff[mi][s] = ra_ * 64 + dw_swz(2 * s + hi, ra_) * 16;
+            boff[mi][s] = rb_ * 64 + dw_swz(2 * s + hi, rb_) * 16;
+        }
+
+    float ry[16], rx[16];
+    int ridx[16];                                   // gather mode: source rows of the NEXT slab to load (fetched one slab ahead,
+                                                    // so the data loads never wait on their own index loads)
+    float bsum = 0.f, chk = 0.f, amax = 0.f;
+    auto load_idx = [&](int m0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ridx[j] = p.x_idx[(size_t)min(m0 + mh * 16 + j, m_end - 1) * p.nseg + seg];
+    };
+    auto load_slab = [&](int m0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int m = m0 + mh * 16 + j;
+            const bool mv = m < m_end;
+            const int mc = min(m, m_end - 1);
+            const float y = p.dY[(size_t)mc * p.ldy + ncol];
+            float xv;
+            if (GATHER) {
+                xv = p.X[(size_t)max(ridx[j], 0) * p.ldx + kin];
+                if (ridx[j] < 0) xv = 0.f;
+            } else {
+                xv = p.X[(size_t)mc * p.ldx + kcol];
+            }
+            ry[j] = mv ? y : 0.f;                    // rows past the M range contribute nothing
+            rx[j] = mv ? xv : 0.f;
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bsum += ry[j];
+        dw_split16(ry, smem[buf][0], smem[buf][1], c, mh, chk, amax);
+        dw_split16(rx, smem[buf][2], smem[buf][3], c, mh, chk, amax);
+    };
+    if (GATHER) load_idx(m_begin);
+    load_slab(m_begin);
+    if (GATHER) load_idx(m_begin + 32);
+    store_slab(0);
+    __syncthreads();
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += 32, buf ^= 1) {
+        const bool more = m0 + 32 < m_end;
+        if (more) {
+            load_slab(m0 + 32);
+            if (GATHER) load_idx(m0 + 64);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            h16x8 a1[2], a2[2], b1[2], b2[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                a1[mi] = *(const h16x8*)(&smem[buf][0][aoff[mi][s]]);
+                a2[mi] = *(const h16x8*)(&smem[buf][1][aoff[mi][s]]);
+                b1[mi] = *(const h16x8*)(&smem[buf][2][boff[mi][s]]);
+                b2[mi] = *(const h16x8*)(&smem[buf][3][boff[mi][s]]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc0[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mi], b1[ni], acc0[mi][ni], 0, 0, 0);
+                    acc1[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mi], b2[ni], acc1[mi][ni], 0, 0, 0);
+                    acc1[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[mi], b1[ni], acc1[mi][ni], 0, 0, 0);
+                }
+        }
+        if (more) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+    if (p.db && tk == 0 && nval) atomicAdd(&p.db[n0 + c], bsum);
+    if (__syncthreads_or((!(fabsf(chk) < INFINITY) || amax >= 32768.0f) ? 1 : 0)) {
+        // exact f32 MFMA straight from memory: lane (l31, hi) of block a / b owns row n / column k, m = m2 + hi
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[a][b][r] = 0.f; acc1[a][b][r] = 0.f; }
+        for (int m2 = m_begin; m2 < m_end; m2 += 2) {
+            const int m = m2 + hi;
+            const bool mv = m < m_end;
+            const int mc = min(m, m_end - 1);
+            float av[2], bv[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int n = min(n0 + wm * 64 + a * 32 + l31, p.N - 1), k = min(k0 + wn * 64 + a * 32 + l31, p.K - 1);
+                av[a] = mv ? p.dY[(size_t)mc * p.ldy + n] : 0.f;
+                if (GATHER) {
+                    const int sg = k / p.seg_len;
+                    const int src = p.x_idx[(size_t)mc * p.nseg + sg];
+                    bv[a] = (mv && src >= 0) ? p.X[(size_t)max(src, 0) * p.ldx + (k - sg * p.seg_len)] : 0.f;
+                } else {
+                    bv[a] = mv ? p.X[(size_t)mc * p.ldx + k] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc0[a][b] = mfma32(av[a], bv[b], acc0[a][b]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = k0 + wn * 64 + b * 32 + l31;
+            if (col >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm * 64 + a * 32 + mfma_row(r, hi);
+                if (row >= p.N) continue;
+                const float v = acc0[a][b][r] + acc1[a][b][r] * (1.0f / 2048.0f);
+                if (p.partial) p.partial[((size_t)split * p.tiles_n * 128 + row) * ((size_t)p.tiles_k * 128) + col] = v;
+                else p.dW[(size_t)row * p.ldw + col] += v;
+            }
+        }
+}
+
+// dW[n, k] += sum over the M splits of their partial products (no atomics: summation order is fixed -> deterministic gradients)
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int ldw, int N, int K,
+                                                        int n_pad, int k_pad, int splits) {
+    const long total = (long)N * K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / K), k = (int)(i - (long)n * K);
+        const float* p = partial + (size_t)n * k_pad + k;
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += p[(size_t)sp * n_pad * k_pad];
+        dW[(size_t)n * ldw + k] += s;
+    }
 }
 
 // dY *= (Y > 0)   (Y = post-ReLU activation)
@@ -406,16 +602,38 @@ extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const 
     p.dW = dW; p.ldw = ldw; p.db = db; p.M = M; p.N = N; p.K = K;
     p.tiles_n = cdiv(N, 128); p.tiles_k = cdiv(K, 128);
     const int tiles = p.tiles_n * p.tiles_k;
-    int splits = cdiv(2048, tiles);
-    const int max_splits = cdiv(M, 256);
+    // about two workgroups per CU; every split reduces at least 128 rows
+    int splits = cdiv(512, tiles);
+    const int max_splits = cdiv(M, 128);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     p.m_chunk = cdiv(cdiv(M, splits), 32) * 32;
     splits = cdiv(M, p.m_chunk);
+    p.partial = nullptr;
+    const size_t n_pad = (size_t)p.tiles_n * 128, k_pad = (size_t)p.tiles_k * 128;
+    if (splits > 1) {
+        // stream-ordered scratch, grown on demand (one stream per process in this library's use)
+        static float* scratch = nullptr;
+        static size_t cap = 0;
+        const size_t need = (size_t)splits * n_pad * k_pad;
+        if (need > cap) {
+            if (scratch) { if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_dw: sync failed"); (void)hipFree(scratch); }
+            cap = need + need / 2;
+            if (hipMalloc((void**)&scratch, cap * sizeof(float)) != hipSuccess) { scratch = nullptr; cap = 0; return bigc_fail(BIGC_ERR_HIP, "linear_dw: hipMalloc of the split scratch failed"); }
+        }
+        p.partial = scratch;
+    }
     {
         ProfScope ps(stream, FAM_LINEAR_DW, 2.0 * M * (double)N * K, 4.0 * ((double)M * N + (double)M * K + (double)N * K));
-        hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
+        if (bigc_linear_get_exact()) hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
+        else if (x_idx) hipLaunchKernelGGL(linear_dw_split_kernel<true>, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(linear_dw_split_kernel<false>, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
         BIGC_LAUNCH_CHECK("linear_dw");
+        if (splits > 1) {
+            hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for((long)N * K)), dim3(256), 0, (hipStream_t)stream, p.partial, dW, ldw, N, K, (int)n_pad,
+                               (int)k_pad, splits);
+            BIGC_LAUNCH_CHECK("dw_reduce");
+        }
     }
     return BIGC_OK;
 }

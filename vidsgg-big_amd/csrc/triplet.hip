@@ -18,7 +18,10 @@ namespace {
 constexpr int SORT_N = 2048;  // >= num_querys * topk
 constexpr uint64_t KEY_DEAD = ~0ull;
 
-__global__ __launch_bounds__(256) void construct_triplets_kernel(const float* __restrict__ logits, int P, const int32_t* __restrict__ soid,
+// NTH threads per video: the per-query softmax / top-k (chains of cross-lane reductions, latency bound) is spread over NTH/64 waves;
+// the ordered compaction at the end uses the first 256 threads.
+constexpr int NTH = 1024;
+__global__ __launch_bounds__(NTH) void construct_triplets_kernel(const float* __restrict__ logits, int P, const int32_t* __restrict__ soid,
                                                                  const int32_t* __restrict__ e_off, const int32_t* __restrict__ trk_dura,
                                                                  const int32_t* __restrict__ trk_cat, const float* __restrict__ trk_score,
                                                                  int nq, int topk, int32_t* __restrict__ quint, float* __restrict__ scores,
@@ -38,16 +41,25 @@ __global__ __launch_bounds__(256) void construct_triplets_kernel(const float* __
     }
 
     // ---- 1. softmax + top-k, one wave per query ------------------------------------------------
-    for (int qi = wave; qi < nq; qi += 4) {
-        const float* lp = logits + ((size_t)vid * nq + qi) * P;
+    // the logits of the wave's next query are requested (unconditionally, from clamped addresses) before the current one is
+    // processed: a query is ~400 instructions, far less than a memory round trip
+    float nx[4];
+    auto fetch = [&](int qi) {
+        const float* lp = logits + ((size_t)vid * nq + min(qi, nq - 1)) * P;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nx[j] = lp[min(lane + 64 * j, P - 1)];
+    };
+    fetch(wave);
+    for (int qi = wave; qi < nq; qi += NTH / 64) {
         float x[4];
         float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = lane + 64 * j;
-            x[j] = c < P ? lp[c] : -INFINITY;
+            x[j] = c < P ? nx[j] : -INFINITY;
             mx = fmaxf(mx, x[j]);
         }
+        fetch(qi + NTH / 64);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float sum = 0.f;
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(256) void construct_triplets_kernel(const float* __
     __syncthreads();
 
     // ---- 2. overlap filter + packed sort keys ------------------------------------------------
-    for (int c = tid; c < SORT_N; c += 256) {
+    for (int c = tid; c < SORT_N; c += NTH) {
         uint64_t key = KEY_DEAD;
         if (c < cap) {
             const int qi = c / topk;
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(256) void construct_triplets_kernel(const float* __
     // ---- 3. bitonic sort (ascending) ---------------------------------------------------------
     for (int k = 2; k <= SORT_N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < SORT_N; i += 256) {
+            for (int i = tid; i < SORT_N; i += NTH) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const uint64_t a = keys[i], b = keys[ixj];
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(256) void construct_triplets_kernel(const float* __
     }
 
     // ---- 4. group heads, representatives ------------------------------------------------------
-    for (int i = tid; i < SORT_N; i += 256) {
+    for (int i = tid; i < SORT_N; i += NTH) {
         int r = -1;
         const uint64_t key = keys[i];
         if (key != KEY_DEAD) {
@@ -144,17 +156,21 @@ __global__ __launch_bounds__(256) void construct_triplets_kernel(const float* __
 
     // ---- 5. ordered compaction -------------------------------------------------------------------
     constexpr int PER = SORT_N / 256;
+    const bool worker = tid < 256;
     int cnt = 0;
+    if (worker) {
 #pragma unroll
-    for (int u = 0; u < PER; ++u) cnt += rep[tid * PER + u] >= 0;
-    scan[tid] = cnt;
+        for (int u = 0; u < PER; ++u) cnt += rep[tid * PER + u] >= 0;
+        scan[tid] = cnt;
+    }
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
-        const int add = tid >= o ? scan[tid - o] : 0;
+        const int add = (worker && tid >= o) ? scan[tid - o] : 0;
         __syncthreads();
-        scan[tid] += add;
+        if (worker) scan[tid] += add;
         __syncthreads();
     }
+    if (!worker) return;
     int pos = scan[tid] - cnt;
     if (tid == 255) n_out[vid] = scan[255];
     const size_t ob = (size_t)vid * cap;
@@ -189,7 +205,7 @@ extern "C" int bigc_construct_triplets(void* stream, const float* logits, int n_
     BIGC_CHECK_ARG(topk > 0 && topk <= n_pcat && nq * topk <= SORT_N, "construct_triplets: num_querys*topk=%d must be <= %d", nq * topk, SORT_N);
     if (n_vid <= 0) return BIGC_OK;
     ProfScope ps(stream, FAM_TRIPLETS, 0.0, 0.0);
-    hipLaunchKernelGGL(construct_triplets_kernel, dim3(n_vid), dim3(256), 0, (hipStream_t)stream, logits, n_pcat, soid, e_off, trk_dura,
+    hipLaunchKernelGGL(construct_triplets_kernel, dim3(n_vid), dim3(NTH), 0, (hipStream_t)stream, logits, n_pcat, soid, e_off, trk_dura,
                        trk_cat, trk_score, nq, topk, quint, scores, dura, qid, n_out);
     BIGC_LAUNCH_CHECK("construct_triplets");
     return BIGC_OK;

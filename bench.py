@@ -208,9 +208,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if not args.no_prof:
-        lib.bigc_prof_reset()
-        lib.bigc_prof_enable(1)
+    # ---- the timed region: K steps, no instrumentation
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -224,10 +222,22 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    lib.bigc_prof_enable(0)
 
+    # ---- the same K steps once more with a HIP event pair around every kernel launch (on the launch stream, inside the
+    # library): per-family launch durations for the roofline.  Kept out of `value` because the ~300 event records per step
+    # cost about 4 % of a step; the instrumented wall time is reported next to it.
     families = {}
+    prof_elapsed = None
     if not args.no_prof:
+        lib.bigc_prof_reset()
+        lib.bigc_prof_enable(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        prof_elapsed = time.perf_counter() - t0
+        lib.bigc_prof_enable(0)
         _lib.check(lib.bigc_prof_collect())
         for f in range(lib.bigc_prof_family_count()):
             ms, n, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
@@ -291,7 +301,9 @@ def main():
                         launches_per_step=lin["launches"] // args.steps,
                         avg_launch_us=round(1e3 * lin["ms"] / lin["launches"], 2),
                         gflop_per_step=round(lin["flops"] / args.steps / 1e9, 1),
-                        share_of_step=round(lin["ms"] / args.steps / ms_per_step, 3))
+                        share_of_step=round(lin["ms"] / args.steps / ms_per_step, 3),
+                        measured="HIP events around each launch, over a repeat of the timed %d steps (instrumented step: %.3f ms)"
+                                 % (args.steps, 1e3 * prof_elapsed / args.steps))
     cpu_baseline = None
     if n_cpu:
         from oracle import bigc_oracle as O

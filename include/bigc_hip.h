@@ -89,6 +89,12 @@ int bigc_linear_get_exact(void);
 int bigc_layernorm_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y,
                        int rows, int d, float eps);
 
+/* LayerNorm fused with the decoder's broadcast add: y[r, :] = LayerNorm(x[r, :]) + add[r % period, :] and, when y_plain is
+ *   not NULL, y_plain[r, :] = LayerNorm(x[r, :]) as well  (norm1 followed by `query + pos_embedding`, models/model_0v10.py:187-189;
+ *   norm3 of layer i feeding `q = k = query + pos` of layer i + 1, :181).  add == NULL: plain LayerNorm (y_plain must be NULL). */
+int bigc_layernorm_add_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y, int rows, int d,
+                           float eps, const float* add, int period, float* y_plain);
+
 /* y[r, :] = x[r, :] + p[r % period, :]   (query + pos_embedding broadcast over the videos of a batch,
  *   models/model_0v10.py:182,189); x == NULL means zeros (tiles pred_query_init over the batch, :465) */
 int bigc_add_rows_f32(void* stream, const float* x, const float* p, float* y, int rows, int d, int period);

@@ -128,6 +128,26 @@ def test_layernorm(lib, rows, d):
     assert rel_err(y, F.layer_norm(x, (d,), w, b, 1e-5)) < 2e-6
 
 
+@pytest.mark.parametrize("rows,d,period,both", [(1000, 512, 192, True), (77, 512, 12, False), (50, 48, 7, True), (130, 128, 130, True)])
+def test_layernorm_add_is_layernorm_then_add_rows(lib, rows, d, period, both):
+    """fused LayerNorm + broadcast add: bit-identical to bigc_layernorm_f32 followed by bigc_add_rows_f32"""
+    g = torch.Generator().manual_seed(rows + d + period)
+    x, w, b, p = dev(torch.randn(rows, d, generator=g) * 2), dev(torch.randn(d, generator=g)), dev(torch.randn(d, generator=g)), \
+        dev(torch.randn(period, d, generator=g))
+    ln = torch.empty(rows, d, device=DEV)
+    want = torch.empty(rows, d, device=DEV)
+    _lib.check(lib.bigc_layernorm_f32(S(), x.data_ptr(), w.data_ptr(), b.data_ptr(), ln.data_ptr(), rows, d, 1e-5))
+    _lib.check(lib.bigc_add_rows_f32(S(), ln.data_ptr(), p.data_ptr(), want.data_ptr(), rows, d, period))
+    y = torch.full((rows, d), float("nan"), device=DEV)
+    plain = torch.full((rows, d), float("nan"), device=DEV)
+    _lib.check(lib.bigc_layernorm_add_f32(S(), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), rows, d, 1e-5, p.data_ptr(), period,
+                                          plain.data_ptr() if both else None))
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)
+    if both:
+        assert torch.equal(plain, ln)
+
+
 def test_add_rows(lib):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(36, 16, generator=g)
@@ -167,6 +187,39 @@ def test_mha_core(lib, hd, H, lens):
     torch.cuda.synchronize()
     assert not torch.isnan(o).any()
     assert rel_err(o, want) < 5e-6
+
+
+@pytest.mark.parametrize("lens", [[40, 64], [150, 20]])
+def test_mha_core_out_of_range_falls_back_to_f32(lib, lens):
+    """head_dim 64 runs on split f16 operands; a value beyond the f16 range (here 1e5 in v, 4e4 in k) must hand the
+    launch to the f32-MFMA kernel and give the same result as the exact mode."""
+    g = torch.Generator().manual_seed(5)
+    H, hd = 2, 64
+    d = H * hd
+    n = sum(lens)
+    qkv = torch.randn(n, 3 * d, generator=g)
+    qkv[3, 2 * d + 7] = 1e5
+    qkv[n - 2, d + 70] = -4e4
+    off = np.concatenate([[0], np.cumsum(lens)])
+    want = torch.empty(n, d, dtype=torch.float64)
+    for s in range(len(lens)):
+        a, b = off[s], off[s + 1]
+        q, k, v = (qkv[a:b, i * d:(i + 1) * d].double().reshape(-1, H, hd).transpose(0, 1) for i in range(3))
+        want[a:b] = (torch.softmax(q @ k.transpose(1, 2) / math.sqrt(hd), -1) @ v).transpose(0, 1).reshape(-1, d)
+    qd, offd = dev(qkv), i32(off)
+    outs = []
+    for exact in (0, 1):
+        prev = lib.bigc_linear_set_exact(exact)
+        try:
+            o = torch.full((n, d), float("nan"), device=DEV)
+            _lib.check(lib.bigc_mha_core_f32(S(), qd.data_ptr(), 3 * d, qd.data_ptr() + 4 * d, 3 * d, qd.data_ptr() + 8 * d, 3 * d,
+                                             o.data_ptr(), d, offd.data_ptr(), offd.data_ptr(), len(lens), max(lens), H, hd, None))
+            torch.cuda.synchronize()
+        finally:
+            lib.bigc_linear_set_exact(prev)
+        outs.append(o.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0], want.float()) < 5e-6
 
 
 def test_mha_core_cross_lengths(lib):

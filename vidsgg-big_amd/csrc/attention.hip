@@ -17,6 +17,10 @@
 // Operands come straight from L2 (the whole working set of a video is < 1 MB).
 #include "common.h"
 #include "prof.h"
+#include <atomic>
+#include <mutex>
+
+extern "C" int bigc_linear_get_exact(void);
 
 namespace {
 
@@ -148,9 +152,10 @@ __global__ __launch_bounds__(256) void mha_core_sp_kernel(const float* __restric
                                                           const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
                                                           const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
                                                           int n_seq, int n_qt, int n_head, float scale, float* __restrict__ lse,
-                                                          const DropSpec drop) {
+                                                          const DropSpec drop, const int* __restrict__ run_flag, int run_id) {
     constexpr int HALF = HD / 2;
     constexpr int NTD = (HD + 31) / 32;
+    if (run_flag && *run_flag != run_id) return;        // fallback launch behind attention_split.hip: only when that one flagged
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const long item = (long)blockIdx.x * 4 + wave;
@@ -547,6 +552,29 @@ extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, con
                                       float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
                                       int n_head, int hd, float* lse, float drop_p, uint32_t drop_seed, uint32_t drop_site);
 
+int bigc_mha_core_h_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                           const int32_t* q_off, const int32_t* k_off, int n_seq, int n_qt, int n_head, float scale, float* lse,
+                           const DropSpec& drop, int grid, int* flag, int run_id);
+
+namespace {
+// BIGC_LINEAR_EXACT / bigc_linear_set_exact also select the f32-MFMA attention kernels
+std::atomic<int> g_mha_run{0};
+constexpr int MHA_SLOTS = 1024;
+std::mutex g_mha_mu;
+int* g_mha_flags[64] = {};
+// one flag word per launch (ring of MHA_SLOTS): the split kernel writes its run id there when an operand is out of range
+int* mha_flag_slot(int run_id) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(g_mha_mu);
+    if (!g_mha_flags[dev]) {
+        if (hipMalloc((void**)&g_mha_flags[dev], MHA_SLOTS * sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemset(g_mha_flags[dev], 0, MHA_SLOTS * sizeof(int)) != hipSuccess) return nullptr;
+    }
+    return g_mha_flags[dev] + (run_id % MHA_SLOTS);
+}
+}  // namespace
+
 extern "C" int bigc_mha_core_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                  float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
                                  int n_head, int hd, float* lse) {
@@ -568,10 +596,19 @@ extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, con
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(stream, FAM_MHA, 0.0, 0.0);
 #define LAUNCH_MHA(HD) hipLaunchKernelGGL(mha_core_kernel<HD>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop)
-#define LAUNCH_SP(HD, NKT) hipLaunchKernelGGL((mha_core_sp_kernel<HD, NKT>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop)
+#define LAUNCH_SP(HD, NKT) hipLaunchKernelGGL((mha_core_sp_kernel<HD, NKT>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, run_flag, run_id)
     // self-attention (same offsets for queries and keys): the longest key sequence is max_q, known on the host ->
     // single-pass kernel with the scores in registers when it fits
     const int nkt = (q_off == k_off) ? n_qt : 1 << 30;
+    // head_dim 64: split-operand f16 MFMA kernel first; the f32-MFMA kernel behind it runs only if an operand was out of range
+    int* run_flag = nullptr;
+    int run_id = 0;
+    if (hd == 64 && nkt <= 6 && ldv % 2 == 0 && ldo % 2 == 0 && !bigc_linear_get_exact()) {
+        run_id = g_mha_run.fetch_add(1, std::memory_order_relaxed) + 1;
+        run_flag = mha_flag_slot(run_id);
+        if (!run_flag) return BIGC_ERR_HIP;
+        bigc_mha_core_h_launch(s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, grid, run_flag, run_id);
+    }
     if (hd == 64 && nkt <= 2) LAUNCH_SP(64, 2);
     else if (hd == 64 && nkt <= 6) LAUNCH_SP(64, 6);
     else if (hd == 16 && nkt <= 2) LAUNCH_SP(16, 2);

@@ -1,0 +1,201 @@
+// Attention core for head_dim 64 on the f16 matrix cores with exactly split f32 operands (the scheme of linear_split.hip):
+// every f32 operand x = h + r * 2^-11 (h = f16(x) leading bits, r = f16 of the scaled remainder), a product costs three
+// v_mfma_f32_32x32x16_f16 (h h, h r, r h) accumulated in f32 in two accumulators -- f32-level error at 1/5 of the MFMA
+// cycles of the f32-MFMA kernels in attention.hip.  Same organisation as mha_core_sp_kernel: one wave per (sequence, head,
+// 32-query tile), transposed score tiles S^T = K Q^T so that a lane owns one query column, all score tiles of the (short)
+// sequence in registers, softmax exactly as torch (exp(s - max) / sum), then O = P V with the probabilities -- already in
+// the A-operand layout -- split on the fly.
+//
+// Operand slots of v_mfma_f32_32x32x16: lane l supplies A[row l&31][slots 8(l>>5) + j] and B[slots 8(l>>5) + j][col l&31],
+// j = 0..7; which contraction index a slot stands for is free as long as A and B agree:
+//   S^T:  slot (hi, j) of step s  <->  head dimension 16 s + 8 hi + j            (8 consecutive floats of a K / Q row)
+//   P V:  slot (hi, j) of step u  <->  key 16 u + 8 (j>>2) + 4 hi + (j&3)        (= accumulator register 8 u + j of S^T)
+// Range: an operand with |x| >= 32768 (or NaN/Inf) raises `flag`; the launcher runs the f32-MFMA kernel right behind,
+// which only does work when the flag carries this launch's id.
+#include "common.h"
+#include "prof.h"
+
+typedef _Float16 a16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 a16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr float NEG_BIG = -1e30f;
+constexpr float RS = 2048.0f, RI = 1.0f / 2048.0f;
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// 8 floats -> 8 heads + 8 scaled residuals; `amax` / `chk` track the range as in linear_split.hip
+__device__ __forceinline__ void split8(const float (&x)[8], a16x8& h, a16x8& r, float& chk, float& amax) {
+    union { a16x2 p[4]; a16x8 v; } hh, rr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x[2 * j], b = x[2 * j + 1];
+        hh.p[j] = __builtin_amdgcn_cvt_pkrtz(a, b);
+        const float ra = (a - (float)hh.p[j][0]) * RS, rb = (b - (float)hh.p[j][1]) * RS;
+        rr.p[j] = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+        chk += ra + rb;
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(amax) : "v"(amax), "v"(a), "v"(b));
+    }
+    h = hh.v;
+    r = rr.v;
+}
+
+#define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void mha_core_h_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                         const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
+                                                         const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
+                                                         int n_seq, int n_qt, int n_head, float scale, float* __restrict__ lse,
+                                                         const DropSpec drop, int* __restrict__ flag, int run_id) {
+    constexpr int HD = 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n_seq * n_qt * n_head) return;
+    const int h = item % n_head;
+    const int qt = (item / n_head) % n_qt;
+    const int s = item / ((long)n_head * n_qt);
+    const int q0 = q_off[s], nq = q_off[s + 1] - q0;
+    const int k0 = k_off[s], nk = k_off[s + 1] - k0;
+    if (qt * 32 >= nq || nk <= 0) return;
+    const int n_kt = (nk + 31) / 32;
+    const int qrow = min(qt * 32 + l31, nq - 1);
+    float chk = 0.f, amax = 0.f;
+
+    // this lane's query row, its four 8-float chunks (head dims 16 s + 8 hi ..), pre-scaled and split
+    a16x8 qh[4], qr[4];
+    {
+        const float* qp = q + (size_t)(q0 + qrow) * ldq + h * HD + 8 * hi;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const f32x4 t0 = *(const f32x4*)(qp + 16 * st), t1 = *(const f32x4*)(qp + 16 * st + 4);
+            const float x[8] = {t0[0] * scale, t0[1] * scale, t0[2] * scale, t0[3] * scale, t1[0] * scale, t1[1] * scale, t1[2] * scale, t1[3] * scale};
+            split8(x, qh[st], qr[st], chk, amax);
+        }
+    }
+
+    // ---- scores: S^T[key][query], all tiles kept
+    f32x16 sc[NKT];
+    float m = NEG_BIG;
+    const float* kbase = k + (size_t)k0 * ldk + h * HD + 8 * hi;
+    f32x4 ka[8], kb[8];
+    auto fetch_k = [&](int kt, f32x4 (&kv)[8]) {
+        const float* kp = kbase + (size_t)min(min(kt, n_kt - 1) * 32 + l31, nk - 1) * ldk;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) { kv[2 * st] = *(const f32x4*)(kp + 16 * st); kv[2 * st + 1] = *(const f32x4*)(kp + 16 * st + 4); }
+    };
+    auto score = [&](int kt, const f32x4 (&kv)[8]) {
+        f32x16 c0 = zero16(), c1 = zero16();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const float x[8] = {kv[2 * st][0], kv[2 * st][1], kv[2 * st][2], kv[2 * st][3], kv[2 * st + 1][0], kv[2 * st + 1][1], kv[2 * st + 1][2], kv[2 * st + 1][3]};
+            a16x8 kh, kr;
+            split8(x, kh, kr, chk, amax);
+            c0 = MFMA_H(kh, qh[st], c0);
+            c1 = MFMA_H(kh, qr[st], c1);
+            c1 = MFMA_H(kr, qh[st], c1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[kt][r] = c0[r] + c1[r] * RI;
+            if (kt * 32 + mfma_row(r, hi) < nk) m = fmaxf(m, sc[kt][r]);
+        }
+    };
+    fetch_k(0, ka);
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt += 2) {
+        if (kt < n_kt) { fetch_k(kt + 1, kb); score(kt, ka); } else { sc[kt] = zero16(); }
+        if (kt + 1 < NKT) {
+            if (kt + 1 < n_kt) { fetch_k(kt + 2, ka); score(kt + 1, kb); } else { sc[kt + 1] = zero16(); }
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = kt < n_kt && kt * 32 + mfma_row(r, hi) < nk;
+            const float e = ok ? expf(sc[kt][r] - m) : 0.f;
+            sc[kt][r] = e;
+            l += e;
+        }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    if (lse && hi == 0 && qt * 32 + l31 < nq) lse[(size_t)(q0 + qt * 32 + l31) * n_head + h] = m + logf(l);
+
+    // ---- O = P V: output column c of d-tile t is head column 2 c + t (one 8-byte load per key row, one 8-byte store per query row)
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    f32x16 o0[2], o1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { o0[t] = zero16(); o1[t] = zero16(); }
+    const float* vbase = v + (size_t)k0 * ldv + h * HD + 2 * l31;
+    v2 va[16], vb[16];
+    auto fetch_v = [&](int kt, v2 (&vv)[16]) {
+        kt = min(kt, n_kt - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = *(const v2*)(vbase + (size_t)min(kt * 32 + mfma_row(r, hi), nk - 1) * ldv);
+    };
+    auto pv_tile = [&](int kt, const v2 (&vv)[16]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float p8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float p = sc[kt][8 * u + j] * inv;
+                if (drop.thresh) p = drop_keep(drop, drop_att_idx(q0 + qrow, n_head, h, kt * 32 + mfma_row(8 * u + j, hi))) ? p * drop.scale : 0.f;
+                p8[j] = p;
+            }
+            a16x8 ph, pr;
+            float c_ = 0.f, a_ = 0.f;                         // probabilities are in [0, 1 / (1 - p_drop)]: no range check needed
+            split8(p8, ph, pr, c_, a_);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float v8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v8[j] = vv[8 * u + j][t];
+                a16x8 vh, vr;
+                split8(v8, vh, vr, chk, amax);
+                o0[t] = MFMA_H(ph, vh, o0[t]);
+                o1[t] = MFMA_H(ph, vr, o1[t]);
+                o1[t] = MFMA_H(pr, vh, o1[t]);
+            }
+        }
+    };
+    fetch_v(0, va);
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt += 2) {
+        if (kt < n_kt) { fetch_v(kt + 1, vb); pv_tile(kt, va); }
+        if (kt + 1 < NKT && kt + 1 < n_kt) { fetch_v(kt + 2, va); pv_tile(kt + 1, vb); }
+    }
+    if (!(fabsf(chk) < INFINITY) || amax >= 32768.0f) atomicMax(flag, run_id);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = qt * 32 + mfma_row(r, hi);
+        if (row < nq) {
+            v2 ov;
+            ov[0] = o0[0][r] + o1[0][r] * RI;
+            ov[1] = o0[1][r] + o1[1][r] * RI;
+            *(v2*)(o + (size_t)(q0 + row) * ldo + h * HD + 2 * l31) = ov;
+        }
+    }
+}
+
+}  // namespace
+
+// launches the split kernel when it applies (head_dim 64, self-attention of at most 192 keys); returns 1 if launched
+int bigc_mha_core_h_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                           const int32_t* q_off, const int32_t* k_off, int n_seq, int n_qt, int n_head, float scale, float* lse,
+                           const DropSpec& drop, int grid, int* flag, int run_id) {
+    if (n_qt <= 2) hipLaunchKernelGGL(mha_core_h_kernel<2>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
+    else if (n_qt <= 6) hipLaunchKernelGGL(mha_core_h_kernel<6>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
+    else return 0;
+    return 1;
+}

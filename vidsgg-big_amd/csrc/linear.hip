@@ -179,6 +179,43 @@ __global__ __launch_bounds__(256, OCC) void linear_f32_kernel(const LinearArgs p
     }
 }
 
+// K = 8 (fc_bbox2enti.0, models/model_0v10.py:290-294: the 8 box coordinates -> dim_enti): 16 flops per output element,
+// so the kernel is bound by writing C (4 N bytes per row against 32 bytes read).  Plain f32 FMAs: a thread keeps the
+// weights of four adjacent output columns in registers and walks down the rows of its block; a wave writes 1 KB
+// contiguous per row.  RL = 256 / (N / 4) rows are in flight per pass.
+constexpr int SK_ROWS = 128;     // rows per workgroup
+__global__ __launch_bounds__(256) void linear_k8_kernel(const LinearArgs p) {
+    const int cg = p.N >> 2, c4 = threadIdx.x % cg, rl = threadIdx.x / cg, nrl = 256 / cg;
+    f32x4 w0[4], w1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float* wp = p.W + (size_t)(4 * c4 + j) * p.ldw;
+        w0[j] = *(const f32x4*)wp;
+        w1[j] = *(const f32x4*)(wp + 4);
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *(const f32x4*)(p.bias + 4 * c4);
+    const bool relu = p.act == BIGC_ACT_RELU, sigm = p.act == BIGC_ACT_SIGMOID;
+    const int r0 = blockIdx.x * SK_ROWS, r1 = min(r0 + SK_ROWS, p.M);
+    for (int r = r0 + rl; r < r1; r += nrl) {
+        const float* ap = p.A + (size_t)r * p.lda;
+        const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = a0[0] * w0[j][0];
+            v = fmaf(a0[1], w0[j][1], v); v = fmaf(a0[2], w0[j][2], v); v = fmaf(a0[3], w0[j][3], v);
+            v = fmaf(a1[0], w1[j][0], v); v = fmaf(a1[1], w1[j][1], v); v = fmaf(a1[2], w1[j][2], v); v = fmaf(a1[3], w1[j][3], v);
+            v += bv[j];
+            if (relu) v = fmaxf(v, 0.f);
+            if (sigm) v = 1.0f / (1.0f + expf(-v));
+            o[j] = v;
+        }
+        if (p.res) o += *(const f32x4*)(p.res + (size_t)r * p.ldr + 4 * c4);
+        *(f32x4*)(p.C + (size_t)r * p.ldc + 4 * c4) = o;
+    }
+}
+
 }  // namespace
 
 // 0: split-operand f16 MFMA kernel (default), 1: exact f32 MFMA kernel; initialised from BIGC_LINEAR_EXACT
@@ -209,6 +246,14 @@ extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int3
     static const int force_bk = getenv("BIGC_LINEAR_BK") ? atoi(getenv("BIGC_LINEAR_BK")) : 0;
     const bool exact_only = g_exact_mode.load() != 0;
     p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr; p.zero_row = nullptr;
+    // K = 8 with a vector-friendly layout: the store-bound FMA kernel (both modes; exact f32)
+    if (K == 8 && !a_idx && N % 4 == 0 && N <= 1024 && 256 % (N / 4) == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&
+        (!bias || ((uintptr_t)bias & 15) == 0) && (!residual || (ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0))) {
+        ProfScope ps(stream, FAM_LINEAR_AUX, flops, bytes);
+        hipLaunchKernelGGL(linear_k8_kernel, dim3(cdiv(M, SK_ROWS)), dim3(256), 0, s, p);
+        BIGC_LAUNCH_CHECK("linear_k8");
+        return BIGC_OK;
+    }
     if (!exact_only) return bigc_linear_split_launch(s, p, flops, bytes);   // f16 MFMAs on split operands, in-kernel range fallback
     ProfScope ps(stream, FAM_LINEAR, flops, bytes);
     // measured on MI355X (benchmarks/linear_shapes.py): NT=2 119 TFLOP/s aggregate, NT=4 112 -> NT=2 by default

@@ -296,17 +296,17 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         // result (after `query += pos`) is tiled over the batch. Later layers run on all B*Q rows.
         const int rows = (i == 0) ? Q : BQ, nseq = (i == 0) ? 1 : B;
         const float* qin = (i == 0) ? m->qinit : w.query;
-        TRY(bigc_add_rows_f32(s, qin, m->pos, w.qk_in, rows, dp, Q));
+        // layers > 0: qk_in = query + pos was written by the previous layer's last LayerNorm
+        if (i == 0) TRY(bigc_add_rows_f32(s, qin, m->pos, w.qk_in, rows, dp, Q));
         TRY(linear(s, w.qk_in, dp, qkp, w.qk, 2 * dp, rows, 2 * dp, dp, BIGC_ACT_NONE));
         TRY(linear(s, qin, dp, vp, w.vv, dp, rows, dp, dp, BIGC_ACT_NONE));
         TRY(bigc_mha_core_f32(s, w.qk, 2 * dp, w.qk + dp, 2 * dp, w.vv, dp, w.ao2, dp, w.q_off, w.q_off, nseq, Q, H, dp / H, nullptr));
         TRY(linear(s, w.ao2, dp, L.out_proj, w.t2, dp, rows, dp, dp, BIGC_ACT_NONE, qin, dp));
-        TRY(bigc_layernorm_f32(s, w.t2, L.n1.g, L.n1.b, w.t3, rows, dp, eps));
         if (i == 0) {
-            TRY(bigc_add_rows_f32(s, w.t3, m->pos, w.qk_in, Q, dp, Q));
+            TRY(bigc_layernorm_add_f32(s, w.t2, L.n1.g, L.n1.b, w.qk_in, Q, dp, eps, m->pos, Q, nullptr));
             TRY(bigc_add_rows_f32(s, nullptr, w.qk_in, w.query, BQ, dp, Q));
         } else {
-            TRY(bigc_add_rows_f32(s, w.t3, m->pos, w.query, BQ, dp, Q));        // query += pos, kept (:189)
+            TRY(bigc_layernorm_add_f32(s, w.t2, L.n1.g, L.n1.b, w.query, BQ, dp, eps, m->pos, Q, nullptr));   // query += pos, kept (:189)
         }
         TRY(linear(s, enco, de, L.e2a, w.e2a, da, NT, da, de, BIGC_ACT_NONE));
         TRY(linear(s, w.query, dp, L.p2a, w.p2a, da, BQ, da, dp, BIGC_ACT_NONE));
@@ -326,7 +326,8 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         TRY(bigc_layernorm_f32(s, w.t3, L.n2.g, L.n2.b, w.t2, BQ, dp, eps));
         TRY(linear(s, w.t2, dp, L.f0, w.rh, df, BQ, df, dp, BIGC_ACT_RELU));
         TRY(linear(s, w.rh, df, L.f3, w.t3, dp, BQ, dp, df, BIGC_ACT_NONE, w.t2, dp));
-        TRY(bigc_layernorm_f32(s, w.t3, L.n3.g, L.n3.b, w.query, BQ, dp, eps));
+        if (i + 1 < c.n_deco_layers) TRY(bigc_layernorm_add_f32(s, w.t3, L.n3.g, L.n3.b, w.qk_in, BQ, dp, eps, m->pos, Q, w.query));
+        else TRY(bigc_layernorm_f32(s, w.t3, L.n3.g, L.n3.b, w.query, BQ, dp, eps));
     }
     if (out->pred_query) {
         hipError_t e = hipMemcpyAsync(out->pred_query, w.query, sizeof(float) * (size_t)BQ * dp, hipMemcpyDeviceToDevice, hs);

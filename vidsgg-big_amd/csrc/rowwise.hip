@@ -13,8 +13,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // torch.nn.LayerNorm: biased variance, eps inside the sqrt (reference: models/model_0v10.py:81-82,171-173)
+// Optional fused broadcast add (the decoder's `query + pos_embedding`, models/model_0v10.py:181,189): with `add`,
+// y = LN(x) + add[row % period] and, when y_plain is given, y_plain = LN(x) as well.
+template <bool ADD>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                                                        float* __restrict__ y, int rows, int d, float eps) {
+                                                        float* __restrict__ y, int rows, int d, float eps,
+                                                        const float* __restrict__ add, int period, float* __restrict__ y_plain) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -53,6 +57,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             f32x4 o;
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = (v[j][c] - mean) * rstd * gg[c] + bb[c];
+            if (ADD) {
+                if (y_plain) ((f32x4*)(y_plain + (size_t)row * d))[i] = o;
+                o += ((const f32x4*)(add + (size_t)(row % period) * d))[i];
+            }
             yp[i] = o;
         }
     }
@@ -61,9 +69,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // Specialised form for d = 4 * G * NVL with G (lanes per row) a power of two <= 64: a wave holds 64 / G rows side by side
 // and UNR such groups in flight (all loads of a wave-iteration are issued before the first reduction), statistics by
 // butterfly shuffles inside the G-lane group.  Same arithmetic order per element as the generic kernel.
-template <int G, int NVL, int UNR>
+template <int G, int NVL, int UNR, bool ADD>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                                                             float* __restrict__ y, int rows, float eps) {
+                                                             float* __restrict__ y, int rows, float eps,
+                                                             const float* __restrict__ add, int period, float* __restrict__ y_plain) {
     constexpr int RPW = 64 / G;                    // rows per wave pass
     constexpr int D4 = G * NVL;                    // float4 per row
     const int lane = threadIdx.x & 63, sub = lane / G, gl = lane % G;
@@ -80,6 +89,15 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     f32x4 gg[NVL], bb[NVL];
 #pragma unroll
     for (int j = 0; j < NVL; ++j) { gg[j] = ((const f32x4*)g)[gl + G * j]; bb[j] = ((const f32x4*)b)[gl + G * j]; }
+    f32x4 av[ADD ? UNR : 1][NVL];
+    if (ADD) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const f32x4* ap = (const f32x4*)add + (size_t)(min(row0 + u * RPW, rows - 1) % period) * D4;
+#pragma unroll
+            for (int j = 0; j < NVL; ++j) av[u][j] = ap[gl + G * j];
+        }
+    }
     auto gsum = [](float t) {
 #pragma unroll
         for (int o = G / 2; o >= 1; o >>= 1) t += __shfl_xor(t, o);
@@ -105,6 +123,10 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
                 f32x4 o;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) o[c] = (v[u][j][c] - mean) * rstd * gg[j][c] + bb[j][c];
+                if (ADD) {
+                    if (y_plain) ((f32x4*)y_plain + (size_t)row * D4)[gl + G * j] = o;
+                    o += av[u][j];
+                }
                 yp[gl + G * j] = o;
             }
         }
@@ -135,22 +157,31 @@ int bigc_fill_offsets(hipStream_t s, int32_t* p, int n, int step) {
     return BIGC_OK;
 }
 
-extern "C" int bigc_layernorm_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y,
-                                  int rows, int d, float eps) {
+extern "C" int bigc_layernorm_add_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y, int rows, int d,
+                                      float eps, const float* add, int period, float* y_plain) {
     BIGC_CHECK_ARG(x && gamma && beta && y, "layernorm: null pointer");
     BIGC_CHECK_ARG(d > 0 && d % 4 == 0 && d <= 2048, "layernorm: d=%d must be a multiple of 4 and <= 2048", d);
+    BIGC_CHECK_ARG(add ? period > 0 : !y_plain, "layernorm: add needs a period, y_plain needs add");
     if (rows <= 0) return BIGC_OK;
-    ProfScope ps(stream, FAM_LAYERNORM, 0.0, 8.0 * rows * (double)d);
+    ProfScope ps(stream, FAM_LAYERNORM, 0.0, (y_plain ? 12.0 : 8.0) * rows * (double)d);
     hipStream_t hs = (hipStream_t)stream;
-#define LN_ROWS(G, NVL, UNR) hipLaunchKernelGGL((layernorm_rows_kernel<G, NVL, UNR>), dim3(cdiv(rows, 4 * (64 / G) * UNR)), dim3(256), 0, hs, x, gamma, beta, y, rows, eps)
+#define LN_ROWS_(G, NVL, UNR, ADD) hipLaunchKernelGGL((layernorm_rows_kernel<G, NVL, UNR, ADD>), dim3(cdiv(rows, 4 * (64 / G) * UNR)), dim3(256), 0, hs, x, gamma, beta, y, rows, eps, add, period, y_plain)
+#define LN_ROWS(G, NVL, UNR) do { if (add) LN_ROWS_(G, NVL, UNR, true); else LN_ROWS_(G, NVL, UNR, false); } while (0)
     if (d == 512) LN_ROWS(64, 2, 4);
     else if (d == 256) LN_ROWS(64, 1, 4);
     else if (d == 128) LN_ROWS(32, 1, 4);
     else if (d == 64) LN_ROWS(16, 1, 4);
-    else hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, hs, x, gamma, beta, y, rows, d, eps);
+    else if (add) hipLaunchKernelGGL(layernorm_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, hs, x, gamma, beta, y, rows, d, eps, add, period, y_plain);
+    else hipLaunchKernelGGL(layernorm_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, hs, x, gamma, beta, y, rows, d, eps, add, period, y_plain);
 #undef LN_ROWS
+#undef LN_ROWS_
     BIGC_LAUNCH_CHECK("layernorm");
     return BIGC_OK;
+}
+
+extern "C" int bigc_layernorm_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y,
+                                  int rows, int d, float eps) {
+    return bigc_layernorm_add_f32(stream, x, gamma, beta, y, rows, d, eps, nullptr, 0, nullptr);
 }
 
 extern "C" int bigc_add_rows_f32(void* stream, const float* x, const float* p, float* y, int rows, int d, int period) {

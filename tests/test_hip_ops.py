@@ -290,6 +290,37 @@ def test_role_attention_and_values(lib, nq, half, d, ns):
         assert torch.equal(vals2, vals3)
 
 
+def test_role_fused_out_of_range_falls_back_to_f32(lib):
+    """operands beyond the f16 range (enco 2e5, p2a 5e4): the split-f16 role kernel must hand over to the f32-MFMA kernel and
+    give the result of the exact mode"""
+    g = torch.Generator().manual_seed(11)
+    B, nq, half, d, ns = 2, 40, 64, 64, [50, 9]
+    NT = sum(ns)
+    p2a = torch.randn(B * nq, 2 * half, generator=g)
+    e2a = torch.randn(NT, 2 * half, generator=g)
+    enco = torch.randn(NT, d, generator=g)
+    enco[3, 5] = 2e5
+    p2a[41, 70] = 5e4
+    e2a[52, 70] = 1e-3
+    off = np.concatenate([[0], np.cumsum(ns)])
+    scale = 1.0 / math.sqrt(d)
+    pd, ed, xd, offd = dev(p2a), dev(e2a), dev(enco), i32(off)
+    outs = []
+    for exact in (0, 1):
+        prev = lib.bigc_linear_set_exact(exact)
+        try:
+            att = torch.full((2 * nq * NT,), float("nan"), device=DEV)
+            vals = torch.full((2, B * nq, d), float("nan"), device=DEV)
+            _lib.check(lib.bigc_role_fused_f32(S(), pd.data_ptr(), 2 * half, ed.data_ptr(), 2 * half, xd.data_ptr(), d, att.data_ptr(),
+                                               vals.data_ptr(), offd.data_ptr(), B, nq, max(ns), half, d, scale))
+            torch.cuda.synchronize()
+        finally:
+            lib.bigc_linear_set_exact(prev)
+        outs.append((att.cpu(), vals.cpu()))
+    assert not torch.isnan(outs[0][1]).any()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def _ragged(lens_per_vid, tmax_extra=0, seed=0, width=24):
     g = torch.Generator().manual_seed(seed)
     lens = [l for v in lens_per_vid for l in v]

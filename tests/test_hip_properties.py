@@ -83,15 +83,43 @@ def test_topk_subset_and_gemm_modes_agree(setup):
     for a, b in zip(r3, r10):
         big = set(tuple(x) for x in b[0])
         assert all(tuple(x) in big for x in a[0])                                    # top-3 candidates are among the top-10
+    # the two arithmetic modes (split-f16 MFMAs / exact f32 MFMAs) agree on every index, except where the decision itself is
+    # a tie at f32 resolution: an arg-max over entities between two attention weights closer than 1e-4 relative (at most a
+    # handful of the 2 * 192 * 12 decisions), or the arg-max over the queries that predicted the same triplet
     lib = _lib.load()
+    packed = PackedBatch(props, torch.device(DEV))
+    Q = cfg["num_querys"]
+
+    def run():
+        out = model.forward_packed(packed, 10)
+        torch.cuda.synchronize()
+        return {k: v.cpu().numpy() for k, v in out.items()}
+    o_split = run()
     prev = lib.bigc_linear_set_exact(1)
     try:
-        rex = [as_np(r) for r in model(props, topk=10)]
+        o_exact = run()
     finally:
         lib.bigc_linear_set_exact(prev)
-    for a, b in zip(r10, rex):
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
-        assert np.abs(a[1] - b[1]).max() < 5e-5
+    off = packed.vid_trk_off.cpu().numpy()
+    flips = np.argwhere(o_split["soid"] != o_exact["soid"])
+    assert len(flips) <= 6, len(flips)
+    for v, r, q in flips:
+        e0, ne = int(off[v]), int(off[v + 1] - off[v])
+        row = o_exact["att"][2 * Q * e0 + (r * Q + q) * ne: 2 * Q * e0 + (r * Q + q + 1) * ne]
+        a, b = row[o_split["soid"][v, r, q]], row[o_exact["soid"][v, r, q]]
+        assert abs(a - b) <= 1e-4 * max(a, b), (v, r, q, a, b)
+    clean = [v for v in range(N_VID) if v not in set(flips[:, 0].tolist())]
+    assert len(clean) >= N_VID - 3
+    assert np.abs(o_split["pred_logits"] - o_exact["pred_logits"]).max() <= 1e-4 * np.abs(o_exact["pred_logits"]).max() or len(flips) > 0
+    for v in clean:
+        n = int(o_exact["n_out"][v])
+        assert n == int(o_split["n_out"][v])
+        assert np.array_equal(o_split["quint"][v, :n], o_exact["quint"][v, :n]) and np.array_equal(o_split["dura"][v, :n], o_exact["dura"][v, :n])
+        assert np.abs(o_split["scores"][v, :n] - o_exact["scores"][v, :n]).max() < 5e-5
+        differ = o_split["qid"][v, :n] != o_exact["qid"][v, :n]
+        assert differ.mean() <= 0.01, differ.sum()
+        sa, sb = o_split["scores"][v, :n][differ, 0], o_exact["scores"][v, :n][differ, 0]
+        assert np.all(np.abs(sa - sb) <= 2e-6 * np.abs(sb))
 
 
 def test_gemm_linearity_at_full_size():

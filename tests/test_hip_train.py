@@ -263,8 +263,13 @@ def test_train_step_vs_reference_golden(name):
         if "grad_" + k in g.files:
             ref = g["grad_" + k]
             worst[k] = max(worst[k], float(np.abs(p.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-12)))
-    bad = {k: v for k, v in worst.items() if v > 5e-4}
+    # Typical deviation is ~1e-5.  A ReLU whose pre-activation lies within f32 rounding of zero may take the other branch
+    # than in the reference run (either is a valid subgradient); one such unit changes the gradient of its own layer by
+    # ~2e-3 and everything upstream of it by a few 1e-4 (measured: decoder layer 3's fc2.0 against the exact-GEMM mode).
+    # So: every parameter within 3e-3, and half of them within 1e-4.
+    bad = {k: v for k, v in worst.items() if v > 3e-3}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+    assert float(np.median(list(worst.values()))) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:10]
 
 
 def test_train_step_then_optimizer_like_the_reference_loop():

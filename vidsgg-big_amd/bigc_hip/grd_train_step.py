@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .train_step import grad_scale
 
 LOSS_KEYS = ("pos_cls", "neg_cls", "pos_ct", "neg_ct", "regr")        # order of the reference's loss_dict (:520-526)
 
@@ -149,6 +150,12 @@ def loss_grad(model, engine, ctx, gs):
 def backward(model, engine, ctx, grad_terms, named_params):
     """HIP backward of every video; returns one gradient per entry of ``named_params`` (views of one flat buffer)."""
     loss_grad(model, engine, ctx, grad_terms.detach().cpu().tolist())
+    # power-of-two scaling of the seed gradients for the split-operand backward GEMMs (see train_step.backward)
+    seeds = [t for v in ctx.vids for t in (v.dregr, v.dconf, v.dcls)]
+    scale = grad_scale(*seeds)
+    if scale != 1.0:
+        for t in seeds:
+            t.mul_(scale)
     dev = ctx.vids[0].feat.device
     trainable = [(k, p) for k, p in named_params if p.requires_grad]
     sizes = [(p.numel() + 3) // 4 * 4 for _, p in trainable]
@@ -166,6 +173,8 @@ def backward(model, engine, ctx, grad_terms, named_params):
         _lib.check(engine.lib.grd_set_dropout(engine.handle, v.drop[0], v.drop[1]))       # the masks of this video's forward
         _lib.check(engine.lib.grd_train_backward(engine.handle, stream, v.feat.data_ptr(), v.T, v.quint.data_ptr(), v.n, v.ws.data_ptr(),
                                                  v.ws.numel(), v.dregr.data_ptr(), v.dconf.data_ptr(), v.dcls.data_ptr()))
+    if scale != 1.0:
+        flat.mul_(1.0 / scale)
     engine.last_flat_grad = flat
     return [views.get(k) for k, _ in named_params]
 

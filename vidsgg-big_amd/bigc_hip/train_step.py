@@ -9,6 +9,8 @@ The result is exposed as a ``torch.autograd.Function`` so that ``loss.backward()
 ``optimizer.step()`` of the reference's training loop work unchanged.
 """
 import ctypes
+import math
+import os
 
 import numpy as np
 import torch
@@ -128,11 +130,30 @@ def loss_grad(model, engine, ctx, gs_pos, gs_neg, gs_adj):
         ctx.loss.data_ptr(), ctx.dlogits.data_ptr(), ctx.ldg, ctx.datt.data_ptr()))
 
 
+def grad_scale(*seeds, target_log2=3):
+    """power of two that brings the largest seed-gradient magnitude to about 2**target_log2 (1.0 when the seeds are all
+    zero or not finite)"""
+    seeds = [t for t in seeds if t is not None and t.numel()]
+    if not seeds or os.environ.get("BIGC_GRAD_SCALE", "1") == "0":
+        return 1.0
+    amax = float(torch.stack([t.abs().max() for t in seeds]).max())          # one host sync
+    if not (amax > 0.0) or not math.isfinite(amax):
+        return 1.0
+    return 2.0 ** (target_log2 - math.ceil(math.log2(amax)))
+
+
 def backward(model, engine, ctx, grad_terms, named_params):
     """Runs the HIP backward; returns one gradient tensor per entry of ``named_params`` (views of a single flat
     buffer -- the message of the data-parallel all-reduce), ``None`` for frozen parameters."""
     g = [float(x) for x in grad_terms.detach().cpu().tolist()]
     loss_grad(model, engine, ctx, g[0], g[1], g[2])
+    # The backward GEMMs split their f32 operands into two f16 (csrc/linear_split.hip): exact for magnitudes inside the
+    # f16 range, so the seed gradients are brought to a magnitude of ~8 by a power of two (exact) and the parameter
+    # gradients scaled back at the end -- the loss scaling of mixed-precision training, here only to keep f32 accuracy.
+    scale = grad_scale(ctx.dlogits, ctx.datt)
+    if scale != 1.0:
+        ctx.dlogits.mul_(scale)
+        ctx.datt.mul_(scale)
     trainable = [(k, p) for k, p in named_params if p.requires_grad]
     total = sum(p.numel() for _, p in trainable)
     flat = torch.zeros((total,), dtype=torch.float32, device=ctx.packed.device)
@@ -145,6 +166,8 @@ def backward(model, engine, ctx, grad_terms, named_params):
         off += n
     _lib.check(engine.lib.bigc_train_backward(engine.handle, _lib.current_stream(), ctypes.byref(ctx.batch), ctx.ws.data_ptr(),
                                               ctx.ws.numel(), ctx.dlogits.data_ptr(), ctx.ldg, ctx.datt.data_ptr()))
+    if scale != 1.0:
+        flat.mul_(1.0 / scale)
     engine.last_flat_grad = flat
     return [views.get(k) for k, _ in named_params]
 

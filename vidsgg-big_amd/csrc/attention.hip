@@ -417,7 +417,9 @@ template <int NET>
 __global__ __launch_bounds__(256) void role_fused_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
                                                          const float* __restrict__ enco, int ldenc, float* __restrict__ att,
                                                          float* __restrict__ values, const int32_t* __restrict__ e_off,
-                                                         int n_vid, int nq, int n_qt, int half, int d, float scale) {
+                                                         int n_vid, int nq, int n_qt, int half, int d, float scale,
+                                                         const int* __restrict__ run_flag, int run_id) {
+    if (run_flag && *run_flag != run_id) return;        // fallback launch behind role_fused_h_kernel: only when that one flagged
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const long item = (long)blockIdx.x * 4 + wave;
@@ -556,6 +558,10 @@ int bigc_mha_core_h_launch(hipStream_t s, const float* q, int ldq, const float* 
                            const int32_t* q_off, const int32_t* k_off, int n_seq, int n_qt, int n_head, float scale, float* lse,
                            const DropSpec& drop, int grid, int* flag, int run_id);
 
+int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, float* att,
+                             float* values, const int32_t* e_off, int n_vid, int nq, int n_qt, int half, int d, float scale, int grid,
+                             int* flag, int run_id);
+
 namespace {
 // BIGC_LINEAR_EXACT / bigc_linear_set_exact also select the f32-MFMA attention kernels
 std::atomic<int> g_mha_run{0};
@@ -665,12 +671,22 @@ extern "C" int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, cons
     const int n_qt = cdiv(nq, 32);
     const int grid = cdiv(n_vid * n_qt, 4);
     ProfScope ps(stream, FAM_ROLE_ATT, 0.0, 0.0);
+    // split-operand f16 MFMA kernel first; the f32-MFMA kernel behind it runs only if an operand was out of the f16 range
+    int* run_flag = nullptr;
+    int run_id = 0;
+    if (d % 32 == 0 && !bigc_linear_get_exact()) {
+        run_id = g_mha_run.fetch_add(1, std::memory_order_relaxed) + 1;
+        run_flag = mha_flag_slot(run_id);
+        if (!run_flag) return BIGC_ERR_HIP;
+        bigc_role_fused_h_launch((hipStream_t)stream, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, n_qt, half, d, scale, grid,
+                                 run_flag, run_id);
+    }
     if (max_ent <= 32)
         hipLaunchKernelGGL(role_fused_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, enco, ldenc, att, values,
-                           e_off, n_vid, nq, n_qt, half, d, scale);
+                           e_off, n_vid, nq, n_qt, half, d, scale, run_flag, run_id);
     else
         hipLaunchKernelGGL(role_fused_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, enco, ldenc, att, values,
-                           e_off, n_vid, nq, n_qt, half, d, scale);
+                           e_off, n_vid, nq, n_qt, half, d, scale, run_flag, run_id);
     BIGC_LAUNCH_CHECK("role_fused");
     return BIGC_OK;
 }

@@ -188,7 +188,197 @@ __global__ __launch_bounds__(256, 2) void mha_core_h_kernel(const float* __restr
     }
 }
 
+// split without the NaN/Inf sum: only the magnitude is tracked (a NaN operand gives NaN outputs on either path)
+__device__ __forceinline__ void split8a(const float (&x)[8], a16x8& h, a16x8& r, float& amax) {
+    union { a16x2 p[4]; a16x8 v; } hh, rr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x[2 * j], b = x[2 * j + 1];
+        hh.p[j] = __builtin_amdgcn_cvt_pkrtz(a, b);
+        rr.p[j] = __builtin_amdgcn_cvt_pkrtz((a - (float)hh.p[j][0]) * RS, (b - (float)hh.p[j][1]) * RS);
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(amax) : "v"(amax), "v"(a), "v"(b));
+    }
+    h = hh.v;
+    r = rr.v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Role attention and its values (models/model_0v10.py:193-211) for videos of at most 64 entities, on split f16 operands:
+// the organisation of role_fused_kernel in attention.hip -- one wave per (video, 32-query tile), the transposed scores of
+// both roles against both 32-entity tiles in registers, softmax over the entities of a role, then over the two roles,
+// values_r = att_r @ enco_output -- with three f16 MFMAs per f32 product.  Score k-slot (hi, j) of step s stands for
+// dimension hi * half/2 + 8 s + j of the role's half, so a lane streams a contiguous half row (a 128-byte line per four
+// steps); the value k-slots are the entities in accumulator-register order as in mha_core_h_kernel.
+__global__ __launch_bounds__(256, 2) void role_fused_h_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
+                                                              const float* __restrict__ enco, int ldenc, float* __restrict__ att,
+                                                              float* __restrict__ values, const int32_t* __restrict__ e_off,
+                                                              int n_vid, int nq, int n_qt, int half, int d, float scale,
+                                                              int* __restrict__ flag, int run_id) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n_vid * n_qt) return;
+    const int qt = item % n_qt, vid = item / n_qt;
+    const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
+    if (qt * 32 >= nq || ne <= 0) return;
+    const int qrow = min(qt * 32 + l31, nq - 1);
+    const int hh = half / 2, n_burst = hh / 32;           // half % 64 == 0 (launcher)
+    const float* qp = p2a + (size_t)(vid * nq + qrow) * ldp + hi * hh;
+    float amax = 0.f;
+
+    // ---- scores: sc[r][et] = S_r^T tile (entity rows, query columns)
+    f32x16 sc[2][2];
+    f32x4 qraw[8], eraw[8];
+    auto fetch_row = [&](const float* p, f32x4 (&v)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(p + 4 * j);
+    };
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+            const float* qb = qp + r * half;
+            const float* eb = e2a + (size_t)(e0 + min(et * 32 + l31, ne - 1)) * lde + hi * hh + r * half;
+            f32x16 c0 = zero16(), c1 = zero16();
+            fetch_row(qb, qraw);
+            fetch_row(eb, eraw);
+            for (int kc = 0; kc < n_burst; ++kc) {
+                const int nx = min(kc + 1, n_burst - 1) * 32;
+                a16x8 qh[4], qr[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const float x[8] = {qraw[2 * s4][0], qraw[2 * s4][1], qraw[2 * s4][2], qraw[2 * s4][3],
+                                        qraw[2 * s4 + 1][0], qraw[2 * s4 + 1][1], qraw[2 * s4 + 1][2], qraw[2 * s4 + 1][3]};
+                    split8a(x, qh[s4], qr[s4], amax);
+                }
+                fetch_row(qb + nx, qraw);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const float x[8] = {eraw[2 * s4][0], eraw[2 * s4][1], eraw[2 * s4][2], eraw[2 * s4][3],
+                                        eraw[2 * s4 + 1][0], eraw[2 * s4 + 1][1], eraw[2 * s4 + 1][2], eraw[2 * s4 + 1][3]};
+                    a16x8 eh, er;
+                    split8a(x, eh, er, amax);
+                    c0 = MFMA_H(eh, qh[s4], c0);
+                    c1 = MFMA_H(eh, qr[s4], c1);
+                    c1 = MFMA_H(er, qh[s4], c1);
+                }
+                fetch_row(eb + nx, eraw);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sc[r][et][g] = c0[g] + c1[g] * RI;
+        }
+
+    // ---- softmax over the entities of each role (torch.softmax: exp(s - max) / sum), then over the two roles
+    float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                sc[r][et][g] *= scale;
+                if (et * 32 + mfma_row(g, hi) < ne) m[r] = fmaxf(m[r], sc[r][et][g]);
+            }
+        m[r] = fmaxf(m[r], __shfl_xor(m[r], 32));
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                if (et * 32 + mfma_row(g, hi) < ne) l[r] += expf(sc[r][et][g] - m[r]);
+        l[r] += __shfl_xor(l[r], 32);
+    }
+    const int qq = qt * 32 + l31;
+    float* abase = att ? att + (size_t)2 * nq * e0 : nullptr;
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int n = et * 32 + mfma_row(g, hi);
+            const float s0 = sc[0][et][g], s1 = sc[1][et][g];
+            const float pe0 = expf(s0 - m[0]) / l[0], pe1 = expf(s1 - m[1]) / l[1];
+            const float mx = fmaxf(s0, s1);
+            const float w0 = expf(s0 - mx), w1 = expf(s1 - mx), ws = w0 + w1;
+            const bool ok = n < ne;
+            const float a0 = ok ? pe0 * (w0 / ws) : 0.f, a1 = ok ? pe1 * (w1 / ws) : 0.f;
+            sc[0][et][g] = a0;
+            sc[1][et][g] = a1;
+            if (abase && ok && qq < nq) {
+                abase[((size_t)0 * nq + qq) * ne + n] = a0;
+                abase[((size_t)1 * nq + qq) * ne + n] = a1;
+            }
+        }
+
+    // ---- values_r = att_r @ enco_output, 32 output columns per pass; the split probabilities are kept for all passes
+    a16x8 ph[2][2][2], pr[2][2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float p8[8], a_ = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p8[j] = sc[r][et][8 * u + j];
+                split8a(p8, ph[r][et][u], pr[r][et][u], a_);          // probabilities: no range check needed
+            }
+    float va[32];
+    // entity rows of this lane's k-slots (clamped: their probabilities are zero)
+    int voff[32];
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) voff[16 * et + g] = (e0 + min(et * 32 + mfma_row(g, hi), ne - 1)) * ldenc + l31;
+    auto fetch_v = [&](int dt) {
+        const float* vb_ = enco + min(dt * 32, d - 32);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) va[i] = vb_[voff[i]];
+    };
+    const int n_dt = d / 32;                               // d % 32 == 0 (launcher)
+    fetch_v(0);
+#pragma unroll 1
+    for (int dt = 0; dt < n_dt; ++dt) {
+        a16x8 vh[2][2], vr[2][2];
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v8[j] = va[16 * et + 8 * u + j];
+                split8a(v8, vh[et][u], vr[et][u], amax);
+            }
+        fetch_v(dt + 1);                                   // the raw registers are free again: next pass's rows (clamped at the end)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            f32x16 c0 = zero16(), c1 = zero16();
+#pragma unroll
+            for (int et = 0; et < 2; ++et)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    c0 = MFMA_H(ph[r][et][u], vh[et][u], c0);
+                    c1 = MFMA_H(ph[r][et][u], vr[et][u], c1);
+                    c1 = MFMA_H(pr[r][et][u], vh[et][u], c1);
+                }
+            float* op = values + ((size_t)r * n_vid * nq + (size_t)vid * nq) * d + dt * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = qt * 32 + mfma_row(g, hi);
+                if (row < nq) op[(size_t)row * d] = c0[g] + c1[g] * RI;
+            }
+        }
+    }
+    if (amax >= 32768.0f) atomicMax(flag, run_id);
+}
+
 }  // namespace
+
+int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, float* att,
+                             float* values, const int32_t* e_off, int n_vid, int nq, int n_qt, int half, int d, float scale, int grid,
+                             int* flag, int run_id) {
+    hipLaunchKernelGGL(role_fused_h_kernel, dim3(grid), dim3(256), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, n_qt,
+                       half, d, scale, flag, run_id);
+    return 1;
+}
 
 // launches the split kernel when it applies (head_dim 64, self-attention of at most 192 keys); returns 1 if launched
 int bigc_mha_core_h_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,

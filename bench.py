@@ -341,7 +341,7 @@ def main():
                                "construct_triplet, exp2 dims (RoI 2048 + I3D 832), %d synthetic videos x N=%d tracklets "
                                "per GPU per step, topk=%d, f32 in / f32 accumulate / f32 out (%s)"
                                % (args.videos, args.n_trajs, args.topk, "GEMMs on the exact f32 MFMA" if EXACT_F32 else
-                                  "GEMMs on f16 MFMAs with exactly split f32 operands, f32-level error; attention on the f32 MFMA"),
+                                  "GEMMs and attention on f16 MFMAs with exactly split f32 operands, f32-level error"),
                    "videos_per_gpu_per_step": args.videos, "tracklets_per_video": args.n_trajs,
                    "rows_per_step": packed.n_rows, "pairs_per_gpu_per_step": pairs_per_step, "parallelism": "dp%d" % world},
         "roofline": roofline, "cpu_baseline": cpu_baseline, "exact_f32_gemm_mode": exact_leg,

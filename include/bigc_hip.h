@@ -16,9 +16,10 @@
  *   - every function returns 0 on success or a negative bigc_status; the message of the
  *     last failure on the calling thread is returned by bigc_last_error();
  *   - one handle per device and per model; a handle may be used from one thread at a time.
- *   - all tensors are IEEE fp32 and every accumulation is fp32; GEMMs run on the f16 matrix cores with
- *     exactly split f32 operands (f32-level error, bigc_linear_set_exact(1) selects the f32 MFMA kernel),
- *     attention on the f32 MFMA; indices are int32 on the device side (the Python host converts to the
+ *   - all tensors are IEEE fp32 and every accumulation is fp32; the GEMMs, the head_dim-64 attention core and the fused
+ *     role attention run on the f16 matrix cores with exactly split f32 operands (f32-level error; operands with
+ *     |x| >= 32768 are redone on the f32 MFMA; bigc_linear_set_exact(1) selects the f32 MFMA kernels throughout), the
+ *     other attention kernels on the f32 MFMA; indices are int32 on the device side (the Python host converts to the
  *     reference's int64 at the boundary).
  */
 #ifndef BIGC_HIP_H
@@ -78,8 +79,9 @@ int bigc_linear_f32(void* stream, const float* A, int lda, const int32_t* a_idx,
                     const float* W, int ldw, const float* bias, const float* residual, int ldr,
                     float* C, int ldc, int M, int N, int K, int act);
 
-/* GEMM arithmetic of bigc_linear_f32 (process-wide): 0 = f16 matrix cores on exactly split f32 operands (default; f32-level
- * error, see csrc/linear_split.hip), 1 = the exact f32 MFMA kernel.  Initial value from the environment variable
+/* Arithmetic of bigc_linear_f32, bigc_mha_core(_drop)_f32 at head_dim 64 and bigc_role_fused_f32 (process-wide): 0 = f16
+ * matrix cores on exactly split f32 operands (default; f32-level error, see csrc/linear_split.hip, csrc/attention_split.hip),
+ * 1 = the exact f32 MFMA kernels.  Initial value from the environment variable
  * BIGC_LINEAR_EXACT.  bigc_linear_set_exact returns the previous mode. */
 int bigc_linear_set_exact(int exact);
 int bigc_linear_get_exact(void);
@@ -425,6 +427,21 @@ int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, const float* k,
 size_t bigc_pair_workspace_bytes(const bigc_model* m, const bigc_batch* b, long n_pairs);
 int bigc_pair_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* vid_pair_off, long n_pairs, void* workspace,
                       size_t workspace_bytes, float* enti2enco, float* pair_logits);
+
+/* ---- Base_C training step (models/model_pairwise_baseline.py:276-312; loop body tools/train_vidor.py:305-330) ---------------
+ * pair_so (n_pairs, 2): GLOBAL tracklet rows (the video's first tracklet row added to the reference's pairid2trajids) of
+ * the labelled pairs of all videos of the batch, concatenated in batch order.  bigc_pair_train_forward keeps every
+ * activation in `workspace` (untouched until the backward) and writes pair_logits (n_pairs, num_pred_cats);
+ * bigc_bce_logits_f32 is F.binary_cross_entropy_with_logits(x, y, reduction='mean') over a (rows, cols) block: *loss +=
+ * the mean, dx = gscale * d mean / dx (either may be NULL); bigc_pair_train_backward takes dlogits (n_pairs, ldg) with
+ * ldg = num_pred_cats rounded up to 4 (zero pad columns) and accumulates into the bigc_set_grad destinations. */
+size_t bigc_pair_train_workspace_bytes(const bigc_model* m, const bigc_batch* b, long n_pairs);
+int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
+                            size_t workspace_bytes, float* pair_logits);
+int bigc_pair_train_backward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
+                             size_t workspace_bytes, const float* dlogits, int ldg);
+int bigc_bce_logits_f32(void* stream, const float* x, int ldx, const float* y, int ldy, long rows, int cols, float gscale, float* loss,
+                        float* dx, int lddx);
 
 /* ---- tracking-result ingest (dataloaders/dataloader_vidvrd.py:585-700, utils/utils_func.py:273-317) ---------------------
  * Assembles the feature rows of the kept tracklets from the raw per-box rows of a video's `.npy` (uploaded once):

@@ -1,7 +1,7 @@
 """CPU oracle for the explicit pairwise baseline (TEST INFRASTRUCTURE ONLY).
 
-Restates ``Base_C.forward_propagation`` / ``prediction_head`` / ``construct_triplet`` of
-``models/model_pairwise_baseline.py`` (:174-197, :236-273, :306-395) with stock torch CPU ops, the front-end being the
+Restates ``Base_C.forward_propagation`` / ``prediction_head`` / ``construct_triplet`` / ``_forward_train`` + ``loss`` of
+``models/model_pairwise_baseline.py`` (:174-197, :236-273, :306-395, :276-312) with stock torch CPU ops, the front-end being the
 one of ``oracle.bigc_oracle`` (same layers, :176-189).  Pinned by ``tests/golden/basec_*.npz``."""
 import numpy as np
 import torch
@@ -17,8 +17,8 @@ def pair_ids(n):
     return mask.nonzero(as_tuple=False)
 
 
-def forward_propagation(sd, cfg, proposal):
-    """(:174-197, 236-273) -> (pair logits (N(N-1), P), enti2enco (N, de))"""
+def forward_propagation(sd, cfg, proposal, pairs=None):
+    """(:174-197, 236-273) -> (pair logits (n_pairs, P), enti2enco (N, de)); pairs = pairid2trajids, default all ordered pairs"""
     dim_feat, n = cfg["dim_feat"], proposal.num_proposals
     traj_bboxes, traj_features = O.preprocess_proposal(proposal)
     visual, classeme = traj_features[:, :, :dim_feat], traj_features[:, :, dim_feat:]
@@ -28,7 +28,7 @@ def forward_propagation(sd, cfg, proposal):
     conv = F.conv1d(enti, sd["conv_feat2enti.weight"], sd["conv_feat2enti.bias"], stride=2, padding=1)
     pooled = F.adaptive_max_pool1d(conv, cfg["enco_pool_len"]).reshape(n, -1)
     feat = O.linear(O.linear(pooled, sd, "fc_enti2enco.0", True), sd, "fc_enti2enco.2", True)
-    pairs = pair_ids(n)
+    pairs = pair_ids(n) if pairs is None else pairs
     cats = proposal.cat_ids[pairs]
     bias = sd["bias_matrix"][cats[:, 0], cats[:, 1], :]
     parts = [feat[pairs[:, 0]], feat[pairs[:, 1]]]
@@ -76,3 +76,12 @@ def forward_test(sd, cfg, proposal_list, topk=10):
         logits, _ = forward_propagation(sd, cfg, p)
         out.append(construct_triplet(p, logits, topk, cfg["rt_triplets_topk"]))
     return out
+
+
+def forward_train(sd, cfg, proposal_list, pos_id_list, label_list):
+    """``Base_C._forward_train`` + ``loss`` (:276-312): BCE-with-logits mean over the labelled pairs of the whole batch.
+    ``sd`` may hold tensors with requires_grad for autograd.  -> (total, {"cls": loss}, logits)"""
+    logits = torch.cat([forward_propagation(sd, cfg, p, ids)[0] for p, ids in zip(proposal_list, pos_id_list)], 0)
+    labels = torch.cat(list(label_list), 0)
+    cls = F.binary_cross_entropy_with_logits(logits, labels, reduction="mean")
+    return cls, {"cls": cls}, logits

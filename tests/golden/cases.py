@@ -321,6 +321,35 @@ BASEC_CASES = {
 }
 
 
+# Base_C training step (models/model_pairwise_baseline.py:276-312): labelled pairs + multi-hot predicate labels per video
+BASEC_TRAIN_CASES = {
+    "basec_train_tiny": dict(base="basec_tiny", videos=[0, 3], pairs=[9, 6], lseed=9701),
+    "basec_train_tiny_emb": dict(base="basec_tiny_emb", videos=[0], pairs=[14], lseed=9702),
+    "basec_train_o_n24": dict(base="basec_o_n24", videos=[0], pairs=[60], lseed=9703),
+}
+
+
+def make_basec_train_case(name):
+    """-> (cfg, state_dict, [proposals], [pairid2trajids (n,2) int64], [multihot (n,P) float32])"""
+    import numpy as np
+    import torch
+    case = BASEC_TRAIN_CASES[name]
+    cfg, sd, props, _ = make_basec_case(case["base"])
+    rs = np.random.RandomState(case["lseed"])
+    props = [props[i] for i in case["videos"]]
+    pos, labels = [], []
+    for p, n_pairs in zip(props, case["pairs"]):
+        n = p.num_proposals
+        allp = np.array([(s, o) for s in range(n) for o in range(n) if s != o], dtype=np.int64)
+        sel = allp[rs.permutation(len(allp))[:n_pairs]]                       # distinct ordered pairs, random order
+        lab = np.zeros((len(sel), cfg["num_pred_cats"]), dtype=np.float32)
+        for r in range(len(sel)):                                             # 1-3 positive predicates per pair (never background)
+            lab[r, rs.choice(np.arange(1, cfg["num_pred_cats"]), size=rs.randint(1, 4), replace=False)] = 1.0
+        pos.append(torch.from_numpy(sel))
+        labels.append(torch.from_numpy(lab))
+    return cfg, sd, props, pos, labels
+
+
 def make_basec_case(name):
     """-> (cfg, state_dict, [proposals], topk)"""
     from bigc_hip.synthetic import basec_state_shapes

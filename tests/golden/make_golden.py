@@ -314,11 +314,46 @@ def run_basec_case(name):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), [None if r is None else tuple(r[0].shape) for r in res])
 
 
+def run_basec_train_case(name):
+    """The reference's Base_C training forward + backward (models/model_pairwise_baseline.py:276-312) on the seeded case:
+    loss, the logits of the labelled pairs, the norm of every parameter gradient and a few gradients in full."""
+    sys.path.insert(0, REFERENCE)
+    from models import model_pairwise_baseline as MB
+    sys.path.remove(REFERENCE)
+    cfg, sd, props, pos, labels = cases.make_basec_train_case(name)
+    d = tempfile.mkdtemp()
+    rc = dict(cfg)
+    np.save(os.path.join(d, "bias.npy"), sd["bias_matrix"].numpy())
+    rc["bias_matrix_path"] = os.path.join(d, "bias.npy")
+    if "EntiNameEmb" in sd:
+        np.save(os.path.join(d, "emb.npy"), sd["EntiNameEmb"].numpy())
+        rc["EntiNameEmb_path"] = os.path.join(d, "emb.npy")
+    model = MB.Base_C(rc, is_train=True)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    total, terms = model(props, pos, labels)
+    total.backward()
+    out = {"versions": np.array([torch.__version__, np.__version__]), "total": np.float64(total.item()), "loss_cls": np.float64(terms["cls"].item())}
+    with torch.no_grad():
+        out["logits"] = torch.cat([model.forward_propagation(p, ids) for p, ids in zip(props, pos)]).numpy()
+    full = ("bias_matrix", "fc_pred2logits.0.weight", "fc_pred2logits.2.bias", "fc_enti2enco.2.weight", "conv_feat2enti.bias", "fc_bbox2enti.0.weight")
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        out["gnorm_" + k] = np.float64(g.norm().item())
+        if k in full and g.numel() <= 600000:
+            out["grad_" + k] = g.numpy()
+    path = os.path.join(cases.GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "loss", out["total"])
+
+
 def main():
     torch.manual_seed(0)
     m10, m07, grd = import_reference()
     names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + list(cases.GRD_TRAIN_CASES) + ["evaluator"] +
-                             list(cases.INGEST_CASES) + list(cases.BASEC_CASES))
+                             list(cases.INGEST_CASES) + list(cases.BASEC_CASES) + list(cases.BASEC_TRAIN_CASES))
     for n in names:
         if n == "evaluator":
             run_evaluator_golden()
@@ -328,6 +363,9 @@ def main():
             continue
         if n in cases.BASEC_CASES:
             run_basec_case(n)
+            continue
+        if n in cases.BASEC_TRAIN_CASES:
+            run_basec_train_case(n)
             continue
         if n in cases.BIGC_CASES:
             run_bigc_case(n, m10, m07)

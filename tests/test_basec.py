@@ -37,7 +37,26 @@ def test_basec_oracle_matches_reference(name):
         _check(r, g, i, 1e-6)
 
 
-def _build(cfg, sd):
+@pytest.mark.parametrize("name", list(cases.BASEC_TRAIN_CASES))
+def test_basec_train_oracle_matches_reference(name):
+    """oracle restatement of _forward_train + loss (:276-312) with autograd vs the reference's loss, logits and gradients"""
+    g = np.load(cases.GOLDEN_DIR + "/" + name + ".npz")
+    cfg, sd, props, pos, labels = cases.make_basec_train_case(name)
+    sdg = {k: (v.clone().requires_grad_(True) if k != "EntiNameEmb" else v) for k, v in sd.items()}
+    total, terms, logits = B.forward_train(sdg, cfg, props, pos, labels)
+    total.backward()
+    assert abs(float(total) - float(g["total"])) < 1e-5 * abs(float(g["total"]))
+    assert np.abs(logits.detach().numpy() - g["logits"]).max() <= 1e-5 * np.abs(g["logits"]).max()
+    for k in g.files:
+        if k.startswith("gnorm_"):
+            got = sdg[k[6:]].grad
+            assert abs(float(0.0 if got is None else got.norm()) - float(g[k])) <= 1e-4 * max(float(g[k]), 1e-8), k
+        if k.startswith("grad_"):
+            ref = g[k]
+            assert np.abs(sdg[k[5:]].grad.numpy() - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-12), k
+
+
+def _build(cfg, sd, is_train=False):
     from models import Base_C
     d = tempfile.mkdtemp()
     mc = dict(cfg)
@@ -46,7 +65,7 @@ def _build(cfg, sd):
     if "EntiNameEmb" in sd:
         np.save(os.path.join(d, "e.npy"), sd["EntiNameEmb"].numpy())
         mc["EntiNameEmb_path"] = os.path.join(d, "e.npy")
-    m = Base_C(mc, is_train=False)
+    m = Base_C(mc, is_train=is_train)
     m.load_state_dict(sd, strict=True)
     return m.to("cuda:0")
 
@@ -75,3 +94,60 @@ def test_basec_hip_matches_reference(name):
             got = out["pair_logits"][off[j]:off[j + 1]].cpu().numpy()
             assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
         j += 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(cases.BASEC_TRAIN_CASES))
+def test_basec_train_hip_matches_reference(name):
+    """HIP training step of Base_C: loss, logits of the labelled pairs and every parameter gradient vs the reference"""
+    g = np.load(cases.GOLDEN_DIR + "/" + name + ".npz")
+    cfg, sd, props, pos, labels = cases.make_basec_train_case(name)
+    model = _build(cfg, sd, is_train=True)
+    total, terms = model([p.to("cuda:0") for p in props], [x.to("cuda:0") for x in pos], [x.to("cuda:0") for x in labels])
+    assert set(terms) == {"cls"}
+    total.backward()
+    torch.cuda.synchronize()
+    assert abs(float(total) - float(g["total"])) < 2e-4 * abs(float(g["total"]))
+    worst = {}
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        want = float(g["gnorm_" + k])
+        got = p.grad
+        assert got is not None, k
+        worst[k] = abs(float(got.norm()) - want) / max(want, 1e-8)
+        if "grad_" + k in g.files:
+            ref = g["grad_" + k]
+            worst[k] = max(worst[k], float(np.abs(got.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-12)))
+    # same rule as test_hip_train.py: a ReLU at a pre-activation within rounding of zero may take the other branch
+    bad = {k: v for k, v in worst.items() if v > 3e-3}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+    assert float(np.median(list(worst.values()))) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:10]
+
+
+@pytest.mark.gpu
+def test_basec_train_every_gradient_matches_oracle_and_optimizer_step_runs():
+    name = "basec_train_tiny"
+    cfg, sd, props, pos, labels = cases.make_basec_train_case(name)
+    sdg = {k: (v.clone().requires_grad_(True) if k != "EntiNameEmb" else v) for k, v in sd.items()}
+    total, _, logits = B.forward_train(sdg, cfg, props, pos, labels)
+    (3.0 * total).backward()                                                   # a non-unit upstream gradient
+    model = _build(cfg, sd, is_train=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    h_total, _ = model([p.to("cuda:0") for p in props], pos, labels)
+    (3.0 * h_total).backward()
+    for k, p in model.named_parameters():
+        ref = sdg[k].grad
+        if ref is None:
+            continue
+        err = float((p.grad.cpu() - ref).abs().max())
+        assert err <= 2e-4 * max(float(ref.abs().max()), 1e-12), (k, err)
+    before = float(h_total)
+    for _ in range(5):                                                          # the reference loop body (tools/train_vidor.py:313-322)
+        opt.zero_grad()
+        loss, _ = model([p.to("cuda:0") for p in props], pos, labels)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=5, norm_type=2)
+        opt.step()
+    assert float(loss) < before

@@ -112,3 +112,32 @@ def test_adj_from_viou_matches_oracle_alignment():
             got = adj_from_viou(vi.clone(), g.adj_matrix.clone(), cfg["positive_vIoU_th"])
             assert torch.equal(got, want)
             assert want.sum() > 0
+
+
+def test_pair_label_assignment_matches_the_reference_loop():
+    """labels_from_viou vs the literal double loop of prop_pair_to_gt_pred (tools/train_vidor.py:131-158) on random vIoU tables"""
+    from collections import defaultdict
+    from bigc_hip.pair_train_step import labels_from_viou
+    rs = np.random.RandomState(3)
+    for trial in range(20):
+        n_prop, n_gt, n_pred, P, th = rs.randint(2, 9), rs.randint(1, 5), rs.randint(1, 7), 11, 0.5
+        vi = torch.from_numpy(rs.uniform(0, 1, size=(n_prop, n_gt)).astype(np.float32))
+        if trial == 0:
+            vi[:] = 0.1                                        # nothing hit
+        cats = rs.randint(1, P, size=n_pred)
+        so = np.stack([rs.randint(0, n_gt, n_pred), rs.randint(0, n_gt, n_pred)], 1)
+        want = defaultdict(list)
+        for g in range(n_pred):
+            for s_ in range(n_prop):
+                for o_ in range(n_prop):
+                    if s_ != o_ and vi[s_, so[g, 0]] > th and vi[o_, so[g, 1]] > th:
+                        want[(s_, o_)].append(int(cats[g]))
+        ids, multihot = labels_from_viou(vi, cats.tolist(), so, th, P)
+        if not want:
+            assert ids is None and multihot is None
+            continue
+        assert [tuple(r) for r in ids.tolist()] == list(want.keys())          # the reference's dict insertion order
+        ref = torch.zeros(len(want), P)
+        for i, c in enumerate(want.values()):
+            ref[i, c] = 1
+        assert torch.equal(multihot, ref)

@@ -70,3 +70,17 @@ def test_vidor_cli_pairwise_baseline():
     log = run([os.path.join(TOOLS, "eval_vidor.py"), "--eval_cls_only", "--use_baseline", "--cfg_path", cfg6, "--output_dir", out_dir,
                "--save_tag", "b", "--synthetic", "4", "--n_trajs", "10"])
     assert "detection recall" in log and os.path.exists(os.path.join(out_dir, "VidORval_infer_results_topk3_b.pkl"))
+
+
+def test_vidor_cli_pairwise_baseline_training_then_eval():
+    """tools/train_vidor.py --train_baseline (reference :175-352) on synthetic videos, then the checkpoint through eval_vidor.py"""
+    cfg6 = os.path.join(ROOT, "vidsgg-big_amd", "experiments", "exp6", "config_.py")
+    out_dir = tempfile.mkdtemp()
+    log = run([os.path.join(TOOLS, "train_vidor.py"), "--train_baseline", "--cfg_path", cfg6, "--output_dir", out_dir, "--save_tag", "bt",
+               "--synthetic", "8", "--n_trajs", "10", "--epochs", "2"])
+    assert "videos have labelled pairs" in log and "loss=" in log
+    ckpt = os.path.join(out_dir, "model_epoch_2_bt.pth")
+    assert os.path.exists(ckpt)
+    log = run([os.path.join(TOOLS, "eval_vidor.py"), "--eval_cls_only", "--use_baseline", "--cfg_path", cfg6, "--ckpt_path", ckpt,
+               "--output_dir", out_dir, "--save_tag", "bt", "--synthetic", "4", "--n_trajs", "10"])
+    assert "detection recall" in log

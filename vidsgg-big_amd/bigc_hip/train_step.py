@@ -34,13 +34,11 @@ def adj_from_viou(vi, adj, viou_th):
     return adj[:, :, pick] * has[None, None, :].to(adj.dtype)
 
 
-def align_batch(lib, packed, gt_graph_list, viou_th):
-    """``enti_viou_align`` for every video of the batch: the vIoU tables come from one HIP kernel launch
-    (``bigc_viou_matrix``; the reference loops over pairs in Python, :576-581), the thresholding on the host.
-    Reproduces the reference's in-place ``gt_graph.traj_durations[:, 1] -= 1`` (:567)."""
+def viou_tables(lib, packed, gt_graph_list):
+    """vIoU of every proposal with every GT trajectory of its video, one HIP kernel launch (``bigc_viou_matrix``; the
+    reference loops over pairs in Python, models/model_0v10.py:576-581, tools/train_vidor.py:110-121):
+    list of (n_proposals, n_gt_traj) f32 host tensors."""
     dev = packed.device
-    for g in gt_graph_list:
-        g.traj_durations[:, 1] -= 1
     n_traj = [len(g.traj_bboxes) for g in gt_graph_list]
     lens = [int(b.shape[0]) for g in gt_graph_list for b in g.traj_bboxes]
     gt_boxes = torch.cat([b.detach().float().cpu() for g in gt_graph_list for b in g.traj_bboxes], 0).contiguous().to(dev)
@@ -54,8 +52,15 @@ def align_batch(lib, packed, gt_graph_list, viou_th):
                                     gt_traj_off.data_ptr(), packed.n_vid, packed.max_trk, g_max, out.data_ptr()))
     vi = out.cpu()
     n_trk = np.diff(packed.vid_trk_off_host)
-    return [adj_from_viou(vi[v, :int(n_trk[v]), :n_traj[v]].clone(), g.adj_matrix.detach().cpu().float(), viou_th)
-            for v, g in enumerate(gt_graph_list)]
+    return [vi[v, :int(n_trk[v]), :n_traj[v]].clone() for v in range(packed.n_vid)]
+
+
+def align_batch(lib, packed, gt_graph_list, viou_th):
+    """``enti_viou_align`` for every video of the batch: vIoU tables from the HIP kernel, the thresholding on the host.
+    Reproduces the reference's in-place ``gt_graph.traj_durations[:, 1] -= 1`` (:567)."""
+    for g in gt_graph_list:
+        g.traj_durations[:, 1] -= 1
+    return [adj_from_viou(vi, g.adj_matrix.detach().cpu().float(), viou_th) for vi, g in zip(viou_tables(lib, packed, gt_graph_list), gt_graph_list)]
 
 
 class TrainContext(object):

@@ -156,6 +156,58 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     }
 }
 
+// ---- the same with explicit (subject, object) rows per pair: training on the labelled pairs (model_pairwise_baseline.py:276-312)
+__global__ __launch_bounds__(256) void pair_hidden_idx_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                              const int32_t* __restrict__ pair_so, float* __restrict__ H, long n_pairs, int d4) {
+    const long total = n_pairs * d4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / d4;
+        const int c = (int)(i - p * d4);
+        const f32x4 a = ((const f32x4*)U)[(size_t)pair_so[2 * p] * d4 + c], b = ((const f32x4*)V)[(size_t)pair_so[2 * p + 1] * d4 + c];
+        f32x4 h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h[k] = fmaxf(a[k] + b[k], 0.f);
+        ((f32x4*)H)[i] = h;
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_bias_idx_kernel(const float* __restrict__ bias_matrix, const int32_t* __restrict__ trk_cat,
+                                                            const int32_t* __restrict__ pair_so, float* __restrict__ out, long n_pairs, int n_cat,
+                                                            int n_pred) {
+    const long total = n_pairs * n_pred;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / n_pred;
+        const int c = (int)(i - p * n_pred);
+        out[i] = bias_matrix[((size_t)trk_cat[pair_so[2 * p]] * n_cat + trk_cat[pair_so[2 * p + 1]]) * n_pred + c];
+    }
+}
+
+// dU[s_p] += dH[p], dV[o_p] += dH[p]: a tracklet takes part in few labelled pairs, float atomics
+__global__ __launch_bounds__(256) void pair_scatter_add_kernel(const float* __restrict__ dH, const int32_t* __restrict__ pair_so,
+                                                               float* __restrict__ dU, float* __restrict__ dV, long n_pairs, int d) {
+    const long total = n_pairs * d;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / d;
+        const int c = (int)(i - p * d);
+        const float g = dH[i];
+        if (g != 0.f) {
+            atomicAdd(&dU[(size_t)pair_so[2 * p] * d + c], g);
+            atomicAdd(&dV[(size_t)pair_so[2 * p + 1] * d + c], g);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_bias_bwd_kernel(const float* __restrict__ dlogits, int ldg, const int32_t* __restrict__ trk_cat,
+                                                            const int32_t* __restrict__ pair_so, float* __restrict__ dbias, long n_pairs,
+                                                            int n_cat, int n_pred) {
+    const long total = n_pairs * n_pred;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / n_pred;
+        const int c = (int)(i - p * n_pred);
+        atomicAdd(&dbias[((size_t)trk_cat[pair_so[2 * p]] * n_cat + trk_cat[pair_so[2 * p + 1]]) * n_pred + c], dlogits[(size_t)p * ldg + c]);
+    }
+}
+
 int grid_of(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 
 }  // namespace
@@ -180,5 +232,32 @@ int bigc_pair_bias(hipStream_t s, const float* bias_matrix, const int32_t* trk_c
 int bigc_gather_rows(hipStream_t s, const float* src, const int32_t* idx, float* out, int n, int d) {
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_of((long)n * d)), dim3(256), 0, s, src, idx, out, (long)n * d, d);
     BIGC_LAUNCH_CHECK("gather_rows");
+    return BIGC_OK;
+}
+
+int bigc_pair_hidden_idx(hipStream_t s, const float* U, const float* V, const int32_t* pair_so, float* H, long n_pairs, int d) {
+    hipLaunchKernelGGL(pair_hidden_idx_kernel, dim3(grid_of(n_pairs * (d / 4))), dim3(256), 0, s, U, V, pair_so, H, n_pairs, d / 4);
+    BIGC_LAUNCH_CHECK("pair_hidden_idx");
+    return BIGC_OK;
+}
+
+int bigc_pair_bias_idx(hipStream_t s, const float* bias_matrix, const int32_t* trk_cat, const int32_t* pair_so, float* out, long n_pairs,
+                       int n_cat, int n_pred) {
+    hipLaunchKernelGGL(pair_bias_idx_kernel, dim3(grid_of(n_pairs * n_pred)), dim3(256), 0, s, bias_matrix, trk_cat, pair_so, out, n_pairs, n_cat, n_pred);
+    BIGC_LAUNCH_CHECK("pair_bias_idx");
+    return BIGC_OK;
+}
+
+int bigc_pair_scatter_add(hipStream_t s, const float* dH, const int32_t* pair_so, float* dU, float* dV, long n_pairs, int d) {
+    hipLaunchKernelGGL(pair_scatter_add_kernel, dim3(grid_of(n_pairs * d)), dim3(256), 0, s, dH, pair_so, dU, dV, n_pairs, d);
+    BIGC_LAUNCH_CHECK("pair_scatter_add");
+    return BIGC_OK;
+}
+
+int bigc_pair_bias_bwd(hipStream_t s, const float* dlogits, int ldg, const int32_t* trk_cat, const int32_t* pair_so, float* dbias, long n_pairs,
+                       int n_cat, int n_pred) {
+    hipLaunchKernelGGL(pair_bias_bwd_kernel, dim3(grid_of(n_pairs * n_pred)), dim3(256), 0, s, dlogits, ldg, trk_cat, pair_so, dbias, n_pairs, n_cat,
+                       n_pred);
+    BIGC_LAUNCH_CHECK("pair_bias_bwd");
     return BIGC_OK;
 }

@@ -166,6 +166,43 @@ __global__ __launch_bounds__(64) void viou_matrix_kernel(const float* __restrict
 }
 }  // namespace
 
+namespace {
+// F.binary_cross_entropy_with_logits(x, y, reduction='mean') over a (rows, cols) block and its gradient
+//   l = max(x, 0) - x y + log1p(exp(-|x|)),  dl/dx = sigmoid(x) - y     (Base_C.loss, models/model_pairwise_baseline.py:301-312)
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy, long rows,
+                                                         int cols, float inv_n, float gscale, float* __restrict__ loss,
+                                                         float* __restrict__ dx, int lddx) {
+    const long total = rows * cols;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float v = x[(size_t)r * ldx + c], t = y[(size_t)r * ldy + c];
+        acc += fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));
+        if (dx) dx[(size_t)r * lddx + c] = (1.0f / (1.0f + expf(-v)) - t) * inv_n * gscale;
+    }
+    acc = wave_sum(acc);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) * inv_n);
+}
+}  // namespace
+
+extern "C" int bigc_bce_logits_f32(void* stream, const float* x, int ldx, const float* y, int ldy, long rows, int cols, float gscale, float* loss,
+                                   float* dx, int lddx) {
+    BIGC_CHECK_ARG(x && y && (loss || dx), "bce_logits: null pointer");
+    BIGC_CHECK_ARG(ldx >= cols && ldy >= cols && (!dx || lddx >= cols), "bce_logits: leading dimension smaller than cols=%d", cols);
+    if (rows <= 0 || cols <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_LOSS, 0.0, 0.0);
+    const long total = rows * cols;
+    const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols, 1.0f / (float)total, gscale,
+                       loss, dx, lddx);
+    BIGC_LAUNCH_CHECK("bce_logits");
+    return BIGC_OK;
+}
+
 extern "C" int bigc_viou_matrix(void* stream, const float* boxes, const int32_t* trk_row_off, const int32_t* trk_dura, const int32_t* e_off,
                                 const float* gt_boxes, const int32_t* gt_row_off, const int32_t* gt_dura, const int32_t* gt_traj_off,
                                 int n_vid, int max_trk, int g_max, float* out) {

@@ -179,6 +179,68 @@ struct Bwd {
 
 }  // namespace
 
+
+#define ZERO(ptr, count) do { hipError_t e_ = hipMemsetAsync((ptr), 0, sizeof(float) * (size_t)(count), hs); \
+    if (e_ != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: memset: %s", hipGetErrorString(e_)); } while (0)
+
+// a1-a4 with every activation kept (models/model_0v10.py:391-458; the same front-end in model_0v7.py and
+// model_pairwise_baseline.py:184-199): w.e2e = enti2enco
+static int frontend_train_forward(bigc_model* m, void* s, const bigc_batch* b, TrainWork& w) {
+    const bigc_config& c = m->cfg;
+    const int R = b->n_rows, NT = b->n_trk, C = b->n_conv;
+    const int de = c.dim_enti, D = c.dim_feat + c.dim_extra;
+    TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
+    TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
+    TRY(linear(s, w.hb, de, m->bbox2, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
+    TRY(linear(s, b->feats, D, m->feat0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
+    TRY(linear(s, w.hv, de, m->feat2, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
+    TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
+    TRY(bigc_linear_f32(s, w.enti, 2 * de, w.conv_idx, 3, 2 * de, m->conv_w_tapmajor, 6 * de, m->conv.b, nullptr, 0, w.conv, de, C, de,
+                        6 * de, BIGC_ACT_NONE));
+    TRY(bigc_adaptive_maxpool(s, w.conv, b->trk_conv_off, w.pooled, NT, de, c.enco_pool_len));
+    TRY(linear(s, w.pooled, de * c.enco_pool_len, m->enco0, w.eh, de, NT, de, de * c.enco_pool_len, BIGC_ACT_RELU));
+    TRY(linear(s, w.eh, de, m->enco2, w.e2e, de, NT, de, de, BIGC_ACT_RELU));
+    return BIGC_OK;
+}
+
+// adjoint of frontend_train_forward: gx = d enti2enco (overwritten), parameter gradients accumulated
+static int frontend_train_backward(bigc_model* m, void* s, const bigc_batch* b, TrainWork& w, Bwd& bw, float* gx) {
+    const bigc_config& c = m->cfg;
+    hipStream_t hs = (hipStream_t)s;
+    const int R = b->n_rows, NT = b->n_trk, C = b->n_conv;
+    const int de = c.dim_enti, D = c.dim_feat + c.dim_extra;
+    // ---- fc_enti2enco, pool, conv, per-frame MLPs (models/model_0v10.py:446-458) ----------------------
+    TRY(bigc_relu_bwd_f32(s, gx, w.e2e, (long)NT * de));
+    float* geh = w.gx;
+    TRY(bw.lin("fc_enti2enco.2", m->enco2, gx, de, w.eh, de, NT, de, de, geh, de, false));
+    TRY(bigc_relu_bwd_f32(s, geh, w.eh, (long)NT * de));
+    TRY(bw.lin("fc_enti2enco.0", m->enco0, geh, de, w.pooled, de * c.enco_pool_len, NT, de, de * c.enco_pool_len, w.gpooled,
+               de * c.enco_pool_len, false));
+    TRY(bigc_maxpool_bwd_f32(s, w.conv, b->trk_conv_off, w.gpooled, w.gconv, NT, de, c.enco_pool_len));
+    if (float* gcw = grad_of(m, "conv_feat2enti.weight")) {
+        ZERO(w.gconvw, (size_t)de * 6 * de);
+        TRY(bigc_linear_dw_f32(s, w.gconv, de, w.enti, 2 * de, w.conv_idx, 3, 2 * de, w.gconvw, 6 * de, grad_of(m, "conv_feat2enti.bias"),
+                               C, de, 6 * de));
+        TRY(bigc_conv_grad_unpack(hs, w.gconvw, gcw, de, 2 * de, 3));
+    }
+    TRY(bigc_conv_gather_bwd_f32(s, w.gconv, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.G, NT, de));
+    if (!m->conv_w_bwd) {
+        hipError_t e = hipMalloc((void**)&m->conv_w_bwd, sizeof(float) * (size_t)2 * de * 3 * de);
+        if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: hipMalloc: %s", hipGetErrorString(e));
+    }
+    TRY(bigc_repack_conv_weight_bwd(hs, m->conv.w, m->conv_w_bwd, de, 2 * de, 3));
+    TRY(bigc_linear_f32(s, w.G, 3 * de, nullptr, 1, 3 * de, m->conv_w_bwd, 3 * de, nullptr, nullptr, 0, w.genti, 2 * de, R, 2 * de, 3 * de,
+                        BIGC_ACT_NONE));
+    TRY(bigc_relu_bwd_f32(s, w.genti, w.enti, (long)R * 2 * de));
+    TRY(bw.lin("fc_bbox2enti.2", m->bbox2, w.genti, 2 * de, w.hb, de, R, de, de, w.gh, de, false));
+    TRY(bigc_relu_bwd_f32(s, w.gh, w.hb, (long)R * de));
+    TRY(bw.lin("fc_bbox2enti.0", m->bbox0, w.gh, de, w.bbox8, 8, R, de, 8, nullptr, 0, false));
+    TRY(bw.lin("fc_feat2enti.2", m->feat2, w.genti + de, 2 * de, w.hv, de, R, de, de, w.gh, de, false));
+    TRY(bigc_relu_bwd_f32(s, w.gh, w.hv, (long)R * de));
+    TRY(bw.lin("fc_feat2enti.0", m->feat0, w.gh, de, b->feats, D, R, de, c.dim_feat, nullptr, 0, false));
+    return BIGC_OK;
+}
+
 extern "C" int bigc_set_dropout(bigc_model* m, float p, uint32_t seed) {
     BIGC_CHECK_ARG(m && p >= 0.f && p < 1.f, "set_dropout: p must be in [0, 1)");
     m->drop_p = p; m->drop_seed = seed;
@@ -219,22 +281,12 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
     TRY(open_arena(m, b, workspace, workspace_bytes, w));
     void* s = stream;
     hipStream_t hs = (hipStream_t)stream;
-    const int R = b->n_rows, NT = b->n_trk, C = b->n_conv, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
+    const int NT = b->n_trk, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
     const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn, D = c.dim_feat + c.dim_extra, H = c.n_att_head, hd = de / H;
     const float eps = 1e-5f;
     const float dp_ = m->drop_p; const uint32_t ds_ = m->drop_seed;      // training-mode dropout (0 = off)
 
-    TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
-    TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
-    TRY(linear(s, w.hb, de, m->bbox2, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
-    TRY(linear(s, b->feats, D, m->feat0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
-    TRY(linear(s, w.hv, de, m->feat2, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
-    TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
-    TRY(bigc_linear_f32(s, w.enti, 2 * de, w.conv_idx, 3, 2 * de, m->conv_w_tapmajor, 6 * de, m->conv.b, nullptr, 0, w.conv, de, C, de,
-                        6 * de, BIGC_ACT_NONE));
-    TRY(bigc_adaptive_maxpool(s, w.conv, b->trk_conv_off, w.pooled, NT, de, c.enco_pool_len));
-    TRY(linear(s, w.pooled, de * c.enco_pool_len, m->enco0, w.eh, de, NT, de, de * c.enco_pool_len, BIGC_ACT_RELU));
-    TRY(linear(s, w.eh, de, m->enco2, w.e2e, de, NT, de, de, BIGC_ACT_RELU));
+    TRY(frontend_train_forward(m, s, b, w));
 
     const float* x = w.e2e;
     for (int i = 0; i < c.n_enco_layers; ++i) {
@@ -344,9 +396,6 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
     return BIGC_OK;
 }
 
-#define ZERO(ptr, count) do { hipError_t e_ = hipMemsetAsync((ptr), 0, sizeof(float) * (size_t)(count), hs); \
-    if (e_ != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: memset: %s", hipGetErrorString(e_)); } while (0)
-
 extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                                    const float* dlogits, int ldg, const float* datt) {
     StaticWeights static_weights(m ? m->epoch : 0);
@@ -357,8 +406,8 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
     TRY(open_arena(m, b, workspace, workspace_bytes, w));
     void* s = stream;
     hipStream_t hs = (hipStream_t)stream;
-    const int R = b->n_rows, NT = b->n_trk, C = b->n_conv, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
-    const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn, D = c.dim_feat + c.dim_extra, H = c.n_att_head, hd = de / H;
+    const int NT = b->n_trk, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
+    const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn, H = c.n_att_head, hd = de / H;
     const int P = c.num_pred_cats, HK = m->head_k;
     const float eps = 1e-5f;
     const float dp_ = m->drop_p; const uint32_t ds_ = m->drop_seed;      // training-mode dropout (0 = off)
@@ -507,34 +556,141 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
     }
     TRY(bigc_axpy_f32(s, gx, w.ge2e, (long)NT * de));                                                  // + head gather path
 
-    // ---- fc_enti2enco, pool, conv, per-frame MLPs (models/model_0v10.py:446-458) ----------------------
-    TRY(bigc_relu_bwd_f32(s, gx, w.e2e, (long)NT * de));
-    float* geh = w.gx;
-    TRY(bw.lin("fc_enti2enco.2", m->enco2, gx, de, w.eh, de, NT, de, de, geh, de, false));
-    TRY(bigc_relu_bwd_f32(s, geh, w.eh, (long)NT * de));
-    TRY(bw.lin("fc_enti2enco.0", m->enco0, geh, de, w.pooled, de * c.enco_pool_len, NT, de, de * c.enco_pool_len, w.gpooled,
-               de * c.enco_pool_len, false));
-    TRY(bigc_maxpool_bwd_f32(s, w.conv, b->trk_conv_off, w.gpooled, w.gconv, NT, de, c.enco_pool_len));
-    if (float* gcw = grad_of(m, "conv_feat2enti.weight")) {
-        ZERO(w.gconvw, (size_t)de * 6 * de);
-        TRY(bigc_linear_dw_f32(s, w.gconv, de, w.enti, 2 * de, w.conv_idx, 3, 2 * de, w.gconvw, 6 * de, grad_of(m, "conv_feat2enti.bias"),
-                               C, de, 6 * de));
-        TRY(bigc_conv_grad_unpack(hs, w.gconvw, gcw, de, 2 * de, 3));
+    TRY(frontend_train_backward(m, s, b, w, bw, gx));
+    return BIGC_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Training step of the pairwise baseline Base_C (models/model_pairwise_baseline.py:276-312): the front-end above, the
+// prediction head (:236-273) on the GIVEN (subject, object) pairs of every video -- first layer factorised per tracklet and
+// role as in bigc_pair_forward -- and its adjoint.  `pair_so` holds GLOBAL tracklet rows (video offset added by the host).
+// ------------------------------------------------------------------------------------------------------------------
+int bigc_pair_hidden_idx(hipStream_t s, const float* U, const float* V, const int32_t* pair_so, float* H, long n_pairs, int d);
+int bigc_pair_bias_idx(hipStream_t s, const float* bias_matrix, const int32_t* trk_cat, const int32_t* pair_so, float* out, long n_pairs,
+                       int n_cat, int n_pred);
+int bigc_pair_scatter_add(hipStream_t s, const float* dH, const int32_t* pair_so, float* dU, float* dV, long n_pairs, int d);
+int bigc_pair_bias_bwd(hipStream_t s, const float* dlogits, int ldg, const int32_t* trk_cat, const int32_t* pair_so, float* dbias, long n_pairs,
+                       int n_cat, int n_pred);
+int bigc_gather_rows(hipStream_t s, const float* src, const int32_t* idx, float* out, int n, int d);
+
+namespace {
+struct PairWork { float *U, *V, *clsme, *H, *bias, *dH, *dU, *dV, *wblk; };
+
+bool pair_layout(const bigc_model* m, const bigc_batch* b, long n_pairs, Arena& a, TrainWork& w, PairWork& pw) {
+    const bigc_config& c = m->cfg;
+    const size_t NT = b->n_trk, df = c.dim_ffn, dc = c.use_clsme ? c.dim_clsme : 0, de = c.dim_enti;
+    train_layout(m, tsizes(m, b), a, w);
+    pw.U = a.take<float>(NT * df); pw.V = a.take<float>(NT * df);
+    pw.clsme = a.take<float>(NT * (dc > 0 ? dc : 1));
+    pw.H = a.take<float>((size_t)n_pairs * df);
+    pw.bias = a.take<float>((size_t)n_pairs * c.num_pred_cats);
+    pw.dH = a.take<float>((size_t)n_pairs * df);
+    pw.dU = a.take<float>(NT * df); pw.dV = a.take<float>(NT * df);
+    pw.wblk = a.take<float>(df * (de > dc ? de : dc));
+    return !a.overflow;
+}
+
+int open_pair_arena(const bigc_model* m, const bigc_batch* b, long n_pairs, void* workspace, size_t workspace_bytes, TrainWork& w, PairWork& pw);
+}  // namespace
+
+extern "C" size_t bigc_pair_train_workspace_bytes(const bigc_model* m, const bigc_batch* b, long n_pairs) {
+    if (!m || !b || n_pairs <= 0) return 0;
+    Arena a{nullptr, (size_t)-1};
+    TrainWork w;
+    PairWork pw;
+    pair_layout(m, b, n_pairs, a, w, pw);
+    return a.off + 256;
+}
+
+namespace {
+int open_pair_arena(const bigc_model* m, const bigc_batch* b, long n_pairs, void* workspace, size_t workspace_bytes, TrainWork& w, PairWork& pw) {
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (!workspace || workspace_bytes < (size_t)(base - (char*)workspace)) return bigc_fail(BIGC_ERR_WORKSPACE, "pair_train: no workspace");
+    Arena a{base, workspace_bytes - (size_t)(base - (char*)workspace)};
+    if (!pair_layout(m, b, n_pairs, a, w, pw))
+        return bigc_fail(BIGC_ERR_WORKSPACE, "pair_train: workspace of %zu bytes too small, need %zu", workspace_bytes,
+                         bigc_pair_train_workspace_bytes(m, b, n_pairs));
+    return BIGC_OK;
+}
+}  // namespace
+
+extern "C" int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
+                                       size_t workspace_bytes, float* pair_logits) {
+    StaticWeights static_weights(m ? m->epoch : 0);
+    BIGC_CHECK_ARG(m && b && pair_so && pair_logits, "pair_train_forward: null pointer");
+    BIGC_CHECK_ARG(m->finalized && m->cfg.variant == 2, "pair_train_forward: needs a finalized pairwise-baseline model");
+    BIGC_CHECK_ARG(b->n_vid > 0 && b->n_trk > 0 && b->n_rows > 0 && b->n_conv > 0 && n_pairs > 0, "pair_train_forward: empty batch");
+    const bigc_config& c = m->cfg;
+    TrainWork w;
+    PairWork pw;
+    TRY(open_pair_arena(m, b, n_pairs, workspace, workspace_bytes, w, pw));
+    void* s = stream;
+    hipStream_t hs = (hipStream_t)stream;
+    const int NT = b->n_trk, de = c.dim_enti, df = c.dim_ffn, dc = c.use_clsme ? c.dim_clsme : 0, hk = m->head_k, P = c.num_pred_cats;
+    TRY(frontend_train_forward(m, s, b, w));
+    const float* W1 = m->head0.w;
+    if (dc > 0) {
+        if (c.has_enti_emb) TRY(bigc_gather_rows(hs, m->emb, b->trk_cat, pw.clsme, NT, dc));                      // (:251-253)
+        else TRY(bigc_stretched_mean(s, b->feats, c.dim_feat + c.dim_extra, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax,
+                                     pw.clsme, NT));                                                               // (:201)
+        // column blocks of W1 (df, hk): [s_clsme | o_clsme | s_feat | o_feat] (:257)
+        TRY(bigc_linear_f32(s, pw.clsme, dc, nullptr, 1, dc, W1, hk, m->head0.b, nullptr, 0, pw.U, df, NT, df, dc, BIGC_ACT_NONE));
+        TRY(bigc_linear_f32(s, w.e2e, de, nullptr, 1, de, W1 + 2 * dc, hk, nullptr, pw.U, df, pw.U, df, NT, df, de, BIGC_ACT_NONE));
+        TRY(bigc_linear_f32(s, pw.clsme, dc, nullptr, 1, dc, W1 + dc, hk, nullptr, nullptr, 0, pw.V, df, NT, df, dc, BIGC_ACT_NONE));
+        TRY(bigc_linear_f32(s, w.e2e, de, nullptr, 1, de, W1 + 2 * dc + de, hk, nullptr, pw.V, df, pw.V, df, NT, df, de, BIGC_ACT_NONE));
+    } else {
+        TRY(bigc_linear_f32(s, w.e2e, de, nullptr, 1, de, W1, hk, m->head0.b, nullptr, 0, pw.U, df, NT, df, de, BIGC_ACT_NONE));
+        TRY(bigc_linear_f32(s, w.e2e, de, nullptr, 1, de, W1 + de, hk, nullptr, nullptr, 0, pw.V, df, NT, df, de, BIGC_ACT_NONE));
     }
-    TRY(bigc_conv_gather_bwd_f32(s, w.gconv, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.G, NT, de));
-    if (!m->conv_w_bwd) {
-        hipError_t e = hipMalloc((void**)&m->conv_w_bwd, sizeof(float) * (size_t)2 * de * 3 * de);
-        if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: hipMalloc: %s", hipGetErrorString(e));
+    TRY(bigc_pair_hidden_idx(hs, pw.U, pw.V, pair_so, pw.H, n_pairs, df));
+    TRY(bigc_pair_bias_idx(hs, m->bias_matrix, b->trk_cat, pair_so, pw.bias, n_pairs, c.num_enti_cats, P));
+    TRY(bigc_linear_f32(s, pw.H, df, nullptr, 1, df, m->head2.w, df, m->head2.b, pw.bias, P, pair_logits, P, (int)n_pairs, P, df, BIGC_ACT_NONE));
+    return BIGC_OK;
+}
+
+extern "C" int bigc_pair_train_backward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
+                                        size_t workspace_bytes, const float* dlogits, int ldg) {
+    StaticWeights static_weights(m ? m->epoch : 0);
+    BIGC_CHECK_ARG(m && b && pair_so && dlogits, "pair_train_backward: null pointer");
+    BIGC_CHECK_ARG(m->finalized && m->cfg.variant == 2 && n_pairs > 0, "pair_train_backward: needs a finalized pairwise-baseline model");
+    const bigc_config& c = m->cfg;
+    BIGC_CHECK_ARG(ldg == round4(c.num_pred_cats), "pair_train_backward: dlogits must have leading dimension %d (zero padded)", round4(c.num_pred_cats));
+    TrainWork w;
+    PairWork pw;
+    TRY(open_pair_arena(m, b, n_pairs, workspace, workspace_bytes, w, pw));
+    void* s = stream;
+    hipStream_t hs = (hipStream_t)stream;
+    const int NT = b->n_trk, de = c.dim_enti, df = c.dim_ffn, dc = c.use_clsme ? c.dim_clsme : 0, hk = m->head_k, P = c.num_pred_cats;
+    Bwd bw{m, s, &w};
+    if (float* gbm = grad_of(m, "bias_matrix"))
+        TRY(bigc_pair_bias_bwd(hs, dlogits, ldg, b->trk_cat, pair_so, gbm, n_pairs, c.num_enti_cats, P));
+    // logits = H W2^T + b2 + bias: dW2, db2, dH; ReLU mask; scatter to the per-tracklet pre-activations U (subject) / V (object)
+    TRY(bw.lin("fc_pred2logits.2", m->head2, dlogits, ldg, pw.H, df, (int)n_pairs, P, df, pw.dH, df, false));
+    TRY(bigc_relu_bwd_f32(s, pw.dH, pw.H, n_pairs * (long)df));
+    ZERO(pw.dU, (size_t)NT * df);
+    ZERO(pw.dV, (size_t)NT * df);
+    TRY(bigc_pair_scatter_add(hs, pw.dH, pair_so, pw.dU, pw.dV, n_pairs, df));
+    // U = [clsme | e2e] W1[:, (0 | 2dc)]^T + b1,  V = [clsme | e2e] W1[:, (dc | 2dc+de)]^T: column blocks of dW1, db1 = colsum(dU)
+    float* gw1 = grad_of(m, "fc_pred2logits.0.weight");
+    float* gb1 = grad_of(m, "fc_pred2logits.0.bias");
+    const int off_se = 2 * dc, off_oe = 2 * dc + de;
+    if (gw1) {
+        if (dc > 0) {
+            TRY(bigc_linear_dw_f32(s, pw.dU, df, pw.clsme, dc, nullptr, 1, dc, gw1, hk, gb1, NT, df, dc));
+            TRY(bigc_linear_dw_f32(s, pw.dV, df, pw.clsme, dc, nullptr, 1, dc, gw1 + dc, hk, nullptr, NT, df, dc));
+            TRY(bigc_linear_dw_f32(s, pw.dU, df, w.e2e, de, nullptr, 1, de, gw1 + off_se, hk, nullptr, NT, df, de));
+        } else {
+            TRY(bigc_linear_dw_f32(s, pw.dU, df, w.e2e, de, nullptr, 1, de, gw1 + off_se, hk, gb1, NT, df, de));
+        }
+        TRY(bigc_linear_dw_f32(s, pw.dV, df, w.e2e, de, nullptr, 1, de, gw1 + off_oe, hk, nullptr, NT, df, de));
     }
-    TRY(bigc_repack_conv_weight_bwd(hs, m->conv.w, m->conv_w_bwd, de, 2 * de, 3));
-    TRY(bigc_linear_f32(s, w.G, 3 * de, nullptr, 1, 3 * de, m->conv_w_bwd, 3 * de, nullptr, nullptr, 0, w.genti, 2 * de, R, 2 * de, 3 * de,
-                        BIGC_ACT_NONE));
-    TRY(bigc_relu_bwd_f32(s, w.genti, w.enti, (long)R * 2 * de));
-    TRY(bw.lin("fc_bbox2enti.2", m->bbox2, w.genti, 2 * de, w.hb, de, R, de, de, w.gh, de, false));
-    TRY(bigc_relu_bwd_f32(s, w.gh, w.hb, (long)R * de));
-    TRY(bw.lin("fc_bbox2enti.0", m->bbox0, w.gh, de, w.bbox8, 8, R, de, 8, nullptr, 0, false));
-    TRY(bw.lin("fc_feat2enti.2", m->feat2, w.genti + de, 2 * de, w.hv, de, R, de, de, w.gh, de, false));
-    TRY(bigc_relu_bwd_f32(s, w.gh, w.hv, (long)R * de));
-    TRY(bw.lin("fc_feat2enti.0", m->feat0, w.gh, de, b->feats, D, R, de, c.dim_feat, nullptr, 0, false));
+    // d enti2enco = dU W1[:, s_feat] + dV W1[:, o_feat]   (the classemes are inputs / a frozen embedding: no gradient)
+    float* gx = w.genco;            // not w.gx: frontend_train_backward uses that one as scratch
+    TRY(bigc_copy_cols(hs, m->head0.w + off_se, hk, pw.wblk, de, df, de));
+    TRY(bw.dx(pw.wblk, pw.dU, df, NT, df, de, gx, de, false));
+    TRY(bigc_copy_cols(hs, m->head0.w + off_oe, hk, pw.wblk, de, df, de));
+    TRY(bw.dx(pw.wblk, pw.dV, df, NT, df, de, gx, de, true));
+    TRY(frontend_train_backward(m, s, b, w, bw, gx));
     return BIGC_OK;
 }

@@ -1,5 +1,5 @@
 """The explicit pairwise baseline on the HIP path: drop-in for the reference's
-``models/model_pairwise_baseline.py:Base_C`` (eval forward).
+``models/model_pairwise_baseline.py:Base_C`` (eval forward: SURVEY.md section 8 row f3; training step :276-312).
 The torch modules only own the parameters under the reference's key names; the front-end, the N x N pair fusion and the
 classifier run in the HIP library (``bigc_pair_forward``); the triplet bookkeeping of ``construct_triplet`` (:306-395) is a
 handful of device-side torch index operations on the pair logits."""
@@ -57,7 +57,8 @@ class Base_C(nn.Module):
         """Eval contract of the reference (:93-127): one entry per video, ``None`` for an empty video or when no pair
         overlaps in time, else ``(uniq_quintuples, uniq_scores (U,3), uniq_dura_inters, uniq_query_ids)``."""
         if self.is_train:
-            raise NotImplementedError("Base_C training (models/model_pairwise_baseline.py:276-303) is not built on the HIP path")
+            assert pos_id_list is not None and label_list is not None
+            return self._forward_train(proposal_list, pos_id_list, label_list)
         self.topk = topk
         keep = [i for i, p in enumerate(proposal_list) if p.num_proposals > 0]
         res = [None] * len(proposal_list)
@@ -72,6 +73,18 @@ class Base_C(nn.Module):
             if off[j + 1] > off[j]:
                 res[i] = self.construct_triplet(proposal_list[i], out["pair_logits"][off[j]:off[j + 1]])
         return res
+
+    def _forward_train(self, proposal_list, pos_id_list, label_list):
+        """(:276-312) logits of the labelled pairs of every video, BCE-with-logits mean over all of them:
+        ``(total_loss, {"cls": loss})``; gradients flow to the parameters through ``HipPairTrainStep``."""
+        from bigc_hip.pair_train_step import HipPairTrainStep
+        assert len(proposal_list) == len(label_list) == len(pos_id_list)
+        dev = next(self.parameters()).device
+        packed = PackedBatch(list(proposal_list), dev)
+        params = [p for _, p in self.named_parameters()]
+        terms = HipPairTrainStep.apply(self, packed, list(pos_id_list), list(label_list), *params)
+        loss_dict = {"cls": terms[0]}
+        return torch.stack(list(loss_dict.values())).sum(), loss_dict
 
     def construct_triplet(self, proposal, pred_logits):
         """(:306-395) on the device: softmax, per-pair top-k, temporal-overlap filter, lexicographic order of the (unique)

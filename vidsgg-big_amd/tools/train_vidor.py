@@ -2,7 +2,7 @@
 """VidOR training on the HIP path with the flags of the reference's ``tools/train_vidor.py:642-651``
 (``--cfg_path --from_checkpoint --ckpt_path --train_baseline --train_grounding --output_dir --save_tag``):
 BIG-C classification stage by default (``train_cls_stage`` :357-495), the temporal grounding scorer with
-``--train_grounding`` (``train_grounding_stage`` :497-636).  One process per GPU
+``--train_grounding`` (``train_grounding_stage`` :497-636), the pairwise baseline with ``--train_baseline`` (:175-352).  One process per GPU
 (``python -m torch.distributed.run --nproc-per-node N tools/train_vidor.py ...``); see ``_common.training_loop``."""
 import argparse
 import os
@@ -41,6 +41,39 @@ def train_cls_stage(cfg_path, output_dir=None, save_tag="", from_checkpoint=Fals
                          sort_key=lambda pg: pg[1].max_frames, from_checkpoint=from_checkpoint, ckpt_path=ckpt_path, epochs=epochs)
 
 
+def train_baseline(cfg_path, output_dir=None, save_tag="", from_checkpoint=False, ckpt_path=None, synthetic=0, n_trajs=24, epochs=None):
+    """``train_baseline`` of the reference (:175-352): Base_C on the proposal pairs that hit a GT predicate
+    (``prop_pair_to_gt_pred`` :78-170, vIoU threshold ``model_config["positive_vIoU_th"]``), BCE over multi-hot labels."""
+    from bigc_hip import _lib
+    from bigc_hip.packed import PackedBatch
+    from bigc_hip.pair_train_step import assign_pair_labels
+    from models import Base_C
+    rank, world, device, dist = init_process()
+    cfg = parse_config_py(cfg_path)
+    output_dir = output_dir or os.path.dirname(os.path.abspath(cfg_path))
+    os.makedirs(output_dir, exist_ok=True)
+    model_config = ensure_table_files(cfg["model_config"], output_dir)
+    torch.manual_seed(0)
+    model = Base_C(model_config, is_train=True).to(device)
+    pairs = [(p, g) for p, g, _ in synthetic_vidor_source(model_config, synthetic, n_trajs, seed=7654)] if synthetic else _dataset(cfg)
+    lib = _lib.load()
+    data, th = [], model_config.get("positive_vIoU_th", 0.5)
+    for p, g in pairs:                                        # label assignment once, as the reference's cached label_map (:226-258)
+        if p.num_proposals < 2 or g.num_trajs == 0 or g.num_preds == 0:
+            continue
+        ids, multihot = assign_pair_labels(lib, PackedBatch([p.to(device)], device), [g], th, model_config["num_pred_cats"])[0]
+        if ids is not None:
+            data.append((p, ids, multihot))
+    if rank == 0:
+        print("Base_C: %d of %d videos have labelled pairs (%d pairs)" % (len(data), len(pairs), sum(int(d[1].shape[0]) for d in data)), flush=True)
+
+    def step(model, items):
+        return model([p.to(device) for p, _, _ in items], [i for _, i, _ in items], [m for _, _, m in items])
+
+    return training_loop(model, data, cfg["train_config"], output_dir, save_tag, step, rank, world, device, dist,
+                         from_checkpoint=from_checkpoint, ckpt_path=ckpt_path, epochs=epochs)
+
+
 def train_grounding_stage(cfg_path, output_dir=None, save_tag="", from_checkpoint=False, ckpt_path=None, synthetic=0, n_trajs=16, epochs=None):
     rank, world, device, dist = init_process()
     cfg = parse_config_py(cfg_path)
@@ -75,10 +108,8 @@ if __name__ == "__main__":
     ap.add_argument("--n_trajs", type=int, default=None)
     ap.add_argument("--epochs", type=int, default=None)
     a = ap.parse_args()
-    if a.train_baseline:
-        raise SystemExit("--train_baseline (Base_C, models/model_pairwise_baseline.py) is outside the BIG-C hot path built here")
     kw = dict(output_dir=a.output_dir, save_tag=a.save_tag, from_checkpoint=a.from_checkpoint, ckpt_path=a.ckpt_path, synthetic=a.synthetic,
               epochs=a.epochs)
     if a.n_trajs:
         kw["n_trajs"] = a.n_trajs
-    (train_grounding_stage if a.train_grounding else train_cls_stage)(a.cfg_path, **kw)
+    (train_baseline if a.train_baseline else train_grounding_stage if a.train_grounding else train_cls_stage)(a.cfg_path, **kw)

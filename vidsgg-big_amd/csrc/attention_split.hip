@@ -14,6 +14,7 @@
 // which only does work when the flag carries this launch's id.
 #include "common.h"
 #include "prof.h"
+#include <cstdlib>
 
 typedef _Float16 a16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 a16x2 __attribute__((ext_vector_type(2)));
@@ -370,6 +371,182 @@ __global__ __launch_bounds__(256, 2) void role_fused_h_kernel(const float* __res
     if (amax >= 32768.0f) atomicMax(flag, run_id);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Self-attention core with K and V of a (sequence, head) split ONCE per workgroup into LDS (mha_core_h_kernel splits them
+// again in every 32-query wave: 6x the conversions and 6x the L2 round trips at 192 queries).  One workgroup of NQT waves
+// per (sequence, head); wave w owns the query tile w.  LDS image, f16 head / residual planes:
+//   K   [key][64 dims], 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ (r & 7)   (ds_read_b128 fragment reads)
+//   V^T [dim][keys of the sequence], rows of 2 * 32 * NQT + 16 bytes; inside a 32-key tile key 16u + 8a + 4hi + b sits at
+//       position 16u + 8hi + 4a + b, so that the 8 k-slots (hi, j = 4a + b) of a lane are one 16-byte read
+template <int NQT, bool DROP>
+__global__ __launch_bounds__(64 * NQT) void mha_core_lds_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                                const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
+                                                                const int32_t* __restrict__ off, int n_head, float scale,
+                                                                float* __restrict__ lse, const DropSpec drop, int* __restrict__ flag, int run_id) {
+    constexpr int HD = 64, NK = 32 * NQT, VS = 2 * NK + 16, NTH = 64 * NQT;
+    constexpr int KP = NK * 128, VP = HD * VS;                 // bytes of a K plane / a V^T plane
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KP + 2 * VP];
+    unsigned char* const Kh = smem;
+    unsigned char* const Kr = smem + KP;
+    unsigned char* const Vh = smem + 2 * KP;
+    unsigned char* const Vr = smem + 2 * KP + VP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.x % n_head, s = blockIdx.x / n_head;
+    const int q0 = off[s], nq = off[s + 1] - q0;               // self-attention: keys = queries
+    if (nq <= 0) return;
+    const int n_kt = (nq + 31) / 32;
+    float chk = 0.f, amax = 0.f;
+
+    // ---- fill: K rows (8 threads per row, 32 bytes of f32 each), V columns (a wave takes 8 keys x 64 dims)
+    {
+        f32x4 kraw[4][2];
+        float vraw[4][8];
+        const float* kb = k + (size_t)q0 * ldk + h * HD;
+        const float* vb = v + (size_t)q0 * ldv + h * HD + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int unit = tid + NTH * r, key = unit >> 3, c = unit & 7;
+            const float* kp = kb + (size_t)min(key, nq - 1) * ldk + 8 * c;
+            kraw[r][0] = *(const f32x4*)kp;
+            kraw[r][1] = *(const f32x4*)(kp + 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k0 = 8 * (wave + NQT * r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vraw[r][j] = vb[(size_t)min(k0 + j, nq - 1) * ldv];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int unit = tid + NTH * r, key = unit >> 3, c = unit & 7;
+            const float x[8] = {kraw[r][0][0], kraw[r][0][1], kraw[r][0][2], kraw[r][0][3], kraw[r][1][0], kraw[r][1][1], kraw[r][1][2], kraw[r][1][3]};
+            a16x8 hh, rr;
+            split8(x, hh, rr, chk, amax);
+            const int a = key * 128 + ((c ^ (key & 7)) << 4);
+            *(a16x8*)(Kh + a) = hh;
+            *(a16x8*)(Kr + a) = rr;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k0 = 8 * (wave + NQT * r);                // keys k0 .. k0+7 = tile kt, u, a: k0 = 32 kt + 16 u + 8 a
+            a16x8 hh, rr;
+            split8(vraw[r], hh, rr, chk, amax);
+            // keys k0 + 4 hi' + b (hi' = 0, 1) go to positions (32 kt + 16 u) + 8 hi' + 4 a + b
+            const int base = (k0 & ~15), a4 = ((k0 >> 3) & 1) * 4;
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const int row = lane * VS;
+            *(h4*)(Vh + row + 2 * (base + a4)) = h4{hh[0], hh[1], hh[2], hh[3]};
+            *(h4*)(Vh + row + 2 * (base + 8 + a4)) = h4{hh[4], hh[5], hh[6], hh[7]};
+            *(h4*)(Vr + row + 2 * (base + a4)) = h4{rr[0], rr[1], rr[2], rr[3]};
+            *(h4*)(Vr + row + 2 * (base + 8 + a4)) = h4{rr[4], rr[5], rr[6], rr[7]};
+        }
+    }
+    // this wave's queries, pre-scaled and split (overlaps the fill of the other waves)
+    const int qt = wave;
+    const bool active = qt * 32 < nq;
+    const int qrow = min(qt * 32 + l31, nq - 1);
+    a16x8 qh[4], qr[4];
+    {
+        const float* qp = q + (size_t)(q0 + qrow) * ldq + h * HD + 8 * hi;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const f32x4 t0 = *(const f32x4*)(qp + 16 * st), t1 = *(const f32x4*)(qp + 16 * st + 4);
+            const float x[8] = {t0[0] * scale, t0[1] * scale, t0[2] * scale, t0[3] * scale, t1[0] * scale, t1[1] * scale, t1[2] * scale, t1[3] * scale};
+            split8(x, qh[st], qr[st], chk, amax);
+        }
+    }
+    if (!(fabsf(chk) < INFINITY) || amax >= 32768.0f) atomicMax(flag, run_id);
+    __syncthreads();
+    if (!active) return;
+
+    // ---- scores S^T[key][query]
+    f32x16 sc[NQT];
+    float m = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < NQT; ++kt) {
+        if (kt < n_kt) {
+            f32x16 c0 = zero16(), c1 = zero16();
+            const int row = kt * 32 + l31;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int a = row * 128 + (((2 * st + hi) ^ (row & 7)) << 4);
+                const a16x8 kh = *(const a16x8*)(Kh + a), kr = *(const a16x8*)(Kr + a);
+                c0 = MFMA_H(kh, qh[st], c0);
+                c1 = MFMA_H(kh, qr[st], c1);
+                c1 = MFMA_H(kr, qh[st], c1);
+            }
+            if (kt * 32 + 32 <= nq) {                           // a full tile: no per-key test (uniform branch)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[kt][r] = c0[r] + c1[r] * RI; m = fmaxf(m, sc[kt][r]); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sc[kt][r] = (kt * 32 + mfma_row(r, hi) < nq) ? c0[r] + c1[r] * RI : NEG_BIG;    // exp(NEG_BIG - m) = 0
+                    m = fmaxf(m, sc[kt][r]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = NEG_BIG;
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+    // exp through v_exp_f32 (2^x): relative error ~1e-7 * max(1, |s - m|), far below the probabilities' own sensitivity to
+    // the f32 round-off of s; masked keys hold NEG_BIG and come out as exactly 0
+    const float mlog = m * 1.44269504088896341f;
+#pragma unroll
+    for (int kt = 0; kt < NQT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], 1.44269504088896341f, -mlog));
+            sc[kt][r] = e;
+            l += e;
+        }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    if (lse && hi == 0 && qt * 32 + l31 < nq) lse[(size_t)(q0 + qt * 32 + l31) * n_head + h] = m + logf(l);
+
+    // ---- O = P V, output column of d-tile t = 32 t + l31
+    f32x16 o0[2], o1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { o0[t] = zero16(); o1[t] = zero16(); }
+#pragma unroll
+    for (int kt = 0; kt < NQT; ++kt) {
+        if (kt < n_kt) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float p8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float p = sc[kt][8 * u + j] * inv;
+                    if (DROP) p = drop_keep(drop, drop_att_idx(q0 + qrow, n_head, h, kt * 32 + mfma_row(8 * u + j, hi))) ? p * drop.scale : 0.f;
+                    p8[j] = p;
+                }
+                a16x8 ph, pr;
+                float a_ = 0.f;
+                split8a(p8, ph, pr, a_);                     // probabilities: no range check needed
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int a = (32 * t + l31) * VS + 2 * (32 * kt + 16 * u + 8 * hi);
+                    const a16x8 vh = *(const a16x8*)(Vh + a), vr = *(const a16x8*)(Vr + a);
+                    o0[t] = MFMA_H(ph, vh, o0[t]);
+                    o1[t] = MFMA_H(ph, vr, o1[t]);
+                    o1[t] = MFMA_H(pr, vh, o1[t]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = qt * 32 + mfma_row(r, hi);
+            if (row < nq) o[(size_t)(q0 + row) * ldo + h * HD + 32 * t + l31] = o0[t][r] + o1[t][r] * RI;
+        }
+}
+
 }  // namespace
 
 int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, float* att,
@@ -384,6 +561,15 @@ int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const flo
 int bigc_mha_core_h_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                            const int32_t* q_off, const int32_t* k_off, int n_seq, int n_qt, int n_head, float scale, float* lse,
                            const DropSpec& drop, int grid, int* flag, int run_id) {
+    // keys = queries of the same sequence (the launcher only comes here for self-attention): K / V shared through LDS
+    static const int use_lds = getenv("BIGC_MHA_LDS") ? atoi(getenv("BIGC_MHA_LDS")) : 1;
+    if (use_lds && n_qt <= 6) {
+#define LAUNCH_LDS(NQT, DROP) hipLaunchKernelGGL((mha_core_lds_kernel<NQT, DROP>), dim3(n_seq * n_head), dim3(64 * NQT), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, n_head, scale, lse, drop, flag, run_id)
+        if (n_qt <= 2) { if (drop.thresh) LAUNCH_LDS(2, true); else LAUNCH_LDS(2, false); }
+        else { if (drop.thresh) LAUNCH_LDS(6, true); else LAUNCH_LDS(6, false); }
+#undef LAUNCH_LDS
+        return 1;
+    }
     if (n_qt <= 2) hipLaunchKernelGGL(mha_core_h_kernel<2>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
     else if (n_qt <= 6) hipLaunchKernelGGL(mha_core_h_kernel<6>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
     else return 0;

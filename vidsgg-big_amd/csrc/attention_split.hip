@@ -547,11 +547,249 @@ __global__ __launch_bounds__(64 * NQT) void mha_core_lds_kernel(const float* __r
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Role attention + values with the entity-side operands split ONCE per video into LDS (role_fused_h_kernel splits e2a and
+// enco_output again in each of the video's 32-query waves).  One workgroup of six waves per video, wave w = query tile w
+// (nq <= 192), 64 KB of LDS used in turn for: e2a of role 0, e2a of role 1 (f16 head / residual planes, [entity][half] rows,
+// 16-byte chunks XOR-swizzled by entity & 7), then enco_output^T in chunks of 256 columns ([column][64 entity positions],
+// chunks swizzled by column & 7, entity positions permuted inside a 32-entity tile as in mha_core_lds_kernel).  The global
+// loads of the next LDS image are issued before the MFMA phase of the current one and held in registers.
+__global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
+                                                             const float* __restrict__ enco, int ldenc, float* __restrict__ att,
+                                                             float* __restrict__ values, const int32_t* __restrict__ e_off,
+                                                             int n_vid, int nq, int half, int d, float scale,
+                                                             int* __restrict__ flag, int run_id) {
+    constexpr int NTH = 384, PLANE = 32768, DC = 256;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE];
+    unsigned char* const Ph = smem;
+    unsigned char* const Pr = smem + PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int vid = blockIdx.x;
+    const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
+    if (ne <= 0) return;
+    const int qt = wave;
+    const bool active = qt * 32 < nq;
+    const int qrow = min(qt * 32 + l31, nq - 1);
+    const int hh = half / 2, per_row = half / 8, n_eunits = 64 * per_row, row_bytes = 2 * half;
+    const float* qp = p2a + (size_t)(vid * nq + qrow) * ldp + hi * hh;
+    float amax = 0.f;
+    float raw[6][8];
+
+    auto e_load = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int unit = min(tid + NTH * i, n_eunits - 1), ent = unit / per_row, c = unit - ent * per_row;
+            const float* p = e2a + (size_t)(e0 + min(ent, ne - 1)) * lde + r * half + 8 * c;
+            const f32x4 t0 = *(const f32x4*)p, t1 = *(const f32x4*)(p + 4);
+            raw[i][0] = t0[0]; raw[i][1] = t0[1]; raw[i][2] = t0[2]; raw[i][3] = t0[3];
+            raw[i][4] = t1[0]; raw[i][5] = t1[1]; raw[i][6] = t1[2]; raw[i][7] = t1[3];
+        }
+    };
+    auto e_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int unit = tid + NTH * i;
+            if (unit < n_eunits) {
+                const int ent = unit / per_row, c = unit - ent * per_row;
+                a16x8 h_, r_;
+                split8a(raw[i], h_, r_, amax);
+                const int a = ent * row_bytes + ((c ^ (ent & 7)) << 4);
+                *(a16x8*)(Ph + a) = h_;
+                *(a16x8*)(Pr + a) = r_;
+            }
+        }
+    };
+    // enco_output^T chunk dc: unit = (entity group g of 8, column dl of the chunk); lanes run along the columns
+    auto v_load = [&](int dc) {
+        const int dw = min(DC, d - dc * DC), n_units = 8 * dw;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int unit = min(tid + NTH * i, n_units - 1), g = unit / dw, dl = unit - g * dw;
+            const float* p = enco + (size_t)e0 * ldenc + dc * DC + dl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[i][j] = p[(size_t)min(8 * g + j, ne - 1) * ldenc];
+        }
+    };
+    auto v_store = [&](int dc) {
+        const int dw = min(DC, d - dc * DC), n_units = 8 * dw;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int unit = tid + NTH * i;
+            if (unit < n_units) {
+                const int g = unit / dw, dl = unit - g * dw;
+                a16x8 h_, r_;
+                split8a(raw[i], h_, r_, amax);
+                // entities 8g + 4hi' + b -> tile et = g>>2, u = (g>>1)&1, a = g&1: positions 16u + 8hi' + 4a + b of the tile
+                const int c0 = 4 * (g >> 2) + 2 * ((g >> 1) & 1), sw = dl & 7, ab = 8 * (g & 1);
+                const int b0 = dl * 128 + ((c0 ^ sw) << 4) + ab, b1 = dl * 128 + (((c0 + 1) ^ sw) << 4) + ab;
+                *(h4*)(Ph + b0) = h4{h_[0], h_[1], h_[2], h_[3]};
+                *(h4*)(Ph + b1) = h4{h_[4], h_[5], h_[6], h_[7]};
+                *(h4*)(Pr + b0) = h4{r_[0], r_[1], r_[2], r_[3]};
+                *(h4*)(Pr + b1) = h4{r_[4], r_[5], r_[6], r_[7]};
+            }
+        }
+    };
+
+    // ---- scores of both roles: sc[r][et] = S_r^T tile (entity rows, query columns)
+    f32x16 sc[2][2];
+    const int n_burst = hh / 32;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        f32x4 qraw[8];
+        e_load(r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qraw[j] = *(const f32x4*)(qp + r * half + 4 * j);
+        e_store();
+        __syncthreads();
+        f32x16 c0[2], c1[2];
+#pragma unroll
+        for (int et = 0; et < 2; ++et) { c0[et] = zero16(); c1[et] = zero16(); }
+        if (active) {
+            for (int kc = 0; kc < n_burst; ++kc) {
+                a16x8 qh[4], qr[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const float x[8] = {qraw[2 * s4][0], qraw[2 * s4][1], qraw[2 * s4][2], qraw[2 * s4][3],
+                                        qraw[2 * s4 + 1][0], qraw[2 * s4 + 1][1], qraw[2 * s4 + 1][2], qraw[2 * s4 + 1][3]};
+                    split8a(x, qh[s4], qr[s4], amax);
+                }
+                const float* qn = qp + r * half + min(kc + 1, n_burst - 1) * 32;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qraw[j] = *(const f32x4*)(qn + 4 * j);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int chunk = hi * (hh / 8) + kc * 4 + s4;
+#pragma unroll
+                    for (int et = 0; et < 2; ++et) {
+                        const int row = 32 * et + l31;
+                        const int a = row * row_bytes + ((chunk ^ (row & 7)) << 4);
+                        const a16x8 eh = *(const a16x8*)(Ph + a), er = *(const a16x8*)(Pr + a);
+                        c0[et] = MFMA_H(eh, qh[s4], c0[et]);
+                        c1[et] = MFMA_H(eh, qr[s4], c1[et]);
+                        c1[et] = MFMA_H(er, qh[s4], c1[et]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sc[r][et][g] = (c0[et][g] + c1[et][g] * RI) * scale;
+        __syncthreads();                                        // every wave is done reading this image
+    }
+
+    // ---- softmax over the entities of each role (torch.softmax: exp(s - max) / sum), then over the two roles: the same
+    // operation sequence as role_fused_kernel, so that arg-max decisions between nearly equal weights fall the same way
+    a16x8 ph[2][2][2], pr[2][2][2];
+    if (active) {
+        float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int et = 0; et < 2; ++et)
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    if (et * 32 + mfma_row(g, hi) < ne) m[r] = fmaxf(m[r], sc[r][et][g]);
+            m[r] = fmaxf(m[r], __shfl_xor(m[r], 32));
+#pragma unroll
+            for (int et = 0; et < 2; ++et)
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    if (et * 32 + mfma_row(g, hi) < ne) l[r] += expf(sc[r][et][g] - m[r]);
+            l[r] += __shfl_xor(l[r], 32);
+        }
+        const int qq = qt * 32 + l31;
+        float* abase = att ? att + (size_t)2 * nq * e0 : nullptr;
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int n = et * 32 + mfma_row(g, hi);
+                const float s0 = sc[0][et][g], s1 = sc[1][et][g];
+                const float pe0 = expf(s0 - m[0]) / l[0], pe1 = expf(s1 - m[1]) / l[1];
+                const float mx = fmaxf(s0, s1);
+                const float w0 = expf(s0 - mx), w1 = expf(s1 - mx), ws = w0 + w1;
+                const bool ok = n < ne;
+                const float a0 = ok ? pe0 * (w0 / ws) : 0.f, a1 = ok ? pe1 * (w1 / ws) : 0.f;
+                sc[0][et][g] = a0;
+                sc[1][et][g] = a1;
+                if (abase && ok && qq < nq) {
+                    abase[((size_t)0 * nq + qq) * ne + n] = a0;
+                    abase[((size_t)1 * nq + qq) * ne + n] = a1;
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int et = 0; et < 2; ++et)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float p8[8], a_ = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) p8[j] = sc[r][et][8 * u + j];
+                    split8a(p8, ph[r][et][u], pr[r][et][u], a_);          // probabilities: no range check needed
+                }
+    }
+
+    // ---- values_r = att_r @ enco_output, 256 columns of enco_output^T in LDS at a time
+    const int n_dc = (d + DC - 1) / DC;
+    for (int dc = 0; dc < n_dc; ++dc) {
+        v_load(dc);
+        v_store(dc);
+        __syncthreads();
+        if (active) {
+            const int n_dt = min(DC, d - dc * DC) / 32;                    // d % 32 == 0 (launcher)
+#pragma unroll 1
+            for (int dtl = 0; dtl < n_dt; ++dtl) {
+                const int dl = 32 * dtl + l31;
+                a16x8 vh[2][2], vr[2][2];
+#pragma unroll
+                for (int et = 0; et < 2; ++et)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int a = dl * 128 + (((4 * et + 2 * u + hi) ^ (dl & 7)) << 4);
+                        vh[et][u] = *(const a16x8*)(Ph + a);
+                        vr[et][u] = *(const a16x8*)(Pr + a);
+                    }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    f32x16 c0 = zero16(), c1 = zero16();
+#pragma unroll
+                    for (int et = 0; et < 2; ++et)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            c0 = MFMA_H(ph[r][et][u], vh[et][u], c0);
+                            c1 = MFMA_H(ph[r][et][u], vr[et][u], c1);
+                            c1 = MFMA_H(pr[r][et][u], vh[et][u], c1);
+                        }
+                    float* op = values + ((size_t)r * n_vid * nq + (size_t)vid * nq) * d + dc * DC + dl;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const int row = qt * 32 + mfma_row(g, hi);
+                        if (row < nq) op[(size_t)row * d] = c0[g] + c1[g] * RI;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (amax >= 32768.0f) atomicMax(flag, run_id);
+}
+
 }  // namespace
 
 int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, float* att,
                              float* values, const int32_t* e_off, int n_vid, int nq, int n_qt, int half, int d, float scale, int grid,
                              int* flag, int run_id) {
+    // at most 192 queries and role halves of at most 256: one workgroup per video with the entity operands shared through LDS
+    static const int use_lds = getenv("BIGC_ROLE_LDS") ? atoi(getenv("BIGC_ROLE_LDS")) : 1;
+    if (use_lds && n_qt <= 6 && half <= 256) {
+        hipLaunchKernelGGL(role_fused_lds_kernel, dim3(n_vid), dim3(384), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, half, d,
+                           scale, flag, run_id);
+        return 1;
+    }
     hipLaunchKernelGGL(role_fused_h_kernel, dim3(grid), dim3(256), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, n_qt,
                        half, d, scale, flag, run_id);
     return 1;

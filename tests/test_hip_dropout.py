@@ -34,7 +34,7 @@ def test_mask_generator_matches_numpy_mirror():
     assert abs(frac - p) < 0.03
 
 
-@pytest.mark.parametrize("H,hd,ql", [(2, 16, [5, 40]), (8, 64, [70, 33]), (4, 8, [3])])
+@pytest.mark.parametrize("H,hd,ql", [(2, 16, [5, 40]), (8, 64, [70, 33]), (4, 8, [3]), (8, 64, [64, 20]), (2, 64, [192, 1, 161])])
 def test_attention_core_with_dropout_fwd_bwd(H, hd, ql):
     lib = _lib.load()
     g = torch.Generator().manual_seed(sum(ql) + hd)

@@ -248,7 +248,8 @@ def test_mha_core_cross_lengths(lib):
     assert rel_err(o, want) < 5e-6
 
 
-@pytest.mark.parametrize("nq,half,d,ns", [(192, 256, 512, [64, 1, 180]), (12, 8, 16, [6, 9]), (40, 16, 160, [33]), (192, 256, 512, [64, 1, 37]), (70, 64, 96, [5, 32])])
+@pytest.mark.parametrize("nq,half,d,ns", [(192, 256, 512, [64, 1, 180]), (12, 8, 16, [6, 9]), (40, 16, 160, [33]), (192, 256, 512, [64, 1, 37]), (70, 64, 96, [5, 32]),
+                                          (200, 128, 320, [40, 64]), (33, 256, 288, [64, 2])])
 def test_role_attention_and_values(lib, nq, half, d, ns):
     g = torch.Generator().manual_seed(nq + half)
     B, NT = len(ns), sum(ns)

@@ -709,8 +709,9 @@ __global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __rest
                 const int n = et * 32 + mfma_row(g, hi);
                 const float s0 = sc[0][et][g], s1 = sc[1][et][g];
                 const float pe0 = expf(s0 - m[0]) / l[0], pe1 = expf(s1 - m[1]) / l[1];
-                const float mx = fmaxf(s0, s1);
-                const float w0 = expf(s0 - mx), w1 = expf(s1 - mx), ws = w0 + w1;
+                // softmax over the two roles: the larger score gives expf(0) = 1 exactly, one exponential for the other
+                const float es = expf(-fabsf(s0 - s1));
+                const float w0 = s0 >= s1 ? 1.0f : es, w1 = s0 >= s1 ? es : 1.0f, ws = w0 + w1;
                 const bool ok = n < ne;
                 const float a0 = ok ? pe0 * (w0 / ws) : 0.f, a1 = ok ? pe1 * (w1 / ws) : 0.f;
                 sc[0][et][g] = a0;

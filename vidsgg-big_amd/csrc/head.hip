@@ -72,7 +72,41 @@ __global__ __launch_bounds__(256) void head_gather_kernel(const float* __restric
     for (int i = threadIdx.x; i < n_pcat; i += 256) bias_out[(size_t)row * n_pcat + i] = bm[i];
 }
 
+// Factorised head (eval, single-layer classifier): the concat row is never built.  logits = query W_q^T + b + bias_matrix row
+// + U[subject] + V[object], where U / V = the per-tracklet products of the subject / object column blocks of the classifier
+// weight (computed by the caller with NT rows instead of B*Q).  This kernel: arg-max, then acc = bias row + U[ts] + V[to].
+__global__ __launch_bounds__(256) void head_pick_kernel(const float* __restrict__ att, const int32_t* __restrict__ e_off,
+                                                        const int32_t* __restrict__ trk_cat, int nq, const float* __restrict__ U,
+                                                        const float* __restrict__ V, int lduv, const float* __restrict__ bias_matrix,
+                                                        int n_ecat, int n_pcat, int32_t* __restrict__ soid, float* __restrict__ acc) {
+    const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;          // one wave per (video, query) row
+    const int row = blockIdx.x * 4 + sub;
+    const int vid = row / nq, qi = row - vid * nq;
+    const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
+    if (ne <= 0) return;
+    int so[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        so[r] = wave_argmax_first(att + (size_t)2 * nq * e0 + ((size_t)r * nq + qi) * ne, ne, lane);
+        if (lane == 0) soid[((size_t)vid * 2 + r) * nq + qi] = so[r];
+    }
+    const int ts = e0 + so[0], to = e0 + so[1];
+    const float* bm = bias_matrix + ((size_t)trk_cat[ts] * n_ecat + trk_cat[to]) * n_pcat;
+    const float* u = U + (size_t)ts * lduv;
+    const float* v = V + (size_t)to * lduv;
+    for (int i = lane; i < n_pcat; i += 64) acc[(size_t)row * n_pcat + i] = (bm[i] + u[i]) + v[i];
+}
+
 }  // namespace
+
+int bigc_head_pick(hipStream_t s, const float* att, const int32_t* e_off, const int32_t* trk_cat, int n_vid, int nq, const float* U,
+                   const float* V, int lduv, const float* bias_matrix, int n_ecat, int n_pcat, int32_t* soid, float* acc) {
+    ProfScope ps((void*)s, FAM_HEAD_GATHER, 0.0, 12.0 * n_vid * (double)nq * n_pcat);
+    hipLaunchKernelGGL(head_pick_kernel, dim3((n_vid * nq + 3) / 4), dim3(256), 0, s, att, e_off, trk_cat, nq, U, V, lduv, bias_matrix, n_ecat,
+                       n_pcat, soid, acc);
+    BIGC_LAUNCH_CHECK("head_pick");
+    return BIGC_OK;
+}
 
 extern "C" int bigc_head_gather(void* stream, const float* att, const int32_t* e_off, const int32_t* trk_cat, int n_vid, int nq,
                                 const float* query, int dq, int n_seg, const float* const* seg_src_host, const int32_t* seg_width_host,

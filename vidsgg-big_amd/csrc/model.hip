@@ -361,12 +361,28 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         }
         seg_src[n_seg] = e2e; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
     }
-    TRY(bigc_head_gather(s, out->att, b->vid_trk_off, b->trk_cat, B, Q, w.query, dp, n_seg, seg_src, seg_w, seg_cat, m->bias_matrix,
-                         c.num_enti_cats, c.num_pred_cats, out->soid, w.head_in, m->head_k, w.bias_g));
     if (c.variant == 0) {
-        TRY(linear(s, w.head_in, m->head_k, m->head0, out->pred_logits, c.num_pred_cats, BQ, c.num_pred_cats, m->head_k, BIGC_ACT_NONE,
-                   w.bias_g, c.num_pred_cats));
+        // Factorised classifier (:498-503): the concat row [query | s_seg0 | o_seg0 | s_seg1 | ...] is never built.  The
+        // subject / object column blocks of the weight are applied per TRACKLET (NT rows instead of B*Q): U = sum over the
+        // segments of seg W[:, s-block]^T, V likewise; then logits = query W[:, :dp]^T + b + (bias row + U[s] + V[o]).
+        const int P = c.num_pred_cats, hk = m->head_k, ldu = (P + 3) & ~3;
+        float* U = w.head_in;                                  // the arena of the concat rows (B*Q x head_k) is far larger
+        float* V = U + (size_t)NT * ldu;
+        int col = dp;
+        for (int g = 0; g < n_seg; ++g) {
+            const float* Wg = m->head0.w + col;
+            for (int role = 0; role < 2; ++role) {
+                float* dst = role == 0 ? U : V;
+                TRY(bigc_linear_f32(s, seg_src[g], seg_w[g], seg_cat[g] ? b->trk_cat : nullptr, 1, seg_w[g], Wg + role * seg_w[g], hk, nullptr,
+                                    g ? dst : nullptr, ldu, dst, ldu, NT, P, seg_w[g], BIGC_ACT_NONE));
+            }
+            col += 2 * seg_w[g];
+        }
+        TRY(bigc_head_pick(hs, out->att, b->vid_trk_off, b->trk_cat, B, Q, U, V, ldu, m->bias_matrix, c.num_enti_cats, P, out->soid, w.bias_g));
+        TRY(bigc_linear_f32(s, w.query, dp, nullptr, 1, dp, m->head0.w, hk, m->head0.b, w.bias_g, P, out->pred_logits, P, BQ, P, dp, BIGC_ACT_NONE));
     } else {
+        TRY(bigc_head_gather(s, out->att, b->vid_trk_off, b->trk_cat, B, Q, w.query, dp, n_seg, seg_src, seg_w, seg_cat, m->bias_matrix,
+                             c.num_enti_cats, c.num_pred_cats, out->soid, w.head_in, m->head_k, w.bias_g));
         TRY(linear(s, w.head_in, m->head_k, m->head0, w.hh, df, BQ, df, m->head_k, BIGC_ACT_RELU));
         TRY(linear(s, w.hh, df, m->head2, out->pred_logits, c.num_pred_cats, BQ, c.num_pred_cats, df, BIGC_ACT_NONE, w.bias_g,
                    c.num_pred_cats));

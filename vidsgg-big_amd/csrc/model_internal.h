@@ -47,4 +47,6 @@ inline int linear(void* s, const float* A, int lda, const Lin& l, float* C, int 
 }
 
 int bigc_fill_offsets(hipStream_t s, int32_t* p, int n, int step);
+int bigc_head_pick(hipStream_t s, const float* att, const int32_t* e_off, const int32_t* trk_cat, int n_vid, int nq, const float* U,
+                   const float* V, int lduv, const float* bias_matrix, int n_ecat, int n_pcat, int32_t* soid, float* acc);
 int bigc_repack_conv_weight(hipStream_t s, const float* w, float* out, int n_out, int n_in, int taps);

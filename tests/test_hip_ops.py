@@ -291,6 +291,43 @@ def test_role_attention_and_values(lib, nq, half, d, ns):
         assert torch.equal(vals2, vals3)
 
 
+@pytest.mark.parametrize("nq,half,d,ns,exact", [(192, 256, 512, [64, 1, 37], 0), (70, 64, 96, [5, 32], 0), (192, 256, 512, [64, 20], 1),
+                                                 (200, 128, 64, [40], 0)])
+def test_role_fused_with_projected_values(lib, nq, half, d, ns, exact):
+    """bigc_role_fused_proj_f32: values_r = relu(att_r @ proj_r + bias_r) with per-role right-hand rows (the first role-wise
+    linear applied to the entity rows), split-operand LDS kernel / f32-MFMA kernel (exact mode, nq > 192)"""
+    g = torch.Generator().manual_seed(nq + d + len(ns))
+    B, NT = len(ns), sum(ns)
+    p2a = torch.randn(B * nq, 2 * half, generator=g)
+    e2a = torch.randn(NT, 2 * half, generator=g)
+    proj = torch.randn(2, NT, d, generator=g)
+    bias = torch.randn(2, d, generator=g)
+    off = np.concatenate([[0], np.cumsum(ns)])
+    scale = 1.0 / math.sqrt(d)
+    att_want, val_want = [], torch.empty(2, B * nq, d)
+    for v in range(B):
+        e = e2a[off[v]:off[v + 1]]
+        p = p2a[v * nq:(v + 1) * nq]
+        s = torch.stack([p[:, :half] @ e[:, :half].t(), p[:, half:] @ e[:, half:].t()], 0) * scale
+        a = torch.softmax(s, 2) * torch.softmax(s, 0)
+        att_want.append(a.reshape(-1))
+        for r in range(2):
+            val_want[r, v * nq:(v + 1) * nq] = torch.relu(a[r] @ proj[r, off[v]:off[v + 1]] + bias[r])
+    att_want = torch.cat(att_want)
+    pd, ed, xd, bd, offd = dev(p2a), dev(e2a), dev(proj), dev(bias), i32(off)
+    att = torch.full((2 * nq * NT,), float("nan"), device=DEV)
+    vals = torch.full((2, B * nq, d), float("nan"), device=DEV)
+    prev = lib.bigc_linear_set_exact(exact)
+    try:
+        _lib.check(lib.bigc_role_fused_proj_f32(S(), pd.data_ptr(), 2 * half, ed.data_ptr(), 2 * half, xd.data_ptr(), d, NT * d, bd.data_ptr(),
+                                                bd.data_ptr() + 4 * d, 1, att.data_ptr(), vals.data_ptr(), offd.data_ptr(), B, nq, max(ns), half, d, scale))
+        torch.cuda.synchronize()
+    finally:
+        lib.bigc_linear_set_exact(prev)
+    assert not torch.isnan(vals).any()
+    assert rel_err(att, att_want) < 1e-5 and rel_err(vals, val_want) < 1e-5
+
+
 def test_role_fused_out_of_range_falls_back_to_f32(lib):
     """operands beyond the f16 range (enco 2e5, p2a 5e4): the split-f16 role kernel must hand over to the f32-MFMA kernel and
     give the result of the exact mode"""

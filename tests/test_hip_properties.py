@@ -110,7 +110,11 @@ def test_topk_subset_and_gemm_modes_agree(setup):
         assert abs(a - b) <= 1e-4 * max(a, b), (v, r, q, a, b)
     clean = [v for v in range(N_VID) if v not in set(flips[:, 0].tolist())]
     assert len(clean) >= N_VID - 3
-    assert np.abs(o_split["pred_logits"] - o_exact["pred_logits"]).max() <= 1e-4 * np.abs(o_exact["pred_logits"]).max() or len(flips) > 0
+    # logits of the two modes: the f32-MFMA mode is itself 2e-4 away from a float64 evaluation (the split mode 3-5e-5,
+    # tests/accuracy_vs_fp64.py), so the two may differ by a few 1e-4; queries whose arg-max entity differs are left out
+    same_so = np.repeat((o_split["soid"] == o_exact["soid"]).all(1).reshape(-1), 1)
+    diff = np.abs(o_split["pred_logits"] - o_exact["pred_logits"]).max(1)
+    assert (diff * same_so).max() <= 6e-4 * np.abs(o_exact["pred_logits"]).max()
     for v in clean:
         n = int(o_exact["n_out"][v])
         assert n == int(o_split["n_out"][v])

@@ -418,7 +418,8 @@ __global__ __launch_bounds__(256) void role_fused_kernel(const float* __restrict
                                                          const float* __restrict__ enco, int ldenc, float* __restrict__ att,
                                                          float* __restrict__ values, const int32_t* __restrict__ e_off,
                                                          int n_vid, int nq, int n_qt, int half, int d, float scale,
-                                                         const int* __restrict__ run_flag, int run_id) {
+                                                         const int* __restrict__ run_flag, int run_id,
+                                                         long role_stride, const float* __restrict__ vbias0, const float* __restrict__ vbias1, int relu) {
     if (run_flag && *run_flag != run_id) return;        // fallback launch behind role_fused_h_kernel: only when that one flagged
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(256) void role_fused_kernel(const float* __restrict
 #pragma unroll 1
         for (int d0 = 0; d0 < d; d0 += 128) {
             const bool cok = d0 + 4 * l31 < d;            // d % 4 == 0 (checked by the launcher)
-            const float* vb = enco + (size_t)e0 * ldenc + (cok ? d0 + 4 * l31 : 0);
+            const float* vb = enco + r * role_stride + (size_t)e0 * ldenc + (cok ? d0 + 4 * l31 : 0);     // role_stride != 0: per-role rows
             f32x16 acc[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = zero16();
@@ -538,10 +539,14 @@ __global__ __launch_bounds__(256) void role_fused_kernel(const float* __restrict
                     for (int t = 0; t < 4; ++t) acc[t] = mfma32(sc[r][et][g], vv[g][t], acc[t]);
             }
             if (cok) {
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (vbias0) bv = *(const f32x4*)((r ? vbias1 : vbias0) + d0 + 4 * l31);
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int row = qt * 32 + mfma_row(g, hi);
-                    if (row < nq) *(f32x4*)(op + (size_t)row * d + d0 + 4 * l31) = f32x4{acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
+                    f32x4 ov = f32x4{acc[0][g], acc[1][g], acc[2][g], acc[3][g]} + bv;
+                    if (relu) { ov[0] = fmaxf(ov[0], 0.f); ov[1] = fmaxf(ov[1], 0.f); ov[2] = fmaxf(ov[2], 0.f); ov[3] = fmaxf(ov[3], 0.f); }
+                    if (row < nq) *(f32x4*)(op + (size_t)row * d + d0 + 4 * l31) = ov;
                 }
             }
         }
@@ -560,7 +565,7 @@ int bigc_mha_core_h_launch(hipStream_t s, const float* q, int ldq, const float* 
 
 int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, float* att,
                              float* values, const int32_t* e_off, int n_vid, int nq, int n_qt, int half, int d, float scale, int grid,
-                             int* flag, int run_id);
+                             int* flag, int run_id, long role_stride, const float* vbias0, const float* vbias1, int relu);
 
 namespace {
 // BIGC_LINEAR_EXACT / bigc_linear_set_exact also select the f32-MFMA attention kernels
@@ -661,9 +666,9 @@ extern "C" int bigc_role_values_f32(void* stream, const float* att, const float*
     return BIGC_OK;
 }
 
-extern "C" int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc,
-                                   float* att, float* values, const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d,
-                                   float scale) {
+static int role_fused_launch(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, long role_stride,
+                             const float* vbias0, const float* vbias1, int relu, float* att, float* values, const int32_t* e_off, int n_vid, int nq, int max_ent,
+                             int half, int d, float scale) {
     BIGC_CHECK_ARG(p2a && e2a && enco && values && e_off, "role_fused: null pointer");
     BIGC_CHECK_ARG(half % 64 == 0 && ldp % 4 == 0 && lde % 4 == 0 && d % 4 == 0 && ldenc % 4 == 0, "role_fused: half=%d must be a multiple of 64, d=%d of 4", half, d);
     BIGC_CHECK_ARG(max_ent >= 1 && max_ent <= 64, "role_fused: at most 64 entities per video (got %d): use role_attention + role_values", max_ent);
@@ -674,19 +679,34 @@ extern "C" int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, cons
     // split-operand f16 MFMA kernel first; the f32-MFMA kernel behind it runs only if an operand was out of the f16 range
     int* run_flag = nullptr;
     int run_id = 0;
-    if (d % 32 == 0 && !bigc_linear_get_exact()) {
+    const bool projected = role_stride != 0 || vbias0 || relu;
+    if (d % 32 == 0 && !bigc_linear_get_exact() && (!projected || (n_qt <= 6 && half <= 256))) {
         run_id = g_mha_run.fetch_add(1, std::memory_order_relaxed) + 1;
         run_flag = mha_flag_slot(run_id);
         if (!run_flag) return BIGC_ERR_HIP;
         bigc_role_fused_h_launch((hipStream_t)stream, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, n_qt, half, d, scale, grid,
-                                 run_flag, run_id);
+                                 run_flag, run_id, role_stride, vbias0, vbias1, relu);
     }
     if (max_ent <= 32)
         hipLaunchKernelGGL(role_fused_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, enco, ldenc, att, values,
-                           e_off, n_vid, nq, n_qt, half, d, scale, run_flag, run_id);
+                           e_off, n_vid, nq, n_qt, half, d, scale, run_flag, run_id, role_stride, vbias0, vbias1, relu);
     else
         hipLaunchKernelGGL(role_fused_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, enco, ldenc, att, values,
-                           e_off, n_vid, nq, n_qt, half, d, scale, run_flag, run_id);
+                           e_off, n_vid, nq, n_qt, half, d, scale, run_flag, run_id, role_stride, vbias0, vbias1, relu);
     BIGC_LAUNCH_CHECK("role_fused");
     return BIGC_OK;
+}
+
+extern "C" int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc,
+                                   float* att, float* values, const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d,
+                                   float scale) {
+    return role_fused_launch(stream, p2a, ldp, e2a, lde, enco, ldenc, 0, nullptr, nullptr, 0, att, values, e_off, n_vid, nq, max_ent, half, d, scale);
+}
+
+extern "C" int bigc_role_fused_proj_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* proj, int ldproj,
+                                        long role_stride, const float* bias0, const float* bias1, int relu, float* att, float* values,
+                                        const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d, float scale) {
+    BIGC_CHECK_ARG(role_stride % 4 == 0 && (bias0 == nullptr) == (bias1 == nullptr), "role_fused_proj: role_stride must be a multiple of 4, both biases or none");
+    BIGC_CHECK_ARG(!bias0 || ((((uintptr_t)bias0) | ((uintptr_t)bias1)) & 15) == 0, "role_fused_proj: biases must be 16-byte aligned");
+    return role_fused_launch(stream, p2a, ldp, e2a, lde, proj, ldproj, role_stride, bias0, bias1, relu, att, values, e_off, n_vid, nq, max_ent, half, d, scale);
 }

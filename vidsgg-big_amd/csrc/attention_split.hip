@@ -558,7 +558,8 @@ __global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __rest
                                                              const float* __restrict__ enco, int ldenc, float* __restrict__ att,
                                                              float* __restrict__ values, const int32_t* __restrict__ e_off,
                                                              int n_vid, int nq, int half, int d, float scale,
-                                                             int* __restrict__ flag, int run_id) {
+                                                             int* __restrict__ flag, int run_id,
+                                                             long role_stride, const float* __restrict__ vbias0, const float* __restrict__ vbias1, int relu) {
     constexpr int NTH = 384, PLANE = 32768, DC = 256;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE];
     unsigned char* const Ph = smem;
@@ -601,12 +602,12 @@ __global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __rest
         }
     };
     // enco_output^T chunk dc: unit = (entity group g of 8, column dl of the chunk); lanes run along the columns
-    auto v_load = [&](int dc) {
+    auto v_load = [&](int dc, int vr) {
         const int dw = min(DC, d - dc * DC), n_units = 8 * dw;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int unit = min(tid + NTH * i, n_units - 1), g = unit / dw, dl = unit - g * dw;
-            const float* p = enco + (size_t)e0 * ldenc + dc * DC + dl;
+            const float* p = enco + vr * role_stride + (size_t)e0 * ldenc + dc * DC + dl;
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[i][j] = p[(size_t)min(8 * g + j, ne - 1) * ldenc];
         }
@@ -734,10 +735,13 @@ __global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __rest
                 }
     }
 
-    // ---- values_r = att_r @ enco_output, 256 columns of enco_output^T in LDS at a time
-    const int n_dc = (d + DC - 1) / DC;
+    // ---- values_r = att_r @ enco_output, 256 columns of enco_output^T in LDS at a time.  With role_stride != 0 each role has
+    // its own right-hand rows (the first role-wise linear already applied to enco_output, see bigc_role_fused_proj_f32):
+    // one pass over the chunks per role, bias and ReLU in the store.
+    const int n_dc = (d + DC - 1) / DC, n_vr = role_stride ? 2 : 1;
+    for (int vr = 0; vr < n_vr; ++vr)
     for (int dc = 0; dc < n_dc; ++dc) {
-        v_load(dc);
+        v_load(dc, vr);
         v_store(dc);
         __syncthreads();
         if (active) {
@@ -745,31 +749,36 @@ __global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __rest
 #pragma unroll 1
             for (int dtl = 0; dtl < n_dt; ++dtl) {
                 const int dl = 32 * dtl + l31;
-                a16x8 vh[2][2], vr[2][2];
+                a16x8 vh[2][2], vr_[2][2];
 #pragma unroll
                 for (int et = 0; et < 2; ++et)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int a = dl * 128 + (((4 * et + 2 * u + hi) ^ (dl & 7)) << 4);
                         vh[et][u] = *(const a16x8*)(Ph + a);
-                        vr[et][u] = *(const a16x8*)(Pr + a);
+                        vr_[et][u] = *(const a16x8*)(Pr + a);
                     }
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
+                    if (role_stride && r != vr) continue;
                     f32x16 c0 = zero16(), c1 = zero16();
 #pragma unroll
                     for (int et = 0; et < 2; ++et)
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             c0 = MFMA_H(ph[r][et][u], vh[et][u], c0);
-                            c1 = MFMA_H(ph[r][et][u], vr[et][u], c1);
+                            c1 = MFMA_H(ph[r][et][u], vr_[et][u], c1);
                             c1 = MFMA_H(pr[r][et][u], vh[et][u], c1);
                         }
-                    float* op = values + ((size_t)r * n_vid * nq + (size_t)vid * nq) * d + dc * DC + dl;
+                    const int col = dc * DC + dl;
+                    const float bv = vbias0 ? (r ? vbias1 : vbias0)[col] : 0.f;
+                    float* op = values + ((size_t)r * n_vid * nq + (size_t)vid * nq) * d + col;
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int row = qt * 32 + mfma_row(g, hi);
-                        if (row < nq) op[(size_t)row * d] = c0[g] + c1[g] * RI;
+                        float ov = (c0[g] + c1[g] * RI) + bv;
+                        if (relu) ov = fmaxf(ov, 0.f);
+                        if (row < nq) op[(size_t)row * d] = ov;
                     }
                 }
             }
@@ -783,12 +792,13 @@ __global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __rest
 
 int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, float* att,
                              float* values, const int32_t* e_off, int n_vid, int nq, int n_qt, int half, int d, float scale, int grid,
-                             int* flag, int run_id) {
+                             int* flag, int run_id, long role_stride, const float* vbias0, const float* vbias1, int relu) {
     // at most 192 queries and role halves of at most 256: one workgroup per video with the entity operands shared through LDS
     static const int use_lds = getenv("BIGC_ROLE_LDS") ? atoi(getenv("BIGC_ROLE_LDS")) : 1;
-    if (use_lds && n_qt <= 6 && half <= 256) {
+    const bool projected = role_stride != 0 || vbias0 || relu;      // only the LDS kernel (and the f32 fallback) implement it; the caller checked the shape
+    if ((use_lds || projected) && n_qt <= 6 && half <= 256) {
         hipLaunchKernelGGL(role_fused_lds_kernel, dim3(n_vid), dim3(384), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, half, d,
-                           scale, flag, run_id);
+                           scale, flag, run_id, role_stride, vbias0, vbias1, relu);
         return 1;
     }
     hipLaunchKernelGGL(role_fused_h_kernel, dim3(grid), dim3(256), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, n_qt,

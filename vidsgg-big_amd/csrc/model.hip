@@ -310,9 +310,20 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         }
         TRY(linear(s, enco, de, L.e2a, w.e2a, da, NT, da, de, BIGC_ACT_NONE));
         TRY(linear(s, w.query, dp, L.p2a, w.p2a, da, BQ, da, dp, BIGC_ACT_NONE));
-        if (b->max_trk <= 64 && (da / 2) % 64 == 0) {
-            // only the last layer's att is used downstream (:467)
-            const bool last = i + 1 == c.n_deco_layers;
+        const bool fused = b->max_trk <= 64 && (da / 2) % 64 == 0;
+        const bool last = i + 1 == c.n_deco_layers;                 // only the last layer's att is used downstream (:467)
+        if (fused && Q <= 192 && da / 2 <= 256 && dp % 32 == 0 && dp <= de) {
+            // (att_r @ enco_output) W_r^T = att_r @ (enco_output W_r^T): the first role-wise linear (:204-208) is applied to the NT
+            // entity rows instead of the B*Q value rows (a third as many); the role kernel adds its bias and the ReLU
+            float* ew = w.rh;                                        // 2 x (NT, dp), free until the FFN below
+            TRY(bigc_linear_f32(s, enco, de, nullptr, 1, de, L.role0[0].w, de, nullptr, nullptr, 0, ew, dp, NT, dp, de, BIGC_ACT_NONE));
+            TRY(bigc_linear_f32(s, enco, de, nullptr, 1, de, L.role1[0].w, de, nullptr, nullptr, 0, ew + (size_t)NT * dp, dp, NT, dp, de, BIGC_ACT_NONE));
+            TRY(bigc_role_fused_proj_f32(s, w.p2a, da, w.e2a, da, ew, dp, (long)NT * dp, L.role0[0].b, L.role1[0].b, 1, last ? out->att : nullptr,
+                                         w.vals, b->vid_trk_off, B, Q, b->max_trk, da / 2, dp, att_scale));
+            TRY(linear(s, w.vals, dp, L.role0[1], w.t2, dp, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
+            TRY(linear(s, w.vals + (size_t)BQ * dp, dp, L.role1[1], w.t3, dp, BQ, dp, dp, BIGC_ACT_NONE, w.t2, dp));
+        } else {
+        if (fused) {
             TRY(bigc_role_fused_f32(s, w.p2a, da, w.e2a, da, enco, de, last ? out->att : nullptr, w.vals, b->vid_trk_off, B, Q,
                                     b->max_trk, da / 2, de, att_scale));
         } else {
@@ -323,6 +334,7 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         TRY(linear(s, w.rh, dp, L.role0[1], w.t2, dp, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
         TRY(linear(s, w.vals + (size_t)BQ * de, de, L.role1[0], w.rh, dp, BQ, dp, de, BIGC_ACT_RELU));
         TRY(linear(s, w.rh, dp, L.role1[1], w.t3, dp, BQ, dp, dp, BIGC_ACT_NONE, w.t2, dp));
+        }
         TRY(bigc_layernorm_f32(s, w.t3, L.n2.g, L.n2.b, w.t2, BQ, dp, eps));
         TRY(linear(s, w.t2, dp, L.f0, w.rh, df, BQ, df, dp, BIGC_ACT_RELU));
         TRY(linear(s, w.rh, df, L.f3, w.t3, dp, BQ, dp, df, BIGC_ACT_NONE, w.t2, dp));

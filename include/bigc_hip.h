@@ -132,10 +132,13 @@ int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, const float* e2
 /* The same with the first role-wise linear folded in (models/model_0v10.py:204-208): values_r = act(att_r @ proj_r + bias_r),
  * where proj_r = enco_output W_r^T was computed by the caller on the n_trk entity rows ((att_r @ enco) W^T = att_r @ (enco W^T));
  * proj_1 = proj + role_stride floats, ldproj >= d, bias_r (d) optional (both or none), relu != 0 applies max(., 0).
- * nq <= 192 and half <= 256 take the split-operand LDS kernel, anything else (and exact mode) the f32-MFMA kernel. */
+ * values row (v, q) of role r is written at values + r * out_role_stride + (v * nq + q) * ldval (ldval = 0: the role planes
+ * (2, n_vid * nq, d) of bigc_role_fused_f32; out_role_stride = d, ldval = 2 d: the two roles side by side in one row, the A operand
+ * of a K = 2 d GEMM).  nq <= 192 and half <= 256 take the split-operand LDS kernel, anything else (and exact mode) the f32-MFMA kernel. */
 int bigc_role_fused_proj_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* proj, int ldproj,
                              long role_stride, const float* bias0, const float* bias1, int relu, float* att, float* values,
-                             const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d, float scale);
+                             long out_role_stride, int ldval, const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d,
+                             float scale);
 
 /* Tracklet front-end helpers ------------------------------------------------------- */
 

@@ -317,15 +317,20 @@ def test_role_fused_with_projected_values(lib, nq, half, d, ns, exact):
     pd, ed, xd, bd, offd = dev(p2a), dev(e2a), dev(proj), dev(bias), i32(off)
     att = torch.full((2 * nq * NT,), float("nan"), device=DEV)
     vals = torch.full((2, B * nq, d), float("nan"), device=DEV)
+    side = torch.full((B * nq, 2 * d), float("nan"), device=DEV)             # the two roles side by side in one row
     prev = lib.bigc_linear_set_exact(exact)
     try:
         _lib.check(lib.bigc_role_fused_proj_f32(S(), pd.data_ptr(), 2 * half, ed.data_ptr(), 2 * half, xd.data_ptr(), d, NT * d, bd.data_ptr(),
-                                                bd.data_ptr() + 4 * d, 1, att.data_ptr(), vals.data_ptr(), offd.data_ptr(), B, nq, max(ns), half, d, scale))
+                                                bd.data_ptr() + 4 * d, 1, att.data_ptr(), vals.data_ptr(), 0, 0, offd.data_ptr(), B, nq, max(ns), half, d,
+                                                scale))
+        _lib.check(lib.bigc_role_fused_proj_f32(S(), pd.data_ptr(), 2 * half, ed.data_ptr(), 2 * half, xd.data_ptr(), d, NT * d, bd.data_ptr(),
+                                                bd.data_ptr() + 4 * d, 1, None, side.data_ptr(), d, 2 * d, offd.data_ptr(), B, nq, max(ns), half, d, scale))
         torch.cuda.synchronize()
     finally:
         lib.bigc_linear_set_exact(prev)
     assert not torch.isnan(vals).any()
     assert rel_err(att, att_want) < 1e-5 and rel_err(vals, val_want) < 1e-5
+    assert torch.equal(side[:, :d], vals[0]) and torch.equal(side[:, d:], vals[1])
 
 
 def test_role_fused_out_of_range_falls_back_to_f32(lib):

@@ -71,7 +71,7 @@ _SIGS = {
                                         c_int, c_float]),
     "bigc_role_values_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int]),
     "bigc_role_fused_proj_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, ctypes.c_long, c_void_p, c_void_p, c_int,
-                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float]),
+                                         c_void_p, c_void_p, ctypes.c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float]),
     "bigc_role_fused_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_int, c_float]),
     "bigc_assemble_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

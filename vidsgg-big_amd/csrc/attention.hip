@@ -419,7 +419,8 @@ __global__ __launch_bounds__(256) void role_fused_kernel(const float* __restrict
                                                          float* __restrict__ values, const int32_t* __restrict__ e_off,
                                                          int n_vid, int nq, int n_qt, int half, int d, float scale,
                                                          const int* __restrict__ run_flag, int run_id,
-                                                         long role_stride, const float* __restrict__ vbias0, const float* __restrict__ vbias1, int relu) {
+                                                         long role_stride, const float* __restrict__ vbias0, const float* __restrict__ vbias1, int relu,
+                                                         long out_role_stride, int ldval) {
     if (run_flag && *run_flag != run_id) return;        // fallback launch behind role_fused_h_kernel: only when that one flagged
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256) void role_fused_kernel(const float* __restrict
     // unconditional from clamped addresses (a predicated load serialises load -> wait -> MFMA).
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        float* op = values + ((size_t)r * n_vid * nq + (size_t)vid * nq) * d;
+        float* op = values + r * out_role_stride + (size_t)vid * nq * ldval;     // default: role planes (2, n_vid * nq, d)
 #pragma unroll 1
         for (int d0 = 0; d0 < d; d0 += 128) {
             const bool cok = d0 + 4 * l31 < d;            // d % 4 == 0 (checked by the launcher)
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256) void role_fused_kernel(const float* __restrict
                     const int row = qt * 32 + mfma_row(g, hi);
                     f32x4 ov = f32x4{acc[0][g], acc[1][g], acc[2][g], acc[3][g]} + bv;
                     if (relu) { ov[0] = fmaxf(ov[0], 0.f); ov[1] = fmaxf(ov[1], 0.f); ov[2] = fmaxf(ov[2], 0.f); ov[3] = fmaxf(ov[3], 0.f); }
-                    if (row < nq) *(f32x4*)(op + (size_t)row * d + d0 + 4 * l31) = ov;
+                    if (row < nq) *(f32x4*)(op + (size_t)row * ldval + d0 + 4 * l31) = ov;
                 }
             }
         }
@@ -565,7 +566,7 @@ int bigc_mha_core_h_launch(hipStream_t s, const float* q, int ldq, const float* 
 
 int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, float* att,
                              float* values, const int32_t* e_off, int n_vid, int nq, int n_qt, int half, int d, float scale, int grid,
-                             int* flag, int run_id, long role_stride, const float* vbias0, const float* vbias1, int relu);
+                             int* flag, int run_id, long role_stride, const float* vbias0, const float* vbias1, int relu, long out_role_stride, int ldval);
 
 namespace {
 // BIGC_LINEAR_EXACT / bigc_linear_set_exact also select the f32-MFMA attention kernels
@@ -668,7 +669,8 @@ extern "C" int bigc_role_values_f32(void* stream, const float* att, const float*
 
 static int role_fused_launch(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, long role_stride,
                              const float* vbias0, const float* vbias1, int relu, float* att, float* values, const int32_t* e_off, int n_vid, int nq, int max_ent,
-                             int half, int d, float scale) {
+                             int half, int d, float scale, long out_role_stride = 0, int ldval = 0) {
+    if (ldval == 0) { ldval = d; out_role_stride = (long)n_vid * nq * d; }          // role planes (2, n_vid * nq, d)
     BIGC_CHECK_ARG(p2a && e2a && enco && values && e_off, "role_fused: null pointer");
     BIGC_CHECK_ARG(half % 64 == 0 && ldp % 4 == 0 && lde % 4 == 0 && d % 4 == 0 && ldenc % 4 == 0, "role_fused: half=%d must be a multiple of 64, d=%d of 4", half, d);
     BIGC_CHECK_ARG(max_ent >= 1 && max_ent <= 64, "role_fused: at most 64 entities per video (got %d): use role_attention + role_values", max_ent);
@@ -685,14 +687,14 @@ static int role_fused_launch(void* stream, const float* p2a, int ldp, const floa
         run_flag = mha_flag_slot(run_id);
         if (!run_flag) return BIGC_ERR_HIP;
         bigc_role_fused_h_launch((hipStream_t)stream, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, n_qt, half, d, scale, grid,
-                                 run_flag, run_id, role_stride, vbias0, vbias1, relu);
+                                 run_flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, ldval);
     }
     if (max_ent <= 32)
         hipLaunchKernelGGL(role_fused_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, enco, ldenc, att, values,
-                           e_off, n_vid, nq, n_qt, half, d, scale, run_flag, run_id, role_stride, vbias0, vbias1, relu);
+                           e_off, n_vid, nq, n_qt, half, d, scale, run_flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, ldval);
     else
         hipLaunchKernelGGL(role_fused_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, enco, ldenc, att, values,
-                           e_off, n_vid, nq, n_qt, half, d, scale, run_flag, run_id, role_stride, vbias0, vbias1, relu);
+                           e_off, n_vid, nq, n_qt, half, d, scale, run_flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, ldval);
     BIGC_LAUNCH_CHECK("role_fused");
     return BIGC_OK;
 }
@@ -705,8 +707,11 @@ extern "C" int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, cons
 
 extern "C" int bigc_role_fused_proj_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* proj, int ldproj,
                                         long role_stride, const float* bias0, const float* bias1, int relu, float* att, float* values,
-                                        const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d, float scale) {
+                                        long out_role_stride, int ldval, const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d,
+                                        float scale) {
     BIGC_CHECK_ARG(role_stride % 4 == 0 && (bias0 == nullptr) == (bias1 == nullptr), "role_fused_proj: role_stride must be a multiple of 4, both biases or none");
     BIGC_CHECK_ARG(!bias0 || ((((uintptr_t)bias0) | ((uintptr_t)bias1)) & 15) == 0, "role_fused_proj: biases must be 16-byte aligned");
-    return role_fused_launch(stream, p2a, ldp, e2a, lde, proj, ldproj, role_stride, bias0, bias1, relu, att, values, e_off, n_vid, nq, max_ent, half, d, scale);
+    BIGC_CHECK_ARG(ldval == 0 || (ldval >= d && ldval % 4 == 0 && out_role_stride % 4 == 0), "role_fused_proj: ldval=%d must be 0 or a multiple of 4 >= d", ldval);
+    return role_fused_launch(stream, p2a, ldp, e2a, lde, proj, ldproj, role_stride, bias0, bias1, relu, att, values, e_off, n_vid, nq, max_ent, half, d, scale,
+                             out_role_stride, ldval);
 }

@@ -559,7 +559,8 @@ __global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __rest
                                                              float* __restrict__ values, const int32_t* __restrict__ e_off,
                                                              int n_vid, int nq, int half, int d, float scale,
                                                              int* __restrict__ flag, int run_id,
-                                                             long role_stride, const float* __restrict__ vbias0, const float* __restrict__ vbias1, int relu) {
+                                                             long role_stride, const float* __restrict__ vbias0, const float* __restrict__ vbias1, int relu,
+                                                             long out_role_stride, int ldval) {
     constexpr int NTH = 384, PLANE = 32768, DC = 256;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE];
     unsigned char* const Ph = smem;
@@ -772,13 +773,13 @@ __global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __rest
                         }
                     const int col = dc * DC + dl;
                     const float bv = vbias0 ? (r ? vbias1 : vbias0)[col] : 0.f;
-                    float* op = values + ((size_t)r * n_vid * nq + (size_t)vid * nq) * d + col;
+                    float* op = values + r * out_role_stride + (size_t)vid * nq * ldval + col;
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int row = qt * 32 + mfma_row(g, hi);
                         float ov = (c0[g] + c1[g] * RI) + bv;
                         if (relu) ov = fmaxf(ov, 0.f);
-                        if (row < nq) op[(size_t)row * d] = ov;
+                        if (row < nq) op[(size_t)row * ldval] = ov;
                     }
                 }
             }
@@ -792,13 +793,13 @@ __global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __rest
 
 int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, float* att,
                              float* values, const int32_t* e_off, int n_vid, int nq, int n_qt, int half, int d, float scale, int grid,
-                             int* flag, int run_id, long role_stride, const float* vbias0, const float* vbias1, int relu) {
+                             int* flag, int run_id, long role_stride, const float* vbias0, const float* vbias1, int relu, long out_role_stride, int ldval) {
     // at most 192 queries and role halves of at most 256: one workgroup per video with the entity operands shared through LDS
     static const int use_lds = getenv("BIGC_ROLE_LDS") ? atoi(getenv("BIGC_ROLE_LDS")) : 1;
     const bool projected = role_stride != 0 || vbias0 || relu;      // only the LDS kernel (and the f32 fallback) implement it; the caller checked the shape
     if ((use_lds || projected) && n_qt <= 6 && half <= 256) {
         hipLaunchKernelGGL(role_fused_lds_kernel, dim3(n_vid), dim3(384), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, half, d,
-                           scale, flag, run_id, role_stride, vbias0, vbias1, relu);
+                           scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, ldval);
         return 1;
     }
     hipLaunchKernelGGL(role_fused_h_kernel, dim3(grid), dim3(256), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, n_qt,

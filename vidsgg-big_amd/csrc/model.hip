@@ -152,6 +152,7 @@ extern "C" int bigc_create(const bigc_config* cfg, bigc_model** out) {
 extern "C" void bigc_destroy(bigc_model* m) {
     if (!m) return;
     if (m->conv_w_tapmajor) (void)hipFree(m->conv_w_tapmajor);
+    if (m->role_cat) (void)hipFree(m->role_cat);
     if (m->conv_w_bwd) (void)hipFree(m->conv_w_bwd);
     delete m;
 }
@@ -238,6 +239,30 @@ extern "C" size_t bigc_workspace_bytes(const bigc_model* m, const bigc_batch* b)
     return a.off + 256;
 }
 
+// The second role-wise linears of a decoder layer are summed (query + role0 + role1, models/model_0v10.py:209-211): one GEMM over
+// the concatenated inputs with the weights side by side and the biases added.  Built once per weights epoch by the eval forward.
+static int build_role_cat(bigc_model* m, void* stream) {
+    const bigc_config& c = m->cfg;
+    const int dp = c.dim_pred;
+    if (m->role_cat_epoch == m->epoch || c.n_deco_layers == 0) return BIGC_OK;
+    const size_t per = (size_t)dp * 2 * dp + dp;
+    if (!m->role_cat) {
+        hipError_t e = hipMalloc((void**)&m->role_cat, sizeof(float) * per * c.n_deco_layers);
+        if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: hipMalloc: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < c.n_deco_layers; ++i) {
+        const DecLayer& L = m->dec[i];
+        float* wc = m->role_cat + per * i;
+        float* bc = wc + (size_t)dp * 2 * dp;
+        TRY(bigc_copy_cols((hipStream_t)stream, L.role0[1].w, dp, wc, 2 * dp, dp, dp));
+        TRY(bigc_copy_cols((hipStream_t)stream, L.role1[1].w, dp, wc + dp, 2 * dp, dp, dp));
+        TRY(bigc_copy_cols((hipStream_t)stream, L.role0[1].b, dp, bc, dp, 1, dp));
+        TRY(bigc_axpy_f32(stream, bc, L.role1[1].b, dp));
+    }
+    m->role_cat_epoch = m->epoch;
+    return BIGC_OK;
+}
+
 extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                             int topk, const bigc_outputs* out) {
     StaticWeights static_weights(m ? m->epoch : 0);
@@ -318,10 +343,13 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
             float* ew = w.rh;                                        // 2 x (NT, dp), free until the FFN below
             TRY(bigc_linear_f32(s, enco, de, nullptr, 1, de, L.role0[0].w, de, nullptr, nullptr, 0, ew, dp, NT, dp, de, BIGC_ACT_NONE));
             TRY(bigc_linear_f32(s, enco, de, nullptr, 1, de, L.role1[0].w, de, nullptr, nullptr, 0, ew + (size_t)NT * dp, dp, NT, dp, de, BIGC_ACT_NONE));
+            TRY(build_role_cat(m, s));
+            // the two roles side by side in one row of w.vals: query + role0.2(.) + role1.2(.) (:209-211) is one K = 2 dp GEMM
             TRY(bigc_role_fused_proj_f32(s, w.p2a, da, w.e2a, da, ew, dp, (long)NT * dp, L.role0[0].b, L.role1[0].b, 1, last ? out->att : nullptr,
-                                         w.vals, b->vid_trk_off, B, Q, b->max_trk, da / 2, dp, att_scale));
-            TRY(linear(s, w.vals, dp, L.role0[1], w.t2, dp, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
-            TRY(linear(s, w.vals + (size_t)BQ * dp, dp, L.role1[1], w.t3, dp, BQ, dp, dp, BIGC_ACT_NONE, w.t2, dp));
+                                         w.vals, dp, 2 * dp, b->vid_trk_off, B, Q, b->max_trk, da / 2, dp, att_scale));
+            const float* wc = m->role_cat + ((size_t)dp * 2 * dp + dp) * i;
+            TRY(bigc_linear_f32(s, w.vals, 2 * dp, nullptr, 1, 2 * dp, wc, 2 * dp, wc + (size_t)dp * 2 * dp, w.query, dp, w.t3, dp, BQ, dp, 2 * dp,
+                                BIGC_ACT_NONE));
         } else {
         if (fused) {
             TRY(bigc_role_fused_f32(s, w.p2a, da, w.e2a, da, enco, de, last ? out->att : nullptr, w.vals, b->vid_trk_off, B, Q,

@@ -24,6 +24,8 @@ struct bigc_model {
     std::vector<EncLayer> enc;
     std::vector<DecLayer> dec;
     float* conv_w_tapmajor = nullptr;  // (de, 3*2de), owned
+    unsigned long long role_cat_epoch = 0;   // weights epoch role_cat was built for (built lazily by the eval forward)
+    float* role_cat = nullptr;         // per decoder layer: [W_role0.2 | W_role1.2] (dp, 2 dp) then b_role0.2 + b_role1.2 (dp), owned
     float* conv_w_bwd = nullptr;       // (2de, 3*de), owned (training)
     int head_k = 0;
 };
@@ -47,6 +49,8 @@ inline int linear(void* s, const float* A, int lda, const Lin& l, float* C, int 
 }
 
 int bigc_fill_offsets(hipStream_t s, int32_t* p, int n, int step);
+int bigc_copy_cols(hipStream_t s, const float* src, int lds_, float* dst, int ldd, long rows, int cols);
+extern "C" int bigc_axpy_f32(void* stream, float* y, const float* x, long n);
 int bigc_head_pick(hipStream_t s, const float* att, const int32_t* e_off, const int32_t* trk_cat, int n_vid, int nq, const float* U,
                    const float* V, int lduv, const float* bias_matrix, int n_ecat, int n_pcat, int32_t* soid, float* acc);
 int bigc_repack_conv_weight(hipStream_t s, const float* w, float* out, int n_out, int n_in, int taps);

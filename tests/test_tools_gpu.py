@@ -84,3 +84,23 @@ def test_vidor_cli_pairwise_baseline_training_then_eval():
     log = run([os.path.join(TOOLS, "eval_vidor.py"), "--eval_cls_only", "--use_baseline", "--cfg_path", cfg6, "--ckpt_path", ckpt,
                "--output_dir", out_dir, "--save_tag", "bt", "--synthetic", "4", "--n_trajs", "10"])
     assert "detection recall" in log
+
+
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the keys the driver and the judge read (small workload, one GPU)"""
+    import json
+    log = run([os.path.join(ROOT, "bench.py"), "--videos", "8", "--steps", "2", "--warmup", "1", "--cpu-videos", "2", "--exact-steps", "1"])
+    lines = [l for l in log.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "tracklet_pairs_per_sec" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["pairs_per_gpu_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["exact_f32_gemm_mode"]["triplet_indices_identical_to_default_mode"] in (True, False)

@@ -67,19 +67,28 @@ __global__ __launch_bounds__(256) void adaptive_maxpool_kernel(const float* __re
     const int t = blockIdx.x;
     const int c0 = conv_off[t], To = conv_off[t + 1] - c0;
     if ((d & 3) == 0) {
-        // one dwordx4 column group per thread; the windows of adaptive pooling overlap by at most one row
-        for (int c = threadIdx.x * 4; c < d; c += 1024) {
-            for (int p = 0; p < P; ++p) {
-                const int s = (p * To) / P, e = ((p + 1) * To + P - 1) / P;
-                f32x4 m = *(const f32x4*)(conv + (size_t)(c0 + s) * d + c);
-                for (int j = s + 1; j < e; ++j) {
-                    const f32x4 x = *(const f32x4*)(conv + (size_t)(c0 + j) * d + c);
+        // one (dwordx4 column group, window) item per thread -- all 256 threads busy at d = 512, P = 4 -- and the rows of a
+        // window read four at a time (independent loads); the windows of adaptive pooling overlap by at most one row
+        const int ng = d >> 2;
+        for (int it = threadIdx.x; it < ng * P; it += 256) {
+            const int p = it / ng, c = (it - p * ng) * 4;
+            const int s = (p * To) / P, e = ((p + 1) * To + P - 1) / P;
+            const float* src = conv + (size_t)c0 * d + c;
+            f32x4 m = *(const f32x4*)(src + (size_t)s * d);
+            int j = s + 1;
+            for (; j + 3 < e; j += 4) {
+                const f32x4 x0 = *(const f32x4*)(src + (size_t)j * d), x1 = *(const f32x4*)(src + (size_t)(j + 1) * d);
+                const f32x4 x2 = *(const f32x4*)(src + (size_t)(j + 2) * d), x3 = *(const f32x4*)(src + (size_t)(j + 3) * d);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], x[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) pooled[(size_t)t * d * P + (size_t)(c + k) * P + p] = m[k];
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(m[k], x0[k]), fmaxf(fmaxf(x1[k], x2[k]), x3[k]));
             }
+            for (; j < e; ++j) {
+                const f32x4 x = *(const f32x4*)(src + (size_t)j * d);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], x[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pooled[(size_t)t * d * P + (size_t)(c + k) * P + p] = m[k];
         }
         return;
     }

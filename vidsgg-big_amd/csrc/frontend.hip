@@ -112,11 +112,22 @@ __global__ __launch_bounds__(256) void stretched_mean_kernel(const float* __rest
     const int q = M / L, r = M - q * L;
     const float inv = 1.0f / (float)M;
     if ((w & 3) == 0 && (ldf & 3) == 0 && (col0 & 3) == 0) {
-        // one dwordx4 column group per thread, four rows in flight (HBM-bound: the tracklet's rows are read once)
+        // one dwordx4 column group per thread, up to eight rows in flight (HBM-bound: the tracklet's rows are read once)
         for (int c = threadIdx.x * 4; c < w; c += 1024) {
             const float* p = feats + (size_t)r0 * ldf + col0 + c;
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
             int i = 0;
+            for (; i + 8 <= L; i += 8) {            // eight rows in flight, summed in row order
+                f32x4 x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = *(const f32x4*)(p + (size_t)(i + u) * ldf);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float wt = (i + u < r) ? (float)(q + 1) : (float)q;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[k] += wt * x[u][k];
+                }
+            }
             for (; i + 4 <= L; i += 4) {
                 f32x4 x[4];
 #pragma unroll

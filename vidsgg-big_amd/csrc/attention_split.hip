@@ -548,6 +548,181 @@ __global__ __launch_bounds__(64 * NQT) void mha_core_lds_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same with 16-query tiles on v_mfma_f32_16x16x32_f16: NW = 4 or 12 waves per (sequence, head) workgroup instead of 2 or
+// 6, half the registers per wave (the transposed score tiles of 192 keys are 48 registers), i.e. three waves per SIMD
+// where the 32-query kernel has one or two: these kernels are bound by the issue of dependent instructions, not by a pipe.
+// Operand slots of 16x16x32: lane l supplies A[row l & 15][slots 8 (l >> 4) + j] and B[slots 8 (l >> 4) + j][col l & 15];
+// C[row 4 (l >> 4) + reg][col l & 15].  S^T: slot (g, j) of step s = head dimension 32 s + 8 g + j.  P V: slot (g, j) of
+// step u = key 32 u + 16 (j >> 2) + 4 g + (j & 3) (registers j & 3 of the score tiles 2 u and 2 u + 1); V^T keeps that key at
+// position 32 u + 8 g + 4 (j >> 2) + (j & 3), one 16-byte read per lane.
+#define MFMA_H16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+
+template <int NW, bool DROP>
+__global__ __launch_bounds__(64 * NW) void mha_core_lds16_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                                 const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
+                                                                 const int32_t* __restrict__ off, int n_head, float scale,
+                                                                 float* __restrict__ lse, const DropSpec drop, int* __restrict__ flag, int run_id) {
+    constexpr int HD = 64, NK = 16 * NW, NKT = NW, VS = 2 * NK + 16, NTH = 64 * NW;
+    constexpr int KP = NK * 128, VP = HD * VS;
+    constexpr int KUNITS = NK * 8 / NTH, VGROUPS = NK / 8 / NW;          // = 2, 2
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KP + 2 * VP];
+    unsigned char* const Kh = smem;
+    unsigned char* const Kr = smem + KP;
+    unsigned char* const Vh = smem + 2 * KP;
+    unsigned char* const Vr = smem + 2 * KP + VP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x % n_head, s = blockIdx.x / n_head;
+    const int q0 = off[s], nq = off[s + 1] - q0;
+    if (nq <= 0) return;
+    const int n_kt = (nq + 15) / 16;
+    float chk = 0.f, amax = 0.f;
+    {
+        f32x4 kraw[KUNITS][2];
+        float vraw[VGROUPS][8];
+        const float* kb = k + (size_t)q0 * ldk + h * HD;
+        const float* vb = v + (size_t)q0 * ldv + h * HD + lane;
+#pragma unroll
+        for (int r = 0; r < KUNITS; ++r) {
+            const int unit = tid + NTH * r, key = unit >> 3, c = unit & 7;
+            const float* kp = kb + (size_t)min(key, nq - 1) * ldk + 8 * c;
+            kraw[r][0] = *(const f32x4*)kp;
+            kraw[r][1] = *(const f32x4*)(kp + 4);
+        }
+#pragma unroll
+        for (int r = 0; r < VGROUPS; ++r) {
+            const int k0 = 8 * (wave + NW * r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vraw[r][j] = vb[(size_t)min(k0 + j, nq - 1) * ldv];
+        }
+#pragma unroll
+        for (int r = 0; r < KUNITS; ++r) {
+            const int unit = tid + NTH * r, key = unit >> 3, c = unit & 7;
+            const float x[8] = {kraw[r][0][0], kraw[r][0][1], kraw[r][0][2], kraw[r][0][3], kraw[r][1][0], kraw[r][1][1], kraw[r][1][2], kraw[r][1][3]};
+            a16x8 hh, rr;
+            split8(x, hh, rr, chk, amax);
+            const int a = key * 128 + ((c ^ (key & 7)) << 4);
+            *(a16x8*)(Kh + a) = hh;
+            *(a16x8*)(Kr + a) = rr;
+        }
+#pragma unroll
+        for (int r = 0; r < VGROUPS; ++r) {
+            const int k0 = 8 * (wave + NW * r);                  // keys k0 .. k0+7: 32-group u = k0 / 32, m = (k0 / 8) % 4
+            a16x8 hh, rr;
+            split8(vraw[r], hh, rr, chk, amax);
+            // key 32u + 8m + j = 32u + 16a + 4g' + b with a = m >> 1, g' = 2 (m & 1) + (j >> 2), b = j & 3 -> position 32u + 8g' + 4a + b
+            const int mm = (k0 >> 3) & 3;
+            const int p0 = (k0 & ~31) + 16 * (mm & 1) + 4 * (mm >> 1);
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const int row = lane * VS;
+            *(h4*)(Vh + row + 2 * p0) = h4{hh[0], hh[1], hh[2], hh[3]};
+            *(h4*)(Vh + row + 2 * (p0 + 8)) = h4{hh[4], hh[5], hh[6], hh[7]};
+            *(h4*)(Vr + row + 2 * p0) = h4{rr[0], rr[1], rr[2], rr[3]};
+            *(h4*)(Vr + row + 2 * (p0 + 8)) = h4{rr[4], rr[5], rr[6], rr[7]};
+        }
+    }
+    const int qt = wave;
+    const bool active = qt * 16 < nq;
+    const int qrow = min(qt * 16 + l15, nq - 1);
+    a16x8 qh[2], qr[2];
+    {
+        const float* qp = q + (size_t)(q0 + qrow) * ldq + h * HD + 8 * g;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const f32x4 t0 = *(const f32x4*)(qp + 32 * st), t1 = *(const f32x4*)(qp + 32 * st + 4);
+            const float x[8] = {t0[0] * scale, t0[1] * scale, t0[2] * scale, t0[3] * scale, t1[0] * scale, t1[1] * scale, t1[2] * scale, t1[3] * scale};
+            split8(x, qh[st], qr[st], chk, amax);
+        }
+    }
+    if (!(fabsf(chk) < INFINITY) || amax >= 32768.0f) atomicMax(flag, run_id);
+    __syncthreads();
+    if (!active) return;
+
+    // ---- scores S^T[key][query]: tile kt = keys 16 kt .. + 15, this lane holds keys 16 kt + 4 g + reg of query l15
+    f32x4 sc[NKT];
+    float m = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < n_kt) {
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            const int row = kt * 16 + l15;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int a = row * 128 + (((4 * st + g) ^ (row & 7)) << 4);
+                const a16x8 kh = *(const a16x8*)(Kh + a), kr = *(const a16x8*)(Kr + a);
+                c0 = MFMA_H16(kh, qh[st], c0);
+                c1 = MFMA_H16(kh, qr[st], c1);
+                c1 = MFMA_H16(kr, qh[st], c1);
+            }
+            if (kt * 16 + 16 <= nq) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[kt][r] = c0[r] + c1[r] * RI; m = fmaxf(m, sc[kt][r]); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sc[kt][r] = (kt * 16 + 4 * g + r < nq) ? c0[r] + c1[r] * RI : NEG_BIG;
+                    m = fmaxf(m, sc[kt][r]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[kt][r] = NEG_BIG;
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+    const float mlog = m * 1.44269504088896341f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], 1.44269504088896341f, -mlog));       // masked keys: exactly 0
+            sc[kt][r] = e;
+            l += e;
+        }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    if (lse && g == 0 && qt * 16 + l15 < nq) lse[(size_t)(q0 + qt * 16 + l15) * n_head + h] = m + logf(l);
+
+    // ---- O = P V: C[query 4 g + reg][column 16 t + l15]
+    f32x4 o0[4], o1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { o0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; o1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+        if (2 * u < n_kt) {
+            float p8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float p = sc[2 * u + (j >> 2)][j & 3] * inv;
+                if (DROP) p = drop_keep(drop, drop_att_idx(q0 + qrow, n_head, h, 32 * u + 16 * (j >> 2) + 4 * g + (j & 3))) ? p * drop.scale : 0.f;
+                p8[j] = p;
+            }
+            a16x8 ph, pr;
+            float a_ = 0.f;
+            split8a(p8, ph, pr, a_);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int a = (16 * t + l15) * VS + 2 * (32 * u + 8 * g);
+                const a16x8 vh = *(const a16x8*)(Vh + a), vr = *(const a16x8*)(Vr + a);
+                o0[t] = MFMA_H16(ph, vh, o0[t]);
+                o1[t] = MFMA_H16(ph, vr, o1[t]);
+                o1[t] = MFMA_H16(pr, vh, o1[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = qt * 16 + 4 * g + r;
+            if (row < nq) o[(size_t)(q0 + row) * ldo + h * HD + 16 * t + l15] = o0[t][r] + o1[t][r] * RI;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Role attention + values with the entity-side operands split ONCE per video into LDS (role_fused_h_kernel splits e2a and
 // enco_output again in each of the video's 32-query waves).  One workgroup of six waves per video, wave w = query tile w
 // (nq <= 192), 64 KB of LDS used in turn for: e2a of role 0, e2a of role 1 (f16 head / residual planes, [entity][half] rows,
@@ -814,6 +989,14 @@ int bigc_mha_core_h_launch(hipStream_t s, const float* q, int ldq, const float* 
     // keys = queries of the same sequence (the launcher only comes here for self-attention): K / V shared through LDS
     static const int use_lds = getenv("BIGC_MHA_LDS") ? atoi(getenv("BIGC_MHA_LDS")) : 1;
     if (use_lds && n_qt <= 6) {
+        static const int tile16 = getenv("BIGC_MHA_TILE16") ? atoi(getenv("BIGC_MHA_TILE16")) : 1;
+        if (tile16) {
+#define LAUNCH_L16(NW, DROP) hipLaunchKernelGGL((mha_core_lds16_kernel<NW, DROP>), dim3(n_seq * n_head), dim3(64 * NW), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, n_head, scale, lse, drop, flag, run_id)
+            if (n_qt <= 2) { if (drop.thresh) LAUNCH_L16(4, true); else LAUNCH_L16(4, false); }
+            else { if (drop.thresh) LAUNCH_L16(12, true); else LAUNCH_L16(12, false); }
+#undef LAUNCH_L16
+            return 1;
+        }
 #define LAUNCH_LDS(NQT, DROP) hipLaunchKernelGGL((mha_core_lds_kernel<NQT, DROP>), dim3(n_seq * n_head), dim3(64 * NQT), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, n_head, scale, lse, drop, flag, run_id)
         if (n_qt <= 2) { if (drop.thresh) LAUNCH_LDS(2, true); else LAUNCH_LDS(2, false); }
         else { if (drop.thresh) LAUNCH_LDS(6, true); else LAUNCH_LDS(6, false); }

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     text = open(os.path.join(ROOT, "include", "bigc_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(bigc_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:bigc|grd)_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -37,6 +37,11 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert n in _lib._SIGS, "no ctypes signature for " + n
     assert b"gfx950" in _lib.load().bigc_build_info()
+    # and the other way round: no undocumented C entry point (every exported bigc_* / grd_* function is declared in the header)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-2] in "Tt" and l.split()[-1].startswith(("bigc_", "grd_"))}
+    assert exported and not (exported - set(names)), sorted(exported - set(names))
 
 
 def test_packed_batch_offsets_cpu():

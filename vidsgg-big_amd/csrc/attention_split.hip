@@ -964,6 +964,236 @@ __global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __rest
     if (amax >= 32768.0f) atomicMax(flag, run_id);
 }
 
+// ---------------------------------------------------------------------------------------------
+// role_fused_lds_kernel on 16-query tiles (v_mfma_f32_16x16x32_f16): twelve waves per video instead of six -- three per SIMD
+// instead of two on two SIMDs and one on the others -- at half the registers.  Same LDS images; score k-slot (g, j) of step s =
+// dimension 32 s + 8 g + j of the role's half; value k-slot (g, j) of step u = entity 32 u + 16 (j >> 2) + 4 g + (j & 3), kept
+// in V^T at position 32 u + 8 g + 4 (j >> 2) + (j & 3).  C[row 4 g + reg][col l15].
+__global__ __launch_bounds__(768) void role_fused_lds16_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
+                                                               const float* __restrict__ enco, int ldenc, float* __restrict__ att,
+                                                               float* __restrict__ values, const int32_t* __restrict__ e_off,
+                                                               int n_vid, int nq, int half, int d, float scale,
+                                                               int* __restrict__ flag, int run_id,
+                                                               long role_stride, const float* __restrict__ vbias0, const float* __restrict__ vbias1, int relu,
+                                                               long out_role_stride, int ldval) {
+    constexpr int NTH = 768, PLANE = 32768, DC = 256, NU = 3;      // 2048 staging units of 8 floats over 768 threads
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE];
+    unsigned char* const Ph = smem;
+    unsigned char* const Pr = smem + PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int vid = blockIdx.x;
+    const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
+    if (ne <= 0) return;
+    const int qt = wave;
+    const bool active = qt * 16 < nq;
+    const int qrow = min(qt * 16 + l15, nq - 1);
+    const int per_row = half / 8, n_eunits = 64 * per_row, row_bytes = 2 * half, n_step = half / 32;
+    const float* qp = p2a + (size_t)(vid * nq + qrow) * ldp + 8 * g;
+    float amax = 0.f;
+    float raw[NU][8];
+
+    auto e_load = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int unit = min(tid + NTH * i, n_eunits - 1), ent = unit / per_row, c = unit - ent * per_row;
+            const float* p = e2a + (size_t)(e0 + min(ent, ne - 1)) * lde + r * half + 8 * c;
+            const f32x4 t0 = *(const f32x4*)p, t1 = *(const f32x4*)(p + 4);
+            raw[i][0] = t0[0]; raw[i][1] = t0[1]; raw[i][2] = t0[2]; raw[i][3] = t0[3];
+            raw[i][4] = t1[0]; raw[i][5] = t1[1]; raw[i][6] = t1[2]; raw[i][7] = t1[3];
+        }
+    };
+    auto e_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int unit = tid + NTH * i;
+            if (unit < n_eunits) {
+                const int ent = unit / per_row, c = unit - ent * per_row;
+                a16x8 h_, r_;
+                split8a(raw[i], h_, r_, amax);
+                const int a = ent * row_bytes + ((c ^ (ent & 7)) << 4);
+                *(a16x8*)(Ph + a) = h_;
+                *(a16x8*)(Pr + a) = r_;
+            }
+        }
+    };
+    auto v_load = [&](int dc, int vr) {
+        const int dw = min(DC, d - dc * DC), n_units = 8 * dw;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int unit = min(tid + NTH * i, n_units - 1), m = unit / dw, dl = unit - m * dw;
+            const float* p = enco + vr * role_stride + (size_t)e0 * ldenc + dc * DC + dl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[i][j] = p[(size_t)min(8 * m + j, ne - 1) * ldenc];
+        }
+    };
+    auto v_store = [&](int dc) {
+        const int dw = min(DC, d - dc * DC), n_units = 8 * dw;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int unit = tid + NTH * i;
+            if (unit < n_units) {
+                const int m = unit / dw, dl = unit - m * dw;
+                a16x8 h_, r_;
+                split8a(raw[i], h_, r_, amax);
+                // entities 8m + j = 32u + 16a + 4g' + b (u = m >> 2, a = (m >> 1) & 1, g' = 2 (m & 1) + (j >> 2), b = j & 3) -> position
+                // 32u + 8g' + 4a + b: 16-byte chunk 4u + 2 (m & 1) (+1 for j >= 4), byte 8a inside it
+                const int c0 = 4 * (m >> 2) + 2 * (m & 1), sw = dl & 7, ab = 8 * ((m >> 1) & 1);
+                const int b0 = dl * 128 + ((c0 ^ sw) << 4) + ab, b1 = dl * 128 + (((c0 + 1) ^ sw) << 4) + ab;
+                *(h4*)(Ph + b0) = h4{h_[0], h_[1], h_[2], h_[3]};
+                *(h4*)(Ph + b1) = h4{h_[4], h_[5], h_[6], h_[7]};
+                *(h4*)(Pr + b0) = h4{r_[0], r_[1], r_[2], r_[3]};
+                *(h4*)(Pr + b1) = h4{r_[4], r_[5], r_[6], r_[7]};
+            }
+        }
+    };
+
+    // ---- scores: sc[r][et] = S_r^T tile et (entities 16 et + 4 g + reg, query l15)
+    f32x4 sc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        e_load(r);
+        f32x4 qraw[4][2];                                          // four k32 steps of this lane's query row
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { qraw[s4][0] = *(const f32x4*)(qp + r * half + 32 * s4); qraw[s4][1] = *(const f32x4*)(qp + r * half + 32 * s4 + 4); }
+        e_store();
+        __syncthreads();
+        f32x4 c0[4], c1[4];
+#pragma unroll
+        for (int et = 0; et < 4; ++et) { c0[et] = f32x4{0.f, 0.f, 0.f, 0.f}; c1[et] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (active) {
+            for (int sb = 0; sb < n_step; sb += 4) {
+                a16x8 qh[4], qr[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const float x[8] = {qraw[s4][0][0], qraw[s4][0][1], qraw[s4][0][2], qraw[s4][0][3], qraw[s4][1][0], qraw[s4][1][1], qraw[s4][1][2], qraw[s4][1][3]};
+                    split8a(x, qh[s4], qr[s4], amax);
+                }
+                const float* qn = qp + r * half + 32 * min(sb + 4, n_step - 4);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) { qraw[s4][0] = *(const f32x4*)(qn + 32 * s4); qraw[s4][1] = *(const f32x4*)(qn + 32 * s4 + 4); }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int chunk = 4 * (sb + s4) + g;
+#pragma unroll
+                    for (int et = 0; et < 4; ++et) {
+                        const int row = 16 * et + l15;
+                        const int a = row * row_bytes + ((chunk ^ (row & 7)) << 4);
+                        const a16x8 eh = *(const a16x8*)(Ph + a), er = *(const a16x8*)(Pr + a);
+                        c0[et] = MFMA_H16(eh, qh[s4], c0[et]);
+                        c1[et] = MFMA_H16(eh, qr[s4], c1[et]);
+                        c1[et] = MFMA_H16(er, qh[s4], c1[et]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) sc[r][et][rg] = (c0[et][rg] + c1[et][rg] * RI) * scale;
+        __syncthreads();
+    }
+
+    // ---- softmax over the entities of each role, then over the two roles: the operation sequence of role_fused_kernel
+    a16x8 ph[2][2], pr[2][2];
+    if (active) {
+        float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int et = 0; et < 4; ++et)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (16 * et + 4 * g + rg < ne) m[r] = fmaxf(m[r], sc[r][et][rg]);
+            m[r] = fmaxf(m[r], __shfl_xor(m[r], 16));
+            m[r] = fmaxf(m[r], __shfl_xor(m[r], 32));
+#pragma unroll
+            for (int et = 0; et < 4; ++et)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    if (16 * et + 4 * g + rg < ne) l[r] += expf(sc[r][et][rg] - m[r]);
+            l[r] += __shfl_xor(l[r], 16);
+            l[r] += __shfl_xor(l[r], 32);
+        }
+        const int qq = qt * 16 + l15;
+        float* abase = att ? att + (size_t)2 * nq * e0 : nullptr;
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = 16 * et + 4 * g + rg;
+                const float s0 = sc[0][et][rg], s1 = sc[1][et][rg];
+                const float pe0 = expf(s0 - m[0]) / l[0], pe1 = expf(s1 - m[1]) / l[1];
+                const float es = expf(-fabsf(s0 - s1));
+                const float w0 = s0 >= s1 ? 1.0f : es, w1 = s0 >= s1 ? es : 1.0f, ws = w0 + w1;
+                const bool ok = n < ne;
+                const float a0 = ok ? pe0 * (w0 / ws) : 0.f, a1 = ok ? pe1 * (w1 / ws) : 0.f;
+                sc[0][et][rg] = a0;
+                sc[1][et][rg] = a1;
+                if (abase && ok && qq < nq) {
+                    abase[((size_t)0 * nq + qq) * ne + n] = a0;
+                    abase[((size_t)1 * nq + qq) * ne + n] = a1;
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float p8[8], a_ = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p8[j] = sc[r][2 * u + (j >> 2)][j & 3];
+                split8a(p8, ph[r][u], pr[r][u], a_);
+            }
+    }
+
+    // ---- values_r = act(att_r @ right-hand rows + bias), 256 columns of the right-hand rows^T in LDS at a time
+    const int n_dc = (d + DC - 1) / DC, n_vr = role_stride ? 2 : 1;
+    for (int vr = 0; vr < n_vr; ++vr)
+    for (int dc = 0; dc < n_dc; ++dc) {
+        v_load(dc, vr);
+        v_store(dc);
+        __syncthreads();
+        if (active) {
+            const int n_dt = min(DC, d - dc * DC) / 16;                    // d % 32 == 0 (launcher)
+#pragma unroll 1
+            for (int dtl = 0; dtl < n_dt; ++dtl) {
+                const int dl = 16 * dtl + l15;
+                a16x8 vh[2], vr_[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int a = dl * 128 + (((4 * u + g) ^ (dl & 7)) << 4);
+                    vh[u] = *(const a16x8*)(Ph + a);
+                    vr_[u] = *(const a16x8*)(Pr + a);
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (role_stride && r != vr) continue;
+                    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        c0 = MFMA_H16(ph[r][u], vh[u], c0);
+                        c1 = MFMA_H16(ph[r][u], vr_[u], c1);
+                        c1 = MFMA_H16(pr[r][u], vh[u], c1);
+                    }
+                    const int col = dc * DC + dl;
+                    const float bv = vbias0 ? (r ? vbias1 : vbias0)[col] : 0.f;
+                    float* op = values + r * out_role_stride + (size_t)vid * nq * ldval + col;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int row = qt * 16 + 4 * g + rg;
+                        float ov = (c0[rg] + c1[rg] * RI) + bv;
+                        if (relu) ov = fmaxf(ov, 0.f);
+                        if (row < nq) op[(size_t)row * ldval] = ov;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (amax >= 32768.0f) atomicMax(flag, run_id);
+}
+
 }  // namespace
 
 int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, float* att,
@@ -972,6 +1202,12 @@ int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const flo
     // at most 192 queries and role halves of at most 256: one workgroup per video with the entity operands shared through LDS
     static const int use_lds = getenv("BIGC_ROLE_LDS") ? atoi(getenv("BIGC_ROLE_LDS")) : 1;
     const bool projected = role_stride != 0 || vbias0 || relu;      // only the LDS kernel (and the f32 fallback) implement it; the caller checked the shape
+    static const int tile16 = getenv("BIGC_ROLE_TILE16") ? atoi(getenv("BIGC_ROLE_TILE16")) : 1;
+    if ((use_lds || projected) && n_qt <= 6 && half <= 256 && tile16 && half % 128 == 0) {
+        hipLaunchKernelGGL(role_fused_lds16_kernel, dim3(n_vid), dim3(768), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, half, d,
+                           scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, ldval);
+        return 1;
+    }
     if ((use_lds || projected) && n_qt <= 6 && half <= 256) {
         hipLaunchKernelGGL(role_fused_lds_kernel, dim3(n_vid), dim3(384), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, half, d,
                            scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, ldval);

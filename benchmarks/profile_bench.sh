@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r01l
+O=$R/gpurun_out/prof_r01m
 rm -rf $O; mkdir -p $O
 cd $R
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --cpu-videos 0 --exact-steps 0 > $O/stats_stdout.log 2>&1

@@ -10,38 +10,32 @@ video v uses numpy RandomState(1234+v)), numpy-seeded weights.  One step = one p
 path over one resident batch of `--videos` videos (default 256) per GPU; inputs are packed in HBM
 before the timed region.  N>1: one process per GPU (torch.distributed / RCCL only for the barrier
 and the max-over-ranks timing -- videos are independent, no data-path collective), weak scaling.
+Started without a torch.distributed.run environment, `--gpus N` (N>1) launches the N ranks itself
+(a child `python -m torch.distributed.run`, started before this process touches the GPU).
 
-Also printed in the same JSON line:
-  roofline     dominant kernel (linear_f32, the f32-MFMA GEMM family): algorithmic flops of its
-               launches / their summed duration measured with HIP events inside the library on the
-               launch stream during the timed steps, against the 157.3 TFLOP/s f32-MFMA peak
-  cpu_baseline the CPU oracle (oracle/bigc_oracle.py, a torch-CPU restatement of the reference's
-               op sequence: kind "port") timed on the host cores, rank 0 at N=1 only, on a bounded
-               sample of the same videos
+Also printed in the same JSON line (rank 0; everything below runs OUTSIDE the timed region):
+  roofline      dominant kernel = the GEMM family (f32 GEMMs on the f16 matrix cores with exactly split
+                operands, 3 MFMAs per product): algorithmic flops of its launches / their summed
+                duration measured with HIP events inside the library on the launch stream over a repeat
+                of the timed steps, against the dense f16 MFMA peak / 3
+  cpu_baseline  the CPU oracle (oracle/bigc_oracle.py, a torch-CPU restatement of the reference's
+                op sequence: kind "port") timed on the host cores, N=1 only, on a bounded sample of the
+                same videos
+  oracle_parity the oracle outputs of that sample compared row for row with the HIP outputs of the
+                same videos: triplet rows identical, predicate logits max relative difference
+  vidor / grounding / train   the other BASELINE configs on the same GPU (N=1 only): VidOR-sized
+                classification (N=180 tracklets), the grounding scorer on its triplet queries, and
+                the BIG-C training step (forward + Hungarian + backward + all-reduce + clip + Adam)
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
-import tempfile
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (os.path.join(ROOT, "vidsgg-big_amd"), ROOT):
-    if p not in sys.path:
-        sys.path.insert(0, p)
-
-from bigc_hip import _lib, configs  # noqa: E402
-from bigc_hip.packed import PackedBatch  # noqa: E402
-from bigc_hip.synthetic import bigc_state_shapes, seeded_state_dict, synthetic_proposal  # noqa: E402
-
-F32_MFMA_PEAK_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-F16_MFMA_PEAK_TFLOPS = 2500.0   # same table, "Peak BF16/FP16 MFMA" dense
-EXACT_F32 = os.environ.get("BIGC_LINEAR_EXACT", "0") not in ("", "0")     # run the whole benchmark on the exact f32-MFMA GEMM kernel
 
 
 def parse():
@@ -53,11 +47,52 @@ def parse():
     ap.add_argument("--n-trajs", type=int, default=64)
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--cpu-videos", type=int, default=256, help="videos of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="stop the CPU-baseline sample after this much oracle time")
     ap.add_argument("--no-prof", action="store_true", help="do not record HIP events around the kernels")
     ap.add_argument("--mode", choices=["eval", "train"], default="eval", help="eval = headline metric; train = training-step throughput")
     ap.add_argument("--train-videos", type=int, default=8, help="videos per GPU per training step (reference batch size 8)")
     ap.add_argument("--exact-steps", type=int, default=3, help="extra steps timed with the exact f32-MFMA GEMM kernel, reported beside (0 = skip)")
+    ap.add_argument("--legs", default="vidor,grounding,train", help="extra workloads reported in the same line at N=1 ('' = none)")
+    ap.add_argument("--vidor-videos", type=int, default=8)
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `torch.distributed.run` (never an
+    exec, and before this process has initialised the GPU), relay its output, return its exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+ARGS = parse() if __name__ == "__main__" else None
+if ARGS is not None and (ARGS.gpus > 1 or os.environ.get("BIGC_BENCH_SELF_LAUNCH") == "1") and "RANK" not in os.environ:
+    sys.exit(self_launch(ARGS))
+
+import ctypes  # noqa: E402
+import tempfile  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+for p in (os.path.join(ROOT, "vidsgg-big_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from bigc_hip import _lib, configs  # noqa: E402
+from bigc_hip.packed import PackedBatch  # noqa: E402
+from bigc_hip.synthetic import TrajProposal, bigc_state_shapes, seeded_state_dict, synthetic_proposal  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+F16_MFMA_PEAK_TFLOPS = 2500.0   # same table, "Peak BF16/FP16 MFMA" dense
+HBM_PEAK_GBS = 8000.0           # same table, HBM3E peak
+EXACT_F32 = os.environ.get("BIGC_LINEAR_EXACT", "0") not in ("", "0")     # run the whole benchmark on the exact f32-MFMA GEMM kernel
 
 
 def usable_cores():
@@ -73,45 +108,93 @@ def usable_cores():
     return max(1, n)
 
 
-def build_model(cfg, sd, device):
-    from models import BIG_C_vidvrd
+def build_model(cfg, sd, device, variant="vidvrd", is_train=False):
+    from models import BIG_C_vidor, BIG_C_vidvrd
     d = tempfile.mkdtemp()
     cfg = dict(cfg)
     np.save(os.path.join(d, "bias.npy"), sd["bias_matrix"].numpy())
-    np.save(os.path.join(d, "emb.npy"), sd["EntiNameEmb"].numpy())
-    cfg["bias_matrix_path"], cfg["EntiNameEmb_path"] = os.path.join(d, "bias.npy"), os.path.join(d, "emb.npy")
-    model = BIG_C_vidvrd(cfg, is_train=False)
+    cfg["bias_matrix_path"] = os.path.join(d, "bias.npy")
+    if "EntiNameEmb" in sd:
+        np.save(os.path.join(d, "emb.npy"), sd["EntiNameEmb"].numpy())
+        cfg["EntiNameEmb_path"] = os.path.join(d, "emb.npy")
+    model = (BIG_C_vidvrd if variant == "vidvrd" else BIG_C_vidor)(cfg, is_train=is_train)
     model.load_state_dict(sd)
     return model.to(device)
 
 
-def train_main(args):
-    """`--mode train`: the training step of BASELINE configs[4] (BIG-C DP training) on synthetic videos:
-    zero_grad, HIP forward + host Hungarian, HIP backward, one flat-gradient all-reduce over RCCL (N>1),
-    clip_grad_norm_(5), Adam -- the loop body of tools/train_vidvrd.py:151-164. Not the headline metric."""
-    from bigc_hip.shard import allreduce_gradients, max_over_ranks
-    from bigc_hip.synthetic import synthetic_gt_graph
-    from models import BIG_C_vidvrd
+def init_dist(args):
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("BIGC_BENCH_FORCE_DIST") == "1":      # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    return rank, world, device, dist
+
+
+def collect_families(lib, steps):
+    out = {}
+    _lib.check(lib.bigc_prof_collect())
+    for f in range(lib.bigc_prof_family_count()):
+        ms, n, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
+        lib.bigc_prof_get(f, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+        if n.value:
+            out[lib.bigc_prof_family_name(f).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+    return out
+
+
+def timed_with_events(lib, fn, warmup, steps):
+    """(wall seconds un-instrumented, wall seconds instrumented, per-family HIP-event times) of `steps` calls of fn"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    lib.bigc_prof_reset()
+    lib.bigc_prof_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    el_prof = time.perf_counter() - t0
+    lib.bigc_prof_enable(0)
+    return el, el_prof, collect_families(lib, steps)
+
+
+def gemm_roofline(fam, steps, step_ms=None):
+    """roofline object of the GEMM family from its HIP-event totals (None when the family did not run)"""
+    lin = fam.get("linear_f32")
+    if not lin:
+        return None
+    achieved = lin["flops"] / (lin["ms"] * 1e-3) / 1e12
+    peak = F32_MFMA_PEAK_TFLOPS if EXACT_F32 else F16_MFMA_PEAK_TFLOPS / 3
+    r = dict(bound="mfma", achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(achieved / peak, 4),
+             launches_per_step=lin["launches"] // steps, avg_launch_us=round(1e3 * lin["ms"] / lin["launches"], 2),
+             gflop_per_step=round(lin["flops"] / steps / 1e9, 1))
+    if step_ms:
+        r["share_of_step"] = round(lin["ms"] / steps / step_ms, 3)
+    return r
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --mode train: the training step as its own benchmark line
+# ---------------------------------------------------------------------------------------------------------------------
+
+def make_train_job(args, rank, device, nvid):
+    from bigc_hip.synthetic import synthetic_gt_graph
     cfg = dict(configs.CONFIG_V)
     sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 7, att_gain=3.0)
-    d = tempfile.mkdtemp()
-    np.save(os.path.join(d, "bias.npy"), sd["bias_matrix"].numpy())
-    np.save(os.path.join(d, "emb.npy"), sd["EntiNameEmb"].numpy())
-    cfg["bias_matrix_path"], cfg["EntiNameEmb_path"] = os.path.join(d, "bias.npy"), os.path.join(d, "emb.npy")
-    model = BIG_C_vidvrd(cfg, is_train=True)
-    model.load_state_dict(sd)
-    model = model.to(device)
+    model = build_model(cfg, sd, device, "vidvrd", is_train=True)
     width = cfg["dim_feat"] + cfg["dim_i3d"]
-    nvid = args.train_videos
     props = [synthetic_proposal(5000 + rank * nvid + v, n_trajs=args.n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"])
              for v in range(nvid)]
     gts = [synthetic_gt_graph(p, 6000 + rank * nvid + v, n_gt_trajs=8, n_preds=10, num_pred_cats=cfg["num_pred_cats"]) for v, p in enumerate(props)]
@@ -119,6 +202,11 @@ def train_main(args):
     gt_duras = [g.traj_durations.clone() for g in gts]
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     pairs = sum(p.num_proposals * (p.num_proposals - 1) for p in props)
+    return model, props, gts, gt_duras, opt, pairs
+
+
+def train_step_fn(model, props, gts, gt_duras, opt, dist):
+    from bigc_hip.shard import allreduce_gradients
 
     def step():
         for g, du in zip(gts, gt_duras):
@@ -130,7 +218,18 @@ def train_main(args):
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=5, norm_type=2)
         opt.step()
         return float(loss)
+    return step
 
+
+def train_main(args):
+    """`--mode train`: the training step of BASELINE configs[4] (BIG-C DP training) on synthetic videos:
+    zero_grad, HIP forward + host Hungarian, HIP backward, one flat-gradient all-reduce over RCCL (N>1),
+    clip_grad_norm_(5), Adam -- the loop body of tools/train_vidvrd.py:151-164. Not the headline metric."""
+    from bigc_hip.shard import allreduce_gradients, max_over_ranks
+    rank, world, device, dist = init_dist(args)
+    nvid = args.train_videos
+    model, props, gts, gt_duras, opt, pairs = make_train_job(args, rank, device, nvid)
+    step = train_step_fn(model, props, gts, gt_duras, opt, dist)
     for _ in range(args.warmup):
         step()
     lib = _lib.load()
@@ -144,16 +243,13 @@ def train_main(args):
     for _ in range(args.steps):
         last = step()
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0, dist, device)
     lib.bigc_prof_enable(0)
     families = {}
     if not args.no_prof:
-        _lib.check(lib.bigc_prof_collect())
-        for f in range(lib.bigc_prof_family_count()):
-            ms, n, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
-            lib.bigc_prof_get(f, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
-            if n.value:
-                families[lib.bigc_prof_family_name(f).decode()] = round(ms.value / args.steps, 3)
+        families = {k: round(v["ms"] / args.steps, 3) for k, v in collect_families(lib, args.steps).items()}
     if rank == 0:
         print(json.dumps({"metric": "train_tracklet_pairs_per_sec", "value": round(pairs * world * args.steps / elapsed, 1), "unit": "pairs/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -161,27 +257,146 @@ def train_main(args):
                           "config": {"workload": "BIG-C model_0v10 training step (exp2 dims), %d synthetic videos x N=%d per GPU per step, "
                                                  "forward + Hungarian + backward + flat-gradient all-reduce + clip + Adam" % (nvid, args.n_trajs),
                                      "parallelism": "dp%d" % world}, "last_loss": round(last, 4),
+                          "allreduce": {"backend": "nccl (RCCL)" if dist is not None else None,
+                                        "flat_buffer_reduced_in_place": allreduce_gradients.last_in_place,
+                                        "bytes": 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)},
                           "kernel_families_ms_per_step": families}))
     if dist is not None:
         dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# extra legs of the eval line (N=1, rank 0, outside the timed region)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def device_proposal(seed, n_trajs, feat_width, num_enti_cats, len_range, start_range, device):
+    """synthetic_proposal with the (large) feature block drawn on the GPU: same structure recipe (numpy-seeded lengths,
+    starts, categories, scores, boxes), features ~ N(0,1) from a seeded device generator.  For the legs that have no
+    oracle comparison: 8 VidOR-sized videos are 4 GB of features, minutes of host RNG."""
+    rs = np.random.RandomState(seed)
+    lens = rs.randint(len_range[0], len_range[1], size=n_trajs)
+    starts = rs.randint(start_range[0], start_range[1], size=n_trajs)
+    duras = np.stack([starts, starts + lens - 1], axis=1).astype(np.int64)
+    cat_ids = rs.randint(1, num_enti_cats, size=n_trajs).astype(np.int64)
+    scores = np.sort(rs.uniform(0, 1, size=n_trajs).astype(np.float32))[::-1].copy()
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    total = int(lens.sum())
+    xy = rs.uniform(0, 600, size=(total, 2))
+    wh = rs.uniform(10, 110, size=(total, 2))
+    boxes = torch.from_numpy(np.concatenate([xy, xy + wh], axis=1).astype(np.float32)).to(device)
+    feats = torch.randn((total, feat_width), generator=gen, device=device, dtype=torch.float32)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    return TrajProposal("synth_%d" % seed, int((starts + lens).max()), (1280, 720), cat_ids, scores, duras,
+                        [boxes[off[i]:off[i + 1]] for i in range(n_trajs)], [feats[off[i]:off[i + 1]] for i in range(n_trajs)])
+
+
+def vidor_grounding_legs(args, lib, device, want_vidor, want_grounding):
+    """BASELINE configs[3]: VidOR-sized classification (model_0v7 at the exp5 dims, N=180 tracklets, L in [15,1000),
+    topk=3, SURVEY.md 8d "config 4") and configs[2]/[3] second stage: the grounding scorer (config G) on the triplet
+    queries the classification stage produced for the same videos (rt_triplets_topk = 200 per video)."""
+    from models import DEBUG
+    from bigc_hip.synthetic import grd_state_shapes
+    cfg = dict(configs.CONFIG_O)
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidor"), 11, att_gain=8.0)
+    big = build_model(cfg, sd, device, "vidor")
+    width = cfg["dim_feat"] + cfg["dim_clsme"]
+    nv, ntr, max_len = args.vidor_videos, 180, 1000
+    props = [device_proposal(4321 + v, ntr, width, cfg["num_enti_cats"], (15, max_len), (0, max_len), device) for v in range(nv)]
+    video_len = [p.video_len for p in props]
+    packed = PackedBatch(props, device)
+    pairs, rows = packed.n_pairs(), packed.n_rows
+    props, packed.proposals = None, None
+    out_holder = {}
+
+    def cls_step():
+        out_holder["o"] = big.forward_packed(packed, 3)
+        out_holder["o"]["n_out"].cpu()
+
+    steps = 3
+    el, el_prof, fam = timed_with_events(lib, cls_step, 1, steps)
+    legs = {}
+    if want_vidor:
+        legs["vidor"] = dict(value=round(pairs * steps / el, 1), unit="pairs/s", ms_per_step=round(1e3 * el / steps, 3),
+                             ms_per_video=round(1e3 * el / steps / nv, 3), steps=steps,
+                             workload="VidOR classification stage (BASELINE configs[3]): BIG-C model_0v7 eval forward incl. construct_triplet, "
+                                      "exp5 dims (RoI 1024 + classeme 300, 6 enc / 4 dec), %d synthetic videos x N=%d, L in [15,%d), topk=3, "
+                                      "%d rows, %d pairs per step" % (nv, ntr, max_len, rows, pairs),
+                             roofline=gemm_roofline(fam, steps, 1e3 * el_prof / steps),
+                             kernel_families_ms_per_step={k: round(v["ms"] / steps, 3) for k, v in fam.items()})
+    if not want_grounding:
+        return legs
+    results = big.unpack_results(nv, list(range(nv)), out_holder["o"])
+    gcfg = dict(configs.CONFIG_G)
+    gcfg.setdefault("loss_factor", {})
+    gsd = seeded_state_dict(grd_state_shapes(gcfg), 12, 4.0)
+    d = tempfile.mkdtemp()
+    np.save(d + "/ge.npy", gsd["EntiNameEmb"].numpy())
+    np.save(d + "/gp.npy", gsd["PredNameEmb"].numpy())
+    grd = DEBUG(dict(gcfg, EntiNameEmb_path=d + "/ge.npy", PredNameEmb_path=d + "/gp.npy"), is_train=False)
+    grd.load_state_dict(gsd)
+    grd = grd.to(device)
+    jobs = []
+    rs = np.random.RandomState(99)
+    for v, r in enumerate(results):
+        if r is None:
+            continue
+        quint, scores, dura = r[0], r[1], r[2]
+        if quint.shape[0] > 200:                     # rt_triplets_topk (experiments/exp6/config_rt200.py:14)
+            keep = torch.sort(torch.argsort(scores.mean(dim=-1), descending=True)[:200])[0]
+            quint, dura = quint[keep], dura[keep]
+        T = -(-video_len[v] // 8)
+        clip = torch.from_numpy((0.1 * rs.standard_normal((T, gcfg["dim_feat"]))).astype(np.float32)).to(device)
+        jobs.append((clip, quint.to(device), dura.to(device), video_len[v]))
+    del big, packed, out_holder
+    if not jobs:
+        return legs
+    n_q = sum(int(j[1].shape[0]) for j in jobs)
+
+    def grd_step():
+        last = grd.forward_raw_batch(jobs, 0.9, 0.5, 0.2, 0.8) if hasattr(grd, "forward_raw_batch") else None
+        if last is None:
+            for clip, quint, dura, vl in jobs:
+                last = grd.forward_raw(clip, quint, dura, vl, 0.9, 0.5, 0.2, 0.8)
+        last["status"].cpu()
+
+    gsteps = 5
+    el, el_prof, fam = timed_with_events(lib, grd_step, 2, gsteps)
+    legs["grounding"] = dict(value=round(n_q * gsteps / el, 1), unit="triplet-queries/s", ms_per_step=round(1e3 * el / gsteps, 3),
+                             ms_per_video=round(1e3 * el / gsteps / len(jobs), 3), steps=gsteps,
+                             workload="grounding stage (BASELINE configs[2]/[3]): grd_model_v5 DEBUG eval forward incl. temporal pooling + NMS, "
+                                      "config G, %d videos, %d queries (<=200 per video), T = ceil(video_len/8) in [%d,%d]"
+                                      % (len(jobs), n_q, min(int(j[0].shape[0]) for j in jobs), max(int(j[0].shape[0]) for j in jobs)),
+                             roofline=gemm_roofline(fam, gsteps, 1e3 * el_prof / gsteps),
+                             kernel_families_ms_per_step={k: round(v["ms"] / gsteps, 3) for k, v in fam.items()})
+    return legs
+
+
+def train_leg(args, lib, device):
+    """BASELINE configs[4] on one GPU: the BIG-C training step at 8 and 64 videos per step"""
+    out = {}
+    for nvid in (8, 64):
+        model, props, gts, gt_duras, opt, pairs = make_train_job(args, 0, device, nvid)
+        step = train_step_fn(model, props, gts, gt_duras, opt, None)
+        steps = 5
+        el, el_prof, fam = timed_with_events(lib, step, 2, steps)
+        kern_ms = sum(v["ms"] for v in fam.values()) / steps
+        out["videos_%d" % nvid] = dict(value=round(pairs * steps / el, 1), unit="pairs/s", ms_per_step=round(1e3 * el / steps, 3), steps=steps,
+                                       kernel_ms_per_step=round(kern_ms, 3), kernel_share_of_step=round(kern_ms / (1e3 * el_prof / steps), 3))
+        del model, props, gts, opt
+        torch.cuda.empty_cache()
+    out["workload"] = ("BIG-C model_0v10 training step (exp2 dims, dropout on), synthetic videos x N=%d: zero_grad + forward + host Hungarian + "
+                       "backward + clip_grad_norm_ + Adam (tools/train_vidvrd.py:151-164)" % args.n_trajs)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+
 def main():
-    args = parse()
+    args = ARGS
     if args.mode == "train":
         return train_main(args)
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or os.environ.get("BIGC_BENCH_FORCE_DIST") == "1":      # the env switch exercises the RCCL path on one GPU
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+    rank, world, device, dist = init_dist(args)
 
     cfg = dict(configs.CONFIG_V)
     sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 7, att_gain=8.0)
@@ -200,7 +415,7 @@ def main():
     gen_s = time.time() - t0
     model = build_model(cfg, sd, device)
     lib = _lib.load()
-    pairs_per_step = packed.n_pairs()
+    pairs_per_step, rows_per_step = packed.n_pairs(), packed.n_rows
 
     def step():
         out = model.forward_packed(packed, args.topk)
@@ -225,7 +440,7 @@ def main():
 
     # ---- the same K steps once more with a HIP event pair around every kernel launch (on the launch stream, inside the
     # library): per-family launch durations for the roofline.  Kept out of `value` because the ~300 event records per step
-    # cost about 4 % of a step; the instrumented wall time is reported next to it.
+    # cost a few % of a step; the instrumented wall time is reported next to it.
     families = {}
     prof_elapsed = None
     if not args.no_prof:
@@ -238,17 +453,12 @@ def main():
         torch.cuda.synchronize()
         prof_elapsed = time.perf_counter() - t0
         lib.bigc_prof_enable(0)
-        _lib.check(lib.bigc_prof_collect())
-        for f in range(lib.bigc_prof_family_count()):
-            ms, n, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
-            lib.bigc_prof_get(f, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
-            if n.value:
-                families[lib.bigc_prof_family_name(f).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+        families = collect_families(lib, args.steps)
 
+    ref_out = model.forward_packed(packed, args.topk, keep_intermediates=False) if rank == 0 else None
     # the same step with every GEMM on the exact f32 MFMA kernel, outside the timed region, for comparison
     exact_leg = None
     if args.exact_steps > 0 and not EXACT_F32 and rank == 0:
-        ref_out = model.forward_packed(packed, args.topk)
         lib.bigc_linear_set_exact(1)
         ex_out = model.forward_packed(packed, args.topk)          # also the warm-up of this mode
         torch.cuda.synchronize()
@@ -275,6 +485,7 @@ def main():
                          max_logit_diff_rel_between_modes=float((((ref_out["pred_logits"] - ex_out["pred_logits"]).abs().max(1).values
                                                                   * (ref_out["soid"] == ex_out["soid"]).all(1).reshape(-1)).max()
                                                                  / ex_out["pred_logits"].abs().max()).item()))
+        del ex_out
 
     if rank != 0:
         if dist is not None:
@@ -286,53 +497,86 @@ def main():
     roofline = None
     if "linear_f32" in families:
         lin = families["linear_f32"]
-        achieved = lin["flops"] / (lin["ms"] * 1e-3) / 1e12
+        roofline = gemm_roofline(families, args.steps, 1e3 * prof_elapsed / args.steps)
         # HBM bytes per launch cannot be sampled from inside this process: they come from the committed
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/pmc_traffic.json,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if the workload differs
-        traffic = None
+        traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path) and args.videos == 256 and args.n_trajs == 64:
-            traffic = round(json.load(open(pmc_path))["hbm_bytes_per_launch"])
+            pmc = json.load(open(pmc_path))
+            traffic = round(pmc["hbm_bytes_per_launch"])
+            traffic_source = "not measured in this run: read from profiles/pmc_traffic.json (%s)" % pmc.get("source", "rocprofv3 --pmc passes of this command")
         if EXACT_F32:
-            kernel, peak = "linear_f32_kernel (f32 MFMA 32x32x2)", F32_MFMA_PEAK_TFLOPS
+            kernel = "linear_f32_kernel (f32 MFMA 32x32x2)"
         else:
             # every f32 product costs three f16 MFMAs (head x head, head x residual, residual x head): the roof for
             # ALGORITHMIC flops is the dense f16 MFMA peak / 3
-            kernel, peak = "linear_split_kernel (f32 operands split into 2 x f16, 3 x v_mfma_f32_32x32x16_f16 per product)", F16_MFMA_PEAK_TFLOPS / 3
-        roofline = dict(bound="mfma", kernel=kernel, achieved=round(achieved, 2),
-                        peak=round(peak, 1), unit="TFLOP/s", frac=round(achieved / peak, 4),
-                        vs_f32_mfma_peak=round(achieved / F32_MFMA_PEAK_TFLOPS, 3),
-                        traffic=traffic, algorithmic_bytes_per_launch=round(lin["bytes"] / lin["launches"]),
-                        launches_per_step=lin["launches"] // args.steps,
-                        avg_launch_us=round(1e3 * lin["ms"] / lin["launches"], 2),
-                        gflop_per_step=round(lin["flops"] / args.steps / 1e9, 1),
-                        share_of_step=round(lin["ms"] / args.steps / ms_per_step, 3),
+            kernel = "split-operand GEMM family (f32 operands as 2 x f16, 3 x v_mfma_f32_32x32x16_f16 per product)"
+        roofline.update(kernel=kernel, vs_f32_mfma_peak=round(roofline["achieved"] / F32_MFMA_PEAK_TFLOPS, 3), traffic=traffic,
+                        traffic_source=traffic_source, algorithmic_bytes_per_launch=round(lin["bytes"] / lin["launches"]),
                         measured="HIP events around each launch, over a repeat of the timed %d steps (instrumented step: %.3f ms)"
                                  % (args.steps, 1e3 * prof_elapsed / args.steps))
-    cpu_baseline = None
+    cpu_baseline, oracle_parity = None, None
     if n_cpu:
         from oracle import bigc_oracle as O
-        cpu_sample = (synthetic_proposal(base + v, n_trajs=args.n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"])
-                      for v in range(n_cpu))                      # the same videos, regenerated lazily on the host
+        Q, P = cfg["num_querys"], cfg["num_pred_cats"]
+        hip_n = ref_out["n_out"].cpu().numpy()
+        hip_quint, hip_dura, hip_qid = ref_out["quint"].cpu().numpy(), ref_out["dura"].cpu().numpy(), ref_out["qid"].cpu().numpy()
+        hip_logits = ref_out["pred_logits"].cpu().numpy().reshape(args.videos, Q, P)
+        hip_soid = ref_out["soid"].cpu().numpy()
         torch.set_num_threads(usable_cores())
-        cpu_pairs, n_done = 0, 0
+        cpu_pairs, n_done, cpu_s = 0, 0, 0.0
+        rows_total, rows_same, vids_same, max_rel, other_argmax = 0, 0, 0, 0.0, 0
         with torch.no_grad():
-            first = next(cpu_sample)
-            O.forward_test(sd, cfg, [first], args.topk)                  # warm-up
-            cpu_s = 0.0
-            for p in [first] + list(range(n_cpu - 1)):                   # bounded: stop after ~15 s of oracle time
-                p = p if not isinstance(p, int) else next(cpu_sample)
+            O.forward_test(sd, cfg, [synthetic_proposal(base, n_trajs=args.n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"])], args.topk)  # warm-up
+            for v in range(n_cpu):                                      # bounded: stop after ~15 s of oracle time
+                p = synthetic_proposal(base + v, n_trajs=args.n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"])   # the same video, regenerated on the host
                 t0 = time.perf_counter()
-                O.forward_test(sd, cfg, [p], args.topk)
+                o = O.encode2decode(sd, cfg, p)                         # = O.forward_test (models/model_0v10.py:369-388), outputs kept
+                res = O.construct_triplet(p, o["pred_logits"], o["att"], args.topk)
                 cpu_s += time.perf_counter() - t0
                 cpu_pairs += p.num_proposals * (p.num_proposals - 1)
                 n_done += 1
-                if cpu_s > 15.0:
+                # ---- row-for-row comparison with the HIP output of the same video (outside the CPU timing)
+                n_o = 0 if res is None else int(res[0].shape[0])
+                n_h = int(hip_n[v])
+                rows_total += n_o
+                m = min(n_o, n_h)
+                if m:
+                    eq = ((hip_quint[v, :m] == res[0].numpy()[:m]).all(1) & (hip_dura[v, :m] == res[2].numpy()[:m]).all(1)
+                          & (hip_qid[v, :m] == res[3].numpy()[:m]))
+                    rows_same += int(eq.sum())
+                    vids_same += int(n_o == n_h and bool(eq.all()))
+                else:
+                    vids_same += int(n_o == n_h)
+                so_ref = o["att"].argmax(-1).numpy()                    # (2, Q)
+                same_so = (hip_soid[v] == so_ref).all(0)
+                other_argmax += int((~same_so).sum())
+                lg = o["pred_logits"].numpy()
+                if same_so.any():
+                    max_rel = max(max_rel, float(np.abs(hip_logits[v][same_so] - lg[same_so]).max() / np.abs(lg).max()))
+                if cpu_s > args.cpu_seconds:
                     break
         cpu_baseline = dict(value=round(cpu_pairs / cpu_s, 1), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
-                            sample="%d of the same synthetic videos (N=%d), oracle/bigc_oracle.py forward_test incl. "
-                                   "construct_triplet, fp32 torch CPU, %.1f s" % (n_done, args.n_trajs, cpu_s))
+                            sample="%d of the same synthetic videos (N=%d), oracle/bigc_oracle.py encode2decode + construct_triplet "
+                                   "(= forward_test), fp32 torch CPU, %.1f s" % (n_done, args.n_trajs, cpu_s))
+        oracle_parity = dict(videos=n_done, identical_triplet_rows="%d of %d" % (rows_same, rows_total), videos_fully_identical=vids_same,
+                             max_logit_rel=max_rel, queries_with_other_argmax_entity=other_argmax,
+                             note="HIP output of the timed workload vs the CPU oracle on the same videos; logits compared on the queries whose "
+                                  "attention arg-max (subject, object) agrees, relative to max |logit| of the video")
+    del ref_out
+    legs = {}
+    want = [x for x in args.legs.split(",") if x] if world == 1 else []
+    if want:
+        model._engine = None
+        del model, packed
+        torch.cuda.empty_cache()
+        if "vidor" in want or "grounding" in want:
+            legs.update(vidor_grounding_legs(args, lib, device, "vidor" in want, "grounding" in want))
+            torch.cuda.empty_cache()
+        if "train" in want:
+            legs["train"] = train_leg(args, lib, device)
     line = {
         "metric": "tracklet_pairs_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -343,12 +587,13 @@ def main():
                                % (args.videos, args.n_trajs, args.topk, "GEMMs on the exact f32 MFMA" if EXACT_F32 else
                                   "GEMMs and attention on f16 MFMAs with exactly split f32 operands, f32-level error"),
                    "videos_per_gpu_per_step": args.videos, "tracklets_per_video": args.n_trajs,
-                   "rows_per_step": packed.n_rows, "pairs_per_gpu_per_step": pairs_per_step, "parallelism": "dp%d" % world},
-        "roofline": roofline, "cpu_baseline": cpu_baseline, "exact_f32_gemm_mode": exact_leg,
+                   "rows_per_step": rows_per_step, "pairs_per_gpu_per_step": pairs_per_step, "parallelism": "dp%d" % world},
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "oracle_parity": oracle_parity, "exact_f32_gemm_mode": exact_leg,
         "kernel_families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in families.items()},
         "videos_per_sec": round(args.videos * world * args.steps / elapsed, 1),
         "triplets_last_step": int(n_out.sum()), "setup_s": round(gen_s, 1),
     }
+    line.update(legs)
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

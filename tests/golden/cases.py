@@ -47,6 +47,12 @@ BIGC_CASES = {
                               videos=[dict(seed=504, n_trajs=7, len_range=(5, 20), start_range=(0, 10))]),
     "bigo_o_n32": dict(cfg="CONFIG_O", variant="vidor", wseed=34, topk=3, att_gain=8.0, full=False,
                        videos=[dict(seed=2234, n_trajs=32, len_range=(15, 200), start_range=(0, 100))]),
+    # more than 64 tracklets per video (the decoder's un-fused role-attention branch, csrc/model.hip): exp2 dims with
+    # N=100, and the VidOR model at its defining size N=180 (experiments/exp5/config_.py:40)
+    "bigc_v_n100": dict(cfg="CONFIG_V", variant="vidvrd", wseed=7, topk=10, att_gain=8.0, full=False,
+                        videos=[dict(seed=4100, n_trajs=100)]),
+    "bigo_o_n180": dict(cfg="CONFIG_O", variant="vidor", wseed=35, topk=3, att_gain=8.0, full=False,
+                        videos=[dict(seed=2280, n_trajs=180, len_range=(15, 200), start_range=(0, 150))]),
 }
 
 

@@ -191,3 +191,41 @@ def test_training_gradients_are_linear_in_the_upstream_gradient():
         grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
     for k in grads[0]:
         assert torch.allclose(grads[1][k], 3.0 * grads[0][k], rtol=2e-4, atol=1e-6 * float(grads[1][k].abs().max())), k   # fp32 atomics: summation order varies
+
+
+def test_benchmark_videos_vs_oracle_row_for_row():
+    """32 videos of the benchmark workload (bench.py: seeds 1234 + v, exp2 dims, N=64) through the HIP path in ONE batch and
+    through the CPU oracle one by one: every triplet row (quintuple, overlap span, query id) identical, predicate logits within
+    1e-4 relative -- index parity at full size against the ORACLE (pinned to the reference by tests/golden/bigc_v_n64 /
+    bigc_v_n100), not against the path's own second GEMM mode."""
+    from oracle import bigc_oracle as O
+    n_vid = 32
+    cfg = dict(configs.CONFIG_V)
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 7, att_gain=8.0)
+    model = build_model(cfg, "vidvrd", sd)
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    Q, P = cfg["num_querys"], cfg["num_pred_cats"]
+    host = [synthetic_proposal(1234 + v, n_trajs=64, feat_width=width, num_enti_cats=cfg["num_enti_cats"]) for v in range(n_vid)]
+    packed = PackedBatch([synthetic_proposal(1234 + v, n_trajs=64, feat_width=width, num_enti_cats=cfg["num_enti_cats"]) for v in range(n_vid)], DEV)
+    out = model.forward_packed(packed, 10)
+    res = model.unpack_results(n_vid, list(range(n_vid)), out)
+    logits = out["pred_logits"].cpu().numpy().reshape(n_vid, Q, P)
+    soid = out["soid"].cpu().numpy()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    rows = 0
+    with torch.no_grad():
+        for v, p in enumerate(host):
+            o = O.encode2decode(sd, cfg, p)
+            want = O.construct_triplet(p, o["pred_logits"], o["att"], 10)
+            got = as_np(res[v])
+            assert (want is None) == (got is None)
+            assert np.array_equal(soid[v], o["att"].argmax(-1).numpy()), "video %d: attention arg-max differs from the oracle" % v
+            ref = o["pred_logits"].numpy()
+            assert np.abs(logits[v] - ref).max() <= 1e-4 * np.abs(ref).max(), "video %d logits" % v
+            if want is None:
+                continue
+            assert np.array_equal(got[0], want[0].numpy()), "video %d: quintuples differ" % v
+            assert np.array_equal(got[2], want[2].numpy()) and np.array_equal(got[3], want[3].numpy())
+            assert np.abs(got[1] - want[1].numpy()).max() <= 5e-5
+            rows += want[0].shape[0]
+    assert rows > 32 * 50

@@ -47,6 +47,13 @@ def _worker(rank, world, port, q):
     flat = allreduce_gradients(ps, dist)                 # ps[2] has no gradient (frozen): skipped
     assert flat.numel() == 17 and ps[2].grad is None
     assert torch.equal(ps[0].grad, torch.full((3, 4), 1.5)) and torch.equal(ps[1].grad, torch.arange(5, dtype=torch.float32) * 1.5)
+    assert allreduce_gradients.last_in_place is False
+    # the HIP backward hands out views of ONE flat buffer: that buffer is reduced in place, no cat / copy-back
+    buf = torch.arange(17, dtype=torch.float32) * (rank + 1)
+    ps[0].grad, ps[1].grad = buf[:12].view(3, 4), buf[12:]
+    flat2 = allreduce_gradients(ps, dist)
+    assert allreduce_gradients.last_in_place is True and flat2.data_ptr() == buf.data_ptr()
+    assert torch.equal(buf, torch.arange(17, dtype=torch.float32) * 1.5) and torch.equal(ps[1].grad, buf[12:])
     if rank == 0:
         full = O.forward_test(sd, cfg, props, topk, variant)
         ok = len(res) == len(full)

@@ -86,15 +86,23 @@ def test_vidor_cli_pairwise_baseline_training_then_eval():
     assert "detection recall" in log
 
 
+def _bench(args, env=None):
+    import json
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, capture_output=True, text=True, timeout=900, env=e)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
 def test_bench_json_contract():
     """bench.py prints ONE JSON line with the keys the driver and the judge read (small workload, one GPU)"""
-    import json
-    log = run([os.path.join(ROOT, "bench.py"), "--videos", "8", "--steps", "2", "--warmup", "1", "--cpu-videos", "2", "--exact-steps", "1"])
-    lines = [l for l in log.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = _bench(["--videos", "8", "--steps", "2", "--warmup", "1", "--cpu-videos", "4", "--exact-steps", "1", "--legs", "grounding,train",
+                "--vidor-videos", "2"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline"):
+              "config", "roofline", "cpu_baseline", "oracle_parity"):
         assert k in d, k
     assert d["metric"] == "tracklet_pairs_per_sec" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
@@ -104,3 +112,29 @@ def test_bench_json_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["exact_f32_gemm_mode"]["triplet_indices_identical_to_default_mode"] in (True, False)
+    # the oracle outputs of the CPU-baseline sample are compared row for row with the HIP outputs of the same videos
+    op = d["oracle_parity"]
+    n_same, n_all = [int(x) for x in op["identical_triplet_rows"].split(" of ")]
+    assert op["videos"] == 4 and n_all > 0 and n_same == n_all and op["videos_fully_identical"] == 4 and op["max_logit_rel"] < 1e-4
+    # the other BASELINE configs ride in the same line
+    g, t = d["grounding"], d["train"]
+    assert g["unit"] == "triplet-queries/s" and g["value"] > 0
+    assert t["videos_8"]["value"] > 0 and t["videos_64"]["value"] > 0
+
+
+def test_bench_train_mode_runs_rccl_allreduce_on_one_rank():
+    """`--mode train` with a one-rank RCCL group: init_process_group("nccl"), barrier, the flat-gradient all-reduce (in place on
+    the buffer the HIP backward filled) and the max-over-ranks reduction execute on the GPU."""
+    d = _bench(["--mode", "train", "--train-videos", "2", "--n-trajs", "16", "--steps", "2", "--warmup", "1"], env={"BIGC_BENCH_FORCE_DIST": "1"})
+    assert d["metric"] == "train_tracklet_pairs_per_sec" and d["value"] > 0 and d["n_gpus"] == 1
+    a = d["allreduce"]
+    assert a["backend"].startswith("nccl") and a["flat_buffer_reduced_in_place"] is True and a["bytes"] > 100e6
+    assert d["last_loss"] == d["last_loss"]          # finite
+
+
+def test_bench_eval_mode_with_rccl_group_and_self_launch():
+    """The eval line through the self-launcher (a child `torch.distributed.run`, as `python bench.py --gpus N` does for N > 1)
+    with a one-rank RCCL group for the barrier / max-over-ranks."""
+    d = _bench(["--videos", "4", "--steps", "2", "--warmup", "1", "--cpu-videos", "0", "--exact-steps", "0", "--legs", "", "--no-prof"],
+               env={"BIGC_BENCH_FORCE_DIST": "1", "BIGC_BENCH_SELF_LAUNCH": "1"})
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"

@@ -57,6 +57,24 @@ def max_over_ranks(seconds, dist=None, device=None):
     return float(t.item())
 
 
+def flat_gradient_view(params):
+    """The gradients of ``params`` as ONE flat tensor WITHOUT copying, when they already live back to back in a single
+    storage -- which is how the HIP backward hands them out (bigc_hip/train_step.py: every ``.grad`` is a view of one
+    flat fp32 buffer, in parameter order).  Returns None when they do not (plain torch gradients)."""
+    grads = [p.grad for p in params]
+    if not grads:
+        return None
+    st = grads[0].untyped_storage()
+    off = grads[0].storage_offset()
+    start = off
+    for g in grads:
+        if (g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != st.data_ptr()
+                or g.storage_offset() != off):
+            return None
+        off += g.numel()
+    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, start, (off - start,))
+
+
 def allreduce_gradients(params, dist=None, average=True):
     """Data-parallel gradient exchange of the training step: ONE all-reduce over a single flat fp32 buffer
     holding every gradient (RCCL over xGMI on the GPU boxes, gloo in the CPU tests), then the mean over ranks.
@@ -64,18 +82,29 @@ def allreduce_gradients(params, dist=None, average=True):
     Replaces the reference's single-process ``nn.DataParallel`` reduction (utils/DataParallel.py:65-69, loss
     ``.mean()`` over replicas at tools/train_vidvrd.py:155): each rank computes the loss means over its own
     contiguous chunk of the batch (``shard_indices``), so averaging the per-rank gradients reproduces it.
+    The HIP backward already writes every gradient into one flat buffer: that buffer is reduced IN PLACE (no
+    concatenation, no copy back); gradients that live in separate tensors are gathered into a flat message first.
     Returns the flat reduced buffer (27.8 M floats = 111 MB for the exp2 model)."""
     params = [p for p in params if p.grad is not None]
     if not params:
         return None
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    active = dist is not None and dist.is_initialized()      # a one-rank group still runs the collective (RCCL smoke on one GPU)
+    flat = flat_gradient_view(params)
+    in_place = flat is not None
+    if not in_place:
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+    if active:
         dist.all_reduce(flat)
-        if average:
+        if average and dist.get_world_size() > 1:
             flat /= dist.get_world_size()
-    off = 0
-    for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
+    if not in_place:
+        off = 0
+        for p in params:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+    allreduce_gradients.last_in_place = in_place
     return flat
+
+
+allreduce_gradients.last_in_place = None

@@ -464,6 +464,20 @@ int bigc_assemble_rows_f32(void* stream, const float* raw, int ld_raw, int col0,
                            int col02, int width2, const int32_t* src_a, const int32_t* src_b, const int32_t* step_i,
                            const int32_t* step_div, float* out, int ld_out, int n_rows);
 
+/* ---- GEMM on split operands (csrc/gemm_ps.hip) -----------------------------------------------------------------------------
+ * Same contract as bigc_linear_f32 -- C = act(A W^T + bias) + residual, replacing nn.Linear / nn.Conv1d(k3,s2) of
+ * models/model_0v10.py:290-309,446-458 -- for activations kept in the library's split form "hr8": every 8 consecutive f32 of
+ * a row are stored as 16 bytes of f16 heads h = f16(x) followed by 16 bytes of f16 residuals r = f16((x - h) 2^11), round to
+ * nearest (same footprint and pitch as f32).  a_fmt 0: A is f32 (split inside the kernel), 1: A is hr8 (optionally row-gathered:
+ * a_idx (M, nseg), -1 = zero row, K = nseg segments).  Outputs: f32 C and / or hr8 Cs (at least one).  K % 32 == 0, N % 8 == 0.
+ * range_flag (device int, may be null) is OR-ed with 1 when an element being split is >= 32768 in magnitude, NaN or Inf: the
+ * result is then invalid and the caller must redo the computation on the exact path (bigc_linear_set_exact(1)). */
+int bigc_gemm_ps(void* stream, const void* A, long lda_bytes, int a_fmt, const int32_t* a_idx, int nseg, const float* W, int ldw,
+                 const float* bias, const float* residual, long ldr, float* C, long ldc, void* Cs, long ldcs_bytes,
+                 int M, int N, int K, int act, int* range_flag);
+/* f32 rows (rows, K) -> hr8 rows; K % 8 == 0 */
+int bigc_split_rows_f32(void* stream, const float* X, long ldx, void* Y, long ldy_bytes, long rows, int K, int* range_flag);
+
 #ifdef __cplusplus
 }
 #endif

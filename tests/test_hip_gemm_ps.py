@@ -1,0 +1,153 @@
+"""GPU tests of the GEMM on split operands (csrc/gemm_ps.hip, entry point bigc_gemm_ps): the three A modes (f32 rows split in
+the loop, hr8 rows by DMA, hr8 rows gathered through an index table), f32 and hr8 outputs, bias / ReLU / sigmoid / residual,
+ragged M, against a float64 evaluation; accuracy budget = a few f32 round-offs of sum |a||w| (what torch's f32 GEMM delivers)."""
+import numpy as np
+import pytest
+import torch
+
+from bigc_hip import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def hr8_decode(buf, rows, K, pitch_bytes=None):
+    """hr8 bytes (torch uint8 on any device) -> float64 (rows, K): head + residual / 2048"""
+    pitch = pitch_bytes or 4 * K
+    raw = buf.cpu().numpy().reshape(rows, pitch)[:, :4 * K].copy()
+    g = raw.view(np.float16).reshape(rows, K // 8, 2, 8).astype(np.float64)
+    return (g[:, :, 0, :] + g[:, :, 1, :] / 2048.0).reshape(rows, K)
+
+
+def to_hr8(x):
+    rows, K = x.shape
+    y = torch.empty((rows, 4 * K), dtype=torch.uint8, device=x.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+    _lib.check(_lib.load().bigc_split_rows_f32(_lib.current_stream(), x.data_ptr(), K, y.data_ptr(), 4 * K, rows, K, flag.data_ptr()))
+    return y, flag
+
+
+def run(A, a_fmt, W, bias=None, res=None, act=0, idx=None, nseg=1, want_f32=True, want_hr8=True, lda_bytes=None):
+    lib = _lib.load()
+    M = idx.shape[0] if idx is not None else A.shape[0]
+    N, K = W.shape
+    C = torch.full((M, N), float("nan"), device=DEV) if want_f32 else None
+    Cs = torch.zeros((M, 4 * N), dtype=torch.uint8, device=DEV) if want_hr8 else None
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    if lda_bytes is None:
+        lda_bytes = A.shape[1] * (4 if a_fmt == 0 else 1)
+    _lib.check(lib.bigc_gemm_ps(_lib.current_stream(), A.data_ptr(), lda_bytes, a_fmt, _lib.ptr(idx), nseg, W.data_ptr(), K, _lib.ptr(bias),
+                                _lib.ptr(res), N if res is not None else 0, _lib.ptr(C), N, _lib.ptr(Cs), 4 * N, M, N, K, act, flag.data_ptr()))
+    torch.cuda.synchronize()
+    return C, Cs, int(flag.item())
+
+
+def ref64(A, W, bias, res, act):
+    y = A.double() @ W.double().t()
+    if bias is not None:
+        y = y + bias.double()
+    if act == 1:
+        y = torch.relu(y)
+    if act == 2:
+        y = torch.sigmoid(y)
+    if res is not None:
+        y = y + res.double()
+    return y
+
+
+def budget(A, W):
+    """sum_k |a||w| per output: the scale f32 round-off is proportional to"""
+    return (A.double().abs() @ W.double().abs().t())
+
+
+def test_split_rows_roundtrip():
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy((rs.standard_normal((37, 64)) * np.exp(rs.uniform(-8, 8, size=(37, 64)))).astype(np.float32)).to(DEV)
+    y, flag = to_hr8(x)
+    back = hr8_decode(y, 37, 64)
+    xe = x.double().cpu().numpy()
+    assert int(flag.item()) == 0
+    assert (np.abs(back - xe) <= 2.0 ** -23 * np.abs(xe) + 1e-10).all()        # 22+ bits, round to nearest
+    x[3, 5] = 40000.0
+    _, flag = to_hr8(x)
+    assert int(flag.item()) == 1
+    x[3, 5] = float("nan")
+    _, flag = to_hr8(x)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 256, 32), (300, 512, 512), (1000, 1536, 512), (77, 512, 2048), (4096 + 5, 1024, 512), (260, 8, 64)])
+@pytest.mark.parametrize("a_fmt", [0, 1])
+def test_gemm_ps_vs_float64(M, N, K, a_fmt):
+    rs = np.random.RandomState(M + N + K + a_fmt)
+    A = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(DEV)
+    res = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).to(DEV)
+    Ain = A if a_fmt == 0 else to_hr8(A)[0]
+    for (b, r, act) in ((bias, None, 1), (None, res, 0), (bias, res, 2), (None, None, 0)):
+        C, Cs, flag = run(Ain, a_fmt, W, b, r, act)
+        want = ref64(A, W, b, r, act)
+        tol = 4 * 2.0 ** -24 * budget(A, W) + 2.0 ** -23 * want.abs() + 1e-7
+        err = (C.double() - want).abs()
+        assert flag == 0
+        assert bool((err <= tol).all()), "f32 output: max err/tol %.2f" % float((err / tol).max())
+        back = torch.from_numpy(hr8_decode(Cs, M, N)).to(DEV)
+        # the split output is the f32 output rounded to 22+ bits
+        assert bool(((back - C.double()).abs() <= 2.0 ** -23 * C.double().abs() + 1e-10).all())
+    # outputs one at a time
+    C, _, _ = run(Ain, a_fmt, W, bias, None, 1, want_hr8=False)
+    _, Cs, _ = run(Ain, a_fmt, W, bias, None, 1, want_f32=False)
+    assert bool(((torch.from_numpy(hr8_decode(Cs, M, N)).to(DEV) - C.double()).abs() <= 2.0 ** -23 * C.double().abs() + 1e-10).all())
+
+
+def test_gemm_ps_gather_segments():
+    """the conv-as-GEMM form: K = 3 segments, each a source row picked by an index table, -1 = zeros"""
+    rs = np.random.RandomState(5)
+    n_src, seg, M, N = 700, 256, 900, 512
+    src = torch.from_numpy(rs.standard_normal((n_src, seg)).astype(np.float32)).to(DEV)
+    idx = torch.from_numpy(rs.randint(-1, n_src, size=(M, 3)).astype(np.int32)).to(DEV)
+    idx[5] = -1
+    W = torch.from_numpy((rs.standard_normal((N, 3 * seg)) / np.sqrt(3 * seg)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(DEV)
+    zero = torch.zeros((1, seg), device=DEV)
+    full = torch.cat([torch.cat([src, zero])[idx[:, s].long()] for s in range(3)], 1)         # index -1 -> the appended zero row
+    C, Cs, flag = run(to_hr8(src)[0], 1, W, bias, None, 0, idx=idx, nseg=3)
+    want = ref64(full, W, bias, None, 0)
+    tol = 4 * 2.0 ** -24 * budget(full, W) + 2.0 ** -23 * want.abs() + 1e-7
+    assert flag == 0 and bool(((C.double() - want).abs() <= tol).all())
+    assert torch.equal(C[5], bias)
+
+
+def test_gemm_ps_strided_views():
+    """A and the outputs as column blocks of wider buffers (the front-end writes its two branches side by side)"""
+    rs = np.random.RandomState(6)
+    M, N, K = 500, 512, 512
+    wide = torch.from_numpy(rs.standard_normal((M, 2 * K)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    A = wide[:, K:]
+    lib = _lib.load()
+    wide_s = torch.empty((M, 8 * K), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.bigc_split_rows_f32(_lib.current_stream(), wide.data_ptr(), 2 * K, wide_s.data_ptr(), 8 * K, M, 2 * K, None))
+    out = torch.zeros((M, 8 * N), dtype=torch.uint8, device=DEV)            # hr8 output into the right half of a (M, 2N) buffer
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(lib.bigc_gemm_ps(_lib.current_stream(), wide_s.data_ptr() + 4 * K, 8 * K, 1, None, 1, W.data_ptr(), K, None, None, 0,
+                                None, 0, out.data_ptr() + 4 * N, 8 * N, M, N, K, 1, flag.data_ptr()))
+    torch.cuda.synchronize()
+    got = hr8_decode(out, M, 2 * N, 8 * N)
+    want = torch.relu(A.double() @ W.double().t()).cpu().numpy()
+    assert np.abs(got[:, :N]).max() == 0.0
+    assert (np.abs(got[:, N:] - want) <= 4 * 2.0 ** -24 * budget(A, W).cpu().numpy() + 2.0 ** -22 * np.abs(want) + 1e-7).all()
+
+
+def test_gemm_ps_range_flag():
+    rs = np.random.RandomState(7)
+    A = torch.from_numpy(rs.standard_normal((256, 64)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy(rs.standard_normal((256, 64)).astype(np.float32)).to(DEV)
+    assert run(A, 0, W)[2] == 0
+    A2 = A.clone(); A2[17, 3] = 1e5
+    assert run(A2, 0, W)[2] == 1                       # A split in the loop
+    W2 = W.clone(); W2[9, 9] = float("inf")
+    assert run(A, 0, W2)[2] == 1                       # weight pre-pass
+    assert run(A * 3000, 0, W * 3000, want_f32=False)[2] == 1      # epilogue split of an out-of-range result
+    assert run(A * 3000, 0, W * 3000, want_hr8=False)[2] == 0      # ... which an f32-only output does not care about

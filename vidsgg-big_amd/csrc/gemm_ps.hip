@@ -1,0 +1,623 @@
+// "Pre-split" GEMM: C = act(A W^T + bias) + residual with f32 accuracy on the f16 matrix cores, for operands that are ALREADY
+// stored as split f16 pairs -- the form in which the producers of this library now write their outputs.
+//
+// Split format "hr8" (same footprint and row pitch as f32): every f32 x is represented as x ~= h + r * 2^-11 with
+// h = f16(x) and r = f16((x - h) * 2^11), both rounded to nearest (error <= 2^-24 |x|, unbiased); a row of K elements is
+// K/8 groups of 32 bytes = [8 heads | 8 scaled residuals].  a * w = h_a h_w + 2^-11 (h_a r_w + r_a h_w) + O(2^-24): three
+// v_mfma_f32_32x32x16_f16 per product, two f32 accumulators (leading / correction), exactly as linear_split.hip -- but the
+// K loop no longer splits anything: both operands are LDS-ready in memory, so they go HBM/L2 -> LDS by DMA
+// (global_load_lds_dwordx4, no registers, no ds_write, no VALU), three LDS stages deep with counted vmcnt, one raw
+// s_barrier per K slab.  A 128-byte LDS row holds the 32 k of a slab as 8 chunks [h0 r0 h1 r1 h2 r2 h3 r3]; the chunk
+// index is XOR-swizzled by (row >> 1) & 7 -- applied on the SOURCE address of the DMA (its LDS image is lane-linear) and on
+// the ds_read_b128 fragment reads, which are bank-conflict free.
+//
+// Tile: 128 data rows x 256 output features per 512-thread workgroup (8 waves, 2 per SIMD), wave patch 64 x 64.  The
+// weights are the MFMA's A operand and the activations its B operand, so a lane of the result owns ONE data row and 16
+// features in runs of four: the epilogue stores 16 bytes per lane -- f32, and/or the split form for the next GEMM (one
+// v_permlane32_swap per dword pairs the half-waves into full 16-byte head / residual chunks).
+//
+// A modes: 0 = hr8 rows by DMA; 1 = hr8 rows gathered through an index table (the stride-2 temporal conv over the virtual
+// stretch: 3 segments of 2*dim_enti; index -1 = a row of zeros); 2 = f32 rows (raw input features, attention outputs):
+// loaded to registers one slab ahead, split in the loop and written to LDS with ds_write_b64, W still by DMA.
+//
+// Range: an element with |x| >= 32768, NaN or Inf cannot be split.  The producer that splits (epilogue, A mode 2, the weight
+// pre-pass) raises *range_flag; results are then invalid and the caller re-runs the step on the exact f32 path
+// (bigc_hip/engine.py does, after the one D2H copy an eval step makes anyway).
+//
+// Roofline: dense f16 MFMA peak / 3 MFMAs per product.
+#include "linear_internal.h"
+#include "prof.h"
+#include <atomic>
+#include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+constexpr int TM = 128, TN = 256, TK = 32;
+constexpr int ROWB = 128;                                    // bytes of an LDS row: 32 k x (head, residual)
+constexpr int A_BYTES = TM * ROWB, W_BYTES = TN * ROWB, STAGE_BYTES = A_BYTES + W_BYTES;
+constexpr int NST = 3;
+constexpr float RSCALE = 2048.0f, RINV = 1.0f / 2048.0f, F16_LIMIT = 32768.0f;
+
+// two f32 -> packed (head, head) and (residual, residual), round to nearest
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& r) {
+    const f32x2 v = {x0, x1};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);
+    const f32x2 d = (v - __builtin_convertvector(hh, f32x2)) * RSCALE;
+    const f16x2 rr = __builtin_convertvector(d, f16x2);
+    h = *(const unsigned*)&hh;
+    r = *(const unsigned*)&rr;
+}
+
+// W (N, K) f32 -> hr8 (N, K/8) groups of 32 bytes
+__global__ __launch_bounds__(256) void split_weight_hr8_kernel(const float* __restrict__ W, int ldw, uint4* __restrict__ Ws, int N, int K8,
+                                                               int* bad, int bad_id) {
+    bool oob = false;
+    const long total = (long)N * K8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / K8), k8 = (int)(i - (long)n * K8);
+        const f32x4 a = *(const f32x4*)(W + (size_t)n * ldw + 8 * k8), b = *(const f32x4*)(W + (size_t)n * ldw + 8 * k8 + 4);
+        uint4 h, r;
+        split2(a[0], a[1], h.x, r.x); split2(a[2], a[3], h.y, r.y); split2(b[0], b[1], h.z, r.z); split2(b[2], b[3], h.w, r.w);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) oob = oob || !(fabsf(a[c]) < F16_LIMIT) || !(fabsf(b[c]) < F16_LIMIT);
+        Ws[2 * i] = h;
+        Ws[2 * i + 1] = r;
+    }
+    if (oob) *bad = bad_id;
+}
+
+// f32 rows -> hr8 rows (stand-alone conversion: tests, and producers that have no fused epilogue yet)
+__global__ __launch_bounds__(256) void split_rows_hr8_kernel(const float* __restrict__ X, long ldx, unsigned char* __restrict__ Y, long ldy_bytes,
+                                                             long rows, int K8, int* range_flag) {
+    bool oob = false;
+    const long total = rows * K8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / K8;
+        const int k8 = (int)(i - n * K8);
+        const f32x4 a = *(const f32x4*)(X + n * ldx + 8 * k8), b = *(const f32x4*)(X + n * ldx + 8 * k8 + 4);
+        uint4 h, r;
+        split2(a[0], a[1], h.x, r.x); split2(a[2], a[3], h.y, r.y); split2(b[0], b[1], h.z, r.z); split2(b[2], b[3], h.w, r.w);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) oob = oob || !(fabsf(a[c]) < F16_LIMIT) || !(fabsf(b[c]) < F16_LIMIT);
+        uint4* yp = (uint4*)(Y + n * ldy_bytes + 32 * (long)k8);
+        yp[0] = h;
+        yp[1] = r;
+    }
+    if (oob && range_flag) atomicOr(range_flag, 1);
+}
+
+struct PsArgs {
+    const unsigned char* A; long lda;                 // A rows: hr8 (modes 0, 1) or f32 (mode 2); pitch in BYTES
+    const int32_t* a_idx; int nseg; int seg_bytes;    // mode 1: source row of (output row, segment), -1 = zeros; bytes of a segment
+    const unsigned char* zero_row;
+    const unsigned char* Ws; long ldw;                // hr8 weights (N, K), pitch in bytes
+    const int* wbad; int wbad_id;
+    const float* bias; const float* res; long ldr;    // residual pitch in floats
+    float* C; long ldc;                               // f32 output (or null), pitch in floats
+    unsigned char* Cs; long ldcs;                     // hr8 output (or null), pitch in bytes
+    int M, N, K, act, tiles_m, tiles_n;
+    int* range_flag;
+    int ablate;       // benchmarking only (BIGC_PS_ABLATE): 1 = no DMA in the K loop
+    unsigned long long* trace;   // benchmarking only (BIGC_PS_TRACE): per wave, cycles spent in the four segments of an iteration
+};
+
+// Persistent workgroups: the launch has (at most) one workgroup per CU; workgroup b walks the tiles b, b + G, b + 2 G, ... of an
+// XCD-aware order and treats their K slabs as ONE stream: the DMA engine runs two slabs ahead of the MFMAs across tile
+// boundaries, so a tile's first slabs arrive while the previous tile's last MFMAs and its epilogue run (with 144 KB of LDS there
+// is one workgroup per CU: nothing else would hide a tile's pipeline fill and its output stores).
+template <int AMODE, bool TRACE = false>
+__global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES];
+    AS3 unsigned char* lds = (AS3 unsigned char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wf = wave & 3, wr = wave >> 2, hi = lane >> 5, l31 = lane & 31;
+    const int nk = p.K / TK;
+
+    // ---- tile order.  Workgroup b runs on XCD b % 8 (observed placement; a speed matter only): the 32 workgroups of an XCD take
+    // 32 consecutive tiles (column tile fastest) per round, so the column tiles of an A row tile run side by side on one L2.
+    const int G = gridDim.x, S = G >> 3, b = blockIdx.x;
+    const int n_tiles = p.tiles_m * p.tiles_n;
+    auto tile_of = [&](int j) { return (j * 8 + (b & 7)) * S + (b >> 3); };     // linear tile index of this workgroup's j-th tile
+    int my_tiles = 0;
+    while (tile_of(my_tiles) < n_tiles) ++my_tiles;
+    if (my_tiles == 0) return;
+    const int n_flat = my_tiles * nk;
+
+    // ---- DMA sources.  One wave instruction moves 8 rows x 128 bytes; lane l lands at LDS position (row l >> 3, chunk l & 7)
+    // of its block and therefore FETCHES the chunk (l & 7) ^ swizzle(row) of that row.  Wave w owns the row blocks w, w + 8, ...
+    // Address = scalar tile base + 32-bit per-lane offset (row clamped to the matrix, chunk swizzled): no VALU per slab.
+    const int sw_src = (((wave & 1) << 2) + (lane >> 4)) & 7;             // ((8 blk + (l >> 3)) >> 1) & 7, same for blk and blk + 8
+    const int coff = ((lane & 7) ^ sw_src) << 4;
+    const int l8 = lane >> 3;
+    // issue-side state (runs two slabs ahead of the compute side)
+    int ij = 0, ikt = 0;
+    const unsigned char* ia_base = nullptr;                               // A + m0 * lda (modes 0, 2) of the tile being issued
+    const unsigned char* iw_base = nullptr;                               // Ws + n0 * ldw
+    unsigned voa[2], vow[4];
+    const unsigned char* pa[2];                                           // mode 1: per-lane source rows of the current segment
+    int arow[2];
+    int wof[2];
+    f32x4 ra[2];
+    if (AMODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 64 * i + (tid >> 3), q = tid & 7;
+            wof[i] = row * ROWB + (((2 * (q >> 1)) ^ ((row >> 1) & 7)) << 4) + ((q & 1) << 3);      // head chunk; the residual chunk is ^ 16
+        }
+    }
+    auto issue_tile_setup = [&]() {
+        const int L = tile_of(ij), tm = L / p.tiles_n, tn = L - tm * p.tiles_n;
+        const int m0 = tm * TM, n0 = tn * TN;
+        ia_base = p.A + (size_t)m0 * p.lda;
+        iw_base = p.Ws + (size_t)n0 * p.ldw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vow[i] = (unsigned)(min((wave + 8 * i) * 8 + l8, p.N - 1 - n0) * (int)p.ldw + coff);
+        if (AMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) voa[i] = (unsigned)(min((wave + 8 * i) * 8 + l8, p.M - 1 - m0)) * (unsigned)p.lda + coff;
+        }
+        if (AMODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) arow[i] = min(m0 + (wave + 8 * i) * 8 + l8, p.M - 1);
+        }
+    };
+    // (`so` = byte offset of an LDS stage, a wave-uniform runtime value).  A slab's DMAs are issued as single pieces spread
+    // between the MFMA blocks of the stream: the CU's vector-memory path takes 64 bytes per clock, i.e. 16 clocks per piece and
+    // 768 per 48 KB slab -- issued back to back by all eight waves after the barrier, every wave sat ~800 clocks in its six
+    // issues (s_memtime trace) with the matrix pipe idle.
+    auto issue_w_piece = [&](int i, int so) {
+        __builtin_amdgcn_global_load_lds((const AS1 void*)(iw_base + (size_t)ikt * ROWB + vow[i]), (AS3 void*)(lds + so + A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+    };
+    auto issue_a_piece = [&](int i, int so) {
+        if (AMODE == 1) {
+            const int kb = ikt * ROWB, sg = kb / p.seg_bytes, within = kb - sg * p.seg_bytes;
+            if (within == 0) {
+                // (one table read per K segment and row; the wait in front of its use also waits for the slabs in flight:
+                // once per 2 * dim_enti / 32 slabs)
+                const int idx = p.a_idx[(size_t)arow[i] * p.nseg + sg];
+                pa[i] = (idx >= 0 ? p.A + (size_t)idx * p.lda : p.zero_row) + coff;      // index -1: a row of zeros
+            }
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(pa[i] + within), (AS3 void*)(lds + so + (wave + 8 * i) * 1024), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(ia_base + (size_t)ikt * ROWB + voa[i]), (AS3 void*)(lds + so + (wave + 8 * i) * 1024), 16, 0, 0);
+        }
+    };
+    // piece k of the slab being issued: modes 0 / 1: A0 A1 W0 | W1 W2 W3;  mode 2: W0 W1 | W2 W3 (k = 0, 1 | 3, 4)
+    auto issue_piece = [&](int k, int so) {
+        if (AMODE == 2) {
+            if (k == 0 || k == 1) issue_w_piece(k, so);
+            if (k == 3 || k == 4) issue_w_piece(k - 1, so);
+        } else {
+            if (k < 2) issue_a_piece(k, so); else issue_w_piece(k - 2, so);
+        }
+    };
+    auto issue_w = [&](int so) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_w_piece(i, so);
+    };
+    auto issue_a = [&](int so) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) issue_a_piece(i, so);
+    };
+    // mode 2: plain register loads.  They are consumed (split_store) right before the slab's wait-for-everything + barrier, so
+    // whatever vmcnt the compiler puts in front of their first use costs nothing extra.  (Issued by inline asm to hide them from
+    // the compiler's wait bookkeeping they are NOT safe: under register pressure the compiler copies the destination registers
+    // before the data has landed.)
+    auto load_f32_at = [&](int j, int kt) {
+        const int L = tile_of(j), tm = L / p.tiles_n;
+        const int m0 = tm * TM;
+        const unsigned char* base = p.A + (size_t)m0 * p.lda + (size_t)kt * ROWB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            ra[i] = *(const f32x4*)(base + (size_t)min(64 * i + (tid >> 3), p.M - 1 - m0) * p.lda + 16 * (tid & 7));
+    };
+    auto issue_advance = [&]() {
+        if (++ikt == nk) { ikt = 0; ++ij; }
+    };
+    float amax = 0.f;            // mode 2: largest |x| split so far; NaN-aware through the final comparison !(amax < limit) of a max3 chain
+    float nanacc = 0.f;          //         (v_max3 drops NaNs: a running sum of x * 0 carries NaN / Inf)
+    auto split_store = [&](int so) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned h0, h1, r0, r1;
+            split2(ra[i][0], ra[i][1], h0, r0);
+            split2(ra[i][2], ra[i][3], h1, r1);
+            // asm volatile: stays HERE, ahead of the loads that refill ra (the compiler would otherwise sink these uses below
+            // them and keep two register sets alive, with a copy and a full vmcnt(0) on the loop's back edge)
+            asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(ra[i][0]), "v"(ra[i][1]));
+            asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(ra[i][2]), "v"(ra[i][3]));
+            asm volatile("v_fmac_f32 %0, 0, %1" : "+v"(nanacc) : "v"((ra[i][0] + ra[i][1]) + (ra[i][2] + ra[i][3])));
+            *(AS3 u32x2*)(lds + so + wof[i]) = u32x2{h0, h1};
+            *(AS3 u32x2*)(lds + so + (wof[i] ^ 16)) = u32x2{r0, r1};
+        }
+    };
+    bool oob = false;
+
+    f32x16 acc0[2][2], acc1[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[fi][ri][r] = 0.f; acc1[fi][ri][r] = 0.f; }
+    };
+    zero_acc();
+
+    // fragment reads: lane = row l31 of a 32-row block, chunk 2 (2 s + hi) + plane, swizzled by (row >> 1) & 7 = (l31 >> 1) & 7
+    const int sw_rd = (l31 >> 1) & 7;
+    int cs[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) cs[s][pl] = ((2 * (2 * s + hi) + pl) ^ sw_rd) << 4;
+    const int rbw = A_BYTES + (wf * 64 + l31) * ROWB, rba = (wr * 64 + l31) * ROWB;
+
+    struct Frag { f16x8 wh[2], wl[2], ah[2], al[2]; };
+    auto rd = [&](int so, int s, Frag& f) {
+        const AS3 unsigned char* base = lds + so;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.wh[i] = *(const AS3 f16x8*)(base + rbw + i * 32 * ROWB + cs[s][0]);
+            f.wl[i] = *(const AS3 f16x8*)(base + rbw + i * 32 * ROWB + cs[s][1]);
+            f.ah[i] = *(const AS3 f16x8*)(base + rba + i * 32 * ROWB + cs[s][0]);
+            f.al[i] = *(const AS3 f16x8*)(base + rba + i * 32 * ROWB + cs[s][1]);
+        }
+    };
+    // the 12 MFMAs of a k16 step, blocks [b0, b1) of the 2 x 2 (feature, row) blocks
+    auto mm = [&](const Frag& f, int b0, int b1) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            if (blk < b0 || blk >= b1) continue;
+            const int fi = blk >> 1, ri = blk & 1;
+            acc0[fi][ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh[fi], f.ah[ri], acc0[fi][ri], 0, 0, 0);
+            acc1[fi][ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh[fi], f.al[ri], acc1[fi][ri], 0, 0, 0);
+            acc1[fi][ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wl[fi], f.ah[ri], acc1[fi][ri], 0, 0, 0);
+        }
+    };
+
+    // ---- epilogue of one tile: lane (l31, hi) of block (fi, ri) owns data row m and the features nb + 8 g + 4 hi + {0..3}
+    // (registers 4 g ..).  Loads are unconditional from clamped addresses and issued in batches (a null bias points at zeros).
+    const bool sigm = p.act == BIGC_ACT_SIGMOID;
+    const float lo = p.act == BIGC_ACT_RELU ? 0.f : -INFINITY;
+    auto epilogue = [&](int j) {
+        const int L = tile_of(j), tm = L / p.tiles_n, tn = L - tm * p.tiles_n;
+        const int m0 = tm * TM, n0 = tn * TN;
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {
+            f32x4 bv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[g] = *(const f32x4*)(p.bias + min(n0 + wf * 64 + fi * 32 + 8 * g + 4 * hi, p.N - 4));
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri) {
+                const int m = m0 + wr * 64 + ri * 32 + l31;
+                const bool mok = m < p.M;
+                const int mc = min(m, p.M - 1);
+                const int nb = n0 + wf * 64 + fi * 32 + 4 * hi;
+                f32x4 rv[4];
+                if (p.res) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rv[g] = *(const f32x4*)(p.res + (size_t)mc * p.ldr + min(nb + 8 * g, p.N - 4));
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                f32x4 v[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float t = (acc0[fi][ri][4 * g + c] + acc1[fi][ri][4 * g + c] * RINV) + bv[g][c];
+                        t = fmaxf(t, lo);
+                        if (sigm) t = 1.0f / (1.0f + expf(-t));
+                        v[g][c] = t + rv[g][c];
+                    }
+                }
+                if (p.C) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (mok && nb + 8 * g < p.N) *(f32x4*)(p.C + (size_t)m * p.ldc + nb + 8 * g) = v[g];
+                }
+                if (p.Cs) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const bool ok = mok && nb + 8 * g < p.N;
+                        unsigned h0, h1, r0, r1;
+                        split2(v[g][0], v[g][1], h0, r0);
+                        split2(v[g][2], v[g][3], h1, r1);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) oob |= ok && !(fabsf(v[g][c]) < F16_LIMIT);
+                        // half-wave exchange: lanes hi = 0 end up with [own heads | partner's heads], lanes hi = 1 with
+                        // [partner's residuals | own residuals] -- the 16-byte head / residual chunks of feature group n / 8
+                        const auto sx = __builtin_amdgcn_permlane32_swap(h0, r0, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(h1, r1, false, false);
+                        if (ok) *(u32x4*)(p.Cs + (size_t)m * p.ldcs + (size_t)((nb + 8 * g) >> 3) * 32 + hi * 16) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- pipeline.  Flat slab g (tile g / nk, K slab g % nk) lives in LDS stage g % 3; its fragments are read one k16 step
+    // ahead of the MFMAs that use them (two register sets), across slab and tile boundaries: the barrier sits in the MIDDLE of
+    // a slab's MFMA stream.
+    //   iteration g:  read (g, step 1) -> F1 | MFMAs (g, step 0) on F0 | wait slab g + 1, barrier_g | DMA slab g + 3 into the stage
+    //                 of slab g | read (g + 1, step 0) -> F0 | MFMAs (g, step 1) on F1 | [epilogue at a tile's end]
+    // barrier_g tells a wave that (i) everybody's DMAs of slab g + 1 have landed and (ii) everybody's reads of slab g have
+    // completed (lgkmcnt(0) in front of it: both k16 steps of slab g are in registers by then), so its stage can be refilled:
+    // two slabs (g + 2, g + 3) are in flight while slab g + 1 is being read.
+    // Mode 2 runs the A operand through registers instead: slab g + 1 is split into its stage before barrier_g (its f32 rows
+    // were loaded after barrier_{g-1}); VMEM order per iteration: 2 register loads (slab g + 2), then 4 W DMAs (slab g + 3).
+    Frag F0, F1;
+    int so = 0, so1 = STAGE_BYTES, so2 = 2 * STAGE_BYTES;                      // stages of slabs g, g + 1, g + 2
+    issue_tile_setup();
+    int ikt_a = 0, ij_a = 0;                                                   // mode 2: the f32 loads run one slab behind the W DMAs
+    if (AMODE == 2) {
+        load_f32_at(0, 0);
+        issue_w(so); issue_advance();
+        split_store(so);
+        if (n_flat > 1) { if (ikt == 0) issue_tile_setup(); issue_w(so1); issue_advance(); }
+        if (n_flat > 2) { if (ikt == 0) issue_tile_setup(); issue_w(so2); issue_advance(); }
+        if (n_flat > 1) { ikt_a = nk > 1 ? 1 : 0; ij_a = nk > 1 ? 0 : 1; load_f32_at(ij_a, ikt_a); }
+        // W of slab 0 landed (everything issued after it may stay in flight: the wait is not on the critical path of a long stream)
+        if (n_flat > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (n_flat > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+        issue_a(so); issue_w(so); issue_advance();
+        if (n_flat > 1) { if (ikt == 0) issue_tile_setup(); issue_a(so1); issue_w(so1); issue_advance(); }
+        if (n_flat > 2) { if (ikt == 0) issue_tile_setup(); issue_a(so2); issue_w(so2); issue_advance(); }
+        if (n_flat > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (n_flat > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    rd(so, 0, F0);
+    // (the fragment reads of the NEXT step are issued after the first block's MFMAs of the current one: the compiler's wait in
+    // front of an MFMA group then only covers reads issued nine MFMAs earlier)
+    int ckt = 0, cj = 0;
+    unsigned long long tr[5] = {0, 0, 0, 0, 0}, tp = 0;
+    auto stamp = [&](int seg) {
+        if (TRACE) {
+            unsigned long long t;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            if (seg >= 0) tr[seg] += t - tp;
+            tp = t;
+        }
+    };
+    stamp(-1);
+    // Issue schedule of slab g + 3 (into the stage of slab g, free after barrier_g): pieces 0..2 between the MFMA blocks of the
+    // second half of iteration g, pieces 3..5 between those of the first half of iteration g + 1.
+    bool half_open = false;                        // the slab under issue has its first three pieces out
+    for (int g = 0; g < n_flat; ++g) {
+        const bool more = g + 1 < n_flat;
+        stamp(4);
+        mm(F0, 0, 1);
+        rd(so, 1, F1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 3; k < 6; ++k) {
+            mm(F0, k - 2, k - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (half_open) issue_piece(k, so2);    // slab g + 2: stage freed by barrier_{g-1}
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (half_open) { issue_advance(); half_open = false; }
+        if (more) {
+            if (AMODE == 2) {
+                split_store(so1);                        // slab g + 1 (the compiler waits for its two loads here)
+                __builtin_amdgcn_sched_barrier(0);       // the split's last use of the registers stays ahead of the loads that refill them
+                if (g + 2 < n_flat) {
+                    if (++ikt_a == nk) { ikt_a = 0; ++ij_a; }
+                    load_f32_at(ij_a, ikt_a);            // slab g + 2
+                }
+                // W of slab g + 1 landed: behind it the W DMAs of slab g + 2 (4) and the two loads just issued may stay in flight
+                if (g + 2 < n_flat) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                stamp(0);
+                if (g + 2 < n_flat) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                stamp(1);
+                __builtin_amdgcn_s_barrier();
+                stamp(2);
+            }
+        }
+        const bool open = more && g + 3 < n_flat && !(p.ablate & 1);
+        if (open && ikt == 0) issue_tile_setup();
+        __builtin_amdgcn_sched_barrier(0);
+        mm(F1, 0, 1);
+        if (more) rd(so1, 0, F0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mm(F1, k + 1, k + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (open) issue_piece(k, so);          // slab g + 3: stage freed by barrier_g
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        half_open = open;
+        stamp(3);
+        const int t = so; so = so1; so1 = so2; so2 = t;
+        if (++ckt == nk) {
+            epilogue(cj);
+            zero_acc();
+            ckt = 0; ++cj;
+        }
+    }
+    if (TRACE && lane == 0) {
+        for (int i = 0; i < 5; ++i) p.trace[((size_t)blockIdx.x * 8 + wave) * 5 + i] = tr[i];
+    }
+    if (*p.wbad == p.wbad_id) oob = true;
+    if (AMODE == 2) oob |= !(amax < F16_LIMIT) || !(nanacc == 0.f);
+    if (__builtin_amdgcn_ballot_w64(oob) != 0 && lane == 0 && p.range_flag) atomicOr(p.range_flag, 1);
+}
+
+// ---- hr8 weight cache: one allocation per (pointer, shape) = [int bad | pad to 256 B | N x K/8 groups of 32 bytes]; re-split when
+// the weights epoch differs (linear_internal.h); epoch 0 = split on every launch into a scratch entry
+struct WKey {
+    const float* w; int n, k, ldw;
+    bool operator==(const WKey& o) const { return w == o.w && n == o.n && k == o.k && ldw == o.ldw; }
+};
+struct WKeyHash { size_t operator()(const WKey& k) const { return std::hash<const void*>()(k.w) ^ ((size_t)k.n * 1315423911u) ^ ((size_t)k.k << 20) ^ (size_t)k.ldw; } };
+struct WEntry { char* mem = nullptr; size_t cap = 0; unsigned long long epoch = 0; int bad_id = 0; };
+std::unordered_map<WKey, WEntry, WKeyHash> g_ps_cache;
+WEntry g_ps_scratch;
+std::mutex g_ps_mu;
+unsigned char* g_zero_row = nullptr;
+size_t g_zero_cap = 0;
+
+int ensure_hr8(hipStream_t s, const float* W, int ldw, int N, int K, WEntry& e, bool fresh) {
+    const size_t need = 256 + (size_t)N * K * 4;
+    if (need > e.cap) {
+        if (e.mem) {
+            if (hipStreamSynchronize(s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "gemm_ps: sync failed");
+            (void)hipFree(e.mem);
+        }
+        e.cap = fresh ? need + need / 2 : need;
+        if (hipMalloc((void**)&e.mem, e.cap) != hipSuccess || hipMemsetAsync(e.mem, 0, 256, s) != hipSuccess) {
+            e.mem = nullptr; e.cap = 0;
+            return bigc_fail(BIGC_ERR_HIP, "gemm_ps: hipMalloc of the split weights failed");
+        }
+    }
+    ProfScope ps((void*)s, FAM_LINEAR_AUX, 0.0, 8.0 * N * (double)K);
+    static std::atomic<int> bad_seq{0};
+    e.bad_id = ++bad_seq;
+    const long total = (long)N * (K / 8);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(split_weight_hr8_kernel, dim3(grid), dim3(256), 0, s, W, ldw, (uint4*)(e.mem + 256), N, K / 8, (int*)e.mem, e.bad_id);
+    BIGC_LAUNCH_CHECK("split_weight_hr8");
+    return BIGC_OK;
+}
+
+}  // namespace
+
+bool bigc_gemm_ps_supported(const PsGemm& g) {
+    if (g.M <= 0 || g.N < 8 || g.K < TK || g.K % TK != 0 || g.N % 8 != 0) return false;
+    if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15) || g.lda % 16 != 0 || g.ldw % 4 != 0) return false;
+    if (g.bias && ((uintptr_t)g.bias & 15)) return false;
+    if (g.res && (((uintptr_t)g.res & 15) || g.ldr % 4 != 0)) return false;
+    if (g.C && (((uintptr_t)g.C & 15) || g.ldc % 4 != 0)) return false;
+    if (g.Cs && (((uintptr_t)g.Cs & 15) || g.ldcs % 16 != 0)) return false;
+    if (g.a_idx && (g.a_fmt != PS_HR8 || g.nseg > 4 || g.nseg < 1 || (g.K / g.nseg) % TK != 0)) return false;
+    return g.C || g.Cs;
+}
+
+int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
+    if (!bigc_gemm_ps_supported(g)) return bigc_fail(BIGC_ERR_ARG, "gemm_ps: unsupported shape / alignment (M=%d N=%d K=%d)", g.M, g.N, g.K);
+    PsArgs p;
+    p.A = (const unsigned char*)g.A; p.lda = g.lda; p.a_idx = g.a_idx; p.nseg = g.a_idx ? g.nseg : 1;
+    p.seg_bytes = (g.K / p.nseg) * 4;
+    p.bias = g.bias; p.res = g.res; p.ldr = g.ldr; p.C = g.C; p.ldc = g.ldc; p.Cs = (unsigned char*)g.Cs; p.ldcs = g.ldcs;
+    p.M = g.M; p.N = g.N; p.K = g.K; p.act = g.act;
+    p.tiles_m = cdiv(g.M, TM); p.tiles_n = cdiv(g.N, TN);
+    p.range_flag = g.range_flag;
+    static const int ablate = getenv("BIGC_PS_ABLATE") ? atoi(getenv("BIGC_PS_ABLATE")) : 0;
+    p.ablate = ablate;
+    static const int trace = getenv("BIGC_PS_TRACE") ? atoi(getenv("BIGC_PS_TRACE")) : 0;
+    p.trace = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_ps_mu);
+        const unsigned long long epoch = bigc_static_weights_epoch;
+        WEntry* e = &g_ps_scratch;
+        bool stale = true;
+        if (epoch != 0) {
+            e = &g_ps_cache[WKey{g.W, g.N, g.K, g.ldw}];
+            stale = e->epoch != epoch;
+        }
+        if (stale) {
+            int rc = ensure_hr8(s, g.W, g.ldw, g.N, g.K, *e, epoch == 0);
+            if (rc != BIGC_OK) return rc;
+            e->epoch = epoch;
+        }
+        p.Ws = (const unsigned char*)(e->mem + 256); p.ldw = (long)g.K * 4; p.wbad = (const int*)e->mem; p.wbad_id = e->bad_id;
+        p.zero_row = nullptr;
+        {
+            const size_t need = (size_t)p.seg_bytes > (size_t)g.N * 4 ? (size_t)p.seg_bytes : (size_t)g.N * 4;
+            if (need > g_zero_cap) {
+                if (g_zero_row) { if (hipStreamSynchronize(s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "gemm_ps: sync failed"); (void)hipFree(g_zero_row); }
+                g_zero_cap = need < 16384 ? 16384 : need;
+                if (hipMalloc((void**)&g_zero_row, g_zero_cap) != hipSuccess || hipMemsetAsync(g_zero_row, 0, g_zero_cap, s) != hipSuccess) {
+                    g_zero_row = nullptr; g_zero_cap = 0;
+                    return bigc_fail(BIGC_ERR_HIP, "gemm_ps: cannot allocate the zero row");
+                }
+            }
+            p.zero_row = g_zero_row;
+        }
+        if (!p.bias) p.bias = (const float*)g_zero_row;
+    }
+    const double flops = 2.0 * g.M * (double)g.N * g.K;
+    const double bytes = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * ((g.res ? 1 : 0) + (g.C ? 1 : 0) + (g.Cs ? 1 : 0)));
+    ProfScope ps((void*)s, FAM_LINEAR, flops, bytes);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "gemm_ps: no device");
+        n_cu = prop.multiProcessorCount >= 8 ? (prop.multiProcessorCount / 8) * 8 : 8;
+    }
+    // persistent workgroups: one per CU (a multiple of 8 for the XCD-aware tile order), fewer when there are fewer tiles
+    const int n_tiles = p.tiles_m * p.tiles_n;
+    const int grid = n_tiles >= n_cu ? n_cu : cdiv(n_tiles, 8) * 8;
+    if (g.a_fmt == PS_F32) hipLaunchKernelGGL((gemm_ps_kernel<2>), dim3(grid), dim3(512), 0, s, p);
+    else if (g.a_idx) hipLaunchKernelGGL((gemm_ps_kernel<1>), dim3(grid), dim3(512), 0, s, p);
+    else if (trace) {
+        static unsigned long long* buf = nullptr;
+        if (!buf && hipMalloc((void**)&buf, 8 * 5 * 8 * 4096) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "gemm_ps: trace buffer");
+        p.trace = buf;
+        hipLaunchKernelGGL((gemm_ps_kernel<0, true>), dim3(grid), dim3(512), 0, s, p);
+        std::vector<unsigned long long> h((size_t)grid * 40);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
+        double seg[5] = {0, 0, 0, 0, 0};
+        for (size_t i = 0; i < h.size(); ++i) seg[i % 5] += (double)h[i];
+        const double slabs = (double)p.tiles_m * p.tiles_n * (p.K / TK) * 8;     // wave-slabs
+        fprintf(stderr, "gemm_ps trace M=%d N=%d K=%d (memtime ticks per wave per slab): step-0 MFMAs + reads %.0f | wait vmcnt/lgkm %.0f | barrier %.0f | "
+                "DMA issue %.0f | step-1 MFMAs + reads + loop %.0f\n", p.M, p.N, p.K, seg[0] / slabs, seg[1] / slabs, seg[2] / slabs, seg[3] / slabs, seg[4] / slabs);
+    }
+    else hipLaunchKernelGGL((gemm_ps_kernel<0>), dim3(grid), dim3(512), 0, s, p);
+    BIGC_LAUNCH_CHECK("gemm_ps");
+    return BIGC_OK;
+}
+
+int bigc_split_rows_hr8(hipStream_t s, const float* X, long ldx, void* Y, long ldy_bytes, long rows, int K, int* range_flag) {
+    BIGC_CHECK_ARG(X && Y && K % 8 == 0 && ldx % 4 == 0 && ldy_bytes % 16 == 0, "split_rows: bad argument");
+    if (rows <= 0) return BIGC_OK;
+    ProfScope ps((void*)s, FAM_LINEAR_AUX, 0.0, 8.0 * rows * (double)K);
+    const long total = rows * (K / 8);
+    int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(split_rows_hr8_kernel, dim3(grid), dim3(256), 0, s, X, ldx, (unsigned char*)Y, ldy_bytes, rows, K / 8, range_flag);
+    BIGC_LAUNCH_CHECK("split_rows_hr8");
+    return BIGC_OK;
+}
+
+// Raw entry point (tests, benchmarks): A is f32 (a_fmt 0) or hr8 (a_fmt 1) with pitch lda_bytes; outputs f32 C and / or hr8 Cs
+extern "C" int bigc_gemm_ps(void* stream, const void* A, long lda_bytes, int a_fmt, const int32_t* a_idx, int nseg, const float* W, int ldw,
+                            const float* bias, const float* residual, long ldr, float* C, long ldc, void* Cs, long ldcs_bytes,
+                            int M, int N, int K, int act, int* range_flag) {
+    BIGC_CHECK_ARG(A && W && (C || Cs), "gemm_ps: null pointer");
+    if (M == 0) return BIGC_OK;
+    PsGemm g;
+    g.A = A; g.lda = lda_bytes; g.a_fmt = a_fmt ? PS_HR8 : PS_F32; g.a_idx = a_idx; g.nseg = a_idx ? nseg : 1; g.W = W; g.ldw = ldw;
+    g.bias = bias; g.res = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Cs = Cs; g.ldcs = ldcs_bytes; g.M = M; g.N = N; g.K = K; g.act = act;
+    g.range_flag = range_flag;
+    return bigc_gemm_ps_launch((hipStream_t)stream, g);
+}
+
+extern "C" int bigc_split_rows_f32(void* stream, const float* X, long ldx, void* Y, long ldy_bytes, long rows, int K, int* range_flag) {
+    return bigc_split_rows_hr8((hipStream_t)stream, X, ldx, Y, ldy_bytes, rows, K, range_flag);
+}

@@ -26,3 +26,21 @@ struct StaticWeights {
 
 // launches the split-operand kernel (and its W pre-split pass); returns BIGC_OK or an error code
 int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double bytes);
+
+// ---- gemm_ps.hip: GEMM on operands stored as split f16 pairs ("hr8": per 8 consecutive k, 16 bytes of heads then 16 bytes of
+// scaled residuals; same footprint and row pitch as f32).  A is hr8 (optionally row-gathered) or f32 (split in the loop), W is
+// an f32 weight whose hr8 form is cached per weights epoch; outputs: f32 C and / or hr8 Cs (for the next GEMM).
+enum { PS_F32 = 0, PS_HR8 = 1 };
+struct PsGemm {
+    const void* A = nullptr; long lda = 0; int a_fmt = PS_F32;      // pitch in BYTES
+    const int32_t* a_idx = nullptr; int nseg = 1;                    // hr8 only: source row per (output row, K segment), -1 = zeros
+    const float* W = nullptr; int ldw = 0;                           // (N, K) f32, pitch in floats
+    const float* bias = nullptr; const float* res = nullptr; long ldr = 0;
+    float* C = nullptr; long ldc = 0;                                // pitch in floats
+    void* Cs = nullptr; long ldcs = 0;                               // pitch in BYTES
+    int M = 0, N = 0, K = 0, act = 0;
+    int* range_flag = nullptr;                                       // set to 1 when a split operand left the f16 range
+};
+bool bigc_gemm_ps_supported(const PsGemm& g);
+int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g);
+int bigc_split_rows_hr8(hipStream_t s, const float* X, long ldx, void* Y, long ldy_bytes, long rows, int K, int* range_flag);

@@ -311,7 +311,7 @@ def vidor_grounding_legs(args, lib, device, want_vidor, want_grounding):
 
     def cls_step():
         out_holder["o"] = big.forward_packed(packed, 3)
-        out_holder["o"]["n_out"].cpu()
+        big.counts(out_holder["o"])
 
     steps = 3
     el, el_prof, fam = timed_with_events(lib, cls_step, 1, steps)
@@ -419,7 +419,7 @@ def main():
 
     def step():
         out = model.forward_packed(packed, args.topk)
-        return out["n_out"].cpu()      # the one D2H copy forward() needs (row counts) -> host sync
+        return model.counts(out)       # the one D2H copy forward() needs (row counts + the GEMM range flag) -> host sync
 
     for _ in range(args.warmup):
         step()
@@ -528,6 +528,7 @@ def main():
         torch.set_num_threads(usable_cores())
         cpu_pairs, n_done, cpu_s = 0, 0, 0.0
         rows_total, rows_same, vids_same, max_rel, other_argmax = 0, 0, 0, 0.0, 0
+        over, over_worse, sd64 = [], 0, None
         with torch.no_grad():
             O.forward_test(sd, cfg, [synthetic_proposal(base, n_trajs=args.n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"])], args.topk)  # warm-up
             for v in range(n_cpu):                                      # bounded: stop after ~15 s of oracle time
@@ -555,7 +556,22 @@ def main():
                 other_argmax += int((~same_so).sum())
                 lg = o["pred_logits"].numpy()
                 if same_so.any():
-                    max_rel = max(max_rel, float(np.abs(hip_logits[v][same_so] - lg[same_so]).max() / np.abs(lg).max()))
+                    d = float(np.abs(hip_logits[v][same_so] - lg[same_so]).max() / np.abs(lg).max())
+                    max_rel = max(max_rel, d)
+                    if d > 1e-4 and len(over) < 8:
+                        # two f32 evaluations more than 1e-4 apart: a float64 evaluation of the oracle arbitrates (outside the CPU timing)
+                        import copy
+                        if sd64 is None:
+                            sd64 = {k: t.double() for k, t in sd.items()}
+                        p64 = copy.deepcopy(p)
+                        p64.bboxes_list = [x.double() for x in p64.bboxes_list]
+                        p64.features_list = [x.double() for x in p64.features_list]
+                        p64.scores = p64.scores.double()
+                        l64 = O.encode2decode(sd64, cfg, p64)["pred_logits"].numpy()
+                        e_hip = float(np.abs(hip_logits[v][same_so] - l64[same_so]).max() / np.abs(lg).max())
+                        e_ref = float(np.abs(lg[same_so] - l64[same_so]).max() / np.abs(lg).max())
+                        over.append(dict(video=v, hip_vs_f32_oracle=d, hip_vs_f64=e_hip, f32_oracle_vs_f64=e_ref))
+                        over_worse += int(e_hip > e_ref)
                 if cpu_s > args.cpu_seconds:
                     break
         cpu_baseline = dict(value=round(cpu_pairs / cpu_s, 1), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
@@ -563,8 +579,11 @@ def main():
                                    "(= forward_test), fp32 torch CPU, %.1f s" % (n_done, args.n_trajs, cpu_s))
         oracle_parity = dict(videos=n_done, identical_triplet_rows="%d of %d" % (rows_same, rows_total), videos_fully_identical=vids_same,
                              max_logit_rel=max_rel, queries_with_other_argmax_entity=other_argmax,
+                             videos_over_1e_4=over, videos_over_1e_4_where_hip_is_farther_from_f64_than_the_f32_oracle=over_worse,
                              note="HIP output of the timed workload vs the CPU oracle on the same videos; logits compared on the queries whose "
-                                  "attention arg-max (subject, object) agrees, relative to max |logit| of the video")
+                                  "attention arg-max (subject, object) agrees, relative to max |logit| of the video; the benchmark model's sharp "
+                                  "attention amplifies f32 round-off, so where two f32 evaluations differ by more than 1e-4 a float64 evaluation of "
+                                  "the oracle is the arbiter")
     del ref_out
     legs = {}
     want = [x for x in args.legs.split(",") if x] if world == 1 else []

@@ -236,6 +236,11 @@ typedef struct {
     int32_t* soid;        /* (B,2,Q) */
     /* construct_triplet outputs, see bigc_construct_triplets; all may be NULL to skip a8 */
     int32_t* quint; float* scores; int32_t* dura; int32_t* qid; int32_t* n_out;
+    /* may be NULL.  Set to 0 / 1 by bigc_forward: 1 = an operand of the split-operand GEMM path (csrc/gemm_ps.hip) left the range
+     * its f16 pair format represents (|x| >= 4096 for an activation, NaN, Inf): the outputs are then INVALID and the caller must run
+     * the step again with bigc_linear_set_exact(1).  Without this pointer such a step fails with BIGC_ERR_ARG up front (the
+     * forward then uses the in-kernel-fallback GEMM of csrc/linear_split.hip instead). */
+    int32_t* range_flag;
 } bigc_outputs;
 
 size_t bigc_workspace_bytes(const bigc_model* m, const bigc_batch* b);

@@ -193,11 +193,28 @@ def test_training_gradients_are_linear_in_the_upstream_gradient():
         assert torch.allclose(grads[1][k], 3.0 * grads[0][k], rtol=2e-4, atol=1e-6 * float(grads[1][k].abs().max())), k   # fp32 atomics: summation order varies
 
 
+def _oracle_fp64_logits(sd, cfg, p):
+    """the oracle evaluated in float64 on the same inputs: the arbiter between two f32 evaluations that disagree"""
+    import copy
+    from oracle import bigc_oracle as O
+    sd64 = {k: v.double() for k, v in sd.items()}
+    p64 = copy.deepcopy(p)
+    p64.bboxes_list = [b.double() for b in p64.bboxes_list]
+    p64.features_list = [f.double() for f in p64.features_list]
+    p64.scores = p64.scores.double()
+    with torch.no_grad():
+        return O.encode2decode(sd64, cfg, p64)["pred_logits"].numpy()
+
+
 def test_benchmark_videos_vs_oracle_row_for_row():
     """32 videos of the benchmark workload (bench.py: seeds 1234 + v, exp2 dims, N=64) through the HIP path in ONE batch and
-    through the CPU oracle one by one: every triplet row (quintuple, overlap span, query id) identical, predicate logits within
-    1e-4 relative -- index parity at full size against the ORACLE (pinned to the reference by tests/golden/bigc_v_n64 /
-    bigc_v_n100), not against the path's own second GEMM mode."""
+    through the CPU oracle one by one: every triplet row (quintuple, overlap span, query id) identical, every attention arg-max
+    identical, predicate logits within 1e-4 relative -- index parity at full size against the ORACLE (pinned to the reference by
+    tests/golden/bigc_v_n64 / bigc_v_n100), not against the path's own second GEMM mode.
+    The benchmark model's attention is sharp by construction (scores of magnitude ~50), which amplifies f32 round-off: on a few
+    videos the f32 oracle itself sits 5e-5 .. 8e-5 from a float64 evaluation (benchmarks/accuracy_stages.py).  Where two f32
+    evaluations differ by more than 1e-4 the float64 oracle arbitrates: the HIP logits must be within 1e-4 of it and at least as
+    close to it as the f32 oracle's are (measured: video 29, f32 oracle 2.1e-4 from float64, HIP 8.9e-5)."""
     from oracle import bigc_oracle as O
     n_vid = 32
     cfg = dict(configs.CONFIG_V)
@@ -212,7 +229,7 @@ def test_benchmark_videos_vs_oracle_row_for_row():
     logits = out["pred_logits"].cpu().numpy().reshape(n_vid, Q, P)
     soid = out["soid"].cpu().numpy()
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    rows = 0
+    rows, arbitrated = 0, 0
     with torch.no_grad():
         for v, p in enumerate(host):
             o = O.encode2decode(sd, cfg, p)
@@ -221,11 +238,18 @@ def test_benchmark_videos_vs_oracle_row_for_row():
             assert (want is None) == (got is None)
             assert np.array_equal(soid[v], o["att"].argmax(-1).numpy()), "video %d: attention arg-max differs from the oracle" % v
             ref = o["pred_logits"].numpy()
-            assert np.abs(logits[v] - ref).max() <= 1e-4 * np.abs(ref).max(), "video %d logits" % v
+            scale = np.abs(ref).max()
+            d = np.abs(logits[v] - ref).max() / scale
+            if d > 1e-4:
+                ref64 = _oracle_fp64_logits(sd, cfg, p)
+                e_hip = np.abs(logits[v] - ref64).max() / scale
+                e_ref = np.abs(ref - ref64).max() / scale
+                assert e_hip <= 1e-4 and e_hip <= e_ref, "video %d logits: |hip - f32 oracle| %.2e, |hip - f64| %.2e, |f32 oracle - f64| %.2e" % (v, d, e_hip, e_ref)
+                arbitrated += 1
             if want is None:
                 continue
             assert np.array_equal(got[0], want[0].numpy()), "video %d: quintuples differ" % v
             assert np.array_equal(got[2], want[2].numpy()) and np.array_equal(got[3], want[3].numpy())
             assert np.abs(got[1] - want[1].numpy()).max() <= 5e-5
             rows += want[0].shape[0]
-    assert rows > 32 * 50
+    assert rows > 32 * 50 and arbitrated <= 2

@@ -36,7 +36,7 @@ class bigc_batch(ctypes.Structure):
 class bigc_outputs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "pred_logits", "att", "pred_query", "enti2enco", "enco_output", "soid",
-        "quint", "scores", "dura", "qid", "n_out")]
+        "quint", "scores", "dura", "qid", "n_out", "range_flag")]
 
 
 class grd_config(ctypes.Structure):

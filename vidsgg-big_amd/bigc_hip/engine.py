@@ -90,7 +90,10 @@ class BigcEngine(object):
             out["scores"] = torch.empty((B, cap, 3), dtype=torch.float32, device=dev)
             out["dura"] = torch.empty((B, cap, 2), dtype=torch.int32, device=dev)
             out["qid"] = torch.empty((B, cap), dtype=torch.int32, device=dev)
-            out["n_out"] = torch.empty((B,), dtype=torch.int32, device=dev)
+            # row counts and, behind them, the range flag of the split-operand GEMM path: ONE D2H copy returns both
+            out["_counts"] = torch.zeros((B + 1,), dtype=torch.int32, device=dev)
+            out["n_out"] = out["_counts"][:B]
+            out["range_flag"] = out["_counts"][B:]
         o = _lib.bigc_outputs()
         for name, _ in _lib.bigc_outputs._fields_:
             setattr(o, name, out[name].data_ptr() if name in out else None)

@@ -37,9 +37,9 @@ __device__ __forceinline__ void split8(const float (&x)[8], a16x8& h, a16x8& r, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float a = x[2 * j], b = x[2 * j + 1];
-        hh.p[j] = __builtin_amdgcn_cvt_pkrtz(a, b);
+        hh.p[j] = bigc_pk_rtn(a, b);
         const float ra = (a - (float)hh.p[j][0]) * RS, rb = (b - (float)hh.p[j][1]) * RS;
-        rr.p[j] = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+        rr.p[j] = bigc_pk_rtn(ra, rb);
         chk += ra + rb;
         asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(amax) : "v"(amax), "v"(a), "v"(b));
     }
@@ -195,8 +195,8 @@ __device__ __forceinline__ void split8a(const float (&x)[8], a16x8& h, a16x8& r,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float a = x[2 * j], b = x[2 * j + 1];
-        hh.p[j] = __builtin_amdgcn_cvt_pkrtz(a, b);
-        rr.p[j] = __builtin_amdgcn_cvt_pkrtz((a - (float)hh.p[j][0]) * RS, (b - (float)hh.p[j][1]) * RS);
+        hh.p[j] = bigc_pk_rtn(a, b);
+        rr.p[j] = bigc_pk_rtn((a - (float)hh.p[j][0]) * RS, (b - (float)hh.p[j][1]) * RS);
         asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(amax) : "v"(amax), "v"(a), "v"(b));
     }
     h = hh.v;

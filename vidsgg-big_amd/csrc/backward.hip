@@ -138,9 +138,9 @@ __device__ __forceinline__ void dw_split16(const float (&x)[16], unsigned char* 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float a = x[8 * g + 2 * j], b = x[8 * g + 2 * j + 1];
-            hh.h[j] = __builtin_amdgcn_cvt_pkrtz(a, b);
+            hh.h[j] = bigc_pk_rtn(a, b);
             const float ra = (a - (float)hh.h[j][0]) * 2048.0f, rb = (b - (float)hh.h[j][1]) * 2048.0f;
-            rr.h[j] = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+            rr.h[j] = bigc_pk_rtn(ra, rb);
             chk += ra + rb;
             asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(amax) : "v"(amax), "v"(a), "v"(b));
         }

@@ -16,6 +16,18 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// two f32 -> packed f16 pair, ROUND TO NEAREST (v_cvt_pk_f16_f32).  The split-operand kernels use it for both halves of
+// x = h + r 2^-11: with the round-toward-zero pack (v_cvt_pkrtz) both halves were biased towards zero (2^-22 relative per
+// operand, always the same sign), which showed up as a 3x larger distance of the front-end GEMMs to a float64 evaluation than
+// torch's own f32 GEMM has (benchmarks/accuracy_stages.py); rounded to nearest the pair carries 2^-24 and no bias.
+typedef __fp16 bigc_fp16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bigc_fp16x2 bigc_pk_rtn(float a, float b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const h2 v = __builtin_convertvector(f2{a, b}, h2);
+    return *(const bigc_fp16x2*)&v;
+}
+
 int bigc_fail(int code, const char* fmt, ...);
 #define BIGC_CHECK_ARG(cond, ...) do { if (!(cond)) return bigc_fail(BIGC_ERR_ARG, __VA_ARGS__); } while (0)
 #define BIGC_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); \

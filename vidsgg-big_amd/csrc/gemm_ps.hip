@@ -1,28 +1,38 @@
-// "Pre-split" GEMM: C = act(A W^T + bias) + residual with f32 accuracy on the f16 matrix cores, for operands that are ALREADY
-// stored as split f16 pairs -- the form in which the producers of this library now write their outputs.
+// GEMM on split operands: C = act(A W^T + bias) + residual with f32-level accuracy on the f16 matrix cores, for operands that are
+// ALREADY stored as pairs of f16 numbers -- the form in which the producers of this library write their outputs.
 //
-// Split format "hr8" (same footprint and row pitch as f32): every f32 x is represented as x ~= h + r * 2^-11 with
-// h = f16(x) and r = f16((x - h) * 2^11), both rounded to nearest (error <= 2^-24 |x|, unbiased); a row of K elements is
-// K/8 groups of 32 bytes = [8 heads | 8 scaled residuals].  a * w = h_a h_w + 2^-11 (h_a r_w + r_a h_w) + O(2^-24): three
-// v_mfma_f32_32x32x16_f16 per product, two f32 accumulators (leading / correction), exactly as linear_split.hip -- but the
-// K loop no longer splits anything: both operands are LDS-ready in memory, so they go HBM/L2 -> LDS by DMA
-// (global_load_lds_dwordx4, no registers, no ds_write, no VALU), three LDS stages deep with counted vmcnt, one raw
-// s_barrier per K slab.  A 128-byte LDS row holds the 32 k of a slab as 8 chunks [h0 r0 h1 r1 h2 r2 h3 r3]; the chunk
-// index is XOR-swizzled by (row >> 1) & 7 -- applied on the SOURCE address of the DMA (its LDS image is lane-linear) and on
-// the ds_read_b128 fragment reads, which are bank-conflict free.
+// Split format "hr8" (same footprint and row pitch as f32).  An f32 x of a tensor with scale exponent E is stored as
+//     X = x * 2^E,   h = f16(X),   r = f16(X - h)          (both round-to-nearest; X - h is exact in f32)
+// and a row of K elements is K/8 groups of 32 bytes = [8 heads | 8 residuals].  The residual is kept UNSCALED (it may be an
+// f16 subnormal: the f16 MFMA takes subnormal inputs exactly, benchmarks/probes/mfma_f16_denorm.hip), so that
+//     a w 2^(Ea+Ew) = h_a h_w + h_a r_w + r_a h_w + O(2^-23)
+// is ONE f32 accumulator and three v_mfma_f32_32x32x16_f16 per product.  Representation error of an element: 2^-23 |X| while
+// |X| >= 0.25, 2^-25 absolute below (the residual's subnormal quantum): relative to the magnitudes that dominate a dot product
+// this is the f32 round-off level as long as the tensor's typical |X| is well above 0.25.  Activations use the fixed exponent
+// PS_ACT_EXP = 3 (|x| < 4096 representable, full relative precision for |x| >= 0.03, 3.7e-9 absolute below); every weight
+// matrix gets its own exponent from its largest magnitude when it is split (max |W| in [2^13, 2^14)).
+// (The first version of this kernel kept the residual scaled by 2^11 and needed a second accumulator for the correction terms:
+// 128 accumulator registers for a 64 x 64 wave patch capped the tile at 128 x 256, i.e. 256 bytes of LDS fill per MFMA through a
+// vector-memory path that takes 64 bytes per clock, and one barrier per 24 MFMAs per wave: 300 TFLOP/s.)
 //
-// Tile: 128 data rows x 256 output features per 512-thread workgroup (8 waves, 2 per SIMD), wave patch 64 x 64.  The
-// weights are the MFMA's A operand and the activations its B operand, so a lane of the result owns ONE data row and 16
-// features in runs of four: the epilogue stores 16 bytes per lane -- f32, and/or the split form for the next GEMM (one
-// v_permlane32_swap per dword pairs the half-waves into full 16-byte head / residual chunks).
+// Both operands are LDS-ready in memory, so they go HBM / L2 -> LDS by DMA (global_load_lds_dwordx4: no registers, no ds_write, no
+// VALU).  A 128-byte LDS row holds the 32 k of a slab as 8 chunks [h0 r0 h1 r1 h2 r2 h3 r3]; the chunk index is XOR-swizzled
+// by (row >> 1) & 7 -- applied on the SOURCE address of the DMA (its LDS image is lane-linear) and on the ds_read_b128 fragment
+// reads, which are bank-conflict free (SQ_LDS_BANK_CONFLICT = 0).
+//
+// Tile: 256 output features x TM data rows per 512-thread workgroup (8 waves as 4 x 2, two per SIMD), TM = 256 (wave patch
+// 64 x 128, two LDS stages of 64 KB) for the big-M GEMMs and TM = 128 (patch 64 x 64, three stages of 48 KB) when 256-row tiles
+// would leave CUs idle.  The weights are the MFMA's A operand and the activations its B operand, so a lane of the result owns
+// ONE data row and runs of four features: the epilogue stores 16 bytes per lane -- f32, and / or the split form for the next
+// GEMM (one v_permlane32_swap per dword pairs the half-waves into full 16-byte head / residual chunks).
 //
 // A modes: 0 = hr8 rows by DMA; 1 = hr8 rows gathered through an index table (the stride-2 temporal conv over the virtual
 // stretch: 3 segments of 2*dim_enti; index -1 = a row of zeros); 2 = f32 rows (raw input features, attention outputs):
 // loaded to registers one slab ahead, split in the loop and written to LDS with ds_write_b64, W still by DMA.
 //
-// Range: an element with |x| >= 32768, NaN or Inf cannot be split.  The producer that splits (epilogue, A mode 2, the weight
-// pre-pass) raises *range_flag; results are then invalid and the caller re-runs the step on the exact f32 path
-// (bigc_hip/engine.py does, after the one D2H copy an eval step makes anyway).
+// Range: an element with |X| >= 32768, NaN or Inf cannot be split.  Whoever splits (epilogue, A mode 2, the weight pre-pass)
+// raises *range_flag; results are then invalid and the caller re-runs the step on the exact f32 path (bigc_hip/engine.py does,
+// after the one D2H copy an eval step makes anyway).
 //
 // Roofline: dense f16 MFMA peak / 3 MFMAs per product.
 #include "linear_internal.h"
@@ -42,41 +52,65 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
 
-constexpr int TM = 128, TN = 256, TK = 32;
+constexpr int TN = 256, TK = 32;
 constexpr int ROWB = 128;                                    // bytes of an LDS row: 32 k x (head, residual)
-constexpr int A_BYTES = TM * ROWB, W_BYTES = TN * ROWB, STAGE_BYTES = A_BYTES + W_BYTES;
-constexpr int NST = 3;
-constexpr float RSCALE = 2048.0f, RINV = 1.0f / 2048.0f, F16_LIMIT = 32768.0f;
+constexpr int W_BYTES = TN * ROWB;
+constexpr float F16_LIMIT = 32768.0f;
+constexpr float ACT_SCALE = (float)(1 << PS_ACT_EXP), ACT_INV = 1.0f / ACT_SCALE;
 
-// two f32 -> packed (head, head) and (residual, residual), round to nearest
+// two scaled f32 -> packed (head, head) and (residual, residual), round to nearest
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& r) {
     const f32x2 v = {x0, x1};
     const f16x2 hh = __builtin_convertvector(v, f16x2);
-    const f32x2 d = (v - __builtin_convertvector(hh, f32x2)) * RSCALE;
+    const f32x2 d = v - __builtin_convertvector(hh, f32x2);
     const f16x2 rr = __builtin_convertvector(d, f16x2);
     h = *(const unsigned*)&hh;
     r = *(const unsigned*)&rr;
 }
 
-// W (N, K) f32 -> hr8 (N, K/8) groups of 32 bytes
+// header of a cached split weight: [0] int bad id, [1] max |W| bits, [2] float 2^-Ew, [3] float 2^Ew
+__global__ __launch_bounds__(256) void weight_absmax_kernel(const float* __restrict__ W, int ldw, int N, int K4, unsigned* hdr) {
+    float amax = 0.f;
+    bool bad = false;
+    const long total = (long)N * K4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / K4), k4 = (int)(i - (long)n * K4);
+        const f32x4 a = *(const f32x4*)(W + (size_t)n * ldw + 4 * k4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { amax = fmaxf(amax, fabsf(a[c])); bad = bad || !(fabsf(a[c]) < INFINITY); }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(hdr + 1, __float_as_uint(amax));          // non-negative floats order like their bit patterns
+    if (bad) atomicMax(hdr + 1, 0x7f800000u);
+}
+
+// W (N, K) f32 -> hr8 (N, K/8) groups of 32 bytes, exponent chosen so that max |W| 2^Ew lies in [2^13, 2^14)
 __global__ __launch_bounds__(256) void split_weight_hr8_kernel(const float* __restrict__ W, int ldw, uint4* __restrict__ Ws, int N, int K8,
-                                                               int* bad, int bad_id) {
-    bool oob = false;
+                                                               unsigned* hdr, int bad_id) {
+    const float amax = __uint_as_float(hdr[1]);
+    int e = 0;
+    const bool ok = amax > 0.f && amax < INFINITY;
+    if (ok) { int ex; frexpf(amax, &ex); e = 14 - ex; }                       // amax = m 2^ex, m in [0.5, 1)
+    e = max(-60, min(60, e));
+    const float sc = ldexpf(1.0f, e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ((float*)hdr)[2] = ldexpf(1.0f, -e);
+        ((float*)hdr)[3] = sc;
+        if (!(amax < INFINITY)) ((int*)hdr)[0] = bad_id;
+    }
     const long total = (long)N * K8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int n = (int)(i / K8), k8 = (int)(i - (long)n * K8);
-        const f32x4 a = *(const f32x4*)(W + (size_t)n * ldw + 8 * k8), b = *(const f32x4*)(W + (size_t)n * ldw + 8 * k8 + 4);
+        const f32x4 a = *(const f32x4*)(W + (size_t)n * ldw + 8 * k8) * sc, b = *(const f32x4*)(W + (size_t)n * ldw + 8 * k8 + 4) * sc;
         uint4 h, r;
         split2(a[0], a[1], h.x, r.x); split2(a[2], a[3], h.y, r.y); split2(b[0], b[1], h.z, r.z); split2(b[2], b[3], h.w, r.w);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) oob = oob || !(fabsf(a[c]) < F16_LIMIT) || !(fabsf(b[c]) < F16_LIMIT);
         Ws[2 * i] = h;
         Ws[2 * i + 1] = r;
     }
-    if (oob) *bad = bad_id;
 }
 
-// f32 rows -> hr8 rows (stand-alone conversion: tests, and producers that have no fused epilogue yet)
+// f32 rows -> hr8 rows at the activation exponent (stand-alone conversion: tests, and producers that have no fused epilogue)
 __global__ __launch_bounds__(256) void split_rows_hr8_kernel(const float* __restrict__ X, long ldx, unsigned char* __restrict__ Y, long ldy_bytes,
                                                              long rows, int K8, int* range_flag) {
     bool oob = false;
@@ -84,7 +118,7 @@ __global__ __launch_bounds__(256) void split_rows_hr8_kernel(const float* __rest
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long n = i / K8;
         const int k8 = (int)(i - n * K8);
-        const f32x4 a = *(const f32x4*)(X + n * ldx + 8 * k8), b = *(const f32x4*)(X + n * ldx + 8 * k8 + 4);
+        const f32x4 a = *(const f32x4*)(X + n * ldx + 8 * k8) * ACT_SCALE, b = *(const f32x4*)(X + n * ldx + 8 * k8 + 4) * ACT_SCALE;
         uint4 h, r;
         split2(a[0], a[1], h.x, r.x); split2(a[2], a[3], h.y, r.y); split2(b[0], b[1], h.z, r.z); split2(b[2], b[3], h.w, r.w);
 #pragma unroll
@@ -101,22 +135,27 @@ struct PsArgs {
     const int32_t* a_idx; int nseg; int seg_bytes;    // mode 1: source row of (output row, segment), -1 = zeros; bytes of a segment
     const unsigned char* zero_row;
     const unsigned char* Ws; long ldw;                // hr8 weights (N, K), pitch in bytes
-    const int* wbad; int wbad_id;
+    const unsigned* whdr; int wbad_id;                // header of the split weight (bad id, max bits, 2^-Ew, 2^Ew)
     const float* bias; const float* res; long ldr;    // residual pitch in floats
     float* C; long ldc;                               // f32 output (or null), pitch in floats
     unsigned char* Cs; long ldcs;                     // hr8 output (or null), pitch in bytes
     int M, N, K, act, tiles_m, tiles_n;
     int* range_flag;
-    int ablate;       // benchmarking only (BIGC_PS_ABLATE): 1 = no DMA in the K loop
-    unsigned long long* trace;   // benchmarking only (BIGC_PS_TRACE): per wave, cycles spent in the four segments of an iteration
+    int ablate;                  // benchmarking only (BIGC_PS_ABLATE): 1 = no DMA in the K loop
+    unsigned long long* trace;   // benchmarking only (BIGC_PS_TRACE): per wave, cycles spent in the segments of an iteration
 };
 
 // Persistent workgroups: the launch has (at most) one workgroup per CU; workgroup b walks the tiles b, b + G, b + 2 G, ... of an
-// XCD-aware order and treats their K slabs as ONE stream: the DMA engine runs two slabs ahead of the MFMAs across tile
-// boundaries, so a tile's first slabs arrive while the previous tile's last MFMAs and its epilogue run (with 144 KB of LDS there
-// is one workgroup per CU: nothing else would hide a tile's pipeline fill and its output stores).
-template <int AMODE, bool TRACE = false>
+// XCD-aware order and treats their K slabs as ONE stream: the DMA engine runs ahead of the MFMAs across tile boundaries, so a
+// tile's first slabs arrive while the previous tile's last MFMAs and its epilogue run (with 128 - 144 KB of LDS there is one
+// workgroup per CU: nothing else would hide a tile's pipeline fill).
+//   RB = 32-row blocks per wave: 2 -> TM = 128 rows, 3 LDS stages;  4 -> TM = 256 rows, 2 LDS stages.
+template <int AMODE, int RB, bool TRACE = false>
 __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
+    constexpr int TM = 64 * RB;
+    constexpr int A_BYTES = TM * ROWB, STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int NST = RB == 2 ? 3 : 2, D = NST - 1;         // LDS stages; slabs in flight beyond the one being read
+    constexpr int NL = RB;                                    // mode 2: f32x4 loads per thread and slab
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES];
     AS3 unsigned char* lds = (AS3 unsigned char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -124,8 +163,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     const int wf = wave & 3, wr = wave >> 2, hi = lane >> 5, l31 = lane & 31;
     const int nk = p.K / TK;
 
-    // ---- tile order.  Workgroup b runs on XCD b % 8 (observed placement; a speed matter only): the 32 workgroups of an XCD take
-    // 32 consecutive tiles (column tile fastest) per round, so the column tiles of an A row tile run side by side on one L2.
+    // ---- tile order.  Workgroup b runs on XCD b % 8 (observed placement; a speed matter only): the workgroups of an XCD take
+    // consecutive tiles (column tile fastest) per round, so the column tiles of an A row tile run side by side on one L2.
     const int G = gridDim.x, S = G >> 3, b = blockIdx.x;
     const int n_tiles = p.tiles_m * p.tiles_n;
     auto tile_of = [&](int j) { return (j * 8 + (b & 7)) * S + (b >> 3); };     // linear tile index of this workgroup's j-th tile
@@ -135,23 +174,30 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     const int n_flat = my_tiles * nk;
 
     // ---- DMA sources.  One wave instruction moves 8 rows x 128 bytes; lane l lands at LDS position (row l >> 3, chunk l & 7)
-    // of its block and therefore FETCHES the chunk (l & 7) ^ swizzle(row) of that row.  Wave w owns the row blocks w, w + 8, ...
-    // Address = scalar tile base + 32-bit per-lane offset (row clamped to the matrix, chunk swizzled): no VALU per slab.
-    const int sw_src = (((wave & 1) << 2) + (lane >> 4)) & 7;             // ((8 blk + (l >> 3)) >> 1) & 7, same for blk and blk + 8
+    // of its block and therefore FETCHES the chunk (l & 7) ^ swizzle(row) of that row.
+    // Wave w owns the row blocks w, w + 8, ... of both operands.
+    // (Measured and dropped: waves 4..7 as dedicated loaders issuing all pieces, their SIMD partners 0..3 pure MFMA + ds_read:
+    // 16 issues of ~100+ clocks per slab and loader made the loaders the critical path, conv GEMM 373 -> 214 TFLOP/s.)
+    // Address = scalar block base + 32-bit per-lane offset (row clamped to the matrix, chunk swizzled), computed per piece.
+    constexpr bool loader = true;
+    const int sw_src = (((wave & 1) << 2) + (lane >> 4)) & 7;             // ((8 blk + (l >> 3)) >> 1) & 7, same for blk and blk + 8 i
     const int coff = ((lane & 7) ^ sw_src) << 4;
     const int l8 = lane >> 3;
-    // issue-side state (runs two slabs ahead of the compute side)
+    constexpr int NA = RB;                                                // A pieces per wave and slab (row blocks w + 8 i)
+    constexpr int NW = 4;                                                 // W pieces per wave and slab
+    constexpr int NPCL = (AMODE == 2 ? 0 : NA) + NW;                      // DMA pieces per wave and slab
+    // issue-side state (runs ahead of the compute side)
     int ij = 0, ikt = 0;
-    const unsigned char* ia_base = nullptr;                               // A + m0 * lda (modes 0, 2) of the tile being issued
+    const unsigned char* ia_base = nullptr;                               // A + m0 * lda of the tile being issued
     const unsigned char* iw_base = nullptr;                               // Ws + n0 * ldw
-    unsigned voa[2], vow[4];
-    const unsigned char* pa[2];                                           // mode 1: per-lane source rows of the current segment
-    int arow[2];
-    int wof[2];
-    f32x4 ra[2];
+    int a_lim = 0, w_lim = 0;                                             // last valid row of the tile, relative to its first
+    int im0 = 0;
+    int gidx[AMODE == 1 ? NA : 1];                                        // mode 1: source row of this lane's row of piece i (-1 = zeros)
+    int wof[NL];
+    f32x4 ra[NL];
     if (AMODE == 2) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NL; ++i) {
             const int row = 64 * i + (tid >> 3), q = tid & 7;
             wof[i] = row * ROWB + (((2 * (q >> 1)) ^ ((row >> 1) & 7)) << 4) + ((q & 1) << 3);      // head chunk; the residual chunk is ^ 16
         }
@@ -159,80 +205,69 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     auto issue_tile_setup = [&]() {
         const int L = tile_of(ij), tm = L / p.tiles_n, tn = L - tm * p.tiles_n;
         const int m0 = tm * TM, n0 = tn * TN;
+        im0 = m0;
         ia_base = p.A + (size_t)m0 * p.lda;
         iw_base = p.Ws + (size_t)n0 * p.ldw;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) vow[i] = (unsigned)(min((wave + 8 * i) * 8 + l8, p.N - 1 - n0) * (int)p.ldw + coff);
-        if (AMODE == 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) voa[i] = (unsigned)(min((wave + 8 * i) * 8 + l8, p.M - 1 - m0)) * (unsigned)p.lda + coff;
-        }
-        if (AMODE == 1) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) arow[i] = min(m0 + (wave + 8 * i) * 8 + l8, p.M - 1);
-        }
+        a_lim = p.M - 1 - m0;
+        w_lim = p.N - 1 - n0;
     };
-    // (`so` = byte offset of an LDS stage, a wave-uniform runtime value).  A slab's DMAs are issued as single pieces spread
-    // between the MFMA blocks of the stream: the CU's vector-memory path takes 64 bytes per clock, i.e. 16 clocks per piece and
-    // 768 per 48 KB slab -- issued back to back by all eight waves after the barrier, every wave sat ~800 clocks in its six
-    // issues (s_memtime trace) with the matrix pipe idle.
+    // (`so` = byte offset of an LDS stage, a wave-uniform runtime value)
     auto issue_w_piece = [&](int i, int so) {
-        __builtin_amdgcn_global_load_lds((const AS1 void*)(iw_base + (size_t)ikt * ROWB + vow[i]), (AS3 void*)(lds + so + A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+        const int blk = wave + 8 * i;
+        const unsigned vo = (unsigned)(min(blk * 8 + l8, w_lim) * (int)p.ldw + coff);
+        __builtin_amdgcn_global_load_lds((const AS1 void*)(iw_base + (size_t)ikt * ROWB + vo), (AS3 void*)(lds + so + A_BYTES + blk * 1024), 16, 0, 0);
     };
     auto issue_a_piece = [&](int i, int so) {
+        const int blk = wave + 8 * i;
         if (AMODE == 1) {
             const int kb = ikt * ROWB, sg = kb / p.seg_bytes, within = kb - sg * p.seg_bytes;
-            if (within == 0) {
-                // (one table read per K segment and row; the wait in front of its use also waits for the slabs in flight:
-                // once per 2 * dim_enti / 32 slabs)
-                const int idx = p.a_idx[(size_t)arow[i] * p.nseg + sg];
-                pa[i] = (idx >= 0 ? p.A + (size_t)idx * p.lda : p.zero_row) + coff;      // index -1: a row of zeros
+            if (within == 0 && i == 0) {
+                // one batch of table reads per K segment (the wait in front of their use also waits for the slabs in flight: once
+                // per 2 * dim_enti / 32 slabs)
+#pragma unroll
+                for (int q = 0; q < NA; ++q) gidx[q] = p.a_idx[(size_t)min(im0 + (wave + 8 * q) * 8 + l8, p.M - 1) * p.nseg + sg];
             }
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(pa[i] + within), (AS3 void*)(lds + so + (wave + 8 * i) * 1024), 16, 0, 0);
+            const unsigned char* src = (gidx[i] >= 0 ? p.A + (size_t)gidx[i] * p.lda : p.zero_row) + coff + within;    // index -1: a row of zeros
+            __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(lds + so + blk * 1024), 16, 0, 0);
         } else {
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(ia_base + (size_t)ikt * ROWB + voa[i]), (AS3 void*)(lds + so + (wave + 8 * i) * 1024), 16, 0, 0);
+            const unsigned vo = (unsigned)min(blk * 8 + l8, a_lim) * (unsigned)p.lda + coff;
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(ia_base + (size_t)ikt * ROWB + vo), (AS3 void*)(lds + so + blk * 1024), 16, 0, 0);
         }
     };
-    // piece k of the slab being issued: modes 0 / 1: A0 A1 W0 | W1 W2 W3;  mode 2: W0 W1 | W2 W3 (k = 0, 1 | 3, 4)
+    // piece k of the slab being issued: modes 0 / 1: A pieces then W pieces; mode 2: W pieces only
     auto issue_piece = [&](int k, int so) {
-        if (AMODE == 2) {
-            if (k == 0 || k == 1) issue_w_piece(k, so);
-            if (k == 3 || k == 4) issue_w_piece(k - 1, so);
-        } else {
-            if (k < 2) issue_a_piece(k, so); else issue_w_piece(k - 2, so);
+        if (AMODE == 2) issue_w_piece(k, so);
+        else if (k < NA) issue_a_piece(k, so);
+        else issue_w_piece(k - NA, so);
+    };
+    auto issue_slab = [&](int so) {
+        if (loader) {
+#pragma unroll
+            for (int k = 0; k < NPCL; ++k) issue_piece(k, so);
         }
     };
-    auto issue_w = [&](int so) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) issue_w_piece(i, so);
+    auto issue_advance = [&]() {
+        if (++ikt == nk) { ikt = 0; ++ij; }
     };
-    auto issue_a = [&](int so) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) issue_a_piece(i, so);
-    };
-    // mode 2: plain register loads.  They are consumed (split_store) right before the slab's wait-for-everything + barrier, so
-    // whatever vmcnt the compiler puts in front of their first use costs nothing extra.  (Issued by inline asm to hide them from
-    // the compiler's wait bookkeeping they are NOT safe: under register pressure the compiler copies the destination registers
-    // before the data has landed.)
+    // mode 2: plain register loads.  They are consumed (split_store) right before a slab's wait + barrier.  (Issued by inline
+    // asm to hide them from the compiler's wait bookkeeping they are NOT safe: under register pressure the compiler copies the
+    // destination registers before the data has landed.)
     auto load_f32_at = [&](int j, int kt) {
         const int L = tile_of(j), tm = L / p.tiles_n;
         const int m0 = tm * TM;
         const unsigned char* base = p.A + (size_t)m0 * p.lda + (size_t)kt * ROWB;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NL; ++i)
             ra[i] = *(const f32x4*)(base + (size_t)min(64 * i + (tid >> 3), p.M - 1 - m0) * p.lda + 16 * (tid & 7));
-    };
-    auto issue_advance = [&]() {
-        if (++ikt == nk) { ikt = 0; ++ij; }
     };
     float amax = 0.f;            // mode 2: largest |x| split so far; NaN-aware through the final comparison !(amax < limit) of a max3 chain
     float nanacc = 0.f;          //         (v_max3 drops NaNs: a running sum of x * 0 carries NaN / Inf)
     auto split_store = [&](int so) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NL; ++i) {
             unsigned h0, h1, r0, r1;
-            split2(ra[i][0], ra[i][1], h0, r0);
-            split2(ra[i][2], ra[i][3], h1, r1);
+            split2(ra[i][0] * ACT_SCALE, ra[i][1] * ACT_SCALE, h0, r0);
+            split2(ra[i][2] * ACT_SCALE, ra[i][3] * ACT_SCALE, h1, r1);
             // asm volatile: stays HERE, ahead of the loads that refill ra (the compiler would otherwise sink these uses below
             // them and keep two register sets alive, with a copy and a full vmcnt(0) on the loop's back edge)
             asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(ra[i][0]), "v"(ra[i][1]));
@@ -244,14 +279,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     };
     bool oob = false;
 
-    f32x16 acc0[2][2], acc1[2][2];
+    f32x16 acc[2][RB];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-            for (int ri = 0; ri < 2; ++ri)
+            for (int ri = 0; ri < RB; ++ri)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc0[fi][ri][r] = 0.f; acc1[fi][ri][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) acc[fi][ri][r] = 0.f;
     };
     zero_acc();
 
@@ -262,28 +297,38 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) cs[s][pl] = ((2 * (2 * s + hi) + pl) ^ sw_rd) << 4;
-    const int rbw = A_BYTES + (wf * 64 + l31) * ROWB, rba = (wr * 64 + l31) * ROWB;
+    const int rbw = A_BYTES + (wf * 64 + l31) * ROWB, rba = (wr * 32 * RB + l31) * ROWB;
 
-    struct Frag { f16x8 wh[2], wl[2], ah[2], al[2]; };
-    auto rd = [&](int so, int s, Frag& f) {
-        const AS3 unsigned char* base = lds + so;
+    // Fragments are read and consumed in UNITS of 12 MFMAs: (k16 step s, row-block pair u) = the wave's 2 feature blocks x 2 of
+    // its RB row blocks.  W fragments (2 blocks x head / residual) live per step, A fragments (2 blocks x head / residual) per
+    // unit, each double-buffered: 64 registers whatever RB is.
+    constexpr int U = RB / 2, NU = 2 * U;                      // units per k16 step / per slab
+    struct WFrag { f16x8 h[2], l[2]; };
+    struct AFrag { f16x8 h[2], l[2]; };
+    WFrag WF[2];
+    AFrag AF[2];
+    auto rd_w = [&](int so, int s, WFrag& f) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            f.wh[i] = *(const AS3 f16x8*)(base + rbw + i * 32 * ROWB + cs[s][0]);
-            f.wl[i] = *(const AS3 f16x8*)(base + rbw + i * 32 * ROWB + cs[s][1]);
-            f.ah[i] = *(const AS3 f16x8*)(base + rba + i * 32 * ROWB + cs[s][0]);
-            f.al[i] = *(const AS3 f16x8*)(base + rba + i * 32 * ROWB + cs[s][1]);
+            f.h[i] = *(const AS3 f16x8*)(lds + so + rbw + i * 32 * ROWB + cs[s][0]);
+            f.l[i] = *(const AS3 f16x8*)(lds + so + rbw + i * 32 * ROWB + cs[s][1]);
         }
     };
-    // the 12 MFMAs of a k16 step, blocks [b0, b1) of the 2 x 2 (feature, row) blocks
-    auto mm = [&](const Frag& f, int b0, int b1) {
+    auto rd_a = [&](int so, int s, int u, AFrag& f) {
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            if (blk < b0 || blk >= b1) continue;
-            const int fi = blk >> 1, ri = blk & 1;
-            acc0[fi][ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh[fi], f.ah[ri], acc0[fi][ri], 0, 0, 0);
-            acc1[fi][ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh[fi], f.al[ri], acc1[fi][ri], 0, 0, 0);
-            acc1[fi][ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wl[fi], f.ah[ri], acc1[fi][ri], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            f.h[i] = *(const AS3 f16x8*)(lds + so + rba + (2 * u + i) * 32 * ROWB + cs[s][0]);
+            f.l[i] = *(const AS3 f16x8*)(lds + so + rba + (2 * u + i) * 32 * ROWB + cs[s][1]);
+        }
+    };
+    // MFMAs [m0, m1) of the 12 of unit u: term-major (head x head over the 4 blocks, then head x residual, residual x head), so
+    // that consecutive MFMAs never accumulate into the same block
+    auto mm = [&](const WFrag& w, const AFrag& a, int u, int m0, int m1) {
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            if (m < m0 || m >= m1) continue;
+            const int t = m >> 2, fi = (m >> 1) & 1, ri = m & 1;
+            acc[fi][2 * u + ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t == 2 ? w.l[fi] : w.h[fi], t == 1 ? a.l[ri] : a.h[ri], acc[fi][2 * u + ri], 0, 0, 0);
         }
     };
 
@@ -291,6 +336,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     // (registers 4 g ..).  Loads are unconditional from clamped addresses and issued in batches (a null bias points at zeros).
     const bool sigm = p.act == BIGC_ACT_SIGMOID;
     const float lo = p.act == BIGC_ACT_RELU ? 0.f : -INFINITY;
+    const float osc = ((const float*)p.whdr)[2] * ACT_INV;                  // 2^-(Ew + Ea)
     auto epilogue = [&](int j) {
         const int L = tile_of(j), tm = L / p.tiles_n, tn = L - tm * p.tiles_n;
         const int m0 = tm * TM, n0 = tn * TN;
@@ -300,8 +346,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) bv[g] = *(const f32x4*)(p.bias + min(n0 + wf * 64 + fi * 32 + 8 * g + 4 * hi, p.N - 4));
 #pragma unroll
-            for (int ri = 0; ri < 2; ++ri) {
-                const int m = m0 + wr * 64 + ri * 32 + l31;
+            for (int ri = 0; ri < RB; ++ri) {
+                const int m = m0 + wr * 32 * RB + ri * 32 + l31;
                 const bool mok = m < p.M;
                 const int mc = min(m, p.M - 1);
                 const int nb = n0 + wf * 64 + fi * 32 + 4 * hi;
@@ -318,7 +364,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                 for (int g = 0; g < 4; ++g) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        float t = (acc0[fi][ri][4 * g + c] + acc1[fi][ri][4 * g + c] * RINV) + bv[g][c];
+                        float t = acc[fi][ri][4 * g + c] * osc + bv[g][c];
                         t = fmaxf(t, lo);
                         if (sigm) t = 1.0f / (1.0f + expf(-t));
                         v[g][c] = t + rv[g][c];
@@ -333,11 +379,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const bool ok = mok && nb + 8 * g < p.N;
+                        const f32x4 x = v[g] * ACT_SCALE;
                         unsigned h0, h1, r0, r1;
-                        split2(v[g][0], v[g][1], h0, r0);
-                        split2(v[g][2], v[g][3], h1, r1);
+                        split2(x[0], x[1], h0, r0);
+                        split2(x[2], x[3], h1, r1);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) oob |= ok && !(fabsf(v[g][c]) < F16_LIMIT);
+                        for (int c = 0; c < 4; ++c) oob |= ok && !(fabsf(x[c]) < F16_LIMIT);
                         // half-wave exchange: lanes hi = 0 end up with [own heads | partner's heads], lanes hi = 1 with
                         // [partner's residuals | own residuals] -- the 16-byte head / residual chunks of feature group n / 8
                         const auto sx = __builtin_amdgcn_permlane32_swap(h0, r0, false, false);
@@ -349,44 +396,38 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         }
     };
 
-    // ---- pipeline.  Flat slab g (tile g / nk, K slab g % nk) lives in LDS stage g % 3; its fragments are read one k16 step
-    // ahead of the MFMAs that use them (two register sets), across slab and tile boundaries: the barrier sits in the MIDDLE of
-    // a slab's MFMA stream.
-    //   iteration g:  read (g, step 1) -> F1 | MFMAs (g, step 0) on F0 | wait slab g + 1, barrier_g | DMA slab g + 3 into the stage
-    //                 of slab g | read (g + 1, step 0) -> F0 | MFMAs (g, step 1) on F1 | [epilogue at a tile's end]
+    // ---- pipeline.  Flat slab g (tile g / nk, K slab g % nk) lives in LDS stage g % NST and is consumed as NU units; the
+    // fragments of a unit are read while the previous unit's MFMAs run, across slab and tile boundaries.  One barrier per slab,
+    // at the start of its LAST unit:
+    //   ... unit NU-2 of slab g | 2 MFMAs of unit NU-1 | wait slab g + 1, barrier_g | reads of unit 0 of slab g + 1 | 10 MFMAs ...
     // barrier_g tells a wave that (i) everybody's DMAs of slab g + 1 have landed and (ii) everybody's reads of slab g have
-    // completed (lgkmcnt(0) in front of it: both k16 steps of slab g are in registers by then), so its stage can be refilled:
-    // two slabs (g + 2, g + 3) are in flight while slab g + 1 is being read.
+    // completed (lgkmcnt(0) in front of it: every unit of slab g is in registers by then), so its stage can be refilled: the DMA
+    // pieces of slab g + NST go out between the MFMAs of the units that follow (three per unit).
     // Mode 2 runs the A operand through registers instead: slab g + 1 is split into its stage before barrier_g (its f32 rows
-    // were loaded after barrier_{g-1}); VMEM order per iteration: 2 register loads (slab g + 2), then 4 W DMAs (slab g + 3).
-    Frag F0, F1;
-    int so = 0, so1 = STAGE_BYTES, so2 = 2 * STAGE_BYTES;                      // stages of slabs g, g + 1, g + 2
+    // were loaded before barrier_{g-1}).
+    int so[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) so[i] = i * STAGE_BYTES;                   // so[0] = stage of slab g, so[1] of g + 1, ...
     issue_tile_setup();
-    int ikt_a = 0, ij_a = 0;                                                   // mode 2: the f32 loads run one slab behind the W DMAs
+    int ikt_a = 0, ij_a = 0;                                                   // mode 2: (tile, slab) of the f32 rows in the registers
     if (AMODE == 2) {
         load_f32_at(0, 0);
-        issue_w(so); issue_advance();
-        split_store(so);
-        if (n_flat > 1) { if (ikt == 0) issue_tile_setup(); issue_w(so1); issue_advance(); }
-        if (n_flat > 2) { if (ikt == 0) issue_tile_setup(); issue_w(so2); issue_advance(); }
+        issue_slab(so[0]); issue_advance();
+        split_store(so[0]);
         if (n_flat > 1) { ikt_a = nk > 1 ? 1 : 0; ij_a = nk > 1 ? 0 : 1; load_f32_at(ij_a, ikt_a); }
-        // W of slab 0 landed (everything issued after it may stay in flight: the wait is not on the critical path of a long stream)
-        if (n_flat > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (n_flat > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (n_flat > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     } else {
-        issue_a(so); issue_w(so); issue_advance();
-        if (n_flat > 1) { if (ikt == 0) issue_tile_setup(); issue_a(so1); issue_w(so1); issue_advance(); }
-        if (n_flat > 2) { if (ikt == 0) issue_tile_setup(); issue_a(so2); issue_w(so2); issue_advance(); }
-        if (n_flat > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (n_flat > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue_slab(so[0]); issue_advance();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    rd(so, 0, F0);
-    // (the fragment reads of the NEXT step are issued after the first block's MFMAs of the current one: the compiler's wait in
-    // front of an MFMA group then only covers reads issued nine MFMAs earlier)
+#pragma unroll
+    for (int d = 1; d <= D; ++d) {
+        if (d < n_flat) { if (ikt == 0) issue_tile_setup(); issue_slab(so[d]); issue_advance(); }
+    }
+    rd_w(so[0], 0, WF[0]);
+    rd_a(so[0], 0, 0, AF[0]);
     int ckt = 0, cj = 0;
     unsigned long long tr[5] = {0, 0, 0, 0, 0}, tp = 0;
     auto stamp = [&](int seg) {
@@ -398,60 +439,72 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         }
     };
     stamp(-1);
-    // Issue schedule of slab g + 3 (into the stage of slab g, free after barrier_g): pieces 0..2 between the MFMA blocks of the
-    // second half of iteration g, pieces 3..5 between those of the first half of iteration g + 1.
-    bool half_open = false;                        // the slab under issue has its first three pieces out
+    // Piece schedule: the slab opened by barrier_g (slab g + NST, into the stage of slab g) gets its first FIRST pieces between
+    // the MFMAs of the unit that holds the barrier (one after every second MFMA), the rest in the unit that follows.
+    constexpr int FIRST = NU == 2 ? 6 : 4;
+    bool opened = false;                           // the slab under issue has its first pieces out
     for (int g = 0; g < n_flat; ++g) {
         const bool more = g + 1 < n_flat;
         stamp(4);
-        mm(F0, 0, 1);
-        rd(so, 1, F1);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 3; k < 6; ++k) {
-            mm(F0, k - 2, k - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (half_open) issue_piece(k, so2);    // slab g + 2: stage freed by barrier_{g-1}
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (half_open) { issue_advance(); half_open = false; }
-        if (more) {
-            if (AMODE == 2) {
-                split_store(so1);                        // slab g + 1 (the compiler waits for its two loads here)
-                __builtin_amdgcn_sched_barrier(0);       // the split's last use of the registers stays ahead of the loads that refill them
-                if (g + 2 < n_flat) {
-                    if (++ikt_a == nk) { ikt_a = 0; ++ij_a; }
-                    load_f32_at(ij_a, ikt_a);            // slab g + 2
-                }
-                // W of slab g + 1 landed: behind it the W DMAs of slab g + 2 (4) and the two loads just issued may stay in flight
-                if (g + 2 < n_flat) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+        for (int n = 0; n < NU; ++n) {
+            const int s = n / U, u = n % U;
+            const bool last = n == NU - 1;
+            if (n == NU / 2 && (p.ablate & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+            if (n == 0 && (p.ablate & 8) && wave >= 4) __builtin_amdgcn_s_setprio(0);
+            mm(WF[s & 1], AF[n & 1], u, 0, 2);
+            bool open_now = false;
+            if (!last) {
+                // fragments of the next unit of this slab
+                if (u == U - 1) rd_w(so[0], s + 1, WF[(s + 1) & 1]);
+                rd_a(so[0], (n + 1) / U, (n + 1) % U, AF[(n + 1) & 1]);
             } else {
-                stamp(0);
-                if (g + 2 < n_flat) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                stamp(1);
-                __builtin_amdgcn_s_barrier();
-                stamp(2);
+                if (more) {
+                    if (AMODE == 2) {
+                        split_store(so[1]);                      // slab g + 1 (the compiler waits for its loads here)
+                        __builtin_amdgcn_sched_barrier(0);       // the split's last use of the registers stays ahead of the loads that refill them
+                        if (g + 2 < n_flat) {
+                            if (++ikt_a == nk) { ikt_a = 0; ++ij_a; }
+                            load_f32_at(ij_a, ikt_a);            // slab g + 2
+                        }
+                        // W of slab g + 1 landed: behind it at most the W pieces of slab g + 2 (D = 2) and the loads just issued
+                        if (g + 2 < n_flat) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((D - 1) * NPCL + NL) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    } else {
+                        stamp(0);
+                        if (D > 1 && g + 2 < n_flat) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((D - 1) * NPCL) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        stamp(1);
+                        __builtin_amdgcn_s_barrier();
+                        stamp(2);
+                    }
+                    open_now = g + NST < n_flat && !(p.ablate & 1);
+                    if (open_now && ikt == 0) issue_tile_setup();
+                    rd_w(so[1], 0, WF[0]);
+                    rd_a(so[1], 0, 0, AF[0]);
+                }
             }
-        }
-        const bool open = more && g + 3 < n_flat && !(p.ablate & 1);
-        if (open && ikt == 0) issue_tile_setup();
-        __builtin_amdgcn_sched_barrier(0);
-        mm(F1, 0, 1);
-        if (more) rd(so1, 0, F0);
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the unit's other ten MFMAs, with up to six DMA pieces between them
+            const int pb = last ? 0 : FIRST + 6 * n, pe = last ? min(FIRST, NPCL) : min(NPCL, FIRST + 6 * (n + 1));
+            const bool issuing = loader && (last ? open_now : opened);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            mm(F1, k + 1, k + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (open) issue_piece(k, so);          // slab g + 3: stage freed by barrier_g
-            __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < 5; ++k) {
+                mm(WF[s & 1], AF[n & 1], u, 2 + 2 * k, 4 + 2 * k);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pb + k < pe && issuing) issue_piece(pb + k, last ? so[0] : so[NST - 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (pb + 5 < pe && issuing) issue_piece(pb + 5, last ? so[0] : so[NST - 1]);
+            if (!last && opened && FIRST + 6 * (n + 1) >= NPCL) { issue_advance(); opened = false; }
+            if (last) opened = open_now;
         }
-        half_open = open;
         stamp(3);
-        const int t = so; so = so1; so1 = so2; so2 = t;
+        const int t = so[0];
+#pragma unroll
+        for (int i = 0; i + 1 < NST; ++i) so[i] = so[i + 1];
+        so[NST - 1] = t;
         if (++ckt == nk) {
             epilogue(cj);
             zero_acc();
@@ -461,12 +514,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     if (TRACE && lane == 0) {
         for (int i = 0; i < 5; ++i) p.trace[((size_t)blockIdx.x * 8 + wave) * 5 + i] = tr[i];
     }
-    if (*p.wbad == p.wbad_id) oob = true;
-    if (AMODE == 2) oob |= !(amax < F16_LIMIT) || !(nanacc == 0.f);
+    if ((int)p.whdr[0] == p.wbad_id) oob = true;
+    if (AMODE == 2) oob |= !(amax * ACT_SCALE < F16_LIMIT) || !(nanacc == 0.f);
     if (__builtin_amdgcn_ballot_w64(oob) != 0 && lane == 0 && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
-// ---- hr8 weight cache: one allocation per (pointer, shape) = [int bad | pad to 256 B | N x K/8 groups of 32 bytes]; re-split when
+// ---- hr8 weight cache: one allocation per (pointer, shape) = [256-byte header | N x K/8 groups of 32 bytes]; re-split when
 // the weights epoch differs (linear_internal.h); epoch 0 = split on every launch into a scratch entry
 struct WKey {
     const float* w; int n, k, ldw;
@@ -488,18 +541,20 @@ int ensure_hr8(hipStream_t s, const float* W, int ldw, int N, int K, WEntry& e, 
             (void)hipFree(e.mem);
         }
         e.cap = fresh ? need + need / 2 : need;
-        if (hipMalloc((void**)&e.mem, e.cap) != hipSuccess || hipMemsetAsync(e.mem, 0, 256, s) != hipSuccess) {
+        if (hipMalloc((void**)&e.mem, e.cap) != hipSuccess) {
             e.mem = nullptr; e.cap = 0;
             return bigc_fail(BIGC_ERR_HIP, "gemm_ps: hipMalloc of the split weights failed");
         }
     }
-    ProfScope ps((void*)s, FAM_LINEAR_AUX, 0.0, 8.0 * N * (double)K);
+    if (hipMemsetAsync(e.mem, 0, 256, s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "gemm_ps: memset failed");
+    ProfScope ps((void*)s, FAM_LINEAR_AUX, 0.0, 12.0 * N * (double)K);
     static std::atomic<int> bad_seq{0};
     e.bad_id = ++bad_seq;
     const long total = (long)N * (K / 8);
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(split_weight_hr8_kernel, dim3(grid), dim3(256), 0, s, W, ldw, (uint4*)(e.mem + 256), N, K / 8, (int*)e.mem, e.bad_id);
+    hipLaunchKernelGGL(weight_absmax_kernel, dim3(grid), dim3(256), 0, s, W, ldw, N, K / 4, (unsigned*)e.mem);
+    hipLaunchKernelGGL(split_weight_hr8_kernel, dim3(grid), dim3(256), 0, s, W, ldw, (uint4*)(e.mem + 256), N, K / 8, (unsigned*)e.mem, e.bad_id);
     BIGC_LAUNCH_CHECK("split_weight_hr8");
     return BIGC_OK;
 }
@@ -514,17 +569,29 @@ bool bigc_gemm_ps_supported(const PsGemm& g) {
     if (g.C && (((uintptr_t)g.C & 15) || g.ldc % 4 != 0)) return false;
     if (g.Cs && (((uintptr_t)g.Cs & 15) || g.ldcs % 16 != 0)) return false;
     if (g.a_idx && (g.a_fmt != PS_HR8 || g.nseg > 4 || g.nseg < 1 || (g.K / g.nseg) % TK != 0)) return false;
+    if ((double)g.lda * 256.0 >= 4294967296.0 || (double)g.K * 4.0 * 256.0 >= 4294967296.0) return false;     // 32-bit in-tile offsets
     return g.C || g.Cs;
 }
 
 int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     if (!bigc_gemm_ps_supported(g)) return bigc_fail(BIGC_ERR_ARG, "gemm_ps: unsupported shape / alignment (M=%d N=%d K=%d)", g.M, g.N, g.K);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "gemm_ps: no device");
+        n_cu = prop.multiProcessorCount >= 8 ? (prop.multiProcessorCount / 8) * 8 : 8;
+    }
     PsArgs p;
     p.A = (const unsigned char*)g.A; p.lda = g.lda; p.a_idx = g.a_idx; p.nseg = g.a_idx ? g.nseg : 1;
     p.seg_bytes = (g.K / p.nseg) * 4;
     p.bias = g.bias; p.res = g.res; p.ldr = g.ldr; p.C = g.C; p.ldc = g.ldc; p.Cs = (unsigned char*)g.Cs; p.ldcs = g.ldcs;
     p.M = g.M; p.N = g.N; p.K = g.K; p.act = g.act;
-    p.tiles_m = cdiv(g.M, TM); p.tiles_n = cdiv(g.N, TN);
+    p.tiles_n = cdiv(g.N, TN);
+    // 256-row tiles when they still give every CU at least three tiles (else the 128-row tiles fill the chip better)
+    static const int force_rb = getenv("BIGC_PS_RB") ? atoi(getenv("BIGC_PS_RB")) : 0;
+    const int rb = force_rb ? force_rb : (cdiv(g.M, 256) * p.tiles_n >= 3 * n_cu ? 4 : 2);
+    p.tiles_m = cdiv(g.M, 64 * rb);
     p.range_flag = g.range_flag;
     static const int ablate = getenv("BIGC_PS_ABLATE") ? atoi(getenv("BIGC_PS_ABLATE")) : 0;
     p.ablate = ablate;
@@ -544,7 +611,7 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
             if (rc != BIGC_OK) return rc;
             e->epoch = epoch;
         }
-        p.Ws = (const unsigned char*)(e->mem + 256); p.ldw = (long)g.K * 4; p.wbad = (const int*)e->mem; p.wbad_id = e->bad_id;
+        p.Ws = (const unsigned char*)(e->mem + 256); p.ldw = (long)g.K * 4; p.whdr = (const unsigned*)e->mem; p.wbad_id = e->bad_id;
         p.zero_row = nullptr;
         {
             const size_t need = (size_t)p.seg_bytes > (size_t)g.N * 4 ? (size_t)p.seg_bytes : (size_t)g.N * 4;
@@ -563,33 +630,33 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     const double flops = 2.0 * g.M * (double)g.N * g.K;
     const double bytes = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * ((g.res ? 1 : 0) + (g.C ? 1 : 0) + (g.Cs ? 1 : 0)));
     ProfScope ps((void*)s, FAM_LINEAR, flops, bytes);
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "gemm_ps: no device");
-        n_cu = prop.multiProcessorCount >= 8 ? (prop.multiProcessorCount / 8) * 8 : 8;
-    }
     // persistent workgroups: one per CU (a multiple of 8 for the XCD-aware tile order), fewer when there are fewer tiles
     const int n_tiles = p.tiles_m * p.tiles_n;
     const int grid = n_tiles >= n_cu ? n_cu : cdiv(n_tiles, 8) * 8;
-    if (g.a_fmt == PS_F32) hipLaunchKernelGGL((gemm_ps_kernel<2>), dim3(grid), dim3(512), 0, s, p);
-    else if (g.a_idx) hipLaunchKernelGGL((gemm_ps_kernel<1>), dim3(grid), dim3(512), 0, s, p);
-    else if (trace) {
+#define PS_LAUNCH(MODE, RBV) hipLaunchKernelGGL((gemm_ps_kernel<MODE, RBV>), dim3(grid), dim3(512), 0, s, p)
+    if (trace && g.a_fmt == PS_HR8 && !g.a_idx) {
         static unsigned long long* buf = nullptr;
         if (!buf && hipMalloc((void**)&buf, 8 * 5 * 8 * 4096) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "gemm_ps: trace buffer");
         p.trace = buf;
-        hipLaunchKernelGGL((gemm_ps_kernel<0, true>), dim3(grid), dim3(512), 0, s, p);
+        if (rb == 4) hipLaunchKernelGGL((gemm_ps_kernel<0, 4, true>), dim3(grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, true>), dim3(grid), dim3(512), 0, s, p);
         std::vector<unsigned long long> h((size_t)grid * 40);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
         double seg[5] = {0, 0, 0, 0, 0};
         for (size_t i = 0; i < h.size(); ++i) seg[i % 5] += (double)h[i];
         const double slabs = (double)p.tiles_m * p.tiles_n * (p.K / TK) * 8;     // wave-slabs
-        fprintf(stderr, "gemm_ps trace M=%d N=%d K=%d (memtime ticks per wave per slab): step-0 MFMAs + reads %.0f | wait vmcnt/lgkm %.0f | barrier %.0f | "
-                "DMA issue %.0f | step-1 MFMAs + reads + loop %.0f\n", p.M, p.N, p.K, seg[0] / slabs, seg[1] / slabs, seg[2] / slabs, seg[3] / slabs, seg[4] / slabs);
+        fprintf(stderr, "gemm_ps trace M=%d N=%d K=%d rb=%d (s_memtime ticks per wave per slab): step-0 MFMAs + reads %.0f | wait vmcnt/lgkm %.0f | "
+                "barrier %.0f | step-1 MFMAs + reads + DMA pieces %.0f | loop end + epilogue %.0f\n", p.M, p.N, p.K, rb, seg[0] / slabs,
+                seg[1] / slabs, seg[2] / slabs, seg[3] / slabs, seg[4] / slabs);
+    } else if (g.a_fmt == PS_F32) {
+        if (rb == 4) PS_LAUNCH(2, 4); else PS_LAUNCH(2, 2);
+    } else if (g.a_idx) {
+        if (rb == 4) PS_LAUNCH(1, 4); else PS_LAUNCH(1, 2);
+    } else {
+        if (rb == 4) PS_LAUNCH(0, 4); else PS_LAUNCH(0, 2);
     }
-    else hipLaunchKernelGGL((gemm_ps_kernel<0>), dim3(grid), dim3(512), 0, s, p);
+#undef PS_LAUNCH
     BIGC_LAUNCH_CHECK("gemm_ps");
     return BIGC_OK;
 }

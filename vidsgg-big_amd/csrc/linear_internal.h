@@ -31,6 +31,7 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
 // scaled residuals; same footprint and row pitch as f32).  A is hr8 (optionally row-gathered) or f32 (split in the loop), W is
 // an f32 weight whose hr8 form is cached per weights epoch; outputs: f32 C and / or hr8 Cs (for the next GEMM).
 enum { PS_F32 = 0, PS_HR8 = 1 };
+#define PS_ACT_EXP 3      /* scale exponent of activations in the hr8 format (gemm_ps.hip): stored value = x * 2^3 */
 struct PsGemm {
     const void* A = nullptr; long lda = 0; int a_fmt = PS_F32;      // pitch in BYTES
     const int32_t* a_idx = nullptr; int nseg = 1;                    // hr8 only: source row per (output row, K segment), -1 = zeros

@@ -1,8 +1,8 @@
 // Split-operand "linear" kernel: the same C = act(A' W^T + bias) + residual as linear.hip, with f32 accuracy, on the
 // f16 matrix cores (v_mfma_f32_32x32x16_f16, 16x the rate of the f32 MFMA).
 //
-// Every f32 operand x is split exactly into two f16 numbers, x = h + r * 2^-11 with h = f16(x) (the 11 leading bits) and
-// r = f16((x - float(h)) * 2^11) (the next 11 bits; x - float(h) is exact in f32).  Then
+// Every f32 operand x is split into two f16 numbers, x = h + r * 2^-11 with h = f16(x) (11 bits, round to nearest) and
+// r = f16((x - float(h)) * 2^11) (the next 11 bits, signed; x - float(h) is exact in f32): |x - h - r 2^-11| <= 2^-24 |x|.  Then
 //     a * w = h_a h_w + 2^-11 (h_a r_w + r_a h_w) + 2^-22 r_a r_w
 // and the last term (<= 2^-22 relative, f32 round-off level) is dropped: three f16 MFMAs per product, accumulated in
 // f32 in TWO accumulators (leading term / correction terms, combined as acc0 + 2^-11 acc1 in the epilogue, so the small
@@ -41,16 +41,16 @@ constexpr float F16_LIMIT = 32768.0f;      // operands at or beyond this magnitu
 union Pack4 { fp16x2 h[2]; uint2 u; };
 
 // four consecutive f32 -> 4 heads + 4 scaled residuals (8 bytes each).  `chk` accumulates the residuals (NaN when an
-// element is NaN/Inf), `amax` the largest magnitude (the round-toward-zero conversion saturates at 65504 instead of
-// overflowing, so the range is checked on the input)
+// element is NaN/Inf), `amax` the largest magnitude (the range is checked on the input).  Both halves are rounded to nearest
+// (common.h: bigc_pk_rtn), so the residual is signed.
 __device__ __forceinline__ void split4(const f32x4 x, uint2& head, uint2& resid, float& chk, float& amax) {
     Pack4 h, r;
-    h.h[0] = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
-    h.h[1] = __builtin_amdgcn_cvt_pkrtz(x[2], x[3]);
+    h.h[0] = bigc_pk_rtn(x[0], x[1]);
+    h.h[1] = bigc_pk_rtn(x[2], x[3]);
     const float r0 = (x[0] - (float)h.h[0][0]) * RSCALE, r1 = (x[1] - (float)h.h[0][1]) * RSCALE;
     const float r2 = (x[2] - (float)h.h[1][0]) * RSCALE, r3 = (x[3] - (float)h.h[1][1]) * RSCALE;
-    r.h[0] = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-    r.h[1] = __builtin_amdgcn_cvt_pkrtz(r2, r3);
+    r.h[0] = bigc_pk_rtn(r0, r1);
+    r.h[1] = bigc_pk_rtn(r2, r3);
     chk += (r0 + r1) + (r2 + r3);
     asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(amax) : "v"(amax), "v"(x[0]), "v"(x[1]));
     asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(amax) : "v"(amax), "v"(x[2]), "v"(x[3]));

@@ -118,13 +118,13 @@ class BigcBase(nn.Module):
         self.topk = topk
         if isinstance(proposal_list, PackedBatch):
             return self.unpack_results(proposal_list.n_vid, list(range(proposal_list.n_vid)),
-                                       self.forward_packed(proposal_list, topk))
+                                       self.forward_checked(proposal_list, topk))
         keep = [i for i, p in enumerate(proposal_list) if p.num_proposals > 0]
         if not keep:
             return [None for _ in proposal_list]
         device = self.pred_query_init.device
         packed = PackedBatch([proposal_list[i] for i in keep], device)
-        return self.unpack_results(len(proposal_list), keep, self.forward_packed(packed, topk))
+        return self.unpack_results(len(proposal_list), keep, self.forward_checked(packed, topk))
 
     def _forward_train(self, proposal_list, gt_graph_list):
         """Training contract of the reference (models/model_0v10.py:510-556): returns
@@ -153,9 +153,36 @@ class BigcBase(nn.Module):
             return self.engine().forward(packed, topk, True, keep_intermediates)
 
     @staticmethod
+    def counts(out):
+        """The one D2H copy (and host sync) of an eval step: triplet row counts per video.  The same copy carries the range
+        flag of the split-operand GEMM path (csrc/gemm_ps.hip): an operand that its f16 pair format cannot hold (|x| >= 4096,
+        NaN, Inf) invalidates the step -> ``OverflowError``; ``forward`` then repeats the step on the exact f32 kernels."""
+        if "_host_counts" not in out:
+            both = out["_counts"].cpu()
+            out["_host_counts"] = both
+            if int(both[-1]) != 0:
+                raise OverflowError("an operand left the range of the split-operand GEMM: repeat the step with bigc_linear_set_exact(1)")
+        return out["_host_counts"][:-1]
+
+    def forward_checked(self, packed, topk):
+        """forward_packed + the count copy; a step whose range flag is raised is repeated on the exact f32 GEMM kernels"""
+        out = self.forward_packed(packed, topk)
+        try:
+            self.counts(out)
+        except OverflowError:
+            lib = self.engine().lib
+            prev = lib.bigc_linear_set_exact(1)
+            try:
+                out = self.forward_packed(packed, topk)
+                self.counts(out)
+            finally:
+                lib.bigc_linear_set_exact(prev)
+        return out
+
+    @staticmethod
     def unpack_results(n_total, keep, out):
         """Padded device outputs -> the reference's per-video list (one D2H copy of the counts)."""
-        n_out = out["n_out"].cpu().tolist()
+        n_out = (out["_host_counts"][:-1] if "_host_counts" in out else BigcBase.counts(out)).tolist()
         quint, dura, qid = out["quint"].long(), out["dura"].long(), out["qid"].long()
         res = [None] * n_total
         for j, i in enumerate(keep):

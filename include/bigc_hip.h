@@ -292,6 +292,11 @@ int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, con
 int bigc_viou_matrix(void* stream, const float* boxes, const int32_t* trk_row_off, const int32_t* trk_dura, const int32_t* e_off,
                      const float* gt_boxes, const int32_t* gt_row_off, const int32_t* gt_dura, const int32_t* gt_traj_off,
                      int n_vid, int max_trk, int g_max, float* out);
+/* vIoU of n_pairs listed pairs (a, b) of trajectory slices: slice i of side A = boxes_a rows [seg_a[3i], seg_a[3i] + seg_a[3i+2]) covering
+ *   the frames [seg_a[3i+1], seg_a[3i+1] + seg_a[3i+2]); same for side B.  The evaluator's `viou` (VidVRDhelperEvalAPIs/common.py:65-106),
+ *   f32 accumulation.  out (n_pairs). */
+int bigc_viou_pairs(void* stream, const float* boxes_a, const int32_t* seg_a, const float* boxes_b, const int32_t* seg_b,
+                    const int32_t* pairs, int n_pairs, float* out);
 /* Hungarian cost (models/model_0v10.py:617-636): cost[v,q,g] (B, nq, g_max) = cost_cls * CE + cost_adj * mean BCE;
  *   g_off (B+1) prefix of GT predicates per video, gt_pred (sum G), gt_adj per video (2, G_v, N_v) at float offset adj_off[v]. */
 int bigc_match_cost(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,

@@ -236,14 +236,22 @@ def duration_overlap(d1, d2):
     return torch.stack([s, e], -1), s <= e
 
 
-def construct_triplet(proposal, pred_logits, att, topk):
+def topk_lowest_index(probs, topk):
+    """top-k with the HIP path's documented tie rule: among exactly equal probabilities the lowest class id comes first
+    (``torch.topk`` leaves that order unspecified; tests/golden/bigc_ties.npz records what it does)."""
+    order = np.stack([np.lexsort((np.arange(row.shape[0]), -row)) for row in probs.numpy()])[:, :topk]
+    top_c = torch.from_numpy(order.astype(np.int64))
+    return torch.gather(probs, 1, top_c), top_c
+
+
+def construct_triplet(proposal, pred_logits, att, topk, topk_fn=None):
     """models/model_0v10.py:707-785. Returns None or (quintuples i64 (U,5), scores f32 (U,3),
     dura_inters i64 (U,2), query_ids i64 (U,)); rows in the lexicographic order of
     ``torch.unique(dim=0)``, group representative = first candidate with the largest
-    predicate probability."""
+    predicate probability.  ``topk_fn`` replaces ``torch.topk`` (tests of the tie rule)."""
     nq = pred_logits.shape[0]
     probs = torch.softmax(pred_logits, dim=-1)
-    top_p, top_c = torch.topk(probs, topk, dim=-1)
+    top_p, top_c = torch.topk(probs, topk, dim=-1) if topk_fn is None else topk_fn(probs, topk)
     cand_score = top_p.reshape(-1)
     cand_cat = top_c.reshape(-1)
     cand_query = torch.arange(nq).repeat_interleave(topk)

@@ -370,3 +370,73 @@ def make_basec_case(name):
             kw.update(len_range=v["len_range"], start_range=v["start_range"])
         props.append(synthetic_proposal(v["seed"], **kw))
     return cfg, sd, props, case["topk"]
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# f1: result conversion (utils/evaluate.py:72-151).  Seeded model outputs in the 4-tuple format of BIG_C.forward.
+# --------------------------------------------------------------------------------------------------------------------
+def make_evalfmt_cases():
+    """-> {name: (dataset_type, use_pku, proposal, result)} with result = None or (quintuples i64 (n,5), scores f32 (n,3),
+    dura_inters i64 (n,2)): subject / object pairs with overlapping durations, spans that are sub-intervals of the overlap (as after
+    grounding), background predicates (skipped by the converter), both VidVRD category numberings, a VidOR video name."""
+    import numpy as np
+    import torch
+    out = {}
+    for name, dataset, use_pku, seed, n_trajs, n_rel, n_ecat, n_pcat, vname in (
+            ("vidvrd", "vidvrd", False, 9901, 9, 40, 36, 133, "ILSVRC2015_train_00005015"),
+            ("vidvrd_pku", "vidvrd", True, 9902, 7, 25, 36, 133, "ILSVRC2015_train_00010001"),
+            ("vidor", "vidor", False, 9903, 12, 30, 81, 51, "0001_3598080384")):
+        rs = np.random.RandomState(seed)
+        p = synthetic_proposal(seed, n_trajs=n_trajs, feat_width=4, num_enti_cats=n_ecat, len_range=(10, 40), start_range=(0, 12), name=vname)
+        du = p.traj_durations.numpy()
+        rows, spans = [], []
+        while len(rows) < n_rel:
+            s, o = rs.randint(0, n_trajs, 2)
+            lo, hi = max(du[s, 0], du[o, 0]), min(du[s, 1], du[o, 1])
+            if s == o or lo > hi:
+                continue
+            a = rs.randint(lo, hi + 1)
+            b = rs.randint(a, hi + 1)
+            pred = 0 if rs.rand() < 0.15 else rs.randint(1, n_pcat)
+            rows.append([pred, int(p.cat_ids[s]), int(p.cat_ids[o]), s, o])
+            spans.append([a, b] if rs.rand() < 0.5 else [lo, hi])
+        scores = torch.from_numpy(rs.uniform(0, 1, size=(n_rel, 3)).astype(np.float32))
+        out[name] = (dataset, use_pku, p, (torch.tensor(rows, dtype=torch.long), scores, torch.tensor(spans, dtype=torch.long)))
+    out["vidvrd_none"] = ("vidvrd", False, synthetic_proposal(9904, n_trajs=3, feat_width=4, num_enti_cats=36, name="ILSVRC2015_train_00000001"), None)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# G5: exact probability ties inside construct_triplet (models/model_0v10.py:712-713).  torch.topk's choice among EXACTLY equal
+# probabilities is an artefact of its partial sort; the fixture records what the reference does so that the build's documented
+# rule (lowest class id) is pinned against it.
+# --------------------------------------------------------------------------------------------------------------------
+def make_ties_case():
+    """-> (proposal, logits (nq, P) f32, att (2, nq, N) f32, topk, boundary_ties {query: tied class ids})
+    queries 0-3: ties INSIDE the top-k (the same k classes whichever order); queries 4-7: a tie that straddles position k (several
+    classes compete for the last slots); the remaining queries have distinct values."""
+    import numpy as np
+    import torch
+    rs = np.random.RandomState(77)
+    nq, P, topk, N = 12, 9, 3, 6
+    p = synthetic_proposal(411, n_trajs=N, feat_width=8, num_enti_cats=7, len_range=(20, 30), start_range=(0, 5))
+    logits = np.stack([rs.permutation(P) for _ in range(nq)]).astype(np.float32) * 0.5 - 2.0
+    logits[0, [2, 5, 7]] = 4.0                     # three-way tie filling the top 3
+    logits[1, [1, 8]] = 3.5; logits[1, 4] = 5.0    # tie for ranks 2-3
+    logits[2, [0, 3]] = 6.0; logits[2, 6] = 2.5    # tie for ranks 1-2 (class 0 = background among them)
+    logits[3, [6, 7, 8]] = 3.0
+    boundary = {}
+    logits[4, :] = -3.0; logits[4, 1] = 5.0; logits[4, 2] = 4.0; logits[4, [3, 5, 8]] = 3.0      # 3 classes tie for the third slot
+    boundary[4] = [3, 5, 8]
+    logits[5, :] = -1.0; logits[5, 7] = 2.0; logits[5, [0, 4, 6, 2]] = 1.0                       # 4 classes tie for slots 2 and 3
+    boundary[5] = [0, 2, 4, 6]
+    logits[6, :] = 0.25                                                                          # everything ties
+    boundary[6] = list(range(P))
+    logits[7, :] = -2.0; logits[7, [1, 2]] = 3.0; logits[7, [5, 6]] = 1.5                        # 2 classes tie for the last slot
+    boundary[7] = [5, 6]
+    att = torch.zeros(2, nq, N)
+    so = rs.randint(0, N, size=(2, nq))
+    so[1] = (so[0] + 1 + rs.randint(0, N - 1, size=nq)) % N            # subject != object
+    for r in range(2):
+        att[r, np.arange(nq), so[r]] = 1.0
+    return p, torch.from_numpy(logits), att, topk, boundary

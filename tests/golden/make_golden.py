@@ -349,14 +349,84 @@ def run_basec_train_case(name):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "loss", out["total"])
 
 
+def run_category_tables():
+    """The dataset vocabularies the result converter needs (utils/categories_v2.py via utils/evaluate.py:9): id -> name lists of
+    VidVRD (standard and the PKU proposals' numbering), VidVRD predicates, VidOR objects and predicates.  Data, written as JSON
+    next to the converter (vidsgg-big_amd/bigc_hip/data/categories.json)."""
+    import contextlib
+    import io
+    import json
+    sys.path.insert(0, REFERENCE)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from utils import categories_v2 as C
+    sys.path.remove(REFERENCE)
+    out = {}
+    for k in ("vidvrd_CatId2name", "vidvrd_PredId2name", "vidor_CatId2name", "vidor_PredId2name", "PKU_vidvrd_CatId2name"):
+        d = getattr(C, k)
+        assert sorted(d) == list(range(len(d)))
+        out[k] = [d[i] for i in range(len(d))]
+    path = os.path.join(os.path.dirname(os.path.dirname(cases.GOLDEN_DIR)), "vidsgg-big_amd", "bigc_hip", "data", "categories.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote", path, {k: len(v) for k, v in out.items()})
+
+
+def run_evalfmt_golden():
+    """EvalFmtCvtor.to_eval_format_pr (utils/evaluate.py:72-151, traj_cutoff utils/utils_func.py:523-536) of the real reference on
+    the seeded cases of cases.make_evalfmt_case: VidVRD with the standard and the PKU category numbering, VidOR (video name
+    reset), a None result, background predicates; plus the grounded variant (score x bin probability, spans x video_len, rounded:
+    tools/eval_vidor.py:236-262 restated by the caller).  The relation dicts are stored as JSON."""
+    import contextlib
+    import io
+    import json
+    sys.path.insert(0, REFERENCE)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from utils.evaluate import EvalFmtCvtor
+    sys.path.remove(REFERENCE)
+    out = {}
+    for name, (dataset, use_pku, proposal, result) in cases.make_evalfmt_cases().items():
+        cvt = EvalFmtCvtor(dataset)
+        if result is not None:
+            quint, scores, dura = result
+            result = (quint, scores.mean(dim=-1) if scores.dim() == 2 else scores, dura)
+        out[name] = cvt.to_eval_format_pr(proposal, result, use_pku=use_pku)
+    path = os.path.join(cases.GOLDEN_DIR, "evalfmt.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), {k: [len(v) for v in d.values()] for k, d in out.items()})
+
+
+def run_ties_golden(m10):
+    """the reference's construct_triplet (models/model_0v10.py:707-785) on logits with EXACT probability ties (cases.make_ties_case)"""
+    import types as _t
+    p, logits, att, topk, _ = cases.make_ties_case()
+    fake = _t.SimpleNamespace(topk=topk, num_anchors=logits.shape[0])
+    res = m10.BIG_C.construct_triplet(fake, p, logits, att)
+    out = {"torch_version": np.array(torch.__version__), "quintuples": res[0].numpy(), "scores": res[1].numpy(), "dura_inters": res[2].numpy(),
+           "query_ids": res[3].numpy(), "topk_classes": torch.topk(torch.softmax(logits, -1), topk, -1)[1].numpy()}
+    path = os.path.join(cases.GOLDEN_DIR, "bigc_ties.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, out["quintuples"].shape, out["topk_classes"][4:8].tolist())
+
+
 def main():
     torch.manual_seed(0)
     m10, m07, grd = import_reference()
-    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + list(cases.GRD_TRAIN_CASES) + ["evaluator"] +
+    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + list(cases.GRD_TRAIN_CASES) + ["evaluator", "categories", "evalfmt", "ties"] +
                              list(cases.INGEST_CASES) + list(cases.BASEC_CASES) + list(cases.BASEC_TRAIN_CASES))
     for n in names:
         if n == "evaluator":
             run_evaluator_golden()
+            continue
+        if n == "ties":
+            run_ties_golden(m10)
+            continue
+        if n == "categories":
+            run_category_tables()
+            continue
+        if n == "evalfmt":
+            run_evalfmt_golden()
             continue
         if n in cases.INGEST_CASES:
             run_ingest_case(n)

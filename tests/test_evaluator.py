@@ -80,3 +80,47 @@ def test_recall_at_50_parity_hip_vs_oracle():
     assert r_h[50] == r_o[50] and r_h[100] == r_o[100]
     assert abs(m_h - m_o) < 1e-6 and p_h == p_o
     assert sum(len(v) for v in hip.values()) == sum(len(v) for v in ora.values()) > 0
+
+
+def test_result_conversion_matches_reference_converter():
+    """to_eval_format against the stored output of the reference's EvalFmtCvtor.to_eval_format_pr (tests/golden/evalfmt.json, made
+    by make_golden.py): every relation dict -- dataset vocabulary (standard / PKU VidVRD numbering, VidOR), VidOR video-name
+    reset, [start, end) durations, trajectories cut to the duration, mean score, background predicates dropped, None result."""
+    import json
+    want = json.load(open(os.path.join(cases.GOLDEN_DIR, "evalfmt.json")))
+    for name, (dataset, use_pku, proposal, result) in cases.make_evalfmt_cases().items():
+        got = E.to_eval_format(proposal, result, dataset_type=dataset, use_pku=use_pku)
+        assert list(got) == list(want[name]), name
+        for vid in got:
+            g, w = got[vid], want[name][vid]
+            assert len(g) == len(w), name
+            for a, b in zip(g, w):
+                assert a["triplet"] == b["triplet"] and list(a["duration"]) == list(b["duration"]), (name, a["triplet"], b["triplet"])
+                assert abs(a["score"] - b["score"]) < 1e-7
+                assert a["sub_traj"] == b["sub_traj"] and a["obj_traj"] == b["obj_traj"]
+    nv, npred = E.name_tables("vidvrd", True)
+    assert len(nv) == 36 and len(npred) == 133 and nv != E.name_tables("vidvrd", False)[0] and sorted(nv) == sorted(E.name_tables("vidvrd", False)[0])
+    assert len(E.name_tables("vidor")[0]) == 81 and len(E.name_tables("vidor")[1]) == 51
+
+
+@pytest.mark.gpu
+def test_device_viou_table_matches_reference_viou():
+    """the batched HIP vIoU kernel (bigc_viou_pairs) against the evaluator's per-pair host computation (common.py:65-106) on the
+    evaluator fixtures, and the metrics computed through it against the reference evaluator's numbers"""
+    g = np.load(os.path.join(cases.GOLDEN_DIR, "evaluator.npz"))
+    n = 0
+    for seed in cases.EVAL_SEEDS:
+        gt, pr = cases.make_eval_case(seed)
+        tables = E.viou_tables_device(gt, pr, "cuda:0")
+        for vid, tab in tables.items():
+            for (i, k), v in tab.items():
+                p, q = pr[vid][i], gt[vid][k]
+                assert tuple(p["triplet"]) == tuple(q["triplet"])
+                ref = min(E.viou(p["sub_traj"], p["duration"], q["sub_traj"], q["duration"]),
+                          E.viou(p["obj_traj"], p["duration"], q["obj_traj"], q["duration"]))
+                assert abs(v - ref) < 2e-6, (vid, i, k, v, ref)
+                n += 1
+        mean_ap, rec, prec = E.evaluate(gt, pr, device="cuda:0")
+        got = np.array([mean_ap, rec[50], rec[100], prec[1], prec[5], prec[10]])
+        assert np.allclose(got, g["s%d" % seed], rtol=0, atol=1e-7), (seed, got, g["s%d" % seed])
+    assert n > 20

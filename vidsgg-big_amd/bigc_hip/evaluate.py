@@ -11,14 +11,48 @@ import numpy as np
 import torch
 
 
-def to_eval_format(proposal, result, score_mode="mean", enti_names=None, pred_names=None):
-    """One video's model output -> ``{video_name: [relation dict, ...]}``.
+_TABLES = None
+
+
+def name_tables(dataset_type, use_pku=False):
+    """(entity id -> name, predicate id -> name) of a dataset, as ``EvalFmtCvtor`` picks them (utils/evaluate.py:13-23,79-82):
+    VidVRD proposals of Liu et al. ("PKU") use another category numbering than the standard one.  The vocabularies are data
+    (``data/categories.json``, written by tests/golden/make_golden.py from utils/categories_v2.py)."""
+    global _TABLES
+    if _TABLES is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "categories.json")) as f:
+            _TABLES = json.load(f)
+    d = dataset_type.lower()
+    assert d in ("vidvrd", "vidor"), dataset_type
+    if d == "vidvrd":
+        return _TABLES["PKU_vidvrd_CatId2name" if use_pku else "vidvrd_CatId2name"], _TABLES["vidvrd_PredId2name"]
+    return _TABLES["vidor_CatId2name"], _TABLES["vidor_PredId2name"]
+
+
+def reset_video_name(video_name, dataset_type):
+    """VidOR names are "<group>_<video id>": the evaluator's ground truth is keyed by the id (utils/evaluate.py:26-38)."""
+    if dataset_type is not None and dataset_type.lower() == "vidor":
+        parts = video_name.split("_")
+        assert len(parts) == 2, video_name
+        return parts[1]
+    return video_name
+
+
+def to_eval_format(proposal, result, score_mode="mean", enti_names=None, pred_names=None, dataset_type=None, use_pku=False):
+    """One video's model output -> ``{video_name: [relation dict, ...]}`` (``EvalFmtCvtor.to_eval_format_pr``,
+    utils/evaluate.py:72-151, with ``traj_cutoff`` utils/utils_func.py:523-536; pinned by tests/golden/evalfmt.json).
 
     ``result`` is ``None`` or the 4-tuple ``BIG_C.forward`` returns (or the 3-tuple ``(quintuples, scores (n,),
     dura_inters)`` the reference's tools pass on).  A relation dict has ``triplet`` (3 names), ``duration``
     ``[start, end)``, ``score``, ``sub_traj`` / ``obj_traj`` (boxes of the subject / object inside the duration).
-    Predicate 0 (background) is skipped (utils/evaluate.py:113-114)."""
-    name = proposal.video_name
+    Predicate 0 (background) is skipped (:113-114).  ``dataset_type`` ("vidvrd" | "vidor", with ``use_pku`` for the PKU
+    proposals' category numbering) selects the dataset's vocabularies; without it (synthetic data) explicit name lists or
+    placeholder names are used."""
+    if dataset_type is not None:
+        enti_names, pred_names = name_tables(dataset_type, use_pku)
+    name = reset_video_name(proposal.video_name, dataset_type)
     if result is None:
         return {name: []}
     quint, scores, dura = result[0], result[1], result[2]
@@ -38,6 +72,7 @@ def to_eval_format(proposal, result, score_mode="mean", enti_names=None, pred_na
         if p == 0:
             continue
         d0, d1 = ds, de + 1                                              # closed -> [start, end)
+        assert spans[st][0] <= d0 and d1 <= spans[st][1] + 1 and spans[ot][0] <= d0 and d1 <= spans[ot][1] + 1
         subj = boxes[st][d0 - spans[st][0]: len(boxes[st]) - (spans[st][1] + 1 - d1)]
         obj = boxes[ot][d0 - spans[ot][0]: len(boxes[ot]) - (spans[ot][1] + 1 - d1)]
         assert len(subj) == len(obj) == d1 - d0
@@ -46,10 +81,12 @@ def to_eval_format(proposal, result, score_mode="mean", enti_names=None, pred_na
     return {name: out}
 
 
-def gt_to_eval_format(gt_graph, enti_names=None, pred_names=None):
+def gt_to_eval_format(gt_graph, enti_names=None, pred_names=None, dataset_type=None):
     """GT relations of one video in the evaluator's format (the reference reads them from prepared JSON files,
     VidVRDhelperEvalAPIs/visual_relation_detection.py:250-265): one relation per GT predicate, trajectories cut
     to the predicate's (closed) duration."""
+    if dataset_type is not None:
+        enti_names, pred_names = name_tables(dataset_type, False)      # ground truth always carries the standard numbering
     en = (lambda i: enti_names[i]) if enti_names is not None else (lambda i: "entity_%d" % i)
     pn = (lambda i: pred_names[i]) if pred_names is not None else (lambda i: "predicate_%d" % i)
     so = gt_graph.adj_matrix.argmax(dim=-1).t().tolist()
@@ -98,25 +135,93 @@ def _prec_rec(tp, n_gt):
     return cum_tp / np.maximum(cum_tp + cum_fp, eps), cum_tp / np.maximum(n_gt, eps)
 
 
-def detection_scores(gt_relations, pred_relations, viou_threshold):
+def viou_tables_device(groundtruth, prediction, device):
+    """vIoU of every (prediction, ground-truth relation) pair with EQUAL triplets of every video, subject and object
+    trajectories, in two launches of the HIP kernel ``bigc_viou_pairs`` (the reference calls a Python frame loop per pair,
+    common.py:65-106 from visual_relation_detection.py:21-27; on VidVRD-test that is the larger part of the evaluation time).
+    -> {video: dict (pred index, gt index) -> min(subject vIoU, object vIoU)} for the videos that have both sides."""
+    from . import _lib
+    lib = _lib.load()
+    boxes = {"p": [], "g": []}
+    segs = {"ps": [], "po": [], "gs": [], "go": []}
+    rows = {"p": 0, "g": 0}
+    pairs, owner = [], []
+
+    def add(side, traj, start):
+        a = np.asarray(traj, dtype=np.float32).reshape(-1, 4)
+        boxes[side].append(a)
+        seg = [rows[side], int(start), a.shape[0]]
+        rows[side] += a.shape[0]
+        return seg
+
+    n_p = n_g = 0
+    for vid, gts in groundtruth.items():
+        preds = prediction.get(vid, [])
+        if not gts or not preds:
+            continue
+        by_trip = {}
+        for k, g in enumerate(gts):
+            by_trip.setdefault(tuple(g["triplet"]), []).append(k)
+        g_base = n_g
+        for g in gts:
+            segs["gs"].append(add("g", g["sub_traj"], g["duration"][0]))
+            segs["go"].append(add("g", g["obj_traj"], g["duration"][0]))
+            n_g += 1
+        for i, p in enumerate(preds):
+            ks = by_trip.get(tuple(p["triplet"]))
+            if not ks:
+                continue
+            segs["ps"].append(add("p", p["sub_traj"], p["duration"][0]))
+            segs["po"].append(add("p", p["obj_traj"], p["duration"][0]))
+            for k in ks:
+                pairs.append((n_p, g_base + k))
+                owner.append((vid, i, k))
+            n_p += 1
+    tables = {}
+    if not pairs:
+        return tables
+    dev = torch.device(device)
+    bp = torch.from_numpy(np.concatenate(boxes["p"])).to(dev)
+    bg = torch.from_numpy(np.concatenate(boxes["g"])).to(dev)
+    pr = torch.tensor(pairs, dtype=torch.int32, device=dev)
+    res = []
+    for a, b in (("ps", "gs"), ("po", "go")):
+        sa = torch.tensor(segs[a], dtype=torch.int32, device=dev)
+        sb = torch.tensor(segs[b], dtype=torch.int32, device=dev)
+        out = torch.empty((len(pairs),), dtype=torch.float32, device=dev)
+        _lib.check(lib.bigc_viou_pairs(_lib.current_stream(), bp.data_ptr(), sa.data_ptr(), bg.data_ptr(), sb.data_ptr(), pr.data_ptr(),
+                                       len(pairs), out.data_ptr()))
+        res.append(out)
+    ov = torch.minimum(res[0], res[1]).cpu().numpy()
+    for (vid, i, k), v in zip(owner, ov):
+        tables.setdefault(vid, {})[(i, k)] = float(v)
+    return tables
+
+
+def detection_scores(gt_relations, pred_relations, viou_threshold, table=None):
     """Greedy matching in descending score order: a prediction hits the not-yet-detected GT relation of the same
-    triplet with the largest min(subject vIoU, object vIoU) >= threshold (visual_relation_detection.py:10-37)."""
-    preds = sorted(pred_relations, key=lambda x: x["score"], reverse=True)
+    triplet with the largest min(subject vIoU, object vIoU) >= threshold (visual_relation_detection.py:10-37).
+    ``table`` (from ``viou_tables_device``): precomputed overlaps keyed by (index into pred_relations, gt index); a value
+    within 1e-5 of the threshold is recomputed on the host in float64, as the reference computes all of them."""
+    order = sorted(range(len(pred_relations)), key=lambda i: pred_relations[i]["score"], reverse=True)
     detected = np.zeros(len(gt_relations), dtype=bool)
-    hit = np.full(len(preds), -np.inf)
+    hit = np.full(len(order), -np.inf)
     gt_trip = [tuple(g["triplet"]) for g in gt_relations]
-    for i, p in enumerate(preds):
+    for rank, i in enumerate(order):
+        p = pred_relations[i]
         best, k_best = -np.inf, -1
         t = tuple(p["triplet"])
         for k, g in enumerate(gt_relations):
             if detected[k] or gt_trip[k] != t:
                 continue
-            ov = min(viou(p["sub_traj"], p["duration"], g["sub_traj"], g["duration"]),
-                     viou(p["obj_traj"], p["duration"], g["obj_traj"], g["duration"]))
+            ov = table.get((i, k)) if table is not None else None
+            if ov is None or abs(ov - viou_threshold) < 1e-5:
+                ov = min(viou(p["sub_traj"], p["duration"], g["sub_traj"], g["duration"]),
+                         viou(p["obj_traj"], p["duration"], g["obj_traj"], g["duration"]))
             if ov >= viou_threshold and ov > best:
                 best, k_best = ov, k
         if k_best >= 0:
-            hit[i] = p["score"]
+            hit[rank] = p["score"]
             detected[k_best] = True
     prec, rec = _prec_rec(np.isfinite(hit), len(gt_relations))
     return prec, rec, hit
@@ -140,8 +245,10 @@ def tagging_scores(gt_relations, pred_relations):
     return prec, rec, scores
 
 
-def evaluate(groundtruth, prediction, viou_threshold=0.5, det_nreturns=(50, 100), tag_nreturns=(1, 5, 10)):
-    """-> (mean_ap, {n: recall@n}, {n: tagging precision@n})   (visual_relation_detection.py:64-120)"""
+def evaluate(groundtruth, prediction, viou_threshold=0.5, det_nreturns=(50, 100), tag_nreturns=(1, 5, 10), device=None):
+    """-> (mean_ap, {n: recall@n}, {n: tagging precision@n})   (visual_relation_detection.py:64-120).
+    With ``device`` (a CUDA device) the vIoU overlaps come from one batched HIP kernel instead of per-pair host loops."""
+    tables = viou_tables_device(groundtruth, prediction, device) if device is not None else {}
     video_ap, tot_scores, tot_tp = {}, {n: [] for n in det_nreturns}, {n: [] for n in det_nreturns}
     prec_at_n = {n: [] for n in tag_nreturns}
     tot_gt = 0
@@ -150,7 +257,7 @@ def evaluate(groundtruth, prediction, viou_threshold=0.5, det_nreturns=(50, 100)
             continue
         tot_gt += len(gt_relations)
         preds = prediction.get(vid, [])
-        prec, rec, scores = detection_scores(gt_relations, preds, viou_threshold)
+        prec, rec, scores = detection_scores(gt_relations, preds, viou_threshold, tables.get(vid) if device is not None else None)
         video_ap[vid] = voc_ap(rec, prec)
         tp = np.isfinite(scores)
         for n in det_nreturns:

@@ -166,6 +166,50 @@ __global__ __launch_bounds__(64) void viou_matrix_kernel(const float* __restrict
 }
 }  // namespace
 
+// vIoU of listed (trajectory slice, trajectory slice) pairs: the evaluator's primitive (VidVRDhelperEvalAPIs/common.py:65-106,
+// called per (prediction, ground-truth relation) with equal triplets from visual_relation_detection.py:10-37, where it is two
+// nested Python loops over frames).  A slice = [first box row, first frame, number of frames]; one wave per pair.
+namespace {
+__global__ __launch_bounds__(64) void viou_pairs_kernel(const float* __restrict__ boxes_a, const int32_t* __restrict__ seg_a,
+                                                        const float* __restrict__ boxes_b, const int32_t* __restrict__ seg_b,
+                                                        const int32_t* __restrict__ pairs, int n_pairs, float* __restrict__ out) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n_pairs) return;
+    const int a = pairs[2 * i], b = pairs[2 * i + 1];
+    const int ra = seg_a[3 * a], fa = seg_a[3 * a + 1], la = seg_a[3 * a + 2];
+    const int rb = seg_b[3 * b], fb = seg_b[3 * b + 1], lb = seg_b[3 * b + 2];
+    const f32x4* pa = (const f32x4*)boxes_a + ra;
+    const f32x4* pb = (const f32x4*)boxes_b + rb;
+    const int s = max(fa, fb), e = min(fa + la, fb + lb);              // [s, e)
+    float res = 0.f;
+    if (s < e) {
+        float va = 0.f, vb = 0.f, inter = 0.f;
+        for (int k = lane; k < la; k += 64) { const f32x4 x = pa[k]; va += (x[2] - x[0] + 1.f) * (x[3] - x[1] + 1.f); }
+        for (int k = lane; k < lb; k += 64) { const f32x4 x = pb[k]; vb += (x[2] - x[0] + 1.f) * (x[3] - x[1] + 1.f); }
+        for (int f = s + lane; f < e; f += 64) {
+            const f32x4 x = pa[f - fa], y = pb[f - fb];
+            const float w = fmaxf(fminf(x[2], y[2]) - fmaxf(x[0], y[0]) + 1.f, 0.f);
+            const float h = fmaxf(fminf(x[3], y[3]) - fmaxf(x[1], y[1]) + 1.f, 0.f);
+            inter += w * h;
+        }
+        va = wave_sum(va); vb = wave_sum(vb); inter = wave_sum(inter);
+        res = inter / (va + vb - inter);
+    }
+    if (lane == 0) out[i] = res;
+}
+}  // namespace
+
+extern "C" int bigc_viou_pairs(void* stream, const float* boxes_a, const int32_t* seg_a, const float* boxes_b, const int32_t* seg_b,
+                               const int32_t* pairs, int n_pairs, float* out) {
+    BIGC_CHECK_ARG(boxes_a && seg_a && boxes_b && seg_b && pairs && out, "viou_pairs: null pointer");
+    BIGC_CHECK_ARG((((uintptr_t)boxes_a | (uintptr_t)boxes_b) & 15) == 0, "viou_pairs: boxes must be 16-byte aligned");
+    if (n_pairs <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_LOSS, 0.0, 0.0);
+    hipLaunchKernelGGL(viou_pairs_kernel, dim3(n_pairs), dim3(64), 0, (hipStream_t)stream, boxes_a, seg_a, boxes_b, seg_b, pairs, n_pairs, out);
+    BIGC_LAUNCH_CHECK("viou_pairs");
+    return BIGC_OK;
+}
+
 namespace {
 // F.binary_cross_entropy_with_logits(x, y, reduction='mean') over a (rows, cols) block and its gradient
 //   l = max(x, 0) - x y + log1p(exp(-|x|)),  dl/dx = sigmoid(x) - y     (Base_C.loss, models/model_pairwise_baseline.py:301-312)

@@ -28,14 +28,14 @@ def _load_data(cfg, synthetic, n_trajs, clip_dim):
     return [(it[1], it[2], it[0]) if len(it) == 3 else (it[0], it[1], None) for it in items]
 
 
-def _report(groundtruth, predictions, output_dir, name, save_json):
+def _report(groundtruth, predictions, output_dir, name, save_json, device=None):
     if save_json:
         with open(os.path.join(output_dir, name), "w") as f:
             json.dump(predictions, f)
     if not groundtruth:
         with open("datasets/GT_json_for_eval/VidORval_gts.json") as f:      # VidVRDhelperEvalAPIs/visual_relation_detection.py:250-256
             groundtruth = json.load(f)
-    mean_ap, rec, prec = E.evaluate(groundtruth, predictions)
+    mean_ap, rec, prec = E.evaluate(groundtruth, predictions, device=device)
     print("detection mean AP (used in challenge): {}".format(mean_ap))
     print("detection recall: {}".format(rec))
     print("tagging precision: {}".format(prec))
@@ -62,15 +62,16 @@ def evaluate_cls_stage(cfg_path, ckpt_path=None, save_tag="", output_dir=None, c
             r = model([p.to(device)], topk=topk)[0]
         cpu = p.to(torch.device("cpu"))
         raw[p.video_name] = None if r is None else [t.cpu() for t in r]
-        predictions.update(E.to_eval_format(cpu, None if r is None else tuple(t.cpu() for t in r)))
-        if g is not None:
-            groundtruth[p.video_name] = E.gt_to_eval_format(g)
+        # VidOR vocabulary, video name reset to the id the ground-truth JSON is keyed by (utils/evaluate.py:26-38)
+        predictions.update(E.to_eval_format(cpu, None if r is None else tuple(t.cpu() for t in r), dataset_type="vidor"))
+        if g is not None and synthetic:          # real data is evaluated against datasets/GT_json_for_eval/VidORval_gts.json (_report)
+            groundtruth[E.reset_video_name(p.video_name, "vidor")] = E.gt_to_eval_format(g, dataset_type="vidor")
     print("inference: %d videos in %.2f s" % (len(data), time.time() - t0))
     path = os.path.join(output_dir, "VidORval_infer_results_{}.pkl".format(save_tag))
     with open(path, "wb") as f:
         pickle.dump(raw, f)
     print("infer_results have been saved at {}".format(path))
-    return _report(groundtruth, predictions, output_dir, "VidORval_predict_relations_{}.json".format(save_tag), save_json)
+    return _report(groundtruth, predictions, output_dir, "VidORval_predict_relations_{}.json".format(save_tag), save_json, device)
 
 
 def evaluate_combined(cfg_path, ckpt_path, cls_stage_result_path, save_tag="", output_dir=None, cuda=0, save_json=False, synthetic=0, n_trajs=32):
@@ -89,8 +90,8 @@ def evaluate_combined(cfg_path, ckpt_path, cls_stage_result_path, save_tag="", o
     predictions, groundtruth, n_skipped = {}, {}, 0
     t0 = time.time()
     for p, g, clip in data:
-        if g is not None:
-            groundtruth[p.video_name] = E.gt_to_eval_format(g)
+        if g is not None and synthetic:
+            groundtruth[E.reset_video_name(p.video_name, "vidor")] = E.gt_to_eval_format(g, dataset_type="vidor")
         res = cls_results.get(p.video_name)
         if res is None:
             continue
@@ -105,9 +106,9 @@ def evaluate_combined(cfg_path, ckpt_path, cls_stage_result_path, save_tag="", o
             continue
         if out[0] is None:
             continue
-        predictions.update(E.to_eval_format(p.to(torch.device("cpu")), combine_with_grounding(res, out, p.video_len)))
+        predictions.update(E.to_eval_format(p.to(torch.device("cpu")), combine_with_grounding(res, out, p.video_len), dataset_type="vidor"))
     print("grounding: %d videos (%d skipped) in %.2f s" % (len(data), n_skipped, time.time() - t0))
-    return _report(groundtruth, predictions, output_dir, "VidORval_predict_relations_aft_grd_{}.json".format(save_tag), save_json)
+    return _report(groundtruth, predictions, output_dir, "VidORval_predict_relations_aft_grd_{}.json".format(save_tag), save_json, device)
 
 
 if __name__ == "__main__":

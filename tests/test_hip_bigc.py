@@ -233,3 +233,23 @@ def test_wrong_feature_width_raises():
     bad = synthetic_proposal(1, n_trajs=3, feat_width=20, num_enti_cats=7, len_range=(5, 9))
     with pytest.raises(AssertionError):
         model([bad], topk=3)
+
+
+def test_invalidate_weights_after_a_write_through_data():
+    """parameters written through ``.data`` do not bump their version counter, which is what the engine watches: the documented
+    remedy ``model.invalidate_weights()`` makes the next forward use the new values (and rebuild the split weight copies)"""
+    cfg, variant, sd, props, topk = cases.make_case("bigc_tiny")
+    model = build_model(cfg, variant, sd)
+    packed = PackedBatch([props[0]], DEV)
+    before = model.forward_packed(packed, topk)["pred_logits"].clone()
+    with torch.no_grad():
+        model.fc_pred2logits.weight.data.mul_(1.5)
+        model.fc_enti2enco[0].weight.data.mul_(0.5)
+    model.invalidate_weights()
+    after = model.forward_packed(packed, topk)["pred_logits"].clone()
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["fc_pred2logits.weight"] *= 1.5
+    sd2["fc_enti2enco.0.weight"] *= 0.5
+    fresh = build_model(cfg, variant, sd2).forward_packed(packed, topk)["pred_logits"]
+    assert not torch.equal(before, after)
+    assert torch.equal(after, fresh)

@@ -320,3 +320,33 @@ def test_train_step_exact_gemm_mode_every_gradient_within_1e_4(name):
             worst[k] = max(worst[k], float(np.abs(p.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-12)))
     bad = {k: v for k, v in worst.items() if v > 1e-4}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+def test_two_forwards_before_one_backward_accumulate_like_autograd():
+    """gradient accumulation over micro-batches: loss_a + loss_b built from two forwards, ONE backward -- every step keeps its
+    own saved activations, so the result is the sum of the two separately computed gradients (the reference's autograd graph
+    supports this pattern)"""
+    cfg, variant, sd, props, gts = cases.make_train_case("bigc_train_tiny")
+    model = build_train_model(cfg, variant, sd)
+
+    def fresh_gts():
+        return cases.make_train_case("bigc_train_tiny")[4]       # the forward mutates the GT durations (reference quirk)
+
+    grads = []
+    for sel in ([0], [1]):
+        g = fresh_gts()
+        model.zero_grad()
+        loss, _ = model([props[i] for i in sel], [g[i] for i in sel])
+        loss.backward()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    g = fresh_gts()
+    model.zero_grad()
+    la, _ = model([props[0]], [g[0]])
+    lb, _ = model([props[1]], [g[1]])              # second forward BEFORE the first backward
+    (la + lb).backward()
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        want = grads[0][k] + grads[1][k]
+        assert float((p.grad - want).abs().max()) <= 1e-5 * max(float(want.abs().max()), 1e-6), k

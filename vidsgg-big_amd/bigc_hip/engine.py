@@ -62,6 +62,13 @@ class BigcEngine(object):
         self._sig = sig
         self._keep = [t for _, t in items]
 
+    def invalidate_weights(self):
+        """Force the next forward to re-register the parameters and rebuild every derived device buffer (split / transposed
+        weight copies, ``role_cat``, the tap-major conv weight).  ``sync_params`` notices a parameter that moved or whose
+        ``_version`` changed (optimizer steps, ``load_state_dict``, ``copy_``); it cannot notice writes through ``p.data``
+        (``p.data.mul_()``, hand-written EMA / clipping code), which do not bump the version counter: call this after those."""
+        self._sig = None
+
     def set_dropout(self, p, seed):
         """Training-mode dropout of the transformer layers (0 = off); masks are a pure function of (seed, site, index)."""
         _lib.check(self.lib.bigc_set_dropout(self.handle, float(p), int(seed)))

@@ -54,6 +54,10 @@ class GrdEngine(object):
         self._sig = sig
         self._keep = [t for _, t in items]
 
+    def invalidate_weights(self):
+        """see BigcEngine.invalidate_weights: needed after writes through ``p.data``, which ``sync_params`` cannot see"""
+        self._sig = None
+
     def tables(self, T, device):
         key = (T, str(device))
         if key not in self._tables:

@@ -76,9 +76,9 @@ def forward(model, engine, packed, gt_graph_list):
     ctx = TrainContext()
     ctx.packed, ctx.batch = packed, packed.as_struct()
     need = lib.bigc_train_workspace_bytes(engine.handle, ctypes.byref(ctx.batch))
-    if engine._train_ws is None or engine._train_ws.numel() < need or engine._train_ws.device != dev:
-        engine._train_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
-    ctx.ws = engine._train_ws
+    # the saved activations belong to THIS step: a second forward before this step's backward (gradient accumulation over
+    # micro-batches, loss1 + loss2) must not overwrite them; torch's caching allocator recycles the block after the backward
+    ctx.ws = torch.empty((need,), dtype=torch.uint8, device=dev)
     ctx.logits = torch.empty((B * Q, P), dtype=torch.float32, device=dev)
     ctx.att = torch.empty((2 * Q * NT,), dtype=torch.float32, device=dev)
     stream = _lib.current_stream()

@@ -583,7 +583,7 @@ int* mha_flag_slot(int run_id) {
         if (hipMalloc((void**)&g_mha_flags[dev], MHA_SLOTS * sizeof(int)) != hipSuccess) return nullptr;
         if (hipMemset(g_mha_flags[dev], 0, MHA_SLOTS * sizeof(int)) != hipSuccess) return nullptr;
     }
-    return g_mha_flags[dev] + (run_id % MHA_SLOTS);
+    return g_mha_flags[dev] + ((unsigned)run_id % MHA_SLOTS);      // (unsigned: the launch counter may wrap)
 }
 }  // namespace
 

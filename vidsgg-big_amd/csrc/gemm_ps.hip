@@ -561,6 +561,18 @@ int ensure_hr8(hipStream_t s, const float* W, int ldw, int N, int K, WEntry& e, 
 
 }  // namespace
 
+void bigc_gemm_ps_cache_forget(const float* w) {
+    std::lock_guard<std::mutex> lock(g_ps_mu);
+    for (auto it = g_ps_cache.begin(); it != g_ps_cache.end();) {
+        if (it->first.w == w) {
+            if (it->second.mem) { (void)hipDeviceSynchronize(); (void)hipFree(it->second.mem); }
+            it = g_ps_cache.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
 bool bigc_gemm_ps_supported(const PsGemm& g) {
     if (g.M <= 0 || g.N < 8 || g.K < TK || g.K % TK != 0 || g.N % 8 != 0) return false;
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15) || g.lda % 16 != 0 || g.ldw % 4 != 0) return false;

@@ -12,6 +12,7 @@
 // encoder, 3n for the query encoder, T for the video encoder); the reference's (N, d, T) tensors are
 // the transposes, so Conv1d(k=1) is a plain linear and LayerNorm needs no transposes.
 #include "grounding_internal.h"
+#include "linear_internal.h"
 #include "prof.h"
 
 namespace {
@@ -458,6 +459,8 @@ extern "C" int grd_create(const grd_config* cfg, grd_model** out) {
 
 extern "C" void grd_destroy(grd_model* m) {
     if (!m) return;
+    for (const auto& kv : m->params) bigc_weight_cache_forget(kv.second.first);      // cached split forms of this model's weights
+    if (m->wq) bigc_weight_cache_forget(m->wq);
     if (m->wq) (void)hipFree(m->wq);
     if (m->bq) (void)hipFree(m->bq);
     delete m;

@@ -24,6 +24,10 @@ struct StaticWeights {
     ~StaticWeights() { bigc_static_weights_epoch = prev; }
 };
 
+// drops the cached split forms of the weight at `w` (both kernels' caches) and frees their device memory; called for every
+// parameter of a model that is destroyed
+void bigc_weight_cache_forget(const float* w);
+void bigc_gemm_ps_cache_forget(const float* w);
 // launches the split-operand kernel (and its W pre-split pass); returns BIGC_OK or an error code
 int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double bytes);
 

@@ -353,6 +353,21 @@ int ensure_split(hipStream_t s, const LinearArgs& p, int K4, WEntry& e, bool fre
 
 }  // namespace
 
+void bigc_weight_cache_forget(const float* w) {
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        for (auto it = g_cache.begin(); it != g_cache.end();) {
+            if (it->first.w == w) {
+                if (it->second.mem) { (void)hipDeviceSynchronize(); (void)hipFree(it->second.mem); }
+                it = g_cache.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    bigc_gemm_ps_cache_forget(w);
+}
+
 thread_local unsigned long long bigc_static_weights_epoch = 0;
 unsigned long long bigc_next_weights_epoch() { return ++g_epoch_seq; }
 

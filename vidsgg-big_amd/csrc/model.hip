@@ -93,10 +93,16 @@ bool layout(const bigc_model* m, const Sizes& z, Arena& a, Work& w) {
     w.p2a = a.take<float>(z.BQ * da);
     w.e2a = a.take<float>(z.NT * da);
     w.vals = a.take<float>(2 * z.BQ * de);
-    w.rh = a.take<float>(z.BQ * (dp > df ? dp : df));
+    {   // also holds the two (NT, dp) projected entity blocks of the fused role path (forward: `ew`)
+        const size_t a1 = z.BQ * (dp > df ? dp : df), a2 = 2 * z.NT * dp;
+        w.rh = a.take<float>(a1 > a2 ? a1 : a2);
+    }
     w.xmean = a.take<float>(z.NT * (c.dim_extra > 0 ? c.dim_extra : 1));
     w.i3dfc = a.take<float>(z.NT * de);
-    w.head_in = a.take<float>(z.BQ * (size_t)m->head_k);
+    {   // also holds U and V of the factorised head: 2 x (NT, ldu)
+        const size_t a1 = z.BQ * (size_t)m->head_k, a2 = 2 * z.NT * (size_t)((c.num_pred_cats + 3) & ~3);
+        w.head_in = a.take<float>(a1 > a2 ? a1 : a2);
+    }
     w.bias_g = a.take<float>(z.BQ * c.num_pred_cats);
     w.hh = a.take<float>(z.BQ * df);
     w.xs = a.take<float>(z.NT * de);
@@ -161,6 +167,11 @@ extern "C" int bigc_create(const bigc_config* cfg, bigc_model** out) {
 
 extern "C" void bigc_destroy(bigc_model* m) {
     if (!m) return;
+    // the split forms of this model's weights are cached per pointer (linear_split.hip / gemm_ps.hip): release them with the model
+    for (const auto& kv : m->params) bigc_weight_cache_forget(kv.second.first);
+    if (m->conv_w_tapmajor) bigc_weight_cache_forget(m->conv_w_tapmajor);
+    if (m->role_cat) bigc_weight_cache_forget(m->role_cat);
+    if (m->conv_w_bwd) bigc_weight_cache_forget(m->conv_w_bwd);
     if (m->conv_w_tapmajor) (void)hipFree(m->conv_w_tapmajor);
     if (m->role_cat) (void)hipFree(m->role_cat);
     if (m->conv_w_bwd) (void)hipFree(m->conv_w_bwd);

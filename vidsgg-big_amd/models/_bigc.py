@@ -139,6 +139,13 @@ class BigcBase(nn.Module):
         loss_dict = {"cls_pos": terms[0], "cls_neg": terms[1], "adj": terms[2]}
         return terms.sum(), loss_dict
 
+    def invalidate_weights(self):
+        """Call after modifying parameters through ``.data`` (in-place writes that do not bump the tensors' version counter,
+        e.g. ``p.data.mul_()`` in hand-written EMA or weight-clipping code): the HIP library keeps split / re-laid-out copies of
+        the weights and otherwise only refreshes them when a parameter moved or its version changed."""
+        if self._engine is not None:
+            self._engine.invalidate_weights()
+
     def engine(self):
         if self._engine is None:
             self._engine = BigcEngine(self.config, self.variant)

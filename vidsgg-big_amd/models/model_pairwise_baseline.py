@@ -46,6 +46,13 @@ class Base_C(nn.Module):
                 nn.init.zeros_(p)
         self._engine = None
 
+    def invalidate_weights(self):
+        """Call after modifying parameters through ``.data`` (in-place writes that do not bump the tensors' version counter,
+        e.g. ``p.data.mul_()`` in hand-written EMA or weight-clipping code): the HIP library keeps split / re-laid-out copies of
+        the weights and otherwise only refreshes them when a parameter moved or its version changed."""
+        if self._engine is not None:
+            self._engine.invalidate_weights()
+
     def engine(self):
         if self._engine is None:
             cfg = dict(self.config)

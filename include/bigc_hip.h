@@ -474,6 +474,23 @@ int bigc_assemble_rows_f32(void* stream, const float* raw, int ld_raw, int col0,
                            int col02, int width2, const int32_t* src_a, const int32_t* src_b, const int32_t* step_i,
                            const int32_t* step_div, float* out, int ld_out, int n_rows);
 
+/* ---- Base_C.construct_triplet (models/model_pairwise_baseline.py:314-395) for all videos of a batch ----------------------------
+ * pair_logits (n_pairs, n_pred): logits of every ordered tracklet pair (bigc_pair_forward; video v's pairs start at vid_pair_off[v],
+ * row-major (s, o) without the diagonal).  Per pair: softmax, top-k; candidates whose subject / object durations do not overlap
+ * are dropped; rows in the lexicographic order of torch.unique(dim=0) over [pred, s_cat, o_cat, s_tid, o_tid]; background
+ * (pred 0) removed.  Outputs: quint (n_pairs*topk, 5) int32, scores (n_pairs*topk, 3) = [pred prob, s score, o score], dura
+ * (n_pairs*topk, 2) closed overlap span; video v's rows start at row vid_pair_off[v]*topk, n_rows[v] of them are valid.
+ * rt_topk > 0 (the reference's rt_triplets_topk, <= 2048): additionally the rt_topk rows of every video with the largest mean
+ * score, descending: quint_top (B, rt_topk, 5), scores_top, dura_top, n_top (B).
+ * bm_off (B) int64 / bm_words (B): offset (in 32-bit words) of video v's bitmap in the scratch region and its words per
+ * predicate class, ceil(N_v^2 / 32); bitmap_words_total = sum_v n_pred * bm_words[v]. */
+size_t bigc_pair_triplets_workspace_bytes(int n_vid, int n_trk, long n_pairs, int topk, long bitmap_words_total);
+int bigc_pair_triplets(void* stream, const float* pair_logits, int n_pred, int topk, const int32_t* vid_trk_off,
+                       const int32_t* vid_pair_off, const int32_t* trk_dura, const int32_t* trk_cat, const float* trk_score,
+                       int n_vid, int n_trk, long n_pairs, const long* bm_off, const int32_t* bm_words, long bitmap_words_total,
+                       void* workspace, size_t workspace_bytes, int32_t* quint, float* scores, int32_t* dura, int32_t* n_rows,
+                       int rt_topk, int32_t* quint_top, float* scores_top, int32_t* dura_top, int32_t* n_top);
+
 /* ---- GEMM on split operands (csrc/gemm_ps.hip) -----------------------------------------------------------------------------
  * Same contract as bigc_linear_f32 -- C = act(A W^T + bias) + residual, replacing nn.Linear / nn.Conv1d(k3,s2) of
  * models/model_0v10.py:290-309,446-458 -- for activations kept in the library's split form "hr8": every 8 consecutive f32 of

@@ -151,3 +151,36 @@ def test_basec_train_every_gradient_matches_oracle_and_optimizer_step_runs():
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=5, norm_type=2)
         opt.step()
     assert float(loss) < before
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_trajs,rt", [(180, 200), (180, -1), (37, 2048), (2, 5)])
+def test_pair_triplets_kernel_vs_torch_restatement_at_vidor_size(n_trajs, rt):
+    """bigc_pair_triplets on random pair logits of a VidOR-sized video (N = 180: 32 220 pairs, 96 660 candidates, far beyond the
+    LDS sort of triplet.hip) against the torch restatement of Base_C.construct_triplet (:314-395), which the reference goldens pin
+    at N <= 24: rows, order, scores, spans -- with and without the rt_triplets_topk cut"""
+    from bigc_hip.packed import PackedBatch
+    from bigc_hip.synthetic import synthetic_proposal
+    cfg, sd, _, _ = cases.make_basec_case("basec_tiny")
+    cfg = dict(cfg, rt_triplets_topk=rt)
+    model = _build(cfg, sd)
+    P, topk = cfg["num_pred_cats"], 3
+    model.topk = topk
+    props = [synthetic_proposal(777, n_trajs=n_trajs, feat_width=36, num_enti_cats=cfg["num_enti_cats"], len_range=(5, 60), start_range=(0, 120)),
+             synthetic_proposal(778, n_trajs=5, feat_width=36, num_enti_cats=cfg["num_enti_cats"], len_range=(5, 20), start_range=(0, 10))]
+    packed = PackedBatch([p.to("cuda:0") for p in props], "cuda:0")
+    n = np.diff(packed.vid_trk_off_host)
+    off = np.concatenate([[0], np.cumsum(n * (n - 1))])
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    logits = torch.randn((int(off[-1]), P), device="cuda:0", generator=g) * 2.0
+    out = {"vid_pair_off": off, "pair_logits": logits, "_keepalive": torch.from_numpy(off.astype(np.int32)).to("cuda:0")}
+    got = model.engine().pair_triplets(packed, out, topk, rt)
+    for v, p in enumerate(props):
+        want = model.construct_triplet(p, logits[off[v]:off[v + 1]])
+        if want is None:
+            assert got[v] is None
+            continue
+        q, s, d = got[v]
+        assert torch.equal(q.cpu(), want[0].cpu()), "video %d quintuples" % v
+        assert torch.equal(d.cpu(), want[2].cpu())
+        assert float((s.cpu() - want[1].cpu()).abs().max()) < 1e-6

@@ -101,6 +101,10 @@ _SIGS = {
     "bigc_pair_train_forward": (c_int, [c_void_p, c_void_p, POINTER(bigc_batch), c_void_p, ctypes.c_long, c_void_p, c_size_t, c_void_p]),
     "bigc_pair_train_backward": (c_int, [c_void_p, c_void_p, POINTER(bigc_batch), c_void_p, ctypes.c_long, c_void_p, c_size_t, c_void_p, c_int]),
     "bigc_bce_logits_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, ctypes.c_long, c_int, c_float, c_void_p, c_void_p, c_int]),
+    "bigc_pair_triplets_workspace_bytes": (c_size_t, [c_int, c_int, ctypes.c_long, c_int, ctypes.c_long]),
+    "bigc_pair_triplets": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_long,
+                                   c_void_p, c_void_p, ctypes.c_long, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "bigc_pair_forward": (c_int, [c_void_p, c_void_p, POINTER(bigc_batch), c_void_p, ctypes.c_long, c_void_p, c_size_t, c_void_p, c_void_p]),
     # training step
     "bigc_transpose_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),

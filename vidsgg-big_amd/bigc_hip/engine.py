@@ -136,3 +136,52 @@ class BigcEngine(object):
                                               self._ws.numel(), _lib.ptr(out.get("enti2enco")), out["pair_logits"].data_ptr()))
         out["_keepalive"] = off_d
         return out
+
+    def pair_triplets(self, packed, pair_out, topk, rt_topk):
+        """Base_C.construct_triplet for every video of the batch in the HIP library (csrc/pair_triplet.hip).
+        -> list (one per video) of None or (quintuples i64 (U,5), scores f32 (U,3), dura_inters i64 (U,2)); ONE D2H copy (the row
+        counts) for the whole batch."""
+        import numpy as np
+        c = self.c
+        dev = packed.device
+        off = pair_out["vid_pair_off"]
+        n_pairs = int(off[-1])
+        B = packed.n_vid
+        if n_pairs == 0:
+            return [None] * B
+        n = np.diff(packed.vid_trk_off_host).astype(np.int64)
+        words = (n * n + 31) // 32
+        bm_off = np.concatenate([[0], np.cumsum(words * c.num_pred_cats)])
+        total_words = int(bm_off[-1])
+        P = c.num_pred_cats
+        off_d = pair_out["_keepalive"]
+        bm_off_d = torch.from_numpy(bm_off[:-1].astype(np.int64)).to(dev)
+        bm_words_d = torch.from_numpy(words.astype(np.int32)).to(dev)
+        need = self.lib.bigc_pair_triplets_workspace_bytes(B, packed.n_trk, n_pairs, int(topk), total_words)
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        cap = n_pairs * topk
+        quint = torch.empty((cap, 5), dtype=torch.int32, device=dev)
+        scores = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+        dura = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        R = int(rt_topk) if rt_topk and rt_topk > 0 else 0
+        counts = torch.zeros((2, B), dtype=torch.int32, device=dev)
+        qt = torch.empty((B, max(R, 1), 5), dtype=torch.int32, device=dev)
+        st = torch.empty((B, max(R, 1), 3), dtype=torch.float32, device=dev)
+        dt = torch.empty((B, max(R, 1), 2), dtype=torch.int32, device=dev)
+        _lib.check(self.lib.bigc_pair_triplets(_lib.current_stream(), pair_out["pair_logits"].data_ptr(), P, int(topk), packed.vid_trk_off.data_ptr(),
+                                               off_d.data_ptr(), packed.trk_dura.data_ptr(), packed.trk_cat.data_ptr(), packed.trk_score.data_ptr(),
+                                               B, packed.n_trk, n_pairs, bm_off_d.data_ptr(), bm_words_d.data_ptr(), total_words, ws.data_ptr(),
+                                               ws.numel(), quint.data_ptr(), scores.data_ptr(), dura.data_ptr(), counts[0].data_ptr(), R,
+                                               qt.data_ptr(), st.data_ptr(), dt.data_ptr(), counts[1].data_ptr()))
+        cnt = counts.cpu().numpy()
+        res = []
+        for v in range(B):
+            if cnt[0, v] == 0:
+                res.append(None)
+            elif R:
+                m = int(cnt[1, v])
+                res.append((qt[v, :m].long(), st[v, :m], dt[v, :m].long()))
+            else:
+                r0, m = int(off[v]) * topk, int(cnt[0, v])
+                res.append((quint[r0:r0 + m].long(), scores[r0:r0 + m], dura[r0:r0 + m].long()))
+        return res

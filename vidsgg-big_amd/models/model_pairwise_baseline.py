@@ -2,7 +2,7 @@
 ``models/model_pairwise_baseline.py:Base_C`` (eval forward: SURVEY.md section 8 row f3; training step :276-312).
 The torch modules only own the parameters under the reference's key names; the front-end, the N x N pair fusion and the
 classifier run in the HIP library (``bigc_pair_forward``); the triplet bookkeeping of ``construct_triplet`` (:306-395) is a
-handful of device-side torch index operations on the pair logits."""
+the HIP library too (``bigc_pair_triplets``, csrc/pair_triplet.hip: no sort, a bitmap prefix sum places every row)."""
 import numpy as np
 import torch
 from torch import nn
@@ -74,11 +74,13 @@ class Base_C(nn.Module):
         dev = next(self.parameters()).device
         packed = PackedBatch([proposal_list[i] for i in keep], dev)
         with torch.no_grad():
-            out = self.engine().pair_forward(packed)
-        off = out["vid_pair_off"]
+            eng = self.engine()
+            out = eng.pair_forward(packed)
+            trip = eng.pair_triplets(packed, out, self.topk, self.rt_triplets_topk)      # construct_triplet (:314-395), all videos at once
         for j, i in enumerate(keep):
-            if off[j + 1] > off[j]:
-                res[i] = self.construct_triplet(proposal_list[i], out["pair_logits"][off[j]:off[j + 1]])
+            if trip[j] is not None:
+                q, s, d = trip[j]
+                res[i] = (q, s, d, torch.empty(size=(s.shape[0],)))
         return res
 
     def _forward_train(self, proposal_list, pos_id_list, label_list):
@@ -94,8 +96,8 @@ class Base_C(nn.Module):
         return torch.stack(list(loss_dict.values())).sum(), loss_dict
 
     def construct_triplet(self, proposal, pred_logits):
-        """(:306-395) on the device: softmax, per-pair top-k, temporal-overlap filter, lexicographic order of the (unique)
-        quintuples, background removal, optional top ``rt_triplets_topk`` by mean score."""
+        """(:306-395) with torch index operations on the device: the restatement the HIP kernels of csrc/pair_triplet.hip (used by
+        ``forward``) are tested against; not on the product path."""
         dev = pred_logits.device
         n, k = proposal.num_proposals, self.topk
         probs = torch.softmax(pred_logits, dim=-1)

@@ -28,11 +28,29 @@ SHAPES = [
 ]
 
 
+# the same layers at the training step's 8-video size (bench.py --mode train): 512 tracklet rows, 1536 query rows
+TRAIN_SHAPES = [
+    ("NT=512 x512x512", 512, 512, 512, False, 0, 30),
+    ("NT=512 x1536x512", 512, 1536, 512, False, 0, 4),
+    ("NT=512 x2048x512", 512, 2048, 512, False, 0, 4),
+    ("BQ=1536 x512x512", 1536, 512, 512, False, 0, 60),
+    ("BQ=1536 x512x512 + res", 1536, 512, 512, True, 0, 20),
+    ("BQ=1536 x1024x512", 1536, 1024, 512, False, 0, 6),
+    ("BQ=1536 x2048x512", 1536, 2048, 512, False, 0, 6),
+    ("BQ=1536 x512x2048", 1536, 512, 2048, False, 0, 6),
+    ("R=9000 x512x512", 9000, 512, 512, False, 0, 4),
+]
+
+
 def main():
+    global SHAPES
     ap = argparse.ArgumentParser()
+    ap.add_argument("--train-shapes", action="store_true")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", type=int, default=-1, help="index of the single shape to run")
     args = ap.parse_args()
+    if args.train_shapes:
+        SHAPES = TRAIN_SHAPES
     lib = _lib.load()
     dev = "cuda:0"
     tot_f, tot_t = 0.0, 0.0

@@ -313,6 +313,10 @@ int bigc_loss_grad(void* stream, const float* logits, int n_pcat, const float* a
 
 /* gradient destination of a trainable parameter (accumulated; NULL unregisters). Frozen parameters are never registered. */
 int bigc_set_grad(bigc_model* m, const char* key, float* ptr);
+/* moves every registered gradient destination from the buffer [old_base, old_base + numel) to the same offset of new_base: the
+ * host side lays all gradients out in one flat buffer, allocates a fresh one per step and keeps the layout (one call per step
+ * instead of one bigc_set_grad per parameter) */
+int bigc_rebase_grads(bigc_model* m, float* old_base, float* new_base, int64_t numel);
 size_t bigc_train_workspace_bytes(const bigc_model* m, const bigc_batch* b);
 /* forward keeping every activation the backward needs inside `workspace` (which must stay untouched until
  * bigc_train_backward); pred_logits (B*Q, P), att (2*Q*NT) of the last decoder layer */

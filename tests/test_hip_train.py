@@ -350,3 +350,51 @@ def test_two_forwards_before_one_backward_accumulate_like_autograd():
             continue
         want = grads[0][k] + grads[1][k]
         assert float((p.grad - want).abs().max()) <= 1e-5 * max(float(want.abs().max()), 1e-6), k
+
+
+def test_gradients_are_bit_reproducible_run_to_run():
+    """The split-M weight-gradient GEMM sums its partial tiles in split order (csrc/backward.hip: dw_reduce_kernel, or the
+    last-arriving workgroup under BIGC_DW_REDUCE=inline) and no weight gradient goes through float atomics: two runs of the same
+    step give identical bits for every weight matrix."""
+    runs = []
+    for _ in range(2):
+        cfg, variant, sd, props, gts = cases.make_train_case("bigc_train_v")
+        model = build_train_model(cfg, variant, sd)
+        model.eval()                                  # no dropout
+        total, _ = model(props, gts)
+        total.backward()
+        torch.cuda.synchronize()
+        runs.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None and k.endswith(".weight") and p.dim() == 2})
+    diff = [k for k in runs[0] if not torch.equal(runs[0][k], runs[1][k])]
+    assert not diff, diff[:10]
+
+
+def test_linear_dw_in_kernel_reduction_equals_the_two_launch_form():
+    """split-M partial tiles: summed by the last-arriving workgroup (BIGC_DW_REDUCE=inline) == summed by the separate reduce kernel
+    (default), bit for bit"""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, "vidsgg-big_amd")
+from bigc_hip import _lib
+lib = _lib.load()
+torch.manual_seed(5)
+M, N, K = 1536, 512, 512
+dY = torch.randn(M, N, device="cuda:0"); X = torch.randn(M, K, device="cuda:0")
+dW = torch.zeros(N, K, device="cuda:0"); db = torch.zeros(N, device="cuda:0")
+for _ in range(2):
+    _lib.check(lib.bigc_linear_dw_f32(_lib.current_stream(), dY.data_ptr(), N, X.data_ptr(), K, None, 1, K, dW.data_ptr(), K, db.data_ptr(), M, N, K))
+torch.cuda.synchronize()
+import hashlib
+print("HASH", hashlib.sha1(dW.cpu().numpy().tobytes()).hexdigest(), float((dW - 2 * dY.t() @ X).abs().max() / (dY.t() @ X).abs().max()))
+'''
+    out = {}
+    for mode in ("inline", "kernel"):
+        env = dict(os.environ, BIGC_DW_REDUCE=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0].split()
+        out[mode] = line[1]
+        assert float(line[2]) < 1e-5
+    assert out["inline"] == out["kernel"]

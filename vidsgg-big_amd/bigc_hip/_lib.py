@@ -132,6 +132,7 @@ _SIGS = {
                                c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
                                c_void_p, c_void_p, c_int, c_void_p]),
     "bigc_set_grad": (c_int, [c_void_p, c_char_p, c_void_p]),
+    "bigc_rebase_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "bigc_set_dropout": (c_int, [c_void_p, c_float, ctypes.c_uint32]),
     "bigc_dropout_f32": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_float, ctypes.c_uint32, ctypes.c_uint32]),
     "bigc_mha_core_drop_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
@@ -208,3 +209,94 @@ def ptr(t):
 def current_stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+
+class _Staging(object):
+    """One pinned host block per device, allocated once and used as two halves in turn.  Pinned blocks from torch's caching
+    host allocator are only recycled once the copy that read them has run; a host that runs ahead of the GPU therefore makes
+    it allocate new pinned memory every step, and every such allocation maps pages into the GPU's address space -- measured as
+    random 40 ms stalls of the GPU queue in the 64-video training step."""
+
+    def __init__(self, nbytes=16 << 20):
+        import torch
+        self.buf = torch.empty((nbytes,), dtype=torch.uint8).pin_memory()
+        self.half, self.off, self.cur, self.events = nbytes // 2, 0, 0, [None, None]
+        self.down = {}
+
+    def put(self, t, device):
+        import torch
+        n = t.numel() * t.element_size()
+        n_al = (n + 255) & ~255
+        if n_al > self.half:
+            return None
+        if self.off + n_al > self.half:          # move to the other half once the copies that read it last time have run
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[self.cur] = ev
+            self.cur ^= 1
+            self.off = 0
+            if self.events[self.cur] is not None:
+                self.events[self.cur].synchronize()
+        start = self.cur * self.half + self.off
+        view = self.buf[start:start + n].view(t.dtype).view(t.shape)
+        view.copy_(t)
+        self.off += n_al
+        return view.to(device, non_blocking=True)
+
+    def download_buffer(self, shape, dtype, slot="default"):
+        """a pinned host tensor for device-to-host copies whose result the host consumes before the slot's next use"""
+        import torch
+        n = 1
+        for s in shape:
+            n *= int(s)
+        cur = self.down.get(slot)
+        if cur is None or cur.numel() < n or cur.dtype != dtype:
+            cur = self.down[slot] = torch.empty((max(2 * n, 1 << 16),), dtype=dtype).pin_memory()
+        return cur[:n].view(shape)
+
+
+_staging = {}
+
+
+def staging(device):
+    import torch
+    key = str(torch.device(device))
+    if key not in _staging:
+        _staging[key] = _Staging()
+    return _staging[key]
+
+
+def upload(host, device):
+    """Host tensor / ndarray -> device without stalling the host: staged in the device's pinned block (``_Staging``) and queued on
+    the current stream.  A plain ``.to(device)`` from pageable memory waits for everything queued before it."""
+    import numpy as np
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(host)) if isinstance(host, np.ndarray) else host.contiguous()
+    if torch.device(device).type != "cuda" or os.environ.get("BIGC_UPLOAD_BLOCKING", "0") == "1":
+        return t.to(device)
+    # Larger uploads take the blocking route: queued as asynchronous copies they made the runtime evict and restore the process's
+    # GPU queues now and then (a doorbell write, hsa_signal_store_screlease, blocked for 40-65 ms with the GPU idle; seen from
+    # 32 videos per step up, where the adjacency upload passes 128 KB) -- measured 65 -> 21 ms per 32-video step with this cap.
+    cap = int(os.environ.get("BIGC_UPLOAD_ASYNC_MAX", "65536"))
+    if t.numel() * t.element_size() > cap:
+        return t.to(device)
+    out = staging(device).put(t, device) if t.numel() else None
+    return out if out is not None else t.to(device)
+
+
+def download(t, slot="default"):
+    """Device tensor -> host tensor through the device's pinned block, waiting only for the copy (and what was queued before it).
+    ``t.cpu()`` into pageable memory makes the runtime pin and unpin the destination for copies beyond its small staging buffers:
+    a page-table update of the GPU per call, harmless while the GPU idles, a stall of tens of ms when work is queued behind it."""
+    import torch
+    if not t.is_cuda:
+        return t
+    if os.environ.get("BIGC_DOWNLOAD_BLOCKING", "0") == "1":
+        return t.cpu()
+    host = staging(t.device).download_buffer(t.shape, t.dtype, slot)
+    host.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ev.synchronize()
+    return host

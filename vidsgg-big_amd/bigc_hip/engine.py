@@ -51,13 +51,15 @@ class BigcEngine(object):
     def sync_params(self, named_tensors):
         """(Re-)register the parameter pointers when a tensor moved or was written in place."""
         items = [(k, t) for k, t in named_tensors]
-        sig = tuple((k, t.data_ptr(), t._version) for k, t in items)
+        ptrs = tuple((k, t.data_ptr()) for k, t in items)
+        sig = (ptrs, tuple(t._version for _, t in items))
         if sig == self._sig:
             return
-        for k, t in items:
-            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \
-                "parameter %s must be a contiguous fp32 tensor on the GPU" % k
-            _lib.check(self.lib.bigc_set_param(self.handle, k.encode(), t.data_ptr(), t.numel()))
+        if self._sig is None or self._sig[0] != ptrs:       # a training step changes the versions only: nothing to re-register
+            for k, t in items:
+                assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \
+                    "parameter %s must be a contiguous fp32 tensor on the GPU" % k
+                _lib.check(self.lib.bigc_set_param(self.handle, k.encode(), t.data_ptr(), t.numel()))
         _lib.check(self.lib.bigc_finalize(self.handle, _lib.current_stream()))
         self._sig = sig
         self._keep = [t for _, t in items]
@@ -68,6 +70,29 @@ class BigcEngine(object):
         ``_version`` changed (optimizer steps, ``load_state_dict``, ``copy_``); it cannot notice writes through ``p.data``
         (``p.data.mul_()``, hand-written EMA / clipping code), which do not bump the version counter: call this after those."""
         self._sig = None
+
+    def flat_gradients(self, trainable, device, set_grad="bigc_set_grad", rebase="bigc_rebase_grads"):
+        """A fresh zeroed flat fp32 buffer holding one gradient per entry of ``trainable`` [(key, parameter)] back to back, and
+        the per-parameter views of it, registered as the gradient destinations of the C model.  The buffer is new every step
+        (autograd may keep the views as ``.grad``); the layout is registered once and moved with one call afterwards."""
+        layout = tuple((k, p.numel()) for k, p in trainable)
+        total = sum(n for _, n in layout)
+        flat = torch.zeros((total,), dtype=torch.float32, device=device)
+        views = torch._utils._unflatten_dense_tensors(flat, [p for _, p in trainable])
+        prev = getattr(self, "_grad_layout", None)
+        if prev is not None and prev[0] == layout and rebase is not None:
+            _lib.check(getattr(self.lib, rebase)(self.handle, prev[1], flat.data_ptr(), total))
+        else:
+            for k in set(k for k, _ in (prev[0] if prev else ())) - set(k for k, _ in layout):
+                _lib.check(getattr(self.lib, set_grad)(self.handle, k.encode(), None))       # frozen since the last step
+            off = 0
+            for (k, n), v in zip(layout, views):
+                assert v.data_ptr() == flat.data_ptr() + 4 * off
+                _lib.check(getattr(self.lib, set_grad)(self.handle, k.encode(), v.data_ptr()))
+                off += n
+        self._grad_layout = (layout, flat.data_ptr())
+        self.last_flat_grad = flat
+        return flat, dict(zip((k for k, _ in trainable), views))
 
     def set_dropout(self, p, seed):
         """Training-mode dropout of the transformer layers (0 = off); masks are a pure function of (seed, site, index)."""

@@ -40,21 +40,27 @@ class PackedBatch(object):
         self.n_conv = int((t_o[trk_vid]).sum())
         assert self.n_rows < 2 ** 31 and self.n_conv * 3 < 2 ** 31
 
-        def i32(a):
-            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+        def on_device(t):                                         # (a no-op .to() still costs microseconds; x 2 per tracklet)
+            return t if t.device == device else t.to(device)
 
+        # every offset table in ONE host-to-device copy
         self.vid_trk_off_host = np.concatenate([[0], np.cumsum(n_per_vid)]).astype(np.int64)
-        self.trk_row_off = i32(np.concatenate([[0], np.cumsum(all_lens)]))
-        self.trk_conv_off = i32(np.concatenate([[0], np.cumsum(t_o[trk_vid])]))
-        self.trk_vid = i32(trk_vid)
-        self.vid_trk_off = i32(self.vid_trk_off_host)
-        self.vid_tmax = i32(tmax)
-        self.vid_wh = torch.tensor(wh, dtype=torch.float32, device=device)
-        self.trk_dura = torch.cat([p.traj_durations.to(device) for p in proposals], 0).to(torch.int32).contiguous()
-        self.trk_cat = torch.cat([p.cat_ids.to(device) for p in proposals], 0).to(torch.int32).contiguous()
-        self.trk_score = torch.cat([p.scores.to(device) for p in proposals], 0).to(torch.float32).contiguous()
-        self.boxes = torch.cat([b.to(device) for p in proposals for b in p.bboxes_list], 0).to(torch.float32).contiguous()
-        self.feats = torch.cat([f.to(device) for p in proposals for f in p.features_list], 0).to(torch.float32).contiguous()
+        tables = [np.concatenate([[0], np.cumsum(all_lens)]), np.concatenate([[0], np.cumsum(t_o[trk_vid])]), trk_vid,
+                  self.vid_trk_off_host, np.asarray(tmax)]
+        sizes = [(len(a) + 3) // 4 * 4 for a in tables]          # 16-byte aligned starts
+        blob = np.zeros((sum(sizes),), dtype=np.int32)
+        starts = np.concatenate([[0], np.cumsum(sizes)])
+        for a, o in zip(tables, starts):
+            blob[o:o + len(a)] = a
+        blob_d = _lib.upload(blob, device)
+        self.trk_row_off, self.trk_conv_off, self.trk_vid, self.vid_trk_off, self.vid_tmax = \
+            [blob_d[o:o + len(a)] for a, o in zip(tables, starts)]
+        self.vid_wh = _lib.upload(np.asarray(wh, dtype=np.float32).reshape(-1, 2), device)
+        self.trk_dura = torch.cat([on_device(p.traj_durations) for p in proposals], 0).to(torch.int32).contiguous()
+        self.trk_cat = torch.cat([on_device(p.cat_ids) for p in proposals], 0).to(torch.int32).contiguous()
+        self.trk_score = torch.cat([on_device(p.scores) for p in proposals], 0).to(torch.float32).contiguous()
+        self.boxes = torch.cat([on_device(b) for p in proposals for b in p.bboxes_list], 0).to(torch.float32).contiguous()
+        self.feats = torch.cat([on_device(f) for p in proposals for f in p.features_list], 0).to(torch.float32).contiguous()
         self.feat_width = int(self.feats.shape[1])
         assert self.boxes.shape == (self.n_rows, 4) and self.feats.shape[0] == self.n_rows
 

@@ -100,19 +100,11 @@ def backward(model, engine, ctx, grad_terms, named_params):
     if scale != 1.0:
         seed = seed * scale
     trainable = [(k, p) for k, p in named_params if p.requires_grad]
-    total = sum(p.numel() for _, p in trainable)
-    flat = torch.zeros((total,), dtype=torch.float32, device=dev)
-    views, off = {}, 0
-    for k, p in trainable:
-        n = p.numel()
-        views[k] = flat[off:off + n].view_as(p)
-        _lib.check(engine.lib.bigc_set_grad(engine.handle, k.encode(), views[k].data_ptr()))
-        off += n
+    flat, views = engine.flat_gradients(trainable, dev)
     _lib.check(engine.lib.bigc_pair_train_backward(engine.handle, _lib.current_stream(), ctypes.byref(ctx.batch), ctx.pair_so.data_ptr(),
                                                    ctx.n_pairs, ctx.ws.data_ptr(), ctx.ws.numel(), seed.data_ptr(), ctx.ldg))
     if scale != 1.0:
         flat.mul_(1.0 / scale)
-    engine.last_flat_grad = flat
     return [views.get(k) for k, _ in named_params]
 
 

@@ -11,6 +11,7 @@ The result is exposed as a ``torch.autograd.Function`` so that ``loss.backward()
 import ctypes
 import math
 import os
+import time
 
 import numpy as np
 import torch
@@ -18,6 +19,20 @@ from scipy.optimize import linear_sum_assignment
 
 from . import _lib
 from .packed import PackedBatch
+
+# Host timeline of the step (BIGC_TRAIN_TRACE=1): seconds spent up to each mark since the previous one, summed over steps.  The
+# marks add no device synchronisation, so a mark right after a blocking copy shows how long the host waited for the GPU there.
+TRACE = {}
+_trace_on = os.environ.get("BIGC_TRAIN_TRACE", "0") == "1"
+_trace_last = [0.0]
+
+
+def mark(name):
+    if _trace_on:
+        now = time.perf_counter()
+        if name is not None:
+            TRACE[name] = TRACE.get(name, 0.0) + now - _trace_last[0]
+        _trace_last[0] = now
 
 
 def adj_from_viou(vi, adj, viou_th):
@@ -34,33 +49,57 @@ def adj_from_viou(vi, adj, viou_th):
     return adj[:, :, pick] * has[None, None, :].to(adj.dtype)
 
 
-def viou_tables(lib, packed, gt_graph_list):
-    """vIoU of every proposal with every GT trajectory of its video, one HIP kernel launch (``bigc_viou_matrix``; the
-    reference loops over pairs in Python, models/model_0v10.py:576-581, tools/train_vidor.py:110-121):
-    list of (n_proposals, n_gt_traj) f32 host tensors."""
+def viou_tables_launch(lib, packed, gt_graph_list):
+    """Queues the vIoU kernel (``bigc_viou_matrix``: every proposal against every GT trajectory of its video; the reference loops
+    over pairs in Python, models/model_0v10.py:576-581, tools/train_vidor.py:110-121) and the copy of its result into pinned host
+    memory on the current stream, and returns without waiting: the tables depend on the boxes only, so the step queues them BEFORE
+    the model forward and thresholds them on the host while the forward runs."""
     dev = packed.device
     n_traj = [len(g.traj_bboxes) for g in gt_graph_list]
     lens = [int(b.shape[0]) for g in gt_graph_list for b in g.traj_bboxes]
-    gt_boxes = torch.cat([b.detach().float().cpu() for g in gt_graph_list for b in g.traj_bboxes], 0).contiguous().to(dev)
-    gt_row_off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
-    gt_dura = torch.cat([g.traj_durations.detach().cpu() for g in gt_graph_list], 0).to(torch.int32).contiguous().to(dev)
-    gt_traj_off = torch.from_numpy(np.concatenate([[0], np.cumsum(n_traj)]).astype(np.int32)).to(dev)
+    gt_boxes = _lib.upload(torch.cat([b.detach().float().cpu() for g in gt_graph_list for b in g.traj_bboxes], 0).contiguous(), dev)
+    gt_row_off = _lib.upload(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), dev)
+    gt_dura = _lib.upload(torch.cat([g.traj_durations.detach().cpu() for g in gt_graph_list], 0).to(torch.int32).contiguous(), dev)
+    gt_traj_off = _lib.upload(np.concatenate([[0], np.cumsum(n_traj)]).astype(np.int32), dev)
     g_max = int(max(n_traj))
     out = torch.zeros((packed.n_vid, packed.max_trk, g_max), dtype=torch.float32, device=dev)
     _lib.check(lib.bigc_viou_matrix(_lib.current_stream(), packed.boxes.data_ptr(), packed.trk_row_off.data_ptr(), packed.trk_dura.data_ptr(),
                                     packed.vid_trk_off.data_ptr(), gt_boxes.data_ptr(), gt_row_off.data_ptr(), gt_dura.data_ptr(),
                                     gt_traj_off.data_ptr(), packed.n_vid, packed.max_trk, g_max, out.data_ptr()))
-    vi = out.cpu()
+    host = _lib.staging(dev).download_buffer(out.shape, torch.float32, "viou")
+    host.copy_(out, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    return host, done, n_traj, (out, gt_boxes, gt_row_off, gt_dura, gt_traj_off)
+
+
+def viou_tables_wait(packed, pending):
+    """-> list of (n_proposals, n_gt_traj) f32 host tensors"""
+    host, done, n_traj, _keep = pending
+    done.synchronize()                                  # waits for the vIoU kernel + copy only, not for what was queued after them
     n_trk = np.diff(packed.vid_trk_off_host)
-    return [vi[v, :int(n_trk[v]), :n_traj[v]].clone() for v in range(packed.n_vid)]
+    return [host[v, :int(n_trk[v]), :n_traj[v]].clone() for v in range(packed.n_vid)]
+
+
+def viou_tables(lib, packed, gt_graph_list):
+    return viou_tables_wait(packed, viou_tables_launch(lib, packed, gt_graph_list))
+
+
+def align_launch(lib, packed, gt_graph_list):
+    """First half of ``enti_viou_align`` for every video of the batch: reproduces the reference's in-place
+    ``gt_graph.traj_durations[:, 1] -= 1`` (:567) and queues the vIoU tables."""
+    for g in gt_graph_list:
+        g.traj_durations[:, 1] -= 1
+    return viou_tables_launch(lib, packed, gt_graph_list)
+
+
+def align_finish(packed, gt_graph_list, pending, viou_th):
+    """Second half: the thresholding of the tables into the aligned adjacency, on the host."""
+    return [adj_from_viou(vi, g.adj_matrix.detach().cpu().float(), viou_th) for vi, g in zip(viou_tables_wait(packed, pending), gt_graph_list)]
 
 
 def align_batch(lib, packed, gt_graph_list, viou_th):
-    """``enti_viou_align`` for every video of the batch: vIoU tables from the HIP kernel, the thresholding on the host.
-    Reproduces the reference's in-place ``gt_graph.traj_durations[:, 1] -= 1`` (:567)."""
-    for g in gt_graph_list:
-        g.traj_durations[:, 1] -= 1
-    return [adj_from_viou(vi, g.adj_matrix.detach().cpu().float(), viou_th) for vi, g in zip(viou_tables(lib, packed, gt_graph_list), gt_graph_list)]
+    return align_finish(packed, gt_graph_list, align_launch(lib, packed, gt_graph_list), viou_th)
 
 
 class TrainContext(object):
@@ -82,26 +121,37 @@ def forward(model, engine, packed, gt_graph_list):
     ctx.logits = torch.empty((B * Q, P), dtype=torch.float32, device=dev)
     ctx.att = torch.empty((2 * Q * NT,), dtype=torch.float32, device=dev)
     stream = _lib.current_stream()
+    mark("fwd: buffers")
+    pending = align_launch(lib, packed, gt_graph_list)          # vIoU tables first: their host half overlaps the model forward
+    mark("fwd: vIoU launch + GT upload")
     _lib.check(lib.bigc_train_forward(engine.handle, stream, ctypes.byref(ctx.batch), ctx.ws.data_ptr(), ctx.ws.numel(),
                                       ctx.logits.data_ptr(), ctx.att.data_ptr()))
+    mark("fwd: bigc_train_forward launches")
     # ground truth, aligned to the proposals on the host
     n_trk = np.diff(packed.vid_trk_off_host)
-    adjs = align_batch(lib, packed, gt_graph_list, model.positive_vIoU_th)
+    adjs = align_finish(packed, gt_graph_list, pending, model.positive_vIoU_th)
+    mark("fwd: vIoU wait + thresholds (host)")
     n_gt = [int(a.shape[1]) for a in adjs]
     assert min(n_gt) > 0, "every training video needs at least one GT predicate"
     g_off = np.concatenate([[0], np.cumsum(n_gt)])
     adj_off = np.concatenate([[0], np.cumsum([2 * g * int(n) for g, n in zip(n_gt, n_trk)])]).astype(np.int64)
-    ctx.g_off = torch.from_numpy(g_off.astype(np.int32)).to(dev)
-    ctx.adj_off = torch.from_numpy(adj_off[:-1].copy()).to(dev)
-    ctx.gt_adj = torch.cat([a.reshape(-1) for a in adjs]).to(dev)
     gt_pred_host = torch.cat([g.pred_cat_ids.detach().cpu() for g in gt_graph_list]).to(torch.int32)
-    ctx.gt_pred = gt_pred_host.to(dev)
+    n_off = (B + 1 + 3) // 4 * 4                        # [g_off | pad | gt_pred] in one copy
+    ints = torch.zeros((n_off + gt_pred_host.numel(),), dtype=torch.int32)
+    ints[:B + 1] = torch.from_numpy(g_off.astype(np.int32))
+    ints[n_off:] = gt_pred_host
+    ints = _lib.upload(ints, dev)
+    ctx.g_off, ctx.gt_pred = ints[:B + 1], ints[n_off:]
+    ctx.adj_off = _lib.upload(adj_off[:-1].copy(), dev)
+    ctx.gt_adj = _lib.upload(torch.cat([a.reshape(-1) for a in adjs]), dev)
     g_max = int(max(n_gt))
     cost = torch.zeros((B, Q, g_max), dtype=torch.float32, device=dev)
     _lib.check(lib.bigc_match_cost(stream, ctx.logits.data_ptr(), P, ctx.att.data_ptr(), packed.vid_trk_off.data_ptr(), ctx.g_off.data_ptr(),
                                    ctx.gt_pred.data_ptr(), ctx.gt_adj.data_ptr(), ctx.adj_off.data_ptr(), B, Q, g_max,
                                    float(model.cost_factor["classification"]), float(model.cost_factor["adj_matrix"]), cost.data_ptr()))
-    cost_host = cost.cpu().numpy()                      # D2H sync, as the reference's cost_all.cpu() (:637)
+    mark("fwd: adjacency upload + cost launch")
+    cost_host = _lib.download(cost, "cost").numpy()      # D2H sync, as the reference's cost_all.cpu() (:637)
+    mark("fwd: WAIT for the forward (cost.cpu())")
     target = np.zeros((B, Q), dtype=np.int32)
     match_g = np.full((B, Q), -1, dtype=np.int32)
     ctx.indices = []
@@ -112,16 +162,18 @@ def forward(model, engine, packed, gt_graph_list):
         target[v, iq] = gt_pred_host[g_off[v] + ig].numpy()
         match_g[v, iq] = ig
         n_adj += 2 * len(iq) * int(n_trk[v])
+    mark("fwd: Hungarian (host)")
     ctx.n_pos = float((target != 0).sum())
     ctx.n_neg = float(max(1, (target == 0).sum()))
     ctx.n_adj = float(n_adj)
-    ctx.target = torch.from_numpy(target.reshape(-1)).to(dev)
-    ctx.match_g = torch.from_numpy(match_g.reshape(-1)).to(dev)
+    both = _lib.upload(np.stack([target.reshape(-1), match_g.reshape(-1)]), dev)
+    ctx.target, ctx.match_g = both[0], both[1]
     ctx.ldg = (P + 3) // 4 * 4
     ctx.dlogits = torch.zeros((B * Q, ctx.ldg), dtype=torch.float32, device=dev)
     ctx.datt = torch.empty_like(ctx.att)
     ctx.loss = torch.zeros((3,), dtype=torch.float32, device=dev)
     loss_grad(model, engine, ctx, 1.0, 1.0, 1.0)
+    mark("fwd: targets upload + loss launch")
     return ctx.loss.clone(), ctx
 
 
@@ -147,33 +199,38 @@ def grad_scale(*seeds, target_log2=3):
     return 2.0 ** (target_log2 - math.ceil(math.log2(amax)))
 
 
+def grad_scale_device(*seeds, target_log2=3):
+    """``grad_scale`` without the host sync: the power of two as a 0-dim device tensor"""
+    seeds = [t for t in seeds if t is not None and t.numel()]
+    if not seeds or os.environ.get("BIGC_GRAD_SCALE", "1") == "0":
+        return None
+    amax = torch.stack([t.abs().max() for t in seeds]).max()
+    ok = torch.isfinite(amax) & (amax > 0)
+    return torch.where(ok, torch.exp2(target_log2 - torch.ceil(torch.log2(torch.where(ok, amax, torch.ones_like(amax))))), torch.ones_like(amax))
+
+
 def backward(model, engine, ctx, grad_terms, named_params):
     """Runs the HIP backward; returns one gradient tensor per entry of ``named_params`` (views of a single flat
     buffer -- the message of the data-parallel all-reduce), ``None`` for frozen parameters."""
+    mark("autograd glue between forward and backward")
     g = [float(x) for x in grad_terms.detach().cpu().tolist()]
+    mark("bwd: WAIT for the upstream gradient (.cpu())")
     loss_grad(model, engine, ctx, g[0], g[1], g[2])
     # The backward GEMMs split their f32 operands into two f16 (csrc/linear_split.hip): exact for magnitudes inside the
     # f16 range, so the seed gradients are brought to a magnitude of ~8 by a power of two (exact) and the parameter
     # gradients scaled back at the end -- the loss scaling of mixed-precision training, here only to keep f32 accuracy.
-    scale = grad_scale(ctx.dlogits, ctx.datt)
-    if scale != 1.0:
+    scale = grad_scale_device(ctx.dlogits, ctx.datt)      # (a device scalar: the step does not wait for it)
+    if scale is not None:
         ctx.dlogits.mul_(scale)
         ctx.datt.mul_(scale)
     trainable = [(k, p) for k, p in named_params if p.requires_grad]
-    total = sum(p.numel() for _, p in trainable)
-    flat = torch.zeros((total,), dtype=torch.float32, device=ctx.packed.device)
-    views, off = {}, 0
-    for k, p in trainable:
-        n = p.numel()
-        assert off % 4 == 0 or True
-        views[k] = flat[off:off + n].view_as(p)
-        _lib.check(engine.lib.bigc_set_grad(engine.handle, k.encode(), views[k].data_ptr()))
-        off += n
+    flat, views = engine.flat_gradients(trainable, ctx.packed.device)
+    mark("bwd: seed scaling + flat gradient buffer")
     _lib.check(engine.lib.bigc_train_backward(engine.handle, _lib.current_stream(), ctypes.byref(ctx.batch), ctx.ws.data_ptr(),
                                               ctx.ws.numel(), ctx.dlogits.data_ptr(), ctx.ldg, ctx.datt.data_ptr()))
-    if scale != 1.0:
-        flat.mul_(1.0 / scale)
-    engine.last_flat_grad = flat
+    mark("bwd: bigc_train_backward launches")
+    if scale is not None:
+        flat.div_(scale)                                   # a power of two: exact
     return [views.get(k) for k, _ in named_params]
 
 
@@ -183,6 +240,7 @@ class HipTrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, packed, gt_graph_list, *params):
         engine = model.engine()
+        mark("register parameters + finalize")
         # dropout follows the module's training flag like the reference's nn.Dropout / nn.MultiheadAttention(dropout=0.1)
         # (models/model_0v10.py:320,326); the per-step seed comes from the global torch RNG
         drop_p = float(getattr(model, "dropout_p", 0.1)) if model.training else 0.0

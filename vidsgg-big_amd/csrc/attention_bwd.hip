@@ -313,7 +313,10 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallGemmArgs p) 
     const int n_role = p.mode == SG_DENCO ? 1 : 2;
     const int n_rt = (p.max_rows + 31) / 32;
     const int n_cc = p.n_cc;       // 128-column chunks (host: from the largest column count over the videos)
-    const long item = (long)blockIdx.x * 4 + wave;
+    // one workgroup per tile; its four waves split the reduction range and meet in LDS (these products are a few hundred waves
+    // of dependent f32 MFMAs in total: what they need is more waves, not more flops per wave)
+    __shared__ float red[3][4][16][64];
+    const long item = blockIdx.x;
     if (item >= (long)p.n_vid * n_role * n_rt * n_cc) return;
     const int cc = item % n_cc;
     const int rt = (item / n_cc) % n_rt;
@@ -357,24 +360,47 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallGemmArgs p) 
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = zero16();
     const int j0 = cc * 128;
+    size_t joff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) joff[t] = (size_t)min(j0 + t * 32 + l31, n - 1) * sb_j;
+    // The loop is a chain of dependent load -> MFMA steps on a handful of waves per video: what it costs is load latency, so
+    // each round issues the loads of SG_U k-pairs (5 per pair) before the first MFMA consumes any.
+    constexpr int SG_U = 8;
+    const int kq = ((kdim + 3) / 4 + 1) / 2 * 2;            // this wave's share of the reduction range (even: k pairs)
+    const int kb = wave * kq, ke = min(kdim, kb + kq);
+    int nt = 0;                                             // live 32-column tiles of this 128-column chunk
+#pragma unroll
+    for (int t = 0; t < 4; ++t) nt += (j0 + t * 32 < n) ? 1 : 0;
     for (int pass = 0; pass < n_pass; ++pass) {
-        const float* Ap = A + (p.mode == SG_DENCO ? (size_t)pass * nq * ne : 0);
+        const float* Ap = A + (p.mode == SG_DENCO ? (size_t)pass * nq * ne : 0) + (size_t)irow * sa_i;
         const float* Bp = B + (p.mode == SG_DENCO ? (size_t)pass * p.n_vid * nq * p.lde : 0);
-        for (int k2 = 0; k2 < kdim; k2 += 2) {
-            const int kk = k2 + hi;
-            const bool kok = kk < kdim;
+        for (int k2 = kb; k2 < ke; k2 += 2 * SG_U) {
             // loads are unconditional from clamped addresses (a predicated load serialises load -> wait -> MFMA): a = 0
             // cancels the k tail, columns j >= n are never stored
-            const float a_raw = Ap[(size_t)irow * sa_i + (size_t)min(kk, kdim - 1) * sa_k];
-            const float a = (iok && kok) ? a_raw : 0.f;
-            const float* bp = Bp + (size_t)min(kk, kdim - 1) * sb_k;
+            float a[SG_U], b[SG_U][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int j = min(j0 + t * 32 + l31, n - 1);
-                acc[t] = mfma32(a, bp[(size_t)j * sb_j], acc[t]);
+            for (int u = 0; u < SG_U; ++u) {
+                const int kk = k2 + 2 * u + hi, kc = min(kk, kdim - 1);
+                const float a_raw = Ap[(size_t)kc * sa_k];
+                a[u] = (iok && kk < ke) ? a_raw : 0.f;
+                const float* bp = Bp + (size_t)kc * sb_k;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (t < nt) b[u][t] = bp[joff[t]];
             }
+#pragma unroll
+            for (int u = 0; u < SG_U; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (t < nt) acc[t] = mfma32(a[u], b[u][t], acc[t]);
         }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave - 1][t][r][lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int j = j0 + t * 32 + l31;
@@ -383,8 +409,9 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallGemmArgs p) 
         for (int r = 0; r < 16; ++r) {
             const int i = rt * 32 + mfma_row(r, hi);
             if (i >= m) continue;
+            const float v = ((acc[t][r] + red[0][t][r][lane]) + red[1][t][r][lane]) + red[2][t][r][lane];
             float* cp = C + (size_t)i * sc_i + j;
-            *cp = accumulate ? *cp + acc[t][r] : acc[t][r];
+            *cp = accumulate ? *cp + v : v;
         }
     }
 }
@@ -471,7 +498,7 @@ extern "C" int bigc_role_small_gemm_f32(void* stream, int mode, const float* att
     p.n_cc = cdiv(cols, 128);
     const long items = (long)n_vid * n_role * cdiv(rows, 32) * p.n_cc;
     ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((int)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((int)items), dim3(256), 0, (hipStream_t)stream, p);
     BIGC_LAUNCH_CHECK("role_small_gemm");
     return BIGC_OK;
 }

@@ -7,6 +7,8 @@
 // stretched-conv gather-sum, head scatter, periodic reduction for the shared query/pos embeddings).
 #include "common.h"
 #include "prof.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -33,8 +35,38 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 struct DwArgs {
     const float* dY; int ldy; const float* X; int ldx; const int32_t* x_idx; int nseg; int seg_len;
     float* dW; int ldw; float* db; int M, N, K; int tiles_n, tiles_k, m_chunk;
-    float* partial;        // when the M range is split: (splits, tiles_n*128, tiles_k*128) partial products, summed by a second kernel
+    float* partial;        // when the M range is split: (splits, tiles_n*128, tiles_k*128) partial products
+    int* arrived;          // per tile: how many of its splits have stored their partial product (nullptr: a second kernel sums them)
+    int splits;
 };
+
+// Split-M tiles without a second launch: every workgroup stores its partial tile, and the one that arrives LAST at a tile adds
+// all of them to dW in split order -- which workgroup does the summing varies from run to run, the order of the sum does not, so
+// the gradients stay bit-reproducible (no float atomics).  The counter is left at zero for the next launch.
+__device__ __forceinline__ void dw_finish_tile(const DwArgs& p, int tile, int n0, int k0) {
+    __shared__ int s_last;
+    __threadfence();                        // partial tile visible device-wide before the arrival is counted
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&p.arrived[tile], 1) == p.splits - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                        // acquire: the other workgroups' partial tiles
+    const size_t k_pad = (size_t)p.tiles_k * 128, plane = (size_t)p.tiles_n * 128 * k_pad;
+    for (int i = threadIdx.x; i < 128 * 32; i += 256) {
+        const int row = n0 + i / 32, col = k0 + (i % 32) * 4;
+        if (row >= p.N || col >= p.K) continue;
+        const float* src = p.partial + (size_t)row * k_pad + col;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < p.splits; ++sp) {
+            const f32x4 v = *(const f32x4*)(src + (size_t)sp * plane);
+            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+        }
+        float* dst = p.dW + (size_t)row * p.ldw + col;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (col + c < p.K) dst[c] += acc[c];
+    }
+    if (threadIdx.x == 0) p.arrived[tile] = 0;
+}
 
 __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2][128 * PITCH];   // [dY^T tile | X^T tile], each [128][32(m)+pad]
@@ -117,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
                 else p.dW[(size_t)row * p.ldw + col] += acc[a][b][r];      // one workgroup per tile: a single writer per element
             }
         }
+    if (p.partial && p.arrived) dw_finish_tile(p, tile, n0, k0);
 }
 
 // The same product on the f16 matrix cores with exactly split f32 operands (see linear_split.hip): both operands are
@@ -297,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void linear_dw_split_kernel(const DwArgs p)
                 else p.dW[(size_t)row * p.ldw + col] += v;
             }
         }
+    if (p.partial && p.arrived) dw_finish_tile(p, tile, n0, k0);
 }
 
 // dW[n, k] += sum over the M splits of their partial products (no atomics: summation order is fixed -> deterministic gradients)
@@ -609,7 +643,7 @@ extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const 
     if (splits < 1) splits = 1;
     p.m_chunk = cdiv(cdiv(M, splits), 32) * 32;
     splits = cdiv(M, p.m_chunk);
-    p.partial = nullptr;
+    p.partial = nullptr; p.arrived = nullptr;
     const size_t n_pad = (size_t)p.tiles_n * 128, k_pad = (size_t)p.tiles_k * 128;
     if (splits > 1) {
         // stream-ordered scratch, grown on demand (one stream per process in this library's use)
@@ -622,14 +656,28 @@ extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const 
             if (hipMalloc((void**)&scratch, cap * sizeof(float)) != hipSuccess) { scratch = nullptr; cap = 0; return bigc_fail(BIGC_ERR_HIP, "linear_dw: hipMalloc of the split scratch failed"); }
         }
         p.partial = scratch;
+        // arrival counters of the in-kernel reduction (zero between launches)
+        static int* arrived = nullptr;
+        // (measured, 8-video training step: the in-kernel form costs 99 us per launch against 19 + 6 us for the two launches --
+        // every workgroup pays a device-scope release, an L2 write-back on this chip -- so it is the opt-in, BIGC_DW_REDUCE=inline)
+        static const bool two_launches = !(getenv("BIGC_DW_REDUCE") && !strcmp(getenv("BIGC_DW_REDUCE"), "inline"));
+        constexpr int ARRIVED_CAP = 16384;
+        if (!arrived && !two_launches) {
+            if (hipMalloc((void**)&arrived, ARRIVED_CAP * sizeof(int)) != hipSuccess || hipMemsetAsync(arrived, 0, ARRIVED_CAP * sizeof(int), (hipStream_t)stream) != hipSuccess) {
+                arrived = nullptr;
+                return bigc_fail(BIGC_ERR_HIP, "linear_dw: hipMalloc of the arrival counters failed");
+            }
+        }
+        p.arrived = (!two_launches && tiles <= ARRIVED_CAP) ? arrived : nullptr;
     }
+    p.splits = splits;
     {
         ProfScope ps(stream, FAM_LINEAR_DW, 2.0 * M * (double)N * K, 4.0 * ((double)M * N + (double)M * K + (double)N * K));
         if (bigc_linear_get_exact()) hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
         else if (x_idx) hipLaunchKernelGGL(linear_dw_split_kernel<true>, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(linear_dw_split_kernel<false>, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
         BIGC_LAUNCH_CHECK("linear_dw");
-        if (splits > 1) {
+        if (splits > 1 && !p.arrived) {
             hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for((long)N * K)), dim3(256), 0, (hipStream_t)stream, p.partial, dW, ldw, N, K, (int)n_pad,
                                (int)k_pad, splits);
             BIGC_LAUNCH_CHECK("dw_reduce");

@@ -469,6 +469,7 @@ extern "C" void grd_destroy(grd_model* m) {
 extern "C" int grd_set_param(grd_model* m, const char* key, const float* ptr, int64_t numel) {
     BIGC_CHECK_ARG(m && key && ptr && numel > 0, "grd_set_param: bad argument");
     BIGC_CHECK_ARG(((uintptr_t)ptr & 15) == 0, "grd_set_param: '%s' is not 16-byte aligned", key);
+    { auto it = m->params.find(key); if (it == m->params.end() || it->second.first != ptr) m->train_jobs.clear(); }
     m->params[key] = std::make_pair(ptr, numel);
     m->finalized = false;
     return BIGC_OK;

@@ -20,4 +20,5 @@ struct grd_model {
     float* wq = nullptr;   // (d, kq) owned: [query_fc.weight | temp_fc.weight | 0 0]
     float* bq = nullptr;   // (d) owned: query_fc.bias + temp_fc.bias
     int kq = 0;
+    std::vector<SplitJob> train_jobs;  // as bigc_model::train_jobs
 };

@@ -415,9 +415,9 @@ struct GBwd {
     int dx(const float* W, const float* dY, int ldy, int M, int N, int K, float* dX, int lddx, bool acc) {
         const int n4 = round4(N);
         BIGC_CHECK_ARG(ldy % 4 == 0 && ldy >= n4, "grd_train: dY leading dimension %d must be a multiple of 4 and >= %d", ldy, n4);
-        TRY(bigc_transpose_pad((hipStream_t)s, W, w->wT, N, K, n4));
-        StaticWeights transposed_copy(0);      // w->wT is rewritten for every layer
-        return bigc_linear_f32(s, dY, ldy, nullptr, 1, n4, w->wT, n4, nullptr, acc ? dX : nullptr, lddx, dX, lddx, M, K, n4, BIGC_ACT_NONE);
+        const float* wT = nullptr;             // cached per weights epoch, refreshed by the step's batched preparation
+        TRY(bigc_weight_transposed((hipStream_t)s, W, N, K, K, &wT));
+        return bigc_linear_f32(s, dY, ldy, nullptr, 1, n4, wT, n4, nullptr, acc ? dX : nullptr, lddx, dX, lddx, M, K, n4, BIGC_ACT_NONE);
     }
     int lin(const std::string& key, const Lin& L, const float* dY, int ldy, const float* X, int ldx, int M, int N, int K, float* dX, int lddx,
             bool acc, bool bias = true) {
@@ -526,6 +526,7 @@ extern "C" int grd_train_forward(grd_model* m, void* stream, const float* video_
                                  float video_len, const float* pos_video, const float* pos_query, void* workspace, size_t workspace_bytes,
                                  float* regrs, float* conf, float* cls) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && video_feat && quint && dura && pos_video && pos_query && regrs && conf && cls, "grd_train_forward: null pointer");
     BIGC_CHECK_ARG(m->finalized && T > 0 && T <= 2048 && n > 0 && video_len > 0, "grd_train_forward: bad argument");
     const grd_config& c = m->cfg;
@@ -533,6 +534,7 @@ extern "C" int grd_train_forward(grd_model* m, void* stream, const float* video_
     GTW w;
     TRY(open_ws(m, T, n, workspace, workspace_bytes, w));
     void* s = stream;
+    TRY(bigc_linear_prepare((hipStream_t)stream, m->train_jobs.data(), (int)m->train_jobs.size()));
     TRY(grd_query_input((hipStream_t)stream, m->enti, m->pred, quint, dura, video_len, w.qin, n, c.dim_clsme, m->kq));
     Lin qlin{m->wq, m->bq};
     TRY(linear(s, w.qin, m->kq, qlin, w.qemb, d, 3 * n, d, m->kq, BIGC_ACT_NONE));
@@ -577,6 +579,7 @@ extern "C" int grd_loss_grad(void* stream, const float* regrs, const float* conf
 extern "C" int grd_train_backward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, int n,
                                   void* workspace, size_t workspace_bytes, const float* dregr, const float* dconf, const float* dcls) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && video_feat && quint && dregr && dconf && dcls, "grd_train_backward: null pointer");
     const grd_config& c = m->cfg;
     const int d = c.dim_hidden, k = c.num_bins;

@@ -1,6 +1,7 @@
 // Shared by linear.hip (exact f32 MFMA kernel) and linear_split.hip (f16x3 split-operand MFMA kernel).
 #pragma once
 #include "common.h"
+#include <vector>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -28,6 +29,21 @@ struct StaticWeights {
 // parameter of a model that is destroyed
 void bigc_weight_cache_forget(const float* w);
 void bigc_gemm_ps_cache_forget(const float* w);
+// Batched weight preparation (linear_split.hip).  A training step changes every weight, so every GEMM of the step would launch
+// its own split (and the backward a transpose as well): instead the entry points of the training step record the (weight, shape)
+// pairs their GEMMs asked for in a per-model list and refresh all of them with a handful of launches at the next step's start.
+struct SplitJob { const float* W; int N, K, ldw; int transposed; };
+extern thread_local std::vector<SplitJob>* bigc_split_recorder;      // where stale lookups under a weights epoch are recorded
+struct SplitRecorder {
+    std::vector<SplitJob>* prev;
+    explicit SplitRecorder(std::vector<SplitJob>* r) : prev(bigc_split_recorder) { bigc_split_recorder = r; }
+    ~SplitRecorder() { bigc_split_recorder = prev; }
+};
+// refreshes the stale entries among `jobs` for the current weights epoch (no-op outside a StaticWeights scope)
+int bigc_linear_prepare(hipStream_t s, const SplitJob* jobs, int n);
+// -> *wT = f32 copy of W^T (K, round4(N)), valid for the current weights epoch, with its split form cached under the copy's own
+// key: pass it to bigc_linear_f32 as an (N'=K, K'=round4(N), ldw=round4(N)) weight.  Outside an epoch scope it is rebuilt per call.
+int bigc_weight_transposed(hipStream_t s, const float* W, int N, int K, int ldw, const float** wT);
 // launches the split-operand kernel (and its W pre-split pass); returns BIGC_OK or an error code
 int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double bytes);
 

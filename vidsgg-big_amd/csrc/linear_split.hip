@@ -73,6 +73,62 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
     if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) *bad = bad_id;       // ids are unique per split: no clearing needed
 }
 
+// Batched weight preparation (training: every weight changes every step, and the backward needs W^T as well): one launch
+// splits up to PREP_MAX weights.  A direct job does what split_weight_kernel does; a transposed job reads W (N, K), and writes
+// W^T padded to n4 = round4(N) columns both as f32 (K, n4) -- the operand of the exact kernel and of the range fallback -- and
+// split (K, n4/4 groups).
+constexpr int PREP_MAX = 48;
+struct PrepJob { const float* W; u32x4* Ws; float* wT; int* bad; int N, K, ldw, bad_id, blk0, nblk, transposed, pad; };
+struct PrepArgs { int n; int pad; PrepJob j[PREP_MAX]; };
+
+__global__ __launch_bounds__(256) void weight_prep_kernel(const PrepArgs a) {
+    __shared__ float tile[64][65];
+    int ji = 0;
+    while (ji + 1 < a.n && (int)blockIdx.x >= a.j[ji + 1].blk0) ++ji;
+    const PrepJob& J = a.j[ji];
+    const int lb = (int)blockIdx.x - J.blk0, tid = threadIdx.x;
+    float chk = 0.f, amax = 0.f;
+    if (!J.transposed) {
+        const int K4 = (J.K + 3) / 4;
+        const long total = (long)J.N * K4;
+        for (long i = (long)lb * 256 + tid; i < total; i += (long)J.nblk * 256) {
+            const int n = (int)(i / K4), k4 = (int)(i - (long)n * K4);
+            const f32x4 x = *(const f32x4*)(J.W + (size_t)n * J.ldw + 4 * k4);
+            uint2 h, r;
+            split4(x, h, r, chk, amax);
+            J.Ws[i] = u32x4{h.x, h.y, r.x, r.y};
+        }
+    } else {
+        // output rows n' = 0..K-1 (columns of W), output columns k' = 0..n4-1 (rows of W, zero beyond N)
+        const int n4 = (J.N + 3) / 4 * 4, K4o = n4 / 4;
+        const int tr = (J.K + 63) / 64, tc = (n4 + 63) / 64;
+        for (int t = lb; t < tr * tc; t += J.nblk) {
+            const int n0 = (t / tc) * 64, k0 = (t % tc) * 64;
+            __syncthreads();
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int idx = tid + 256 * i, kk = idx >> 6, nn = idx & 63;
+                const int row = k0 + kk, col = n0 + nn;
+                tile[kk][nn] = (row < J.N && col < J.K) ? J.W[(size_t)row * J.ldw + col] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int item = tid + 256 * i, k4l = item & 15, nn = item >> 4;
+                const int orow = n0 + nn, ok4 = k0 / 4 + k4l;
+                if (orow < J.K && ok4 < K4o) {
+                    const f32x4 x = {tile[4 * k4l][nn], tile[4 * k4l + 1][nn], tile[4 * k4l + 2][nn], tile[4 * k4l + 3][nn]};
+                    uint2 h, r;
+                    split4(x, h, r, chk, amax);
+                    J.Ws[(size_t)orow * K4o + ok4] = u32x4{h.x, h.y, r.x, r.y};
+                    *(f32x4*)(J.wT + (size_t)orow * n4 + 4 * ok4) = x;
+                }
+            }
+        }
+    }
+    if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) *J.bad = J.bad_id;
+}
+
 __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((row >> 2) & 3); }
 
 // WN = wave columns: 2 -> 128x128 tile, 256 threads, two workgroups per CU; 4 -> 128x256 tile, 512 threads (one workgroup
@@ -351,6 +407,89 @@ int ensure_split(hipStream_t s, const LinearArgs& p, int K4, WEntry& e, bool fre
     return BIGC_OK;
 }
 
+
+// transposed f32 copies of weights (K, round4(N)), one per (pointer, shape); their split form lives in g_cache under the key of
+// the copy itself, so the ordinary launch path finds it
+struct TEntry { float* wT = nullptr; size_t cap = 0; unsigned long long epoch = 0; };
+std::unordered_map<WKey, TEntry, WKeyHash> g_tcache;
+std::atomic<int> g_bad_seq{1 << 20};
+
+int reserve_split(hipStream_t s, WEntry& e, size_t need) {
+    if (need <= e.cap) return BIGC_OK;
+    if (e.mem) {
+        if (hipStreamSynchronize(s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_split: sync failed");
+        (void)hipFree(e.mem);
+    }
+    e.cap = need;
+    if (hipMalloc((void**)&e.mem, e.cap) != hipSuccess || hipMemsetAsync(e.mem, 0, 256, s) != hipSuccess) {
+        e.mem = nullptr; e.cap = 0;
+        return bigc_fail(BIGC_ERR_HIP, "linear_split: hipMalloc of the split weights failed");
+    }
+    return BIGC_OK;
+}
+
+// (caller holds g_cache_mu) refreshes every stale job of `jobs` for `epoch` with as few launches as possible
+int prepare_locked(hipStream_t s, const SplitJob* jobs, int n, unsigned long long epoch) {
+    PrepArgs a;
+    a.n = 0; a.pad = 0;
+    int blocks = 0;
+    double bytes = 0.0;
+    auto flush = [&]() -> int {
+        if (a.n == 0) return BIGC_OK;
+        ProfScope ps((void*)s, FAM_LINEAR_AUX, 0.0, bytes);
+        hipLaunchKernelGGL(weight_prep_kernel, dim3(blocks), dim3(256), 0, s, a);
+        BIGC_LAUNCH_CHECK("weight_prep");
+        a.n = 0; blocks = 0; bytes = 0.0;
+        return BIGC_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+        const SplitJob& q = jobs[i];
+        PrepJob J;
+        J.W = q.W; J.N = q.N; J.K = q.K; J.ldw = q.ldw; J.transposed = q.transposed ? 1 : 0; J.pad = 0; J.wT = nullptr;
+        WEntry* e;
+        long work;
+        if (!q.transposed) {
+            e = &g_cache[WKey{q.W, q.N, q.K, q.ldw}];
+            if (epoch != 0 && e->epoch == epoch) continue;
+            const int K4 = (q.K + 3) / 4;
+            int rc = reserve_split(s, *e, 256 + (size_t)q.N * K4 * sizeof(u32x4));
+            if (rc != BIGC_OK) return rc;
+            work = ((long)q.N * K4 + 1023) / 1024;
+        } else {
+            TEntry& t = g_tcache[WKey{q.W, q.N, q.K, q.ldw}];
+            const int n4 = (q.N + 3) / 4 * 4;
+            if (epoch != 0 && t.epoch == epoch && t.wT) continue;
+            const size_t need = (size_t)q.K * n4;
+            if (need > t.cap) {
+                if (t.wT) {
+                    if (hipStreamSynchronize(s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_split: sync failed");
+                    auto sp = g_cache.find(WKey{t.wT, q.K, n4, n4});
+                    if (sp != g_cache.end()) { if (sp->second.mem) (void)hipFree(sp->second.mem); g_cache.erase(sp); }
+                    (void)hipFree(t.wT);
+                }
+                if (hipMalloc((void**)&t.wT, need * sizeof(float)) != hipSuccess) { t.wT = nullptr; t.cap = 0; return bigc_fail(BIGC_ERR_HIP, "linear_split: hipMalloc of a transposed weight failed"); }
+                t.cap = need;
+            }
+            t.epoch = epoch;
+            e = &g_cache[WKey{t.wT, q.K, n4, n4}];
+            int rc = reserve_split(s, *e, 256 + (size_t)q.K * (n4 / 4) * sizeof(u32x4));
+            if (rc != BIGC_OK) return rc;
+            J.wT = t.wT;
+            work = (long)((q.K + 63) / 64) * ((n4 + 63) / 64);
+        }
+        e->epoch = epoch;
+        e->bad_id = ++g_bad_seq;
+        J.Ws = (u32x4*)(e->mem + 256); J.bad = (int*)e->mem; J.bad_id = e->bad_id;
+        J.nblk = (int)(work < 1 ? 1 : (work > 256 ? 256 : work));
+        J.blk0 = blocks;
+        blocks += J.nblk;
+        bytes += 8.0 * q.N * (double)q.K * (q.transposed ? 1.5 : 1.0);
+        a.j[a.n++] = J;
+        if (a.n == PREP_MAX) { int rc = flush(); if (rc != BIGC_OK) return rc; }
+    }
+    return flush();
+}
+
 }  // namespace
 
 void bigc_weight_cache_forget(const float* w) {
@@ -365,11 +504,58 @@ void bigc_weight_cache_forget(const float* w) {
             }
         }
     }
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        for (auto it = g_tcache.begin(); it != g_tcache.end();) {
+            if (it->first.w == w) {
+                if (it->second.wT) {
+                    (void)hipDeviceSynchronize();
+                    const int n4 = (it->first.n + 3) / 4 * 4;
+                    auto sp = g_cache.find(WKey{it->second.wT, it->first.k, n4, n4});
+                    if (sp != g_cache.end()) { if (sp->second.mem) (void)hipFree(sp->second.mem); g_cache.erase(sp); }
+                    (void)hipFree(it->second.wT);
+                }
+                it = g_tcache.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
     bigc_gemm_ps_cache_forget(w);
 }
 
 thread_local unsigned long long bigc_static_weights_epoch = 0;
 unsigned long long bigc_next_weights_epoch() { return ++g_epoch_seq; }
+thread_local std::vector<SplitJob>* bigc_split_recorder = nullptr;
+
+static void record_job(const SplitJob& q) {
+    if (!bigc_split_recorder) return;
+    for (const SplitJob& o : *bigc_split_recorder)
+        if (o.W == q.W && o.N == q.N && o.K == q.K && o.ldw == q.ldw && o.transposed == q.transposed) return;
+    bigc_split_recorder->push_back(q);
+}
+
+int bigc_linear_prepare(hipStream_t s, const SplitJob* jobs, int n) {
+    if (n <= 0 || bigc_static_weights_epoch == 0) return BIGC_OK;
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    return prepare_locked(s, jobs, n, bigc_static_weights_epoch);
+}
+
+int bigc_weight_transposed(hipStream_t s, const float* W, int N, int K, int ldw, const float** wT) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    const SplitJob q{W, N, K, ldw, 1};
+    const unsigned long long epoch = bigc_static_weights_epoch;
+    auto it = g_tcache.find(WKey{W, N, K, ldw});
+    if (epoch == 0 || it == g_tcache.end() || it->second.epoch != epoch || !it->second.wT) {
+        int rc = prepare_locked(s, &q, 1, epoch);
+        if (rc != BIGC_OK) return rc;
+        if (epoch != 0) record_job(q);
+        it = g_tcache.find(WKey{W, N, K, ldw});
+    }
+    *wT = it->second.wT;
+    return BIGC_OK;
+}
+
 
 int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double bytes) {
     const int K4 = (p.K + 3) / 4;
@@ -386,6 +572,7 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
             int rc = ensure_split(s, p, K4, *e, epoch == 0);
             if (rc != BIGC_OK) return rc;
             e->epoch = epoch;
+            if (epoch != 0) record_job(SplitJob{p.W, p.N, p.K, p.ldw, 0});
         }
         p.Ws = (const u32x4*)(e->mem + 256); p.ldws = K4; p.wbad = (const int*)e->mem; p.wbad_id = e->bad_id;
     }
@@ -409,7 +596,9 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
     // 128x256 tiles (eight waves share one split of the A slab) unless the last column tile would be mostly empty:
     // 277 vs 260 TFLOP/s over the benchmark step's GEMMs (benchmarks/linear_shapes.py)
     const int rem = p.N % 256;
-    const int wn = force_wn ? (force_wn == 4 ? 4 : 2) : ((p.N > 192 && (rem == 0 || rem > 128)) ? 4 : 2);
+    // ... and unless that leaves half the chip idle (training-step sizes: 1536 x 512 is 24 wide tiles; 23 vs 28 us per launch)
+    const bool few = (long)p.tiles_m * cdiv(p.N, 256) <= 128;
+    const int wn = force_wn ? (force_wn == 4 ? 4 : 2) : ((p.N > 192 && (rem == 0 || rem > 128) && !few) ? 4 : 2);
     p.tiles_n = cdiv(p.N, 64 * wn);
     const int grid2 = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
 #define LAUNCH_SPLIT(G, T, W) hipLaunchKernelGGL((linear_split_kernel<G, T, W>), dim3(grid2), dim3(128 * W), 0, s, p)

@@ -181,6 +181,8 @@ extern "C" void bigc_destroy(bigc_model* m) {
 extern "C" int bigc_set_param(bigc_model* m, const char* key, const float* ptr, int64_t numel) {
     BIGC_CHECK_ARG(m && key && ptr && numel > 0, "set_param: bad argument");
     BIGC_CHECK_ARG(((uintptr_t)ptr & 15) == 0, "set_param: '%s' is not 16-byte aligned", key);
+    auto it = m->params.find(key);
+    if (it == m->params.end() || it->second.first != ptr) m->train_jobs.clear();    // recorded jobs may name the old buffer
     m->params[key] = std::make_pair(ptr, numel);
     m->finalized = false;
     return BIGC_OK;

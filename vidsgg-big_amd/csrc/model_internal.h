@@ -28,6 +28,7 @@ struct bigc_model {
     float* role_cat = nullptr;         // per decoder layer: [W_role0.2 | W_role1.2] (dp, 2 dp) then b_role0.2 + b_role1.2 (dp), owned
     float* conv_w_bwd = nullptr;       // (2de, 3*de), owned (training)
     int head_k = 0;
+    std::vector<SplitJob> train_jobs;  // (weight, shape) pairs the training step's GEMMs asked for: refreshed in one batch per step (linear_internal.h)
 };
 
 struct Arena {

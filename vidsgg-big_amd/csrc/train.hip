@@ -167,9 +167,16 @@ struct Bwd {
         return BIGC_OK;
     }
     // dX[M,K] (=|+=) dY[M,N] W[N,K] through a transposed, 4-padded copy of W
-    int dx(const float* W, const float* dY, int ldy, int M, int N, int K, float* dX, int lddx, bool accumulate) {
+    // (`parameter`: W is a model parameter, constant for the weights epoch: its transposed copy and split form are cached and
+    // refreshed in the step's batched preparation; other buffers are transposed per call)
+    int dx(const float* W, const float* dY, int ldy, int M, int N, int K, float* dX, int lddx, bool accumulate, bool parameter = true) {
         const int n4 = round4(N);
         BIGC_CHECK_ARG(ldy % 4 == 0 && ldy >= n4, "train: dY leading dimension %d must be a multiple of 4 and >= %d", ldy, n4);
+        if (parameter) {
+            const float* wT = nullptr;
+            TRY(bigc_weight_transposed((hipStream_t)s, W, N, K, K, &wT));
+            return bigc_linear_f32(s, dY, ldy, nullptr, 1, n4, wT, n4, nullptr, accumulate ? dX : nullptr, lddx, dX, lddx, M, K, n4, BIGC_ACT_NONE);
+        }
         TRY(bigc_transpose_pad((hipStream_t)s, W, w->wT, N, K, n4));
         StaticWeights transposed_copy(0);      // w->wT is rewritten for every layer
         return bigc_linear_f32(s, dY, ldy, nullptr, 1, n4, w->wT, n4, nullptr, accumulate ? dX : nullptr, lddx, dX, lddx, M, K, n4,
@@ -253,6 +260,15 @@ extern "C" int bigc_set_grad(bigc_model* m, const char* key, float* ptr) {
     return BIGC_OK;
 }
 
+extern "C" int bigc_rebase_grads(bigc_model* m, float* old_base, float* new_base, int64_t numel) {
+    BIGC_CHECK_ARG(m && old_base && new_base && numel > 0, "rebase_grads: bad argument");
+    for (auto& kv : m->grads) {
+        BIGC_CHECK_ARG(kv.second >= old_base && kv.second < old_base + numel, "rebase_grads: the destination of '%s' is not inside the old buffer", kv.first.c_str());
+        kv.second = new_base + (kv.second - old_base);
+    }
+    return BIGC_OK;
+}
+
 extern "C" size_t bigc_train_workspace_bytes(const bigc_model* m, const bigc_batch* b) {
     if (!m || !b) return 0;
     Arena a{nullptr, (size_t)-1};
@@ -273,6 +289,7 @@ static int open_arena(const bigc_model* m, const bigc_batch* b, void* workspace,
 extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                                   float* pred_logits, float* att_out) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && b && pred_logits && att_out, "train_forward: null pointer");
     BIGC_CHECK_ARG(m->finalized, "train_forward: call bigc_finalize first");
     BIGC_CHECK_ARG(b->n_vid > 0 && b->n_trk > 0 && b->n_rows > 0 && b->n_conv > 0 && b->max_trk > 0 && b->max_trk <= 512, "train_forward: bad batch");
@@ -281,6 +298,7 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
     TRY(open_arena(m, b, workspace, workspace_bytes, w));
     void* s = stream;
     hipStream_t hs = (hipStream_t)stream;
+    TRY(bigc_linear_prepare(hs, m->train_jobs.data(), (int)m->train_jobs.size()));     // every weight changed since the last step: one batched re-split
     const int NT = b->n_trk, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
     const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn, D = c.dim_feat + c.dim_extra, H = c.n_att_head, hd = de / H;
     const float eps = 1e-5f;
@@ -399,6 +417,7 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
 extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                                    const float* dlogits, int ldg, const float* datt) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && b && dlogits && datt, "train_backward: null pointer");
     const bigc_config& c = m->cfg;
     BIGC_CHECK_ARG(ldg == round4(c.num_pred_cats), "train_backward: dlogits must have leading dimension %d (zero padded)", round4(c.num_pred_cats));
@@ -618,6 +637,7 @@ int open_pair_arena(const bigc_model* m, const bigc_batch* b, long n_pairs, void
 extern "C" int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
                                        size_t workspace_bytes, float* pair_logits) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && b && pair_so && pair_logits, "pair_train_forward: null pointer");
     BIGC_CHECK_ARG(m->finalized && m->cfg.variant == 2, "pair_train_forward: needs a finalized pairwise-baseline model");
     BIGC_CHECK_ARG(b->n_vid > 0 && b->n_trk > 0 && b->n_rows > 0 && b->n_conv > 0 && n_pairs > 0, "pair_train_forward: empty batch");
@@ -627,6 +647,7 @@ extern "C" int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_b
     TRY(open_pair_arena(m, b, n_pairs, workspace, workspace_bytes, w, pw));
     void* s = stream;
     hipStream_t hs = (hipStream_t)stream;
+    TRY(bigc_linear_prepare(hs, m->train_jobs.data(), (int)m->train_jobs.size()));     // every weight changed since the last step: one batched re-split
     const int NT = b->n_trk, de = c.dim_enti, df = c.dim_ffn, dc = c.use_clsme ? c.dim_clsme : 0, hk = m->head_k, P = c.num_pred_cats;
     TRY(frontend_train_forward(m, s, b, w));
     const float* W1 = m->head0.w;
@@ -652,6 +673,7 @@ extern "C" int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_b
 extern "C" int bigc_pair_train_backward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
                                         size_t workspace_bytes, const float* dlogits, int ldg) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && b && pair_so && dlogits, "pair_train_backward: null pointer");
     BIGC_CHECK_ARG(m->finalized && m->cfg.variant == 2 && n_pairs > 0, "pair_train_backward: needs a finalized pairwise-baseline model");
     const bigc_config& c = m->cfg;
@@ -688,9 +710,9 @@ extern "C" int bigc_pair_train_backward(bigc_model* m, void* stream, const bigc_
     // d enti2enco = dU W1[:, s_feat] + dV W1[:, o_feat]   (the classemes are inputs / a frozen embedding: no gradient)
     float* gx = w.genco;            // not w.gx: frontend_train_backward uses that one as scratch
     TRY(bigc_copy_cols(hs, m->head0.w + off_se, hk, pw.wblk, de, df, de));
-    TRY(bw.dx(pw.wblk, pw.dU, df, NT, df, de, gx, de, false));
+    TRY(bw.dx(pw.wblk, pw.dU, df, NT, df, de, gx, de, false, false));
     TRY(bigc_copy_cols(hs, m->head0.w + off_oe, hk, pw.wblk, de, df, de));
-    TRY(bw.dx(pw.wblk, pw.dV, df, NT, df, de, gx, de, true));
+    TRY(bw.dx(pw.wblk, pw.dV, df, NT, df, de, gx, de, true, false));
     TRY(frontend_train_backward(m, s, b, w, bw, gx));
     return BIGC_OK;
 }

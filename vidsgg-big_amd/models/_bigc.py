@@ -90,6 +90,7 @@ class BigcBase(nn.Module):
         self._build_head(c)
         self._reset_parameters()
         self._engine = None
+        object.__setattr__(self, "_state_items", None)
 
     # ---- hooks for the two variants -----------------------------------------------------
     def _build_embeddings(self, c):
@@ -134,7 +135,10 @@ class BigcBase(nn.Module):
         from bigc_hip.train_step import HipTrainStep
         assert len(proposal_list) == len(gt_graph_list)
         assert all(p.num_proposals > 0 for p in proposal_list), "videos without proposals are filtered out before training"
+        from bigc_hip.train_step import mark
+        mark("step glue (zero_grad ...)")
         packed = PackedBatch(list(proposal_list), self.pred_query_init.device)
+        mark("pack the batch")
         terms = HipTrainStep.apply(self, packed, list(gt_graph_list), *[p for _, p in self.named_parameters()])
         loss_dict = {"cls_pos": terms[0], "cls_neg": terms[1], "adj": terms[2]}
         return terms.sum(), loss_dict
@@ -142,15 +146,38 @@ class BigcBase(nn.Module):
     def invalidate_weights(self):
         """Call after modifying parameters through ``.data`` (in-place writes that do not bump the tensors' version counter,
         e.g. ``p.data.mul_()`` in hand-written EMA or weight-clipping code): the HIP library keeps split / re-laid-out copies of
-        the weights and otherwise only refreshes them when a parameter moved or its version changed."""
+        the weights and otherwise only refreshes them when a parameter moved or its version changed.  Also call it after
+        REPLACING a parameter, buffer or submodule of a nested module by a new object (``model.decoder_layers[0].fc2 = ...``):
+        the list of parameter tensors is walked once and kept (replacements on the model itself, ``.to()``, ``load_state_dict``
+        and optimizer steps are noticed without it)."""
+        object.__setattr__(self, "_state_items", None)       # also re-walk the module tree (see engine())
         if self._engine is not None:
             self._engine.invalidate_weights()
 
     def engine(self):
         if self._engine is None:
             self._engine = BigcEngine(self.config, self.variant)
-        self._engine.sync_params((k, v) for k, v in self.state_dict(keep_vars=True).items())
+        if self._state_items is None:      # (the walk over ~300 parameters costs 0.4 ms: kept until the module tree changes)
+            self._state_items = list(self.state_dict(keep_vars=True).items())
+        self._engine.sync_params(self._state_items)
         return self._engine
+
+    def __setattr__(self, name, value):
+        if name != "_state_items" and isinstance(value, (torch.Tensor, nn.Module)):
+            object.__setattr__(self, "_state_items", None)          # a parameter / buffer / submodule was replaced
+        super().__setattr__(name, value)
+
+    def _apply(self, fn, *args, **kwargs):
+        object.__setattr__(self, "_state_items", None)              # .to() / .cuda() / .float() may swap the tensors
+        return super()._apply(fn, *args, **kwargs)
+
+    def register_buffer(self, *args, **kwargs):
+        object.__setattr__(self, "_state_items", None)
+        return super().register_buffer(*args, **kwargs)
+
+    def register_parameter(self, *args, **kwargs):
+        object.__setattr__(self, "_state_items", None)
+        return super().register_parameter(*args, **kwargs)
 
     def forward_packed(self, packed, topk=None, keep_intermediates=False):
         """HIP forward on a resident PackedBatch -> dict of padded device tensors (no host sync)."""

@@ -114,11 +114,11 @@ def training_loop(model, data, train_config, output_dir, save_tag, step, rank, w
     (utils/DataParallel.py:80-113), ONE flat gradient all-reduce, ``clip_grad_norm_(5)``, checkpoints in the reference's
     format with the ``module.`` key prefix.  ``step(model, items)`` -> (loss, terms)."""
     import random
-    from bigc_hip.shard import allreduce_gradients, shard_indices
+    from bigc_hip.shard import allreduce_gradients, clip_grad_norm_, shard_indices
     batch_size, total_epoch = train_config["batch_size"], epochs or train_config["total_epoch"]
     n_iter = len(data) // batch_size
     milestones = [int(m * len(data) / batch_size) for m in train_config["epoch_lr_milestones"]]
-    optimizer = torch.optim.Adam(model.parameters(), lr=train_config["initial_lr"])
+    optimizer = torch.optim.Adam(model.parameters(), lr=train_config["initial_lr"], fused=device.type == "cuda")
     scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma=train_config["lr_decay"])
     crt_epoch = 0
     if from_checkpoint:
@@ -142,8 +142,8 @@ def training_loop(model, data, train_config, output_dir, save_tag, step, rank, w
             loss, terms = step(model, mine)
             loss = loss.mean()
             loss.backward()
-            allreduce_gradients(model.parameters(), dist)
-            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=5, norm_type=2)
+            flat = allreduce_gradients(model.parameters(), dist)
+            clip_grad_norm_(model.parameters(), 5, flat=flat)
             optimizer.step()
             scheduler.step()
             if rank == 0 and it % 10 == 0:

@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--exact-steps", type=int, default=3, help="extra steps timed with the exact f32-MFMA GEMM kernel, reported beside (0 = skip)")
     ap.add_argument("--legs", default="vidor,grounding,train", help="extra workloads reported in the same line at N=1 ('' = none)")
     ap.add_argument("--vidor-videos", type=int, default=8)
+    ap.add_argument("--grd-one-video-per-call", action="store_true", help="grounding leg: the reference's one-video forward instead of the batched one")
     return ap.parse_args()
 
 
@@ -363,10 +364,11 @@ def vidor_grounding_legs(args, lib, device, want_vidor, want_grounding):
     n_q = sum(int(j[1].shape[0]) for j in jobs)
 
     def grd_step():
-        last = grd.forward_raw_batch(jobs, 0.9, 0.5, 0.2, 0.8) if hasattr(grd, "forward_raw_batch") else None
-        if last is None:
+        if args.grd_one_video_per_call:
             for clip, quint, dura, vl in jobs:
                 last = grd.forward_raw(clip, quint, dura, vl, 0.9, 0.5, 0.2, 0.8)
+        else:
+            last = grd.forward_raw_batch(jobs, 0.9, 0.5, 0.2, 0.8)[-1]
         last["status"].cpu()
 
     gsteps = 5

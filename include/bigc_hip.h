@@ -390,6 +390,28 @@ int grd_forward(grd_model* m, void* stream, const float* video_feat, int T, cons
                 float score_th, float tiou_th, float bins_th, float nms_th,
                 void* workspace, size_t workspace_bytes, const grd_outputs* out);
 
+/* Several videos per call.  The reference scores one video per forward (models/grd_model_v5.py:196-221, the loop of
+ * tools/eval_vidor.py); every step of it is row-wise or per (query, clip sequence), so the videos of a batch are laid back to
+ * back -- clip rows of all videos (total_T), queries of all videos (n_query), and per query the clips of its video (total_rows =
+ * sum over queries of T of its video) -- and the per-sequence steps (depth-wise convolutions, attention, co-attention, temporal
+ * pooling / NMS) follow the offset tables below.  Results are identical to the per-video calls.  All tables in device memory. */
+typedef struct {
+    int32_t n_vid, n_query, max_T;
+    int64_t total_T, total_rows;
+    const int32_t* vid_row_off;   /* (n_vid + 1) first clip row of every video */
+    const int32_t* q_vid;         /* (n_query) video of every query; queries grouped by video, in video order */
+    const int32_t* q_row_off;     /* (n_query + 1) first combined row of every query */
+    const float* vid_len;         /* (n_vid) video_len in frames */
+} grd_batch;
+size_t grd_batch_workspace_bytes(const grd_model* m, const grd_batch* b);
+/* video_feat (total_T, dim_feat), quint (n_query, 5), dura (n_query, 2); pos_video (>= max_T, d), pos_query (3, d); clip (total_T) =
+ * the videos' linspace(0, 1, T_v) tables back to back; outputs as grd_outputs with n = n_query and n*T -> total_rows, T -> total_T;
+ * status (1 + n_vid): [any, per video] set to 1 where temporal pooling selected no clip (the reference raises there). */
+int grd_forward_batch(grd_model* m, void* stream, const float* video_feat, const grd_batch* b, const int32_t* quint, const int32_t* dura,
+                      const float* pos_video, const float* pos_query, const float* clip,
+                      float score_th, float tiou_th, float bins_th, float nms_th,
+                      void* workspace, size_t workspace_bytes, const grd_outputs* out);
+
 /* ---- grounding scorer, training step (models/grd_model_v5.py:375-389 DEBUG._forward_train) -------------------------
  * One video per call, as the reference loops (:379-385); the loss means run over the whole batch (:444-527), so
  * the host passes the batch-wide element counts to grd_loss_grad.

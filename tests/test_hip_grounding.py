@@ -184,3 +184,47 @@ def test_grounding_empty_and_all_zero_scores():
     info = torch.tensor([[0.1, 0.5], [0.2, 0.9]])
     _, _, _, status = run_postprocess(regrs, neg, neg, info, k, cases.GRD_TH)
     assert status == 1
+
+
+def test_grounding_batch_of_videos_vs_reference_golden_and_vs_one_video_calls():
+    """grd_forward_batch on the three grd_tiny videos (T = 9 / 33 / 2 clips, n = 5 / 1 / 4 queries) in ONE call: every video's
+    result matches the reference golden and is bit-identical to the one-video-per-call forward."""
+    g = np.load(os.path.join(cases.GOLDEN_DIR, "grd_tiny.npz"))
+    cfg, sd, videos = cases.make_grd_case("grd_tiny")
+    model = build_model(cfg, sd)
+    jobs = [(feat.to(DEV), quint, dura, vl) for feat, (quint, dura, vl) in videos]
+    outs = model.forward_raw_batch(jobs, **cases.GRD_TH)
+    torch.cuda.synchronize()
+    assert len(outs) == len(videos)
+    for v, (o, job) in enumerate(zip(outs, jobs)):
+        pre = "v%d_" % v
+        assert int(o["status"].item()) == 0
+        assert np.abs(o["pooled_se"].cpu().numpy() - g[pre + "pooled_se"]).max() < 2e-5
+        assert np.abs(o["bins_probs"].cpu().numpy() - g[pre + "bins_probs"]).max() < 2e-5
+        assert np.array_equal(o["bins_mask"].bool().cpu().numpy(), g[pre + "bins_mask"])
+        one = model.forward_raw(job[0], job[1], job[2], job[3], **cases.GRD_TH)
+        for key in ("pooled_se", "bins_probs", "bins_mask"):
+            assert torch.equal(one[key], o[key]), (v, key)
+
+
+def test_grounding_batch_at_config_g_dims_equals_one_video_calls_and_splits_into_groups():
+    """config G (d=128, 10 bins), 7 videos with T in [2, 125] and n in [1, 40]: batched == per video, bit for bit, also when the
+    engine has to split the list into several calls"""
+    cfg = dict(cases.GRD_CASES["grd_g_n64"]["cfg"])
+    _, sd, _ = cases.make_grd_case("grd_g_n64")
+    model = build_model(dict(cfg, loss_factor=dict(classification=1.0, centerness=1.0, regression=1.0)), sd)
+    rs = np.random.RandomState(5)
+    jobs = []
+    for v, (T, n) in enumerate([(125, 40), (2, 3), (33, 1), (64, 17), (15, 40), (100, 9), (7, 5)]):
+        feat, (quint, dura, vl) = cases.make_grd_inputs(cfg, dict(seed=900 + v, T=T, n=n, video_len=8 * T - int(rs.randint(0, 8))))
+        jobs.append((feat.to(DEV), quint, dura, vl))
+    ones = [model.forward_raw(*j, **cases.GRD_TH) for j in jobs]
+    eng = model.engine()
+    for cap in (eng.BATCH_ROWS, 3000):
+        eng.BATCH_ROWS = cap
+        outs = model.forward_raw_batch(jobs, **cases.GRD_TH)
+        torch.cuda.synchronize()
+        for v, (a, b) in enumerate(zip(ones, outs)):
+            assert int(a["status"].item()) == int(b["status"].item())
+            for key in ("pooled_se", "bins_probs", "bins_mask"):
+                assert torch.equal(a[key], b[key]), (cap, v, key)

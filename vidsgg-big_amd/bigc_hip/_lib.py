@@ -48,6 +48,11 @@ class grd_outputs(ctypes.Structure):
                                         "video_enc", "query_enc", "combined_enc")]
 
 
+class grd_batch(ctypes.Structure):
+    _fields_ = [("n_vid", ctypes.c_int32), ("n_query", ctypes.c_int32), ("max_T", ctypes.c_int32), ("total_T", ctypes.c_int64),
+                ("total_rows", ctypes.c_int64), ("vid_row_off", c_void_p), ("q_vid", c_void_p), ("q_row_off", c_void_p), ("vid_len", c_void_p)]
+
+
 _SIGS = {
     "bigc_last_error": (c_char_p, []),
     "bigc_build_info": (c_char_p, []),
@@ -155,6 +160,9 @@ _SIGS = {
     "grd_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "grd_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                             c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_size_t, POINTER(grd_outputs)]),
+    "grd_batch_workspace_bytes": (c_size_t, [c_void_p, POINTER(grd_batch)]),
+    "grd_forward_batch": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(grd_batch), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_float, c_float, c_float, c_float, c_void_p, c_size_t, POINTER(grd_outputs)]),
     "grd_set_grad": (c_int, [c_void_p, c_char_p, c_void_p]),
     "grd_set_dropout": (c_int, [c_void_p, c_float, ctypes.c_uint32]),
     "grd_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),

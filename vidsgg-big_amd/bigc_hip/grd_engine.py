@@ -103,3 +103,74 @@ class GrdEngine(object):
                                         self._ws.data_ptr(), self._ws.numel(), ctypes.byref(o)))
         out["_keepalive"] = (q32, d32, video_feature)
         return out
+
+    # rows of the combined encoder per call of forward_batch: 8 buffers of (rows, d) + (rows, 4d) + (rows, 3d) f32 ~ 8 KB per row at d=128
+    BATCH_ROWS = 400000
+
+    def forward_batch(self, jobs, score_th, tiou_th, bins_th, nms_th):
+        """Several videos per launch sequence (``grd_forward_batch``).  ``jobs``: list of (video_feature (T,dim_feat) f32 cuda,
+        quint (n,5), dura (n,2), video_len).  -> list of per-video dicts (views of the batch outputs) with the keys of ``forward``;
+        ``status`` is a 1-element view per video.  Videos are grouped into calls of at most ``BATCH_ROWS`` combined rows."""
+        groups, cur, rows = [], [], 0
+        for j in jobs:
+            r = int(j[0].shape[0]) * int(j[1].shape[0])
+            if cur and rows + r > self.BATCH_ROWS:
+                groups.append(cur)
+                cur, rows = [], 0
+            cur.append(j)
+            rows += r
+        if cur:
+            groups.append(cur)
+        out = []
+        for g in groups:
+            out.extend(self._forward_group(g, score_th, tiou_th, bins_th, nms_th))
+        return out
+
+    def _forward_group(self, jobs, score_th, tiou_th, bins_th, nms_th):
+        dev = jobs[0][0].device
+        V = len(jobs)
+        T = np.asarray([int(j[0].shape[0]) for j in jobs], dtype=np.int64)
+        nq = np.asarray([int(j[1].shape[0]) for j in jobs], dtype=np.int64)
+        assert T.min() > 0 and nq.min() > 0, "videos without clips or without queries are filtered out by the caller"
+        Q, total_T, total_rows, max_T = int(nq.sum()), int(T.sum()), int((T * nq).sum()), int(T.max())
+        k, d = self.c.num_bins, self.c.dim_hidden
+        feat = torch.cat([j[0].to(dtype=torch.float32) for j in jobs], 0).contiguous()
+        assert feat.is_cuda and feat.shape[1] == self.c.dim_feat
+        q32 = torch.cat([j[1].to(device=dev, dtype=torch.int32) for j in jobs], 0).contiguous()
+        d32 = torch.cat([j[2].to(device=dev, dtype=torch.int32) for j in jobs], 0).contiguous()
+        q_vid = np.repeat(np.arange(V), nq)
+        tables = [np.concatenate([[0], np.cumsum(T)]), q_vid, np.concatenate([[0], np.cumsum(T[q_vid])])]
+        sizes = [(len(a) + 3) // 4 * 4 for a in tables]
+        starts = np.concatenate([[0], np.cumsum(sizes)])
+        blob = np.zeros((int(starts[-1]),), dtype=np.int32)
+        for a, o in zip(tables, starts):
+            blob[o:o + len(a)] = a
+        blob_d = _lib.upload(blob, dev)
+        vid_row_off, q_vid_d, q_row_off = [blob_d[o:o + len(a)] for a, o in zip(tables, starts)]
+        vlen = _lib.upload(np.asarray([float(j[3]) for j in jobs], dtype=np.float32), dev)
+        pos_v, pos_q, _ = self.tables(max_T, dev)
+        clip = torch.cat([self.tables(int(t), dev)[2] for t in T])
+        b = _lib.grd_batch()
+        b.n_vid, b.n_query, b.max_T, b.total_T, b.total_rows = V, Q, max_T, total_T, total_rows
+        b.vid_row_off, b.q_vid, b.q_row_off, b.vid_len = vid_row_off.data_ptr(), q_vid_d.data_ptr(), q_row_off.data_ptr(), vlen.data_ptr()
+        res = {
+            "pooled_se": torch.empty((Q, k + 1, 2), dtype=torch.float32, device=dev),
+            "bins_probs": torch.empty((Q, k + 1), dtype=torch.float32, device=dev),
+            "bins_mask": torch.empty((Q, k + 1), dtype=torch.uint8, device=dev),
+            "status": torch.zeros((1 + V,), dtype=torch.int32, device=dev),
+        }
+        o = _lib.grd_outputs()
+        for name, _ in _lib.grd_outputs._fields_:
+            setattr(o, name, res[name].data_ptr() if name in res else None)
+        need = self.lib.grd_batch_workspace_bytes(self.handle, ctypes.byref(b))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = None
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _lib.check(self.lib.grd_forward_batch(self.handle, _lib.current_stream(), feat.data_ptr(), ctypes.byref(b), q32.data_ptr(), d32.data_ptr(),
+                                              pos_v.data_ptr(), pos_q.data_ptr(), clip.data_ptr(), float(score_th), float(tiou_th),
+                                              float(bins_th), float(nms_th), self._ws.data_ptr(), self._ws.numel(), ctypes.byref(o)))
+        keep = (feat, q32, d32, blob_d, vlen, clip)
+        qo = np.concatenate([[0], np.cumsum(nq)])
+        return [{"pooled_se": res["pooled_se"][qo[v]:qo[v + 1]], "bins_probs": res["bins_probs"][qo[v]:qo[v + 1]],
+                 "bins_mask": res["bins_mask"][qo[v]:qo[v + 1]], "status": res["status"][1 + v:2 + v], "_batch_status": res["status"],
+                 "_keepalive": keep} for v in range(V)]

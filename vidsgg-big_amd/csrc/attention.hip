@@ -560,6 +560,9 @@ extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, con
                                       float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
                                       int n_head, int hd, float* lse, float drop_p, uint32_t drop_seed, uint32_t drop_site);
 
+int bigc_mha_core_h16_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                             const int32_t* q_off, const int32_t* k_off, int n_seq, int n_qt, int nkt, int n_head, float scale, float* lse,
+                             const DropSpec& drop, int grid, int* flag, int run_id);
 int bigc_mha_core_h_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                            const int32_t* q_off, const int32_t* k_off, int n_seq, int n_qt, int n_head, float scale, float* lse,
                            const DropSpec& drop, int grid, int* flag, int run_id);
@@ -620,6 +623,12 @@ extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, con
         run_flag = mha_flag_slot(run_id);
         if (!run_flag) return BIGC_ERR_HIP;
         bigc_mha_core_h_launch(s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, grid, run_flag, run_id);
+    }
+    if (hd == 16 && nkt <= 8 && !bigc_linear_get_exact()) {
+        run_id = g_mha_run.fetch_add(1, std::memory_order_relaxed) + 1;
+        run_flag = mha_flag_slot(run_id);
+        if (!run_flag) return BIGC_ERR_HIP;
+        bigc_mha_core_h16_launch(s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, nkt, n_head, scale, lse, drop, grid, run_flag, run_id);
     }
     if (hd == 64 && nkt <= 2) LAUNCH_SP(64, 2);
     else if (hd == 64 && nkt <= 6) LAUNCH_SP(64, 6);

@@ -49,13 +49,16 @@ __device__ __forceinline__ void split8(const float (&x)[8], a16x8& h, a16x8& r, 
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
-template <int NKT>
+// HD = 64: four 16-dimension steps per score tile, two 32-column output tiles; HD = 16 (the grounding encoders, 8 heads of
+// d = 128): one step, one output tile whose upper 16 columns are idle.
+template <int NKT, int HD = 64>
 __global__ __launch_bounds__(256, 2) void mha_core_h_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                          const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
                                                          const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
                                                          int n_seq, int n_qt, int n_head, float scale, float* __restrict__ lse,
                                                          const DropSpec drop, int* __restrict__ flag, int run_id) {
-    constexpr int HD = 64;
+    constexpr int NST = HD / 16;                 // 16-dimension steps of a score tile
+    constexpr int NT = HD >= 32 ? HD / 32 : 1;   // 32-column output tiles
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const long item = (long)blockIdx.x * 4 + wave;
@@ -70,12 +73,12 @@ __global__ __launch_bounds__(256, 2) void mha_core_h_kernel(const float* __restr
     const int qrow = min(qt * 32 + l31, nq - 1);
     float chk = 0.f, amax = 0.f;
 
-    // this lane's query row, its four 8-float chunks (head dims 16 s + 8 hi ..), pre-scaled and split
-    a16x8 qh[4], qr[4];
+    // this lane's query row, its 8-float chunks (head dims 16 s + 8 hi ..), pre-scaled and split
+    a16x8 qh[NST], qr[NST];
     {
         const float* qp = q + (size_t)(q0 + qrow) * ldq + h * HD + 8 * hi;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        for (int st = 0; st < NST; ++st) {
             const f32x4 t0 = *(const f32x4*)(qp + 16 * st), t1 = *(const f32x4*)(qp + 16 * st + 4);
             const float x[8] = {t0[0] * scale, t0[1] * scale, t0[2] * scale, t0[3] * scale, t1[0] * scale, t1[1] * scale, t1[2] * scale, t1[3] * scale};
             split8(x, qh[st], qr[st], chk, amax);
@@ -86,16 +89,16 @@ __global__ __launch_bounds__(256, 2) void mha_core_h_kernel(const float* __restr
     f32x16 sc[NKT];
     float m = NEG_BIG;
     const float* kbase = k + (size_t)k0 * ldk + h * HD + 8 * hi;
-    f32x4 ka[8], kb[8];
-    auto fetch_k = [&](int kt, f32x4 (&kv)[8]) {
+    f32x4 ka[2 * NST], kb[2 * NST];
+    auto fetch_k = [&](int kt, f32x4 (&kv)[2 * NST]) {
         const float* kp = kbase + (size_t)min(min(kt, n_kt - 1) * 32 + l31, nk - 1) * ldk;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) { kv[2 * st] = *(const f32x4*)(kp + 16 * st); kv[2 * st + 1] = *(const f32x4*)(kp + 16 * st + 4); }
+        for (int st = 0; st < NST; ++st) { kv[2 * st] = *(const f32x4*)(kp + 16 * st); kv[2 * st + 1] = *(const f32x4*)(kp + 16 * st + 4); }
     };
-    auto score = [&](int kt, const f32x4 (&kv)[8]) {
+    auto score = [&](int kt, const f32x4 (&kv)[2 * NST]) {
         f32x16 c0 = zero16(), c1 = zero16();
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        for (int st = 0; st < NST; ++st) {
             const float x[8] = {kv[2 * st][0], kv[2 * st][1], kv[2 * st][2], kv[2 * st][3], kv[2 * st + 1][0], kv[2 * st + 1][1], kv[2 * st + 1][2], kv[2 * st + 1][3]};
             a16x8 kh, kr;
             split8(x, kh, kr, chk, amax);
@@ -132,19 +135,21 @@ __global__ __launch_bounds__(256, 2) void mha_core_h_kernel(const float* __restr
     const float inv = 1.f / l;
     if (lse && hi == 0 && qt * 32 + l31 < nq) lse[(size_t)(q0 + qt * 32 + l31) * n_head + h] = m + logf(l);
 
-    // ---- O = P V: output column c of d-tile t is head column 2 c + t (one 8-byte load per key row, one 8-byte store per query row)
-    typedef float v2 __attribute__((ext_vector_type(2)));
-    f32x16 o0[2], o1[2];
+    // ---- O = P V: output column c of d-tile t is head column NT c + t (one load per key row, one store per query row); head
+    // widths below 32 leave the lanes past the width on column 0, their results unused
+    struct vrow { float x[NT]; };
+    f32x16 o0[NT], o1[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { o0[t] = zero16(); o1[t] = zero16(); }
-    const float* vbase = v + (size_t)k0 * ldv + h * HD + 2 * l31;
-    v2 va[16], vb[16];
-    auto fetch_v = [&](int kt, v2 (&vv)[16]) {
+    for (int t = 0; t < NT; ++t) { o0[t] = zero16(); o1[t] = zero16(); }
+    const bool col_ok = NT * l31 < HD;
+    const float* vbase = v + (size_t)k0 * ldv + h * HD + (col_ok ? NT * l31 : 0);
+    vrow va[16], vb[16];
+    auto fetch_v = [&](int kt, vrow (&vv)[16]) {
         kt = min(kt, n_kt - 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) vv[r] = *(const v2*)(vbase + (size_t)min(kt * 32 + mfma_row(r, hi), nk - 1) * ldv);
+        for (int r = 0; r < 16; ++r) vv[r] = *(const vrow*)(vbase + (size_t)min(kt * 32 + mfma_row(r, hi), nk - 1) * ldv);
     };
-    auto pv_tile = [&](int kt, const v2 (&vv)[16]) {
+    auto pv_tile = [&](int kt, const vrow (&vv)[16]) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             float p8[8];
@@ -158,10 +163,10 @@ __global__ __launch_bounds__(256, 2) void mha_core_h_kernel(const float* __restr
             float c_ = 0.f, a_ = 0.f;                         // probabilities are in [0, 1 / (1 - p_drop)]: no range check needed
             split8(p8, ph, pr, c_, a_);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 float v8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v8[j] = vv[8 * u + j][t];
+                for (int j = 0; j < 8; ++j) v8[j] = vv[8 * u + j].x[t];
                 a16x8 vh, vr;
                 split8(v8, vh, vr, chk, amax);
                 o0[t] = MFMA_H(ph, vh, o0[t]);
@@ -177,14 +182,15 @@ __global__ __launch_bounds__(256, 2) void mha_core_h_kernel(const float* __restr
         if (kt + 1 < NKT && kt + 1 < n_kt) { fetch_v(kt + 2, va); pv_tile(kt + 1, vb); }
     }
     if (!(fabsf(chk) < INFINITY) || amax >= 32768.0f) atomicMax(flag, run_id);
+    if (!col_ok) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = qt * 32 + mfma_row(r, hi);
         if (row < nq) {
-            v2 ov;
-            ov[0] = o0[0][r] + o1[0][r] * RI;
-            ov[1] = o0[1][r] + o1[1][r] * RI;
-            *(v2*)(o + (size_t)(q0 + row) * ldo + h * HD + 2 * l31) = ov;
+            vrow ov;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ov.x[t] = o0[t][r] + o1[t][r] * RI;
+            *(vrow*)(o + (size_t)(q0 + row) * ldo + h * HD + NT * l31) = ov;
         }
     }
 }
@@ -1241,6 +1247,17 @@ int bigc_mha_core_h_launch(hipStream_t s, const float* q, int ldq, const float* 
     }
     if (n_qt <= 2) hipLaunchKernelGGL(mha_core_h_kernel<2>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
     else if (n_qt <= 6) hipLaunchKernelGGL(mha_core_h_kernel<6>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
+    else return 0;
+    return 1;
+}
+
+// head_dim 16 (self- or cross-attention with at most 8 key tiles): the register kernel above
+int bigc_mha_core_h16_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                             const int32_t* q_off, const int32_t* k_off, int n_seq, int n_qt, int nkt, int n_head, float scale, float* lse,
+                             const DropSpec& drop, int grid, int* flag, int run_id) {
+    if (nkt <= 2) hipLaunchKernelGGL((mha_core_h_kernel<2, 16>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
+    else if (nkt <= 4) hipLaunchKernelGGL((mha_core_h_kernel<4, 16>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
+    else if (nkt <= 8) hipLaunchKernelGGL((mha_core_h_kernel<8, 16>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
     else return 0;
     return 1;
 }

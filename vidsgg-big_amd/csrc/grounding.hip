@@ -40,10 +40,50 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     }
 }
 
+// ---- several videos per call: sequences of different lengths back to back -------------------------------------------------
+// row_info[r] = (position of row r inside its sequence, length of that sequence); one workgroup per sequence
+__global__ __launch_bounds__(256) void seq_rows_kernel(const int32_t* __restrict__ seq_off, int2* __restrict__ row_info) {
+    const int r0 = seq_off[blockIdx.x], T = seq_off[blockIdx.x + 1] - r0;
+    for (int t = threadIdx.x; t < T; t += 256) row_info[r0 + t] = make_int2(t, T);
+}
+
+__global__ __launch_bounds__(256) void dwconv_ragged_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ y, long total4, const int2* __restrict__ row_info, int d4, int ks) {
+    const int half = ks / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long row = i / d4;
+        const int c4 = (int)(i - row * d4);
+        const int2 tT = row_info[row];
+        f32x4 acc = ((const f32x4*)b)[c4];
+        const float* wp = w + (size_t)c4 * 4 * ks;
+        for (int j = 0; j < ks; ++j) {
+            const int tt = tT.x + j - half;
+            if (tt < 0 || tt >= tT.y) continue;
+            const f32x4 xv = ((const f32x4*)x)[(row + (j - half)) * d4 + c4];
+            acc[0] += wp[j] * xv[0];
+            acc[1] += wp[ks + j] * xv[1];
+            acc[2] += wp[2 * ks + j] * xv[2];
+            acc[3] += wp[3 * ks + j] * xv[3];
+        }
+        ((f32x4*)y)[i] = acc;
+    }
+}
+
+// y = x + pos[position of the row in its sequence]
+__global__ __launch_bounds__(256) void add_pos_ragged_kernel(const float* __restrict__ x, const float* __restrict__ pos, float* __restrict__ y,
+                                                             long n4, int d4, const int2* __restrict__ row_info) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long row = i / d4;
+        const int c = (int)(i - row * d4);
+        ((f32x4*)y)[i] = ((const f32x4*)x)[i] + ((const f32x4*)pos)[(size_t)row_info[row].x * d4 + c];
+    }
+}
+
 // rows (3n, kq): [emb(300) | s/len | e/len | 0 0]; word order [subject, predicate, object] (:323)
 __global__ __launch_bounds__(256) void query_input_kernel(const float* __restrict__ enti, const float* __restrict__ pred,
                                                           const int32_t* __restrict__ quint, const int32_t* __restrict__ dura,
-                                                          float video_len, float* __restrict__ out, int n, int de, int kq) {
+                                                          float video_len, const int32_t* __restrict__ q_vid,
+                                                          const float* __restrict__ vid_len, float* __restrict__ out, int n, int de, int kq) {
     const long total = (long)3 * n * kq;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long row = i / kq;
@@ -54,7 +94,7 @@ __global__ __launch_bounds__(256) void query_input_kernel(const float* __restric
             const int id = quint[q * 5 + (l == 0 ? 1 : (l == 1 ? 0 : 2))];
             v = (l == 1 ? pred : enti)[(size_t)id * de + c];
         } else if (c < de + 2) {
-            v = (float)dura[q * 2 + (c - de)] / video_len;       // uniq_dura_inters.float() / video_len (:324)
+            v = (float)dura[q * 2 + (c - de)] / (q_vid ? vid_len[q_vid[q]] : video_len);       // uniq_dura_inters.float() / video_len (:324)
         }
         out[i] = v;
     }
@@ -73,9 +113,10 @@ __global__ void build_query_weight_kernel(const float* __restrict__ wq, const fl
 }
 
 // info (n,2) = dura / video_len
-__global__ void span_info_kernel(const int32_t* __restrict__ dura, float video_len, float* __restrict__ info, int n2) {
+__global__ void span_info_kernel(const int32_t* __restrict__ dura, float video_len, const int32_t* __restrict__ q_vid,
+                                 const float* __restrict__ vid_len, float* __restrict__ info, int n2) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n2) info[i] = (float)dura[i] / video_len;
+    if (i < n2) info[i] = (float)dura[i] / (q_vid ? vid_len[q_vid[i >> 1]] : video_len);
 }
 
 __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
@@ -94,8 +135,18 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) 
 
 // reference: models/grd_model_v5.py:346-365
 __global__ __launch_bounds__(256) void coattention_kernel(const float* __restrict__ video, const float* __restrict__ proj,
-                                                          const float* __restrict__ query, float* __restrict__ out, int T, int d) {
+                                                          const float* __restrict__ query, float* __restrict__ out, int T, int d,
+                                                          const int32_t* __restrict__ q_vid, const int32_t* __restrict__ vid_row_off,
+                                                          const int32_t* __restrict__ q_row_off) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    size_t out_row = (size_t)blockIdx.x * T;
+    if (q_vid) {                    // several videos: this query's video rows, its own T and its place in the output
+        const int v = q_vid[blockIdx.x], r0 = vid_row_off[v];
+        T = vid_row_off[v + 1] - r0;
+        video += (size_t)r0 * d;
+        proj += (size_t)r0 * d;
+        out_row = q_row_off[blockIdx.x];
+    }
     float* q = lds;                 // 3*d
     float* s2 = q + 3 * d;          // 3*d
     float* sim_r = s2 + 3 * d;      // 3*T
@@ -143,7 +194,7 @@ __global__ __launch_bounds__(256) void coattention_kernel(const float* __restric
         s2[e] = acc;
     }
     __syncthreads();
-    float* ob = out + (size_t)i * T * 4 * d;
+    float* ob = out + out_row * 4 * d;
     for (int e = tid; e < T * d; e += 256) {
         const int t = e / d, c = e - t * d;
         const float v = video[e];
@@ -163,14 +214,22 @@ __global__ __launch_bounds__(64) void postprocess_kernel(const float* __restrict
                                                          const float* __restrict__ info, int T, int k, float score_th, float tiou_th,
                                                          float bins_th, float nms_th, float* __restrict__ pooled_se,
                                                          float* __restrict__ bins_probs, uint8_t* __restrict__ bins_mask,
-                                                         int32_t* __restrict__ status) {
+                                                         int32_t* __restrict__ status, const int32_t* __restrict__ q_vid,
+                                                         const int32_t* __restrict__ vid_row_off, const int32_t* __restrict__ q_row_off) {
     __shared__ float sp_s[17], sp_e[17], prob[17];
     __shared__ int ovl[17];
     const int i = blockIdx.x, lane = threadIdx.x;
     const float is = info[2 * i], ie = info[2 * i + 1];
-    const float* cf = conf + (size_t)i * T * k;
-    const float* cl = cls + (size_t)i * T * k;
-    const float* rg = regrs + (size_t)i * T * 2 * k;
+    size_t row0 = (size_t)i * T;
+    if (q_vid) {                    // several videos: clip = the concatenated per-video linspace tables
+        const int v = q_vid[i], r0 = vid_row_off[v];
+        T = vid_row_off[v + 1] - r0;
+        clip += r0;
+        row0 = q_row_off[i];
+    }
+    const float* cf = conf + row0 * k;
+    const float* cl = cls + row0 * k;
+    const float* rg = regrs + row0 * 2 * k;
     for (int b = 0; b < k; ++b) {
         float bv = -INFINITY;
         int bt = 0x7fffffff;
@@ -199,7 +258,7 @@ __global__ __launch_bounds__(64) void postprocess_kernel(const float* __restrict
             pe = fmaxf(pe, __shfl_xor(pe, o));
         }
         if (lane == 0) {
-            if (ps == INFINITY) { status[0] = 1; ps = ts; pe = te; }
+            if (ps == INFINITY) { status[0] = 1; if (q_vid) status[1 + q_vid[i]] = 1; ps = ts; pe = te; }
             const float s = fmaxf(is, ps), e = fminf(ie, pe);
             const bool ov = s <= e;
             sp_s[b] = ov ? s : is; sp_e[b] = ov ? e : ie; ovl[b] = ov; prob[b] = bv;
@@ -255,7 +314,8 @@ int grid_for(long n, int cap = 4096) { long g = (n + 255) / 256; return (int)(g 
 // shared with grounding_train.hip
 int grd_query_input(hipStream_t hs, const float* enti, const float* pred, const int32_t* quint, const int32_t* dura, float video_len,
                     float* out, int n, int de, int kq) {
-    hipLaunchKernelGGL(query_input_kernel, dim3(grid_for((long)3 * n * kq)), dim3(256), 0, hs, enti, pred, quint, dura, video_len, out, n, de, kq);
+    hipLaunchKernelGGL(query_input_kernel, dim3(grid_for((long)3 * n * kq)), dim3(256), 0, hs, enti, pred, quint, dura, video_len, nullptr, nullptr,
+                       out, n, de, kq);
     BIGC_LAUNCH_CHECK("query_input");
     return BIGC_OK;
 }
@@ -277,7 +337,7 @@ extern "C" int grd_coattention_f32(void* stream, const float* video, const float
     if (n <= 0) return BIGC_OK;
     const size_t lds = sizeof(float) * (6 * (size_t)d + 6 * (size_t)T + 4);
     ProfScope ps(stream, FAM_GROUNDING, 0.0, 16.0 * n * (double)T * d);
-    hipLaunchKernelGGL(coattention_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, video, proj, query, out, T, d);
+    hipLaunchKernelGGL(coattention_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, video, proj, query, out, T, d, nullptr, nullptr, nullptr);
     BIGC_LAUNCH_CHECK("coattention");
     return BIGC_OK;
 }
@@ -292,7 +352,7 @@ extern "C" int grd_postprocess(void* stream, const float* regrs, const float* co
     if (n <= 0) return BIGC_OK;
     ProfScope ps(stream, FAM_GROUNDING, 0.0, 0.0);
     hipLaunchKernelGGL(postprocess_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, regrs, conf, cls, clip, info, T, k, score_th, tiou_th,
-                       bins_th, nms_th, pooled_se, bins_probs, bins_mask, status);
+                       bins_th, nms_th, pooled_se, bins_probs, bins_mask, status, nullptr, nullptr, nullptr);
     BIGC_LAUNCH_CHECK("postprocess");
     return BIGC_OK;
 }
@@ -375,26 +435,30 @@ struct GArena {
 struct GWork {
     float *b0, *b1, *b2, *b3, *qkv, *att, *venc, *qenc, *proj, *qin, *comb, *regrs, *conf, *cls, *info;
     int32_t* off;
+    int2 *vinfo, *cinfo;      // several videos per call: (position, length) of every video row / every combined row
 };
 
-bool glayout(const grd_model* m, int T, int n, GArena& a, GWork& w) {
+// total_T = sum of the videos' clip counts, total_rows = sum over queries of their video's clip count (one video: T and n*T)
+bool glayout(const grd_model* m, long total_T, int n, long total_rows, bool ragged, GArena& a, GWork& w) {
     const size_t d = m->cfg.dim_hidden, k = m->cfg.num_bins;
-    size_t rows = (size_t)n * T;
+    size_t rows = (size_t)total_rows;
     if (rows < (size_t)3 * n) rows = (size_t)3 * n;
-    if (rows < (size_t)T) rows = T;
+    if (rows < (size_t)total_T) rows = total_T;
     w.b0 = a.take<float>(rows * d); w.b1 = a.take<float>(rows * d); w.b2 = a.take<float>(rows * d); w.b3 = a.take<float>(rows * d);
     w.qkv = a.take<float>(rows * 3 * d);
     w.att = a.take<float>(rows * d);
-    w.venc = a.take<float>((size_t)T * d);
+    w.venc = a.take<float>((size_t)total_T * d);
     w.qenc = a.take<float>((size_t)3 * n * d);
-    w.proj = a.take<float>((size_t)T * d);
+    w.proj = a.take<float>((size_t)total_T * d);
     w.qin = a.take<float>((size_t)3 * n * m->kq);
-    w.comb = a.take<float>((size_t)n * T * 4 * d);
-    w.regrs = a.take<float>((size_t)n * T * 2 * k);
-    w.conf = a.take<float>((size_t)n * T * k);
-    w.cls = a.take<float>((size_t)n * T * k);
+    w.comb = a.take<float>((size_t)total_rows * 4 * d);
+    w.regrs = a.take<float>((size_t)total_rows * 2 * k);
+    w.conf = a.take<float>((size_t)total_rows * k);
+    w.cls = a.take<float>((size_t)total_rows * k);
     w.info = a.take<float>((size_t)2 * n);
     w.off = a.take<int32_t>(rows + 2);
+    w.vinfo = ragged ? a.take<int2>((size_t)total_T) : nullptr;
+    w.cinfo = ragged ? a.take<int2>((size_t)total_rows) : nullptr;
     return !a.overflow;
 }
 
@@ -405,22 +469,51 @@ inline int glinear(void* s, const float* A, int lda, const Lin& l, float* C, int
     return bigc_linear_f32(s, A, lda, nullptr, 1, K, l.w, K, l.b, res, ldr, C, ldc, M, N, K, act);
 }
 
-// QANetEncoderLayer.forward, eval mode (models/grd_model_v5.py:110-137). x (n_seq*T, d) -> out (same shape).
+// A set of sequences laid back to back as rows: n_seq of the same length T (info == nullptr), or of different lengths given by
+// their row offsets `off` (n_seq + 1) and the per-row (position, length) table `info` (several videos per call).
+struct Seqs { int n_seq; int T; long rows; int max_T; const int32_t* off; const int2* info; };
+
+int seq_dwconv(void* s, const float* x, const DW& c, float* y, const Seqs& q, int d, int ks) {
+    if (!q.info) return bigc_dwconv_f32(s, x, c.dw_w, c.dw_b, y, q.n_seq, q.T, d, ks);
+    const long total4 = q.rows * (d / 4);
+    ProfScope ps(s, FAM_GROUNDING, 0.0, 8.0 * q.rows * (double)d);
+    hipLaunchKernelGGL(dwconv_ragged_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, x, c.dw_w, c.dw_b, y, total4, q.info, d / 4, ks);
+    BIGC_LAUNCH_CHECK("dwconv_ragged");
+    return BIGC_OK;
+}
+
+// out = act(point_wise(depth_wise(x))) (+ res): one pass over x when the split-operand GEMM can evaluate the depth-wise
+// convolution while it stages its rows, else the two kernels (scratch: `dw`)
+int dwsep(void* s, const float* x, const DW& c, float* dw, float* out, int ldo, int n_out, const Seqs& q, int d, int ks, int act,
+          const float* res = nullptr, int ldr = 0) {
+    if (bigc_linear_dwsep_supported(n_out, d, ks))
+        return bigc_linear_dwsep(s, x, d, c.dw_w, c.dw_b, ks, q.T, q.info, c.pw.w, d, c.pw.b, res, ldr, out, ldo, (int)q.rows, n_out, d, act);
+    GTRY(seq_dwconv(s, x, c, dw, q, d, ks));
+    return glinear(s, dw, d, c.pw, out, ldo, (int)q.rows, n_out, d, act, res, ldr);
+}
+
+// QANetEncoderLayer.forward, eval mode (models/grd_model_v5.py:110-137). x (rows, d) -> out (same shape).
 // Uses w.b0..b3, w.qkv, w.att, w.off; `out` may be one of the caller's buffers but not b0..b3.
-int qanet(void* s, const Enc& E, const float* x, const float* pos, int n_seq, int T, int d, const GWork& w, float* out) {
-    const int rows = n_seq * T;
+int qanet(void* s, const Enc& E, const float* x, const float* pos, const Seqs& q, int d, const GWork& w, float* out) {
+    const int rows = (int)q.rows;
     float *res = w.b0, *ln = w.b1, *dw = w.b2, *nxt = w.b3;
-    GTRY(bigc_add_rows_f32(s, x, pos, res, rows, d, T));                       // out = x + pos ; res = out
+    if (!q.info) {
+        GTRY(bigc_add_rows_f32(s, x, pos, res, rows, d, q.T));                 // out = x + pos ; res = out
+    } else {
+        ProfScope ps(s, FAM_GROUNDING, 0.0, 8.0 * q.rows * (double)d);
+        hipLaunchKernelGGL(add_pos_ragged_kernel, dim3(grid_for(q.rows * (d / 4))), dim3(256), 0, (hipStream_t)s, x, pos, res, q.rows * (d / 4), d / 4, q.info);
+        BIGC_LAUNCH_CHECK("add_pos_ragged");
+    }
     GTRY(bigc_layernorm_f32(s, res, E.normb.w, E.normb.b, ln, rows, d, 1e-5f));
     for (int i = 0; i < 4; ++i) {
-        GTRY(bigc_dwconv_f32(s, ln, E.conv[i].dw_w, E.conv[i].dw_b, dw, n_seq, T, d, E.ks));
-        GTRY(glinear(s, dw, d, E.conv[i].pw, nxt, d, rows, d, d, BIGC_ACT_RELU, res, d));   // relu(conv) + res
+        GTRY(dwsep(s, ln, E.conv[i], dw, nxt, d, d, q, d, E.ks, BIGC_ACT_RELU, res, d));    // relu(conv) + res
         float* t = res; res = nxt; nxt = t;
         GTRY(bigc_layernorm_f32(s, res, E.norm_seq[i].w, E.norm_seq[i].b, ln, rows, d, 1e-5f));
     }
     GTRY(glinear(s, ln, d, E.in_proj, w.qkv, 3 * d, rows, 3 * d, d, BIGC_ACT_NONE));
-    GTRY(bigc_fill_offsets((hipStream_t)s, w.off, n_seq + 1, T));
-    GTRY(bigc_mha_core_f32(s, w.qkv, 3 * d, w.qkv + d, 3 * d, w.qkv + 2 * d, 3 * d, w.att, d, w.off, w.off, n_seq, T, 8, d / 8, nullptr));
+    const int32_t* off = q.off;
+    if (!q.info) { GTRY(bigc_fill_offsets((hipStream_t)s, w.off, q.n_seq + 1, q.T)); off = w.off; }
+    GTRY(bigc_mha_core_f32(s, w.qkv, 3 * d, w.qkv + d, 3 * d, w.qkv + 2 * d, 3 * d, w.att, d, off, off, q.n_seq, q.max_T, 8, d / 8, nullptr));
     GTRY(glinear(s, w.att, d, E.out_proj, nxt, d, rows, d, d, BIGC_ACT_NONE, res, d));        // attn + res
     res = nxt;
     GTRY(bigc_layernorm_f32(s, res, E.norme.w, E.norme.b, ln, rows, d, 1e-5f));
@@ -429,17 +522,98 @@ int qanet(void* s, const Enc& E, const float* x, const float* pos, int n_seq, in
 }
 
 // 4 x (DWsep k3 + ReLU) + DWsep -> c_out   (models/grd_model_v5.py:182-193)
-int run_head(void* s, const Head& H, const float* x, int n_seq, int T, int d, const GWork& w, float* out, int act) {
-    const int rows = n_seq * T;
+int run_head(void* s, const Head& H, const float* x, const Seqs& q, int d, const GWork& w, float* out, int act) {
     const float* cur = x;
     float* pp[2] = {w.b0, w.b1};
     for (int i = 0; i < 4; ++i) {
-        GTRY(bigc_dwconv_f32(s, cur, H.layer[i].dw_w, H.layer[i].dw_b, w.b2, n_seq, T, d, 3));
-        GTRY(glinear(s, w.b2, d, H.layer[i].pw, pp[i & 1], d, rows, d, d, BIGC_ACT_RELU));
+        GTRY(dwsep(s, cur, H.layer[i], w.b2, pp[i & 1], d, d, q, d, 3, BIGC_ACT_RELU));
         cur = pp[i & 1];
     }
-    GTRY(bigc_dwconv_f32(s, cur, H.layer[4].dw_w, H.layer[4].dw_b, w.b2, n_seq, T, d, 3));
-    GTRY(glinear(s, w.b2, d, H.layer[4].pw, out, H.c_out, rows, H.c_out, d, act));
+    GTRY(dwsep(s, cur, H.layer[4], w.b2, out, H.c_out, H.c_out, q, d, 3, act));
+    return BIGC_OK;
+}
+
+// a12-a16 for one video (b == nullptr: T clips, n queries) or for several videos at once (b: ragged descriptors)
+int forward_impl(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, const int32_t* dura, int n,
+                 float video_len, const grd_batch* b, const float* pos_video, const float* pos_query, const float* clip,
+                 float score_th, float tiou_th, float bins_th, float nms_th, void* workspace, size_t workspace_bytes, const grd_outputs* out) {
+    const grd_config& c = m->cfg;
+    const int d = c.dim_hidden, k = c.num_bins;
+    const long total_T = b ? b->total_T : T, total_rows = b ? b->total_rows : (long)n * T;
+    const int max_T = b ? b->max_T : T, n_vid = b ? b->n_vid : 1;
+    BIGC_CHECK_ARG(total_rows < (1L << 31) / (4 * d) * 4, "grd_forward: %ld combined rows do not fit 32-bit row indexing, split the batch", total_rows);
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (!workspace || workspace_bytes < (size_t)(base - (char*)workspace)) return bigc_fail(BIGC_ERR_WORKSPACE, "grd_forward: no workspace");
+    GArena a{base, workspace_bytes - (size_t)(base - (char*)workspace)};
+    GWork w;
+    if (!glayout(m, total_T, n, total_rows, b != nullptr, a, w))
+        return bigc_fail(BIGC_ERR_WORKSPACE, "grd_forward: workspace of %zu bytes too small, need %zu", workspace_bytes, a.off + 256);
+    void* s = stream;
+    hipStream_t hs = (hipStream_t)stream;
+    const int32_t* q_vid = b ? b->q_vid : nullptr;
+    const float* vid_len = b ? b->vid_len : nullptr;
+    Seqs sv{n_vid, T, total_T, max_T, b ? b->vid_row_off : nullptr, nullptr};       // the videos' clip sequences
+    Seqs sq{n, 3, (long)3 * n, 3, nullptr, nullptr};                                  // the queries' three words
+    Seqs sc{n, T, total_rows, max_T, b ? b->q_row_off : nullptr, nullptr};            // every query against its video's clips
+    if (b) {
+        hipLaunchKernelGGL(seq_rows_kernel, dim3(n_vid), dim3(256), 0, hs, b->vid_row_off, w.vinfo);
+        hipLaunchKernelGGL(seq_rows_kernel, dim3(n), dim3(256), 0, hs, b->q_row_off, w.cinfo);
+        BIGC_LAUNCH_CHECK("seq_rows");
+        sv.info = w.vinfo; sc.info = w.cinfo;
+    }
+
+    // a12: prepare_data (:310-328) fused with query_fc + temp_fc (:337-339)
+    hipLaunchKernelGGL(query_input_kernel, dim3(grid_for((long)3 * n * m->kq)), dim3(256), 0, hs, m->enti, m->pred, quint, dura, video_len,
+                       q_vid, vid_len, w.qin, n, c.dim_clsme, m->kq);
+    BIGC_LAUNCH_CHECK("query_input");
+    hipLaunchKernelGGL(span_info_kernel, dim3(cdiv(2 * n, 256)), dim3(256), 0, hs, dura, video_len, q_vid, vid_len, w.info, 2 * n);
+    BIGC_LAUNCH_CHECK("span_info");
+    Lin qlin{m->wq, m->bq};
+    float* qemb = w.comb;                         // (3n, d) scratch, comb is free until the co-attention
+    GTRY(glinear(s, w.qin, m->kq, qlin, qemb, d, 3 * n, d, m->kq, BIGC_ACT_NONE));
+    float* vemb = w.comb + (size_t)3 * n * d;     // (total_T, d)
+    GTRY(glinear(s, video_feat, c.dim_feat, m->video_fc, vemb, d, (int)total_T, d, c.dim_feat, BIGC_ACT_NONE));
+
+    // a13: the two encoders, co-attention, fusion, combined encoder, three heads (:341-372)
+    float* venc = out->video_enc ? out->video_enc : w.venc;
+    float* qenc = out->query_enc ? out->query_enc : w.qenc;
+    GTRY(qanet(s, m->video_enc, vemb, pos_video, sv, d, w, venc));
+    GTRY(qanet(s, m->query_enc, qemb, pos_query, sq, d, w, qenc));
+    GTRY(glinear(s, venc, d, m->proj2sim, w.proj, d, (int)total_T, d, d, BIGC_ACT_NONE));
+    if (!b) {
+        GTRY(grd_coattention_f32(s, venc, w.proj, qenc, w.comb, n, T, d));
+    } else {
+        BIGC_CHECK_ARG(max_T <= 2048 && d <= 256, "grd_forward_batch: max_T=%d (<=2048) d=%d (<=256)", max_T, d);
+        const size_t lds = sizeof(float) * (6 * (size_t)d + 6 * (size_t)max_T + 4);
+        ProfScope ps(stream, FAM_GROUNDING, 0.0, 16.0 * total_rows * (double)d);
+        hipLaunchKernelGGL(coattention_kernel, dim3(n), dim3(256), lds, hs, venc, w.proj, qenc, w.comb, max_T, d, q_vid, b->vid_row_off, b->q_row_off);
+        BIGC_LAUNCH_CHECK("coattention");
+    }
+    float* cin = w.att;                           // (rows, d) free between qanet calls
+    GTRY(glinear(s, w.comb, 4 * d, m->vq_fc, cin, d, (int)total_rows, d, 4 * d, BIGC_ACT_NONE));
+    float* cenc = out->combined_enc ? out->combined_enc : w.comb;     // comb (rows*4d) is free again
+    // qanet reads its input into b0 first, and w.att is only rewritten by the attention step, after
+    // the input has been consumed
+    GTRY(qanet(s, m->comb_enc, cin, pos_video, sc, d, w, cenc));
+    float* regrs = out->regrs ? out->regrs : w.regrs;
+    float* conf = out->conf ? out->conf : w.conf;
+    float* cls = out->cls ? out->cls : w.cls;
+    GTRY(run_head(s, m->regr_head, cenc, sc, d, w, regrs, BIGC_ACT_SIGMOID));
+    GTRY(run_head(s, m->conf_head, cenc, sc, d, w, conf, BIGC_ACT_NONE));
+    GTRY(run_head(s, m->cls_head, cenc, sc, d, w, cls, BIGC_ACT_NONE));
+
+    // a14-a16: pooling, clipping, NMS, masks (:533-572)
+    if (!b) {
+        GTRY(grd_postprocess(s, regrs, conf, cls, clip, w.info, n, T, k, score_th, tiou_th, bins_th, nms_th, out->pooled_se, out->bins_probs,
+                             out->bins_mask, out->status));
+    } else {
+        hipError_t e = hipMemsetAsync(out->status, 0, sizeof(int32_t) * (size_t)(1 + n_vid), hs);
+        if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_forward_batch: memset: %s", hipGetErrorString(e));
+        ProfScope ps(stream, FAM_GROUNDING, 0.0, 0.0);
+        hipLaunchKernelGGL(postprocess_kernel, dim3(n), dim3(64), 0, hs, regrs, conf, cls, clip, w.info, max_T, k, score_th, tiou_th, bins_th, nms_th,
+                           out->pooled_se, out->bins_probs, out->bins_mask, out->status, q_vid, b->vid_row_off, b->q_row_off);
+        BIGC_LAUNCH_CHECK("postprocess");
+    }
     return BIGC_OK;
 }
 
@@ -511,7 +685,15 @@ extern "C" size_t grd_workspace_bytes(const grd_model* m, int T, int n) {
     if (!m || T <= 0 || n <= 0) return 0;
     GArena a{nullptr, (size_t)-1};
     GWork w;
-    glayout(m, T, n, a, w);
+    glayout(m, T, n, (long)n * T, false, a, w);
+    return a.off + 256;
+}
+
+extern "C" size_t grd_batch_workspace_bytes(const grd_model* m, const grd_batch* b) {
+    if (!m || !b || b->n_query <= 0 || b->total_T <= 0) return 0;
+    GArena a{nullptr, (size_t)-1};
+    GWork w;
+    glayout(m, b->total_T, b->n_query, b->total_rows, true, a, w);
     return a.off + 256;
 }
 
@@ -524,51 +706,20 @@ extern "C" int grd_forward(grd_model* m, void* stream, const float* video_feat, 
     BIGC_CHECK_ARG(m->finalized, "grd_forward: call grd_finalize after setting the parameters");
     BIGC_CHECK_ARG(T > 0 && n > 0 && video_len > 0, "grd_forward: T=%d n=%d video_len=%f", T, n, video_len);
     BIGC_CHECK_ARG(out->pooled_se && out->bins_probs && out->bins_mask && out->status, "grd_forward: required outputs missing");
-    const grd_config& c = m->cfg;
-    const int d = c.dim_hidden, k = c.num_bins;
-    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    if (!workspace || workspace_bytes < (size_t)(base - (char*)workspace)) return bigc_fail(BIGC_ERR_WORKSPACE, "grd_forward: no workspace");
-    GArena a{base, workspace_bytes - (size_t)(base - (char*)workspace)};
-    GWork w;
-    if (!glayout(m, T, n, a, w)) return bigc_fail(BIGC_ERR_WORKSPACE, "grd_forward: workspace of %zu bytes too small, need %zu",
-                                                  workspace_bytes, grd_workspace_bytes(m, T, n));
-    void* s = stream;
-    hipStream_t hs = (hipStream_t)stream;
+    return forward_impl(m, stream, video_feat, T, quint, dura, n, video_len, nullptr, pos_video, pos_query, clip, score_th, tiou_th, bins_th, nms_th,
+                        workspace, workspace_bytes, out);
+}
 
-    // a12: prepare_data (:310-328) fused with query_fc + temp_fc (:337-339)
-    hipLaunchKernelGGL(query_input_kernel, dim3(grid_for((long)3 * n * m->kq)), dim3(256), 0, hs, m->enti, m->pred, quint, dura, video_len,
-                       w.qin, n, c.dim_clsme, m->kq);
-    BIGC_LAUNCH_CHECK("query_input");
-    hipLaunchKernelGGL(span_info_kernel, dim3(cdiv(2 * n, 256)), dim3(256), 0, hs, dura, video_len, w.info, 2 * n);
-    BIGC_LAUNCH_CHECK("span_info");
-    Lin qlin{m->wq, m->bq};
-    float* qemb = w.comb;                         // (3n, d) scratch, comb is free until the co-attention
-    GTRY(glinear(s, w.qin, m->kq, qlin, qemb, d, 3 * n, d, m->kq, BIGC_ACT_NONE));
-    float* vemb = w.comb + (size_t)3 * n * d;     // (T, d)
-    GTRY(glinear(s, video_feat, c.dim_feat, m->video_fc, vemb, d, T, d, c.dim_feat, BIGC_ACT_NONE));
-
-    // a13: the two encoders, co-attention, fusion, combined encoder, three heads (:341-372)
-    float* venc = out->video_enc ? out->video_enc : w.venc;
-    float* qenc = out->query_enc ? out->query_enc : w.qenc;
-    GTRY(qanet(s, m->video_enc, vemb, pos_video, 1, T, d, w, venc));
-    GTRY(qanet(s, m->query_enc, qemb, pos_query, n, 3, d, w, qenc));
-    GTRY(glinear(s, venc, d, m->proj2sim, w.proj, d, T, d, d, BIGC_ACT_NONE));
-    GTRY(grd_coattention_f32(s, venc, w.proj, qenc, w.comb, n, T, d));
-    float* cin = w.att;                           // (n*T, d) free between qanet calls
-    GTRY(glinear(s, w.comb, 4 * d, m->vq_fc, cin, d, n * T, d, 4 * d, BIGC_ACT_NONE));
-    float* cenc = out->combined_enc ? out->combined_enc : w.comb;     // comb (n*T*4d) is free again
-    // qanet reads its input into b0 first, and w.att is only rewritten by the attention step, after
-    // the input has been consumed
-    GTRY(qanet(s, m->comb_enc, cin, pos_video, n, T, d, w, cenc));
-    float* regrs = out->regrs ? out->regrs : w.regrs;
-    float* conf = out->conf ? out->conf : w.conf;
-    float* cls = out->cls ? out->cls : w.cls;
-    GTRY(run_head(s, m->regr_head, cenc, n, T, d, w, regrs, BIGC_ACT_SIGMOID));
-    GTRY(run_head(s, m->conf_head, cenc, n, T, d, w, conf, BIGC_ACT_NONE));
-    GTRY(run_head(s, m->cls_head, cenc, n, T, d, w, cls, BIGC_ACT_NONE));
-
-    // a14-a16: pooling, clipping, NMS, masks (:533-572)
-    GTRY(grd_postprocess(s, regrs, conf, cls, clip, w.info, n, T, k, score_th, tiou_th, bins_th, nms_th, out->pooled_se, out->bins_probs,
-                         out->bins_mask, out->status));
-    return BIGC_OK;
+extern "C" int grd_forward_batch(grd_model* m, void* stream, const float* video_feat, const grd_batch* b, const int32_t* quint, const int32_t* dura,
+                                 const float* pos_video, const float* pos_query, const float* clip,
+                                 float score_th, float tiou_th, float bins_th, float nms_th,
+                                 void* workspace, size_t workspace_bytes, const grd_outputs* out) {
+    StaticWeights static_weights(m ? m->epoch : 0);
+    BIGC_CHECK_ARG(m && video_feat && b && quint && dura && pos_video && pos_query && clip && out, "grd_forward_batch: null pointer");
+    BIGC_CHECK_ARG(m->finalized, "grd_forward_batch: call grd_finalize after setting the parameters");
+    BIGC_CHECK_ARG(b->n_vid > 0 && b->n_query > 0 && b->total_T > 0 && b->total_rows > 0 && b->max_T > 0, "grd_forward_batch: empty batch");
+    BIGC_CHECK_ARG(b->vid_row_off && b->q_vid && b->q_row_off && b->vid_len, "grd_forward_batch: batch tables missing");
+    BIGC_CHECK_ARG(out->pooled_se && out->bins_probs && out->bins_mask && out->status, "grd_forward_batch: required outputs missing");
+    return forward_impl(m, stream, video_feat, b->max_T, quint, dura, b->n_query, 1.0f, b, pos_video, pos_query, clip, score_th, tiou_th, bins_th,
+                        nms_th, workspace, workspace_bytes, out);
 }

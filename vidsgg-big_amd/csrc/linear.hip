@@ -223,6 +223,30 @@ static std::atomic<int> g_exact_mode{(getenv("BIGC_LINEAR_EXACT") && atoi(getenv
 extern "C" int bigc_linear_set_exact(int exact) { return g_exact_mode.exchange(exact ? 1 : 0); }
 extern "C" int bigc_linear_get_exact(void) { return g_exact_mode.load(); }
 
+bool bigc_linear_dwsep_supported(int N, int K, int ks) {
+    static const bool off = getenv("BIGC_DWSEP_FUSED") && atoi(getenv("BIGC_DWSEP_FUSED")) == 0;
+    return !off && g_exact_mode.load() == 0 && K % 32 == 0 && (ks == 3 || ks == 7);
+}
+
+int bigc_linear_dwsep(void* stream, const float* X, int ldx, const float* dw_w, const float* dw_b, int ks, int T, const int2* row_info,
+                      const float* W, int ldw, const float* bias, const float* res, int ldr, float* C, int ldc, int M, int N, int K, int act) {
+    BIGC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && X && dw_w && dw_b && W && C, "linear_dwsep: bad argument");
+    BIGC_CHECK_ARG(bigc_linear_dwsep_supported(N, K, ks), "linear_dwsep: unsupported shape / mode (K=%d ks=%d)", K, ks);
+    BIGC_CHECK_ARG(ldx % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)dw_w & 15) == 0 &&
+                   ((uintptr_t)dw_b & 15) == 0, "linear_dwsep: alignment");
+    BIGC_CHECK_ARG(row_info || T > 0, "linear_dwsep: sequence length");
+    if (M == 0) return BIGC_OK;
+    LinearArgs p;
+    p.A = X; p.lda = ldx; p.a_idx = nullptr; p.nseg = 1; p.seg_len = K;
+    p.W = W; p.ldw = ldw; p.bias = bias; p.res = res; p.ldr = ldr; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.act = act;
+    p.tiles_m = cdiv(M, BM); p.tiles_n = 0;
+    p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr; p.zero_row = nullptr;
+    p.dw_w = dw_w; p.dw_b = dw_b; p.dw_ks = ks; p.dw_T = T; p.dw_info = row_info;
+    const double flops = 2.0 * M * (double)N * K + 2.0 * M * (double)K * ks, bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (res ? 2 : 1));
+    return bigc_linear_split_launch((hipStream_t)stream, p, flops, bytes);
+}
+
 extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int32_t* a_idx, int nseg, int seg_len,
                                const float* W, int ldw, const float* bias, const float* residual, int ldr,
                                float* C, int ldc, int M, int N, int K, int act) {

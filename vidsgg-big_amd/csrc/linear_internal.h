@@ -12,6 +12,10 @@ struct LinearArgs {
     const u32x4* Ws; int ldws;            // split kernel: W as [N][ldws] groups of 4 k: {4 x f16 head, 4 x f16 scaled residual}
     const float* zero_row;                // split kernel, gather mode: seg_len zeros standing for the row index -1
     const int* wbad; int wbad_id;         // split kernel: *wbad == wbad_id when the split W holds an out-of-range element
+    // split kernel, depth-wise-separable mode: the A operand is dwconv(A) evaluated while the rows are staged -- a k=dw_ks
+    // (3 or 7) depth-wise convolution along the rows of each sequence, zero padded, weights (K, dw_ks), bias (K).  Sequences are
+    // dw_T rows each, or of the lengths given per row by dw_info (position, length).  dw_w == nullptr: off.
+    const float* dw_w = nullptr; const float* dw_b = nullptr; int dw_ks = 0; int dw_T = 0; const int2* dw_info = nullptr;
 };
 
 // Weights that stay constant between launches are split once and cached per (pointer, shape) for an "epoch": the model
@@ -44,6 +48,11 @@ int bigc_linear_prepare(hipStream_t s, const SplitJob* jobs, int n);
 // -> *wT = f32 copy of W^T (K, round4(N)), valid for the current weights epoch, with its split form cached under the copy's own
 // key: pass it to bigc_linear_f32 as an (N'=K, K'=round4(N), ldw=round4(N)) weight.  Outside an epoch scope it is rebuilt per call.
 int bigc_weight_transposed(hipStream_t s, const float* W, int N, int K, int ldw, const float** wT);
+// y = act(dwconv(x) W^T + bias) (+ res) in one pass over x (grounding: every depth-wise-separable convolution of the QANet
+// encoders and of the heads, models/grd_model_v5.py:81-107): false when the current mode / shape needs the two-kernel form
+bool bigc_linear_dwsep_supported(int N, int K, int ks);
+int bigc_linear_dwsep(void* stream, const float* X, int ldx, const float* dw_w, const float* dw_b, int ks, int T, const int2* row_info,
+                      const float* W, int ldw, const float* bias, const float* res, int ldr, float* C, int ldc, int M, int N, int K, int act);
 // launches the split-operand kernel (and its W pre-split pass); returns BIGC_OK or an error code
 int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double bytes);
 

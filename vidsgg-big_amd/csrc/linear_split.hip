@@ -133,8 +133,9 @@ __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((row >>
 
 // WN = wave columns: 2 -> 128x128 tile, 256 threads, two workgroups per CU; 4 -> 128x256 tile, 512 threads (one workgroup
 // per CU, same two waves per SIMD): the A slab is split once for eight waves instead of four.
-template <bool GATHER, bool KTAIL, int WN>
-__global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void linear_split_kernel(const LinearArgs p) {
+// DWK > 0: depth-wise-separable mode (LinearArgs::dw_*), DWK = kernel size of the depth-wise convolution.
+template <bool GATHER, bool KTAIL, int WN, int DWK = 0>
+__global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linear_split_kernel(const LinearArgs p) {
     constexpr int NTH = 128 * WN, BNT = 64 * WN;     // threads, tile width
     constexpr int RPP = NTH / 8;                     // rows staged per pass (8 threads x 16 bytes per 32-k row)
     constexpr int NA = BM / RPP, NB = BNT / RPP;     // passes over the A / W rows
@@ -159,6 +160,27 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void linear_split_kernel
     for (int i = 0; i < NA; ++i) arow[i] = p.A + (size_t)min(m0 + lr + RPP * i, p.M - 1) * p.lda;
 #pragma unroll
     for (int i = 0; i < NB; ++i) wrow[i] = p.Ws + (size_t)min(n0 + lr + RPP * i, p.N - 1) * p.ldws;
+    // depth-wise-separable mode: per staged row, the element offset of every tap's row relative to the row itself, and which
+    // taps fall inside the row's sequence (the others read the row itself and are dropped)
+    constexpr int DWN = DWK > 0 ? DWK : 1;
+    int dwoff[NA][DWN];
+    unsigned dwmask[NA];
+    if (DWK > 0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = min(m0 + lr + RPP * i, p.M - 1);
+            int t, T;
+            if (p.dw_info) { const int2 v = p.dw_info[row]; t = v.x; T = v.y; } else { t = row % p.dw_T; T = p.dw_T; }
+            dwmask[i] = 0;
+#pragma unroll
+            for (int jj = 0; jj < DWN; ++jj) {
+                const int tt = t + jj - DWK / 2;
+                const bool ok = tt >= 0 && tt < T;
+                dwmask[i] |= ok ? (1u << jj) : 0u;
+                dwoff[i][jj] = ok ? (jj - DWK / 2) * p.lda : 0;
+            }
+        }
+    }
     // A is prefetched two slabs ahead in two register sets (its rows stream from HBM), W one slab ahead (L2-resident)
     f32x4 ra0[NA], ra1[NA];
     u32x4 rb[NB];
@@ -188,6 +210,38 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void linear_split_kernel
     auto load_a = [&](int kt, f32x4 (&ra)[NA]) {
         int kc, acol; bool kval;
         slab_cols(kt, kc, acol, kval);
+        if (DWK > 0) {
+            // a[row][k] = b[k] + sum_j w[k][j] x[row + j - DWK/2][k]: all tap loads first, then the sums in the tap order of
+            // dwconv_kernel (grounding.hip)
+            float wf[4 * DWN];
+#pragma unroll
+            for (int u = 0; u < DWN; ++u) {
+                const f32x4 t4 = ((const f32x4*)(p.dw_w + (size_t)kc * DWK))[u];
+                wf[4 * u] = t4[0]; wf[4 * u + 1] = t4[1]; wf[4 * u + 2] = t4[2]; wf[4 * u + 3] = t4[3];
+            }
+            const f32x4 bq = *(const f32x4*)(p.dw_b + kc);
+            constexpr int RG = DWK > 3 ? 2 : NA;          // rows whose taps are in flight together (registers: RG * DWK quads)
+#pragma unroll
+            for (int i0 = 0; i0 < NA; i0 += RG) {
+                f32x4 xv[RG][DWN];
+#pragma unroll
+                for (int i = 0; i < RG; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < DWN; ++jj) xv[i][jj] = *(const f32x4*)(arow[i0 + i] + dwoff[i0 + i][jj] + acol);
+#pragma unroll
+                for (int i = 0; i < RG; ++i) {
+                    f32x4 acc = bq;
+#pragma unroll
+                    for (int jj = 0; jj < DWN; ++jj) {
+                        const bool ok = (dwmask[i0 + i] >> jj) & 1u;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c] = ok ? acc[c] + wf[c * DWK + jj] * xv[i][jj][c] : acc[c];
+                    }
+                    ra[i0 + i] = acc;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             ra[i] = *(const f32x4*)(arow[i] + acol);
@@ -315,6 +369,19 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void linear_split_kernel
                 }
                 av[mi] = *(const f32x4*)src;
                 if (zero) av[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (DWK > 0) {
+                    int t, T;
+                    if (p.dw_info) { const int2 v = p.dw_info[mrow]; t = v.x; T = v.y; } else { t = mrow % p.dw_T; T = p.dw_T; }
+                    f32x4 acc = *(const f32x4*)(p.dw_b + kcl);
+                    for (int jj = 0; jj < DWK; ++jj) {
+                        const int tt = t + jj - DWK / 2;
+                        if (tt < 0 || tt >= T) continue;
+                        const f32x4 xq = *(const f32x4*)(p.A + (size_t)(mrow + jj - DWK / 2) * p.lda + kcl);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c] += p.dw_w[(size_t)(kcl + c) * DWK + jj] * xq[c];
+                    }
+                    av[mi] = kok ? acc : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
                 const int nrow = min(n0 + wn * 64 + mi * 32 + l31, p.N - 1);
                 wv[mi] = *(const f32x4*)(p.W + (size_t)nrow * p.ldw + kcl);
                 if (!kok) wv[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -598,9 +665,16 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
     const int rem = p.N % 256;
     // ... and unless that leaves half the chip idle (training-step sizes: 1536 x 512 is 24 wide tiles; 23 vs 28 us per launch)
     const bool few = (long)p.tiles_m * cdiv(p.N, 256) <= 128;
-    const int wn = force_wn ? (force_wn == 4 ? 4 : 2) : ((p.N > 192 && (rem == 0 || rem > 128) && !few) ? 4 : 2);
+    const int wn = p.dw_w ? 2 : (force_wn ? (force_wn == 4 ? 4 : 2) : ((p.N > 192 && (rem == 0 || rem > 128) && !few) ? 4 : 2));
     p.tiles_n = cdiv(p.N, 64 * wn);
     const int grid2 = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
+    if (p.dw_w) {
+        if (p.a_idx || ktail || (p.dw_ks != 3 && p.dw_ks != 7)) return bigc_fail(BIGC_ERR_ARG, "linear_split: depth-wise mode needs K %% 32 == 0, no gather, ks 3 or 7");
+        if (p.dw_ks == 3) hipLaunchKernelGGL((linear_split_kernel<false, false, 2, 3>), dim3(grid2), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((linear_split_kernel<false, false, 2, 7>), dim3(grid2), dim3(256), 0, s, p);
+        BIGC_LAUNCH_CHECK("linear_split (dwsep)");
+        return BIGC_OK;
+    }
 #define LAUNCH_SPLIT(G, T, W) hipLaunchKernelGGL((linear_split_kernel<G, T, W>), dim3(grid2), dim3(128 * W), 0, s, p)
     if (wn == 4) {
         if (p.a_idx) { if (ktail) LAUNCH_SPLIT(true, true, 4); else LAUNCH_SPLIT(true, false, 4); }

@@ -109,6 +109,14 @@ class DEBUG(nn.Module):
         terms = HipGrdTrainStep.apply(self, feats, list(gt_graph_list), *self.parameters())
         return terms.sum(), {k: terms[i] for i, k in enumerate(LOSS_KEYS)}
 
+    def forward_raw_batch(self, jobs, score_th=0.5, tiou_th=0.5, bins_th=0.1, nms_th=0.5):
+        """The eval forward for several videos at once: ``jobs`` = [(video_feature (T,dim_feat), uniq_quintuples (n,5),
+        uniq_dura_inters (n,2), video_len), ...] -> one dict per video (pooled_se, bins_probs, bins_mask (uint8), status), identical
+        to ``forward_raw`` per video.  The reference scores one video per call (models/grd_model_v5.py:196-221); batching is what
+        fills the GPU: a 200-query video is ~75 launches of a few thousand rows each."""
+        with torch.no_grad():
+            return self.engine().forward_batch(jobs, score_th, tiou_th, bins_th, nms_th)
+
     def forward_raw(self, video_feature, quint, dura, video_len, score_th, tiou_th, bins_th, nms_th, keep_intermediates=False):
         with torch.no_grad():
             return self.engine().forward(video_feature, quint, dura, video_len, score_th, tiou_th, bins_th, nms_th, keep_intermediates)

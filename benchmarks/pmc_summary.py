@@ -32,19 +32,29 @@ def per_dispatch(path, kernel):
     return out, grid
 
 
-def last_pass(d, n_passes):
-    ids = sorted(d)
-    per = len(ids) // n_passes
-    return ids[-per:]
+MARKER = "bbox_feat_kernel"        # first kernel of every BIG-C forward pass
+
+
+def one_step(path):
+    """(first, last) dispatch ids of one whole forward pass of the timed loop: from the second-to-last marker launch up to (not
+    including) the last one"""
+    marks = sorted(int(r["Dispatch_Id"]) for r in csv.DictReader(open(path)) if MARKER in r["Kernel_Name"])
+    marks = sorted(set(marks))
+    assert len(marks) >= 3, "need at least three forward passes in the trace"
+    return marks[-3], marks[-2]
+
+
+def in_step(d, span):
+    return [i for i in sorted(d) if span[0] <= i < span[1]]
 
 
 def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-    n_passes = 3                       # bench.py --steps 2 --warmup 1
     shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_bench_kernel_stats.csv"))
     fetch, grid = per_dispatch(os.path.join(src, "pmc_FETCH_SIZE", "pmc_counter_collection.csv"), KERNEL)
     write, _ = per_dispatch(os.path.join(src, "pmc_WRITE_SIZE", "pmc_counter_collection.csv"), KERNEL)
-    fid, wid = last_pass(fetch, n_passes), last_pass(write, n_passes)
+    fpath, wpath = os.path.join(src, "pmc_FETCH_SIZE", "pmc_counter_collection.csv"), os.path.join(src, "pmc_WRITE_SIZE", "pmc_counter_collection.csv")
+    fid, wid = in_step(fetch, one_step(fpath)), in_step(write, one_step(wpath))
     assert len(fid) == len(wid)
     tot_f = tot_w = 0.0
     with open(os.path.join(dst, tag + "_pmc_linear_hbm.csv"), "w") as f:
@@ -61,20 +71,26 @@ def main():
                          "--cpu-videos 0 --no-prof` (benchmarks/profile_bench.sh); the last step's GEMM launches; FETCH_SIZE doubled per "
                          "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); counter unit KiB"},
               open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    # every kernel of the last step (not only the GEMM family): the step's total HBM traffic
+    all_f, _ = per_dispatch(os.path.join(src, "pmc_FETCH_SIZE", "pmc_counter_collection.csv"), "")
+    all_w, _ = per_dispatch(os.path.join(src, "pmc_WRITE_SIZE", "pmc_counter_collection.csv"), "")
+    step_f = sum(all_f[i]["FETCH_SIZE"] for i in in_step(all_f, one_step(fpath))) * 1024 * 2
+    step_w = sum(all_w[i]["WRITE_SIZE"] for i in in_step(all_w, one_step(wpath))) * 1024
     sums = OrderedDict()
     for sub in ("pmc_sq1", "pmc_sq2"):
         p = os.path.join(src, sub, "pmc_counter_collection.csv")
         if not os.path.exists(p):
             continue
         d, _ = per_dispatch(p, KERNEL)
-        for i in last_pass(d, n_passes):
+        for i in in_step(d, one_step(p)):
             for k, v in d[i].items():
                 sums[k] = sums.get(k, 0.0) + v
     with open(os.path.join(dst, tag + "_pmc_linear_sq.csv"), "w") as f:
         f.write("counter,sum_over_%d_gemm_launches_of_one_step\n" % len(fid))
         for k, v in sums.items():
             f.write("%s,%d\n" % (k, v))
-    print(json.dumps({"fetch_GB": tot_f / 1e9, "write_GB": tot_w / 1e9, "per_launch_MB": (tot_f + tot_w) / len(fid) / 1e6, "sq": sums}, indent=1))
+    print(json.dumps({"whole_step_fetch_GB_all_kernels": step_f / 1e9, "whole_step_write_GB_all_kernels": step_w / 1e9,
+                      "fetch_GB": tot_f / 1e9, "write_GB": tot_w / 1e9, "per_launch_MB": (tot_f + tot_w) / len(fid) / 1e6, "sq": sums}, indent=1))
 
 
 if __name__ == "__main__":

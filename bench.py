@@ -463,6 +463,15 @@ def main():
     # ---- the same K steps once more with a HIP event pair around every kernel launch (on the launch stream, inside the
     # library): per-family launch durations for the roofline.  Kept out of `value` because the ~300 event records per step
     # cost a few % of a step; the instrumented wall time is reported next to it.
+    # SURVEY.md 8(d) quotes the MEDIAN step time: the same K steps once more, each one waited for (rank 0, outside `value`)
+    per_step = []
+    if rank == 0:
+        for _ in range(args.steps):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            per_step.append(time.perf_counter() - t1)
     families = {}
     prof_elapsed = None
     if not args.no_prof:
@@ -632,6 +641,7 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu_baseline, "oracle_parity": oracle_parity, "exact_f32_gemm_mode": exact_leg,
         "kernel_families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in families.items()},
         "videos_per_sec": round(args.videos * world * args.steps / elapsed, 1),
+        "ms_per_step_median_each_step_synchronised": round(1e3 * float(np.median(per_step)), 3) if per_step else None,
         "triplets_last_step": int(n_out.sum()), "setup_s": round(gen_s, 1),
     }
     line.update(legs)

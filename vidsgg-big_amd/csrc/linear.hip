@@ -223,6 +223,32 @@ static std::atomic<int> g_exact_mode{(getenv("BIGC_LINEAR_EXACT") && atoi(getenv
 extern "C" int bigc_linear_set_exact(int exact) { return g_exact_mode.exchange(exact ? 1 : 0); }
 extern "C" int bigc_linear_get_exact(void) { return g_exact_mode.load(); }
 
+bool bigc_linear_pre8_supported(int N, int K) {
+    // Opt-in (BIGC_PRE8_FUSED=1).  Measured on the 256-video step: hb (1.19 GB written + read) disappears and so does the 0.29 ms
+    // K = 8 kernel, but the 64 extra FMAs per staged quad sit in the MFMA-bound loop of a power-limited kernel: the fused GEMM
+    // takes 1.2 ms longer (22.17 vs 21.37 ms per step).  Traffic is not what this step waits for.
+    static const bool on = getenv("BIGC_PRE8_FUSED") && atoi(getenv("BIGC_PRE8_FUSED")) == 1;
+    return on && g_exact_mode.load() == 0 && K % 32 == 0;
+}
+
+int bigc_linear_pre8(void* stream, const float* x8, const float* W0, const float* b0, const float* W, int ldw, const float* bias,
+                     float* C, int ldc, int M, int N, int K, int act) {
+    BIGC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && x8 && W0 && b0 && W && C, "linear_pre8: bad argument");
+    BIGC_CHECK_ARG(bigc_linear_pre8_supported(N, K), "linear_pre8: unsupported shape / mode (K=%d)", K);
+    BIGC_CHECK_ARG(ldw % 4 == 0 && ((uintptr_t)x8 & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)W0 & 15) == 0 && ((uintptr_t)b0 & 15) == 0,
+                   "linear_pre8: alignment");
+    if (M == 0) return BIGC_OK;
+    LinearArgs p;
+    p.A = x8; p.lda = 8; p.a_idx = nullptr; p.nseg = 1; p.seg_len = K;      // (A itself is not read: the staged operand comes from pre_*)
+    p.W = W; p.ldw = ldw; p.bias = bias; p.res = nullptr; p.ldr = 0; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.act = act;
+    p.tiles_m = cdiv(M, BM); p.tiles_n = 0;
+    p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr; p.zero_row = nullptr;
+    p.pre_x = x8; p.pre_w = W0; p.pre_b = b0;
+    const double flops = 2.0 * M * (double)N * K + 2.0 * M * (double)K * 8, bytes = 4.0 * ((double)M * 8 + (double)N * K + (double)M * N);
+    return bigc_linear_split_launch((hipStream_t)stream, p, flops, bytes);
+}
+
 bool bigc_linear_dwsep_supported(int N, int K, int ks) {
     static const bool off = getenv("BIGC_DWSEP_FUSED") && atoi(getenv("BIGC_DWSEP_FUSED")) == 0;
     return !off && g_exact_mode.load() == 0 && K % 32 == 0 && (ks == 3 || ks == 7);

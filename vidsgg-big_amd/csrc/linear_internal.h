@@ -16,6 +16,9 @@ struct LinearArgs {
     // (3 or 7) depth-wise convolution along the rows of each sequence, zero padded, weights (K, dw_ks), bias (K).  Sequences are
     // dw_T rows each, or of the lengths given per row by dw_info (position, length).  dw_w == nullptr: off.
     const float* dw_w = nullptr; const float* dw_b = nullptr; int dw_ks = 0; int dw_T = 0; const int2* dw_info = nullptr;
+    // split kernel, preceding-layer mode: A = relu(pre_x pre_w^T + pre_b) with pre_x (M, 8), pre_w (K, 8), pre_b (K), evaluated while
+    // the rows are staged (fc_bbox2enti.0 -> .2, models/model_0v10.py:446: the 8 -> 512 layer's output never exists in HBM)
+    const float* pre_x = nullptr; const float* pre_w = nullptr; const float* pre_b = nullptr;
 };
 
 // Weights that stay constant between launches are split once and cached per (pointer, shape) for an "epoch": the model
@@ -50,6 +53,10 @@ int bigc_linear_prepare(hipStream_t s, const SplitJob* jobs, int n);
 int bigc_weight_transposed(hipStream_t s, const float* W, int N, int K, int ldw, const float** wT);
 // y = act(dwconv(x) W^T + bias) (+ res) in one pass over x (grounding: every depth-wise-separable convolution of the QANet
 // encoders and of the heads, models/grd_model_v5.py:81-107): false when the current mode / shape needs the two-kernel form
+// y = act(relu(x8 W0^T + b0) W^T + bias): the K = 8 layer folded into the staging of the next GEMM; false -> two launches
+bool bigc_linear_pre8_supported(int N, int K);
+int bigc_linear_pre8(void* stream, const float* x8, const float* W0, const float* b0, const float* W, int ldw, const float* bias,
+                     float* C, int ldc, int M, int N, int K, int act);
 bool bigc_linear_dwsep_supported(int N, int K, int ks);
 int bigc_linear_dwsep(void* stream, const float* X, int ldx, const float* dw_w, const float* dw_b, int ks, int T, const int2* row_info,
                       const float* W, int ldw, const float* bias, const float* res, int ldr, float* C, int ldc, int M, int N, int K, int act);

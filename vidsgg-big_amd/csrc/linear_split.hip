@@ -134,7 +134,8 @@ __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((row >>
 // WN = wave columns: 2 -> 128x128 tile, 256 threads, two workgroups per CU; 4 -> 128x256 tile, 512 threads (one workgroup
 // per CU, same two waves per SIMD): the A slab is split once for eight waves instead of four.
 // DWK > 0: depth-wise-separable mode (LinearArgs::dw_*), DWK = kernel size of the depth-wise convolution.
-template <bool GATHER, bool KTAIL, int WN, int DWK = 0>
+// PRE8: preceding-layer mode (LinearArgs::pre_*).
+template <bool GATHER, bool KTAIL, int WN, int DWK = 0, bool PRE8 = false>
 __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linear_split_kernel(const LinearArgs p) {
     constexpr int NTH = 128 * WN, BNT = 64 * WN;     // threads, tile width
     constexpr int RPP = NTH / 8;                     // rows staged per pass (8 threads x 16 bytes per 32-k row)
@@ -210,6 +211,31 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
     auto load_a = [&](int kt, f32x4 (&ra)[NA]) {
         int kc, acol; bool kval;
         slab_cols(kt, kc, acol, kval);
+        if (PRE8) {
+            // a[row][k] = relu(b0[k] + sum_j x8[row][j] W0[k][j]), the operation order of linear_k8_kernel (linear.hip)
+            f32x4 w0[4], w1[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float* wp = p.pre_w + (size_t)(kc + c) * 8;
+                w0[c] = *(const f32x4*)wp;
+                w1[c] = *(const f32x4*)(wp + 4);
+            }
+            const f32x4 bq = *(const f32x4*)(p.pre_b + kc);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const float* xp = p.pre_x + (size_t)min(m0 + lr + RPP * i, p.M - 1) * 8;
+                const f32x4 a0 = *(const f32x4*)xp, a1 = *(const f32x4*)(xp + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = a0[0] * w0[c][0];
+                    v = fmaf(a0[1], w0[c][1], v); v = fmaf(a0[2], w0[c][2], v); v = fmaf(a0[3], w0[c][3], v);
+                    v = fmaf(a1[0], w1[c][0], v); v = fmaf(a1[1], w1[c][1], v); v = fmaf(a1[2], w1[c][2], v); v = fmaf(a1[3], w1[c][3], v);
+                    v += bq[c];
+                    ra[i][c] = fmaxf(v, 0.f);
+                }
+            }
+            return;
+        }
         if (DWK > 0) {
             // a[row][k] = b[k] + sum_j w[k][j] x[row + j - DWK/2][k]: all tap loads first, then the sums in the tap order of
             // dwconv_kernel (grounding.hip)
@@ -369,6 +395,19 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
                 }
                 av[mi] = *(const f32x4*)src;
                 if (zero) av[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (PRE8) {
+                    const float* xp = p.pre_x + (size_t)mrow * 8;
+                    const f32x4 a0 = *(const f32x4*)xp, a1 = *(const f32x4*)(xp + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float* wp = p.pre_w + (size_t)(kcl + c) * 8;
+                        float v = a0[0] * wp[0];
+                        v = fmaf(a0[1], wp[1], v); v = fmaf(a0[2], wp[2], v); v = fmaf(a0[3], wp[3], v);
+                        v = fmaf(a1[0], wp[4], v); v = fmaf(a1[1], wp[5], v); v = fmaf(a1[2], wp[6], v); v = fmaf(a1[3], wp[7], v);
+                        v += p.pre_b[kcl + c];
+                        av[mi][c] = kok ? fmaxf(v, 0.f) : 0.f;
+                    }
+                }
                 if (DWK > 0) {
                     int t, T;
                     if (p.dw_info) { const int2 v = p.dw_info[mrow]; t = v.x; T = v.y; } else { t = mrow % p.dw_T; T = p.dw_T; }
@@ -668,6 +707,13 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
     const int wn = p.dw_w ? 2 : (force_wn ? (force_wn == 4 ? 4 : 2) : ((p.N > 192 && (rem == 0 || rem > 128) && !few) ? 4 : 2));
     p.tiles_n = cdiv(p.N, 64 * wn);
     const int grid2 = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
+    if (p.pre_x) {
+        if (p.a_idx || ktail || p.dw_w) return bigc_fail(BIGC_ERR_ARG, "linear_split: preceding-layer mode needs K %% 32 == 0, no gather");
+        if (wn == 4) hipLaunchKernelGGL((linear_split_kernel<false, false, 4, 0, true>), dim3(grid2), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((linear_split_kernel<false, false, 2, 0, true>), dim3(grid2), dim3(256), 0, s, p);
+        BIGC_LAUNCH_CHECK("linear_split (pre8)");
+        return BIGC_OK;
+    }
     if (p.dw_w) {
         if (p.a_idx || ktail || (p.dw_ks != 3 && p.dw_ks != 7)) return bigc_fail(BIGC_ERR_ARG, "linear_split: depth-wise mode needs K %% 32 == 0, no gather, ks 3 or 7");
         if (p.dw_ks == 3) hipLaunchKernelGGL((linear_split_kernel<false, false, 2, 3>), dim3(grid2), dim3(256), 0, s, p);

@@ -133,8 +133,12 @@ int run_frontend(const bigc_model* m, void* s, const bigc_batch* b, const Work& 
     const int R = b->n_rows, NT = b->n_trk, C = b->n_conv;
     const int de = c.dim_enti, D = c.dim_feat + c.dim_extra;
     TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
-    TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
-    TRY(linear(s, w.hb, de, m->bbox2, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
+    if (bigc_linear_pre8_supported(de, de)) {     // the 8 -> de layer evaluated inside the staging of the de -> de GEMM: hb is never written
+        TRY(bigc_linear_pre8(s, w.bbox8, m->bbox0.w, m->bbox0.b, m->bbox2.w, de, m->bbox2.b, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
+    } else {
+        TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
+        TRY(linear(s, w.hb, de, m->bbox2, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
+    }
     TRY(linear(s, b->feats, D, m->feat0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
     TRY(linear(s, w.hv, de, m->feat2, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
     TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));

@@ -147,6 +147,10 @@ TRAIN_CASES = {
     # exp2 dims, one N=16 video: loss terms, matching, gradient norms of every parameter + a few full gradients
     "bigc_train_v": dict(cfg="CONFIG_V", variant="vidvrd", wseed=53, att_gain=3.0, full=False,
                          videos=[dict(seed=704, n_trajs=16)], gts=[dict(seed=714, n_gt_trajs=6, n_preds=5)]),
+    # exp5 dims (model_0v7: RoI 1024 + classeme 300, 6 encoder / 4 decoder layers), two videos of N = 14 / 9: VidOR training step
+    "bigo_train_o": dict(cfg="CONFIG_O", variant="vidor", wseed=54, att_gain=3.0, full=False,
+                         videos=[dict(seed=705, n_trajs=14), dict(seed=706, n_trajs=9)],
+                         gts=[dict(seed=715, n_gt_trajs=6, n_preds=5), dict(seed=716, n_gt_trajs=4, n_preds=3)]),
 }
 TRAIN_FULL_GRADS_V = ["fc_pred2logits.bias", "decoder_layers.5.norm3.weight", "decoder_layers.0.fc_pred2att.bias",
                       "encoder_layers.0.norm1.weight", "conv_feat2enti.bias", "fc_bbox2enti.0.weight", "pos_embedding"]

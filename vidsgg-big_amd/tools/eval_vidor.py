@@ -74,7 +74,8 @@ def evaluate_cls_stage(cfg_path, ckpt_path=None, save_tag="", output_dir=None, c
     return _report(groundtruth, predictions, output_dir, "VidORval_predict_relations_{}.json".format(save_tag), save_json, device)
 
 
-def evaluate_combined(cfg_path, ckpt_path, cls_stage_result_path, save_tag="", output_dir=None, cuda=0, save_json=False, synthetic=0, n_trajs=32):
+def evaluate_combined(cfg_path, ckpt_path, cls_stage_result_path, save_tag="", output_dir=None, cuda=0, save_json=False, synthetic=0, n_trajs=32,
+                      grd_batch=8):
     cfg = parse_config_py(cfg_path)
     ic = cfg["inference_config"]
     output_dir = output_dir or os.path.dirname(os.path.abspath(cfg_path))
@@ -89,24 +90,37 @@ def evaluate_combined(cfg_path, ckpt_path, cls_stage_result_path, save_tag="", o
         cls_results = pickle.load(f)
     predictions, groundtruth, n_skipped = {}, {}, 0
     t0 = time.time()
+    th = (ic["score_th"], ic["tiou_th"], ic["bins_th"], ic["nms_th"])
+
+    def flush(batch):
+        """several videos per launch sequence (grd_forward_batch); the reference scores them one by one (tools/eval_vidor.py)"""
+        nonlocal n_skipped
+        if not batch:
+            return
+        jobs = [(clip.to(device), res[0].to(device), res[2].to(device), p.video_len) for p, res, clip in batch]
+        with torch.no_grad():
+            outs = model.forward_raw_batch(jobs, *th)
+        for (p, res, clip), o in zip(batch, outs):
+            if int(o["status"].item()) != 0:
+                # the reference stops here (min() of an empty selection, models/grd_model_v5.py:726)
+                print("skipping {}: temporal pooling selected no clip for some (query, bin): all scores are zero".format(p.video_name))
+                n_skipped += 1
+                continue
+            out = (o["pooled_se"], o["bins_probs"], o["bins_mask"].bool())
+            predictions.update(E.to_eval_format(p.to(torch.device("cpu")), combine_with_grounding(res, out, p.video_len), dataset_type="vidor"))
+
+    batch = []
     for p, g, clip in data:
         if g is not None and synthetic:
             groundtruth[E.reset_video_name(p.video_name, "vidor")] = E.gt_to_eval_format(g, dataset_type="vidor")
         res = cls_results.get(p.video_name)
-        if res is None:
+        if res is None or res[0] is None or res[0].shape[0] == 0:
             continue
-        quint, scores, dura, qid = res
-        try:
-            with torch.no_grad():
-                out = model([clip.to(device)], [(quint.to(device), dura.to(device), p.video_len)], ic["score_th"], ic["tiou_th"],
-                            ic["bins_th"], ic["nms_th"], with_gt_data=False)
-        except IndexError as e:          # the reference stops here (min() of an empty selection, models/grd_model_v5.py:726)
-            print("skipping {}: {}".format(p.video_name, e))
-            n_skipped += 1
-            continue
-        if out[0] is None:
-            continue
-        predictions.update(E.to_eval_format(p.to(torch.device("cpu")), combine_with_grounding(res, out, p.video_len), dataset_type="vidor"))
+        batch.append((p, res, clip))
+        if len(batch) == grd_batch:
+            flush(batch)
+            batch = []
+    flush(batch)
     print("grounding: %d videos (%d skipped) in %.2f s" % (len(data), n_skipped, time.time() - t0))
     return _report(groundtruth, predictions, output_dir, "VidORval_predict_relations_aft_grd_{}.json".format(save_tag), save_json, device)
 
@@ -125,6 +139,7 @@ if __name__ == "__main__":
     ap.add_argument("--cls_stage_result_path", type=str, default=None)
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N generated videos instead of a dataset")
     ap.add_argument("--n_trajs", type=int, default=32)
+    ap.add_argument("--grd_batch", type=int, default=8, help="videos per grounding launch sequence (1 = the reference's one video per forward)")
     a = ap.parse_args()
     if a.json_results_path is not None:
         with open(a.json_results_path) as f:
@@ -134,4 +149,4 @@ if __name__ == "__main__":
                            model_class=Base_C if a.use_baseline else BIG_C_vidor)        # tools/eval_vidor.py:310
     else:
         evaluate_combined(a.cfg_path, a.ckpt_path, a.cls_stage_result_path, a.save_tag, a.output_dir, a.cuda, a.save_json_results,
-                          a.synthetic, a.n_trajs)
+                          a.synthetic, a.n_trajs, a.grd_batch)

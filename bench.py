@@ -559,7 +559,27 @@ def main():
         torch.set_num_threads(usable_cores())
         cpu_pairs, n_done, cpu_s = 0, 0, 0.0
         rows_total, rows_same, vids_same, max_rel, other_argmax = 0, 0, 0, 0.0, 0
-        over, over_worse, sd64 = [], 0, None
+        over, over_worse, sd64, row_diffs = [], 0, None, []
+
+        def f64_eval(p):
+            """the oracle once more in float64 (the arbiter where two f32 evaluations disagree; outside the CPU timing)"""
+            nonlocal sd64
+            import copy
+            if sd64 is None:
+                sd64 = {k: t.double() for k, t in sd.items()}
+            p64 = copy.deepcopy(p)
+            p64.bboxes_list = [x.double() for x in p64.bboxes_list]
+            p64.features_list = [x.double() for x in p64.features_list]
+            p64.scores = p64.scores.double()
+            o64 = O.encode2decode(sd64, cfg, p64)
+            return o64, O.construct_triplet(p64, o64["pred_logits"], o64["att"], args.topk)
+
+        def same_rows(a_quint, a_dura, a_qid, n_a, res):
+            n_r = 0 if res is None else int(res[0].shape[0])
+            if n_a != n_r:
+                return False
+            return n_r == 0 or bool(((a_quint[:n_r] == res[0].numpy()).all(1) & (a_dura[:n_r] == res[2].numpy()).all(1) & (a_qid[:n_r] == res[3].numpy())).all())
+
         with torch.no_grad():
             O.forward_test(sd, cfg, [synthetic_proposal(base, n_trajs=args.n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"])], args.topk)  # warm-up
             for v in range(n_cpu):                                      # bounded: stop after ~15 s of oracle time
@@ -579,9 +599,18 @@ def main():
                     eq = ((hip_quint[v, :m] == res[0].numpy()[:m]).all(1) & (hip_dura[v, :m] == res[2].numpy()[:m]).all(1)
                           & (hip_qid[v, :m] == res[3].numpy()[:m]))
                     rows_same += int(eq.sum())
-                    vids_same += int(n_o == n_h and bool(eq.all()))
+                    vid_same = n_o == n_h and bool(eq.all())
                 else:
-                    vids_same += int(n_o == n_h)
+                    vid_same = n_o == n_h
+                vids_same += int(vid_same)
+                if not vid_same and len(row_diffs) < 8:
+                    # a triplet row differs between two f32 evaluations (a top-k / arg-max decision within round-off of a tie):
+                    # which of the two does the float64 oracle side with?
+                    _, res64 = f64_eval(p)
+                    row_diffs.append(dict(video=v, rows_differing=int(max(n_o, n_h) - (int(eq.sum()) if m else 0)),
+                                          hip_rows_equal_the_f64_oracles=same_rows(hip_quint[v], hip_dura[v], hip_qid[v], n_h, res64),
+                                          f32_oracle_rows_equal_the_f64_oracles=same_rows(res[0].numpy() if res else None, res[2].numpy() if res else None,
+                                                                                           res[3].numpy() if res else None, n_o, res64)))
                 so_ref = o["att"].argmax(-1).numpy()                    # (2, Q)
                 same_so = (hip_soid[v] == so_ref).all(0)
                 other_argmax += int((~same_so).sum())
@@ -591,14 +620,7 @@ def main():
                     max_rel = max(max_rel, d)
                     if d > 1e-4 and len(over) < 8:
                         # two f32 evaluations more than 1e-4 apart: a float64 evaluation of the oracle arbitrates (outside the CPU timing)
-                        import copy
-                        if sd64 is None:
-                            sd64 = {k: t.double() for k, t in sd.items()}
-                        p64 = copy.deepcopy(p)
-                        p64.bboxes_list = [x.double() for x in p64.bboxes_list]
-                        p64.features_list = [x.double() for x in p64.features_list]
-                        p64.scores = p64.scores.double()
-                        l64 = O.encode2decode(sd64, cfg, p64)["pred_logits"].numpy()
+                        l64 = f64_eval(p)[0]["pred_logits"].numpy()
                         e_hip = float(np.abs(hip_logits[v][same_so] - l64[same_so]).max() / np.abs(lg).max())
                         e_ref = float(np.abs(lg[same_so] - l64[same_so]).max() / np.abs(lg).max())
                         over.append(dict(video=v, hip_vs_f32_oracle=d, hip_vs_f64=e_hip, f32_oracle_vs_f64=e_ref))
@@ -610,6 +632,7 @@ def main():
                                    "(= forward_test), fp32 torch CPU, %.1f s" % (n_done, args.n_trajs, cpu_s))
         oracle_parity = dict(videos=n_done, identical_triplet_rows="%d of %d" % (rows_same, rows_total), videos_fully_identical=vids_same,
                              max_logit_rel=max_rel, queries_with_other_argmax_entity=other_argmax,
+                             videos_with_differing_rows=row_diffs,
                              videos_over_1e_4=over, videos_over_1e_4_where_hip_is_farther_from_f64_than_the_f32_oracle=over_worse,
                              note="HIP output of the timed workload vs the CPU oracle on the same videos; logits compared on the queries whose "
                                   "attention arg-max (subject, object) agrees, relative to max |logit| of the video; the benchmark model's sharp "

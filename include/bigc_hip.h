@@ -530,6 +530,12 @@ int bigc_gemm_ps(void* stream, const void* A, long lda_bytes, int a_fmt, const i
                  int M, int N, int K, int act, int* range_flag);
 /* f32 rows (rows, K) -> hr8 rows; K % 8 == 0 */
 int bigc_split_rows_f32(void* stream, const float* X, long ldx, void* Y, long ldy_bytes, long rows, int K, int* range_flag);
+/* act(A W^T + bias) + residual on the default split-operand GEMM (f32 A, as bigc_linear_f32) with the result written in the split
+ * form "hr8" (Cs, pitch ldcs_bytes; N % 8 == 0) and / or as f32 (C may be NULL): the producer side of a GEMM -> GEMM chain whose
+ * second GEMM is bigc_gemm_ps (models/model_0v10.py:446-448 fc_feat2enti.0 -> .2 -> conv, FFN pairs :113, :220).  K == 8 runs
+ * the store-bound FMA kernel.  An element the split form cannot hold sets *range_flag. */
+int bigc_linear_hr8out_f32(void* stream, const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
+                           float* C, int ldc, void* Cs, long ldcs_bytes, int M, int N, int K, int act, int* range_flag);
 
 #ifdef __cplusplus
 }

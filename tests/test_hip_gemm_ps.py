@@ -163,3 +163,49 @@ def test_gemm_ps_range_flag():
     tiny = run(A, 0, W * 1e-6, want_hr8=False)                      # every weight matrix gets its own exponent: tiny weights keep f32-level accuracy
     want = A.double() @ (W.double() * 1e-6).t()
     assert tiny[2] == 0 and bool(((tiny[0].double() - want).abs() <= 2e-6 * want.abs().max()).all())
+
+
+@pytest.mark.parametrize("M,N,K,act,use_res,want_f32", [(300, 512, 512, 1, False, False), (1000, 256, 2048, 1, False, True), (129, 64, 96, 0, True, True),
+                                                          (5000, 512, 8, 1, False, False), (777, 1024, 512, 1, False, False)])
+def test_default_gemm_writes_the_split_form_for_the_next_gemm(M, N, K, act, use_res, want_f32):
+    """bigc_linear_hr8out_f32: the split-operand GEMM with f32 input (linear_split_kernel; K = 8: linear_k8_kernel) writing its
+    result as hr8: decoded, it equals the f32 result of bigc_linear_f32 on the same inputs within the representation error, and
+    its f32 twin (when asked for) is bit-identical to it"""
+    lib = _lib.load()
+    rs = np.random.RandomState(M + N + K)
+    A = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(DEV)
+    R = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).to(DEV) if use_res else None
+    want = torch.empty((M, N), device=DEV)
+    _lib.check(lib.bigc_linear_f32(_lib.current_stream(), A.data_ptr(), K, None, 1, K, W.data_ptr(), K, b.data_ptr(), _lib.ptr(R), N, want.data_ptr(), N,
+                                   M, N, K, act))
+    C = torch.full((M, N), float("nan"), device=DEV) if want_f32 else None
+    Cs = torch.zeros((M, 4 * N), dtype=torch.uint8, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(lib.bigc_linear_hr8out_f32(_lib.current_stream(), A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), _lib.ptr(R), N, _lib.ptr(C), N,
+                                          Cs.data_ptr(), 4 * N, M, N, K, act, flag.data_ptr()))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    w64 = want.double().cpu().numpy()
+    assert (np.abs(hr8_decode(Cs, M, N) - w64) <= repr_tol(w64)).all()
+    if want_f32:
+        assert torch.equal(C, want)
+    # ... and it feeds bigc_gemm_ps directly
+    W2 = torch.from_numpy((rs.standard_normal((64, N)) / np.sqrt(N)).astype(np.float32)).to(DEV)
+    C2, _, f2 = run(Cs, 1, W2, want_hr8=False, lda_bytes=4 * N)
+    assert f2 == 0
+    ref = want.double() @ W2.double().t()
+    assert float((C2.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+def test_default_gemm_split_form_output_raises_the_range_flag():
+    lib = _lib.load()
+    A = torch.ones((128, 64), device=DEV)
+    W = torch.full((16, 64), 100.0, device=DEV)           # outputs 6400 * 8 = 51200 >= 32768 in the scaled form
+    Cs = torch.zeros((128, 64), dtype=torch.uint8, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(lib.bigc_linear_hr8out_f32(_lib.current_stream(), A.data_ptr(), 64, W.data_ptr(), 64, None, None, 0, None, 0, Cs.data_ptr(), 64,
+                                          128, 16, 64, 0, flag.data_ptr()))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void linear_k8_kernel(const LinearArgs p) {
     if (p.bias) bv = *(const f32x4*)(p.bias + 4 * c4);
     const bool relu = p.act == BIGC_ACT_RELU, sigm = p.act == BIGC_ACT_SIGMOID;
     const int r0 = blockIdx.x * SK_ROWS, r1 = min(r0 + SK_ROWS, p.M);
+    bool oob = false;
     for (int r = r0 + rl; r < r1; r += nrl) {
         const float* ap = p.A + (size_t)r * p.lda;
         const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4);
@@ -212,8 +213,36 @@ __global__ __launch_bounds__(256) void linear_k8_kernel(const LinearArgs p) {
             o[j] = v;
         }
         if (p.res) o += *(const f32x4*)(p.res + (size_t)r * p.ldr + 4 * c4);
-        *(f32x4*)(p.C + (size_t)r * p.ldc + 4 * c4) = o;
+        if (p.C) *(f32x4*)(p.C + (size_t)r * p.ldc + 4 * c4) = o;
+        if (p.Cs) {
+            // split form "hr8" (gemm_ps.hip): a group is 8 columns = this lane's four and its neighbour's (c4 ^ 1, the adjacent lane)
+            const f32x4 x = o * (float)(1 << PS_ACT_EXP);
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = __shfl_xor(x[j], 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oob = oob || !(fabsf(x[j]) < 32768.0f);
+            if ((c4 & 1) == 0) {
+                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                typedef float f2_t __attribute__((ext_vector_type(2)));
+                uint4 hh, rr;
+                unsigned* hp = (unsigned*)&hh;
+                unsigned* rp = (unsigned*)&rr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f2_t v2 = q < 2 ? f2_t{x[2 * q], x[2 * q + 1]} : f2_t{y[2 * q - 4], y[2 * q - 3]};
+                    const h2_t h2 = __builtin_convertvector(v2, h2_t);
+                    const h2_t r2 = __builtin_convertvector(v2 - __builtin_convertvector(h2, f2_t), h2_t);
+                    hp[q] = *(const unsigned*)&h2;
+                    rp[q] = *(const unsigned*)&r2;
+                }
+                uint4* yp = (uint4*)(p.Cs + (size_t)r * p.ldcs + (size_t)(c4 >> 1) * 32);
+                yp[0] = hh;
+                yp[1] = rr;
+            }
+        }
     }
+    if (p.Cs && oob && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
 }  // namespace
@@ -222,6 +251,48 @@ __global__ __launch_bounds__(256) void linear_k8_kernel(const LinearArgs p) {
 static std::atomic<int> g_exact_mode{(getenv("BIGC_LINEAR_EXACT") && atoi(getenv("BIGC_LINEAR_EXACT")) != 0) ? 1 : 0};
 extern "C" int bigc_linear_set_exact(int exact) { return g_exact_mode.exchange(exact ? 1 : 0); }
 extern "C" int bigc_linear_get_exact(void) { return g_exact_mode.load(); }
+
+int bigc_linear_hr8out(void* stream, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
+                       float* C, int ldc, void* Cs, long ldcs, int M, int N, int K, int act, int* range_flag) {
+    BIGC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && A && W && Cs, "linear_hr8out: bad argument");
+    BIGC_CHECK_ARG(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && N % 8 == 0 && ldcs % 4 == 0 && ((uintptr_t)Cs & 15) == 0 && ((uintptr_t)A & 15) == 0 &&
+                   ((uintptr_t)W & 15) == 0, "linear_hr8out: alignment (N=%d must be a multiple of 8)", N);
+    BIGC_CHECK_ARG(g_exact_mode.load() == 0, "linear_hr8out: not available in exact mode");
+    if (M == 0) return BIGC_OK;
+    LinearArgs p;
+    p.A = A; p.lda = lda; p.a_idx = nullptr; p.nseg = 1; p.seg_len = K;
+    p.W = W; p.ldw = ldw; p.bias = bias; p.res = res; p.ldr = ldr; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.act = act;
+    p.tiles_m = cdiv(M, BM); p.tiles_n = 0;
+    p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr; p.zero_row = nullptr;
+    p.Cs = (unsigned char*)Cs; p.ldcs = ldcs * 4; p.range_flag = range_flag;
+    const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * ((res ? 1 : 0) + (C ? 2 : 1)));
+    return bigc_linear_split_launch((hipStream_t)stream, p, flops, bytes);
+}
+
+int bigc_linear_k8_hr8out(void* stream, const float* A, const float* W, const float* bias, void* Cs, long ldcs, int M, int N, int act, int* range_flag) {
+    BIGC_CHECK_ARG(A && W && Cs && M >= 0 && N % 8 == 0 && N <= 1024 && 256 % (N / 4) == 0 && ((uintptr_t)Cs & 15) == 0 && ldcs % 4 == 0 &&
+                   (!bias || ((uintptr_t)bias & 15) == 0), "linear_k8_hr8out: bad argument");
+    if (M == 0) return BIGC_OK;
+    LinearArgs p;
+    p.A = A; p.lda = 8; p.a_idx = nullptr; p.nseg = 1; p.seg_len = 8;
+    p.W = W; p.ldw = 8; p.bias = bias; p.res = nullptr; p.ldr = 0; p.C = nullptr; p.ldc = 0;
+    p.M = M; p.N = N; p.K = 8; p.act = act; p.tiles_m = 0; p.tiles_n = 0;
+    p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr; p.zero_row = nullptr;
+    p.Cs = (unsigned char*)Cs; p.ldcs = ldcs * 4; p.range_flag = range_flag;
+    ProfScope ps(stream, FAM_LINEAR_AUX, 2.0 * M * (double)N * 8, 4.0 * ((double)M * 8 + (double)M * N));
+    hipLaunchKernelGGL(linear_k8_kernel, dim3(cdiv(M, SK_ROWS)), dim3(256), 0, (hipStream_t)stream, p);
+    BIGC_LAUNCH_CHECK("linear_k8 (hr8)");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_linear_hr8out_f32(void* stream, const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
+                                      float* C, int ldc, void* Cs, long ldcs_bytes, int M, int N, int K, int act, int* range_flag) {
+    BIGC_CHECK_ARG(ldcs_bytes % 16 == 0, "linear_hr8out: ldcs_bytes must be a multiple of 16");
+    if (K == 8 && !C && !residual && lda == 8 && ldw == 8)
+        return bigc_linear_k8_hr8out(stream, A, W, bias, Cs, ldcs_bytes / 4, M, N, act, range_flag);
+    return bigc_linear_hr8out(stream, A, lda, W, ldw, bias, residual, ldr, C, ldc, Cs, ldcs_bytes / 4, M, N, K, act, range_flag);
+}
 
 bool bigc_linear_pre8_supported(int N, int K) {
     // Opt-in (BIGC_PRE8_FUSED=1).  Measured on the 256-video step: hb (1.19 GB written + read) disappears and so does the 0.29 ms

@@ -19,6 +19,9 @@ struct LinearArgs {
     // split kernel, preceding-layer mode: A = relu(pre_x pre_w^T + pre_b) with pre_x (M, 8), pre_w (K, 8), pre_b (K), evaluated while
     // the rows are staged (fc_bbox2enti.0 -> .2, models/model_0v10.py:446: the 8 -> 512 layer's output never exists in HBM)
     const float* pre_x = nullptr; const float* pre_w = nullptr; const float* pre_b = nullptr;
+    // split kernel: also / instead of C, the result in the split form "hr8" of gemm_ps.hip (pitch in BYTES; N % 8 == 0); an
+    // element that form cannot hold sets *range_flag
+    unsigned char* Cs = nullptr; long ldcs = 0; int* range_flag = nullptr;
 };
 
 // Weights that stay constant between launches are split once and cached per (pointer, shape) for an "epoch": the model
@@ -53,6 +56,12 @@ int bigc_linear_prepare(hipStream_t s, const SplitJob* jobs, int n);
 int bigc_weight_transposed(hipStream_t s, const float* W, int N, int K, int ldw, const float** wT);
 // y = act(dwconv(x) W^T + bias) (+ res) in one pass over x (grounding: every depth-wise-separable convolution of the QANet
 // encoders and of the heads, models/grd_model_v5.py:81-107): false when the current mode / shape needs the two-kernel form
+// C (f32, may be null) and / or Cs (split form "hr8", pitch ldcs floats = 4 ldcs bytes) = act(A W^T + bias) + res on linear_split_kernel:
+// the producer side of a GEMM -> GEMM chain whose second GEMM runs on gemm_ps.hip
+int bigc_linear_hr8out(void* stream, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
+                       float* C, int ldc, void* Cs, long ldcs, int M, int N, int K, int act, int* range_flag);
+// the K = 8 GEMM (linear_k8_kernel) with its output in the split form
+int bigc_linear_k8_hr8out(void* stream, const float* A, const float* W, const float* bias, void* Cs, long ldcs, int M, int N, int act, int* range_flag);
 // y = act(relu(x8 W0^T + b0) W^T + bias): the K = 8 layer folded into the staging of the next GEMM; false -> two launches
 bool bigc_linear_pre8_supported(int N, int K);
 int bigc_linear_pre8(void* stream, const float* x8, const float* W0, const float* b0, const float* W, int ldw, const float* bias,

@@ -129,6 +129,18 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const PrepArgs a) {
     if (!(fabsf(chk) < INFINITY) || amax >= F16_LIMIT) *J.bad = J.bad_id;
 }
 
+// two f32 (already scaled) -> packed (head, head) and (residual, residual) of the "hr8" form, round to nearest
+__device__ __forceinline__ void split_rtn2(float x0, float x1, unsigned& h, unsigned& r) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t v = {x0, x1};
+    const h2_t hh = __builtin_convertvector(v, h2_t);
+    const f2_t d = v - __builtin_convertvector(hh, f2_t);
+    const h2_t rr = __builtin_convertvector(d, h2_t);
+    h = *(const unsigned*)&hh;
+    r = *(const unsigned*)&rr;
+}
+
 __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((row >> 2) & 3); }
 
 // WN = wave columns: 2 -> 128x128 tile, 256 threads, two workgroups per CU; 4 -> 128x256 tile, 512 threads (one workgroup
@@ -442,6 +454,9 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
         bv[ni] = p.bias ? p.bias[min(colv[ni], p.N - 1)] : 0.f;
     }
     const bool relu = p.act == BIGC_ACT_RELU, sigm = p.act == BIGC_ACT_SIGMOID;
+    constexpr int HP = 68;                      // pitch (floats) of the transposition corner of the split-form output
+    constexpr float PS_SCALE = (float)(1 << PS_ACT_EXP);
+    bool hr_oob = false;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int rbase = m0 + wm * 64 + mi * 32;
@@ -459,21 +474,61 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
 #pragma unroll
                 for (int r = 0; r < 16; ++r) rv[ni][r] = 0.f;
         }
+        if (!p.Cs) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            if (colv[ni] >= p.N) continue;
-            float* cp = p.C + colv[ni];
+            for (int ni = 0; ni < 2; ++ni) {
+                if (colv[ni] >= p.N) continue;
+                float* cp = p.C + colv[ni];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + mfma_row(r, hi);
+                    float v = (acc0[mi][ni][r] + acc1[mi][ni][r] * RINV) + bv[ni];
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (sigm) v = 1.0f / (1.0f + expf(-v));
+                    v += rv[ni][r];
+                    if (row < p.M) cp[(size_t)row * p.ldc] = v;
+                }
+            }
+            continue;
+        }
+        // Output in the split form "hr8" of gemm_ps.hip (the next GEMM's operand: per 8 columns, 16 bytes of f16 heads then 16 of
+        // residuals of x * 2^PS_ACT_EXP).  A lane owns one column and 16 rows of a block; a group needs 8 columns of one row: the
+        // wave's 32 x 64 values go through its own corner of the (now idle) staging LDS, natural row order, pitch 68 floats.
+        float* tr = (float*)&smem[0][0] + wave * (32 * HP);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = rbase + mfma_row(r, hi);
                 float v = (acc0[mi][ni][r] + acc1[mi][ni][r] * RINV) + bv[ni];
                 if (relu) v = fmaxf(v, 0.f);
                 if (sigm) v = 1.0f / (1.0f + expf(-v));
                 v += rv[ni][r];
-                if (row < p.M) cp[(size_t)row * p.ldc] = v;
+                if (p.C && colv[ni] < p.N && rbase + mfma_row(r, hi) < p.M) p.C[(size_t)(rbase + mfma_row(r, hi)) * p.ldc + colv[ni]] = v;
+                tr[mfma_row(r, hi) * HP + ni * 32 + l31] = v;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const int lrow = pp * 8 + (lane >> 3), g = lane & 7;
+            const f32x4 x0 = *(const f32x4*)(tr + lrow * HP + 8 * g) * PS_SCALE, x1 = *(const f32x4*)(tr + lrow * HP + 8 * g + 4) * PS_SCALE;
+            const int row = rbase + lrow, col0 = n0 + wn * 64 + 8 * g;
+            const bool ok = row < p.M && col0 < p.N;
+            uint4 hh, rr;
+            split_rtn2(x0[0], x0[1], hh.x, rr.x); split_rtn2(x0[2], x0[3], hh.y, rr.y);
+            split_rtn2(x1[0], x1[1], hh.z, rr.z); split_rtn2(x1[2], x1[3], hh.w, rr.w);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hr_oob = hr_oob || (ok && (!(fabsf(x0[c]) < F16_LIMIT) || !(fabsf(x1[c]) < F16_LIMIT)));
+            if (ok) {
+                uint4* yp = (uint4*)(p.Cs + (size_t)row * p.ldcs + (size_t)(col0 >> 3) * 32);
+                yp[0] = hh;
+                yp[1] = rr;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
+    if (p.Cs && hr_oob && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
 // split weights: one allocation per (pointer, shape) = [int bad | pad to 256 B | N x K/4 groups]; re-split in place when the

@@ -317,6 +317,33 @@ bool ps_config_ok(const bigc_config& c) {
     return (c.dim_enti * c.enco_pool_len) % 32 == 0 && (c.dim_att / 2) % 8 == 0;
 }
 
+// Default eval path, GEMM -> GEMM chains ("chained" mode): where a GEMM's output only feeds another GEMM, the first one
+// (linear_split_kernel: f32 operand, split in the loop) writes it in the split form and the second one runs on gemm_ps.hip, whose
+// K loop is DMA + MFMA only.  Measured in the model (rocprofv3, 256-video step): conv GEMM 4.65 -> 3.79 ms, fc_feat2enti.2
+// 1.09 -> 0.82 ms.  GEMMs whose operand comes from a LayerNorm, an attention kernel or the input features stay on linear_split
+// (gemm_ps with an f32 operand is slower than it).  hb / hv / enti / eh / fh / the decoder's FFN hidden are hr8 in this mode.
+int run_frontend_chained(const bigc_model* m, void* s, const bigc_batch* b, const Work& w, float* e2e) {
+    const bigc_config& c = m->cfg;
+    const int R = b->n_rows, NT = b->n_trk, C = b->n_conv;
+    const int de = c.dim_enti, D = c.dim_feat + c.dim_extra;
+    PsCtx cx{(hipStream_t)s, w.flag};
+    TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
+    TRY(bigc_linear_k8_hr8out(s, w.bbox8, m->bbox0.w, m->bbox0.b, w.hb, de, R, de, BIGC_ACT_RELU, w.flag));
+    TRY(ps(cx, w.hb, de, true, m->bbox2, de, nullptr, 0, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
+    TRY(bigc_linear_hr8out(s, b->feats, D, m->feat0.w, c.dim_feat, m->feat0.b, nullptr, 0, nullptr, 0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU, w.flag));
+    TRY(ps(cx, w.hv, de, true, m->feat2, de, nullptr, 0, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
+    TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
+    {
+        Lin cw{m->conv_w_tapmajor, m->conv.b};
+        TRY(ps(cx, w.enti, 2 * de, true, cw, 6 * de, w.conv, de, nullptr, 0, C, de, 6 * de, BIGC_ACT_NONE, nullptr, 0, w.conv_idx, 3));
+    }
+    TRY(bigc_adaptive_maxpool(s, w.conv, b->trk_conv_off, w.pooled, NT, de, c.enco_pool_len));
+    TRY(bigc_linear_hr8out(s, w.pooled, de * c.enco_pool_len, m->enco0.w, de * c.enco_pool_len, m->enco0.b, nullptr, 0, nullptr, 0, w.eh, de, NT, de,
+                           de * c.enco_pool_len, BIGC_ACT_RELU, w.flag));
+    TRY(ps(cx, w.eh, de, true, m->enco2, de, e2e, de, nullptr, 0, NT, de, de, BIGC_ACT_RELU));
+    return BIGC_OK;
+}
+
 int forward_ps(bigc_model* m, void* stream, const bigc_batch* b, const Work& w, int topk, const bigc_outputs* out) {
     const bigc_config& c = m->cfg;
     hipStream_t hs = (hipStream_t)stream;
@@ -515,6 +542,11 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
     static const bool ps_on = getenv("BIGC_PS") && atoi(getenv("BIGC_PS")) != 0;
     if (out->range_flag && ps_on && !bigc_linear_get_exact() && ps_config_ok(c)) return forward_ps(m, stream, b, w, topk, out);
     if (out->range_flag && hipMemsetAsync(out->range_flag, 0, sizeof(int32_t), hs) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: memset failed");
+    // chained mode (default when the caller reads the range flag; BIGC_CHAINED=0 switches it off): see run_frontend_chained
+    static const bool chained_off = getenv("BIGC_CHAINED") && atoi(getenv("BIGC_CHAINED")) == 0;
+    const bool chained = out->range_flag && !chained_off && !bigc_linear_get_exact() && ps_config_ok(c);
+    PsCtx cx{hs, w.flag};
+    if (chained && hipMemsetAsync(w.flag, 0, sizeof(int32_t), hs) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: memset failed");
     const int NT = b->n_trk, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
     const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn;
     const int D = c.dim_feat + c.dim_extra;
@@ -522,7 +554,8 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
     const float eps = 1e-5f;
 
     float* e2e = out->enti2enco ? out->enti2enco : w.e2e;
-    TRY(run_frontend(m, s, b, w, e2e));
+    if (chained) TRY(run_frontend_chained(m, s, b, w, e2e));
+    else TRY(run_frontend(m, s, b, w, e2e));
 
     // ---- a5: encoder, sequence = the tracklets of a video (:459-462, layer :103-117)
     const float* x = e2e;
@@ -533,8 +566,13 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
                               B, b->max_trk, H, hd, nullptr));
         TRY(linear(s, w.ao, de, L.out_proj, w.t1, de, NT, de, de, BIGC_ACT_NONE, x, de));
         TRY(bigc_layernorm_f32(s, w.t1, L.n1.g, L.n1.b, w.x1, NT, de, eps));
-        TRY(linear(s, w.x1, de, L.l1, w.fh, df, NT, df, de, BIGC_ACT_RELU));
-        TRY(linear(s, w.fh, df, L.l2, w.t1, de, NT, de, df, BIGC_ACT_NONE, w.x1, de));
+        if (chained) {
+            TRY(bigc_linear_hr8out(s, w.x1, de, L.l1.w, de, L.l1.b, nullptr, 0, nullptr, 0, w.fh, df, NT, df, de, BIGC_ACT_RELU, w.flag));
+            TRY(ps(cx, w.fh, df, true, L.l2, df, w.t1, de, nullptr, 0, NT, de, df, BIGC_ACT_NONE, w.x1, de));
+        } else {
+            TRY(linear(s, w.x1, de, L.l1, w.fh, df, NT, df, de, BIGC_ACT_RELU));
+            TRY(linear(s, w.fh, df, L.l2, w.t1, de, NT, de, df, BIGC_ACT_NONE, w.x1, de));
+        }
         float* xo = (i == c.n_enco_layers - 1) ? (out->enco_output ? out->enco_output : w.enco) : w.x0;
         TRY(bigc_layernorm_f32(s, w.t1, L.n2.g, L.n2.b, xo, NT, de, eps));
         x = xo;
@@ -597,8 +635,13 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         TRY(linear(s, w.rh, dp, L.role1[1], w.t3, dp, BQ, dp, dp, BIGC_ACT_NONE, w.t2, dp));
         }
         TRY(bigc_layernorm_f32(s, w.t3, L.n2.g, L.n2.b, w.t2, BQ, dp, eps));
-        TRY(linear(s, w.t2, dp, L.f0, w.rh, df, BQ, df, dp, BIGC_ACT_RELU));
-        TRY(linear(s, w.rh, df, L.f3, w.t3, dp, BQ, dp, df, BIGC_ACT_NONE, w.t2, dp));
+        if (chained) {
+            TRY(bigc_linear_hr8out(s, w.t2, dp, L.f0.w, dp, L.f0.b, nullptr, 0, nullptr, 0, w.rh, df, BQ, df, dp, BIGC_ACT_RELU, w.flag));
+            TRY(ps(cx, w.rh, df, true, L.f3, df, w.t3, dp, nullptr, 0, BQ, dp, df, BIGC_ACT_NONE, w.t2, dp));
+        } else {
+            TRY(linear(s, w.t2, dp, L.f0, w.rh, df, BQ, df, dp, BIGC_ACT_RELU));
+            TRY(linear(s, w.rh, df, L.f3, w.t3, dp, BQ, dp, df, BIGC_ACT_NONE, w.t2, dp));
+        }
         if (i + 1 < c.n_deco_layers) TRY(bigc_layernorm_add_f32(s, w.t3, L.n3.g, L.n3.b, w.qk_in, BQ, dp, eps, m->pos, Q, w.query));
         else TRY(bigc_layernorm_f32(s, w.t3, L.n3.g, L.n3.b, w.query, BQ, dp, eps));
     }
@@ -667,6 +710,8 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         TRY(bigc_construct_triplets(s, out->pred_logits, c.num_pred_cats, out->soid, b->vid_trk_off, b->trk_dura, b->trk_cat, b->trk_score,
                                     B, Q, topk, out->quint, out->scores, out->dura, out->qid, out->n_out));
     }
+    if (chained && hipMemcpyAsync(out->range_flag, w.flag, sizeof(int32_t), hipMemcpyDeviceToDevice, hs) != hipSuccess)
+        return bigc_fail(BIGC_ERR_HIP, "forward: memcpy failed");
     return BIGC_OK;
 }
 

@@ -17,14 +17,14 @@ import shutil
 import sys
 from collections import OrderedDict, defaultdict
 
-KERNEL = "linear_split_kernel"
+KERNEL = ("linear_split_kernel", "gemm_ps_kernel")      # the GEMM family: f32-operand kernel + pre-split-operand kernel
 
 
 def per_dispatch(path, kernel):
     """-> OrderedDict dispatch_id -> {counter: value}, and grid sizes, for kernels whose name contains `kernel`"""
     out, grid = OrderedDict(), {}
     for r in csv.DictReader(open(path)):
-        if kernel not in r["Kernel_Name"]:
+        if not any(k in r["Kernel_Name"] for k in ((kernel,) if isinstance(kernel, str) else kernel)):
             continue
         d = int(r["Dispatch_Id"])
         out.setdefault(d, defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
@@ -65,7 +65,7 @@ def main():
             tot_f += fb
             tot_w += wb
             f.write("%d,%d,%.1f,%d,%.1f,%d\n" % (i, grid[a], fk, fb, wk, wb))
-    json.dump({"kernel": KERNEL, "launches_per_step": len(fid), "fetch_bytes_per_step": tot_f, "write_bytes_per_step": tot_w,
+    json.dump({"kernel": " + ".join(KERNEL), "launches_per_step": len(fid), "fetch_bytes_per_step": tot_f, "write_bytes_per_step": tot_w,
                "hbm_bytes_per_launch": (tot_f + tot_w) / len(fid),
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 2 --warmup 1 "
                          "--cpu-videos 0 --no-prof` (benchmarks/profile_bench.sh); the last step's GEMM launches; FETCH_SIZE doubled per "

@@ -379,7 +379,10 @@ def vidor_grounding_legs(args, lib, device, want_vidor, want_grounding):
                 last = grd.forward_raw(clip, quint, dura, vl, 0.9, 0.5, 0.2, 0.8)
         else:
             last = grd.forward_raw_batch(jobs, 0.9, 0.5, 0.2, 0.8)[-1]
-        last["status"].cpu()
+        if args.grd_one_video_per_call:
+            last["status"].cpu()         # the reference's loop reads every video's result before the next forward
+        # batched: results stay on the device; like the headline loop, the timed region waits for the GPU once at its end, so
+        # the host's packing of the next batch overlaps this one's kernels
 
     gsteps = 5
     el, el_prof, fam = timed_with_events(lib, grd_step, 2, gsteps)

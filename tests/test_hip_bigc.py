@@ -267,3 +267,35 @@ def test_opt_in_fused_bbox_layers_reproduce_the_reference_goldens():
                        env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_chained_gemms_range_flag_reruns_the_step_on_the_exact_path():
+    """exp2 dims, the default (chained) eval path: features scaled until a front-end activation no longer fits the split form
+    (|x| >= 4096) -> the forward raises the range flag with the row counts, ``forward_checked`` repeats the step on the exact
+    kernels, and the caller gets exactly what exact mode gives; the unscaled input does not raise the flag"""
+    import copy
+    from bigc_hip import _lib
+    cfg, variant, sd, props, topk = cases.make_case("bigc_v_n64")
+    model = build_model(cfg, variant, sd)
+    p = props[0]
+    packed = PackedBatch([copy.deepcopy(p).to(DEV)], DEV)
+    out = model.forward_packed(packed, topk)
+    assert int(out["range_flag"].item()) == 0
+    big = copy.deepcopy(p)
+    big.features_list = [f * 3000.0 for f in big.features_list]
+    packed_big = PackedBatch([big.to(DEV)], DEV)
+    raw = model.forward_packed(packed_big, topk)
+    assert int(raw["range_flag"].item()) == 1
+    with pytest.raises(OverflowError):
+        model.counts(raw)
+    got = model.forward_checked(packed_big, topk)
+    lib = _lib.load()
+    prev = lib.bigc_linear_set_exact(1)
+    try:
+        want = model.forward_packed(packed_big, topk)
+        model.counts(want)
+    finally:
+        lib.bigc_linear_set_exact(prev)
+    assert torch.equal(got["pred_logits"], want["pred_logits"]) and torch.equal(got["n_out"], want["n_out"])
+    n = int(want["n_out"][0])      # rows past the count are padding, never written
+    assert n > 0 and torch.equal(got["quint"][0, :n], want["quint"][0, :n]) and torch.equal(got["qid"][0, :n], want["qid"][0, :n])

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     constexpr int A_BYTES = TM * ROWB, STAGE_BYTES = A_BYTES + W_BYTES;
     constexpr int NST = RB == 2 ? 3 : 2, D = NST - 1;         // LDS stages; slabs in flight beyond the one being read
     constexpr int NL = RB;                                    // mode 2: f32x4 loads per thread and slab
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES];
+    constexpr int MAXSEG = 4;                                 // mode 1: K segments (gathered row tables) supported
+    constexpr int IDX_OFF = NST * STAGE_BYTES;                // mode 1: behind the stages, a lane-private table of source rows (below)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES + (AMODE == 1 ? RB * MAXSEG * 2048 : 0)];
     AS3 unsigned char* lds = (AS3 unsigned char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -191,8 +193,15 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     const unsigned char* ia_base = nullptr;                               // A + m0 * lda of the tile being issued
     const unsigned char* iw_base = nullptr;                               // Ws + n0 * ldw
     int a_lim = 0, w_lim = 0;                                             // last valid row of the tile, relative to its first
-    int im0 = 0;
-    int gidx[AMODE == 1 ? NA : 1];                                        // mode 1: source row of this lane's row of piece i (-1 = zeros)
+    // mode 1: source row of this lane's row of piece i in K segment sg (-1 = zeros).  The slabs of a gathered GEMM are walked
+    // SEGMENT-INTERLEAVED -- slab ikt = (chunk ikt / nseg, segment ikt % nseg) -- so that the taps of the temporal conv, which
+    // read the same source rows (output position t reads the stretched frames 2t-1, 2t, 2t+1: neighbouring positions share a
+    // frame, and the stretch repeats rows), fetch a 128-byte line from all segments within a few slabs of each other: the
+    // repeats hit in L2 instead of going back to HBM a third of a K loop later (tap-major order: 6.9 GB fetched for 2.4 GB of
+    // distinct rows per 256-video step).  Every lane then needs NA * nseg row numbers at hand; the kernel is at its register
+    // limit (twelve more live registers spilled in the K loop: 4.5 -> 6.1 ms), so they live in LDS, slot (piece, segment) of
+    // lane tid at IDX_OFF + ((piece * MAXSEG + segment) * 512 + tid) * 4: written once per tile, one ds_read_b32 per piece.
+    int isg = 0, ichunk = 0;                                              // mode 1: (segment, chunk) of slab ikt
     int wof[NL];
     f32x4 ra[NL];
     if (AMODE == 2) {
@@ -205,29 +214,35 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     auto issue_tile_setup = [&]() {
         const int L = tile_of(ij), tm = L / p.tiles_n, tn = L - tm * p.tiles_n;
         const int m0 = tm * TM, n0 = tn * TN;
-        im0 = m0;
         ia_base = p.A + (size_t)m0 * p.lda;
         iw_base = p.Ws + (size_t)n0 * p.ldw;
         a_lim = p.M - 1 - m0;
         w_lim = p.N - 1 - n0;
+        if (AMODE == 1) {
+            // one batch of table reads per tile (the wait in front of the ds_writes also waits for the slabs in flight)
+            int v[NA * MAXSEG];
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int32_t* ip = p.a_idx + (size_t)min(m0 + (wave + 8 * q) * 8 + l8, p.M - 1) * p.nseg;
+#pragma unroll
+                for (int sg = 0; sg < MAXSEG; ++sg) v[q * MAXSEG + sg] = ip[min(sg, p.nseg - 1)];
+            }
+#pragma unroll
+            for (int q = 0; q < NA * MAXSEG; ++q) *(AS3 int*)(lds + IDX_OFF + (q * 512 + tid) * 4) = v[q];
+        }
     };
     // (`so` = byte offset of an LDS stage, a wave-uniform runtime value)
     auto issue_w_piece = [&](int i, int so) {
         const int blk = wave + 8 * i;
         const unsigned vo = (unsigned)(min(blk * 8 + l8, w_lim) * (int)p.ldw + coff);
-        __builtin_amdgcn_global_load_lds((const AS1 void*)(iw_base + (size_t)ikt * ROWB + vo), (AS3 void*)(lds + so + A_BYTES + blk * 1024), 16, 0, 0);
+        const size_t kb = AMODE == 1 ? (size_t)isg * p.seg_bytes + (size_t)ichunk * ROWB : (size_t)ikt * ROWB;      // K offset of the slab in a W row
+        __builtin_amdgcn_global_load_lds((const AS1 void*)(iw_base + kb + vo), (AS3 void*)(lds + so + A_BYTES + blk * 1024), 16, 0, 0);
     };
     auto issue_a_piece = [&](int i, int so) {
         const int blk = wave + 8 * i;
         if (AMODE == 1) {
-            const int kb = ikt * ROWB, sg = kb / p.seg_bytes, within = kb - sg * p.seg_bytes;
-            if (within == 0 && i == 0) {
-                // one batch of table reads per K segment (the wait in front of their use also waits for the slabs in flight: once
-                // per 2 * dim_enti / 32 slabs)
-#pragma unroll
-                for (int q = 0; q < NA; ++q) gidx[q] = p.a_idx[(size_t)min(im0 + (wave + 8 * q) * 8 + l8, p.M - 1) * p.nseg + sg];
-            }
-            const unsigned char* src = (gidx[i] >= 0 ? p.A + (size_t)gidx[i] * p.lda : p.zero_row) + coff + within;    // index -1: a row of zeros
+            const int gi = *(const AS3 int*)(lds + IDX_OFF + ((i * MAXSEG + isg) * 512 + tid) * 4);
+            const unsigned char* src = (gi >= 0 ? p.A + (size_t)gi * p.lda : p.zero_row) + coff + ichunk * ROWB;    // index -1: a row of zeros
             __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(lds + so + blk * 1024), 16, 0, 0);
         } else {
             const unsigned vo = (unsigned)min(blk * 8 + l8, a_lim) * (unsigned)p.lda + coff;
@@ -247,7 +262,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         }
     };
     auto issue_advance = [&]() {
-        if (++ikt == nk) { ikt = 0; ++ij; }
+        if (AMODE == 1 && ++isg == p.nseg) { isg = 0; ++ichunk; }
+        if (++ikt == nk) { ikt = 0; ++ij; isg = 0; ichunk = 0; }
     };
     // mode 2: plain register loads.  They are consumed (split_store) right before a slab's wait + barrier.  (Issued by inline
     // asm to hide them from the compiler's wait bookkeeping they are NOT safe: under register pressure the compiler copies the

@@ -1,7 +1,7 @@
 # per-kernel times of the grounding leg: bash benchmarks/grd_probe.sh (on the GPU box)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/grd -o bench -- python3 $R/bench.py --videos 32 --steps 2 --warmup 1 --cpu-videos 0 --exact-steps 0 --no-prof --legs grounding > /tmp/grd.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/grd -o bench -- python3 $R/bench.py --videos 32 --steps 2 --warmup 1 --cpu-videos 0 --exact-steps 0 --fast-steps 0 --no-prof --legs grounding > /tmp/grd.log 2>&1
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("/tmp/grd/bench_kernel_trace.csv")))

@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_r01e
 rm -rf $O; mkdir -p $O
 cd $R
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --cpu-videos 0 --exact-steps 0 > $O/stats_stdout.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --cpu-videos 0 --exact-steps 0 --fast-steps 0 > $O/stats_stdout.log 2>&1
 python3 - <<'PY'
 import csv,os
 p=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/prof_r01e/stats/bench_kernel_stats.csv"

@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for e in 0 1; do
-  BIGC_CHAINED=$e timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps$e -o bench -- python3 $R/bench.py --cpu-videos 0 --exact-steps 0 --legs none --steps 5 --warmup 2 > /tmp/ps$e.log 2>&1
+  BIGC_CHAINED=$e timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps$e -o bench -- python3 $R/bench.py --cpu-videos 0 --exact-steps 0 --fast-steps 0 --legs none --steps 5 --warmup 2 > /tmp/ps$e.log 2>&1
   tail -1 /tmp/ps$e.log | cut -c1-200
   echo "== BIGC_CHAINED=$e"
   python3 - <<PY

@@ -85,6 +85,13 @@ int bigc_linear_f32(void* stream, const float* A, int lda, const int32_t* a_idx,
  * BIGC_LINEAR_EXACT.  bigc_linear_set_exact returns the previous mode. */
 int bigc_linear_set_exact(int exact);
 int bigc_linear_get_exact(void);
+/* Opt-in reduced-precision mode of the GEMMs (never the default; also env BIGC_FAST=1): operands rounded to ONE f16 each (11-bit
+ * mantissa), one f16 MFMA per product instead of three, f32 accumulation.  This is the "bf16 fast mode" of the survey's build plan
+ * (BASELINE configs[1]): it does NOT meet the 1e-4 logit tolerance and is gated on Recall@50 parity
+ * instead (tests/test_hip_fast.py).  Ignored while the exact mode is on.  bigc_linear_set_fast returns the previous mode;
+ * bigc_linear_get_fast the mode in effect. */
+int bigc_linear_set_fast(int fast);
+int bigc_linear_get_fast(void);
 
 /* y[r, :] = LayerNorm(x[r, :]) * gamma + beta over d columns, eps inside the sqrt
  *   (torch.nn.LayerNorm, models/model_0v10.py:81-82,171-173). d <= 2048, d % 4 == 0. */

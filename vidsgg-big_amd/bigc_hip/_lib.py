@@ -72,6 +72,8 @@ _SIGS = {
                                        c_int, c_int, c_int, c_int, c_void_p]),
     "bigc_linear_set_exact": (c_int, [c_int]),
     "bigc_linear_get_exact": (c_int, []),
+    "bigc_linear_set_fast": (c_int, [c_int]),
+    "bigc_linear_get_fast": (c_int, []),
     "bigc_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
     "bigc_layernorm_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "bigc_add_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),

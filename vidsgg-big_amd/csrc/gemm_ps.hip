@@ -150,7 +150,9 @@ struct PsArgs {
 // tile's first slabs arrive while the previous tile's last MFMAs and its epilogue run (with 128 - 144 KB of LDS there is one
 // workgroup per CU: nothing else would hide a tile's pipeline fill).
 //   RB = 32-row blocks per wave: 2 -> TM = 128 rows, 3 LDS stages;  4 -> TM = 256 rows, 2 LDS stages.
-template <int AMODE, int RB, bool TRACE = false>
+//   FAST: reduced-precision mode (bigc_linear_set_fast): heads only, one MFMA per product; the residual chunks still travel
+//   with their rows (the format is the producers') but are not read from LDS.
+template <int AMODE, int RB, bool TRACE = false, bool FAST = false>
 __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     constexpr int TM = 64 * RB;
     constexpr int A_BYTES = TM * ROWB, STAGE_BYTES = A_BYTES + W_BYTES;
@@ -327,14 +329,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f.h[i] = *(const AS3 f16x8*)(lds + so + rbw + i * 32 * ROWB + cs[s][0]);
-            f.l[i] = *(const AS3 f16x8*)(lds + so + rbw + i * 32 * ROWB + cs[s][1]);
+            if (!FAST) f.l[i] = *(const AS3 f16x8*)(lds + so + rbw + i * 32 * ROWB + cs[s][1]);
         }
     };
     auto rd_a = [&](int so, int s, int u, AFrag& f) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f.h[i] = *(const AS3 f16x8*)(lds + so + rba + (2 * u + i) * 32 * ROWB + cs[s][0]);
-            f.l[i] = *(const AS3 f16x8*)(lds + so + rba + (2 * u + i) * 32 * ROWB + cs[s][1]);
+            if (!FAST) f.l[i] = *(const AS3 f16x8*)(lds + so + rba + (2 * u + i) * 32 * ROWB + cs[s][1]);
         }
     };
     // MFMAs [m0, m1) of the 12 of unit u: term-major (head x head over the 4 blocks, then head x residual, residual x head), so
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         for (int m = 0; m < 12; ++m) {
             if (m < m0 || m >= m1) continue;
             const int t = m >> 2, fi = (m >> 1) & 1, ri = m & 1;
+            if (FAST && t > 0) continue;
             acc[fi][2 * u + ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t == 2 ? w.l[fi] : w.h[fi], t == 1 ? a.l[ri] : a.h[ri], acc[fi][2 * u + ri], 0, 0, 0);
         }
     };
@@ -677,6 +680,12 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
         fprintf(stderr, "gemm_ps trace M=%d N=%d K=%d rb=%d (s_memtime ticks per wave per slab): step-0 MFMAs + reads %.0f | wait vmcnt/lgkm %.0f | "
                 "barrier %.0f | step-1 MFMAs + reads + DMA pieces %.0f | loop end + epilogue %.0f\n", p.M, p.N, p.K, rb, seg[0] / slabs,
                 seg[1] / slabs, seg[2] / slabs, seg[3] / slabs, seg[4] / slabs);
+    } else if (bigc_linear_get_fast()) {
+#define PS_LAUNCH_FAST(MODE, RBV) hipLaunchKernelGGL((gemm_ps_kernel<MODE, RBV, false, true>), dim3(grid), dim3(512), 0, s, p)
+        if (g.a_fmt == PS_F32) { if (rb == 4) PS_LAUNCH_FAST(2, 4); else PS_LAUNCH_FAST(2, 2); }
+        else if (g.a_idx) { if (rb == 4) PS_LAUNCH_FAST(1, 4); else PS_LAUNCH_FAST(1, 2); }
+        else { if (rb == 4) PS_LAUNCH_FAST(0, 4); else PS_LAUNCH_FAST(0, 2); }
+#undef PS_LAUNCH_FAST
     } else if (g.a_fmt == PS_F32) {
         if (rb == 4) PS_LAUNCH(2, 4); else PS_LAUNCH(2, 2);
     } else if (g.a_idx) {

@@ -251,6 +251,12 @@ __global__ __launch_bounds__(256) void linear_k8_kernel(const LinearArgs p) {
 static std::atomic<int> g_exact_mode{(getenv("BIGC_LINEAR_EXACT") && atoi(getenv("BIGC_LINEAR_EXACT")) != 0) ? 1 : 0};
 extern "C" int bigc_linear_set_exact(int exact) { return g_exact_mode.exchange(exact ? 1 : 0); }
 extern "C" int bigc_linear_get_exact(void) { return g_exact_mode.load(); }
+// Opt-in reduced-precision mode of the split-operand GEMM kernels (linear_split.hip, gemm_ps.hip): every operand rounded to one
+// f16 (11-bit mantissa), ONE v_mfma_f32_32x32x16_f16 per product, f32 accumulation -- the "bf16 fast mode" of SURVEY section 7
+// step 10, gated on Recall@50 parity instead of the 1e-4 logit tolerance.  Never the default; initialised from BIGC_FAST.
+static std::atomic<int> g_fast_mode{(getenv("BIGC_FAST") && atoi(getenv("BIGC_FAST")) != 0) ? 1 : 0};
+extern "C" int bigc_linear_set_fast(int fast) { return g_fast_mode.exchange(fast ? 1 : 0); }
+extern "C" int bigc_linear_get_fast(void) { return g_exact_mode.load() ? 0 : g_fast_mode.load(); }
 
 int bigc_linear_hr8out(void* stream, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
                        float* C, int ldc, void* Cs, long ldcs, int M, int N, int K, int act, int* range_flag) {

@@ -27,6 +27,7 @@ struct LinearArgs {
 // Weights that stay constant between launches are split once and cached per (pointer, shape) for an "epoch": the model
 // entry points open a StaticWeights scope with the epoch they drew at finalize time; outside such a scope (epoch 0, e.g.
 // the raw bigc_linear_f32 entry point or the transposed weight copies of the backward pass) W is split on every launch.
+extern "C" int bigc_linear_get_fast(void);     // linear.hip: 1 = reduced-precision mode (one f16 MFMA per product)
 extern thread_local unsigned long long bigc_static_weights_epoch;
 unsigned long long bigc_next_weights_epoch();
 struct StaticWeights {

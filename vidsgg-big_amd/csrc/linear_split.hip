@@ -147,7 +147,9 @@ __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((row >>
 // per CU, same two waves per SIMD): the A slab is split once for eight waves instead of four.
 // DWK > 0: depth-wise-separable mode (LinearArgs::dw_*), DWK = kernel size of the depth-wise convolution.
 // PRE8: preceding-layer mode (LinearArgs::pre_*).
-template <bool GATHER, bool KTAIL, int WN, int DWK = 0, bool PRE8 = false>
+// FAST: the opt-in reduced-precision mode (bigc_linear_set_fast / BIGC_FAST=1, linear.hip): operands rounded to ONE f16 each,
+// one MFMA per product -- the residual planes are neither written nor read and the correction accumulator stays zero.
+template <bool GATHER, bool KTAIL, int WN, int DWK = 0, bool PRE8 = false, bool FAST = false>
 __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linear_split_kernel(const LinearArgs p) {
     constexpr int NTH = 128 * WN, BNT = 64 * WN;     // threads, tile width
     constexpr int RPP = NTH / 8;                     // rows staged per pass (8 threads x 16 bytes per 32-k row)
@@ -309,12 +311,12 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
             uint2 h, r;
             split4(ra[i], h, r, chk, amax);
             *(uint2*)(&smem[buf][soff[i]]) = h;
-            *(uint2*)(&smem[buf][PA + soff[i]]) = r;
+            if (!FAST) *(uint2*)(&smem[buf][PA + soff[i]]) = r;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             *(uint2*)(&smem[buf][2 * PA + soff[i]]) = make_uint2(rb[i][0], rb[i][1]);
-            *(uint2*)(&smem[buf][2 * PA + PW + soff[i]]) = make_uint2(rb[i][2], rb[i][3]);
+            if (!FAST) *(uint2*)(&smem[buf][2 * PA + PW + soff[i]]) = make_uint2(rb[i][2], rb[i][3]);
         }
     };
 
@@ -349,17 +351,21 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 a1[mi] = *(const f16x8*)(&smem[buf][aoff[mi][s]]);
-                a2[mi] = *(const f16x8*)(&smem[buf][PA + aoff[mi][s]]);
                 b1[mi] = *(const f16x8*)(&smem[buf][2 * PA + boff[mi][s]]);
-                b2[mi] = *(const f16x8*)(&smem[buf][2 * PA + PW + boff[mi][s]]);
+                if (!FAST) {
+                    a2[mi] = *(const f16x8*)(&smem[buf][PA + aoff[mi][s]]);
+                    b2[mi] = *(const f16x8*)(&smem[buf][2 * PA + PW + boff[mi][s]]);
+                }
             }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     acc0[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mi], b1[ni], acc0[mi][ni], 0, 0, 0);
-                    acc1[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mi], b2[ni], acc1[mi][ni], 0, 0, 0);
-                    acc1[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[mi], b1[ni], acc1[mi][ni], 0, 0, 0);
+                    if (!FAST) {
+                        acc1[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mi], b2[ni], acc1[mi][ni], 0, 0, 0);
+                        acc1[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[mi], b1[ni], acc1[mi][ni], 0, 0, 0);
+                    }
                 }
         }
         store_tiles(buf ^ 1, sp);
@@ -776,7 +782,9 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
         BIGC_LAUNCH_CHECK("linear_split (dwsep)");
         return BIGC_OK;
     }
-#define LAUNCH_SPLIT(G, T, W) hipLaunchKernelGGL((linear_split_kernel<G, T, W>), dim3(grid2), dim3(128 * W), 0, s, p)
+#define LAUNCH_SPLIT(G, T, W) do { if (fast) hipLaunchKernelGGL((linear_split_kernel<G, T, W, 0, false, true>), dim3(grid2), dim3(128 * W), 0, s, p); \
+                                   else hipLaunchKernelGGL((linear_split_kernel<G, T, W>), dim3(grid2), dim3(128 * W), 0, s, p); } while (0)
+    const bool fast = bigc_linear_get_fast() != 0;
     if (wn == 4) {
         if (p.a_idx) { if (ktail) LAUNCH_SPLIT(true, true, 4); else LAUNCH_SPLIT(true, false, 4); }
         else { if (ktail) LAUNCH_SPLIT(false, true, 4); else LAUNCH_SPLIT(false, false, 4); }

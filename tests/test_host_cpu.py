@@ -146,3 +146,32 @@ def test_pair_label_assignment_matches_the_reference_loop():
         for i, c in enumerate(want.values()):
             ref[i, c] = 1
         assert torch.equal(multihot, ref)
+
+
+def test_host_side_under_address_and_ub_sanitizers():
+    """The library's host code (argument checks, parameter table, finalize's resolver, the workspace arena layout, mode switches,
+    profiling table) compiled host-only with -fsanitize=address,undefined and driven by tests/native/host_sanitize.cpp -- no GPU,
+    no device code: any heap misuse, leak or undefined integer arithmetic in those paths fails the run."""
+    import subprocess
+    from bigc_hip.engine import BigcEngine
+    csrc = os.path.join(ROOT, "vidsgg-big_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "asan", "-j8"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PATH="/opt/rocm/bin:" + os.environ.get("PATH", "")))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = []
+    for variant, cname in (("vidvrd", "CONFIG_V"), ("vidor", "CONFIG_O"), ("vidvrd", "CONFIG_TINY")):
+        cfg = cases.get_cfg(cname)
+        eng = BigcEngine(cfg, variant)
+        lines.append("model " + " ".join(str(int(getattr(eng.c, f))) for f, _ in _lib.bigc_config._fields_))
+        for k, shape in bigc_state_shapes(cfg, variant):
+            lines.append("param %s %d" % (k, int(np.prod(shape))))
+        # (videos, tracklets, rows, conv rows, max tracklets per video): one video, the benchmark step, a VidOR-sized batch
+        for b in ((1, 1, 5, 3, 1), (8, 300, 9000, 5000, 64), (256, 16384, 579295, 519168, 64), (16, 2880, 1456366, 1300000, 180)):
+            lines.append("batch %d %d %d %d %d" % b)
+    spec = os.path.join(tempfile.mkdtemp(), "spec.txt")
+    open(spec, "w").write("\n".join(lines) + "\n")
+    exe = os.path.join(ROOT, "vidsgg-big_amd", "lib", "host_sanitize")
+    r = subprocess.run([exe, spec], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"))
+    assert r.returncode == 0 and "host_sanitize: OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]

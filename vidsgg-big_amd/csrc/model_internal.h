@@ -36,7 +36,7 @@ struct Arena {
     template <typename T> T* take(size_t n) {
         size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
         if (off + bytes > cap) { overflow = true; return nullptr; }
-        T* p = (T*)(base + off);
+        T* p = (T*)((uintptr_t)base + off);       // (measuring runs have a null base: no pointer arithmetic on it)
         off += bytes;
         return p;
     }

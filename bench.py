@@ -622,6 +622,15 @@ def main():
             # every f32 product costs three f16 MFMAs (head x head, head x residual, residual x head): the roof for
             # ALGORITHMIC flops is the dense f16 MFMA peak / 3
             kernel = "split-operand GEMM family (f32 operands as 2 x f16, 3 x v_mfma_f32_32x32x16_f16 per product)"
+        # what the matrix pipe of this chip sustains on operands that toggle (a register-only MFMA loop, benchmarks/probes/mfma_peak.hip,
+        # committed as profiles/mfma_peak.json): context for `frac`, which stays priced against the guide's 2.5 PFLOP/s
+        mp_path = os.path.join(ROOT, "profiles", "mfma_peak.json")
+        if os.path.exists(mp_path) and not EXACT_F32:
+            mp = json.load(open(mp_path))
+            roofline["sustained_mfma_peak"] = dict(tflops_f16_random_operands=mp["random_f16_tflops"], tflops_f16_zero_operands=mp["zeros_tflops"],
+                                                   three_mfma_gemm_ceiling=round(mp["random_f16_tflops"] / 3, 1),
+                                                   frac_of_that_ceiling=round(roofline["achieved"] / (mp["random_f16_tflops"] / 3), 4),
+                                                   source="not measured in this run: profiles/mfma_peak.json (benchmarks/probes/mfma_peak.hip)")
         roofline.update(kernel=kernel, vs_f32_mfma_peak=round(roofline["achieved"] / F32_MFMA_PEAK_TFLOPS, 3), traffic=traffic,
                         traffic_source=traffic_source, algorithmic_bytes_per_launch=round(lin["bytes"] / lin["launches"]),
                         measured="HIP events around each launch, over a repeat of the timed %d steps (instrumented step: %.3f ms)"

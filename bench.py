@@ -23,6 +23,8 @@ Also printed in the same JSON line (rank 0; everything below runs OUTSIDE the ti
                 same videos
   oracle_parity the oracle outputs of that sample compared row for row with the HIP outputs of the
                 same videos: triplet rows identical, predicate logits max relative difference
+  exact_f32_gemm_mode / fast_f16_gemm_mode   the same step with every GEMM on the exact f32 MFMA, and in the opt-in
+                reduced-precision mode (one f16 MFMA per product) with its Recall@50 gate
   vidor / grounding / train   the other BASELINE configs on the same GPU (N=1 only): VidOR-sized
                 classification (N=180 tracklets), the grounding scorer on its triplet queries, and
                 the BIG-C training step (forward + Hungarian + backward + all-reduce + clip + Adam)

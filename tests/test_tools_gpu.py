@@ -112,6 +112,11 @@ def test_bench_json_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["exact_f32_gemm_mode"]["triplet_indices_identical_to_default_mode"] in (True, False)
+    # the opt-in reduced-precision mode rides along with its Recall@50 gate -- and is a different arithmetic
+    f = d["fast_f16_gemm_mode"]
+    assert f["value"] > 0 and f["recall_gate"]["passed"] is True and f["recall_gate"]["abs_diff_recall50"] <= 1e-3
+    assert 1e-6 < f["max_logit_diff_rel_vs_parity_mode"] < 0.2
+    assert r["sustained_mfma_peak"]["three_mfma_gemm_ceiling"] > 0
     # the oracle outputs of the CPU-baseline sample are compared row for row with the HIP outputs of the same videos
     op = d["oracle_parity"]
     n_same, n_all = [int(x) for x in op["identical_triplet_rows"].split(" of ")]

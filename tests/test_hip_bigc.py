@@ -129,6 +129,38 @@ def test_bigc_batch_vs_oracle_ragged():
         j += 1
 
 
+@pytest.mark.parametrize("variant,cfg_name,n_big", [("vidor", "CONFIG_TINY_O", 180), ("vidvrd", "CONFIG_TINY", 300)])
+def test_bigc_batch_mixing_many_and_few_tracklets_vs_oracle(variant, cfg_name, n_big):
+    """One batch holding a video with more than 64 tracklets (VidOR's 180; 300, beyond anything the datasets have) next to small ones:
+    max_trk of the BATCH selects the unfused role-attention branch for every video of it, small ones included -- rows, durations and
+    query ids identical to the oracle's per-video evaluation, logits within 1e-4."""
+    cfg = cases.get_cfg(cfg_name)
+    from bigc_hip.synthetic import bigc_state_shapes, seeded_state_dict
+    sd = seeded_state_dict(bigc_state_shapes(cfg, variant), 23, att_gain=6.0)
+    specs = [dict(seed=501, n_trajs=5, len_range=(5, 30), start_range=(0, 10)),
+             dict(seed=502, n_trajs=n_big, len_range=(5, 60), start_range=(0, 40)),
+             dict(seed=503, n_trajs=64, len_range=(6, 20), start_range=(0, 8)),
+             dict(seed=504, n_trajs=2, len_range=(9, 12))]
+    props = [cases.make_proposal(cfg, variant, s) for s in specs]
+    model = build_model(cfg, variant, sd)
+    topk = 3
+    got = model(props, topk=topk)
+    want = O.forward_test(sd, cfg, props, topk=topk, variant=variant)
+    for gv, wv in zip(got, want):
+        if wv is None:
+            assert gv is None
+            continue
+        check_tuple_exact(gv, *[t.numpy() for t in wv])
+    packed = PackedBatch(props, DEV)
+    assert packed.max_trk == n_big
+    out = model.forward_packed(packed, topk)
+    logits = out["pred_logits"].cpu().numpy().reshape(packed.n_vid, cfg["num_querys"], -1)
+    for j, p in enumerate(props):
+        o = O.encode2decode(sd, cfg, p, variant)
+        assert rel(logits[j], o["pred_logits"].numpy()) < LOGIT_RTOL
+        assert np.array_equal(out["soid"].cpu().numpy()[j], o["att"].argmax(-1).numpy())
+
+
 def test_construct_triplets_duplicates_and_ties():
     """a8 alone on crafted logits: duplicated quintuples across queries (same subject/object, same
     predicate), exact probability ties inside a query and between duplicates, background drop."""

@@ -69,6 +69,111 @@ __global__ __launch_bounds__(256) void dwconv_ragged_kernel(const float* __restr
     }
 }
 
+// The depth-wise convolution as a stream: a thread owns four channels and a run of DW_RUN consecutive rows, keeps the ks input rows
+// under the filter in registers (each row is loaded once per run, not once per tap: the per-tap version above issues 5 loads per
+// tap and output quad -- 35 for k = 7 -- and runs at 2.2 TB/s) and its 4 x ks filter weights too.  Same operation order per output
+// as dwconv_kernel (bias, then the taps inside the sequence in ascending order).  row_info == nullptr: sequences of T rows.
+constexpr int DW_RUN = 16;
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                          float* __restrict__ y, long rows, int T, const int2* __restrict__ row_info, int d4) {
+    constexpr int H = KS / 2;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = (int)(g % d4);
+    const long r0 = (g / d4) * DW_RUN;
+    if (r0 >= rows) return;
+    float wt[4][KS];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < KS; ++j) wt[c][j] = w[(size_t)(4 * c4 + c) * KS + j];
+    const f32x4 bias = ((const f32x4*)b)[c4];
+    const f32x4* xp = (const f32x4*)x + c4;
+    f32x4 win[KS];                                            // win[j] = row r + j - H (clamped to the tensor; taps outside the sequence are skipped)
+#pragma unroll
+    for (int j = 1; j < KS; ++j) win[j] = xp[min(max(r0 + j - 1 - H, 0L), rows - 1) * d4];
+    const long r1 = min(r0 + DW_RUN, rows);
+    for (long r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int j = 0; j + 1 < KS; ++j) win[j] = win[j + 1];
+        win[KS - 1] = xp[min(r + H, rows - 1) * d4];
+        int t, len;
+        if (row_info) { const int2 v = row_info[r]; t = v.x; len = v.y; } else { t = (int)(r % T); len = T; }
+        f32x4 acc = bias;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const int tt = t + j - H;
+            if (tt < 0 || tt >= len) continue;
+            acc[0] += wt[0][j] * win[j][0];
+            acc[1] += wt[1][j] * win[j][1];
+            acc[2] += wt[2][j] * win[j][2];
+            acc[3] += wt[3][j] * win[j][3];
+        }
+        ((f32x4*)y)[r * d4 + c4] = acc;
+    }
+}
+
+// LayerNorm + depth-wise convolution in one pass (the four LN -> DepthWiseSeparableConv pairs of a QANet encoder layer,
+// models/grd_model_v5.py:126-131: the normalised tensor feeds only the convolution): d = 128, a run of rows per group of 32 lanes
+// (four channels per lane), the statistics of every row entering the filter window by butterfly shuffles inside the group --
+// the arithmetic of layernorm_rows_kernel<32, 1, ...> (rowwise.hip) operation for operation -- and the normalised rows never
+// touch memory.  Halo rows (ks - 1 per run) are normalised twice.
+template <int KS>
+__global__ __launch_bounds__(256) void ln_dwconv_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
+                                                             long rows, int T, const int2* __restrict__ row_info) {
+    constexpr int H = KS / 2, D4 = 32;
+    const int c4 = threadIdx.x & 31;
+    const long r0 = ((long)blockIdx.x * 8 + (threadIdx.x >> 5)) * DW_RUN;
+    if (r0 >= rows) return;                                   // (whole 32-lane groups leave together)
+    float wt[4][KS];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < KS; ++j) wt[c][j] = w[(size_t)(4 * c4 + c) * KS + j];
+    const f32x4 bias = ((const f32x4*)b)[c4], gg = ((const f32x4*)gamma)[c4], bb = ((const f32x4*)beta)[c4];
+    const f32x4* xp = (const f32x4*)x + c4;
+    auto gsum = [](float t) {
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+        return t;
+    };
+    auto ln_row = [&](long r) {
+        const f32x4 v = xp[min(max(r, 0L), rows - 1) * D4];
+        const float mean = gsum((v[0] + v[1]) + (v[2] + v[3])) / (float)(4 * D4);
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float t = v[c] - mean; ss += t * t; }
+        const float rstd = 1.0f / sqrtf(gsum(ss) / (float)(4 * D4) + eps);
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = (v[c] - mean) * rstd * gg[c] + bb[c];
+        return o;
+    };
+    f32x4 win[KS];
+#pragma unroll
+    for (int j = 1; j < KS; ++j) win[j] = ln_row(r0 + j - 1 - H);
+    const long r1 = min(r0 + DW_RUN, rows);
+    for (long r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int j = 0; j + 1 < KS; ++j) win[j] = win[j + 1];
+        win[KS - 1] = ln_row(r + H);
+        int t, len;
+        if (row_info) { const int2 v = row_info[r]; t = v.x; len = v.y; } else { t = (int)(r % T); len = T; }
+        f32x4 acc = bias;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const int tt = t + j - H;
+            if (tt < 0 || tt >= len) continue;
+            acc[0] += wt[0][j] * win[j][0];
+            acc[1] += wt[1][j] * win[j][1];
+            acc[2] += wt[2][j] * win[j][2];
+            acc[3] += wt[3][j] * win[j][3];
+        }
+        ((f32x4*)y)[r * D4 + c4] = acc;
+    }
+}
+
 // y = x + pos[position of the row in its sequence]
 __global__ __launch_bounds__(256) void add_pos_ragged_kernel(const float* __restrict__ x, const float* __restrict__ pos, float* __restrict__ y,
                                                              long n4, int d4, const int2* __restrict__ row_info) {
@@ -474,6 +579,15 @@ inline int glinear(void* s, const float* A, int lda, const Lin& l, float* C, int
 struct Seqs { int n_seq; int T; long rows; int max_T; const int32_t* off; const int2* info; };
 
 int seq_dwconv(void* s, const float* x, const DW& c, float* y, const Seqs& q, int d, int ks) {
+    if (ks == 3 || ks == 7) {
+        ProfScope ps(s, FAM_GROUNDING, 0.0, 8.0 * q.rows * (double)d);
+        const long threads = ((q.rows + DW_RUN - 1) / DW_RUN) * (d / 4);
+        const int grid = (int)((threads + 255) / 256);
+        if (ks == 3) hipLaunchKernelGGL(dwconv_rows_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, c.dw_w, c.dw_b, y, q.rows, q.T, q.info, d / 4);
+        else hipLaunchKernelGGL(dwconv_rows_kernel<7>, dim3(grid), dim3(256), 0, (hipStream_t)s, x, c.dw_w, c.dw_b, y, q.rows, q.T, q.info, d / 4);
+        BIGC_LAUNCH_CHECK("dwconv_rows");
+        return BIGC_OK;
+    }
     if (!q.info) return bigc_dwconv_f32(s, x, c.dw_w, c.dw_b, y, q.n_seq, q.T, d, ks);
     const long total4 = q.rows * (d / 4);
     ProfScope ps(s, FAM_GROUNDING, 0.0, 8.0 * q.rows * (double)d);
@@ -482,11 +596,21 @@ int seq_dwconv(void* s, const float* x, const DW& c, float* y, const Seqs& q, in
     return BIGC_OK;
 }
 
+// whether a depth-wise-separable layer runs with its convolution inside the GEMM's operand staging (see dwsep)
+bool dwsep_fused(int n_out, int d, int ks) {
+    // k = 7 with a residual (the QANet encoders): the streaming depth-wise kernel + the plain GEMM beat the convolution evaluated in
+    // the GEMM's operand staging (60 + 80 us against 221 us per layer on 240 k rows: seven taps per staged quad leave that kernel one
+    // 4-wave workgroup per CU); k = 3 (the heads) stays fused (105 against 50 + 65 us).  BIGC_DWSEP_FUSED=1 / 0 forces either form.
+    static const int fused_env = getenv("BIGC_DWSEP_FUSED") ? atoi(getenv("BIGC_DWSEP_FUSED")) : -1;
+    const bool fuse = fused_env >= 0 ? fused_env != 0 : ks != 7;
+    return fuse && bigc_linear_dwsep_supported(n_out, d, ks);
+}
+
 // out = act(point_wise(depth_wise(x))) (+ res): one pass over x when the split-operand GEMM can evaluate the depth-wise
 // convolution while it stages its rows, else the two kernels (scratch: `dw`)
 int dwsep(void* s, const float* x, const DW& c, float* dw, float* out, int ldo, int n_out, const Seqs& q, int d, int ks, int act,
           const float* res = nullptr, int ldr = 0) {
-    if (bigc_linear_dwsep_supported(n_out, d, ks))
+    if (dwsep_fused(n_out, d, ks))
         return bigc_linear_dwsep(s, x, d, c.dw_w, c.dw_b, ks, q.T, q.info, c.pw.w, d, c.pw.b, res, ldr, out, ldo, (int)q.rows, n_out, d, act);
     GTRY(seq_dwconv(s, x, c, dw, q, d, ks));
     return glinear(s, dw, d, c.pw, out, ldo, (int)q.rows, n_out, d, act, res, ldr);
@@ -504,12 +628,27 @@ int qanet(void* s, const Enc& E, const float* x, const float* pos, const Seqs& q
         hipLaunchKernelGGL(add_pos_ragged_kernel, dim3(grid_for(q.rows * (d / 4))), dim3(256), 0, (hipStream_t)s, x, pos, res, q.rows * (d / 4), d / 4, q.info);
         BIGC_LAUNCH_CHECK("add_pos_ragged");
     }
-    GTRY(bigc_layernorm_f32(s, res, E.normb.w, E.normb.b, ln, rows, d, 1e-5f));
+    // LN -> depth-wise conv -> point-wise GEMM: where the depth-wise stage is a kernel of its own (k = 7, see dwsep), the LayerNorm in
+    // front of it is evaluated inside that kernel and the normalised tensor is never written
+    static const bool ln_fuse_off = getenv("BIGC_LN_DWCONV") && atoi(getenv("BIGC_LN_DWCONV")) == 0;
+    const bool ln_fused = !ln_fuse_off && d == 128 && (E.ks == 3 || E.ks == 7) && !dwsep_fused(d, d, E.ks);
+    const Lin* lnw = &E.normb;
     for (int i = 0; i < 4; ++i) {
-        GTRY(dwsep(s, ln, E.conv[i], dw, nxt, d, d, q, d, E.ks, BIGC_ACT_RELU, res, d));    // relu(conv) + res
+        if (ln_fused) {
+            ProfScope ps(s, FAM_GROUNDING, 0.0, 8.0 * rows * (double)d);
+            const int grid = (int)((((long)rows + DW_RUN - 1) / DW_RUN + 7) / 8);
+            if (E.ks == 3) hipLaunchKernelGGL(ln_dwconv_rows_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)s, res, lnw->w, lnw->b, 1e-5f, E.conv[i].dw_w, E.conv[i].dw_b, dw, (long)rows, q.T, q.info);
+            else hipLaunchKernelGGL(ln_dwconv_rows_kernel<7>, dim3(grid), dim3(256), 0, (hipStream_t)s, res, lnw->w, lnw->b, 1e-5f, E.conv[i].dw_w, E.conv[i].dw_b, dw, (long)rows, q.T, q.info);
+            BIGC_LAUNCH_CHECK("ln_dwconv_rows");
+            GTRY(glinear(s, dw, d, E.conv[i].pw, nxt, d, rows, d, d, BIGC_ACT_RELU, res, d));    // relu(pw(conv(LN(res)))) + res
+        } else {
+            GTRY(bigc_layernorm_f32(s, res, lnw->w, lnw->b, ln, rows, d, 1e-5f));
+            GTRY(dwsep(s, ln, E.conv[i], dw, nxt, d, d, q, d, E.ks, BIGC_ACT_RELU, res, d));    // relu(conv) + res
+        }
         float* t = res; res = nxt; nxt = t;
-        GTRY(bigc_layernorm_f32(s, res, E.norm_seq[i].w, E.norm_seq[i].b, ln, rows, d, 1e-5f));
+        lnw = &E.norm_seq[i];
     }
+    GTRY(bigc_layernorm_f32(s, res, lnw->w, lnw->b, ln, rows, d, 1e-5f));
     GTRY(glinear(s, ln, d, E.in_proj, w.qkv, 3 * d, rows, 3 * d, d, BIGC_ACT_NONE));
     const int32_t* off = q.off;
     if (!q.info) { GTRY(bigc_fill_offsets((hipStream_t)s, w.off, q.n_seq + 1, q.T)); off = w.off; }

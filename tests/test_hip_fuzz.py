@@ -75,3 +75,61 @@ def test_random_configuration_vs_oracle(seed):
         o = O.encode2decode(sd, cfg, p, variant)
         assert rel(logits[j], o["pred_logits"].numpy()) < LOGIT_RTOL, (seed, j)
         assert np.array_equal(soid[j], o["att"].argmax(-1).numpy()), (seed, j)
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_grounding_configuration_vs_oracle(seed):
+    """The grounding scorer on seeded random configurations (hidden width 64 / 128 -- 128 runs the streaming depth-wise kernels with
+    the folded LayerNorm --, 2-10 bins, clip features of width 32-256) and random batches of videos (T = 1 .. 150 clips, n = 1 .. 30
+    queries): the three heads within 1e-4 of the oracle's forward_propagation, and the batched call bit-identical to one-video calls."""
+    from bigc_hip.synthetic import grd_state_shapes
+    from oracle import grd_oracle as G
+    from test_hip_grounding import build_model as build_grd
+    rs = np.random.RandomState(7000 + seed)
+    cfg = dict(dim_feat=int(rs.choice([32, 64, 256])), dim_clsme=300, dim_hidden=int(rs.choice([64, 128, 128])), num_bins=int(rs.randint(2, 11)),
+               loss_factor=dict(classification=1.0, centerness=1.0, regression=1.0))
+    sd = seeded_state_dict(grd_state_shapes(cfg), 300 + seed, float(rs.choice([1.0, 4.0])))
+    model = build_grd(cfg, sd)
+    k = cfg["num_bins"]
+    jobs = []
+    for v in range(int(rs.randint(1, 5))):
+        spec = dict(seed=int(rs.randint(1 << 20)), T=int(rs.choice([1, 2, 3, 9, 40, 150])), n=int(rs.choice([1, 2, 7, 30])), video_len=int(rs.randint(20, 1200)))
+        feat, (quint, dura, vl) = cases.make_grd_inputs(cfg, spec)
+        jobs.append((feat, quint, dura, vl))
+    th = dict(cases.GRD_TH)
+    outs = model.forward_raw_batch([(f.to(DEV), q, d, vl) for f, q, d, vl in jobs], **th)
+    for (feat, quint, dura, vl), o in zip(jobs, outs):
+        n, T = quint.shape[0], feat.shape[0]
+        one = model.forward_raw(feat.to(DEV), quint, dura, vl, keep_intermediates=True, **th)
+        words, info = G.prepare_data(sd, quint, dura, vl)
+        with torch.no_grad():
+            regrs, conf, cls = G.forward_propagation(sd, feat, words, info)
+        assert rel(one["regrs"].cpu().numpy().reshape(n, T, 2 * k), regrs.numpy()) < 1e-4
+        assert rel(one["conf"].cpu().numpy().reshape(n, T, k), conf.numpy()) < 1e-4
+        assert rel(one["cls"].cpu().numpy().reshape(n, T, k), cls.numpy()) < 1e-4
+        for key in ("pooled_se", "bins_probs", "bins_mask"):
+            assert torch.equal(one[key], o[key]), (seed, key)
+
+
+@pytest.mark.parametrize("hidden", [64, 128])
+def test_grounding_batch_mixing_short_and_long_videos_equals_one_video_calls(hidden):
+    """The attention kernels switch from the single-pass to the two-pass form at a head-dim dependent sequence length (256 clips at
+    head dims 8 / 16), per launch: the engine only batches videos on the same side of that limit, so a 40-clip video scored next to a
+    300-clip one gets exactly the bits of its one-video call (found by the randomised test above at head dim 8, where the limit used
+    to be 64 clips)."""
+    from bigc_hip.synthetic import grd_state_shapes
+    from test_hip_grounding import build_model as build_grd
+    cfg = dict(dim_feat=64, dim_clsme=300, dim_hidden=hidden, num_bins=4, loss_factor=dict(classification=1.0, centerness=1.0, regression=1.0))
+    sd = seeded_state_dict(grd_state_shapes(cfg), 77, 4.0)
+    model = build_grd(cfg, sd)
+    jobs = []
+    for v, (T, n) in enumerate([(40, 5), (300, 3), (150, 4), (257, 2), (2, 6)]):
+        feat, (quint, dura, vl) = cases.make_grd_inputs(cfg, dict(seed=880 + v, T=T, n=n, video_len=8 * T))
+        jobs.append((feat.to(DEV), quint, dura, vl))
+    th = dict(cases.GRD_TH)
+    outs = model.forward_raw_batch(jobs, **th)
+    assert len(outs) == len(jobs)
+    for job, o in zip(jobs, outs):
+        one = model.forward_raw(*job, **th)
+        for key in ("pooled_se", "bins_probs", "bins_mask"):
+            assert torch.equal(one[key], o[key]), (int(job[0].shape[0]), key)

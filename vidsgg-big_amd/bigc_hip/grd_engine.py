@@ -111,19 +111,29 @@ class GrdEngine(object):
         """Several videos per launch sequence (``grd_forward_batch``).  ``jobs``: list of (video_feature (T,dim_feat) f32 cuda,
         quint (n,5), dura (n,2), video_len).  -> list of per-video dicts (views of the batch outputs) with the keys of ``forward``;
         ``status`` is a 1-element view per video.  Videos are grouped into calls of at most ``BATCH_ROWS`` combined rows."""
-        groups, cur, rows = [], [], 0
-        for j in jobs:
+        # The attention kernels keep the scores of a sequence in registers up to a head-dim dependent length and switch to a two-pass
+        # form beyond it (csrc/attention.hip: bigc_mha_core_drop_f32), and the form is chosen per LAUNCH from the longest sequence:
+        # a video is therefore only batched with videos on its own side of that limit, so that its result does not depend on its
+        # company (identical, bit for bit, to the one-video call).
+        limit = 32 * {8: 8, 16: 8, 32: 6, 64: 6}[self.c.dim_hidden // 8]
+        order = sorted(range(len(jobs)), key=lambda i: int(jobs[i][0].shape[0]) > limit)          # stable: short videos first, long ones after
+        groups, cur, rows, side = [], [], 0, None
+        for i in order:
+            j = jobs[i]
             r = int(j[0].shape[0]) * int(j[1].shape[0])
-            if cur and rows + r > self.BATCH_ROWS:
+            s_ = int(j[0].shape[0]) > limit
+            if cur and (rows + r > self.BATCH_ROWS or s_ != side):
                 groups.append(cur)
                 cur, rows = [], 0
-            cur.append(j)
+            cur.append(i)
             rows += r
+            side = s_
         if cur:
             groups.append(cur)
-        out = []
+        out = [None] * len(jobs)
         for g in groups:
-            out.extend(self._forward_group(g, score_th, tiou_th, bins_th, nms_th))
+            for i, o in zip(g, self._forward_group([jobs[i] for i in g], score_th, tiou_th, bins_th, nms_th)):
+                out[i] = o
         return out
 
     def _forward_group(self, jobs, score_th, tiou_th, bins_th, nms_th):

@@ -635,6 +635,7 @@ extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, con
     else if (hd == 16 && nkt <= 2) LAUNCH_SP(16, 2);
     else if (hd == 16 && nkt <= 8) LAUNCH_SP(16, 8);
     else if (hd == 8 && nkt <= 2) LAUNCH_SP(8, 2);
+    else if (hd == 8 && nkt <= 8) LAUNCH_SP(8, 8);          // (same single-pass arithmetic as <8, 2>: a batch with a longer video must not change a shorter one's bits)
     else if (hd == 32 && nkt <= 6) LAUNCH_SP(32, 6);
     else
     switch (hd) {

@@ -133,3 +133,47 @@ def test_grounding_batch_mixing_short_and_long_videos_equals_one_video_calls(hid
         one = model.forward_raw(*job, **th)
         for key in ("pooled_se", "bins_probs", "bins_mask"):
             assert torch.equal(one[key], o[key]), (int(job[0].shape[0]), key)
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_training_step_vs_oracle_autograd(seed):
+    """The BIG-C training step (forward, Hungarian matching on the device-computed cost, loss, hand-written backward) on seeded random
+    configurations and batches against the oracle's autograd: total loss within 2e-4, matching identical, every parameter gradient
+    within 3e-3 of the oracle's (relative to its largest entry) and the median parameter within 1e-4 -- the bounds of the golden tests
+    (tests/test_hip_train.py explains the slack: a ReLU within f32 round-off of zero may take the other branch)."""
+    import copy
+    from bigc_hip.synthetic import synthetic_gt_graph
+    from oracle import bigc_train_oracle as T
+    from test_hip_train import build_train_model
+    variant, cfg, specs, _, gain = random_case(50 + seed)
+    specs = [s for s in specs if s.get("n_trajs", 0) >= 5 and not s.get("disjoint")][:3]
+    if not specs:
+        specs = [dict(seed=4242 + seed, n_trajs=12, len_range=(6, 30), start_range=(0, 10))]
+    for s in specs:
+        s["n_trajs"] = min(s["n_trajs"], 40)
+        s["start_range"] = (0, 6)                                   # overlapping tracklets: the GT sampler needs overlapping pairs
+    sd = seeded_state_dict(bigc_state_shapes(cfg, variant), 500 + seed, att_gain=min(gain, 3.0))
+    props = [cases.make_proposal(cfg, variant, s) for s in specs]
+    gts = [synthetic_gt_graph(p, 600 + seed + i, n_gt_trajs=min(5, p.num_proposals), n_preds=4, num_pred_cats=cfg["num_pred_cats"]) for i, p in enumerate(props)]
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want_total, _, want_idx = T.forward_train(sdg, cfg, copy.deepcopy(props), copy.deepcopy(gts), variant)
+    want_total.backward()
+    model = build_train_model(cfg, variant, sd)
+    total, terms = model(props, copy.deepcopy(gts))
+    total.backward()
+    torch.cuda.synchronize()
+    assert abs(float(total.detach()) - float(want_total.detach())) < 2e-4 * abs(float(want_total.detach()))
+    for (iq, ig), (wq, wg) in zip(model.last_match_indices, want_idx):
+        assert np.array_equal(np.asarray(iq), np.asarray(wq)) and np.array_equal(np.asarray(ig), np.asarray(wg))
+    worst = {}
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        w_ = sdg[k].grad
+        if w_ is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        worst[k] = float((p.grad.cpu() - w_).abs().max() / max(float(w_.abs().max()), 1e-12))
+    bad = {k: v for k, v in worst.items() if v > 3e-3}
+    assert not bad, (seed, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
+    assert float(np.median(list(worst.values()))) < 1e-4

@@ -177,3 +177,57 @@ def test_random_training_step_vs_oracle_autograd(seed):
     bad = {k: v for k, v in worst.items() if v > 3e-3}
     assert not bad, (seed, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
     assert float(np.median(list(worst.values()))) < 1e-4
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_pairwise_baseline_vs_oracle(seed):
+    """Base_C (the explicit N x N pair classifier, models/model_pairwise_baseline.py) on seeded random configurations: triplet rows
+    (incl. the order of the rt_triplets_topk cut), spans and tracklet scores identical to the oracle's, predicate probability within
+    5e-5, pair logits within 1e-4."""
+    from bigc_hip.synthetic import basec_state_shapes, synthetic_proposal
+    from oracle import basec_oracle as B
+    from test_basec import _build
+    rs = np.random.RandomState(8000 + seed)
+    width = int(rs.choice([16, 32, 64, 128]))
+    mode = int(rs.randint(0, 3))
+    cfg = dict(num_enti_cats=int(rs.randint(3, 40)), num_pred_cats=int(rs.randint(3, 50)), dim_feat=int(rs.choice([24, 64, 96])),
+               dim_clsme=int(rs.choice([12, 20, 32])), dim_enti=width, dim_ffn=int(rs.choice([32, 64, 128])), enco_pool_len=4,
+               use_clsme=mode != 2, rt_triplets_topk=int(rs.choice([-1, 5, 50, 200])), EntiNameEmb_path=None)
+    if mode == 1:
+        cfg["_with_EntiNameEmb"] = True
+    sd = seeded_state_dict(basec_state_shapes(cfg), 900 + seed, 1.0)
+    fw = cfg["dim_feat"] + (cfg["dim_clsme"] if (cfg["use_clsme"] and not cfg.get("_with_EntiNameEmb")) else 0)
+    props = []
+    for v in range(int(rs.randint(1, 5))):
+        n = int(rs.choice([0, 1, 2, 7, 30, 70]))
+        kw = dict(n_trajs=n, feat_width=fw, num_enti_cats=cfg["num_enti_cats"])
+        if n:
+            lo = int(rs.randint(4, 20))
+            kw.update(len_range=(lo, lo + int(rs.randint(1, 30))), start_range=(0, int(rs.randint(1, 40))))
+        props.append(synthetic_proposal(int(rs.randint(1 << 20)), **kw))
+    topk = int(min(rs.randint(1, 5), cfg["num_pred_cats"] - 1))
+    model = _build(cfg, sd)
+    import copy
+    got = model([copy.deepcopy(p).to(DEV) for p in props], topk=topk)
+    want = B.forward_test(sd, cfg, props, topk=topk)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        if w is None:
+            assert g is None
+            continue
+        assert g is not None
+        assert np.array_equal(g[0].cpu().numpy(), w[0].numpy()) and np.array_equal(g[2].cpu().numpy(), w[2].numpy())
+        gs, ws = g[1].cpu().numpy(), w[1].numpy()
+        assert np.array_equal(gs[:, 1:], ws[:, 1:]) and np.abs(gs[:, 0] - ws[:, 0]).max() < 5e-5
+    keep = [copy.deepcopy(p).to(DEV) for p in props if p.num_proposals > 0]
+    if keep:
+        out = model.engine().pair_forward(PackedBatch(keep, DEV))
+        off, j = out["vid_pair_off"], 0
+        for p in props:
+            if p.num_proposals == 0:
+                continue
+            if p.num_proposals > 1:
+                ref = B.forward_propagation(sd, cfg, p)[0].numpy()
+                got_l = out["pair_logits"][off[j]:off[j + 1]].cpu().numpy()
+                assert got_l.shape == ref.shape and np.abs(got_l - ref).max() <= 1e-4 * np.abs(ref).max()
+            j += 1

@@ -231,3 +231,15 @@ def test_random_pairwise_baseline_vs_oracle(seed):
                 got_l = out["pair_logits"][off[j]:off[j + 1]].cpu().numpy()
                 assert got_l.shape == ref.shape and np.abs(got_l - ref).max() <= 1e-4 * np.abs(ref).max()
             j += 1
+
+
+@pytest.mark.parametrize("seed", list(range(30, 38)))
+def test_random_evaluator_device_tables_equal_host_viou(seed):
+    """The evaluator with its vIoU overlaps from the batched device table (bigc_viou_pairs) against the per-pair host evaluation
+    (= VidVRDhelperEvalAPIs/common.py:65-106, pinned by tests/golden/evaluator.npz) on seeded random GT / prediction sets:
+    mAP, Recall@50 / @100 and the tagging precisions identical."""
+    from bigc_hip import evaluate as E
+    gt, pr = cases.make_eval_case(seed, n_videos=int(3 + seed % 5))
+    m_h, r_h, p_h = E.evaluate(gt, pr)
+    m_d, r_d, p_d = E.evaluate(gt, pr, device=DEV)
+    assert abs(m_h - m_d) < 1e-9 and r_h == r_d and p_h == p_d

@@ -243,3 +243,41 @@ def test_random_evaluator_device_tables_equal_host_viou(seed):
     m_h, r_h, p_h = E.evaluate(gt, pr)
     m_d, r_d, p_d = E.evaluate(gt, pr, device=DEV)
     assert abs(m_h - m_d) < 1e-9 and r_h == r_d and p_h == p_d
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_grounding_training_step_vs_oracle_autograd(seed):
+    """The grounding scorer's training step on seeded random configurations (hidden 64 / 128, 2-10 bins, 1-3 videos of 4-60 clips,
+    the reference's randperm negatives replayed through the global RNG): the five loss terms within 1e-4 and every parameter gradient
+    within 5e-4 of the oracle's autograd -- the bounds of the golden tests (tests/test_hip_grd_train.py)."""
+    from oracle import grd_train_oracle as GT
+    from test_hip_grd_train import build_model as build_grd_train
+    rs = np.random.RandomState(6000 + seed)
+    name = "_fuzz_%d" % seed
+    cases.GRD_TRAIN_CASES[name] = dict(
+        cfg=dict(dim_feat=int(rs.choice([32, 64, 128])), dim_clsme=300, dim_hidden=int(rs.choice([64, 128])), num_bins=int(rs.randint(2, 11))),
+        wseed=700 + seed, gain=float(rs.choice([1.0, 2.0])), rng_seed=int(rs.randint(1 << 20)), full=False,
+        videos=[dict(seed=int(rs.randint(1 << 20)), T=int(rs.choice([4, 9, 25, 60])), n_gt_trajs=int(rs.randint(3, 7)), n_preds=int(rs.randint(2, 7)))
+                for _ in range(int(rs.randint(1, 4)))])
+    try:
+        cfg, sd, feats, gts, rng_seed = cases.make_grd_train_case(name)
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        torch.manual_seed(rng_seed)
+        total, terms, _ = GT.forward_train(sdg, cfg, feats, gts)
+        total.backward()
+        cfg, sd, feats, gts, rng_seed = cases.make_grd_train_case(name)
+        model = build_grd_train(cfg, sd)
+        torch.manual_seed(rng_seed)
+        h_total, h_terms = model([f.to(DEV) for f in feats], gts)
+        h_total.backward()
+    finally:
+        del cases.GRD_TRAIN_CASES[name]
+    for k in terms:
+        assert abs(float(h_terms[k].detach()) - float(terms[k].detach())) < 1e-4 * max(1.0, abs(float(terms[k].detach()))), (seed, k)
+    for k, p in model.named_parameters():
+        ref = sdg[k].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        err = float((p.grad.cpu() - ref).abs().max())
+        assert err <= 5e-4 * max(float(ref.abs().max()), 1e-12), (seed, k, err, float(ref.abs().max()))

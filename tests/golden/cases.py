@@ -275,6 +275,12 @@ def make_grd_train_case(name):
 INGEST_CASES = {
     "ingest_pku_i3d": dict(seed=901, n_traj=9, dim_box=16, dim_i3d=8, min_frames_th=5, max_proposal=6, with_i3d=True),
     "ingest_pku": dict(seed=902, n_traj=7, dim_box=12, dim_i3d=0, min_frames_th=4, max_proposal=50, with_i3d=False),
+    # more draws of the same generator: more tracklets than max_proposal (sort by score + truncation), a threshold that filters several,
+    # wider features, no truncation at all
+    "ingest_pku_i3d_b": dict(seed=903, n_traj=14, dim_box=24, dim_i3d=12, min_frames_th=7, max_proposal=5, with_i3d=True),
+    "ingest_pku_i3d_c": dict(seed=904, n_traj=6, dim_box=8, dim_i3d=4, min_frames_th=3, max_proposal=100, with_i3d=True),
+    "ingest_pku_b": dict(seed=905, n_traj=12, dim_box=20, dim_i3d=0, min_frames_th=10, max_proposal=4, with_i3d=False),
+    "ingest_pku_c": dict(seed=906, n_traj=16, dim_box=16, dim_i3d=0, min_frames_th=5, max_proposal=9, with_i3d=False),
 }
 
 

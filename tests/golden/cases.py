@@ -36,6 +36,9 @@ BIGC_CASES = {
     # G2: full config V, N=64, the benchmark's first video (seed 1234)
     "bigc_v_n64": dict(cfg="CONFIG_V", variant="vidvrd", wseed=7, topk=10, att_gain=8.0, full=False,
                        videos=[dict(seed=1234, n_trajs=64)]),
+    # ... and four more videos of the benchmark workload (seeds 1235..1238) through the real reference, outputs only
+    "bigc_v_n64_more": dict(cfg="CONFIG_V", variant="vidvrd", wseed=7, topk=10, att_gain=8.0, full=False, slim=True,
+                            videos=[dict(seed=1235 + i, n_trajs=64) for i in range(4)]),
     # G3: the VidOR model (models/model_0v7.py): classeme carried in the features / category embedding /
     # no classeme at all, tiny dims with all intermediates; then the exp5 dims with N=32
     "bigo_tiny_clsme": dict(cfg="CONFIG_TINY_O", variant="vidor", wseed=31, topk=3, att_gain=6.0, full=True,

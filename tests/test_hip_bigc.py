@@ -74,6 +74,10 @@ def test_bigc_vs_reference_golden(name):
         out = model.forward_packed(packed, topk, keep_intermediates=True)
         torch.cuda.synchronize()
         n = p.num_proposals
+        if pre + "att_argmax" in g.files:            # outputs-only fixture: the contract itself
+            assert rel(out["pred_logits"].cpu().numpy(), g[pre + "pred_logits"]) < LOGIT_RTOL
+            assert np.array_equal(out["soid"].cpu().numpy()[0], g[pre + "att_argmax"])
+            continue
         assert rel(out["enti2enco"].cpu().numpy(), g[pre + "enti2enco"]) < 2e-5
         assert rel(out["enco_output"].cpu().numpy(), g[pre + "enco_output"]) < 5e-5
         # pred_query (the last LayerNorm's output) is an intermediate: measured up to 1.2e-4 at N=100 where the logits -- the

@@ -109,6 +109,10 @@ GRD_CASES = {
     # full dims (config G), n=64 queries x T=120 clips: outputs only
     "grd_g_n64": dict(cfg=dict(dim_feat=1024, dim_clsme=300, dim_hidden=128, num_bins=10), wseed=42, gain=4.0, full=False,
                       videos=[dict(seed=604, T=120, n=64, video_len=960)]),
+    # config G on more videos (VidOR-like clip counts T = ceil(video_len / 8), up to 200 queries), final outputs only
+    "grd_g_more": dict(cfg=dict(dim_feat=1024, dim_clsme=300, dim_hidden=128, num_bins=10), wseed=42, gain=4.0, full=False, slim=True,
+                       videos=[dict(seed=611, T=75, n=200, video_len=600), dict(seed=612, T=240, n=37, video_len=1920),
+                               dict(seed=613, T=33, n=120, video_len=260), dict(seed=614, T=300, n=12, video_len=2400)]),
 }
 
 

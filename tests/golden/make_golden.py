@@ -150,6 +150,8 @@ def run_grd_case(name, grd):
             out[pre + "pooled_se"] = pooled.numpy()
             out[pre + "bins_probs"] = probs.numpy()
             out[pre + "bins_mask"] = mask.numpy()
+            if case.get("slim", False):          # final outputs only (a few KB per video)
+                continue
             words, info = model.prepare_data(data)
             regrs, conf, cls = model.forward_propagation(feat, words, info)
             out[pre + "regrs"], out[pre + "conf"], out[pre + "cls"] = regrs.numpy(), conf.numpy(), cls.numpy()

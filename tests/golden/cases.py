@@ -39,6 +39,11 @@ BIGC_CASES = {
     # ... and four more videos of the benchmark workload (seeds 1235..1238) through the real reference, outputs only
     "bigc_v_n64_more": dict(cfg="CONFIG_V", variant="vidvrd", wseed=7, topk=10, att_gain=8.0, full=False, slim=True,
                             videos=[dict(seed=1235 + i, n_trajs=64) for i in range(4)]),
+    # ... and more VidOR-sized videos (exp5 dims) through the real reference, outputs only: N = 120 / 180 / 75 tracklets of up to 400 frames
+    "bigo_o_more": dict(cfg="CONFIG_O", variant="vidor", wseed=35, topk=3, att_gain=8.0, full=False, slim=True,
+                        videos=[dict(seed=2290, n_trajs=120, len_range=(15, 400), start_range=(0, 200)),
+                                dict(seed=2291, n_trajs=180, len_range=(15, 120), start_range=(0, 300)),
+                                dict(seed=2292, n_trajs=75, len_range=(30, 250), start_range=(0, 60))]),
     # G3: the VidOR model (models/model_0v7.py): classeme carried in the features / category embedding /
     # no classeme at all, tiny dims with all intermediates; then the exp5 dims with N=32
     "bigo_tiny_clsme": dict(cfg="CONFIG_TINY_O", variant="vidor", wseed=31, topk=3, att_gain=6.0, full=True,

@@ -164,6 +164,11 @@ TRAIN_CASES = {
                          videos=[dict(seed=705, n_trajs=14), dict(seed=706, n_trajs=9)],
                          gts=[dict(seed=715, n_gt_trajs=6, n_preds=5), dict(seed=716, n_gt_trajs=4, n_preds=3)]),
 }
+# the benchmark-sized training step through the real reference: two videos of N = 64 / 40 at exp2 dims, loss terms, matching and the
+# gradient NORM of every parameter (no full gradients: a few KB)
+TRAIN_CASES["bigc_train_v64"] = dict(cfg="CONFIG_V", variant="vidvrd", wseed=53, att_gain=3.0, full=False, slim=True,
+                                     videos=[dict(seed=707, n_trajs=64), dict(seed=708, n_trajs=40)],
+                                     gts=[dict(seed=717, n_gt_trajs=8, n_preds=10), dict(seed=718, n_gt_trajs=6, n_preds=6)])
 TRAIN_FULL_GRADS_V = ["fc_pred2logits.bias", "decoder_layers.5.norm3.weight", "decoder_layers.0.fc_pred2att.bias",
                       "encoder_layers.0.norm1.weight", "conv_feat2enti.bias", "fc_bbox2enti.0.weight", "pos_embedding"]
 

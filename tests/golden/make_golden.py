@@ -199,7 +199,7 @@ def run_train_case(name, m10, m07):
     for k, p in model.named_parameters():
         g = p.grad
         out["gnorm_" + k] = np.array(0.0 if g is None else float(g.norm()))
-        if g is not None and (case.get("full", False) or k in cases.TRAIN_FULL_GRADS_V):
+        if g is not None and not case.get("slim", False) and (case.get("full", False) or k in cases.TRAIN_FULL_GRADS_V):
             out["grad_" + k] = g.numpy()
     path = os.path.join(cases.GOLDEN_DIR, name + ".npz")
     np.savez_compressed(path, **out)

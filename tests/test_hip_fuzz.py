@@ -281,3 +281,67 @@ def test_random_grounding_training_step_vs_oracle_autograd(seed):
             continue
         err = float((p.grad.cpu() - ref).abs().max())
         assert err <= 5e-4 * max(float(ref.abs().max()), 1e-12), (seed, k, err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_linear_shapes_vs_float64(seed):
+    """bigc_linear_f32 on seeded random shapes: M from 1 to 3000, N from 4 to 700 (any multiple of 4: narrow and ragged last tiles),
+    K from 4 to 1500 (ragged last K slab), padded pitches, bias / ReLU / sigmoid / residual, row gather over 1-3 segments with -1
+    (zero) rows -- against float64 within 6 f32 round-offs of sum |a||w|; and the pre-split-operand GEMM (bigc_gemm_ps) on the shapes
+    it supports (K a multiple of 32, N of 8) with its f32 and split outputs."""
+    from bigc_hip import _lib
+    from test_hip_gemm_ps import hr8_decode, repr_tol, to_hr8
+    lib = _lib.load()
+    rs = np.random.RandomState(5000 + seed)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    M = int(rs.choice([1, 2, 31, 33, 127, 129, 500, 3000]))
+    N = 4 * int(rs.randint(1, 176))
+    nseg = int(rs.choice([0, 0, 1, 2, 3]))
+    seg = 32 * int(rs.randint(1, 12)) if nseg > 1 else 4 * int(rs.randint(1, 376))
+    K = seg * max(nseg, 1)
+    lda = seg + 4 * int(rs.randint(0, 3))
+    n_src = M if nseg == 0 else int(rs.randint(1, 400))
+    src = torch.randn(n_src, lda, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) * 0.06
+    bias = torch.randn(N, device=DEV, generator=g) if rs.rand() < 0.7 else None
+    res = torch.randn(M, N, device=DEV, generator=g) if rs.rand() < 0.4 else None
+    act = int(rs.choice([0, 1, 2]))
+    idx = None
+    if nseg:
+        idx = torch.from_numpy(rs.randint(-1, n_src, size=(M, nseg)).astype(np.int32)).to(DEV)
+        zero = torch.zeros(1, seg, device=DEV)
+        A64 = torch.cat([torch.cat([src[:, :seg], zero])[idx[:, s].long()] for s in range(nseg)], 1).double()
+    else:
+        A64 = src[:, :seg].double()
+    ldc = N + 4 * int(rs.randint(0, 3))
+    C = torch.full((M, ldc), float("nan"), device=DEV)
+    _lib.check(lib.bigc_linear_f32(_lib.current_stream(), src.data_ptr(), lda, _lib.ptr(idx), max(nseg, 1), seg, W.data_ptr(), K, _lib.ptr(bias),
+                                   _lib.ptr(res), N, C.data_ptr(), ldc, M, N, K, act))
+    torch.cuda.synchronize()
+    pre = A64 @ W.double().t() + (bias.double() if bias is not None else 0)
+    want = torch.relu(pre) if act == 1 else (torch.sigmoid(pre) if act == 2 else pre)
+    if res is not None:
+        want = want + res.double()
+    scale = A64.abs() @ W.double().abs().t() + (bias.double().abs() if bias is not None else 0) + (res.double().abs() if res is not None else 0) + 1e-30
+    got = C[:, :N].double()
+    assert torch.isnan(C[:, N:]).all()                                            # the padding of the output pitch is untouched
+    if act == 2:
+        assert float((got - want).abs().max()) < 2e-6
+    else:
+        assert float(((got - want).abs() / scale).max()) < 6 * 2.0 ** -24, (M, N, K, nseg, act)
+    # the same product on the split-operand GEMM where its shape constraints hold (dense A only)
+    if nseg == 0 and K % 32 == 0 and N % 8 == 0 and lda == seg:
+        As, flag0 = to_hr8(src)
+        C2 = torch.full((M, N), float("nan"), device=DEV)
+        Cs = torch.zeros((M, 4 * N), dtype=torch.uint8, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        _lib.check(lib.bigc_gemm_ps(_lib.current_stream(), As.data_ptr(), 4 * K, 1, None, 1, W.data_ptr(), K, _lib.ptr(bias), _lib.ptr(res), N if res is not None else 0,
+                                    C2.data_ptr(), N, Cs.data_ptr(), 4 * N, M, N, K, act, flag.data_ptr()))
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        if act == 2:
+            assert float((C2.double() - want).abs().max()) < 2e-6
+        else:
+            assert float(((C2.double() - want).abs() / scale).max()) < 8 * 2.0 ** -24, (M, N, K, act)
+        c64 = C2.double().cpu().numpy()
+        assert (np.abs(hr8_decode(Cs, M, N) - c64) <= repr_tol(c64)).all()

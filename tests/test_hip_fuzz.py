@@ -345,3 +345,46 @@ def test_random_linear_shapes_vs_float64(seed):
             assert float(((C2.double() - want).abs() / scale).max()) < 8 * 2.0 ** -24, (M, N, K, act)
         c64 = C2.double().cpu().numpy()
         assert (np.abs(hr8_decode(Cs, M, N) - c64) <= repr_tol(c64)).all()
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_ragged_attention_vs_float64(seed):
+    """bigc_mha_core_f32 on seeded random ragged self-attention problems: head dims 8 / 16 / 32 / 64, 1-12 heads, 1-9 sequences of
+    1 .. 500 rows (the launcher's kernel choice follows the LONGEST one: split-f16 single pass, f32 single pass, two passes), sharp
+    and flat score distributions -- against a float64 softmax(q k^T / sqrt(hd)) v, 1e-5 of the largest output; and each sequence
+    alone gives the bits it gets inside the batch whenever both launches fall on the same side of the single-pass limit."""
+    import math
+    from bigc_hip import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(4000 + seed)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    hd = int(rs.choice([8, 16, 32, 64]))
+    H = int(rs.choice([1, 2, 8, 12]))
+    d = hd * H
+    lens = [int(rs.choice([1, 2, 31, 32, 33, 64, 100, 192, 193, 256, 257, 500])) for _ in range(int(rs.randint(1, 10)))]
+    gain = float(rs.choice([0.3, 1.0, 3.0]))
+    n = sum(lens)
+    qkv = torch.randn(n, 3 * d, device=DEV, generator=g)
+    qkv[:, :2 * d] *= gain
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    offd = torch.from_numpy(off).to(DEV)
+
+    def run(x, o_, offs, n_seq, max_len):
+        _lib.check(lib.bigc_mha_core_f32(_lib.current_stream(), x.data_ptr(), 3 * d, x.data_ptr() + 4 * d, 3 * d, x.data_ptr() + 8 * d, 3 * d,
+                                         o_.data_ptr(), d, offs.data_ptr(), offs.data_ptr(), n_seq, max_len, H, hd, None))
+    o = torch.full((n, d), float("nan"), device=DEV)
+    run(qkv, o, offd, len(lens), max(lens))
+    torch.cuda.synchronize()
+    assert not torch.isnan(o).any()
+    limit = 32 * {8: 8, 16: 8, 32: 6, 64: 6}[hd]
+    for s in range(len(lens)):
+        a, b = int(off[s]), int(off[s + 1])
+        q, k, v = (qkv[a:b, i * d:(i + 1) * d].double().reshape(-1, H, hd).transpose(0, 1) for i in range(3))
+        want = (torch.softmax(q @ k.transpose(1, 2) / math.sqrt(hd), -1) @ v).transpose(0, 1).reshape(-1, d)
+        assert float((o[a:b].double() - want).abs().max() / want.abs().max()) < 1e-5, (seed, s, lens[s])
+        if (lens[s] > limit) == (max(lens) > limit):
+            one = torch.full((b - a, d), float("nan"), device=DEV)
+            x1 = qkv[a:b].contiguous()
+            run(x1, one, torch.tensor([0, b - a], dtype=torch.int32, device=DEV), 1, b - a)
+            torch.cuda.synchronize()
+            assert torch.equal(one, o[a:b]), (seed, s, lens[s], "alone != in the batch")

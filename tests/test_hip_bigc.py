@@ -155,6 +155,12 @@ def test_bigc_batch_mixing_many_and_few_tracklets_vs_oracle(variant, cfg_name, n
             assert gv is None
             continue
         check_tuple_exact(gv, *[t.numpy() for t in wv])
+    # ... and forward() batches a video only with videos of its own size class: every video's result is, bit for bit, what it gives alone
+    for p_, gv in zip(props, got):
+        alone = model([p_], topk=topk)[0]
+        assert (alone is None) == (gv is None)
+        if gv is not None:
+            assert all(torch.equal(a, b) for a, b in zip(alone, gv))
     packed = PackedBatch(props, DEV)
     assert packed.max_trk == n_big
     out = model.forward_packed(packed, topk)

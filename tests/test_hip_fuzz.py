@@ -65,6 +65,12 @@ def test_random_configuration_vs_oracle(seed):
             assert gv is None
         else:
             check_tuple_exact(gv, *[t.numpy() for t in wv])
+    # a video's result does not depend on its company in the batch: bit for bit what it gives alone
+    for p_, gv in zip(props, got):
+        alone = model([p_], topk=topk)[0]
+        assert (alone is None) == (gv is None)
+        if gv is not None:
+            assert all(torch.equal(a, b) for a, b in zip(alone, gv)), (seed, p_.num_proposals)
     live = [p for p in props if p.num_proposals > 0]
     if not live:
         return

@@ -124,8 +124,20 @@ class BigcBase(nn.Module):
         if not keep:
             return [None for _ in proposal_list]
         device = self.pred_query_init.device
-        packed = PackedBatch([proposal_list[i] for i in keep], device)
-        return self.unpack_results(len(proposal_list), keep, self.forward_checked(packed, topk))
+        # The library picks its attention kernels per batch from the LARGEST video (fused role attention up to 64 tracklets, scores in
+        # registers up to 192; csrc/model.hip, csrc/attention.hip): videos are therefore only batched with videos of their own class,
+        # so that a video's result does not depend on its company -- it is, bit for bit, what the video gives alone (the reference
+        # scores one video at a time, models/model_0v10.py:376).
+        classes = {}
+        for i in keep:
+            n = proposal_list[i].num_proposals
+            classes.setdefault(0 if n <= 64 else (1 if n <= 192 else 2), []).append(i)
+        res = [None] * len(proposal_list)
+        for idx in classes.values():
+            packed = PackedBatch([proposal_list[i] for i in idx], device)
+            for i, r in zip(idx, self.unpack_results(len(idx), list(range(len(idx))), self.forward_checked(packed, topk))):
+                res[i] = r
+        return res
 
     def _forward_train(self, proposal_list, gt_graph_list):
         """Training contract of the reference (models/model_0v10.py:510-556): returns

@@ -225,6 +225,12 @@ def test_random_pairwise_baseline_vs_oracle(seed):
         assert np.array_equal(g[0].cpu().numpy(), w[0].numpy()) and np.array_equal(g[2].cpu().numpy(), w[2].numpy())
         gs, ws = g[1].cpu().numpy(), w[1].numpy()
         assert np.array_equal(gs[:, 1:], ws[:, 1:]) and np.abs(gs[:, 0] - ws[:, 0]).max() < 5e-5
+    for p_, g in zip(props, got):                          # ... and independent of the batch a video is scored in
+        alone = model([copy.deepcopy(p_).to(DEV)], topk=topk)[0]
+        assert (alone is None) == (g is None)
+        if g is not None:
+            # (the fourth entry is an uninitialised placeholder, as in the reference: models/model_pairwise_baseline.py:395)
+            assert all(torch.equal(a, b) for a, b in zip(alone[:3], g[:3])), (seed, p_.num_proposals)
     keep = [copy.deepcopy(p).to(DEV) for p in props if p.num_proposals > 0]
     if keep:
         out = model.engine().pair_forward(PackedBatch(keep, DEV))

@@ -151,6 +151,23 @@ def test_basec_train_every_gradient_matches_oracle_and_optimizer_step_runs():
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=5, norm_type=2)
         opt.step()
     assert float(loss) < before
+    # after the optimizer steps every derived buffer (split weights, transposed copies, the conv weight repacked for the backward)
+    # must follow the CURRENT weights: gradients at the updated weights against the oracle's autograd at those weights
+    sd2 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    sdg2 = {k: (v.requires_grad_(True) if k != "EntiNameEmb" else v) for k, v in sd2.items()}
+    props_cpu = cases.make_basec_train_case(name)[2]                            # (.to("cuda:0") above moved `props` in place)
+    total2, _, _ = B.forward_train(sdg2, cfg, props_cpu, pos, labels)
+    total2.backward()
+    opt.zero_grad()
+    h2, _ = model([p.to("cuda:0") for p in props], pos, labels)
+    h2.backward()
+    assert abs(float(h2) - float(total2)) < 2e-4 * abs(float(total2))
+    for k, p in model.named_parameters():
+        ref = sdg2[k].grad
+        if ref is None:
+            continue
+        err = float((p.grad.cpu() - ref).abs().max())
+        assert err <= 1e-3 * max(float(ref.abs().max()), 1e-12), (k, err)
 
 
 @pytest.mark.gpu

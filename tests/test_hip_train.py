@@ -292,6 +292,43 @@ def test_train_step_then_optimizer_like_the_reference_loop():
 
 
 @pytest.mark.parametrize("name", ["bigc_train_tiny", "bigc_train_v"])
+def test_gradients_of_later_optimizer_steps_follow_the_updated_weights(name):
+    """Every buffer DERIVED from a weight (split forms, transposed copies, the backward's repack of the conv weight) must be
+    refreshed after each optimizer step: the gradients of the 2nd and 3rd step, taken at the weights Adam produced, are compared
+    with the oracle's autograd AT THOSE WEIGHTS (a derived buffer left at the previous step's values shows up in the gradients
+    of everything below the conv: fc_bbox2enti.*, fc_feat2enti.*)."""
+    cfg, variant, sd, props, _ = cases.make_train_case(name)
+    model = build_train_model(cfg, variant, sd)
+    # a large step (stale weights would be far from the current ones), but not so large that the exp2-dims model diverges
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3 if name == "bigc_train_tiny" else 3e-4)
+    for step in range(3):
+        gts = cases.make_train_case(name)[4]
+        opt.zero_grad()
+        loss, _ = model(props, gts)
+        loss.backward()
+        torch.cuda.synchronize()
+        if step > 0:
+            sdg = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+            want, _, _ = T.forward_train(sdg, cfg, props, cases.make_train_case(name)[4], variant)
+            want.backward()
+            assert abs(float(loss) - float(want)) < 2e-4 * abs(float(want))
+            worst = {}
+            # (relative to the parameter's own largest gradient entry, or -- for a parameter whose gradient all but vanished, e.g.
+            # fc_enti2att.bias under a saturated attention -- to 1e-4 of the largest entry of any gradient of the step)
+            gmax = max(float(sdg[k].grad.abs().max()) for k, p in model.named_parameters() if p.grad is not None)
+            for k, p in model.named_parameters():
+                if p.grad is None:
+                    continue
+                ref = sdg[k].grad
+                worst[k] = float((p.grad.cpu() - ref).abs().max() / max(float(ref.abs().max()), 1e-4 * gmax))
+            bad = {k: v for k, v in worst.items() if v > 3e-3}
+            assert not bad, (step, sorted(bad.items(), key=lambda kv: -kv[1])[:10])
+            front = [v for k, v in worst.items() if k.startswith(("fc_bbox2enti", "fc_feat2enti"))]
+            assert front and max(front) < 2e-3, (step, front)
+        opt.step()
+
+
+@pytest.mark.parametrize("name", ["bigc_train_tiny", "bigc_train_v"])
 def test_train_step_exact_gemm_mode_every_gradient_within_1e_4(name):
     """The same golden with every GEMM on the exact f32 MFMA (bigc_linear_set_exact(1)): no ReLU sits on the other side of zero
     than in the reference run, and EVERY parameter gradient agrees within 1e-4 (the 3e-3 slack of the default-mode test above is

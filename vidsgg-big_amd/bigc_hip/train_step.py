@@ -219,7 +219,11 @@ def backward(model, engine, ctx, grad_terms, named_params):
     # The backward GEMMs split their f32 operands into two f16 (csrc/linear_split.hip): exact for magnitudes inside the
     # f16 range, so the seed gradients are brought to a magnitude of ~8 by a power of two (exact) and the parameter
     # gradients scaled back at the end -- the loss scaling of mixed-precision training, here only to keep f32 accuracy.
-    scale = grad_scale_device(ctx.dlogits, ctx.datt)      # (a device scalar: the step does not wait for it)
+    # d att = w (a - t) / max(a (1 - a), 1e-12) (csrc/loss.hip, as torch's BCE backward) reaches 1e10 on a saturated attention
+    # weight, while what the GEMMs see of it -- after the double-softmax backward, an f32 kernel, multiplied it by ~a (1 - a) -- is
+    # of ordinary size.  Taking the scale from the raw d att would push d logits (and with it every weight gradient) under the
+    # split format's floor of 2^-35: the magnitude that counts is the one behind the softmax.
+    scale = grad_scale_device(ctx.dlogits, ctx.datt * (ctx.att * (1.0 - ctx.att)))      # (a device scalar: the step does not wait for it)
     if scale is not None:
         ctx.dlogits.mul_(scale)
         ctx.datt.mul_(scale)

@@ -253,6 +253,9 @@ extern "C" int bigc_finalize(bigc_model* m, void* stream) {
         if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "finalize: hipMalloc: %s", hipGetErrorString(e));
     }
     TRY(bigc_repack_conv_weight((hipStream_t)stream, m->conv.w, m->conv_w_tapmajor, de, 2 * de, 3));
+    // the backward's repack of the conv weight is a derived buffer whose split form is cached per epoch like any weight's: it
+    // must be current BEFORE the step's batched re-split (bigc_linear_prepare in *_train_forward), i.e. here, not in the backward
+    if (m->conv_w_bwd) TRY(bigc_repack_conv_weight_bwd((hipStream_t)stream, m->conv.w, m->conv_w_bwd, de, 2 * de, 3));
     m->epoch = bigc_next_weights_epoch();
     m->finalized = true;
     return BIGC_OK;

@@ -55,3 +55,4 @@ extern "C" int bigc_axpy_f32(void* stream, float* y, const float* x, long n);
 int bigc_head_pick(hipStream_t s, const float* att, const int32_t* e_off, const int32_t* trk_cat, int n_vid, int nq, const float* U,
                    const float* V, int lduv, const float* bias_matrix, int n_ecat, int n_pcat, int32_t* soid, float* acc);
 int bigc_repack_conv_weight(hipStream_t s, const float* w, float* out, int n_out, int n_in, int taps);
+int bigc_repack_conv_weight_bwd(hipStream_t s, const float* w, float* out, int n_out, int n_in, int taps);     // backward.hip

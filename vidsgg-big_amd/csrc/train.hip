@@ -231,11 +231,11 @@ static int frontend_train_backward(bigc_model* m, void* s, const bigc_batch* b, 
         TRY(bigc_conv_grad_unpack(hs, w.gconvw, gcw, de, 2 * de, 3));
     }
     TRY(bigc_conv_gather_bwd_f32(s, w.gconv, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.G, NT, de));
-    if (!m->conv_w_bwd) {
+    if (!m->conv_w_bwd) {       // first backward of this model: later steps find it repacked by bigc_finalize (before the re-split)
         hipError_t e = hipMalloc((void**)&m->conv_w_bwd, sizeof(float) * (size_t)2 * de * 3 * de);
         if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: hipMalloc: %s", hipGetErrorString(e));
+        TRY(bigc_repack_conv_weight_bwd(hs, m->conv.w, m->conv_w_bwd, de, 2 * de, 3));
     }
-    TRY(bigc_repack_conv_weight_bwd(hs, m->conv.w, m->conv_w_bwd, de, 2 * de, 3));
     TRY(bigc_linear_f32(s, w.G, 3 * de, nullptr, 1, 3 * de, m->conv_w_bwd, 3 * de, nullptr, nullptr, 0, w.genti, 2 * de, R, 2 * de, 3 * de,
                         BIGC_ACT_NONE));
     TRY(bigc_relu_bwd_f32(s, w.genti, w.enti, (long)R * 2 * de));

@@ -291,16 +291,17 @@ def test_train_step_then_optimizer_like_the_reference_loop():
     assert losses[-1] < losses[0]
 
 
-@pytest.mark.parametrize("name", ["bigc_train_tiny", "bigc_train_v"])
-def test_gradients_of_later_optimizer_steps_follow_the_updated_weights(name):
+@pytest.mark.parametrize("name,fused", [("bigc_train_tiny", False), ("bigc_train_tiny", True), ("bigc_train_v", True)])
+def test_gradients_of_later_optimizer_steps_follow_the_updated_weights(name, fused):
     """Every buffer DERIVED from a weight (split forms, transposed copies, the backward's repack of the conv weight) must be
     refreshed after each optimizer step: the gradients of the 2nd and 3rd step, taken at the weights Adam produced, are compared
     with the oracle's autograd AT THOSE WEIGHTS (a derived buffer left at the previous step's values shows up in the gradients
-    of everything below the conv: fc_bbox2enti.*, fc_feat2enti.*)."""
+    of everything below the conv: fc_bbox2enti.*, fc_feat2enti.*).  ``fused``: torch's fused Adam -- what tools/ and bench.py use --
+    updates the parameters WITHOUT bumping their version counters, so the step cannot rely on them to notice new weights."""
     cfg, variant, sd, props, _ = cases.make_train_case(name)
     model = build_train_model(cfg, variant, sd)
     # a large step (stale weights would be far from the current ones), but not so large that the exp2-dims model diverges
-    opt = torch.optim.Adam(model.parameters(), lr=3e-3 if name == "bigc_train_tiny" else 3e-4)
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3 if name == "bigc_train_tiny" else 3e-4, fused=fused)
     for step in range(3):
         gts = cases.make_train_case(name)[4]
         opt.zero_grad()

@@ -48,12 +48,16 @@ class BigcEngine(object):
         except Exception:
             pass
 
-    def sync_params(self, named_tensors):
-        """(Re-)register the parameter pointers when a tensor moved or was written in place."""
+    def sync_params(self, named_tensors, force=False):
+        """(Re-)register the parameter pointers when a tensor moved, and rebuild the derived device buffers (``bigc_finalize``: new
+        weights epoch) when a tensor was written in place.  ``force``: rebuild even though no version counter moved -- the training
+        steps pass it, because the optimizer they follow may be a FUSED one (``torch.optim.Adam(fused=True)``), whose in-place
+        update does not bump ``_version`` (measured, torch 2.10): without it every GEMM of the next forward would multiply by the
+        split copy of the previous weights."""
         items = [(k, t) for k, t in named_tensors]
         ptrs = tuple((k, t.data_ptr()) for k, t in items)
         sig = (ptrs, tuple(t._version for _, t in items))
-        if sig == self._sig:
+        if sig == self._sig and not force:
             return
         if self._sig is None or self._sig[0] != ptrs:       # a training step changes the versions only: nothing to re-register
             for k, t in items:
@@ -68,7 +72,9 @@ class BigcEngine(object):
         """Force the next forward to re-register the parameters and rebuild every derived device buffer (split / transposed
         weight copies, ``role_cat``, the tap-major conv weight).  ``sync_params`` notices a parameter that moved or whose
         ``_version`` changed (optimizer steps, ``load_state_dict``, ``copy_``); it cannot notice writes through ``p.data``
-        (``p.data.mul_()``, hand-written EMA / clipping code), which do not bump the version counter: call this after those."""
+        (``p.data.mul_()``, hand-written EMA / clipping code) or by a fused optimizer (``Adam(fused=True)`` updates the parameters
+        without bumping ``_version``), which leave the version counter alone: call this after those.  (The training steps of this
+        package refresh the weights on every forward themselves.)"""
         self._sig = None
 
     def flat_gradients(self, trainable, device, set_grad="bigc_set_grad", rebase="bigc_rebase_grads"):

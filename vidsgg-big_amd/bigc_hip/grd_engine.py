@@ -41,10 +41,11 @@ class GrdEngine(object):
         except Exception:
             pass
 
-    def sync_params(self, named_tensors):
+    def sync_params(self, named_tensors, force=False):
+        """``force``: see BigcEngine.sync_params (a fused optimizer's update does not bump the version counters)"""
         items = [(k, t) for k, t in named_tensors]
         sig = tuple((k, t.data_ptr(), t._version) for k, t in items)
-        if sig == self._sig:
+        if sig == self._sig and not force:
             return
         for k, t in items:
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \

@@ -184,7 +184,7 @@ class HipGrdTrainStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, video_feature_list, gt_graph_list, *params):
-        engine = model.engine()
+        engine = model.engine(force=True)      # the weights changed since the last step, whether or not a version counter says so (fused optimizers)
         with torch.no_grad():
             terms, tctx = forward(model, engine, video_feature_list, gt_graph_list)
         ctx.model, ctx.engine, ctx.tctx = model, engine, tctx

@@ -113,7 +113,7 @@ class HipPairTrainStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, packed, pos_id_list, label_list, *params):
-        engine = model.engine()
+        engine = model.engine(force=True)      # the weights changed since the last step, whether or not a version counter says so (fused optimizers)
         with torch.no_grad():
             terms, tctx = forward(model, engine, packed, pos_id_list, label_list)
         ctx.model, ctx.engine, ctx.tctx = model, engine, tctx

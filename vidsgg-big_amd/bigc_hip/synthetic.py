@@ -324,3 +324,47 @@ def synthetic_gt_graph(proposal, seed, n_gt_trajs=6, n_preds=5, num_pred_cats=13
         pd.append([max(int(duras[a, 0]), int(duras[b, 0])), min(int(duras[a, 1]), int(duras[b, 1]))])
     pred_cats = rs.randint(1, num_pred_cats, size=len(sel))
     return VideoGraph(proposal.video_name, proposal.video_len, proposal.video_wh, cats, duras, boxes, pred_cats, pd, adj)
+
+
+# --------------------------------------------------------------------------------------
+# a LEARNABLE synthetic relation set (Recall@50 that is not zero)
+# --------------------------------------------------------------------------------------
+
+def relational_video(seed, n_trajs=64, feat_width=2048 + 832, num_enti_cats=36, num_pred_cats=133, n_actors=4, marker=3.0,
+                     marker_width=128, name=None):
+    """One synthetic video (SURVEY.md section 8d recipe) whose ground truth a model can LEARN, so that Recall@50 on held-out
+    videos is far from zero after a few hundred training steps (with section 8d's random predicates every recall is 0 and a
+    recall-parity gate compares 0 with 0).
+
+    ``n_actors`` tracklets that share a frame are the "actors": actor k carries a marker, ``+marker`` on feature columns
+    ``[k * marker_width, (k + 1) * marker_width)`` of every one of its frames.  The ground truth is the ``n_actors *
+    (n_actors - 1)`` ordered actor pairs (12 relations, as section 8d), predicate of (actor a, actor b) = ``1 + a * n_actors + b``,
+    GT trajectories = the actors' own proposal boxes (vIoU = 1 when the model picks the pair), GT span = the overlap span.
+    -> (TrajProposal, VideoGraph)"""
+    p = synthetic_proposal(seed, n_trajs=n_trajs, feat_width=feat_width, num_enti_cats=num_enti_cats, name=name)
+    rs = np.random.RandomState(seed + 500009)
+    duras = p.traj_durations.numpy()
+    assert n_actors * marker_width <= feat_width and 1 + n_actors * n_actors <= num_pred_cats
+    # the frame most tracklets cover: all tracklets that cover it overlap pairwise
+    cover = np.zeros(p.video_len + 1, dtype=np.int64)
+    for s, e in duras:
+        cover[s:e + 1] += 1
+    t_star = int(np.argmax(cover))
+    cand = np.flatnonzero((duras[:, 0] <= t_star) & (duras[:, 1] >= t_star))
+    assert len(cand) >= n_actors, "fewer than %d tracklets share a frame: choose another seed" % n_actors
+    actors = np.sort(rs.choice(cand, size=n_actors, replace=False))
+    rs.shuffle(actors)                                         # actor slot k is not tied to the score order
+    for k, t in enumerate(actors):
+        p.features_list[int(t)][:, k * marker_width:(k + 1) * marker_width] += marker
+    pairs = [(a, b) for a in range(n_actors) for b in range(n_actors) if a != b]
+    adj = np.zeros((2, len(pairs), n_actors), dtype=np.float32)
+    spans, preds = [], []
+    for j, (a, b) in enumerate(pairs):
+        adj[0, j, a] = 1.0
+        adj[1, j, b] = 1.0
+        da, db = duras[actors[a]], duras[actors[b]]
+        spans.append([max(int(da[0]), int(db[0])), min(int(da[1]), int(db[1]))])
+        preds.append(1 + a * n_actors + b)
+    g = VideoGraph(p.video_name, p.video_len, p.video_wh, p.cat_ids[actors].clone(), p.traj_durations[actors].clone(),
+                   [p.bboxes_list[int(t)].clone() for t in actors], np.asarray(preds, dtype=np.int64), spans, adj)
+    return p, g

@@ -243,7 +243,7 @@ class HipTrainStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, packed, gt_graph_list, *params):
-        engine = model.engine()
+        engine = model.engine(force=True)      # the weights changed since the last step, whether or not a version counter says so (fused optimizers)
         mark("register parameters + finalize")
         # dropout follows the module's training flag like the reference's nn.Dropout / nn.MultiheadAttention(dropout=0.1)
         # (models/model_0v10.py:320,326); the per-step seed comes from the global torch RNG

@@ -166,12 +166,14 @@ class BigcBase(nn.Module):
         if self._engine is not None:
             self._engine.invalidate_weights()
 
-    def engine(self):
+    def engine(self, force=False):
+        """``force``: refresh the library's derived weight buffers even if no parameter's version counter moved (training steps:
+        a fused optimizer updates the parameters without bumping it)"""
         if self._engine is None:
             self._engine = BigcEngine(self.config, self.variant)
         if self._state_items is None:      # (the walk over ~300 parameters costs 0.4 ms: kept until the module tree changes)
             self._state_items = list(self.state_dict(keep_vars=True).items())
-        self._engine.sync_params(self._state_items)
+        self._engine.sync_params(self._state_items, force)
         return self._engine
 
     def __setattr__(self, name, value):

@@ -75,10 +75,10 @@ class DEBUG(nn.Module):
         if self._engine is not None:
             self._engine.invalidate_weights()
 
-    def engine(self):
+    def engine(self, force=False):
         if self._engine is None:
             self._engine = GrdEngine(self.config)
-        self._engine.sync_params((k, v) for k, v in self.state_dict(keep_vars=True).items())
+        self._engine.sync_params(((k, v) for k, v in self.state_dict(keep_vars=True).items()), force)
         return self._engine
 
     def forward(self, video_feature_list, data_list, score_th=0.5, tiou_th=0.5, bins_th=0.1, nms_th=0.5, with_gt_data=True):

@@ -53,11 +53,11 @@ class Base_C(nn.Module):
         if self._engine is not None:
             self._engine.invalidate_weights()
 
-    def engine(self):
+    def engine(self, force=False):
         if self._engine is None:
             cfg = dict(self.config)
             self._engine = BigcEngine(cfg, "pairwise")
-        self._engine.sync_params((k, v) for k, v in self.state_dict(keep_vars=True).items())
+        self._engine.sync_params(((k, v) for k, v in self.state_dict(keep_vars=True).items()), force)
         return self._engine
 
     def forward(self, proposal_list, pos_id_list=None, label_list=None, topk=10):

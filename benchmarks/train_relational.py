@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--att-gain", type=float, default=1.0)
     ap.add_argument("--marker", type=float, default=3.0)
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--small", action="store_true")
+    ap.add_argument("--actors", type=int, default=4)
     ap.add_argument("--dropout", type=int, default=1)
     a = ap.parse_args()
     from models import BIG_C_vidvrd
@@ -37,11 +39,14 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
         import cases
         cfg = cases.get_cfg("CONFIG_TINY")
+    elif a.small:
+        cfg = dict(configs.CONFIG_V, num_enti_cats=9, num_pred_cats=20, dim_ffn=64, dim_enti=64, dim_pred=64, dim_att=64, dim_feat=128, dim_clsme=12,
+                   dim_i3d=32, n_enco_layers=2, n_deco_layers=3, n_att_head=4, num_querys=32)
     else:
         cfg = dict(configs.CONFIG_V)
     width = cfg["dim_feat"] + (cfg.get("dim_i3d") or 0)
-    mw = 128 if not a.tiny else max(4, cfg["dim_feat"] // 8)
-    n_trajs = 64 if not a.tiny else 12
+    mw = 128 if not (a.tiny or a.small) else max(4, cfg["dim_feat"] // 8)
+    n_trajs = 64 if not (a.tiny or a.small) else 16
     sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 11, att_gain=a.att_gain)
     d = tempfile.mkdtemp()
     np.save(d + "/b.npy", sd["bias_matrix"].numpy()); np.save(d + "/e.npy", sd["EntiNameEmb"].numpy())
@@ -53,7 +58,7 @@ def main():
         model.eval()
     ev = BIG_C_vidvrd(mcfg, is_train=False).to(dev)
     mk = lambda s: relational_video(s, n_trajs=n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"], num_pred_cats=cfg["num_pred_cats"],
-                                    marker=a.marker, marker_width=mw)
+                                    marker=a.marker, marker_width=mw, n_actors=a.actors)
     t0 = time.time()
     train = [mk(20000 + v) for v in range(a.train_videos)]
     held = [mk(30000 + v) for v in range(a.eval_videos)]

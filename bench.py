@@ -698,6 +698,7 @@ def main():
                                  % (args.steps, 1e3 * prof_elapsed / args.steps))
     cpu_baseline, oracle_parity = None, None
     if n_cpu:
+        from oracle import accuracy as A
         from oracle import bigc_oracle as O
         Q, P = cfg["num_querys"], cfg["num_pred_cats"]
         hip_n = ref_out["n_out"].cpu().numpy()
@@ -707,18 +708,14 @@ def main():
         torch.set_num_threads(usable_cores())
         cpu_pairs, n_done, cpu_s = 0, 0, 0.0
         rows_total, rows_same, vids_same, max_rel, other_argmax = 0, 0, 0, 0.0, 0
-        over, over_worse, sd64, row_diffs = [], 0, None, []
+        over, over_worse, over_failed, sd64, row_diffs = [], 0, 0, None, []
 
         def f64_eval(p):
             """the oracle once more in float64 (the arbiter where two f32 evaluations disagree; outside the CPU timing)"""
             nonlocal sd64
-            import copy
             if sd64 is None:
                 sd64 = {k: t.double() for k, t in sd.items()}
-            p64 = copy.deepcopy(p)
-            p64.bboxes_list = [x.double() for x in p64.bboxes_list]
-            p64.features_list = [x.double() for x in p64.features_list]
-            p64.scores = p64.scores.double()
+            _, p64 = A.to_f64({}, p)
             o64 = O.encode2decode(sd64, cfg, p64)
             return o64, O.construct_triplet(p64, o64["pred_logits"], o64["att"], args.topk)
 
@@ -766,13 +763,16 @@ def main():
                 if same_so.any():
                     d = float(np.abs(hip_logits[v][same_so] - lg[same_so]).max() / np.abs(lg).max())
                     max_rel = max(max_rel, d)
-                    if d > 1e-4 and len(over) < 8:
-                        # two f32 evaluations more than 1e-4 apart: a float64 evaluation of the oracle arbitrates (outside the CPU timing)
-                        l64 = f64_eval(p)[0]["pred_logits"].numpy()
-                        e_hip = float(np.abs(hip_logits[v][same_so] - l64[same_so]).max() / np.abs(lg).max())
-                        e_ref = float(np.abs(lg[same_so] - l64[same_so]).max() / np.abs(lg).max())
-                        over.append(dict(video=v, hip_vs_f32_oracle=d, hip_vs_f64=e_hip, f32_oracle_vs_f64=e_ref))
-                        over_worse += int(e_hip > e_ref)
+                    if d > 1e-4 and len(over) < 12:
+                        # two f32 evaluations more than 1e-4 apart: a float64 evaluation of the oracle is the truth, and where HIP is more
+                        # than 1e-4 from it, the video's own float32 noise floor decides (oracle/accuracy.py; outside the CPU timing)
+                        if sd64 is None:
+                            sd64 = {k: t.double() for k, t in sd.items()}
+                        a = A.arbitrate(sd, cfg, p, hip_logits[v], lg, sd64=sd64, rows=same_so)
+                        a.update(video=v, hip_vs_f32_oracle=d)
+                        over.append(a)
+                        over_worse += int(a["hip_vs_f64"] > max(1e-4, a["f32_oracle_vs_f64"]))
+                        over_failed += int(not a["passed"])
                 if cpu_s > args.cpu_seconds:
                     break
         cpu_baseline = dict(value=round(cpu_pairs / cpu_s, 1), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
@@ -782,10 +782,13 @@ def main():
                              max_logit_rel=max_rel, queries_with_other_argmax_entity=other_argmax,
                              videos_with_differing_rows=row_diffs,
                              videos_over_1e_4=over, videos_over_1e_4_where_hip_is_farther_from_f64_than_the_f32_oracle=over_worse,
+                             videos_outside_1e_4_and_their_f32_noise_floor=over_failed,
                              note="HIP output of the timed workload vs the CPU oracle on the same videos; logits compared on the queries whose "
                                   "attention arg-max (subject, object) agrees, relative to max |logit| of the video; the benchmark model's sharp "
                                   "attention amplifies f32 round-off, so where two f32 evaluations differ by more than 1e-4 a float64 evaluation of "
-                                  "the oracle is the arbiter")
+                                  "the oracle is the truth, and a video on which HIP is more than 1e-4 from it is held against its own float32 noise floor: 4 x the rms "
+                                  "error of f32 evaluations of that video with inputs perturbed by one rounding (oracle/accuracy.py; per-stage evidence in "
+                                  "benchmarks/accuracy_layers.py / accuracy_mixed.py, DESIGN.md section 4)")
     del ref_out
     legs = {}
     want = [x for x in args.legs.split(",") if x] if world == 1 else []

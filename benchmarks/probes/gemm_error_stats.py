@@ -29,4 +29,13 @@ for name, M, N, K, relu in [("K=2048 N(0,1) x xavier", 2048, 512, 2048, False), 
         torch.cuda.synchronize()
         print("   %-21s:" % label, stats(C.cpu()))
     lib.bigc_linear_set_exact(0)
+    # gemm_ps: the operand stored as f16 pairs ("hr8"), ONE accumulator for all three MFMAs of a product
+    if K % 32 == 0:
+        Y = torch.empty((M, 4 * K), dtype=torch.uint8, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.bigc_split_rows_f32(_lib.current_stream(), Ad.data_ptr(), K, Y.data_ptr(), 4 * K, M, K, flag.data_ptr()))
+        C = torch.empty(M, N, device=dev)
+        _lib.check(lib.bigc_gemm_ps(_lib.current_stream(), Y.data_ptr(), 4 * K, 1, None, 1, Wd.data_ptr(), K, None, None, 0, C.data_ptr(), N, None, 0, M, N, K, 0, flag.data_ptr()))
+        torch.cuda.synchronize()
+        print("   %-21s:" % "HIP gemm_ps (hr8 A)", stats(C.cpu()), " (vs the f64 product of the UNSPLIT operand)")
     print("   (rms of C = 1 unit; u = 2^-24)")

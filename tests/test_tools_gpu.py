@@ -125,8 +125,8 @@ def test_bench_json_contract():
     op = d["oracle_parity"]
     n_same, n_all = [int(x) for x in op["identical_triplet_rows"].split(" of ")]
     assert op["videos"] == 4 and n_all > 0 and n_same == n_all and op["videos_fully_identical"] == 4
-    # within 1e-4 of the f32 oracle, or (sharp-attention outliers) at least as close to a float64 evaluation as the f32 oracle is
-    assert op["videos_over_1e_4_where_hip_is_farther_from_f64_than_the_f32_oracle"] == 0 and len(op["videos_over_1e_4"]) <= 1
+    # per video: within 1e-4 of the f32 oracle, or of a float64 evaluation, or inside the video's own f32 noise floor (oracle/accuracy.py)
+    assert op["videos_outside_1e_4_and_their_f32_noise_floor"] == 0 and len(op["videos_over_1e_4"]) <= 1
     # the other BASELINE configs ride in the same line
     g, t = d["grounding"], d["train"]
     assert g["unit"] == "triplet-queries/s" and g["value"] > 0

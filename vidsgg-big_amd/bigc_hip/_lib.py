@@ -30,7 +30,8 @@ class bigc_batch(ctypes.Structure):
                 ("feats", c_void_p), ("boxes", c_void_p), ("trk_row_off", c_void_p),
                 ("trk_conv_off", c_void_p), ("trk_vid", c_void_p), ("trk_dura", c_void_p),
                 ("trk_cat", c_void_p), ("trk_score", c_void_p), ("vid_trk_off", c_void_p),
-                ("vid_tmax", c_void_p), ("vid_wh", c_void_p)]
+                ("vid_tmax", c_void_p), ("vid_wh", c_void_p),
+                ("feats_hr8", c_void_p), ("ld_feats_hr8", ctypes.c_int64), ("feats_hr8_flag", c_void_p)]
 
 
 class bigc_outputs(ctypes.Structure):

@@ -2,6 +2,7 @@
 table in sync with the torch parameters, allocates outputs/workspace with torch and calls
 ``bigc_forward`` on the current HIP stream."""
 import ctypes
+import os
 
 import torch
 
@@ -135,6 +136,9 @@ class BigcEngine(object):
         o = _lib.bigc_outputs()
         for name, _ in _lib.bigc_outputs._fields_:
             setattr(o, name, out[name].data_ptr() if name in out else None)
+        # eval forwards read the visual features in the split form (written once per packed batch; BIGC_FEAT_HR8=0 switches it off)
+        if with_triplets and c.dim_feat % 32 == 0 and os.environ.get("BIGC_FEAT_HR8", "1") != "0":
+            packed.split_features(c.dim_feat)
         b = packed.as_struct()
         need = self.lib.bigc_workspace_bytes(self.handle, ctypes.byref(b))
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:

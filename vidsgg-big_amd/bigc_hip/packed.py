@@ -62,7 +62,21 @@ class PackedBatch(object):
         self.boxes = torch.cat([on_device(b) for p in proposals for b in p.bboxes_list], 0).to(torch.float32).contiguous()
         self.feats = torch.cat([on_device(f) for p in proposals for f in p.features_list], 0).to(torch.float32).contiguous()
         self.feat_width = int(self.feats.shape[1])
+        self.feats_hr8, self.feats_hr8_flag = None, None          # see split_features()
         assert self.boxes.shape == (self.n_rows, 4) and self.feats.shape[0] == self.n_rows
+
+    def split_features(self, dim_feat):
+        """The visual feature columns once more in the split form "hr8" (pairs of f16, same footprint as f32; csrc/gemm_ps.hip): an
+        eval forward then runs fc_feat2enti.0 on operands that are already split.  One pass over the features (read 4 B, write 4 B
+        per element; a real ingest path writes the form while it assembles the rows, csrc/ingest.hip).  Idempotent."""
+        if self.feats_hr8 is not None and self.feats_hr8.shape[1] == 4 * dim_feat:
+            return
+        assert dim_feat % 8 == 0 and dim_feat <= self.feat_width
+        lib = _lib.load()
+        self.feats_hr8 = torch.empty((self.n_rows, 4 * dim_feat), dtype=torch.uint8, device=self.device)
+        self.feats_hr8_flag = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        _lib.check(lib.bigc_split_rows_f32(_lib.current_stream(), self.feats.data_ptr(), self.feat_width, self.feats_hr8.data_ptr(), 4 * dim_feat,
+                                           self.n_rows, dim_feat, self.feats_hr8_flag.data_ptr()))
 
     def n_pairs(self):
         """tracklet-pairs of the batch: sum_v N_v (N_v - 1)."""
@@ -75,4 +89,6 @@ class PackedBatch(object):
         for name in ("feats", "boxes", "trk_row_off", "trk_conv_off", "trk_vid", "trk_dura", "trk_cat",
                      "trk_score", "vid_trk_off", "vid_tmax", "vid_wh"):
             setattr(b, name, getattr(self, name).data_ptr())
+        if self.feats_hr8 is not None:
+            b.feats_hr8, b.ld_feats_hr8, b.feats_hr8_flag = self.feats_hr8.data_ptr(), int(self.feats_hr8.shape[1]), self.feats_hr8_flag.data_ptr()
         return b

@@ -141,6 +141,7 @@ struct PsArgs {
     unsigned char* Cs; long ldcs;                     // hr8 output (or null), pitch in bytes
     int M, N, K, act, tiles_m, tiles_n;
     int* range_flag;
+    int blk;                     // BLOCKED kernels only: K slabs per accumulation block (a power of two), see `tot` in the kernel
     int ablate;                  // benchmarking only (BIGC_PS_ABLATE): 1 = no DMA in the K loop
     unsigned long long* trace;   // benchmarking only (BIGC_PS_TRACE): per wave, cycles spent in the segments of an iteration
 };
@@ -152,7 +153,7 @@ struct PsArgs {
 //   RB = 32-row blocks per wave: 2 -> TM = 128 rows, 3 LDS stages;  4 -> TM = 256 rows, 2 LDS stages.
 //   FAST: reduced-precision mode (bigc_linear_set_fast): heads only, one MFMA per product; the residual chunks still travel
 //   with their rows (the format is the producers') but are not read from LDS.
-template <int AMODE, int RB, bool TRACE = false, bool FAST = false>
+template <int AMODE, int RB, bool TRACE = false, bool FAST = false, bool BLOCKED = false>
 __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     constexpr int TM = 64 * RB;
     constexpr int A_BYTES = TM * ROWB, STAGE_BYTES = A_BYTES + W_BYTES;
@@ -298,15 +299,34 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     bool oob = false;
 
     f32x16 acc[2][RB];
+    // Blocked accumulation (template parameter BLOCKED, RB = 2 only; opt-in through BIGC_PS_BLK, not used by the model).  Every MFMA
+    // rounds its accumulator once, by ~2^-24 of the accumulator's CURRENT magnitude, and this kernel issues three MFMAs per k16 step
+    // into ONE accumulator: over K = 3072 that is 576 roundings at the magnitude of the growing sum -- measured 10.3 x 2^-24 rms of
+    // the result against 6.0 for the two-accumulator kernel of linear_split.hip and 3.2 for torch's CPU GEMM (benchmarks/probes/
+    // gemm_error_stats.py).  With BLOCKED, `acc` only ever holds the partial sum of p.blk slabs (small, so its roundings are small)
+    // and is folded into the running total `tot` once per block: measured 2.97 (K = 3072), 2.87 (K = 2048), 2.28 (K = 512) -- below
+    // the CPU GEMM's.  It is not the default because the second register set does not fit: the 128-row kernel goes from 181 to
+    // 256 registers + 55 spilled in the K loop (60 TFLOP/s), and the 256-row kernel has no room at all; a blocked kernel needs the
+    // one-wave-per-SIMD layout (512 registers per wave).  Kept as the measuring instrument for what blocking buys.
+    static_assert(!BLOCKED || (RB == 2 && !FAST), "blocked accumulation: 128-row tiles only");
+    f32x16 tot[2][BLOCKED ? RB : 1];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
             for (int ri = 0; ri < RB; ++ri)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[fi][ri][r] = 0.f;
+                for (int r = 0; r < 16; ++r) { acc[fi][ri][r] = 0.f; if (BLOCKED) tot[fi][ri][r] = 0.f; }
     };
     zero_acc();
+    auto fold_block = [&]() {
+        if (BLOCKED) {
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int ri = 0; ri < RB; ++ri) { tot[fi][ri] += acc[fi][ri]; acc[fi][ri] = acc[fi][ri] - acc[fi][ri]; }
+        }
+    };
 
     // fragment reads: lane = row l31 of a 32-row block, chunk 2 (2 s + hi) + plane, swizzled by (row >> 1) & 7 = (l31 >> 1) & 7
     const int sw_rd = (l31 >> 1) & 7;
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                 for (int g = 0; g < 4; ++g) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        float t = acc[fi][ri][4 * g + c] * osc + bv[g][c];
+                        float t = (BLOCKED ? tot[fi][ri][4 * g + c] : acc[fi][ri][4 * g + c]) * osc + bv[g][c];      // (blocked: the last block was folded in)
                         t = fmaxf(t, lo);
                         if (sigm) t = 1.0f / (1.0f + expf(-t));
                         v[g][c] = t + rv[g][c];
@@ -525,9 +545,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         for (int i = 0; i + 1 < NST; ++i) so[i] = so[i + 1];
         so[NST - 1] = t;
         if (++ckt == nk) {
+            fold_block();
             epilogue(cj);
             zero_acc();
             ckt = 0; ++cj;
+        } else if (BLOCKED && p.blk > 0 && (ckt & (p.blk - 1)) == 0) {
+            fold_block();
         }
     }
     if (TRACE && lane == 0) {
@@ -621,9 +644,13 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     p.tiles_n = cdiv(g.N, TN);
     // 256-row tiles when they still give every CU at least three tiles (else the 128-row tiles fill the chip better)
     static const int force_rb = getenv("BIGC_PS_RB") ? atoi(getenv("BIGC_PS_RB")) : 0;
-    const int rb = force_rb ? force_rb : (cdiv(g.M, 256) * p.tiles_n >= 3 * n_cu ? 4 : 2);
+    static const bool want_blk = getenv("BIGC_PS_BLK") && atoi(getenv("BIGC_PS_BLK")) > 0;
+    const int rb = (want_blk && g.a_fmt == PS_HR8) ? 2 : (force_rb ? force_rb : (cdiv(g.M, 256) * p.tiles_n >= 3 * n_cu ? 4 : 2));
     p.tiles_m = cdiv(g.M, 64 * rb);
     p.range_flag = g.range_flag;
+    // opt-in blocked accumulation (BIGC_PS_BLK = K slabs per block, a power of two): 128-row tiles, plain / gathered hr8 operand
+    static const int force_blk = getenv("BIGC_PS_BLK") ? atoi(getenv("BIGC_PS_BLK")) : 0;
+    p.blk = (force_blk > 0 && !(force_blk & (force_blk - 1)) && g.a_fmt == PS_HR8 && !bigc_linear_get_fast()) ? force_blk : 0;
     static const int ablate = getenv("BIGC_PS_ABLATE") ? atoi(getenv("BIGC_PS_ABLATE")) : 0;
     p.ablate = ablate;
     static const int trace = getenv("BIGC_PS_TRACE") ? atoi(getenv("BIGC_PS_TRACE")) : 0;
@@ -688,6 +715,9 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
 #undef PS_LAUNCH_FAST
     } else if (g.a_fmt == PS_F32) {
         if (rb == 4) PS_LAUNCH(2, 4); else PS_LAUNCH(2, 2);
+    } else if (p.blk > 0) {
+        if (g.a_idx) hipLaunchKernelGGL((gemm_ps_kernel<1, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
     } else if (g.a_idx) {
         if (rb == 4) PS_LAUNCH(1, 4); else PS_LAUNCH(1, 2);
     } else {

@@ -304,6 +304,13 @@ namespace {
 
 struct PsCtx { hipStream_t s; int* flag; };
 
+__global__ void or_flag_kernel(int* dst, const int32_t* src) { if (*src) atomicOr(dst, 1); }
+int bigc_or_flag(hipStream_t s, int* dst, const int32_t* src) {
+    hipLaunchKernelGGL(or_flag_kernel, dim3(1), dim3(1), 0, s, dst, src);
+    BIGC_LAUNCH_CHECK("or_flag");
+    return BIGC_OK;
+}
+
 // C / Cs = act(A W^T + b) + res;  a_hr8: A is in split form.  Pitches in floats (the hr8 form has the same pitch in bytes / 4).
 int ps(const PsCtx& c, const void* A, long lda, bool a_hr8, const Lin& l, int ldw, float* C, long ldc, void* Cs, long ldcs, int M, int N, int K, int act,
        const float* res = nullptr, long ldr = 0, const int32_t* a_idx = nullptr, int nseg = 1) {
@@ -333,7 +340,13 @@ int run_frontend_chained(const bigc_model* m, void* s, const bigc_batch* b, cons
     TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
     TRY(bigc_linear_k8_hr8out(s, w.bbox8, m->bbox0.w, m->bbox0.b, w.hb, de, R, de, BIGC_ACT_RELU, w.flag));
     TRY(ps(cx, w.hb, de, true, m->bbox2, de, nullptr, 0, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
-    TRY(bigc_linear_hr8out(s, b->feats, D, m->feat0.w, c.dim_feat, m->feat0.b, nullptr, 0, nullptr, 0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU, w.flag));
+    if (b->feats_hr8 && b->ld_feats_hr8 % 16 == 0 && c.dim_feat % 32 == 0) {
+        // the features were split when the batch was packed (bigc_batch.feats_hr8): the K = dim_feat GEMM reads them by DMA
+        TRY(ps(cx, b->feats_hr8, b->ld_feats_hr8 / 4, true, m->feat0, c.dim_feat, nullptr, 0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
+        if (b->feats_hr8_flag) TRY(bigc_or_flag((hipStream_t)s, w.flag, b->feats_hr8_flag));
+    } else {
+        TRY(bigc_linear_hr8out(s, b->feats, D, m->feat0.w, c.dim_feat, m->feat0.b, nullptr, 0, nullptr, 0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU, w.flag));
+    }
     TRY(ps(cx, w.hv, de, true, m->feat2, de, nullptr, 0, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
     TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
     {

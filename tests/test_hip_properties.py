@@ -201,7 +201,8 @@ def test_benchmark_videos_vs_oracle_row_for_row():
 
     PER VIDEO: the HIP logits are within 1e-4 of the f32 oracle's; where they are not, a float64 evaluation of the oracle is the
     truth and the video passes if HIP is within 1e-4 of it -- or within the video's own float32 noise floor (oracle/accuracy.py:
-    4 x the rms error of f32 evaluations of that video with inputs perturbed by one rounding).  The benchmark model's attention is
+    4 x the rms error of f32 evaluations of that video with inputs perturbed by one rounding, x 2 for the measured
+    rounding-error ratio of the HIP front-end GEMMs to MKL's).  The benchmark model's attention is
     sharp by construction (scores of magnitude ~50): on a few videos a rounding error of 5e-7 in the encoder output moves the logits
     by 1e-4, for the f32 oracle (video 29: 2.1e-4 from float64 on 16 threads, 1.3e-4 on 8) as for the HIP path (video 28: 1.2e-4);
     benchmarks/accuracy_layers.py shows the per-layer error of the two to be equal and the difference to be amplification.

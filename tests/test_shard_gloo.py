@@ -11,7 +11,7 @@ import torch
 import torch.multiprocessing as mp
 
 import cases
-from bigc_hip.shard import allreduce_gradients, gather_results, max_over_ranks, shard_indices
+from bigc_hip.shard import allreduce_gradients, balanced_assignment, gather_results, max_over_ranks, shard_indices, zero_gradients
 
 
 def test_shard_indices_partition():
@@ -25,6 +25,23 @@ def test_shard_indices_partition():
                 assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     assert shard_indices(8, 1, 2) == [4, 5, 6, 7]           # utils/DataParallel.py:80-92
     assert shard_indices(4, 0, 2) == [0, 3] and shard_indices(4, 1, 2) == [1, 2]   # scatter_42 :95-113
+
+
+def test_balanced_assignment_for_inference():
+    """size-balanced, deterministic, a partition; every rank computes it without communicating"""
+    import numpy as np
+    rs = np.random.RandomState(3)
+    for n in (0, 1, 5, 37, 200):
+        costs = rs.randint(100, 5000, size=n).tolist()
+        for world in (1, 2, 3, 8):
+            parts = balanced_assignment(costs, world)
+            assert len(parts) == world and sorted(i for p in parts for i in p) == list(range(n))
+            assert all(p == sorted(p) for p in parts) and parts == balanced_assignment(costs, world)
+            if n >= 4 * world:
+                loads = [sum(costs[i] for i in p) for p in parts]
+                assert max(loads) - min(loads) <= max(costs)                     # LPT: within one item of each other
+    assert balanced_assignment([5, 5, 5, 5], 2) == [[0, 2], [1, 3]]              # equal costs: round-robin in index order
+    assert balanced_assignment([1, 100, 1, 1], 2) == [[1], [0, 2, 3]]
 
 
 def _worker(rank, world, port, q):
@@ -54,6 +71,15 @@ def _worker(rank, world, port, q):
     flat2 = allreduce_gradients(ps, dist)
     assert allreduce_gradients.last_in_place is True and flat2.data_ptr() == buf.data_ptr()
     assert torch.equal(buf, torch.arange(17, dtype=torch.float32) * 1.5) and torch.equal(ps[1].grad, buf[12:])
+    # a batch smaller than the world: the rank without a chunk contributes zeros and the mean is over the ranks that had one
+    # (the reference's DataParallel only makes as many replicas as scatter() gives chunks, utils/DataParallel.py:65-69)
+    qs = [torch.nn.Parameter(torch.zeros(2, 2)), torch.nn.Parameter(torch.zeros(3))]
+    if rank == 0:
+        qs[0].grad, qs[1].grad = torch.full((2, 2), 4.0), torch.full((3,), 2.0)
+    else:
+        zero_gradients(qs)
+    allreduce_gradients(qs, dist, contributing=1)
+    assert torch.equal(qs[0].grad, torch.full((2, 2), 4.0)) and torch.equal(qs[1].grad, torch.full((3,), 2.0))
     if rank == 0:
         full = O.forward_test(sd, cfg, props, topk, variant)
         ok = len(res) == len(full)

@@ -23,6 +23,23 @@ def shard_indices(batch_size, rank, world):
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
+def balanced_assignment(costs, world):
+    """Size-balanced assignment of independent work items (videos) to ``world`` ranks for INFERENCE ("round-robin
+    or size-balanced (by sum L) assignment of videos to 8 processes"; the reference's eval loops go through the videos one by one,
+    tools/eval_vidvrd.py:117-121, tools/eval_vidor.py:218-256).  Longest-processing-time greedy: items by decreasing cost, each to the
+    rank with the smallest load so far (ties: lowest rank; equal costs keep their order) -- deterministic, so every rank computes the
+    same assignment without communicating.  -> list of ``world`` index lists, each in increasing index order."""
+    assert world >= 1
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += float(costs[i])
+    return [sorted(x) for x in out]
+
+
 def gather_results(local_results, local_indices, batch_size, dist=None, dst=0):
     """Reassemble the per-video results of all ranks in batch order on rank ``dst`` (None elsewhere).
     Tensors are moved to the CPU before they are pickled."""
@@ -76,7 +93,15 @@ def flat_gradient_view(params):
     return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, g0.storage_offset(), (off,))
 
 
-def allreduce_gradients(params, dist=None, average=True):
+def zero_gradients(params):
+    """``.grad`` = zeros for every trainable parameter: what a rank whose chunk of the batch is EMPTY (batch smaller than the number of
+    ranks) contributes to the gradient all-reduce -- it still has to take part in the collective."""
+    for p in params:
+        if p.requires_grad:
+            p.grad = torch.zeros_like(p)
+
+
+def allreduce_gradients(params, dist=None, average=True, contributing=None):
     """Data-parallel gradient exchange of the training step: ONE all-reduce over a single flat fp32 buffer
     holding every gradient (RCCL over xGMI on the GPU boxes, gloo in the CPU tests), then the mean over ranks.
 
@@ -85,6 +110,7 @@ def allreduce_gradients(params, dist=None, average=True):
     contiguous chunk of the batch (``shard_indices``), so averaging the per-rank gradients reproduces it.
     The HIP backward already writes every gradient into one flat buffer: that buffer is reduced IN PLACE (no
     concatenation, no copy back); gradients that live in separate tensors are gathered into a flat message first.
+    ``contributing``: number of ranks with a non-empty chunk (``min(batch_size, world)``) when some ranks ran ``zero_gradients``.
     Returns the flat reduced buffer (27.8 M floats = 111 MB for the exp2 model)."""
     params = [p for p in params if p.grad is not None]
     if not params:
@@ -96,8 +122,11 @@ def allreduce_gradients(params, dist=None, average=True):
         flat = torch.cat([p.grad.reshape(-1) for p in params])
     if active:
         dist.all_reduce(flat)
-        if average and dist.get_world_size() > 1:
-            flat /= dist.get_world_size()
+        # mean over the replicas that HAD a chunk (``contributing``; default: all ranks): the reference's DataParallel only
+        # creates as many replicas as scatter() returns chunks (utils/DataParallel.py:65-69) and averages over those
+        n = dist.get_world_size() if contributing is None else int(contributing)
+        if average and n > 1:
+            flat /= n
     if not in_place:
         off = 0
         for p in params:

@@ -94,17 +94,35 @@ def ensure_grounding_files(model_config, out_dir, seed=0):
     return cfg
 
 
-def init_process():
-    """One process per GPU: (rank, world, device, dist-or-None) from the torch.distributed.run environment."""
+def init_process(cuda=None):
+    """One process per GPU: (rank, world, device, dist-or-None) from the torch.distributed.run environment.  Rank r uses GPU
+    LOCAL_RANK (``cuda`` when started without a launcher).  BIGC_DIST_BACKEND=gloo with BIGC_DIST_ONE_GPU=1 puts every rank on GPU 0
+    and exchanges through the host: how the two-rank paths are tested on a one-GPU box (RCCL cannot put two ranks on one device)."""
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    backend = os.environ.get("BIGC_DIST_BACKEND", "nccl")
+    if world == 1 and cuda is not None:
+        local = cuda
+    if os.environ.get("BIGC_DIST_ONE_GPU", "0") == "1":
+        local = 0
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     return rank, world, device, dist
+
+
+def shard_for_inference(data, costs, rank, world):
+    """This rank's videos of an inference run: size-balanced over the ranks (bigc_hip.shard.balanced_assignment).
+    -> (indices into ``data``, the items)"""
+    from bigc_hip.shard import balanced_assignment
+    mine = balanced_assignment(costs, world)[rank]
+    return mine, [data[i] for i in mine]
 
 
 def training_loop(model, data, train_config, output_dir, save_tag, step, rank, world, device, dist, sort_key=None,
@@ -114,7 +132,7 @@ def training_loop(model, data, train_config, output_dir, save_tag, step, rank, w
     (utils/DataParallel.py:80-113), ONE flat gradient all-reduce, ``clip_grad_norm_(5)``, checkpoints in the reference's
     format with the ``module.`` key prefix.  ``step(model, items)`` -> (loss, terms)."""
     import random
-    from bigc_hip.shard import allreduce_gradients, clip_grad_norm_, shard_indices
+    from bigc_hip.shard import allreduce_gradients, clip_grad_norm_, shard_indices, zero_gradients
     batch_size, total_epoch = train_config["batch_size"], epochs or train_config["total_epoch"]
     n_iter = len(data) // batch_size
     milestones = [int(m * len(data) / batch_size) for m in train_config["epoch_lr_milestones"]]
@@ -139,10 +157,14 @@ def training_loop(model, data, train_config, output_dir, save_tag, step, rank, w
                 batch = sorted(batch, key=sort_key)
             mine = [batch[i] for i in shard_indices(len(batch), rank, world)]
             optimizer.zero_grad()
-            loss, terms = step(model, mine)
-            loss = loss.mean()
-            loss.backward()
-            flat = allreduce_gradients(model.parameters(), dist)
+            if mine:
+                loss, terms = step(model, mine)
+                loss = loss.mean()
+                loss.backward()
+            else:                                           # batch smaller than the number of ranks: nothing to compute here, but the
+                zero_gradients(list(model.parameters()))    # collective below needs every rank
+                loss, terms = torch.zeros((), device=device), {}
+            flat = allreduce_gradients(model.parameters(), dist, contributing=min(len(batch), world))
             clip_grad_norm_(model.parameters(), 5, flat=flat)
             optimizer.step()
             scheduler.step()

@@ -3,7 +3,11 @@
 ``--eval_cls_only`` runs the BIG-C classification stage (``evaluate_cls_stage`` :21-138) and saves the per-video results
 pickle; without it the grounding stage re-scores those results (``evaluate_combined`` :141-282, needs
 ``--cls_stage_result_path``); ``--json_results_path`` only evaluates a saved prediction file.
-``--synthetic N`` generates the videos, clip features and ground truth instead of reading a dataset."""
+``--synthetic N`` generates the videos, clip features and ground truth instead of reading a dataset.
+
+Several GPUs: start it under ``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1``: one process per GPU, each
+scoring its size-balanced share of the videos; per-video results are gathered on rank 0, which saves and evaluates them (SURVEY.md
+section 8e; replaces utils/DataParallel.py:45-113 around tools/eval_vidor.py:218-256)."""
 import argparse
 import json
 import os
@@ -12,10 +16,12 @@ import time
 
 import torch
 
-from _common import (ensure_grounding_files, ensure_table_files, load_checkpoint_into, parse_config_py, synthetic_vidor_source)
+from _common import (ensure_grounding_files, ensure_table_files, init_process, load_checkpoint_into, parse_config_py, shard_for_inference,
+                     synthetic_vidor_source)
 
 from bigc_hip import evaluate as E
 from bigc_hip.pipeline import combine_with_grounding
+from bigc_hip.shard import gather_results
 from models import BIG_C_vidor, Base_C, DEBUG
 
 
@@ -49,24 +55,37 @@ def evaluate_cls_stage(cfg_path, ckpt_path=None, save_tag="", output_dir=None, c
     save_tag = "topk{}_{}".format(topk, save_tag)                       # tools/eval_vidor.py:47
     output_dir = output_dir or os.path.dirname(os.path.abspath(cfg_path))
     os.makedirs(output_dir, exist_ok=True)
-    device = torch.device("cuda:%d" % cuda)
+    rank, world, device, dist = init_process(cuda)
+    torch.manual_seed(0)            # without --ckpt_path (synthetic smoke runs) every rank must draw the same initial weights
     model = model_class(ensure_table_files(cfg["model_config"], output_dir), is_train=False).to(device)
     if ckpt_path:
         load_checkpoint_into(model, ckpt_path, device)
     model.eval()
     data = _load_data(cfg, synthetic, n_trajs, None)
     predictions, groundtruth, raw = {}, {}, {}
+    costs = [sum(int(b.shape[0]) for b in p.bboxes_list) if p.num_proposals > 0 else 1 for p, _, _ in data]
+    mine, my_data = shard_for_inference(data, costs, rank, world)
     t0 = time.time()
-    for p, g, _ in data:
+    my_results = []
+    for p, g, _ in my_data:
         with torch.no_grad():
             r = model([p.to(device)], topk=topk)[0]
+        my_results.append(None if r is None else tuple(t.cpu() for t in r))
+    torch.cuda.synchronize()
+    all_results = gather_results(my_results, mine, len(data), dist)
+    if all_results is None:                                 # ranks other than 0 are done
+        dist.destroy_process_group()
+        return None
+    for (p, g, _), r in zip(data, all_results):
         cpu = p.to(torch.device("cpu"))
-        raw[p.video_name] = None if r is None else [t.cpu() for t in r]
+        raw[p.video_name] = None if r is None else list(r)
         # VidOR vocabulary, video name reset to the id the ground-truth JSON is keyed by (utils/evaluate.py:26-38)
-        predictions.update(E.to_eval_format(cpu, None if r is None else tuple(t.cpu() for t in r), dataset_type="vidor"))
+        predictions.update(E.to_eval_format(cpu, r, dataset_type="vidor"))
         if g is not None and synthetic:          # real data is evaluated against datasets/GT_json_for_eval/VidORval_gts.json (_report)
             groundtruth[E.reset_video_name(p.video_name, "vidor")] = E.gt_to_eval_format(g, dataset_type="vidor")
-    print("inference: %d videos in %.2f s" % (len(data), time.time() - t0))
+    if dist is not None:
+        dist.destroy_process_group()
+    print("inference: %d videos in %.2f s on %d GPU(s)" % (len(data), time.time() - t0, world))
     path = os.path.join(output_dir, "VidORval_infer_results_{}.pkl".format(save_tag))
     with open(path, "wb") as f:
         pickle.dump(raw, f)
@@ -80,7 +99,8 @@ def evaluate_combined(cfg_path, ckpt_path, cls_stage_result_path, save_tag="", o
     ic = cfg["inference_config"]
     output_dir = output_dir or os.path.dirname(os.path.abspath(cfg_path))
     os.makedirs(output_dir, exist_ok=True)
-    device = torch.device("cuda:%d" % cuda)
+    rank, world, device, dist = init_process(cuda)
+    torch.manual_seed(0)
     model = DEBUG(ensure_grounding_files(cfg["model_config"], output_dir), is_train=False).to(device)
     if ckpt_path:
         load_checkpoint_into(model, ckpt_path, device)
@@ -106,22 +126,36 @@ def evaluate_combined(cfg_path, ckpt_path, cls_stage_result_path, save_tag="", o
                 print("skipping {}: temporal pooling selected no clip for some (query, bin): all scores are zero".format(p.video_name))
                 n_skipped += 1
                 continue
-            out = (o["pooled_se"], o["bins_probs"], o["bins_mask"].bool())
-            predictions.update(E.to_eval_format(p.to(torch.device("cpu")), combine_with_grounding(res, out, p.video_len), dataset_type="vidor"))
+            out = (o["pooled_se"].cpu(), o["bins_probs"].cpu(), o["bins_mask"].bool().cpu())
+            my_relations.update(E.to_eval_format(p.to(torch.device("cpu")), combine_with_grounding(tuple(t.cpu() for t in res), out, p.video_len),
+                                                 dataset_type="vidor"))
 
-    batch = []
+    # the videos that have classification results, shared out by the work of the grounding stage: queries x clips
+    todo = []
     for p, g, clip in data:
         if g is not None and synthetic:
             groundtruth[E.reset_video_name(p.video_name, "vidor")] = E.gt_to_eval_format(g, dataset_type="vidor")
         res = cls_results.get(p.video_name)
         if res is None or res[0] is None or res[0].shape[0] == 0:
             continue
-        batch.append((p, res, clip))
-        if len(batch) == grd_batch:
-            flush(batch)
-            batch = []
-    flush(batch)
-    print("grounding: %d videos (%d skipped) in %.2f s" % (len(data), n_skipped, time.time() - t0))
+        todo.append((p, res, clip))
+    costs = [int(res[0].shape[0]) * int(clip.shape[0]) for p, res, clip in todo]
+    mine, my_todo = shard_for_inference(todo, costs, rank, world)
+    my_relations = {}
+    for s0 in range(0, len(my_todo), grd_batch):
+        flush(my_todo[s0:s0 + grd_batch])
+    torch.cuda.synchronize()
+    parts = gather_results([(my_relations, n_skipped)], [rank], world, dist)       # one (relations, skipped) pair per rank
+    if parts is None:
+        dist.destroy_process_group()
+        return None
+    n_skipped = 0
+    for rel, sk in parts:
+        predictions.update(rel)
+        n_skipped += sk
+    if dist is not None:
+        dist.destroy_process_group()
+    print("grounding: %d videos (%d skipped) in %.2f s on %d GPU(s)" % (len(data), n_skipped, time.time() - t0, world))
     return _report(groundtruth, predictions, output_dir, "VidORval_predict_relations_aft_grd_{}.json".format(save_tag), save_json, device)
 
 

@@ -4,7 +4,12 @@
 
 Data: with ``--synthetic N`` the videos and their ground truth are generated (no dataset is needed); otherwise
 the reference's own ``dataloaders.dataloader_vidvrd`` must be importable (put the reference checkout AFTER this
-package on PYTHONPATH) and is used exactly as the reference does (tools/eval_vidvrd.py:91-108)."""
+package on PYTHONPATH) and is used exactly as the reference does (tools/eval_vidvrd.py:91-108).
+
+Several GPUs: ``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 eval_vidvrd.py ...`` -- one process per
+GPU, each scoring its size-balanced share of the videos (no data-path collective: videos are independent, SURVEY.md section 8e);
+the per-video results are gathered on rank 0, which converts, saves and evaluates them exactly as the one-process run does
+(replaces the reference's DataParallel wrapper, utils/DataParallel.py:45-113, around tools/eval_vidvrd.py:117-121)."""
 import argparse
 import json
 import os
@@ -14,9 +19,10 @@ import time
 
 import torch
 
-from _common import ensure_table_files, load_checkpoint_into, parse_config_py, synthetic_source
+from _common import ensure_table_files, init_process, load_checkpoint_into, parse_config_py, shard_for_inference, synthetic_source
 
 from bigc_hip import evaluate as E
+from bigc_hip.shard import gather_results
 from models import BIG_C_vidvrd
 
 
@@ -27,8 +33,9 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
     topk = infer_config.get("topk", 10)
     output_dir = output_dir or os.path.dirname(os.path.abspath(cfg_path))
     os.makedirs(output_dir, exist_ok=True)
-    device = torch.device("cuda:%d" % cuda)
+    rank, world, device, dist = init_process(cuda)
     model_config = ensure_table_files(model_config, output_dir)
+    torch.manual_seed(0)            # without --ckpt_path (synthetic smoke runs) every rank must draw the same initial weights
     model = BIG_C_vidvrd(model_config, is_train=False).to(device)
     if ckpt_path:
         load_checkpoint_into(model, ckpt_path, device)
@@ -59,18 +66,27 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
     # does.  Synthetic videos have no JSON: their ground truth comes from the generated graphs, which share the proposals'
     # numbering, so both sides use the standard table.
     pku_names = use_pku and not synthetic
+    # this rank's share of the videos, balanced by the number of feature rows (sum of the tracklet lengths)
+    costs = [sum(int(b.shape[0]) for b in p.bboxes_list) if p.num_proposals > 0 else 1 for p, _ in data]
+    mine, my_data = shard_for_inference(data, costs, rank, world)
     t0 = time.time()
-    for s in range(0, len(data), batch_videos):
-        chunk = data[s:s + batch_videos]
+    my_results = []
+    for s in range(0, len(my_data), batch_videos):
+        chunk = my_data[s:s + batch_videos]
         props = [p.to(device) for p, _ in chunk]
         with torch.no_grad():
             results = model(props, topk=topk)               # one packed HIP forward for the whole chunk
-        for (p, g), r in zip(chunk, results):
-            predictions.update(E.to_eval_format(p.to(torch.device("cpu")), None if r is None else tuple(t.cpu() for t in r),
-                                                dataset_type="vidvrd", use_pku=pku_names))
-            raw[p.video_name] = None if r is None else [t.cpu() for t in r]
-            if g is not None and synthetic:
-                groundtruth[p.video_name] = E.gt_to_eval_format(g, dataset_type="vidvrd")
+        my_results += [None if r is None else tuple(t.cpu() for t in r) for r in results]
+    torch.cuda.synchronize()
+    all_results = gather_results(my_results, mine, len(data), dist)
+    if all_results is None:                                 # ranks other than 0 are done
+        dist.destroy_process_group()
+        return None
+    for (p, g), r in zip(data, all_results):
+        predictions.update(E.to_eval_format(p.to(torch.device("cpu")), r, dataset_type="vidvrd", use_pku=pku_names))
+        raw[p.video_name] = None if r is None else list(r)
+        if g is not None and synthetic:
+            groundtruth[p.video_name] = E.gt_to_eval_format(g, dataset_type="vidvrd")
     infer_s = time.time() - t0
     with open(os.path.join(output_dir, "VidVRDtest_infer_result_%s.pkl" % save_tag), "wb") as f:
         pickle.dump(raw, f)
@@ -82,10 +98,12 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
         with open(gt_json) as f:
             groundtruth = json.load(f)
     mean_ap, rec, prec = E.evaluate(groundtruth, predictions, device=device)     # vIoU overlaps from one batched HIP kernel
-    print("inference: %d videos in %.2f s" % (len(data), infer_s))
+    print("inference: %d videos in %.2f s on %d GPU(s)" % (len(data), infer_s, world))
     print("detection mean AP (used in challenge): {}".format(mean_ap))
     print("detection recall: {}".format(rec))
     print("tagging precision: {}".format(prec))
+    if dist is not None:
+        dist.destroy_process_group()
     return mean_ap, rec, prec
 
 

@@ -59,7 +59,8 @@ def parse():
     ap.add_argument("--recall-steps", type=int, default=400, help="training iterations of the Recall@50 leg (0 = skip the leg)")
     ap.add_argument("--recall-videos", type=int, default=16, help="held-out videos the Recall@50 leg scores (HIP, HIP reduced precision, CPU oracle)")
     ap.add_argument("--legs", default="vidor,grounding,train", help="extra workloads reported in the same line at N=1 ('' = none)")
-    ap.add_argument("--vidor-videos", type=int, default=8)
+    ap.add_argument("--vidor-videos", type=int, default=16, help="videos of the VidOR leg (SURVEY.md 8d: 16 x N = 180, L in [15, 1000))")
+    ap.add_argument("--vidor-oracle-videos", type=int, default=2, help="of those, host-seeded ones that are also run through the CPU oracle (outside the timing)")
     ap.add_argument("--grd-one-video-per-call", action="store_true", help="grounding leg: the reference's one-video forward instead of the batched one")
     return ap.parse_args()
 
@@ -328,7 +329,14 @@ def vidor_grounding_legs(args, lib, device, want_vidor, want_grounding):
     big = build_model(cfg, sd, device, "vidor")
     width = cfg["dim_feat"] + cfg["dim_clsme"]
     nv, ntr, max_len = args.vidor_videos, 180, 1000
-    props = [device_proposal(4321 + v, ntr, width, cfg["num_enti_cats"], (15, max_len), (0, max_len), device) for v in range(nv)]
+    # the first `--vidor-oracle-videos` videos are generated on the HOST (numpy-seeded, SURVEY.md 8d recipe) so that the CPU oracle can
+    # score the very same inputs; the others draw their (large) feature block on the device
+    n_host = min(args.vidor_oracle_videos, nv) if want_vidor else 0
+    host_props = [synthetic_proposal(4321 + v, n_trajs=ntr, feat_width=width, num_enti_cats=cfg["num_enti_cats"], len_range=(15, max_len),
+                                     start_range=(0, max_len)) for v in range(n_host)]
+    import copy
+    props = [copy.deepcopy(p).to(device) for p in host_props] + \
+            [device_proposal(4321 + v, ntr, width, cfg["num_enti_cats"], (15, max_len), (0, max_len), device) for v in range(n_host, nv)]
     video_len = [p.video_len for p in props]
     packed = PackedBatch(props, device)
     pairs, rows = packed.n_pairs(), packed.n_rows
@@ -350,9 +358,45 @@ def vidor_grounding_legs(args, lib, device, want_vidor, want_grounding):
                                       "%d rows, %d pairs per step" % (nv, ntr, max_len, rows, pairs),
                              roofline=gemm_roofline(fam, steps, 1e3 * el_prof / steps),
                              kernel_families_ms_per_step={k: round(v["ms"] / steps, 3) for k, v in fam.items()})
+    if want_vidor and n_host:
+        # the host-seeded videos through the CPU oracle (models/model_0v7.py:434-513 restated), outside the timing: rows identical, logits 1e-4
+        from oracle import bigc_oracle as O
+        Q, P = cfg["num_querys"], cfg["num_pred_cats"]
+        o = out_holder["o"]
+        hip_logits = o["pred_logits"][:n_host * Q].cpu().numpy().reshape(n_host, Q, P)
+        hip_res = big.unpack_results(nv, list(range(nv)), o)[:n_host]
+        torch.set_num_threads(usable_cores())
+        rows_same, rows_all, max_rel, t0 = 0, 0, 0.0, time.perf_counter()
+        with torch.no_grad():
+            for v, p in enumerate(host_props):
+                oo = O.encode2decode(sd, cfg, p, "vidor")
+                want = O.construct_triplet(p, oo["pred_logits"], oo["att"], 3)
+                got = hip_res[v]
+                n_w = 0 if want is None else int(want[0].shape[0])
+                rows_all += n_w
+                if want is not None and got is not None and got[0].shape[0] == n_w:
+                    rows_same += int(((got[0].cpu() == want[0]).all(1) & (got[2].cpu() == want[2]).all(1) & (got[3].cpu() == want[3])).sum())
+                lg = oo["pred_logits"].numpy()
+                max_rel = max(max_rel, float(np.abs(hip_logits[v] - lg).max() / np.abs(lg).max()))
+        legs["vidor"]["oracle_parity"] = dict(videos=n_host, identical_triplet_rows="%d of %d" % (rows_same, rows_all), max_logit_rel=max_rel,
+                                              oracle_seconds=round(time.perf_counter() - t0, 1),
+                                              note="host-seeded videos of this leg (N = 180, L in [15, 1000)) through oracle/bigc_oracle.py, variant vidor")
+        host_props = None
     if not want_grounding:
         return legs
+    # the grounding leg scores clip sequences of T = ceil(video_len / 8) in [60, 400]: its queries come from the classification
+    # stage run (untimed) on videos whose lengths are spread accordingly -- the 16 videos above all have video_len ~ 2000, T ~ 245
+    del packed
+    g_lens = [480, 800, 1100, 1400, 1800, 2200, 2700, 3200]
+    g_props = [device_proposal(5321 + v, ntr, width, cfg["num_enti_cats"], (15, max(30, L // 2)), (0, max(30, L // 2)), device) for v, L in enumerate(g_lens)]
+    video_len = [p.video_len for p in g_props]
+    nv = len(g_props)
+    g_packed = PackedBatch(g_props, device)
+    g_props, g_packed.proposals = None, None
+    out_holder["o"] = big.forward_packed(g_packed, 3)
+    big.counts(out_holder["o"])
     results = big.unpack_results(nv, list(range(nv)), out_holder["o"])
+    del g_packed
     gcfg = dict(configs.CONFIG_G)
     gcfg.setdefault("loss_factor", {})
     gsd = seeded_state_dict(grd_state_shapes(gcfg), 12, 4.0)
@@ -374,7 +418,7 @@ def vidor_grounding_legs(args, lib, device, want_vidor, want_grounding):
         T = -(-video_len[v] // 8)
         clip = torch.from_numpy((0.1 * rs.standard_normal((T, gcfg["dim_feat"]))).astype(np.float32)).to(device)
         jobs.append((clip, quint.to(device), dura.to(device), video_len[v]))
-    del big, packed, out_holder
+    del big, out_holder
     if not jobs:
         return legs
     n_q = sum(int(j[1].shape[0]) for j in jobs)

@@ -216,6 +216,11 @@ void bigc_destroy(bigc_model* m);
 int bigc_set_param(bigc_model* m, const char* key, const float* ptr, int64_t numel);
 /* resolve all keys, build derived device tables (tap-major conv weight); call again after weights change */
 int bigc_finalize(bigc_model* m, void* stream);
+/* This handle's arithmetic mode: exact (1 = every GEMM / attention kernel on the f32 MFMA) and fast (1 = the opt-in reduced-precision
+ * GEMMs), each -1 to follow the process-wide default of bigc_linear_set_exact / bigc_linear_set_fast.  The mode applies to the calls
+ * made THROUGH the handle (bigc_forward, bigc_train_*, bigc_pair_*), on the calling thread only: handles are independent of each
+ * other (one per GPU and thread, as the reference's DataParallel runs its replicas, utils/DataParallel.py:68). */
+int bigc_set_mode(bigc_model* m, int exact, int fast);
 
 /* One packed batch of videos: the device-resident ragged tracklet store. */
 typedef struct {
@@ -379,6 +384,8 @@ int grd_create(const grd_config* cfg, grd_model** out);
 void grd_destroy(grd_model* m);
 int grd_set_param(grd_model* m, const char* key, const float* ptr, int64_t numel);
 int grd_finalize(grd_model* m, void* stream);
+/* as bigc_set_mode, for the grounding scorer's handle (grd_forward*, grd_train_*) */
+int grd_set_mode(grd_model* m, int exact, int fast);
 size_t grd_workspace_bytes(const grd_model* m, int T, int n);
 
 typedef struct {

@@ -44,6 +44,10 @@ BIGC_CASES = {
                         videos=[dict(seed=2290, n_trajs=120, len_range=(15, 400), start_range=(0, 200)),
                                 dict(seed=2291, n_trajs=180, len_range=(15, 120), start_range=(0, 300)),
                                 dict(seed=2292, n_trajs=75, len_range=(30, 250), start_range=(0, 60))]),
+    # ... and a video of LONG tracklets (400 .. 1000 frames: the upper end of the VidOR benchmark leg, bench.py, L in [15, 1000)) through the
+    # real reference, outputs only: conv length 500, 41 k packed rows for one video
+    "bigo_o_long": dict(cfg="CONFIG_O", variant="vidor", wseed=35, topk=3, att_gain=8.0, full=False, slim=True,
+                        videos=[dict(seed=2295, n_trajs=60, len_range=(400, 1000), start_range=(0, 200))]),
     # G3: the VidOR model (models/model_0v7.py): classeme carried in the features / category embedding /
     # no classeme at all, tiny dims with all intermediates; then the exp5 dims with N=32
     "bigo_tiny_clsme": dict(cfg="CONFIG_TINY_O", variant="vidor", wseed=31, topk=3, att_gain=6.0, full=True,

@@ -149,3 +149,72 @@ def test_recall_gate_of_the_fast_mode(cfg_name, n_videos, n_trajs, topk):
     assert float(same.float().mean()) > 0.9                                      # the attention arg-max survives for most queries
     rel = float(((lg_p - lg_f).abs().max(1).values * same).max() / lg_p.abs().max())
     assert 1e-6 < rel < 0.1, rel
+
+
+def test_arithmetic_mode_is_per_handle_and_per_thread():
+    """bigc_set_mode: the arithmetic mode travels with the model handle ("re-entrant per handle"; the reference's
+    DataParallel runs one replica per thread, utils/DataParallel.py:68).  Three models with the same weights in one process -- default,
+    exact f32 MFMA, reduced precision: each gives, bit for bit, what the whole process gives under the corresponding process-wide
+    switch, the process-wide switches stay untouched, and running the three from three threads at once changes nothing."""
+    import threading
+    from test_hip_bigc import build_model
+    from bigc_hip.synthetic import synthetic_proposal
+    lib = _lib.load()
+    cfg = cases.get_cfg("CONFIG_TINY")
+    cfg = dict(cfg, dim_enti=64, dim_pred=64, dim_att=64, dim_ffn=64, dim_feat=128, dim_i3d=32, n_att_head=4, num_querys=24)     # wide enough for the production kernels
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 91, att_gain=3.0)
+    props = [synthetic_proposal(4400 + v, n_trajs=20, feat_width=160, num_enti_cats=cfg["num_enti_cats"], len_range=(6, 40), start_range=(0, 20)).to(DEV)
+             for v in range(6)]
+    packed = PackedBatch(props, DEV)
+    keys = ("pred_logits", "quint", "scores", "n_out")
+
+    def run(model):
+        out = model.forward_packed(packed, 3)
+        model.counts(out)
+        return {k: out[k].clone() for k in keys}
+
+    # references under the process-wide switches
+    base = build_model(cfg, "vidvrd", sd)
+    want = {"default": run(base)}
+    prev = lib.bigc_linear_set_exact(1)
+    try:
+        want["exact"] = run(base)
+    finally:
+        lib.bigc_linear_set_exact(prev)
+    prev = lib.bigc_linear_set_fast(1)
+    try:
+        want["fast"] = run(base)
+    finally:
+        lib.bigc_linear_set_fast(prev)
+    assert not torch.equal(want["default"]["pred_logits"], want["exact"]["pred_logits"])
+    assert not torch.equal(want["default"]["pred_logits"], want["fast"]["pred_logits"])
+    # one handle per mode
+    models = {"default": build_model(cfg, "vidvrd", sd), "exact": build_model(cfg, "vidvrd", sd), "fast": build_model(cfg, "vidvrd", sd)}
+    models["exact"].engine().set_mode(exact=1)
+    models["fast"].engine().set_mode(fast=1)
+    for _ in range(2):
+        for name in ("fast", "default", "exact"):
+            got = run(models[name])
+            assert all(torch.equal(got[k], want[name][k]) for k in keys), (name, {k: float((got[k].float() - want[name][k].float()).abs().max()) for k in keys},
+                                                                          {m: float((got["pred_logits"] - want[m]["pred_logits"]).abs().max()) for m in want})
+    assert lib.bigc_linear_get_exact() == 0 and lib.bigc_linear_get_fast() == 0          # the process-wide switches were never touched
+    # ... and from three threads at once (each call opens its own thread-local scope)
+    results, errors = {}, []
+
+    def worker(name):
+        try:
+            torch.cuda.set_device(0)
+            for _ in range(5):
+                results[name] = run(models[name])
+        except Exception as e:                         # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(n,)) for n in models]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for name in models:
+        assert all(torch.equal(results[name][k], want[name][k]) for k in keys), name

@@ -71,6 +71,8 @@ _SIGS = {
     "bigc_split_rows_f32": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, ctypes.c_long, c_int, c_void_p]),
     "bigc_linear_hr8out_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, ctypes.c_long,
                                        c_int, c_int, c_int, c_int, c_void_p]),
+    "bigc_set_mode": (c_int, [c_void_p, c_int, c_int]),
+    "grd_set_mode": (c_int, [c_void_p, c_int, c_int]),
     "bigc_linear_set_exact": (c_int, [c_int]),
     "bigc_linear_get_exact": (c_int, []),
     "bigc_linear_set_fast": (c_int, [c_int]),

@@ -41,6 +41,7 @@ class BigcEngine(object):
         self._ws = None
         self._train_ws = None
         self.last_flat_grad = None
+        self.mode = (-1, -1)
 
     def __del__(self):
         try:
@@ -100,6 +101,13 @@ class BigcEngine(object):
         self._grad_layout = (layout, flat.data_ptr())
         self.last_flat_grad = flat
         return flat, dict(zip((k for k, _ in trainable), views))
+
+    def set_mode(self, exact=-1, fast=-1):
+        """This handle's arithmetic mode (``bigc_set_mode``): ``exact`` = 1 every GEMM / attention kernel on the f32 MFMA, ``fast`` = 1
+        the opt-in reduced-precision GEMMs, -1 = follow the process-wide default (BIGC_LINEAR_EXACT / BIGC_FAST,
+        ``bigc_linear_set_exact`` / ``bigc_linear_set_fast``).  Other handles are not affected."""
+        _lib.check(self.lib.bigc_set_mode(self.handle, int(exact), int(fast)))
+        self.mode = (int(exact), int(fast))
 
     def set_dropout(self, p, seed):
         """Training-mode dropout of the transformer layers (0 = off); masks are a pure function of (seed, site, index)."""

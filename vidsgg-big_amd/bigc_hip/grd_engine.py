@@ -55,6 +55,10 @@ class GrdEngine(object):
         self._sig = sig
         self._keep = [t for _, t in items]
 
+    def set_mode(self, exact=-1, fast=-1):
+        """this handle's arithmetic mode (``grd_set_mode``), see BigcEngine.set_mode"""
+        _lib.check(self.lib.grd_set_mode(self.handle, int(exact), int(fast)))
+
     def invalidate_weights(self):
         """see BigcEngine.invalidate_weights: needed after writes through ``p.data``, which ``sync_params`` cannot see"""
         self._sig = None

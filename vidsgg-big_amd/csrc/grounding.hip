@@ -788,6 +788,12 @@ extern "C" int grd_set_param(grd_model* m, const char* key, const float* ptr, in
     return BIGC_OK;
 }
 
+extern "C" int grd_set_mode(grd_model* m, int exact, int fast) {
+    BIGC_CHECK_ARG(m && exact >= -1 && exact <= 1 && fast >= -1 && fast <= 1, "grd_set_mode: exact / fast must be -1 (process default), 0 or 1");
+    m->mode_exact = exact; m->mode_fast = fast;
+    return BIGC_OK;
+}
+
 extern "C" int grd_finalize(grd_model* m, void* stream) {
     BIGC_CHECK_ARG(m, "grd_finalize: null model");
     const grd_config& c = m->cfg;
@@ -841,6 +847,7 @@ extern "C" int grd_forward(grd_model* m, void* stream, const float* video_feat, 
                            float score_th, float tiou_th, float bins_th, float nms_th,
                            void* workspace, size_t workspace_bytes, const grd_outputs* out) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     BIGC_CHECK_ARG(m && video_feat && quint && dura && pos_video && pos_query && clip && out, "grd_forward: null pointer");
     BIGC_CHECK_ARG(m->finalized, "grd_forward: call grd_finalize after setting the parameters");
     BIGC_CHECK_ARG(T > 0 && n > 0 && video_len > 0, "grd_forward: T=%d n=%d video_len=%f", T, n, video_len);
@@ -854,6 +861,7 @@ extern "C" int grd_forward_batch(grd_model* m, void* stream, const float* video_
                                  float score_th, float tiou_th, float bins_th, float nms_th,
                                  void* workspace, size_t workspace_bytes, const grd_outputs* out) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     BIGC_CHECK_ARG(m && video_feat && b && quint && dura && pos_video && pos_query && clip && out, "grd_forward_batch: null pointer");
     BIGC_CHECK_ARG(m->finalized, "grd_forward_batch: call grd_finalize after setting the parameters");
     BIGC_CHECK_ARG(b->n_vid > 0 && b->n_query > 0 && b->total_T > 0 && b->total_rows > 0 && b->max_T > 0, "grd_forward_batch: empty batch");

@@ -13,6 +13,7 @@ struct grd_model {
     bool finalized = false;
     float drop_p = 0.f; unsigned int drop_seed = 0;   // training-mode dropout of the QANet layers (grd_set_dropout); 0 = off
     unsigned long long epoch = 0;          // drawn at finalize: scope of the cached split weights
+    int mode_exact = -1, mode_fast = -1;   // this handle's arithmetic mode (grd_set_mode); -1 = the process default
     const float *enti = nullptr, *pred = nullptr;
     Lin video_fc, vq_fc, proj2sim, query_fc, temp_fc;
     Enc video_enc, query_enc, comb_enc;

@@ -526,6 +526,7 @@ extern "C" int grd_train_forward(grd_model* m, void* stream, const float* video_
                                  float video_len, const float* pos_video, const float* pos_query, void* workspace, size_t workspace_bytes,
                                  float* regrs, float* conf, float* cls) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && video_feat && quint && dura && pos_video && pos_query && regrs && conf && cls, "grd_train_forward: null pointer");
     BIGC_CHECK_ARG(m->finalized && T > 0 && T <= 2048 && n > 0 && video_len > 0, "grd_train_forward: bad argument");
@@ -579,6 +580,7 @@ extern "C" int grd_loss_grad(void* stream, const float* regrs, const float* conf
 extern "C" int grd_train_backward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, int n,
                                   void* workspace, size_t workspace_bytes, const float* dregr, const float* dconf, const float* dcls) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && video_feat && quint && dregr && dconf && dcls, "grd_train_backward: null pointer");
     const grd_config& c = m->cfg;

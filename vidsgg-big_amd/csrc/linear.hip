@@ -247,23 +247,31 @@ __global__ __launch_bounds__(256) void linear_k8_kernel(const LinearArgs p) {
 
 }  // namespace
 
-// 0: split-operand f16 MFMA kernel (default), 1: exact f32 MFMA kernel; initialised from BIGC_LINEAR_EXACT
+// Arithmetic mode.  The PROCESS default (0: split-operand f16 MFMA kernels, 1: exact f32 MFMA kernels; initialised from
+// BIGC_LINEAR_EXACT) applies to the raw kernel entry points and to every model that has no mode of its own.  A model handle can
+// carry its own (bigc_set_mode / grd_set_mode): its entry points open a ModeScope, a thread-local override for the duration of the
+// call, so two models in one process -- or one model per thread and GPU, as the reference's DataParallel runs them
+// (utils/DataParallel.py:68) -- do not share the switch.
 static std::atomic<int> g_exact_mode{(getenv("BIGC_LINEAR_EXACT") && atoi(getenv("BIGC_LINEAR_EXACT")) != 0) ? 1 : 0};
+thread_local int bigc_mode_exact_override = -1, bigc_mode_fast_override = -1;
 extern "C" int bigc_linear_set_exact(int exact) { return g_exact_mode.exchange(exact ? 1 : 0); }
-extern "C" int bigc_linear_get_exact(void) { return g_exact_mode.load(); }
+extern "C" int bigc_linear_get_exact(void) { return bigc_mode_exact_override >= 0 ? bigc_mode_exact_override : g_exact_mode.load(); }
 // Opt-in reduced-precision mode of the split-operand GEMM kernels (linear_split.hip, gemm_ps.hip): every operand rounded to one
 // f16 (11-bit mantissa), ONE v_mfma_f32_32x32x16_f16 per product, f32 accumulation -- the "bf16 fast mode" of SURVEY section 7
 // step 10, gated on Recall@50 parity instead of the 1e-4 logit tolerance.  Never the default; initialised from BIGC_FAST.
 static std::atomic<int> g_fast_mode{(getenv("BIGC_FAST") && atoi(getenv("BIGC_FAST")) != 0) ? 1 : 0};
 extern "C" int bigc_linear_set_fast(int fast) { return g_fast_mode.exchange(fast ? 1 : 0); }
-extern "C" int bigc_linear_get_fast(void) { return g_exact_mode.load() ? 0 : g_fast_mode.load(); }
+extern "C" int bigc_linear_get_fast(void) {
+    if (bigc_linear_get_exact()) return 0;
+    return bigc_mode_fast_override >= 0 ? bigc_mode_fast_override : g_fast_mode.load();
+}
 
 int bigc_linear_hr8out(void* stream, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
                        float* C, int ldc, void* Cs, long ldcs, int M, int N, int K, int act, int* range_flag) {
     BIGC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && A && W && Cs, "linear_hr8out: bad argument");
     BIGC_CHECK_ARG(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && N % 8 == 0 && ldcs % 4 == 0 && ((uintptr_t)Cs & 15) == 0 && ((uintptr_t)A & 15) == 0 &&
                    ((uintptr_t)W & 15) == 0, "linear_hr8out: alignment (N=%d must be a multiple of 8)", N);
-    BIGC_CHECK_ARG(g_exact_mode.load() == 0, "linear_hr8out: not available in exact mode");
+    BIGC_CHECK_ARG(bigc_linear_get_exact() == 0, "linear_hr8out: not available in exact mode");
     if (M == 0) return BIGC_OK;
     LinearArgs p;
     p.A = A; p.lda = lda; p.a_idx = nullptr; p.nseg = 1; p.seg_len = K;
@@ -305,7 +313,7 @@ bool bigc_linear_pre8_supported(int N, int K) {
     // K = 8 kernel, but the 64 extra FMAs per staged quad sit in the MFMA-bound loop of a power-limited kernel: the fused GEMM
     // takes 1.2 ms longer (22.17 vs 21.37 ms per step).  Traffic is not what this step waits for.
     static const bool on = getenv("BIGC_PRE8_FUSED") && atoi(getenv("BIGC_PRE8_FUSED")) == 1;
-    return on && g_exact_mode.load() == 0 && K % 32 == 0;
+    return on && bigc_linear_get_exact() == 0 && K % 32 == 0;
 }
 
 int bigc_linear_pre8(void* stream, const float* x8, const float* W0, const float* b0, const float* W, int ldw, const float* bias,
@@ -328,7 +336,7 @@ int bigc_linear_pre8(void* stream, const float* x8, const float* W0, const float
 
 bool bigc_linear_dwsep_supported(int N, int K, int ks) {
     static const bool off = getenv("BIGC_DWSEP_FUSED") && atoi(getenv("BIGC_DWSEP_FUSED")) == 0;
-    return !off && g_exact_mode.load() == 0 && K % 32 == 0 && (ks == 3 || ks == 7);
+    return !off && bigc_linear_get_exact() == 0 && K % 32 == 0 && (ks == 3 || ks == 7);
 }
 
 int bigc_linear_dwsep(void* stream, const float* X, int ldx, const float* dw_w, const float* dw_b, int ks, int T, const int2* row_info,
@@ -371,7 +379,7 @@ extern "C" int bigc_linear_f32(void* stream, const float* A, int lda, const int3
     const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1));
     static const int force_nt = getenv("BIGC_LINEAR_NT") ? atoi(getenv("BIGC_LINEAR_NT")) : 0;
     static const int force_bk = getenv("BIGC_LINEAR_BK") ? atoi(getenv("BIGC_LINEAR_BK")) : 0;
-    const bool exact_only = g_exact_mode.load() != 0;
+    const bool exact_only = bigc_linear_get_exact() != 0;
     p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr; p.zero_row = nullptr;
     // K = 8 with a vector-friendly layout: the store-bound FMA kernel (both modes; exact f32)
     if (K == 8 && !a_idx && N % 4 == 0 && N <= 1024 && 256 % (N / 4) == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 &&

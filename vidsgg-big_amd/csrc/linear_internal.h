@@ -28,6 +28,16 @@ struct LinearArgs {
 // entry points open a StaticWeights scope with the epoch they drew at finalize time; outside such a scope (epoch 0, e.g.
 // the raw bigc_linear_f32 entry point or the transposed weight copies of the backward pass) W is split on every launch.
 extern "C" int bigc_linear_get_fast(void);     // linear.hip: 1 = reduced-precision mode (one f16 MFMA per product)
+// per-call override of the process-wide arithmetic mode (linear.hip): -1 = follow the process default
+extern thread_local int bigc_mode_exact_override, bigc_mode_fast_override;
+struct ModeScope {
+    int pe, pf;
+    ModeScope(int exact, int fast) : pe(bigc_mode_exact_override), pf(bigc_mode_fast_override) {
+        if (exact >= 0) bigc_mode_exact_override = exact;
+        if (fast >= 0) bigc_mode_fast_override = fast;
+    }
+    ~ModeScope() { bigc_mode_exact_override = pe; bigc_mode_fast_override = pf; }
+};
 extern thread_local unsigned long long bigc_static_weights_epoch;
 unsigned long long bigc_next_weights_epoch();
 struct StaticWeights {

@@ -192,6 +192,12 @@ extern "C" int bigc_set_param(bigc_model* m, const char* key, const float* ptr, 
     return BIGC_OK;
 }
 
+extern "C" int bigc_set_mode(bigc_model* m, int exact, int fast) {
+    BIGC_CHECK_ARG(m && exact >= -1 && exact <= 1 && fast >= -1 && fast <= 1, "set_mode: exact / fast must be -1 (process default), 0 or 1");
+    m->mode_exact = exact; m->mode_fast = fast;
+    return BIGC_OK;
+}
+
 extern "C" int bigc_finalize(bigc_model* m, void* stream) {
     BIGC_CHECK_ARG(m, "finalize: null model");
     const bigc_config& c = m->cfg;
@@ -536,6 +542,7 @@ int forward_ps(bigc_model* m, void* stream, const bigc_batch* b, const Work& w, 
 extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                             int topk, const bigc_outputs* out) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     BIGC_CHECK_ARG(m && b && out, "forward: null pointer");
     BIGC_CHECK_ARG(m->finalized, "forward: call bigc_finalize after setting the parameters");
     BIGC_CHECK_ARG(m->cfg.variant != 2, "forward: the pairwise baseline runs through bigc_pair_forward");
@@ -754,6 +761,7 @@ extern "C" size_t bigc_pair_workspace_bytes(const bigc_model* m, const bigc_batc
 extern "C" int bigc_pair_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* vid_pair_off, long n_pairs, void* workspace,
                                  size_t workspace_bytes, float* enti2enco, float* pair_logits) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     BIGC_CHECK_ARG(m && b && vid_pair_off && pair_logits, "pair_forward: null pointer");
     BIGC_CHECK_ARG(m->finalized && m->cfg.variant == 2, "pair_forward: needs a finalized pairwise-baseline model");
     BIGC_CHECK_ARG(b->n_vid > 0 && b->n_trk > 0 && b->n_rows > 0 && b->n_conv > 0 && n_pairs > 0, "pair_forward: empty batch");

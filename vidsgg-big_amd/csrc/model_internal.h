@@ -18,6 +18,7 @@ struct bigc_model {
     bool finalized = false;
     float drop_p = 0.f; unsigned int drop_seed = 0;   // training-mode dropout (bigc_set_dropout); 0 = off
     unsigned long long epoch = 0;          // drawn at finalize: scope of the cached split weights (linear_internal.h)
+    int mode_exact = -1, mode_fast = -1;   // this handle's arithmetic mode (bigc_set_mode); -1 = the process default
     // resolved
     const float *emb = nullptr, *pos = nullptr, *qinit = nullptr, *bias_matrix = nullptr;
     Lin feat0, feat2, bbox0, bbox2, conv, enco0, enco2, i3d, head0, head2;

@@ -289,6 +289,7 @@ static int open_arena(const bigc_model* m, const bigc_batch* b, void* workspace,
 extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                                   float* pred_logits, float* att_out) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && b && pred_logits && att_out, "train_forward: null pointer");
     BIGC_CHECK_ARG(m->finalized, "train_forward: call bigc_finalize first");
@@ -417,6 +418,7 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
 extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                                    const float* dlogits, int ldg, const float* datt) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && b && dlogits && datt, "train_backward: null pointer");
     const bigc_config& c = m->cfg;
@@ -637,6 +639,7 @@ int open_pair_arena(const bigc_model* m, const bigc_batch* b, long n_pairs, void
 extern "C" int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
                                        size_t workspace_bytes, float* pair_logits) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && b && pair_so && pair_logits, "pair_train_forward: null pointer");
     BIGC_CHECK_ARG(m->finalized && m->cfg.variant == 2, "pair_train_forward: needs a finalized pairwise-baseline model");
@@ -673,6 +676,7 @@ extern "C" int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_b
 extern "C" int bigc_pair_train_backward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
                                         size_t workspace_bytes, const float* dlogits, int ldg) {
     StaticWeights static_weights(m ? m->epoch : 0);
+    ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     SplitRecorder recorder(m ? &m->train_jobs : nullptr);
     BIGC_CHECK_ARG(m && b && pair_so && dlogits, "pair_train_backward: null pointer");
     BIGC_CHECK_ARG(m->finalized && m->cfg.variant == 2 && n_pairs > 0, "pair_train_backward: needs a finalized pairwise-baseline model");

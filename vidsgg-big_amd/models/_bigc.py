@@ -218,13 +218,14 @@ class BigcBase(nn.Module):
         try:
             self.counts(out)
         except OverflowError:
-            lib = self.engine().lib
-            prev = lib.bigc_linear_set_exact(1)
+            eng = self.engine()
+            prev = eng.mode
+            eng.set_mode(1, prev[1])                   # THIS handle only: other models / threads of the process keep their mode
             try:
                 out = self.forward_packed(packed, topk)
                 self.counts(out)
             finally:
-                lib.bigc_linear_set_exact(prev)
+                eng.set_mode(*prev)
         return out
 
     @staticmethod

@@ -94,36 +94,3 @@ class Base_C(nn.Module):
         terms = HipPairTrainStep.apply(self, packed, list(pos_id_list), list(label_list), *params)
         loss_dict = {"cls": terms[0]}
         return torch.stack(list(loss_dict.values())).sum(), loss_dict
-
-    def construct_triplet(self, proposal, pred_logits):
-        """(:306-395) with torch index operations on the device: the restatement the HIP kernels of csrc/pair_triplet.hip (used by
-        ``forward``) are tested against; not on the product path."""
-        dev = pred_logits.device
-        n, k = proposal.num_proposals, self.topk
-        probs = torch.softmax(pred_logits, dim=-1)
-        scores, cats = torch.topk(probs, k, dim=-1)
-        scores, cats = scores.reshape(-1), cats.reshape(-1)
-        dura = proposal.traj_durations.to(dev)
-        idx = torch.arange(n, device=dev)
-        so = torch.stack(torch.meshgrid(idx, idx, indexing="ij"), -1).reshape(-1, 2)
-        so = so[so[:, 0] != so[:, 1]]                                           # trajid2pairid (:105-112)
-        so = torch.repeat_interleave(so, k, dim=0)
-        s_d, o_d = dura[so[:, 0]], dura[so[:, 1]]
-        start, end = torch.maximum(s_d[:, 0], o_d[:, 0]), torch.minimum(s_d[:, 1], o_d[:, 1])
-        pos = end >= start                                                      # closed intervals (utils/utils_func.py:347-373)
-        if int(pos.sum()) == 0:
-            return None
-        so, scores, cats, start, end = so[pos], scores[pos], cats[pos], start[pos], end[pos]
-        enti_cat, enti_score = proposal.cat_ids.to(dev), proposal.scores.to(dev)
-        quint = torch.cat([cats[:, None], enti_cat[so], so], dim=-1)            # [pred, s_cat, o_cat, s_tid, o_tid]
-        trip = torch.stack([scores, enti_score[so[:, 0]], enti_score[so[:, 1]]], -1)
-        # every (pair, predicate) occurs once: torch.unique(dim=0) only sorts the rows lexicographically (:349-358)
-        key = (((quint[:, 0] * 512 + quint[:, 1]) * 512 + quint[:, 2]) * 1024 + quint[:, 3]) * 1024 + quint[:, 4]
-        order = torch.argsort(key)
-        quint, trip, inters = quint[order], trip[order], torch.stack([start, end], -1)[order]
-        mask = quint[:, 0] != 0
-        quint, trip, inters = quint[mask], trip[mask], inters[mask]
-        if self.rt_triplets_topk > 0:
-            top = trip.mean(dim=-1).argsort(descending=True)[:self.rt_triplets_topk]
-            quint, trip, inters = quint[top], trip[top], inters[top]
-        return quint, trip, inters, torch.empty(size=(trip.shape[0],))

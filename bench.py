@@ -581,9 +581,27 @@ def train_leg(args, lib, device):
         steps = 8
         el, el_prof, fam = timed_with_events(lib, step, 4, steps)
         kern_ms = sum(v["ms"] for v in fam.values()) / steps       # the library's kernels (HIP events); torch's Adam / clip kernels come on top
+        # roofline of the step's GEMMs: forward + dX = dY W (family linear_f32) and dW = dY^T X (family linear_dw), both on the split-operand
+        # f16 MFMAs (three per product): algorithmic flops / HIP-event time against the dense f16 peak / 3
+        peak_f = F32_MFMA_PEAK_TFLOPS if EXACT_F32 else F16_MFMA_PEAK_TFLOPS / 3
+        roof = gemm_roofline(fam, steps, 1e3 * el_prof / steps)
+        dw = fam.get("linear_dw")
+        if roof is not None and dw:
+            lin = fam["linear_f32"]
+            both_fl, both_ms = lin["flops"] + dw["flops"], lin["ms"] + dw["ms"]
+            roof = dict(bound="mfma", achieved=round(both_fl / both_ms / 1e9, 2), peak=round(peak_f, 1), unit="TFLOP/s",
+                        frac=round(both_fl / both_ms / 1e9 / peak_f, 4), kernel="forward + dX + dW GEMMs of the training step (split-operand f16 MFMAs)",
+                        forward_and_dx=dict(tflops=roof["achieved"] if roof["unit"] == "TFLOP/s" else roof.get("tflops"), frac=round(lin["flops"] / lin["ms"] / 1e9 / peak_f, 4),
+                                            launches_per_step=lin["launches"] // steps, gflop_per_step=round(lin["flops"] / steps / 1e9, 1),
+                                            ms_per_step=round(lin["ms"] / steps, 3)),
+                        dw=dict(tflops=round(dw["flops"] / dw["ms"] / 1e9, 2), frac=round(dw["flops"] / dw["ms"] / 1e9 / peak_f, 4),
+                                launches_per_step=dw["launches"] // steps, gflop_per_step=round(dw["flops"] / steps / 1e9, 1), ms_per_step=round(dw["ms"] / steps, 3)),
+                        share_of_step=round(both_ms / steps / (1e3 * el_prof / steps), 3), traffic=None,
+                        measured="HIP events around each launch over %d instrumented steps" % steps)
         out["videos_%d" % nvid] = dict(value=round(pairs * steps / el, 1), unit="pairs/s", ms_per_step=round(1e3 * el / steps, 3), steps=steps,
                                        kernel_ms_per_step=round(kern_ms, 3), kernel_share_of_step=round(kern_ms / (1e3 * el / steps), 3),
-                                       instrumented_ms_per_step=round(1e3 * el_prof / steps, 3))
+                                       instrumented_ms_per_step=round(1e3 * el_prof / steps, 3), roofline=roof,
+                                       kernel_families_ms_per_step={k: round(v["ms"] / steps, 3) for k, v in fam.items()})
         del model, props, gts, opt
         torch.cuda.empty_cache()
     out["workload"] = ("BIG-C model_0v10 training step (exp2 dims, dropout on), synthetic videos x N=%d: zero_grad + forward + host Hungarian + "

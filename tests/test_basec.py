@@ -205,8 +205,8 @@ def test_basec_train_every_gradient_matches_oracle_and_optimizer_step_runs():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_trajs,rt", [(180, 200), (180, -1), (37, 2048), (2, 5)])
-def test_pair_triplets_kernel_vs_torch_restatement_at_vidor_size(n_trajs, rt):
+@pytest.mark.parametrize("n_trajs,rt,score_shift", [(180, 200, 0.0), (180, -1, 0.0), (37, 2048, 0.0), (2, 5, 0.0), (90, 150, -0.9), (60, 40, -3.0)])
+def test_pair_triplets_kernel_vs_torch_restatement_at_vidor_size(n_trajs, rt, score_shift):
     """bigc_pair_triplets on random pair logits of a VidOR-sized video (N = 180: 32 220 pairs, 96 660 candidates, far beyond the
     LDS sort of triplet.hip) against the torch restatement of Base_C.construct_triplet (:314-395), which the reference goldens pin
     at N <= 24: rows, order, scores, spans -- with and without the rt_triplets_topk cut"""
@@ -219,6 +219,8 @@ def test_pair_triplets_kernel_vs_torch_restatement_at_vidor_size(n_trajs, rt):
     model.topk = topk
     props = [synthetic_proposal(777, n_trajs=n_trajs, feat_width=36, num_enti_cats=cfg["num_enti_cats"], len_range=(5, 60), start_range=(0, 120)),
              synthetic_proposal(778, n_trajs=5, feat_width=36, num_enti_cats=cfg["num_enti_cats"], len_range=(5, 20), start_range=(0, 10))]
+    for p in props:            # score_shift < 0: tracklet scores (and with them the mean scores of the top-R cut) of both signs, e.g. log-scores
+        p.scores = p.scores + score_shift
     packed = PackedBatch([p.to("cuda:0") for p in props], "cuda:0")
     n = np.diff(packed.vid_trk_off_host)
     off = np.concatenate([[0], np.cumsum(n * (n - 1))])
@@ -235,3 +237,28 @@ def test_pair_triplets_kernel_vs_torch_restatement_at_vidor_size(n_trajs, rt):
         assert torch.equal(q.cpu(), want[0].cpu()), "video %d quintuples" % v
         assert torch.equal(d.cpu(), want[2].cpu())
         assert float((s.cpu() - want[1].cpu()).abs().max()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_pair_triplets_none_only_when_no_pair_overlaps():
+    """models/model_pairwise_baseline.py:373-395: None when no ordered pair of the video overlaps in time; a video whose every row is
+    the background predicate gives a tuple of EMPTY tensors"""
+    from bigc_hip.packed import PackedBatch
+    from bigc_hip.synthetic import synthetic_proposal
+    cfg, sd, _, _ = cases.make_basec_case("basec_tiny")
+    model = _build(dict(cfg, rt_triplets_topk=-1), sd)
+    P = cfg["num_pred_cats"]
+    model.topk = 1
+    overlapping = synthetic_proposal(901, n_trajs=4, feat_width=36, num_enti_cats=cfg["num_enti_cats"], len_range=(20, 30), start_range=(0, 5))
+    disjoint = synthetic_proposal(902, n_trajs=3, feat_width=36, num_enti_cats=cfg["num_enti_cats"], len_range=(5, 6), start_range=(0, 1))
+    disjoint.traj_durations = torch.tensor([[0, 4], [10, 14], [20, 24]])
+    props = [overlapping, disjoint]
+    packed = PackedBatch([p.to("cuda:0") for p in props], "cuda:0")
+    n = np.diff(packed.vid_trk_off_host)
+    off = np.concatenate([[0], np.cumsum(n * (n - 1))])
+    logits = torch.full((int(off[-1]), P), -5.0, device="cuda:0")
+    logits[:, 0] = 5.0                                       # the background predicate wins every pair: with topk = 1 every row is dropped
+    out = {"vid_pair_off": off, "pair_logits": logits, "_keepalive": torch.from_numpy(off.astype(np.int32)).to("cuda:0")}
+    got = model.engine().pair_triplets(packed, out, 1, -1)
+    assert got[1] is None
+    assert got[0] is not None and got[0][0].shape == (0, 5) and got[0][1].shape == (0, 3) and got[0][2].shape == (0, 2)

@@ -247,7 +247,7 @@ class _Staging(object):
             return None
         if self.off + n_al > self.half:          # move to the other half once the copies that read it last time have run
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(torch.cuda.current_stream(device))          # the stream of the TARGET device (the copies below are queued there)
             self.events[self.cur] = ev
             self.cur ^= 1
             self.off = 0
@@ -257,7 +257,8 @@ class _Staging(object):
         view = self.buf[start:start + n].view(t.dtype).view(t.shape)
         view.copy_(t)
         self.off += n_al
-        return view.to(device, non_blocking=True)
+        with torch.cuda.device(device):               # the copy goes to the current stream of `device`, whatever the caller's current device is
+            return view.to(device, non_blocking=True)
 
     def download_buffer(self, shape, dtype, slot="default"):
         """a pinned host tensor for device-to-host copies whose result the host consumes before the slot's next use"""
@@ -310,8 +311,9 @@ def download(t, slot="default"):
     if os.environ.get("BIGC_DOWNLOAD_BLOCKING", "0") == "1":
         return t.cpu()
     host = staging(t.device).download_buffer(t.shape, t.dtype, slot)
-    host.copy_(t, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
+    with torch.cuda.device(t.device):                 # copy and event on the current stream of the TENSOR's device, not of the caller's
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(t.device))
     ev.synchronize()
     return host

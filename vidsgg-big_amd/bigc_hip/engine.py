@@ -217,10 +217,21 @@ class BigcEngine(object):
                                                ws.numel(), quint.data_ptr(), scores.data_ptr(), dura.data_ptr(), counts[0].data_ptr(), R,
                                                qt.data_ptr(), st.data_ptr(), dt.data_ptr(), counts[1].data_ptr()))
         cnt = counts.cpu().numpy()
+        # The reference returns None only when NO ordered pair of the video overlaps in time (models/model_pairwise_baseline.py:373-377);
+        # a video whose every surviving row is the background predicate gets a tuple of EMPTY tensors (:379-395).
+        dura_h = packed.trk_dura.cpu().numpy()
+        voff = packed.vid_trk_off_host
         res = []
         for v in range(B):
             if cnt[0, v] == 0:
-                res.append(None)
+                d = dura_h[voff[v]:voff[v + 1]]
+                ov = (np.maximum(d[:, None, 0], d[None, :, 0]) <= np.minimum(d[:, None, 1], d[None, :, 1]))
+                np.fill_diagonal(ov, False)
+                if not ov.any():
+                    res.append(None)
+                else:
+                    res.append((torch.empty((0, 5), dtype=torch.long, device=dev), torch.empty((0, 3), dtype=torch.float32, device=dev),
+                                torch.empty((0, 2), dtype=torch.long, device=dev)))
             elif R:
                 m = int(cnt[1, v])
                 res.append((qt[v, :m].long(), st[v, :m], dt[v, :m].long()))

@@ -69,7 +69,7 @@ def viou_tables_launch(lib, packed, gt_graph_list):
     host = _lib.staging(dev).download_buffer(out.shape, torch.float32, "viou")
     host.copy_(out, non_blocking=True)
     done = torch.cuda.Event()
-    done.record()
+    done.record(torch.cuda.current_stream(dev))
     return host, done, n_traj, (out, gt_boxes, gt_row_off, gt_dura, gt_traj_off)
 
 

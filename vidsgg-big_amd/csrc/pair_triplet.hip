@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(const float* __restrict_
 // rt_triplets_topk: the R rows with the largest mean score, in descending order (ties: lower row first)
 constexpr int SEL_MAX = 2048;
 __device__ __forceinline__ uint32_t mean_key(const float* sc) {
-    return __float_as_uint((sc[0] + sc[1] + sc[2]) / 3.0f);        // positive floats order like their bit patterns
+    // an unsigned key that orders like the float over ALL floats (tracklet scores may be negative, e.g. log-scores): positive values
+    // get their sign bit set, negative ones are complemented; -0.0 is folded into +0.0 first (they compare equal as floats)
+    const uint32_t b = __float_as_uint((sc[0] + sc[1] + sc[2]) / 3.0f + 0.0f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 __global__ __launch_bounds__(1024) void pair_select_kernel(const int32_t* __restrict__ vid_pair_off, int topk, const int32_t* __restrict__ n_rows,
                                                            int R, const int32_t* __restrict__ quint, const float* __restrict__ scores,

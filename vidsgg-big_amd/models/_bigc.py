@@ -91,6 +91,7 @@ class BigcBase(nn.Module):
         self._reset_parameters()
         self._engine = None
         object.__setattr__(self, "_state_items", None)
+        object.__setattr__(self, "_tree_sig", ([], []))
 
     # ---- hooks for the two variants -----------------------------------------------------
     def _build_embeddings(self, c):
@@ -128,10 +129,15 @@ class BigcBase(nn.Module):
         # registers up to 192; csrc/model.hip, csrc/attention.hip): videos are therefore only batched with videos of their own class,
         # so that a video's result does not depend on its company -- it is, bit for bit, what the video gives alone (the reference
         # scores one video at a time, models/model_0v10.py:376).
+        # (class limits follow the kernels' own: 64 tracklets = the fused role attention; then the attention core's single-pass limit,
+        # csrc/attention.hip: 192 keys at head_dim 64 / 32, 256 at head_dim 16 / 8.  A PackedBatch given directly is run as ONE batch:
+        # whoever packs videos of different classes together gets, for the smaller ones, the larger class's kernels.)
+        hd = self.config["dim_enti"] // self.config["n_att_head"]
+        single_pass = 256 if hd in (8, 16) else 192
         classes = {}
         for i in keep:
             n = proposal_list[i].num_proposals
-            classes.setdefault(0 if n <= 64 else (1 if n <= 192 else 2), []).append(i)
+            classes.setdefault(0 if n <= 64 else (1 if n <= single_pass else 2), []).append(i)
         res = [None] * len(proposal_list)
         for idx in classes.values():
             packed = PackedBatch([proposal_list[i] for i in idx], device)
@@ -171,10 +177,34 @@ class BigcBase(nn.Module):
         a fused optimizer updates the parameters without bumping it)"""
         if self._engine is None:
             self._engine = BigcEngine(self.config, self.variant)
-        if self._state_items is None:      # (the walk over ~300 parameters costs 0.4 ms: kept until the module tree changes)
+        if self._state_items is None or not self._tree_unchanged():
+            # (the state_dict walk over ~300 tensors costs 0.3 ms: kept while the module tree is what it was)
             self._state_items = list(self.state_dict(keep_vars=True).items())
+            # what the cheap check below looks at: every module's place in its parent, every tensor's place in its module.  A nested
+            # replacement -- ``load_state_dict(assign=True)``, ``model.encoder_layers[0].float()``, ``layer.fc = nn.Linear(..)``, a
+            # parametrization -- changes one of these identities without passing through this class's __setattr__ / _apply.
+            mods, tens = [], []
+            for name, mod in self.named_modules():
+                for cname, child in mod._modules.items():
+                    mods.append((mod._modules, cname, child))
+                for tname, t in mod._parameters.items():
+                    tens.append((mod._parameters, tname, t))
+                for tname, t in mod._buffers.items():
+                    tens.append((mod._buffers, tname, t))
+            object.__setattr__(self, "_tree_sig", (mods, tens))
         self._engine.sync_params(self._state_items, force)
         return self._engine
+
+    def _tree_unchanged(self):
+        """every module still sits where it sat in its parent and every parameter / buffer is still the same object (~40 us)"""
+        mods, tens = self._tree_sig
+        for d, k, v in mods:
+            if d.get(k) is not v:
+                return False
+        for d, k, v in tens:
+            if d.get(k) is not v:
+                return False
+        return True
 
     def __setattr__(self, name, value):
         if name != "_state_items" and isinstance(value, (torch.Tensor, nn.Module)):

@@ -103,6 +103,10 @@ int bigc_layernorm_f32(void* stream, const float* x, const float* gamma, const f
  *   norm3 of layer i feeding `q = k = query + pos` of layer i + 1, :181).  add == NULL: plain LayerNorm (y_plain must be NULL). */
 int bigc_layernorm_add_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y, int rows, int d,
                            float eps, const float* add, int period, float* y_plain);
+/* nn.LayerNorm whose result the next GEMM reads in the split form "hr8" of bigc_gemm_ps: y (f32, may be NULL) and ys (hr8 rows of d * 4
+ * bytes at pitch ldys_bytes); d in {64, 128, 256, 512}; an element with |y| >= 4096 sets *range_flag */
+int bigc_layernorm_hr8_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y, void* ys, long ldys_bytes,
+                           int rows, int d, float eps, int* range_flag);
 
 /* y[r, :] = x[r, :] + p[r % period, :]   (query + pos_embedding broadcast over the videos of a batch,
  *   models/model_0v10.py:182,189); x == NULL means zeros (tiles pred_query_init over the batch, :465) */

@@ -567,7 +567,11 @@ template <int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW) void mha_core_lds16_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                                  const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
                                                                  const int32_t* __restrict__ off, int n_head, float scale,
-                                                                 float* __restrict__ lse, const DropSpec drop, int* __restrict__ flag, int run_id) {
+                                                                 float* __restrict__ lse, const DropSpec drop, int* __restrict__ flag, int run_id,
+                                                                 unsigned char* __restrict__ os = nullptr, long ldos = 0, int* __restrict__ range_flag = nullptr) {
+    // os != nullptr: the output goes out in the split form "hr8" of csrc/gemm_ps.hip (row pitch ldos bytes) INSTEAD of f32 -- its only
+    // reader is the out_proj GEMM -- and an operand or result outside the form's range raises *range_flag (the step is then redone on
+    // the exact path, there is no f32 fallback launch behind this one)
     constexpr int HD = 64, NK = 16 * NW, NKT = NW, VS = 2 * NK + 16, NTH = 64 * NW;
     constexpr int KP = NK * 128, VP = HD * VS;
     constexpr int KUNITS = NK * 8 / NTH, VGROUPS = NK / 8 / NW;          // = 2, 2
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(64 * NW) void mha_core_lds16_kernel(const float* __
             split8(x, qh[st], qr[st], chk, amax);
         }
     }
-    if (!(fabsf(chk) < INFINITY) || amax >= 32768.0f) atomicMax(flag, run_id);
+    if (!(fabsf(chk) < INFINITY) || amax >= 32768.0f) { atomicMax(flag, run_id); if (range_flag) atomicOr(range_flag, 1); }
     __syncthreads();
     if (!active) return;
 
@@ -718,6 +722,25 @@ __global__ __launch_bounds__(64 * NW) void mha_core_lds16_kernel(const float* __
                 o1[t] = MFMA_H16(pr, vh, o1[t]);
             }
         }
+    }
+    if (os) {
+        bool oob = false;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = qt * 16 + 4 * g + r, col = h * HD + 16 * t + l15;
+                const float X = (o0[t][r] + o1[t][r] * RI) * 8.0f;              // PS_ACT_EXP = 3
+                const _Float16 hh = (_Float16)X, rr = (_Float16)(X - (float)hh);
+                if (row < nq) {
+                    unsigned char* gp = os + (size_t)(q0 + row) * ldos + (size_t)(col >> 3) * 32 + (col & 7) * 2;
+                    *(_Float16*)gp = hh;
+                    *(_Float16*)(gp + 16) = rr;
+                    oob = oob || !(fabsf(X) < 32768.f);
+                }
+            }
+        if (oob && range_flag) atomicOr(range_flag, 1);
+        return;
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -981,7 +1004,10 @@ __global__ __launch_bounds__(768) void role_fused_lds16_kernel(const float* __re
                                                                int n_vid, int nq, int half, int d, float scale,
                                                                int* __restrict__ flag, int run_id,
                                                                long role_stride, const float* __restrict__ vbias0, const float* __restrict__ vbias1, int relu,
-                                                               long out_role_stride, int ldval) {
+                                                               long out_role_stride, int ldval,
+                                                               unsigned char* __restrict__ vals_s = nullptr, long ldvs = 0, int* __restrict__ range_flag = nullptr) {
+    // vals_s != nullptr: the values go out in the split form "hr8" (row pitch ldvs bytes, role r at byte offset 4 r out_role_stride)
+    // INSTEAD of f32 -- their only reader is the GEMM of the second role-wise linears -- see mha_core_lds16_kernel
     constexpr int NTH = 768, PLANE = 32768, DC = 256, NU = 3;      // 2048 staging units of 8 floats over 768 threads
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE];
     unsigned char* const Ph = smem;
@@ -997,6 +1023,7 @@ __global__ __launch_bounds__(768) void role_fused_lds16_kernel(const float* __re
     const int per_row = half / 8, n_eunits = 64 * per_row, row_bytes = 2 * half, n_step = half / 32;
     const float* qp = p2a + (size_t)(vid * nq + qrow) * ldp + 8 * g;
     float amax = 0.f;
+    bool hr_oob = false;
     float raw[NU][8];
 
     auto e_load = [&](int r) {
@@ -1184,6 +1211,24 @@ __global__ __launch_bounds__(768) void role_fused_lds16_kernel(const float* __re
                     }
                     const int col = dc * DC + dl;
                     const float bv = vbias0 ? (r ? vbias1 : vbias0)[col] : 0.f;
+                    if (vals_s) {
+                        const int ocol = (int)(r * out_role_stride) + col;            // (the two roles side by side in one row)
+                        unsigned char* gp = vals_s + (size_t)vid * nq * ldvs + (size_t)(ocol >> 3) * 32 + (ocol & 7) * 2;
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int row = qt * 16 + 4 * g + rg;
+                            float ov = (c0[rg] + c1[rg] * RI) + bv;
+                            if (relu) ov = fmaxf(ov, 0.f);
+                            const float X = ov * 8.0f;
+                            const _Float16 hh = (_Float16)X, rr = (_Float16)(X - (float)hh);
+                            if (row < nq) {
+                                *(_Float16*)(gp + (size_t)row * ldvs) = hh;
+                                *(_Float16*)(gp + (size_t)row * ldvs + 16) = rr;
+                                hr_oob = hr_oob || !(fabsf(X) < 32768.f);
+                            }
+                        }
+                        continue;
+                    }
                     float* op = values + r * out_role_stride + (size_t)vid * nq * ldval + col;
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
@@ -1197,10 +1242,21 @@ __global__ __launch_bounds__(768) void role_fused_lds16_kernel(const float* __re
         }
         __syncthreads();
     }
-    if (amax >= 32768.0f) atomicMax(flag, run_id);
+    if (amax >= 32768.0f) { atomicMax(flag, run_id); if (range_flag) atomicOr(range_flag, 1); }
+    if (hr_oob && range_flag) atomicOr(range_flag, 1);
 }
 
 }  // namespace
+
+#include <atomic>
+static std::atomic<int> g_hr8_run{0};
+// the per-launch flag word the kernels raise for the f32 fallback of the f32-output path: the hr8-output launches have no fallback
+// (they raise the step's range flag instead) and share one word that nobody reads
+static int* hr8_dummy_flag() {
+    static int* p = nullptr;
+    if (!p && (hipMalloc((void**)&p, sizeof(int)) != hipSuccess || hipMemset(p, 0, sizeof(int)) != hipSuccess)) p = nullptr;
+    return p;
+}
 
 int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc, float* att,
                              float* values, const int32_t* e_off, int n_vid, int nq, int n_qt, int half, int d, float scale, int grid,
@@ -1259,5 +1315,37 @@ int bigc_mha_core_h16_launch(hipStream_t s, const float* q, int ldq, const float
     else if (nkt <= 4) hipLaunchKernelGGL((mha_core_h_kernel<4, 16>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
     else if (nkt <= 8) hipLaunchKernelGGL((mha_core_h_kernel<8, 16>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
     else return 0;
+    return 1;
+}
+
+// Self-attention core (head_dim 64, at most 192 keys per sequence) with the output in the split form "hr8" for the out_proj GEMM on
+// pre-split operands; returns 0 when the shape is outside what the LDS kernel covers (the caller then uses the f32 path)
+int bigc_mha_core_hr8_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, void* os, long ldos,
+                             const int32_t* q_off, int n_seq, int max_q, int n_head, int hd, int* range_flag) {
+    const int n_qt = (max_q + 31) / 32;
+    if (hd != 64 || n_qt > 6 || n_seq <= 0 || !os || ldos % 16 != 0) return 0;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int run_id = g_hr8_run.fetch_add(1, std::memory_order_relaxed) + 1;
+    int* flag = hr8_dummy_flag();
+    if (!flag) return 0;
+    DropSpec drop = make_drop(0.f, 0, 0);
+#define LAUNCH_L16H(NW) hipLaunchKernelGGL((mha_core_lds16_kernel<NW, false>), dim3(n_seq * n_head), dim3(64 * NW), 0, s, q, ldq, k, ldk, v, ldv, (float*)nullptr, 0, q_off, n_head, scale, (float*)nullptr, drop, flag, run_id, (unsigned char*)os, ldos, range_flag)
+    if (n_qt <= 2) LAUNCH_L16H(4); else LAUNCH_L16H(12);
+#undef LAUNCH_L16H
+    return 1;
+}
+
+// role_fused_lds16_kernel in its projected form (bigc_role_fused_proj_f32) with the values in the split form; returns 0 if the shape
+// is outside the kernel's
+int bigc_role_fused_proj_hr8_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* rhs, int ldrhs, long role_stride,
+                                    const float* vbias0, const float* vbias1, int relu, float* att, void* vals_s, long ldvs, long out_role_stride,
+                                    const int32_t* e_off, int n_vid, int nq, int max_trk, int half, int d, float scale, int* range_flag) {
+    const int n_qt = (nq + 31) / 32;
+    if (max_trk > 64 || n_qt > 6 || half > 256 || half % 128 != 0 || d % 32 != 0 || !vals_s || ldvs % 16 != 0 || n_vid <= 0) return 0;
+    const int run_id = g_hr8_run.fetch_add(1, std::memory_order_relaxed) + 1;
+    int* flag = hr8_dummy_flag();
+    if (!flag) return 0;
+    hipLaunchKernelGGL(role_fused_lds16_kernel, dim3(n_vid), dim3(768), 0, s, p2a, ldp, e2a, lde, rhs, ldrhs, att, (float*)nullptr, e_off, n_vid, nq, half, d,
+                       scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, 0, (unsigned char*)vals_s, ldvs, range_flag);
     return 1;
 }

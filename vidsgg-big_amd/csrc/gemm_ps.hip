@@ -137,6 +137,7 @@ struct PsArgs {
     const unsigned char* Ws; long ldw;                // hr8 weights (N, K), pitch in bytes
     const unsigned* whdr; int wbad_id;                // header of the split weight (bad id, max bits, 2^-Ew, 2^Ew)
     const float* bias; const float* res; long ldr;    // residual pitch in floats
+    int res_period;                                   // > 0: the residual of output row m is row m % res_period of `res` (a table that repeats per sequence)
     float* C; long ldc;                               // f32 output (or null), pitch in floats
     unsigned char* Cs; long ldcs;                     // hr8 output (or null), pitch in bytes
     int M, N, K, act, tiles_m, tiles_n;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                 f32x4 rv[4];
                 if (p.res) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) rv[g] = *(const f32x4*)(p.res + (size_t)mc * p.ldr + min(nb + 8 * g, p.N - 4));
+                    for (int g = 0; g < 4; ++g) rv[g] = *(const f32x4*)(p.res + (size_t)(p.res_period > 0 ? mc % p.res_period : mc) * p.ldr + min(nb + 8 * g, p.N - 4));
                 } else {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) rv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -639,7 +640,7 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     PsArgs p;
     p.A = (const unsigned char*)g.A; p.lda = g.lda; p.a_idx = g.a_idx; p.nseg = g.a_idx ? g.nseg : 1;
     p.seg_bytes = (g.K / p.nseg) * 4;
-    p.bias = g.bias; p.res = g.res; p.ldr = g.ldr; p.C = g.C; p.ldc = g.ldc; p.Cs = (unsigned char*)g.Cs; p.ldcs = g.ldcs;
+    p.bias = g.bias; p.res = g.res; p.ldr = g.ldr; p.res_period = g.res ? g.res_period : 0; p.C = g.C; p.ldc = g.ldc; p.Cs = (unsigned char*)g.Cs; p.ldcs = g.ldcs;
     p.M = g.M; p.N = g.N; p.K = g.K; p.act = g.act;
     p.tiles_n = cdiv(g.N, TN);
     // 256-row tiles when they still give every CU at least three tiles (else the 128-row tiles fill the chip better)

@@ -93,6 +93,7 @@ struct PsGemm {
     const int32_t* a_idx = nullptr; int nseg = 1;                    // hr8 only: source row per (output row, K segment), -1 = zeros
     const float* W = nullptr; int ldw = 0;                           // (N, K) f32, pitch in floats
     const float* bias = nullptr; const float* res = nullptr; long ldr = 0;
+    int res_period = 0;                                              // > 0: residual row of output row m = m % res_period (e.g. W pos_embedding per query)
     float* C = nullptr; long ldc = 0;                                // pitch in floats
     void* Cs = nullptr; long ldcs = 0;                               // pitch in BYTES
     int M = 0, N = 0, K = 0, act = 0;

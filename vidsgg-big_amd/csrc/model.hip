@@ -85,8 +85,8 @@ bool layout(const bigc_model* m, const Sizes& z, Arena& a, Work& w) {
     w.q_off = a.take<int32_t>(z.B + 1);
     w.query = a.take<float>(z.BQ * dp);
     w.qk_in = a.take<float>(z.BQ * dp);
-    w.qk = a.take<float>(z.BQ * 2 * dp);
-    w.vv = a.take<float>(z.BQ * dp);
+    w.qk = a.take<float>(z.BQ * 3 * dp);       // (B Q, 2 dp) q | k  -- or, in the one-GEMM form of the decoder, (B Q, 3 dp) q | k | v
+    w.vv = w.qk + z.BQ * 2 * dp;               // (B Q, dp) v of the two-GEMM form: the tail of the same block
     w.ao2 = a.take<float>(z.BQ * dp);
     w.t2 = a.take<float>(z.BQ * dp);
     w.t3 = a.take<float>(z.BQ * dp);
@@ -179,6 +179,7 @@ extern "C" void bigc_destroy(bigc_model* m) {
     if (m->conv_w_tapmajor) (void)hipFree(m->conv_w_tapmajor);
     if (m->role_cat) (void)hipFree(m->role_cat);
     if (m->conv_w_bwd) (void)hipFree(m->conv_w_bwd);
+    if (m->qkpos) (void)hipFree(m->qkpos);
     delete m;
 }
 
@@ -299,6 +300,28 @@ static int build_role_cat(bigc_model* m, void* stream) {
     return BIGC_OK;
 }
 
+// in_proj of a decoder layer's self-attention reads q = k = query + pos and v = query (models/model_0v10.py:181-183).  W (query + pos) =
+// W query + W pos, and W pos is the same (num_querys, 2 dp) table for every video: built once per weights epoch as (num_querys, 3 dp)
+// rows [pos Wq^T | pos Wk^T | 0], it enters the ONE q / k / v GEMM of the layer as a residual that repeats per video
+// (PsGemm.res_period) -- `query + pos` is never materialised and the GEMM reads its operand once instead of twice.
+static int build_qkpos(bigc_model* m, void* stream) {
+    const bigc_config& c = m->cfg;
+    const int dp = c.dim_pred, Q = c.num_querys;
+    if (m->qkpos_epoch == m->epoch || c.n_deco_layers == 0) return BIGC_OK;
+    const size_t per = (size_t)Q * 3 * dp;
+    if (!m->qkpos) {
+        hipError_t e = hipMalloc((void**)&m->qkpos, sizeof(float) * per * c.n_deco_layers);
+        if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: hipMalloc: %s", hipGetErrorString(e));
+    }
+    if (hipMemsetAsync(m->qkpos, 0, sizeof(float) * per * c.n_deco_layers, (hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: memset failed");
+    StaticWeights once(0);                       // a one-off product per epoch: nothing to cache
+    for (int i = 0; i < c.n_deco_layers; ++i)
+        TRY(bigc_linear_f32(stream, m->pos, dp, nullptr, 1, dp, m->dec[i].in_proj.w, dp, nullptr, nullptr, 0, m->qkpos + per * i, 3 * dp, Q, 2 * dp, dp,
+                            BIGC_ACT_NONE));
+    m->qkpos_epoch = m->epoch;
+    return BIGC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Eval forward on the split-operand GEMM (csrc/gemm_ps.hip).  Same op sequence as bigc_forward below; what changes is the
 // FORM in which a GEMM's output is written: when its only consumer is another GEMM it is stored as f16 head / residual pairs
@@ -306,6 +329,14 @@ static int build_role_cat(bigc_model* m, void* stream) {
 // an hr8 twin from the producing GEMM's epilogue when a GEMM reads them too).  f32 tensors produced by non-GEMM kernels
 // (LayerNorm, attention, max-pool, the raw features) enter a GEMM through its in-loop split (A mode 2).
 // ------------------------------------------------------------------------------------------------
+int bigc_mha_core_hr8_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, void* os, long ldos,
+                             const int32_t* q_off, int n_seq, int max_q, int n_head, int hd, int* range_flag);
+int bigc_role_fused_proj_hr8_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* rhs, int ldrhs, long role_stride,
+                                    const float* vbias0, const float* vbias1, int relu, float* att, void* vals_s, long ldvs, long out_role_stride,
+                                    const int32_t* e_off, int n_vid, int nq, int max_trk, int half, int d, float scale, int* range_flag);
+int bigc_layernorm_hr8(hipStream_t hs, const float* x, const float* gamma, const float* beta, float* y, void* ys, long ldys, int rows, int d,
+                       float eps, int* range_flag);
+
 namespace {
 
 struct PsCtx { hipStream_t s; int* flag; };
@@ -319,8 +350,9 @@ int bigc_or_flag(hipStream_t s, int* dst, const int32_t* src) {
 
 // C / Cs = act(A W^T + b) + res;  a_hr8: A is in split form.  Pitches in floats (the hr8 form has the same pitch in bytes / 4).
 int ps(const PsCtx& c, const void* A, long lda, bool a_hr8, const Lin& l, int ldw, float* C, long ldc, void* Cs, long ldcs, int M, int N, int K, int act,
-       const float* res = nullptr, long ldr = 0, const int32_t* a_idx = nullptr, int nseg = 1) {
+       const float* res = nullptr, long ldr = 0, const int32_t* a_idx = nullptr, int nseg = 1, int res_period = 0) {
     PsGemm g;
+    g.res_period = res_period;
     g.A = A; g.lda = lda * 4; g.a_fmt = a_hr8 ? PS_HR8 : PS_F32; g.a_idx = a_idx; g.nseg = nseg; g.W = l.w; g.ldw = ldw; g.bias = l.b;
     g.res = res; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Cs = Cs; g.ldcs = ldcs * 4; g.M = M; g.N = N; g.K = K; g.act = act; g.range_flag = c.flag;
     return bigc_gemm_ps_launch(c.s, g);
@@ -615,6 +647,32 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         // result (after `query += pos`) is tiled over the batch. Later layers run on all B*Q rows.
         const int rows = (i == 0) ? Q : BQ, nseq = (i == 0) ? 1 : B;
         const float* qin = (i == 0) ? m->qinit : w.query;
+        const bool fused = b->max_trk <= 64 && (da / 2) % 64 == 0;
+        const bool last = i + 1 == c.n_deco_layers;                 // only the last layer's att is used downstream (:467)
+        // "pre-split" form of the layer (large batches; BIGC_PRESPLIT): every producer whose result only a GEMM reads next writes the split
+        // form -- the LayerNorms an hr8 twin, the attention core and the role attention ONLY the split form -- so that in_proj (one
+        // q / k / v GEMM, build_qkpos), out_proj, the second role-wise linears, fc2.0 and fc2.3 run on csrc/gemm_ps.hip (K loop =
+        // DMA + MFMA).  fc_pred2att / fc_enti2att, whose rounding the sharp attention amplifies, stay on the two-accumulator kernel.
+        // NOT the default: measured on the 256-video step (rocprofv3, profiles/r03_presplit_probe.log) the GEMM family takes 16.0 ms
+        // against 16.2 ms and the step 19.33 against 19.10 ms -- at M = 49152, N = 512 the 256-row tiles of gemm_ps are 384 for 256
+        // CUs (the launcher falls back to its 128-row kernel: 119 us per GEMM against 100 us for linear_split), the LayerNorms write a
+        // second output (+0.35 ms), and the one-accumulator GEMMs round coarser (oracle/accuracy.py).  It pays from 512 videos per step.
+        // BIGC_PRESPLIT = 1 / 0 forces it on / off; unset: on when the decoder's (B Q, dp) GEMMs fill the chip with 256-row tiles
+        // (512 videos per step: 55.4 -> 56.6 M pairs/s)
+        static const int presplit_env = getenv("BIGC_PRESPLIT") ? atoi(getenv("BIGC_PRESPLIT")) : -1;
+        const bool presplit_off = presplit_env == 0 || (presplit_env < 0 && (long)((BQ + 255) / 256) * ((dp + 255) / 256) < 3 * 256);
+        const bool presplit = chained && !presplit_off && fused && Q <= 192 && da / 2 <= 256 && (da / 2) % 128 == 0 && dp % 32 == 0 && dp <= de &&
+                              dp / H == 64 && (dp == 512 || dp == 256 || dp == 128 || dp == 64) && df % 32 == 0;
+        if (presplit && i > 0) {
+            TRY(build_qkpos(m, s));
+            // w.querys = the split twin of w.query, written by the previous layer's last LayerNorm
+            TRY(ps(cx, w.querys, dp, true, L.in_proj, dp, w.qk, 3 * dp, nullptr, 0, BQ, 3 * dp, dp, BIGC_ACT_NONE,
+                   m->qkpos + (size_t)Q * 3 * dp * i, 3 * dp, nullptr, 1, Q));
+            if (!bigc_mha_core_hr8_launch(hs, w.qk, 3 * dp, w.qk + dp, 3 * dp, w.qk + 2 * dp, 3 * dp, w.ao2, (long)dp * 4, w.q_off, B, Q, H, dp / H, w.flag))
+                return bigc_fail(BIGC_ERR_ARG, "forward: self-attention shape outside the split-output kernel");
+            TRY(ps(cx, w.ao2, dp, true, L.out_proj, dp, w.t2, dp, nullptr, 0, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
+            TRY(bigc_layernorm_add_f32(s, w.t2, L.n1.g, L.n1.b, w.query, BQ, dp, eps, m->pos, Q, nullptr));   // query += pos, kept (:189)
+        } else {
         // layers > 0: qk_in = query + pos was written by the previous layer's last LayerNorm
         if (i == 0) TRY(bigc_add_rows_f32(s, qin, m->pos, w.qk_in, rows, dp, Q));
         TRY(linear(s, w.qk_in, dp, qkp, w.qk, 2 * dp, rows, 2 * dp, dp, BIGC_ACT_NONE));
@@ -627,10 +685,27 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         } else {
             TRY(bigc_layernorm_add_f32(s, w.t2, L.n1.g, L.n1.b, w.query, BQ, dp, eps, m->pos, Q, nullptr));   // query += pos, kept (:189)
         }
+        }
         TRY(linear(s, enco, de, L.e2a, w.e2a, da, NT, da, de, BIGC_ACT_NONE));
         TRY(linear(s, w.query, dp, L.p2a, w.p2a, da, BQ, da, dp, BIGC_ACT_NONE));
-        const bool fused = b->max_trk <= 64 && (da / 2) % 64 == 0;
-        const bool last = i + 1 == c.n_deco_layers;                 // only the last layer's att is used downstream (:467)
+        if (presplit) {
+            float* ew = w.rh;                                        // 2 x (NT, dp), free until the FFN below
+            TRY(bigc_linear_f32(s, enco, de, nullptr, 1, de, L.role0[0].w, de, nullptr, nullptr, 0, ew, dp, NT, dp, de, BIGC_ACT_NONE));
+            TRY(bigc_linear_f32(s, enco, de, nullptr, 1, de, L.role1[0].w, de, nullptr, nullptr, 0, ew + (size_t)NT * dp, dp, NT, dp, de, BIGC_ACT_NONE));
+            TRY(build_role_cat(m, s));
+            if (!bigc_role_fused_proj_hr8_launch(hs, w.p2a, da, w.e2a, da, ew, dp, (long)NT * dp, L.role0[0].b, L.role1[0].b, 1, last ? out->att : nullptr,
+                                                 w.vals, (long)2 * dp * 4, dp, b->vid_trk_off, B, Q, b->max_trk, da / 2, dp, att_scale, w.flag))
+                return bigc_fail(BIGC_ERR_ARG, "forward: role-attention shape outside the split-output kernel");
+            const float* wc = m->role_cat + ((size_t)dp * 2 * dp + dp) * i;
+            Lin rc{wc, wc + (size_t)dp * 2 * dp};
+            TRY(ps(cx, w.vals, 2 * dp, true, rc, 2 * dp, w.t3, dp, nullptr, 0, BQ, dp, 2 * dp, BIGC_ACT_NONE, w.query, dp));
+            TRY(bigc_layernorm_hr8(hs, w.t3, L.n2.g, L.n2.b, w.t2, w.qkins, (long)dp * 4, BQ, dp, eps, w.flag));           // t2 and its split twin
+            TRY(ps(cx, w.qkins, dp, true, L.f0, dp, nullptr, 0, w.rh, df, BQ, df, dp, BIGC_ACT_RELU));
+            TRY(ps(cx, w.rh, df, true, L.f3, df, w.t3, dp, nullptr, 0, BQ, dp, df, BIGC_ACT_NONE, w.t2, dp));
+            if (!last) TRY(bigc_layernorm_hr8(hs, w.t3, L.n3.g, L.n3.b, w.query, w.querys, (long)dp * 4, BQ, dp, eps, w.flag));   // query and its split twin
+            else TRY(bigc_layernorm_f32(s, w.t3, L.n3.g, L.n3.b, w.query, BQ, dp, eps));
+            continue;
+        }
         if (fused && Q <= 192 && da / 2 <= 256 && dp % 32 == 0 && dp <= de) {
             // (att_r @ enco_output) W_r^T = att_r @ (enco_output W_r^T): the first role-wise linear (:204-208) is applied to the NT
             // entity rows instead of the B*Q value rows (a third as many); the role kernel adds its bias and the ReLU

@@ -69,12 +69,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // Specialised form for d = 4 * G * NVL with G (lanes per row) a power of two <= 64: a wave holds 64 / G rows side by side
 // and UNR such groups in flight (all loads of a wave-iteration are issued before the first reduction), statistics by
 // butterfly shuffles inside the G-lane group.  Same arithmetic order per element as the generic kernel.
-template <int G, int NVL, int UNR, bool ADD>
+// HR8: the result also (or only, y == nullptr) in the split form "hr8" of csrc/gemm_ps.hip -- per 8 columns 16 bytes of f16 heads then
+// 16 bytes of f16 residuals of 8 x -- for the GEMM that reads it next (a lane owns 4 consecutive columns: half a group of each).
+template <int G, int NVL, int UNR, bool ADD, bool HR8 = false>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                              float* __restrict__ y, int rows, float eps,
-                                                             const float* __restrict__ add, int period, float* __restrict__ y_plain) {
+                                                             const float* __restrict__ add, int period, float* __restrict__ y_plain,
+                                                             unsigned char* __restrict__ ys = nullptr, long ldys = 0, int* __restrict__ range_flag = nullptr) {
     constexpr int RPW = 64 / G;                    // rows per wave pass
     constexpr int D4 = G * NVL;                    // float4 per row
+    bool oob = false;
     const int lane = threadIdx.x & 63, sub = lane / G, gl = lane % G;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int row0 = wave * RPW * UNR + sub;
@@ -127,10 +131,22 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
                     if (y_plain) ((f32x4*)y_plain + (size_t)row * D4)[gl + G * j] = o;
                     o += av[u][j];
                 }
-                yp[gl + G * j] = o;
+                if (!HR8 || y) yp[gl + G * j] = o;
+                if (HR8) {
+                    const int q = gl + G * j;                       // columns 4 q .. 4 q + 3: half (q & 1) of group q >> 1
+                    const f32x4 X = o * 8.0f;                       // PS_ACT_EXP = 3 (linear_internal.h)
+                    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                    const h16x4 hh = __builtin_convertvector(X, h16x4);
+                    const h16x4 rr = __builtin_convertvector(X - __builtin_convertvector(hh, f32x4), h16x4);
+                    unsigned char* gp = ys + (size_t)row * ldys + (size_t)(q >> 1) * 32 + (q & 1) * 8;
+                    *(h16x4*)gp = hh;
+                    *(h16x4*)(gp + 16) = rr;
+                    oob = oob || !(fabsf(X[0]) < 32768.f) || !(fabsf(X[1]) < 32768.f) || !(fabsf(X[2]) < 32768.f) || !(fabsf(X[3]) < 32768.f);
+                }
             }
         }
     }
+    if (HR8 && oob && range_flag) atomicOr(range_flag, 1);
 }
 
 __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ x, const float* __restrict__ p, float* __restrict__ y,
@@ -177,6 +193,28 @@ extern "C" int bigc_layernorm_add_f32(void* stream, const float* x, const float*
 #undef LN_ROWS_
     BIGC_LAUNCH_CHECK("layernorm");
     return BIGC_OK;
+}
+
+// LayerNorm whose result a GEMM on pre-split operands reads next: y (f32, may be null) and / or ys (split form, pitch ldys bytes)
+int bigc_layernorm_hr8(hipStream_t hs, const float* x, const float* gamma, const float* beta, float* y, void* ys, long ldys, int rows, int d,
+                       float eps, int* range_flag) {
+    BIGC_CHECK_ARG(x && gamma && beta && ys && ldys % 16 == 0 && ldys >= 4L * d, "layernorm_hr8: bad argument");
+    BIGC_CHECK_ARG(d == 512 || d == 256 || d == 128 || d == 64, "layernorm_hr8: d=%d not in {64, 128, 256, 512}", d);
+    if (rows <= 0) return BIGC_OK;
+    ProfScope ps((void*)hs, FAM_LAYERNORM, 0.0, (y ? 12.0 : 8.0) * rows * (double)d);
+#define LN_HR8(G, NVL, UNR) hipLaunchKernelGGL((layernorm_rows_kernel<G, NVL, UNR, false, true>), dim3(cdiv(rows, 4 * (64 / G) * UNR)), dim3(256), 0, hs, x, gamma, beta, y, rows, eps, nullptr, 0, nullptr, (unsigned char*)ys, ldys, range_flag)
+    if (d == 512) LN_HR8(64, 2, 4);
+    else if (d == 256) LN_HR8(64, 1, 4);
+    else if (d == 128) LN_HR8(32, 1, 4);
+    else LN_HR8(16, 1, 4);
+#undef LN_HR8
+    BIGC_LAUNCH_CHECK("layernorm_hr8");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_layernorm_hr8_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y, void* ys, long ldys_bytes,
+                                      int rows, int d, float eps, int* range_flag) {
+    return bigc_layernorm_hr8((hipStream_t)stream, x, gamma, beta, y, ys, ldys_bytes, rows, d, eps, range_flag);
 }
 
 extern "C" int bigc_layernorm_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y,

@@ -733,12 +733,18 @@ def main():
         # HBM bytes per launch cannot be sampled from inside this process: they come from the committed
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/pmc_traffic.json,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if the workload differs
-        traffic, traffic_source = None, None
+        traffic, traffic_source, step_traffic = None, None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path) and args.videos == 256 and args.n_trajs == 64:
             pmc = json.load(open(pmc_path))
-            traffic = round(pmc["hbm_bytes_per_launch"])
-            traffic_source = "not measured in this run: read from profiles/pmc_traffic.json (%s)" % pmc.get("source", "rocprofv3 --pmc passes of this command")
+            sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+            from pmc_summary import csrc_sha16
+            if pmc.get("csrc_sha16") == csrc_sha16():
+                traffic = round(pmc["hbm_bytes_per_launch"])
+                step_traffic = pmc.get("whole_step_fetch_bytes_all_kernels", 0) + pmc.get("whole_step_write_bytes_all_kernels", 0)
+                traffic_source = "not measured in this run: profiles/pmc_traffic.json (%s), rocprofv3 --pmc passes of this command on these kernel sources" % pmc.get("tag", "")
+            else:
+                traffic_source = "profiles/pmc_traffic.json was measured on other kernel sources (csrc fingerprint differs): not reported"
         if EXACT_F32:
             kernel = "linear_f32_kernel (f32 MFMA 32x32x2)"
         else:
@@ -754,8 +760,13 @@ def main():
                                                    three_mfma_gemm_ceiling=round(mp["random_f16_tflops"] / 3, 1),
                                                    frac_of_that_ceiling=round(roofline["achieved"] / (mp["random_f16_tflops"] / 3), 4),
                                                    source="not measured in this run: profiles/mfma_peak.json (benchmarks/probes/mfma_peak.hip)")
+        # SURVEY.md 8(d)'s algorithmic bytes of the STEP: features + boxes read once (6.7 kB per pair) + the weights once per batch
+        alg_8d = rows_per_step * (width + 4) * 4 + 4 * sum(int(v.numel()) for v in sd.values())
         roofline.update(kernel=kernel, vs_f32_mfma_peak=round(roofline["achieved"] / F32_MFMA_PEAK_TFLOPS, 3), traffic=traffic,
                         traffic_source=traffic_source, algorithmic_bytes_per_launch=round(lin["bytes"] / lin["launches"]),
+                        step_traffic_all_kernels=dict(hbm_bytes=step_traffic, algorithmic_bytes_survey_8d=alg_8d,
+                                                      ratio=round(step_traffic / alg_8d, 2) if step_traffic else None,
+                                                      note="HBM bytes of every kernel of one step (same PMC passes) against features + boxes + weights read once"),
                         measured="HIP events around each launch, over a repeat of the timed %d steps (instrumented step: %.3f ms)"
                                  % (args.steps, 1e3 * prof_elapsed / args.steps))
     cpu_baseline, oracle_parity = None, None

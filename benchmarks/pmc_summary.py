@@ -20,6 +20,19 @@ from collections import OrderedDict, defaultdict
 KERNEL = ("linear_split_kernel", "gemm_ps_kernel")      # the GEMM family: f32-operand kernel + pre-split-operand kernel
 
 
+def csrc_sha16():
+    """fingerprint of the kernel sources the measurement belongs to (tests/test_host_cpu.py fails when profiles/pmc_traffic.json
+    was measured on other sources: a stale committed number is not evidence)"""
+    import glob
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vidsgg-big_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")) + glob.glob(os.path.join(root, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def per_dispatch(path, kernel):
     """-> OrderedDict dispatch_id -> {counter: value}, and grid sizes, for kernels whose name contains `kernel`"""
     out, grid = OrderedDict(), {}
@@ -65,17 +78,19 @@ def main():
             tot_f += fb
             tot_w += wb
             f.write("%d,%d,%.1f,%d,%.1f,%d\n" % (i, grid[a], fk, fb, wk, wb))
-    json.dump({"kernel": " + ".join(KERNEL), "launches_per_step": len(fid), "fetch_bytes_per_step": tot_f, "write_bytes_per_step": tot_w,
-               "hbm_bytes_per_launch": (tot_f + tot_w) / len(fid),
-               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 2 --warmup 1 "
-                         "--cpu-videos 0 --no-prof` (benchmarks/profile_bench.sh); the last step's GEMM launches; FETCH_SIZE doubled per "
-                         "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); counter unit KiB"},
-              open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     # every kernel of the last step (not only the GEMM family): the step's total HBM traffic
     all_f, _ = per_dispatch(os.path.join(src, "pmc_FETCH_SIZE", "pmc_counter_collection.csv"), "")
     all_w, _ = per_dispatch(os.path.join(src, "pmc_WRITE_SIZE", "pmc_counter_collection.csv"), "")
     step_f = sum(all_f[i]["FETCH_SIZE"] for i in in_step(all_f, one_step(fpath))) * 1024 * 2
     step_w = sum(all_w[i]["WRITE_SIZE"] for i in in_step(all_w, one_step(wpath))) * 1024
+    json.dump({"kernel": " + ".join(KERNEL), "launches_per_step": len(fid), "fetch_bytes_per_step": tot_f, "write_bytes_per_step": tot_w,
+               "hbm_bytes_per_launch": (tot_f + tot_w) / len(fid),
+               "whole_step_fetch_bytes_all_kernels": step_f, "whole_step_write_bytes_all_kernels": step_w,
+               "csrc_sha16": csrc_sha16(), "tag": tag,
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 2 --warmup 1 "
+                         "--cpu-videos 0 --no-prof` (benchmarks/profile_bench.sh); the last step's GEMM launches; FETCH_SIZE doubled per "
+                         "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); counter unit KiB"},
+              open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     sums = OrderedDict()
     for sub in ("pmc_sq1", "pmc_sq2"):
         p = os.path.join(src, sub, "pmc_counter_collection.csv")

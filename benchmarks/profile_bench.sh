@@ -4,15 +4,15 @@
 # per-kernel stats land in gpurun_out/summary_$TAG/ -- copy them into profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r02a}
+TAG=${TAG:-r03a}
 O=/tmp/prof_$TAG
 S=$R/gpurun_out/summary_$TAG
 rm -rf $O $S; mkdir -p $O $S
 cd $R
-HEAD="--cpu-videos 0 --exact-steps 0 --fast-steps 0 --legs none"
+HEAD="--cpu-videos 0 --exact-steps 0 --fast-steps 0 --recall-steps 0 --legs none"
 # (1) per-kernel durations of the headline workload (13 forward passes), and of the whole default command with its extra legs
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py $HEAD > $O/stats_stdout.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_full -o bench -- python3 bench.py --cpu-videos 0 --exact-steps 0 --fast-steps 0 > $O/stats_full_stdout.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_full -o bench -- python3 bench.py --cpu-videos 0 --exact-steps 0 --fast-steps 0 --recall-steps 0 > $O/stats_full_stdout.log 2>&1
 # (2) HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md), then two SQ passes
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-prof $HEAD > $O/pmc_$c.log 2>&1

@@ -3,6 +3,7 @@ declares, the host packing logic, and the drop-in module surface."""
 import ctypes
 import os
 import re
+import sys
 import tempfile
 
 import numpy as np
@@ -175,3 +176,15 @@ def test_host_side_under_address_and_ub_sanitizers():
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"))
     assert r.returncode == 0 and "host_sanitize: OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_committed_pmc_traffic_belongs_to_the_current_kernel_sources():
+    """profiles/pmc_traffic.json (read by bench.py for roofline.traffic: HBM counters cannot be sampled from inside the process) carries
+    the fingerprint of the kernel sources it was measured on: a number measured on other kernels is not evidence, bench.py then reports
+    null -- and this test fails until benchmarks/profile_bench.sh has been re-run on the GPU box"""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+    from pmc_summary import csrc_sha16
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert pmc.get("csrc_sha16") == csrc_sha16(), "profiles/pmc_traffic.json is stale: re-run `TAG=r0X bash benchmarks/profile_bench.sh` on the GPU box"
+    assert pmc["hbm_bytes_per_launch"] > 0 and pmc["whole_step_fetch_bytes_all_kernels"] > 0

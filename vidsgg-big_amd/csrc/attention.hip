@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
                                                        const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
                                                        const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
                                                        int n_seq, int n_qt, int n_head, float scale, float* __restrict__ lse,
-                                                       const DropSpec drop) {
+                                                       const DropSpec drop, const int* __restrict__ run_flag = nullptr, int run_id = 0) {
+    if (run_flag && *run_flag != run_id) return;        // fallback launch behind mha_core_h16_long_kernel: only when that one flagged
     constexpr int HALF = HD / 2;
     constexpr int NTD = (HD + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -624,11 +625,15 @@ extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, con
         if (!run_flag) return BIGC_ERR_HIP;
         bigc_mha_core_h_launch(s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, grid, run_flag, run_id);
     }
-    if (hd == 16 && nkt <= 8 && !bigc_linear_get_exact()) {
+    bool long16 = false;
+    if (hd == 16 && !bigc_linear_get_exact() && (nkt <= 8 || (q_off == k_off && !lse && !drop.thresh))) {
+        // (beyond 8 key tiles: the chunked kernel for eval self-attention -- no log-sum-exp output, no dropout; the two-pass f32
+        // kernel behind it then only runs when an operand was out of range)
         run_id = g_mha_run.fetch_add(1, std::memory_order_relaxed) + 1;
         run_flag = mha_flag_slot(run_id);
         if (!run_flag) return BIGC_ERR_HIP;
-        bigc_mha_core_h16_launch(s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, nkt, n_head, scale, lse, drop, grid, run_flag, run_id);
+        long16 = bigc_mha_core_h16_launch(s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, nkt, n_head, scale, lse, drop, grid, run_flag, run_id) != 0 && nkt > 8;
+        if (nkt > 8 && !long16) { run_flag = nullptr; run_id = 0; }
     }
     if (hd == 64 && nkt <= 2) LAUNCH_SP(64, 2);
     else if (hd == 64 && nkt <= 6) LAUNCH_SP(64, 6);
@@ -640,7 +645,10 @@ extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, con
     else
     switch (hd) {
         case 8: LAUNCH_MHA(8); break;
-        case 16: LAUNCH_MHA(16); break;
+        case 16:
+            if (long16) hipLaunchKernelGGL(mha_core_kernel<16>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, run_flag, run_id);
+            else LAUNCH_MHA(16);
+            break;
         case 32: LAUNCH_MHA(32); break;
         default: LAUNCH_MHA(64); break;
     }

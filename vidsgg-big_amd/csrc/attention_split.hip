@@ -195,6 +195,116 @@ __global__ __launch_bounds__(256, 2) void mha_core_h_kernel(const float* __restr
     }
 }
 
+// head_dim 16, sequences LONGER than the 256 keys whose scores mha_core_h_kernel<8, 16> keeps in registers (the grounding scorer's
+// clip sequences run to T = 400): the keys are walked in chunks of 8 tiles with a running maximum and sum
+// (the running output and sum are rescaled by exp(m_old - m_new) when a chunk raises the maximum), so any length is one pass over
+// K and V on the split-f16 MFMAs -- the two-pass f32-MFMA kernel it replaces took 550 us per launch on the grounding leg.
+// Same lane roles as mha_core_h_kernel<., 16>; the normalisation happens once at the end (o / l instead of p / l before P V).
+__global__ __launch_bounds__(256, 2) void mha_core_h16_long_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                                   const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
+                                                                   const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
+                                                                   int n_seq, int n_qt, int n_head, float scale, int* __restrict__ flag, int run_id) {
+    constexpr int HD = 16, CH = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)n_seq * n_qt * n_head) return;
+    const int h = item % n_head;
+    const int qt = (item / n_head) % n_qt;
+    const int s = item / ((long)n_head * n_qt);
+    const int q0 = q_off[s], nq = q_off[s + 1] - q0;
+    const int k0 = k_off[s], nk = k_off[s + 1] - k0;
+    if (qt * 32 >= nq || nk <= 0) return;
+    const int n_kt = (nk + 31) / 32;
+    const int qrow = min(qt * 32 + l31, nq - 1);
+    float chk = 0.f, amax = 0.f;
+    a16x8 qh, qr;
+    {
+        const float* qp = q + (size_t)(q0 + qrow) * ldq + h * HD + 8 * hi;
+        const f32x4 t0 = *(const f32x4*)qp, t1 = *(const f32x4*)(qp + 4);
+        const float x[8] = {t0[0] * scale, t0[1] * scale, t0[2] * scale, t0[3] * scale, t1[0] * scale, t1[1] * scale, t1[2] * scale, t1[3] * scale};
+        split8(x, qh, qr, chk, amax);
+    }
+    const float* kbase = k + (size_t)k0 * ldk + h * HD + 8 * hi;
+    const bool col_ok = l31 < HD;
+    const float* vbase = v + (size_t)k0 * ldv + h * HD + (col_ok ? l31 : 0);
+    float m = NEG_BIG, l = 0.f;
+    f32x16 o0 = zero16(), o1 = zero16();
+    for (int c0 = 0; c0 < n_kt; c0 += CH) {
+        f32x16 sc[CH];
+        float mc = NEG_BIG;
+#pragma unroll
+        for (int kt = 0; kt < CH; ++kt) {
+            if (c0 + kt < n_kt) {
+                const float* kp = kbase + (size_t)min((c0 + kt) * 32 + l31, nk - 1) * ldk;
+                const f32x4 a = *(const f32x4*)kp, b = *(const f32x4*)(kp + 4);
+                const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                a16x8 kh, kr;
+                split8(x, kh, kr, chk, amax);
+                f32x16 c_0 = zero16(), c_1 = zero16();
+                c_0 = MFMA_H(kh, qh, c_0);
+                c_1 = MFMA_H(kh, qr, c_1);
+                c_1 = MFMA_H(kr, qh, c_1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sc[kt][r] = c_0[r] + c_1[r] * RI;
+                    if ((c0 + kt) * 32 + mfma_row(r, hi) < nk) mc = fmaxf(mc, sc[kt][r]);
+                }
+            } else {
+                sc[kt] = zero16();
+            }
+        }
+        mc = fmaxf(mc, __shfl_xor(mc, 32));
+        const float mn = fmaxf(m, mc);
+        const float alpha = expf(m - mn);               // 0 for the first chunk (m = NEG_BIG)
+        m = mn;
+        l *= alpha;
+        // the running output is held TRANSPOSED to the scores: register r of a lane belongs to query row mfma_row(r, hi), whose
+        // rescale factor lives in lane mfma_row(r, hi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float ar = __shfl(alpha, mfma_row(r, hi)); o0[r] *= ar; o1[r] *= ar; }
+#pragma unroll
+        for (int kt = 0; kt < CH; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = c0 + kt < n_kt && (c0 + kt) * 32 + mfma_row(r, hi) < nk;
+                const float e = ok ? expf(sc[kt][r] - m) : 0.f;
+                sc[kt][r] = e;
+                l += e;
+            }
+#pragma unroll
+        for (int kt = 0; kt < CH; ++kt) {
+            if (c0 + kt < n_kt) {
+                float vv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vv[r] = vbase[(size_t)min((c0 + kt) * 32 + mfma_row(r, hi), nk - 1) * ldv];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float p8[8], v8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { p8[j] = sc[kt][8 * u + j]; v8[j] = vv[8 * u + j]; }
+                    a16x8 ph, pr, vh, vr;
+                    float c_ = 0.f, a_ = 0.f;
+                    split8(p8, ph, pr, c_, a_);
+                    split8(v8, vh, vr, chk, amax);
+                    o0 = MFMA_H(ph, vh, o0);
+                    o1 = MFMA_H(ph, vr, o1);
+                    o1 = MFMA_H(pr, vh, o1);
+                }
+            }
+        }
+    }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    if (!(fabsf(chk) < INFINITY) || amax >= 32768.0f) atomicMax(flag, run_id);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = qt * 32 + mfma_row(r, hi);
+        const float ir = __shfl(inv, mfma_row(r, hi));           // (all lanes take part in the shuffle: no early return above it)
+        if (col_ok && row < nq) o[(size_t)(q0 + row) * ldo + h * HD + l31] = (o0[r] + o1[r] * RI) * ir;
+    }
+}
+
 // split without the NaN/Inf sum: only the magnitude is tracked (a NaN operand gives NaN outputs on either path)
 __device__ __forceinline__ void split8a(const float (&x)[8], a16x8& h, a16x8& r, float& amax) {
     union { a16x2 p[4]; a16x8 v; } hh, rr;
@@ -1314,6 +1424,7 @@ int bigc_mha_core_h16_launch(hipStream_t s, const float* q, int ldq, const float
     if (nkt <= 2) hipLaunchKernelGGL((mha_core_h_kernel<2, 16>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
     else if (nkt <= 4) hipLaunchKernelGGL((mha_core_h_kernel<4, 16>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
     else if (nkt <= 8) hipLaunchKernelGGL((mha_core_h_kernel<8, 16>), dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, flag, run_id);
+    else if (!lse && !drop.thresh) hipLaunchKernelGGL(mha_core_h16_long_kernel, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, flag, run_id);
     else return 0;
     return 1;
 }

@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gp -o bench -- python3 $R/bench.py --videos 8 --cpu-videos 0 --exact-steps 0 --fast-steps 0 --recall-steps 0 --legs grounding --steps 2 --warmup 1 --no-prof > /tmp/gp.log 2>&1
 tail -1 /tmp/gp.log | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); g=d['grounding']; print('grounding', g['value'], g['ms_per_step'], g['workload'])"
+pass"
 python3 - <<PY
 import csv, glob
 f = glob.glob("/tmp/gp/**/bench_kernel_trace.csv", recursive=True)[0]

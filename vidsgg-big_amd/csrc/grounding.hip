@@ -737,9 +737,20 @@ int forward_impl(grd_model* m, void* stream, const float* video_feat, int T, con
     float* regrs = out->regrs ? out->regrs : w.regrs;
     float* conf = out->conf ? out->conf : w.conf;
     float* cls = out->cls ? out->cls : w.cls;
-    GTRY(run_head(s, m->regr_head, cenc, sc, d, w, regrs, BIGC_ACT_SIGMOID));
-    GTRY(run_head(s, m->conf_head, cenc, sc, d, w, conf, BIGC_ACT_NONE));
-    GTRY(run_head(s, m->cls_head, cenc, sc, d, w, cls, BIGC_ACT_NONE));
+    if (grd_head_chain_supported(d, m->regr_head, m->conf_head, m->cls_head)) {
+        // the three heads' five layers each in ONE launch, the intermediate activations in LDS (csrc/grounding_heads.hip)
+        const Head* const heads[3] = {&m->regr_head, &m->conf_head, &m->cls_head};
+        float* const outs[3] = {regrs, conf, cls};
+        const int acts[3] = {BIGC_ACT_SIGMOID, BIGC_ACT_NONE, BIGC_ACT_NONE};
+        if (!m->head_frag && hipMalloc(&m->head_frag, grd_head_frag_bytes()) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_forward: hipMalloc failed");
+        const bool refresh = m->head_frag_epoch != m->epoch;
+        GTRY(grd_head_chain(hs, cenc, sc.rows, sc.T, sc.info, heads, outs, acts, m->head_frag, refresh));
+        m->head_frag_epoch = m->epoch;
+    } else {
+        GTRY(run_head(s, m->regr_head, cenc, sc, d, w, regrs, BIGC_ACT_SIGMOID));
+        GTRY(run_head(s, m->conf_head, cenc, sc, d, w, conf, BIGC_ACT_NONE));
+        GTRY(run_head(s, m->cls_head, cenc, sc, d, w, cls, BIGC_ACT_NONE));
+    }
 
     // a14-a16: pooling, clipping, NMS, masks (:533-572)
     if (!b) {
@@ -776,6 +787,7 @@ extern "C" void grd_destroy(grd_model* m) {
     if (m->wq) bigc_weight_cache_forget(m->wq);
     if (m->wq) (void)hipFree(m->wq);
     if (m->bq) (void)hipFree(m->bq);
+    if (m->head_frag) (void)hipFree(m->head_frag);
     delete m;
 }
 

@@ -21,5 +21,12 @@ struct grd_model {
     float* wq = nullptr;   // (d, kq) owned: [query_fc.weight | temp_fc.weight | 0 0]
     float* bq = nullptr;   // (d) owned: query_fc.bias + temp_fc.bias
     int kq = 0;
+    void* head_frag = nullptr; unsigned long long head_frag_epoch = 0;   // the heads' point-wise weights in MFMA fragment order (grounding_heads.hip), owned
     std::vector<SplitJob> train_jobs;  // as bigc_model::train_jobs
 };
+
+// csrc/grounding_heads.hip: the three 5-layer prediction heads in one launch, intermediate layers in LDS
+bool grd_head_chain_supported(int d, const Head& a, const Head& b, const Head& c);
+size_t grd_head_frag_bytes();
+int grd_head_chain(hipStream_t s, const float* x, long rows, int T, const int2* info, const Head* const heads[3], float* const outs[3], const int acts[3],
+                   void* frag, bool refresh);

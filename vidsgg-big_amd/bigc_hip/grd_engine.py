@@ -116,11 +116,13 @@ class GrdEngine(object):
         """Several videos per launch sequence (``grd_forward_batch``).  ``jobs``: list of (video_feature (T,dim_feat) f32 cuda,
         quint (n,5), dura (n,2), video_len).  -> list of per-video dicts (views of the batch outputs) with the keys of ``forward``;
         ``status`` is a 1-element view per video.  Videos are grouped into calls of at most ``BATCH_ROWS`` combined rows."""
-        # The attention kernels keep the scores of a sequence in registers up to a head-dim dependent length and switch to a two-pass
-        # form beyond it (csrc/attention.hip: bigc_mha_core_drop_f32), and the form is chosen per LAUNCH from the longest sequence:
-        # a video is therefore only batched with videos on its own side of that limit, so that its result does not depend on its
-        # company (identical, bit for bit, to the one-video call).
-        limit = 32 * {8: 8, 16: 8, 32: 6, 64: 6}[self.c.dim_hidden // 8]
+        # At head dims 8 / 32 / 64 the attention kernels keep the scores of a sequence in registers up to a head-dim dependent length and
+        # switch to a two-pass form beyond it (csrc/attention.hip: bigc_mha_core_drop_f32), chosen per LAUNCH from the longest sequence:
+        # there a video is only batched with videos on its own side of that limit, so that its result does not depend on its company
+        # (identical, bit for bit, to the one-video call).  At head dim 16 (config G: 8 heads of 16) every sequence up to 1024 clips
+        # runs the same chunked arithmetic (mha_core_hd16_lds_kernel): one class.
+        hd = self.c.dim_hidden // 8
+        limit = 1024 if hd == 16 else 32 * {8: 8, 32: 6, 64: 6}[hd]
         order = sorted(range(len(jobs)), key=lambda i: int(jobs[i][0].shape[0]) > limit)          # stable: short videos first, long ones after
         groups, cur, rows, side = [], [], 0, None
         for i in order:

@@ -572,6 +572,8 @@ int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const flo
                              float* values, const int32_t* e_off, int n_vid, int nq, int n_qt, int half, int d, float scale, int grid,
                              int* flag, int run_id, long role_stride, const float* vbias0, const float* vbias1, int relu, long out_role_stride, int ldval);
 
+int bigc_mha_core_hd16_lds_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                  const int32_t* off, int n_seq, int max_q, int n_head, float scale, int* flag, int run_id);
 namespace {
 // BIGC_LINEAR_EXACT / bigc_linear_set_exact also select the f32-MFMA attention kernels
 std::atomic<int> g_mha_run{0};
@@ -626,6 +628,20 @@ extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, con
         bigc_mha_core_h_launch(s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, grid, run_flag, run_id);
     }
     bool long16 = false;
+    if (hd == 16 && !bigc_linear_get_exact() && q_off == k_off && !lse && !drop.thresh && max_q <= 1024) {
+        // eval self-attention of the grounding encoders: K / V split once per (sequence, head) into LDS, the same chunked arithmetic for
+        // every length (so a sequence's bits do not depend on its batch); the gated two-pass f32 kernel behind it is the range fallback
+        run_id = g_mha_run.fetch_add(1, std::memory_order_relaxed) + 1;
+        run_flag = mha_flag_slot(run_id);
+        if (!run_flag) return BIGC_ERR_HIP;
+        long16 = bigc_mha_core_hd16_lds_launch(s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, n_seq, max_q, n_head, scale, run_flag, run_id) != 0;
+        if (!long16) { run_flag = nullptr; run_id = 0; }
+    }
+    if (long16) {
+        hipLaunchKernelGGL(mha_core_kernel<16>, dim3(grid), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, q_off, k_off, n_seq, n_qt, n_head, scale, lse, drop, run_flag, run_id);
+        BIGC_LAUNCH_CHECK("mha_core");
+        return BIGC_OK;
+    }
     if (hd == 16 && !bigc_linear_get_exact() && (nkt <= 8 || (q_off == k_off && !lse && !drop.thresh))) {
         // (beyond 8 key tiles: the chunked kernel for eval self-attention -- no log-sum-exp output, no dropout; the two-pass f32
         // kernel behind it then only runs when an operand was out of range)

@@ -23,6 +23,9 @@ namespace {
 
 constexpr float NEG_BIG = -1e30f;
 constexpr float RS = 2048.0f, RI = 1.0f / 2048.0f;
+// e^x through v_exp_f32 (2^x, ~1 ulp): the chunked head_dim 16 kernels evaluate 16 exponentials per lane and key tile and are bound by
+// their VALU work, the library expf costs ~10 instructions each
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void mha_core_h16_long_kernel(const float* 
         }
         mc = fmaxf(mc, __shfl_xor(mc, 32));
         const float mn = fmaxf(m, mc);
-        const float alpha = expf(m - mn);               // 0 for the first chunk (m = NEG_BIG)
+        const float alpha = fast_exp(m - mn);               // 0 for the first chunk (m = NEG_BIG)
         m = mn;
         l *= alpha;
         // the running output is held TRANSPOSED to the scores: register r of a lane belongs to query row mfma_row(r, hi), whose
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void mha_core_h16_long_kernel(const float* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const bool ok = c0 + kt < n_kt && (c0 + kt) * 32 + mfma_row(r, hi) < nk;
-                const float e = ok ? expf(sc[kt][r] - m) : 0.f;
+                const float e = ok ? fast_exp(sc[kt][r] - m) : 0.f;
                 sc[kt][r] = e;
                 l += e;
             }
@@ -303,6 +306,137 @@ __global__ __launch_bounds__(256, 2) void mha_core_h16_long_kernel(const float* 
         const float ir = __shfl(inv, mfma_row(r, hi));           // (all lanes take part in the shuffle: no early return above it)
         if (col_ok && row < nq) o[(size_t)(q0 + row) * ldo + h * HD + l31] = (o0[r] + o1[r] * RI) * ir;
     }
+}
+
+// head_dim 16 self-attention with K and V of a (sequence, head) split ONCE into LDS and shared by the sequence's query tiles (the
+// register kernels above split every key / value tile again in each of the T / 32 waves that walk it: at T = 200 .. 400 that was most
+// of their VALU work).  One workgroup of NW waves per (sequence, head); wave w takes the 32-query tiles w, w + NW, ...; keys are walked
+// in chunks of 8 tiles with a running maximum and sum as in mha_core_h16_long_kernel, so every length runs the SAME arithmetic -- a
+// sequence's result does not depend on what else is in the launch.  LDS: K as f16 head / residual planes [key][16] (32 bytes a key),
+// V transposed [column][keys + 8] with the keys of a 32-key tile permuted so that a lane's eight k-slots of the P V MFMA are one
+// 16-byte read.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void mha_core_hd16_lds_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                                    const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
+                                                                    const int32_t* __restrict__ off, int n_head, float scale, int tp_max,
+                                                                    int* __restrict__ flag, int run_id) {
+    constexpr int HD = 16, CH = 8, NTH = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hd16_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.x % n_head, s = blockIdx.x / n_head;
+    const int q0 = off[s], nq = off[s + 1] - q0;
+    if (nq <= 0) return;
+    const int n_kt = (nq + 31) / 32, tp = n_kt * 32, vs = tp_max + 8;
+    unsigned char* const Kh = hd16_smem;
+    unsigned char* const Kr = Kh + (size_t)tp_max * 32;
+    unsigned char* const Vh = Kr + (size_t)tp_max * 32;
+    unsigned char* const Vr = Vh + (size_t)HD * vs * 2;
+    float chk = 0.f, amax = 0.f;
+    // ---- stage K: unit = (key, half of the head dimension)
+    for (int unit = tid; unit < tp * 2; unit += NTH) {
+        const int key = unit >> 1, c = unit & 1;
+        const float* kp = k + (size_t)(q0 + min(key, nq - 1)) * ldk + h * HD + 8 * c;
+        const f32x4 a = *(const f32x4*)kp, b = *(const f32x4*)(kp + 4);
+        const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        a16x8 kh, kr;
+        split8(x, kh, kr, chk, amax);
+        *(a16x8*)(Kh + key * 32 + 16 * c) = kh;
+        *(a16x8*)(Kr + key * 32 + 16 * c) = kr;
+    }
+    // ---- stage V^T: unit = (tile, group of 8 permuted keys, column); position 8 grp + j of a tile holds key (j & 3) + 8 (j >> 2) + 16 (grp >> 1) + 4 (grp & 1)
+    for (int unit = tid; unit < n_kt * 4 * HD; unit += NTH) {
+        const int col = unit & 15, grp = (unit >> 4) & 3, tile = unit >> 6;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = tile * 32 + (j & 3) + 8 * (j >> 2) + 16 * (grp >> 1) + 4 * (grp & 1);
+            x[j] = v[(size_t)(q0 + min(key, nq - 1)) * ldv + h * HD + col];
+        }
+        a16x8 vh, vr;
+        split8(x, vh, vr, chk, amax);
+        *(a16x8*)(Vh + ((size_t)col * vs + tile * 32 + grp * 8) * 2) = vh;
+        *(a16x8*)(Vr + ((size_t)col * vs + tile * 32 + grp * 8) * 2) = vr;
+    }
+    __syncthreads();
+    const int colc = min(l31, HD - 1);
+    for (int qt = wave; qt < n_kt; qt += NW) {
+        const int qrow = min(qt * 32 + l31, nq - 1);
+        a16x8 qh, qr;
+        {
+            const float* qp = q + (size_t)(q0 + qrow) * ldq + h * HD + 8 * hi;
+            const f32x4 t0 = *(const f32x4*)qp, t1 = *(const f32x4*)(qp + 4);
+            const float x[8] = {t0[0] * scale, t0[1] * scale, t0[2] * scale, t0[3] * scale, t1[0] * scale, t1[1] * scale, t1[2] * scale, t1[3] * scale};
+            split8(x, qh, qr, chk, amax);
+        }
+        float m = NEG_BIG, l = 0.f;
+        f32x16 o0 = zero16(), o1 = zero16();
+        for (int c0 = 0; c0 < n_kt; c0 += CH) {
+            f32x16 sc[CH];
+            float mc = NEG_BIG;
+#pragma unroll
+            for (int kt = 0; kt < CH; ++kt) {
+                if (c0 + kt < n_kt) {
+                    const int key = (c0 + kt) * 32 + l31;
+                    const a16x8 kh = *(const a16x8*)(Kh + key * 32 + 16 * hi), kr = *(const a16x8*)(Kr + key * 32 + 16 * hi);
+                    f32x16 c_0 = zero16(), c_1 = zero16();
+                    c_0 = MFMA_H(kh, qh, c_0);
+                    c_1 = MFMA_H(kh, qr, c_1);
+                    c_1 = MFMA_H(kr, qh, c_1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        sc[kt][r] = c_0[r] + c_1[r] * RI;
+                        if ((c0 + kt) * 32 + mfma_row(r, hi) < nq) mc = fmaxf(mc, sc[kt][r]);
+                    }
+                } else {
+                    sc[kt] = zero16();
+                }
+            }
+            mc = fmaxf(mc, __shfl_xor(mc, 32));
+            const float mn = fmaxf(m, mc);
+            const float alpha = fast_exp(m - mn);
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float ar = __shfl(alpha, mfma_row(r, hi)); o0[r] *= ar; o1[r] *= ar; }
+#pragma unroll
+            for (int kt = 0; kt < CH; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = c0 + kt < n_kt && (c0 + kt) * 32 + mfma_row(r, hi) < nq;
+                    const float e = ok ? fast_exp(sc[kt][r] - m) : 0.f;
+                    sc[kt][r] = e;
+                    l += e;
+                }
+#pragma unroll
+            for (int kt = 0; kt < CH; ++kt) {
+                if (c0 + kt < n_kt) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        float p8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) p8[j] = sc[kt][8 * u + j];
+                        a16x8 ph, pr;
+                        float c_ = 0.f, a_ = 0.f;
+                        split8(p8, ph, pr, c_, a_);
+                        const size_t va = ((size_t)colc * vs + (c0 + kt) * 32 + 8 * (2 * u + hi)) * 2;
+                        const a16x8 vh = *(const a16x8*)(Vh + va), vr = *(const a16x8*)(Vr + va);
+                        o0 = MFMA_H(ph, vh, o0);
+                        o1 = MFMA_H(ph, vr, o1);
+                        o1 = MFMA_H(pr, vh, o1);
+                    }
+                }
+            }
+        }
+        l += __shfl_xor(l, 32);
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = qt * 32 + mfma_row(r, hi);
+            const float ir = __shfl(inv, mfma_row(r, hi));
+            if (l31 < HD && row < nq) o[(size_t)(q0 + row) * ldo + h * HD + l31] = (o0[r] + o1[r] * RI) * ir;
+        }
+    }
+    if (!(fabsf(chk) < INFINITY) || amax >= 32768.0f) atomicMax(flag, run_id);
 }
 
 // split without the NaN/Inf sum: only the magnitude is tracked (a NaN operand gives NaN outputs on either path)
@@ -1458,5 +1592,25 @@ int bigc_role_fused_proj_hr8_launch(hipStream_t s, const float* p2a, int ldp, co
     if (!flag) return 0;
     hipLaunchKernelGGL(role_fused_lds16_kernel, dim3(n_vid), dim3(768), 0, s, p2a, ldp, e2a, lde, rhs, ldrhs, att, (float*)nullptr, e_off, n_vid, nq, half, d,
                        scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, 0, (unsigned char*)vals_s, ldvs, range_flag);
+    return 1;
+}
+
+// head_dim 16 self-attention through the LDS kernel above (eval: no log-sum-exp, no dropout): every sequence of up to 1024 rows;
+// returns 1 if launched
+int bigc_mha_core_hd16_lds_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                  const int32_t* off, int n_seq, int max_q, int n_head, float scale, int* flag, int run_id) {
+    static const bool off_env = getenv("BIGC_MHA_HD16_LDS") && atoi(getenv("BIGC_MHA_HD16_LDS")) == 0;
+    if (off_env || max_q < 1 || max_q > 1024 || n_seq <= 0) return 0;
+    const int tp = (max_q + 31) / 32 * 32;
+    const size_t lds = (size_t)2 * tp * 32 + (size_t)2 * 16 * (tp + 8) * 2;
+    if (max_q <= 128) {
+        static bool attr4 = false;
+        if (!attr4) { (void)hipFuncSetAttribute((const void*)mha_core_hd16_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr4 = true; }
+        hipLaunchKernelGGL(mha_core_hd16_lds_kernel<4>, dim3(n_seq * n_head), dim3(256), lds, s, q, ldq, k, ldk, v, ldv, o, ldo, off, n_head, scale, tp, flag, run_id);
+    } else {
+        static bool attr8 = false;
+        if (!attr8) { (void)hipFuncSetAttribute((const void*)mha_core_hd16_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr8 = true; }
+        hipLaunchKernelGGL(mha_core_hd16_lds_kernel<8>, dim3(n_seq * n_head), dim3(512), lds, s, q, ldq, k, ldk, v, ldv, o, ldo, off, n_head, scale, tp, flag, run_id);
+    }
     return 1;
 }

@@ -21,9 +21,10 @@ __device__ __forceinline__ f32x16 zero16() {
 // delta[row, h] = sum_d dO[row, h*hd + d] * O[row, h*hd + d].  hd / 4 lanes per (row, head), one 16-byte load each, a butterfly over the
 // group (hd in {8, 16, 32, 64}: groups of 2 .. 16 lanes): coalesced lines instead of one lane walking a 256-byte row segment
 __global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict__ dO, int lddo, const float* __restrict__ O, int ldo,
-                                                        float* __restrict__ delta, long rows, int n_head, int hd) {
+                                                        float* __restrict__ delta, long rows, int n_head, int hd, float* __restrict__ amax_slot) {
     const int g = hd >> 2;                                   // lanes per (row, head)
     const long items = rows * n_head;
+    float am = 0.f;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < items * g; t += (long)gridDim.x * 256) {
         const long i = t / g;
         const int c = (int)(t - i * g);
@@ -33,6 +34,20 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict_
         float s = (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
         for (int o = g >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o);
         if (c == 0) delta[i] = s;
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
+        if (a[0] != a[0] || a[1] != a[1] || a[2] != a[2] || a[3] != a[3]) am = INFINITY;
+    }
+    // max |dO| for the split kernels' gradient scale (attention_bwd_split.hip); bit patterns of non-negative floats order like the floats
+    // (one atomic per workgroup: 16 k same-address atomics, one per wave, cost 130 us)
+    if (amax_slot) {
+        __shared__ float wam[4];
+        for (int o = 32; o >= 1; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+        if ((threadIdx.x & 63) == 0) wam[threadIdx.x >> 6] = am;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            am = fmaxf(fmaxf(wam[0], wam[1]), fmaxf(wam[2], wam[3]));
+            if (am > 0.f) atomicMax((unsigned int*)amax_slot, __float_as_uint(am));
+        }
     }
 }
 
@@ -42,7 +57,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          float* __restrict__ dq, int lddq, const int32_t* __restrict__ q_off,
                                                          const int32_t* __restrict__ k_off, int n_seq, int n_qt, int n_head, float scale,
-                                                         const DropSpec drop) {
+                                                         const DropSpec drop, const int* __restrict__ run_flag, int run_id) {
+    if (run_flag && *run_flag != run_id) return;        // fallback launch behind attention_bwd_split.hip: only when that one flagged
     constexpr int HALF = HD / 2;
     constexpr int NTD = (HD + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -113,7 +129,9 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restric
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv,
                                                           const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
-                                                          int n_seq, int n_kt, int n_head, float scale, const DropSpec drop) {
+                                                          int n_seq, int n_kt, int n_head, float scale, const DropSpec drop,
+                                                          const int* __restrict__ run_flag, int run_id) {
+    if (run_flag && *run_flag != run_id) return;
     constexpr int HALF = HD / 2;
     constexpr int NTD = (HD + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -225,11 +243,23 @@ __global__ __launch_bounds__(256) void role_attention_bwd_kernel(const float* __
         for (int r = 0; r < 16; ++r) { s0[r] *= scale; s1[r] *= scale; }
     };
 
+    // videos of at most 64 entities (the training workloads): the score tiles of both roles are computed ONCE and kept in registers
+    // for the three passes below (each tile is 2 x half / 2 dependent f32 MFMAs: recomputing them was two thirds of this kernel)
+    const bool cached = n_et <= 2;
+    f32x16 cs0[2], cs1[2];
+    if (cached) {
+        score_tile(0, cs0[0], cs1[0]);
+        if (n_et > 1) score_tile(1, cs0[1], cs1[1]); else { cs0[1] = zero16(); cs1[1] = zero16(); }
+    }
+    auto tile = [&](int et, f32x16& s0, f32x16& s1) {
+        if (cached) { s0 = et == 0 ? cs0[0] : cs0[1]; s1 = et == 0 ? cs1[0] : cs1[1]; }
+        else score_tile(et, s0, s1);
+    };
     // pass 1: softmax-over-entities statistics of both roles
     float m0 = NEG_BIG, l0 = 0.f, m1 = NEG_BIG, l1 = 0.f;
     for (int et = 0; et < n_et; ++et) {
         f32x16 s0, s1;
-        score_tile(et, s0, s1);
+        tile(et, s0, s1);
         float t0 = NEG_BIG, t1 = NEG_BIG;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -260,7 +290,7 @@ __global__ __launch_bounds__(256) void role_attention_bwd_kernel(const float* __
     float c0 = 0.f, c1 = 0.f;
     for (int et = 0; et < n_et; ++et) {
         f32x16 s0, s1;
-        score_tile(et, s0, s1);
+        tile(et, s0, s1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = et * 32 + mfma_row(r, hi);
@@ -279,7 +309,7 @@ __global__ __launch_bounds__(256) void role_attention_bwd_kernel(const float* __
     // pass 3: ds_r = 2 g_r att_r - E_r c_r - R_r (g_0 att_0 + g_1 att_1)
     for (int et = 0; et < n_et; ++et) {
         f32x16 s0, s1;
-        score_tile(et, s0, s1);
+        tile(et, s0, s1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = et * 32 + mfma_row(r, hi);
@@ -429,6 +459,12 @@ extern "C" int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, cons
                                      float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                                      const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
                                      int n_head, int hd, float drop_p, uint32_t drop_seed, uint32_t drop_site);
+// attention_bwd_split.hip
+int bigc_mha_bwd_h_prepare(hipStream_t s, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv, int** flag, int* run_id, float** amax_slot);
+void bigc_mha_bwd_h_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* dO, int lddo,
+                           const float* lse, const float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                           const int32_t* q_off, const int32_t* k_off, int n_seq, int n_qt, int n_kt, int n_head, float scale,
+                           const DropSpec& drop, int* flag, int run_id, const float* amax_slot);
 
 extern "C" int bigc_mha_bwd_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                 const float* o, int ldo, const float* dO, int lddo, const float* lse, float* delta_scratch,
@@ -451,13 +487,24 @@ extern "C" int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, cons
     hipStream_t s = (hipStream_t)stream;
     const float scale = 1.0f / sqrtf((float)hd);
     ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
-    hipLaunchKernelGGL(mha_delta_kernel, dim3(grid_for(total_q_rows * n_head * (hd / 4))), dim3(256), 0, s, dO, lddo, o, ldo, delta_scratch, total_q_rows, n_head, hd);
+    // head_dim 64 (the BIG-C encoder / decoder layers): split-operand f16 MFMA kernels first; the f32-MFMA kernels behind them run only if
+    // an operand was out of the split's range
+    int* run_flag = nullptr;
+    int run_id = 0;
+    float* amax_slot = nullptr;
+    if (hd == 64 && !bigc_linear_get_exact() && bigc_mha_bwd_h_prepare(s, ldq, ldk, ldv, lddo, lddq, lddk, lddv, &run_flag, &run_id, &amax_slot) < 0)
+        return bigc_fail(BIGC_ERR_HIP, "mha_bwd: no flag memory");
+    hipLaunchKernelGGL(mha_delta_kernel, dim3(grid_for(total_q_rows * n_head * (hd / 4), amax_slot ? 1024 : 4096)), dim3(256), 0, s, dO, lddo, o, ldo, delta_scratch, total_q_rows, n_head, hd,
+                       amax_slot);
     BIGC_LAUNCH_CHECK("mha_delta");
     const int n_qt = cdiv(max_q, 32), n_kt = cdiv(max_k, 32);
     const int gq = (int)(((long)n_seq * n_qt * n_head + 3) / 4), gk = (int)(((long)n_seq * n_kt * n_head + 3) / 4);
 #define LAUNCH_BWD(HD) \
-    hipLaunchKernelGGL(mha_bwd_dq_kernel<HD>, dim3(gq), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dq, lddq, q_off, k_off, n_seq, n_qt, n_head, scale, drop); \
-    hipLaunchKernelGGL(mha_bwd_dkv_kernel<HD>, dim3(gk), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dk, lddk, dv, lddv, q_off, k_off, n_seq, n_kt, n_head, scale, drop)
+    hipLaunchKernelGGL(mha_bwd_dq_kernel<HD>, dim3(gq), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dq, lddq, q_off, k_off, n_seq, n_qt, n_head, scale, drop, run_flag, run_id); \
+    hipLaunchKernelGGL(mha_bwd_dkv_kernel<HD>, dim3(gk), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dk, lddk, dv, lddv, q_off, k_off, n_seq, n_kt, n_head, scale, drop, run_flag, run_id)
+    if (run_flag)
+        bigc_mha_bwd_h_launch(s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dq, lddq, dk, lddk, dv, lddv, q_off, k_off, n_seq, n_qt, n_kt, n_head, scale,
+                              drop, run_flag, run_id, amax_slot);
     switch (hd) {
         case 8: LAUNCH_BWD(8); break;
         case 16: LAUNCH_BWD(16); break;

@@ -627,7 +627,23 @@ def main():
     # features (the 256-video set is 6.7 GB; 8 ranks of it would not fit in host memory)
     props = [synthetic_proposal(base + v, n_trajs=args.n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"]).to(device)
              for v in range(args.videos)]
+    torch.cuda.synchronize()
+    tp = time.perf_counter()
     packed = PackedBatch(props, device)
+    torch.cuda.synchronize()
+    pack_ms = 1e3 * (time.perf_counter() - tp)
+    # the split-form copy of the RoI columns (fc_feat2enti.0's operand) is part of packing: written once per resident batch, outside the
+    # timed steps like the reference's proposal.to(device) -- and reported here so that nothing hides there (one pass: 4.7 GB read,
+    # 4.7 GB written per 256 videos)
+    pack_hr8_ms = 0.0
+    if os.environ.get("BIGC_FEAT_HR8", "1") != "0":
+        packed.split_features(cfg["dim_feat"])          # first call: loads the kernel, allocates the 4.7 GB
+        torch.cuda.synchronize()
+        packed.feats_hr8 = None                         # (its block goes back to torch's cache)
+        tp = time.perf_counter()
+        packed.split_features(cfg["dim_feat"])          # timed: allocation from torch's cache + the one pass
+        torch.cuda.synchronize()
+        pack_hr8_ms = 1e3 * (time.perf_counter() - tp)
     props = None
     packed.proposals = None
     n_cpu = min(args.cpu_videos, args.videos) if (rank == 0 and world == 1) else 0
@@ -893,6 +909,9 @@ def main():
         "videos_per_sec": round(args.videos * world * args.steps / elapsed, 1),
         "ms_per_step_median_each_step_synchronised": round(1e3 * float(np.median(per_step)), 3) if per_step else None,
         "triplets_last_step": int(n_out.sum()), "setup_s": round(gen_s, 1),
+        "pack_ms_once_per_resident_batch": {"ragged_pack_of_device_proposals": round(pack_ms, 1), "hr8_copy_of_roi_columns": round(pack_hr8_ms, 2),
+                                            "note": "outside the timed steps (the batch stays resident, as the reference's proposal.to(device)); "
+                                                    "per step it would add %.1f %%" % (100.0 * pack_hr8_ms / (1e3 * elapsed / args.steps))},
     }
     line.update(legs)
     print(json.dumps(line))

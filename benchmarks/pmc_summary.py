@@ -83,6 +83,19 @@ def main():
     all_w, _ = per_dispatch(os.path.join(src, "pmc_WRITE_SIZE", "pmc_counter_collection.csv"), "")
     step_f = sum(all_f[i]["FETCH_SIZE"] for i in in_step(all_f, one_step(fpath))) * 1024 * 2
     step_w = sum(all_w[i]["WRITE_SIZE"] for i in in_step(all_w, one_step(wpath))) * 1024
+    # every launch of that step in order: kernel, HBM bytes fetched (corrected) and written -- where the step's traffic goes
+    names = {}
+    for r in csv.DictReader(open(fpath)):
+        names[int(r["Dispatch_Id"])] = r["Kernel_Name"]
+    fi, wi = in_step(all_f, one_step(fpath)), in_step(all_w, one_step(wpath))
+    if len(fi) == len(wi):
+        import re
+        with open(os.path.join(dst, tag + "_pmc_step_hbm_by_launch.csv"), "w") as f:
+            f.write("launch_in_step,kernel,fetch_MB_corrected_x2,write_MB\n")
+            for i, (a, b) in enumerate(zip(fi, wi)):
+                n = re.sub(r"\(anonymous namespace\)::", "", names.get(a, "?"))
+                n = re.sub(r"\(.*", "", n).replace("void ", "")
+                f.write("%d,%s,%.1f,%.1f\n" % (i, n.replace(",", ";"), all_f[a]["FETCH_SIZE"] * 2048 / 1e6, all_w[b]["WRITE_SIZE"] * 1024 / 1e6))
     json.dump({"kernel": " + ".join(KERNEL), "launches_per_step": len(fid), "fetch_bytes_per_step": tot_f, "write_bytes_per_step": tot_w,
                "hbm_bytes_per_launch": (tot_f + tot_w) / len(fid),
                "whole_step_fetch_bytes_all_kernels": step_f, "whole_step_write_bytes_all_kernels": step_w,

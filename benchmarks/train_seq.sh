@@ -1,0 +1,24 @@
+# every launch of ONE steady-state training step (64 videos by default), in order, with its duration (rocprofv3 kernel trace):
+#   bash benchmarks/train_seq.sh [videos]        (on the GPU box; output on stdout)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+V=${1:-64}
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tseq -o bench -- python3 $R/bench.py --mode train --train-videos $V --steps 4 --warmup 2 --no-prof > /tmp/tseq.log 2>&1
+tail -1 /tmp/tseq.log | cut -c1-200
+python3 - <<PY
+import csv, re
+rows = list(csv.DictReader(open("/tmp/tseq/bench_kernel_trace.csv")))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "bbox_feat_kernel" in r["Kernel_Name"]]
+seg = rows[idx[-2]:idx[-1]]
+t0 = int(seg[0]["Start_Timestamp"])
+tot = 0
+for r in seg:
+    n = r["Kernel_Name"]
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"\(.*", "", n).replace("void ", "")
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    tot += d
+    print("%9.1f us  +%8.1f  grid %-8s wg %-4s %s" % (d / 1e3, (int(r["Start_Timestamp"]) - t0) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?")), n[:80]))
+print("kernels of the step: %.3f ms in %d launches; wall %.3f ms" % (tot / 1e6, len(seg), (int(seg[-1]["End_Timestamp"]) - t0) / 1e6))
+PY

@@ -465,6 +465,27 @@ def fast_mode_leg(args, lib, model, packed, step, ref_out, cfg, base, width, pai
         fa_elapsed = time.perf_counter() - t0
     finally:
         lib.bigc_linear_set_fast(0)
+    # the literal bf16 arithmetic of BASELINE configs[1] (operands rounded to bf16, v_mfma_f32_32x32x16_bf16; no GEMM -> GEMM chains)
+    lib.bigc_linear_set_fast(2)
+    try:
+        bf_out = model.forward_packed(packed, args.topk)
+        model.counts(bf_out)
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.fast_steps):
+            step()
+        torch.cuda.synchronize()
+        bf_elapsed = time.perf_counter() - t0
+    finally:
+        lib.bigc_linear_set_fast(0)
+    bf_same = (ref_out["soid"] == bf_out["soid"]).all(1).reshape(-1)
+    bf16 = dict(value=round(pairs_per_step * args.fast_steps / bf_elapsed, 1), unit="pairs/s (this GPU)", ms_per_step=round(1e3 * bf_elapsed / args.fast_steps, 3),
+                arithmetic="GEMM operands rounded to one bf16 (8-bit mantissa), one v_mfma_f32_32x32x16_bf16 per product, f32 accumulate; every GEMM on the "
+                           "f32-operand kernel (the split form that chains GEMMs carries f16 heads); opt-in (BIGC_FAST=bf16 / bigc_linear_set_fast(2))",
+                max_logit_diff_rel_vs_parity_mode=float((((ref_out["pred_logits"] - bf_out["pred_logits"]).abs().max(1).values * bf_same).max()
+                                                         / ref_out["pred_logits"].abs().max()).item()),
+                queries_with_other_argmax_entity=int((~bf_same).sum()), gate="recall.bf16_gate_passed")
     same_so = (ref_out["soid"] == fa_out["soid"]).all(1).reshape(-1)
     logit_rel = float((((ref_out["pred_logits"] - fa_out["pred_logits"]).abs().max(1).values * same_so).max() / ref_out["pred_logits"].abs().max()).item())
     nv = min(32, args.videos)
@@ -501,7 +522,7 @@ def fast_mode_leg(args, lib, model, packed, step, ref_out, cfg, base, width, pai
                 steps=args.fast_steps, arithmetic="GEMM operands rounded to one f16 (11-bit mantissa), one v_mfma_f32_32x32x16_f16 per product, f32 accumulate; "
                                                   "attention kernels unchanged; opt-in (BIGC_FAST=1 / bigc_linear_set_fast), never the headline",
                 max_logit_diff_rel_vs_parity_mode=logit_rel, queries_with_other_argmax_entity=int((~same_so).sum()),
-                top50_triplets_in_common_on_the_benchmark_model="%d of %d" % (common, total),
+                top50_triplets_in_common_on_the_benchmark_model="%d of %d" % (common, total), bf16=bf16,
                 recall_on_model_derived_gt=dict(gt_relations=sum(len(x) for x in gts2.values()), recall50_parity=r2_p[50], recall50_fast=r2_f[50],
                                                 recall100_parity=r2_p[100], recall100_fast=r2_f[100], abs_diff_recall50=abs(r2_p[50] - r2_f[50]),
                                                 note="GT = 12 of the parity mode's 100 best relations per video: a sensitivity figure; the gate is in `recall`"))
@@ -543,6 +564,8 @@ def recall_leg(args, lib, device):
         lib.bigc_linear_set_fast(1)
         try:
             rel["hip_fast"] = R.relations(props, model(dev_props, topk=args.topk))
+            lib.bigc_linear_set_fast(2)
+            rel["hip_bf16"] = R.relations(props, model(dev_props, topk=args.topk))
         finally:
             lib.bigc_linear_set_fast(0)
     torch.set_num_threads(usable_cores())
@@ -566,6 +589,10 @@ def recall_leg(args, lib, device):
                    abs_diff_recall50_fast_vs_parity_mode=abs(res["hip_fast"][1][50] - res["hip"][1][50]),
                    fast_gate="|R@50(reduced precision) - R@50(parity mode)| <= 1e-3 (SURVEY.md 8d)",
                    fast_gate_passed=bool(abs(res["hip_fast"][1][50] - res["hip"][1][50]) <= 1e-3))
+    if "hip_bf16" in res:
+        out.update(recall50_hip_bf16=res["hip_bf16"][1][50], recall100_hip_bf16=res["hip_bf16"][1][100], mean_ap_hip_bf16=res["hip_bf16"][0],
+                   abs_diff_recall50_bf16_vs_parity_mode=abs(res["hip_bf16"][1][50] - res["hip"][1][50]),
+                   bf16_gate_passed=bool(abs(res["hip_bf16"][1][50] - res["hip"][1][50]) <= 1e-3))
     model._engine = None
     del model
     torch.cuda.empty_cache()

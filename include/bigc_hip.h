@@ -85,11 +85,12 @@ int bigc_linear_f32(void* stream, const float* A, int lda, const int32_t* a_idx,
  * BIGC_LINEAR_EXACT.  bigc_linear_set_exact returns the previous mode. */
 int bigc_linear_set_exact(int exact);
 int bigc_linear_get_exact(void);
-/* Opt-in reduced-precision mode of the GEMMs (never the default; also env BIGC_FAST=1): operands rounded to ONE f16 each (11-bit
- * mantissa), one f16 MFMA per product instead of three, f32 accumulation.  This is the "bf16 fast mode" of the survey's build plan
- * (BASELINE configs[1]): it does NOT meet the 1e-4 logit tolerance and is gated on Recall@50 parity
- * instead (tests/test_hip_fast.py).  Ignored while the exact mode is on.  bigc_linear_set_fast returns the previous mode;
- * bigc_linear_get_fast the mode in effect. */
+/* Opt-in reduced-precision modes of the GEMMs (never the default; also env BIGC_FAST = 1 | f16 | 2 | bf16): fast = 1: operands rounded
+ * to ONE f16 each (11-bit mantissa), one f16 MFMA per product instead of three, f32 accumulation; fast = 2: the literal bf16
+ * arithmetic (operands rounded to one bf16, one bf16 MFMA per product; model forwards then do not chain GEMMs through the f16 split
+ * form).  These are the "bf16 fast mode" of the survey's build plan (BASELINE configs[1]): they do NOT
+ * meet the 1e-4 logit tolerance and are gated on Recall@50 parity instead (tests/test_hip_fast.py).  Ignored while the exact mode is
+ * on.  bigc_linear_set_fast returns the previous mode; bigc_linear_get_fast the mode in effect (0, 1 or 2). */
 int bigc_linear_set_fast(int fast);
 int bigc_linear_get_fast(void);
 
@@ -220,8 +221,8 @@ void bigc_destroy(bigc_model* m);
 int bigc_set_param(bigc_model* m, const char* key, const float* ptr, int64_t numel);
 /* resolve all keys, build derived device tables (tap-major conv weight); call again after weights change */
 int bigc_finalize(bigc_model* m, void* stream);
-/* This handle's arithmetic mode: exact (1 = every GEMM / attention kernel on the f32 MFMA) and fast (1 = the opt-in reduced-precision
- * GEMMs), each -1 to follow the process-wide default of bigc_linear_set_exact / bigc_linear_set_fast.  The mode applies to the calls
+/* This handle's arithmetic mode: exact (1 = every GEMM / attention kernel on the f32 MFMA) and fast (1 / 2 = the opt-in f16 / bf16
+ * reduced-precision GEMMs), each -1 to follow the process-wide default of bigc_linear_set_exact / bigc_linear_set_fast.  The mode applies to the calls
  * made THROUGH the handle (bigc_forward, bigc_train_*, bigc_pair_*), on the calling thread only: handles are independent of each
  * other (one per GPU and thread, as the reference's DataParallel runs its replicas, utils/DataParallel.py:68). */
 int bigc_set_mode(bigc_model* m, int exact, int fast);

@@ -75,6 +75,66 @@ def test_fast_linear_equals_the_f16_rounded_product(M, N, K, res):
     assert float(((C.double() - full).abs() / scale).max()) > 2.0 ** -16
 
 
+@pytest.mark.parametrize("M,N,K,res", [(1000, 512, 512, False), (700, 133, 300, True), (4096, 1024, 2048, False)])
+def test_bf16_linear_equals_the_bf16_rounded_product(M, N, K, res):
+    """mode 2 (BIGC_FAST=bf16 / bigc_linear_set_fast(2)), the literal bf16 arithmetic of BASELINE configs[1]: bigc_linear_f32 =
+    (bf16(A) bf16(W)^T accumulated in f32) + bias + residual.  Products of bf16 pairs are exact in f32; the weight's bf16 is rounded
+    from its cached split form (22 bits of it), so an element sitting within 2^-22 of a bf16 rounding boundary may round the other
+    way: the bound allows for one such element per dot product on top of the f32 accumulation."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    A = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) * 0.05
+    b = torch.randn(N, device=DEV, generator=g)
+    R = torch.randn(M, N, device=DEV, generator=g) if res else None
+    C = torch.full((M, N), float("nan"), device=DEV)
+    lib = _lib.load()
+    prev = lib.bigc_linear_set_fast(2)
+    try:
+        assert lib.bigc_linear_get_fast() == 2
+        _lib.check(lib.bigc_linear_f32(_lib.current_stream(), A.data_ptr(), K, None, 1, K, W.data_ptr(), K, b.data_ptr(), _lib.ptr(R), N, C.data_ptr(), N,
+                                       M, N, K, 1))
+        torch.cuda.synchronize()
+    finally:
+        lib.bigc_linear_set_fast(prev)
+    Ar, Wr = A.bfloat16().double(), W.bfloat16().double()
+    ref = torch.relu(Ar @ Wr.t() + b.double())
+    if res:
+        ref = ref + R.double()
+    scale = Ar.abs() @ Wr.abs().t() + b.double().abs()
+    err = float(((C.double() - ref).abs() / scale).max())
+    assert err < 8 * 2.0 ** -24 + 2.0 ** -8 / K * 4, err          # f32 accumulation + (rarely) one weight element rounded the other way
+    # it is the bf16 product, not the f16-rounded one and not the full-precision one
+    f16ref = torch.relu(A.half().double() @ W.half().double().t() + b.double()) + (R.double() if res else 0)
+    assert float(((C.double() - f16ref).abs() / scale).max()) > 2.0 ** -13
+    assert not torch.isnan(C).any()
+
+
+def test_bf16_mode_of_a_model_handle():
+    """bigc_set_mode(handle, fast = 2): the model forward in the bf16 arithmetic (no GEMM -> GEMM chains through the f16 split form).
+    It runs, differs from the parity mode by bf16-sized amounts, and leaves no trace once the handle is back in the default mode
+    (its Recall@50 gate is bench.py's `recall.bf16_gate_passed`, on a trained model)."""
+    cfg, variant, sd, props, _topk = cases.make_case("bigc_v_n64")
+    from test_hip_bigc import build_model
+    model = build_model(cfg, variant, sd)
+    dev_props = [p.to(DEV) for p in props]
+    packed = PackedBatch([p for p in dev_props if p.num_proposals > 0], DEV)
+    ref = model.forward_packed(packed, 10)
+    torch.cuda.synchronize()
+    ref_logits = ref["pred_logits"].clone()
+    model.engine().set_mode(fast=2)
+    try:
+        out = model.forward_packed(packed, 10)
+        torch.cuda.synchronize()
+        d = float((out["pred_logits"] - ref_logits).abs().max() / ref_logits.abs().max())
+    finally:
+        model.engine().set_mode(fast=-1)
+    assert 1e-5 < d < 10.0, d          # (sharp-attention seeded weights: bf16 flips arg-max entities, whole logit rows change)
+    assert torch.isfinite(out["pred_logits"]).all()
+    again = model.forward_packed(packed, 10)
+    torch.cuda.synchronize()
+    assert torch.equal(again["pred_logits"], ref_logits)
+
+
 def test_fast_gemm_ps_reads_the_heads_only():
     """bigc_gemm_ps on an hr8 operand in fast mode = product of the f16 heads of both operands (activations stored as x * 8,
     weights scaled per matrix by a power of two: the heads are f16(x * 2^e) / 2^e), f32 and hr8 outputs"""

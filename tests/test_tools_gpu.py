@@ -120,6 +120,9 @@ def test_bench_json_contract():
     assert rc["recall50_oracle"] > 0 and rc["recall50_hip"] == rc["recall50_oracle"] and rc["parity_gate_passed"] is True
     assert rc["relations_hip"] == rc["relations_oracle"] > 0 and "fast_gate_passed" in rc and rc["abs_diff_recall50_fast_vs_parity_mode"] <= 0.05
     assert 1e-6 < f["max_logit_diff_rel_vs_parity_mode"] < 0.2
+    # the literal bf16 arithmetic of BASELINE configs[1] rides along too, with the same gate
+    assert f["bf16"]["value"] > 0 and f["bf16"]["max_logit_diff_rel_vs_parity_mode"] > 1e-5
+    assert "bf16_gate_passed" in rc and rc["abs_diff_recall50_bf16_vs_parity_mode"] <= 0.05
     assert r["sustained_mfma_peak"]["three_mfma_gemm_ceiling"] > 0
     # the oracle outputs of the CPU-baseline sample are compared row for row with the HIP outputs of the same videos
     op = d["oracle_parity"]

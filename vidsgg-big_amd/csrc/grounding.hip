@@ -801,7 +801,7 @@ extern "C" int grd_set_param(grd_model* m, const char* key, const float* ptr, in
 }
 
 extern "C" int grd_set_mode(grd_model* m, int exact, int fast) {
-    BIGC_CHECK_ARG(m && exact >= -1 && exact <= 1 && fast >= -1 && fast <= 1, "grd_set_mode: exact / fast must be -1 (process default), 0 or 1");
+    BIGC_CHECK_ARG(m && exact >= -1 && exact <= 1 && fast >= -1 && fast <= 2, "grd_set_mode: exact must be -1 (process default), 0 or 1; fast -1, 0, 1 (f16) or 2 (bf16)");
     m->mode_exact = exact; m->mode_fast = fast;
     return BIGC_OK;
 }

@@ -18,6 +18,7 @@
 #include "prof.h"
 #include <stdlib.h>
 #include <atomic>
+#include <string.h>
 
 namespace {
 
@@ -256,11 +257,22 @@ static std::atomic<int> g_exact_mode{(getenv("BIGC_LINEAR_EXACT") && atoi(getenv
 thread_local int bigc_mode_exact_override = -1, bigc_mode_fast_override = -1;
 extern "C" int bigc_linear_set_exact(int exact) { return g_exact_mode.exchange(exact ? 1 : 0); }
 extern "C" int bigc_linear_get_exact(void) { return bigc_mode_exact_override >= 0 ? bigc_mode_exact_override : g_exact_mode.load(); }
-// Opt-in reduced-precision mode of the split-operand GEMM kernels (linear_split.hip, gemm_ps.hip): every operand rounded to one
-// f16 (11-bit mantissa), ONE v_mfma_f32_32x32x16_f16 per product, f32 accumulation -- the "bf16 fast mode" of SURVEY section 7
-// step 10, gated on Recall@50 parity instead of the 1e-4 logit tolerance.  Never the default; initialised from BIGC_FAST.
-static std::atomic<int> g_fast_mode{(getenv("BIGC_FAST") && atoi(getenv("BIGC_FAST")) != 0) ? 1 : 0};
-extern "C" int bigc_linear_set_fast(int fast) { return g_fast_mode.exchange(fast ? 1 : 0); }
+// Opt-in reduced-precision modes of the split-operand GEMM kernels (linear_split.hip, gemm_ps.hip), the "bf16 fast mode" of SURVEY
+// section 7 step 10 / BASELINE configs[1], gated on Recall@50 parity instead of the 1e-4 logit tolerance:
+//   1 (BIGC_FAST=1 / f16)   every operand rounded to one f16 (11-bit mantissa), ONE v_mfma_f32_32x32x16_f16 per product, f32 accumulation
+//   2 (BIGC_FAST=2 / bf16)  the literal bf16 arithmetic: operands rounded to one bf16 (8-bit mantissa), v_mfma_f32_32x32x16_bf16; the model
+//                           forwards then do not chain GEMMs through the split form (it carries f16 heads), every GEMM runs on linear_split
+// Never the default; initialised from BIGC_FAST.
+static int fast_from_env() {
+    const char* e = getenv("BIGC_FAST");
+    if (!e) return 0;
+    if (!strcmp(e, "bf16")) return 2;
+    if (!strcmp(e, "f16")) return 1;
+    const int v = atoi(e);
+    return v == 2 ? 2 : (v != 0 ? 1 : 0);
+}
+static std::atomic<int> g_fast_mode{fast_from_env()};
+extern "C" int bigc_linear_set_fast(int fast) { return g_fast_mode.exchange(fast == 2 ? 2 : (fast ? 1 : 0)); }
 extern "C" int bigc_linear_get_fast(void) {
     if (bigc_linear_get_exact()) return 0;
     return bigc_mode_fast_override >= 0 ? bigc_mode_fast_override : g_fast_mode.load();

@@ -141,15 +141,26 @@ __device__ __forceinline__ void split_rtn2(float x0, float x1, unsigned& h, unsi
     r = *(const unsigned*)&rr;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // v_cvt_pk_bf16_f32: round to nearest even
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    return *(const unsigned*)&h;
+}
+
 __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((row >> 2) & 3); }
 
 // WN = wave columns: 2 -> 128x128 tile, 256 threads, two workgroups per CU; 4 -> 128x256 tile, 512 threads (one workgroup
 // per CU, same two waves per SIMD): the A slab is split once for eight waves instead of four.
 // DWK > 0: depth-wise-separable mode (LinearArgs::dw_*), DWK = kernel size of the depth-wise convolution.
 // PRE8: preceding-layer mode (LinearArgs::pre_*).
-// FAST: the opt-in reduced-precision mode (bigc_linear_set_fast / BIGC_FAST=1, linear.hip): operands rounded to ONE f16 each,
-// one MFMA per product -- the residual planes are neither written nor read and the correction accumulator stays zero.
-template <bool GATHER, bool KTAIL, int WN, int DWK = 0, bool PRE8 = false, bool FAST = false>
+// FAST: the opt-in reduced-precision modes (bigc_linear_set_fast / BIGC_FAST, linear.hip): 1 = operands rounded to ONE f16 each,
+// 2 = to one bf16 each (the literal "bf16" run of BASELINE configs[1]: 8-bit mantissa, v_mfma_f32_32x32x16_bf16; the weight's bf16
+// is rounded from its cached split form h + r 2^-11, which holds 22 bits of it); one MFMA per product -- the residual planes are
+// neither written nor read and the correction accumulator stays zero.  The range checks are those of the split (|x| < 32768).
+template <bool GATHER, bool KTAIL, int WN, int DWK = 0, bool PRE8 = false, int FAST = 0>
 __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linear_split_kernel(const LinearArgs p) {
     constexpr int NTH = 128 * WN, BNT = 64 * WN;     // threads, tile width
     constexpr int RPP = NTH / 8;                     // rows staged per pass (8 threads x 16 bytes per 32-k row)
@@ -310,12 +321,25 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
         for (int i = 0; i < NA; ++i) {
             uint2 h, r;
             split4(ra[i], h, r, chk, amax);
+            if (FAST == 2) h = make_uint2(pk_bf16(ra[i][0], ra[i][1]), pk_bf16(ra[i][2], ra[i][3]));
             *(uint2*)(&smem[buf][soff[i]]) = h;
             if (!FAST) *(uint2*)(&smem[buf][PA + soff[i]]) = r;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            *(uint2*)(&smem[buf][2 * PA + soff[i]]) = make_uint2(rb[i][0], rb[i][1]);
+            if (FAST == 2) {
+                float w[4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned hu = rb[i][j], ru = rb[i][2 + j];
+                    const fp16x2 hh = *(const fp16x2*)&hu, rr = *(const fp16x2*)&ru;
+                    w[2 * j] = (float)hh[0] + (float)rr[0] * (1.0f / RSCALE);
+                    w[2 * j + 1] = (float)hh[1] + (float)rr[1] * (1.0f / RSCALE);
+                }
+                *(uint2*)(&smem[buf][2 * PA + soff[i]]) = make_uint2(pk_bf16(w[0], w[1]), pk_bf16(w[2], w[3]));
+            } else {
+                *(uint2*)(&smem[buf][2 * PA + soff[i]]) = make_uint2(rb[i][0], rb[i][1]);
+            }
             if (!FAST) *(uint2*)(&smem[buf][2 * PA + PW + soff[i]]) = make_uint2(rb[i][2], rb[i][3]);
         }
     };
@@ -361,7 +385,8 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    acc0[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mi], b1[ni], acc0[mi][ni], 0, 0, 0);
+                    if (FAST == 2) acc0[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&a1[mi], *(const bf16x8*)&b1[ni], acc0[mi][ni], 0, 0, 0);
+                    else acc0[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mi], b1[ni], acc0[mi][ni], 0, 0, 0);
                     if (!FAST) {
                         acc1[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mi], b2[ni], acc1[mi][ni], 0, 0, 0);
                         acc1[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[mi], b1[ni], acc1[mi][ni], 0, 0, 0);
@@ -782,9 +807,10 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
         BIGC_LAUNCH_CHECK("linear_split (dwsep)");
         return BIGC_OK;
     }
-#define LAUNCH_SPLIT(G, T, W) do { if (fast) hipLaunchKernelGGL((linear_split_kernel<G, T, W, 0, false, true>), dim3(grid2), dim3(128 * W), 0, s, p); \
+#define LAUNCH_SPLIT(G, T, W) do { if (fast == 2) hipLaunchKernelGGL((linear_split_kernel<G, T, W, 0, false, 2>), dim3(grid2), dim3(128 * W), 0, s, p); \
+                                   else if (fast) hipLaunchKernelGGL((linear_split_kernel<G, T, W, 0, false, 1>), dim3(grid2), dim3(128 * W), 0, s, p); \
                                    else hipLaunchKernelGGL((linear_split_kernel<G, T, W>), dim3(grid2), dim3(128 * W), 0, s, p); } while (0)
-    const bool fast = bigc_linear_get_fast() != 0;
+    const int fast = bigc_linear_get_fast();
     if (wn == 4) {
         if (p.a_idx) { if (ktail) LAUNCH_SPLIT(true, true, 4); else LAUNCH_SPLIT(true, false, 4); }
         else { if (ktail) LAUNCH_SPLIT(false, true, 4); else LAUNCH_SPLIT(false, false, 4); }

@@ -194,7 +194,7 @@ extern "C" int bigc_set_param(bigc_model* m, const char* key, const float* ptr, 
 }
 
 extern "C" int bigc_set_mode(bigc_model* m, int exact, int fast) {
-    BIGC_CHECK_ARG(m && exact >= -1 && exact <= 1 && fast >= -1 && fast <= 1, "set_mode: exact / fast must be -1 (process default), 0 or 1");
+    BIGC_CHECK_ARG(m && exact >= -1 && exact <= 1 && fast >= -1 && fast <= 2, "set_mode: exact must be -1 (process default), 0 or 1; fast -1, 0, 1 (f16) or 2 (bf16)");
     m->mode_exact = exact; m->mode_fast = fast;
     return BIGC_OK;
 }
@@ -595,11 +595,12 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
     // operand and the dimensions fit.  Measured on the benchmark step: 23.4 ms against 21.1 ms for the default path below
     // ("gemm_ps"), so it is not the default.
     static const bool ps_on = getenv("BIGC_PS") && atoi(getenv("BIGC_PS")) != 0;
-    if (out->range_flag && ps_on && !bigc_linear_get_exact() && ps_config_ok(c)) return forward_ps(m, stream, b, w, topk, out);
+    if (out->range_flag && ps_on && !bigc_linear_get_exact() && bigc_linear_get_fast() != 2 && ps_config_ok(c)) return forward_ps(m, stream, b, w, topk, out);
     if (out->range_flag && hipMemsetAsync(out->range_flag, 0, sizeof(int32_t), hs) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: memset failed");
     // chained mode (default when the caller reads the range flag; BIGC_CHAINED=0 switches it off): see run_frontend_chained
     static const bool chained_off = getenv("BIGC_CHAINED") && atoi(getenv("BIGC_CHAINED")) == 0;
-    const bool chained = out->range_flag && !chained_off && !bigc_linear_get_exact() && ps_config_ok(c);
+    // (not in the bf16 mode: the split form carries f16 heads, so a GEMM on pre-split operands could only round to f16)
+    const bool chained = out->range_flag && !chained_off && !bigc_linear_get_exact() && bigc_linear_get_fast() != 2 && ps_config_ok(c);
     PsCtx cx{hs, w.flag};
     if (chained && hipMemsetAsync(w.flag, 0, sizeof(int32_t), hs) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: memset failed");
     const int NT = b->n_trk, B = b->n_vid, Q = c.num_querys, BQ = B * Q;

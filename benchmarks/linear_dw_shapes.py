@@ -16,10 +16,13 @@ SHAPES = [("fc_feat2enti.0", 144824, 512, 2048), ("fc_*2enti.2", 144824, 512, 51
 def main():
     lib = _lib.load()
     dev = "cuda:0"
-    for exact in (1, 0):
+    only = int(sys.argv[sys.argv.index("--only") + 1]) if "--only" in sys.argv else None      # --only i: shape i, split mode only
+    for exact in ((0,) if only is not None else (1, 0)):
         lib.bigc_linear_set_exact(exact)
         print("== exact f32 MFMA" if exact else "== split f16x3")
-        for name, M, N, K in SHAPES + [("conv k3s2 (gather)", 129792, 512, 3072)]:
+        for si, (name, M, N, K) in enumerate(SHAPES + [("conv k3s2 (gather)", 129792, 512, 3072)]):
+            if only is not None and si != only:
+                continue
             gather = "gather" in name
             dY = torch.randn(M, N, device=dev) * 0.1
             X = torch.randn(M, K // 3 if gather else K, device=dev)

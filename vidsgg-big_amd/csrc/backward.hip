@@ -163,6 +163,8 @@ typedef __fp16 hp16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int dw_swz(int chunk, int row) { return chunk ^ ((row >> 2) & 3); }
 
 // 16 consecutive-m values of one column -> 32 bytes of heads + 32 bytes of scaled residuals, written into the column's LDS row
+// (scalar f32 arithmetic on purpose: the same split written on 2-vectors compiles to v_pk_add_f32 / v_pk_mul_f32, 19 % fewer VALU
+// instructions and 7 % MORE time -- packed f32 instructions stall the issue beside MFMAs)
 __device__ __forceinline__ void dw_split16(const float (&x)[16], unsigned char* head_row, unsigned char* resid_row, int row, int mh,
                                            float& chk, float& amax) {
 #pragma unroll
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(256, 2) void linear_dw_split_kernel(const DwArgs p)
     const int n0 = tn * 128, k0 = tk * 128;
     const int m_begin = split * p.m_chunk, m_end = min(p.M, m_begin + p.m_chunk);
     if (m_begin >= m_end) return;
-    const int c = tid & 127, mh = tid >> 7;
+    const int c = tid & 127;
+    const int mh = __builtin_amdgcn_readfirstlane(tid >> 7);                   // wave-uniform: the rows a wave loads are scalar addresses
     const int ncol = min(n0 + c, p.N - 1), kcol = min(k0 + c, p.K - 1);       // clamped: surplus rows of dW are never stored
     const bool nval = n0 + c < p.N;
     int seg = 0, kin = kcol;
@@ -221,14 +224,36 @@ __global__ __launch_bounds__(256, 2) void linear_dw_split_kernel(const DwArgs p)
     int ridx[16];                                   // gather mode: source rows of the NEXT slab to load (fetched one slab ahead,
                                                     // so the data loads never wait on their own index loads)
     float bsum = 0.f, chk = 0.f, amax = 0.f;
+    const bool do_bias = p.db && tk == 0;           // (uniform) the bias gradient is the column sum of dY: only the first k tile adds it up
     auto load_idx = [&](int m0) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) ridx[j] = p.x_idx[(size_t)min(m0 + mh * 16 + j, m_end - 1) * p.nseg + seg];
     };
+    // The loop is VALU-bound (rocprofv3 --pmc, benchmarks/pmc_dw.sh: 15 VALU instructions per MFMA, the matrix pipe 27 % busy and
+    // hardly ever at the same time as the VALU): a full slab -- all but the last of a split -- is 32 loads off wave-uniform row
+    // bases without clamps or selects
     auto load_slab = [&](int m0) {
+        const int mb = m0 + mh * 16;
+        if (mb + 16 <= m_end) {
+            const float* yp = p.dY + (size_t)mb * p.ldy + ncol;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) ry[j] = yp[(size_t)j * p.ldy];
+            if (GATHER) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float xv = p.X[(size_t)max(ridx[j], 0) * p.ldx + kin];
+                    rx[j] = ridx[j] < 0 ? 0.f : xv;
+                }
+            } else {
+                const float* xp = p.X + (size_t)mb * p.ldx + kcol;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) rx[j] = xp[(size_t)j * p.ldx];
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int m = m0 + mh * 16 + j;
+            const int m = mb + j;
             const bool mv = m < m_end;
             const int mc = min(m, m_end - 1);
             const float y = p.dY[(size_t)mc * p.ldy + ncol];
@@ -244,8 +269,10 @@ __global__ __launch_bounds__(256, 2) void linear_dw_split_kernel(const DwArgs p)
         }
     };
     auto store_slab = [&](int buf) {
+        if (do_bias) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) bsum += ry[j];
+            for (int j = 0; j < 16; ++j) bsum += ry[j];
+        }
         dw_split16(ry, smem[buf][0], smem[buf][1], c, mh, chk, amax);
         dw_split16(rx, smem[buf][2], smem[buf][3], c, mh, chk, amax);
     };
@@ -283,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void linear_dw_split_kernel(const DwArgs p)
         if (more) store_slab(buf ^ 1);
         __syncthreads();
     }
-    if (p.db && tk == 0 && nval) atomicAdd(&p.db[n0 + c], bsum);
+    if (do_bias && nval) atomicAdd(&p.db[n0 + c], bsum);
     if (__syncthreads_or((!(fabsf(chk) < INFINITY) || amax >= 32768.0f) ? 1 : 0)) {
         // exact f32 MFMA straight from memory: lane (l31, hi) of block a / b owns row n / column k, m = m2 + hi
 #pragma unroll

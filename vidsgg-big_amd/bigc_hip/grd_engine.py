@@ -153,8 +153,9 @@ class GrdEngine(object):
         k, d = self.c.num_bins, self.c.dim_hidden
         feat = torch.cat([j[0].to(dtype=torch.float32) for j in jobs], 0).contiguous()
         assert feat.is_cuda and feat.shape[1] == self.c.dim_feat
-        q32 = torch.cat([j[1].to(device=dev, dtype=torch.int32) for j in jobs], 0).contiguous()
-        d32 = torch.cat([j[2].to(device=dev, dtype=torch.int32) for j in jobs], 0).contiguous()
+        # (concatenate first, convert once: one conversion kernel per table instead of one per video)
+        q32 = torch.cat([j[1].to(device=dev) for j in jobs], 0).to(torch.int32).contiguous()
+        d32 = torch.cat([j[2].to(device=dev) for j in jobs], 0).to(torch.int32).contiguous()
         q_vid = np.repeat(np.arange(V), nq)
         tables = [np.concatenate([[0], np.cumsum(T)]), q_vid, np.concatenate([[0], np.cumsum(T[q_vid])])]
         sizes = [(len(a) + 3) // 4 * 4 for a in tables]

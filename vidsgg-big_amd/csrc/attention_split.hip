@@ -399,14 +399,16 @@ __global__ __launch_bounds__(64 * NW) void mha_core_hd16_lds_kernel(const float*
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float ar = __shfl(alpha, mfma_row(r, hi)); o0[r] *= ar; o1[r] *= ar; }
 #pragma unroll
-            for (int kt = 0; kt < CH; ++kt)
+            for (int kt = 0; kt < CH; ++kt) {
+                if (c0 + kt >= n_kt) continue;              // (uniform; a tile past the sequence would only add zeros: skipping it changes no bit)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const bool ok = c0 + kt < n_kt && (c0 + kt) * 32 + mfma_row(r, hi) < nq;
+                    const bool ok = (c0 + kt) * 32 + mfma_row(r, hi) < nq;
                     const float e = ok ? fast_exp(sc[kt][r] - m) : 0.f;
                     sc[kt][r] = e;
                     l += e;
                 }
+            }
 #pragma unroll
             for (int kt = 0; kt < CH; ++kt) {
                 if (c0 + kt < n_kt) {
@@ -1603,14 +1605,16 @@ int bigc_mha_core_hd16_lds_launch(hipStream_t s, const float* q, int ldq, const 
     if (off_env || max_q < 1 || max_q > 1024 || n_seq <= 0) return 0;
     const int tp = (max_q + 31) / 32 * 32;
     const size_t lds = (size_t)2 * tp * 32 + (size_t)2 * 16 * (tp + 8) * 2;
-    if (max_q <= 128) {
-        static bool attr4 = false;
-        if (!attr4) { (void)hipFuncSetAttribute((const void*)mha_core_hd16_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr4 = true; }
-        hipLaunchKernelGGL(mha_core_hd16_lds_kernel<4>, dim3(n_seq * n_head), dim3(256), lds, s, q, ldq, k, ldk, v, ldv, o, ldo, off, n_head, scale, tp, flag, run_id);
-    } else {
-        static bool attr8 = false;
-        if (!attr8) { (void)hipFuncSetAttribute((const void*)mha_core_hd16_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr8 = true; }
-        hipLaunchKernelGGL(mha_core_hd16_lds_kernel<8>, dim3(n_seq * n_head), dim3(512), lds, s, q, ldq, k, ldk, v, ldv, o, ldo, off, n_head, scale, tp, flag, run_id);
-    }
+    // waves per workgroup by the longest sequence (the arithmetic of a sequence does not depend on it: wave w takes the query tiles
+    // w, w + NW, ...): one wave for sequences of at most 32 rows (the query encoder's 3 tokens: 8784 workgroups of four waves, three
+    // of them idle, took 203 us), two up to 64, four up to 128, eight above
+#define LAUNCH_HD16(NWV) do { static bool attr = false; \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)mha_core_hd16_lds_kernel<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; } \
+        hipLaunchKernelGGL(mha_core_hd16_lds_kernel<NWV>, dim3(n_seq * n_head), dim3(64 * NWV), lds, s, q, ldq, k, ldk, v, ldv, o, ldo, off, n_head, scale, tp, flag, run_id); } while (0)
+    if (max_q <= 32) LAUNCH_HD16(1);
+    else if (max_q <= 64) LAUNCH_HD16(2);
+    else if (max_q <= 128) LAUNCH_HD16(4);
+    else LAUNCH_HD16(8);
+#undef LAUNCH_HD16
     return 1;
 }

@@ -15,7 +15,7 @@ for P in "$P1" "$P3" "$P4"; do
 done
 F="$F" python3 - <<'PY'
 import csv, glob, collections, os
-flt = os.environ["F"].split(",")
+flt = os.environ["F"].split("|")
 for one in flt:
     tot = collections.defaultdict(float); n = collections.Counter()
     for f in glob.glob("/tmp/pmc_ek/p*/**/*counter_collection.csv", recursive=True):

@@ -186,12 +186,12 @@ __device__ __forceinline__ void dw_split16(const float (&x)[16], unsigned char* 
 }
 
 template <bool GATHER>
-__global__ __launch_bounds__(256, 2) void linear_dw_split_kernel(const DwArgs p) {
+__device__ __forceinline__ void linear_dw_split_body(const DwArgs& p, const int bid) {
     // [buffer][dY^T head | dY^T resid | X^T head | X^T resid][128 rows][64 bytes = 32 m]
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][4][128 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, l31 = lane & 31;
-    const int tile = blockIdx.x % (p.tiles_n * p.tiles_k), split = blockIdx.x / (p.tiles_n * p.tiles_k);
+    const int tile = bid % (p.tiles_n * p.tiles_k), split = bid / (p.tiles_n * p.tiles_k);
     const int tn = tile / p.tiles_k, tk = tile % p.tiles_k;
     const int n0 = tn * 128, k0 = tk * 128;
     const int m_begin = split * p.m_chunk, m_end = min(p.M, m_begin + p.m_chunk);
@@ -358,6 +358,54 @@ __global__ __launch_bounds__(256, 2) void linear_dw_split_kernel(const DwArgs p)
             }
         }
     if (p.partial && p.arrived) dw_finish_tile(p, tile, n0, k0);
+}
+
+template <bool GATHER>
+__global__ __launch_bounds__(256, 2) void linear_dw_split_kernel(const DwArgs p) { linear_dw_split_body<GATHER>(p, blockIdx.x); }
+
+// Several weight-gradient products in ONE launch (the eleven of a decoder layer: 512 x 512 .. 1024 x 512 outputs whose
+// contraction over the B*Q rows has to be split to fill the chip -- one by one they were 16 tiles x 32 splits of twelve slabs
+// each plus a reduction launch per product; together they are 224 tiles, two splits, one reduction launch).  The workgroups of
+// job j are start[j] .. start[j + 1] - 1.
+constexpr int DW_GROUP_MAX = 12;
+struct DwGroup { int n; int start[DW_GROUP_MAX + 1]; DwArgs job[DW_GROUP_MAX]; };
+
+__global__ __launch_bounds__(256, 2) void linear_dw_group_kernel(const DwGroup g) {
+    int j = 0;
+    while (j + 1 < g.n && (int)blockIdx.x >= g.start[j + 1]) ++j;
+    linear_dw_split_body<false>(g.job[j], (int)blockIdx.x - g.start[j]);
+}
+
+// the reductions of a group's partial products in one launch: workgroups start[j] .. start[j + 1] - 1 walk job j's N x K elements
+__global__ __launch_bounds__(256) void dw_reduce_group_kernel(const DwGroup g) {
+    int j = 0;
+    while (j + 1 < g.n && (int)blockIdx.x >= g.start[j + 1]) ++j;
+    const DwArgs& p = g.job[j];
+    if (!p.partial) return;
+    const int nb = g.start[j + 1] - g.start[j], b = (int)blockIdx.x - g.start[j];
+    const size_t n_pad = (size_t)p.tiles_n * 128, k_pad = (size_t)p.tiles_k * 128;
+    if (((p.K | p.ldw) & 3) == 0 && ((uintptr_t)p.dW & 15) == 0) {      // (gradient views of the flat buffer need not be 16-byte aligned)
+        // four consecutive k per thread (16-byte accesses), one or two passes per thread
+        const int K4 = p.K >> 2;
+        const long total = (long)p.N * K4;
+        for (long i = (long)b * 256 + threadIdx.x; i < total; i += (long)nb * 256) {
+            const int n = (int)(i / K4), k = (int)(i - (long)n * K4) * 4;
+            const float* src = p.partial + (size_t)n * k_pad + k;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < p.splits; ++sp) s += *(const f32x4*)(src + (size_t)sp * n_pad * k_pad);
+            f32x4* dst = (f32x4*)(p.dW + (size_t)n * p.ldw + k);
+            *dst = *dst + s;
+        }
+        return;
+    }
+    const long total = (long)p.N * p.K;
+    for (long i = (long)b * 256 + threadIdx.x; i < total; i += (long)nb * 256) {
+        const int n = (int)(i / p.K), k = (int)(i - (long)n * p.K);
+        const float* src = p.partial + (size_t)n * k_pad + k;
+        float s = 0.f;
+        for (int sp = 0; sp < p.splits; ++sp) s += src[(size_t)sp * n_pad * k_pad];
+        p.dW[(size_t)n * p.ldw + k] += s;
+    }
 }
 
 // dW[n, k] += sum over the M splits of their partial products (no atomics: summation order is fixed -> deterministic gradients)
@@ -708,6 +756,85 @@ extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const 
             hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for((long)N * K)), dim3(256), 0, (hipStream_t)stream, p.partial, dW, ldw, N, K, (int)n_pad,
                                (int)k_pad, splits);
             BIGC_LAUNCH_CHECK("dw_reduce");
+        }
+    }
+    return BIGC_OK;
+}
+
+// Grouped form of bigc_linear_dw_f32 (no gather): jobs[i] = {dY, ldy, X, ldx, dW, ldw, db, M, N, K}.  The operands must stay
+// untouched until the launch has run (the caller -- train.hip's decoder layer -- hands over buffers nothing writes to before its
+// flush).  Exact mode and single products go through bigc_linear_dw_f32.
+int bigc_linear_dw_group(void* stream, const BigcDwJob* jobs, int n) {
+    if (n <= 0) return BIGC_OK;
+    if (n == 1 || bigc_linear_get_exact()) {
+        for (int i = 0; i < n; ++i) {
+            const BigcDwJob& q = jobs[i];
+            int rc = bigc_linear_dw_f32(stream, q.dY, q.ldy, q.X, q.ldx, nullptr, 1, q.K, q.dW, q.ldw, q.db, q.M, q.N, q.K);
+            if (rc != BIGC_OK) return rc;
+        }
+        return BIGC_OK;
+    }
+    for (int base = 0; base < n; base += DW_GROUP_MAX) {
+        const int cnt = n - base < DW_GROUP_MAX ? n - base : DW_GROUP_MAX;
+        DwGroup g, r;
+        g.n = r.n = cnt;
+        long tiles_total = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const BigcDwJob& q = jobs[base + i];
+            BIGC_CHECK_ARG(q.dY && q.X && q.dW && q.M > 0 && q.N > 0 && q.K > 0, "linear_dw_group: bad job %d", base + i);
+            tiles_total += (long)cdiv(q.N, 128) * cdiv(q.K, 128);
+        }
+        // about two workgroups per CU over the whole group; every split reduces at least 128 rows
+        int want = (int)cdiv(512, (int)tiles_total);
+        if (want < 1) want = 1;
+        size_t need = 0;
+        int blocks = 0, rblocks = 0;
+        double flops = 0, bytes = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const BigcDwJob& q = jobs[base + i];
+            DwArgs& p = g.job[i];
+            p.dY = q.dY; p.ldy = q.ldy; p.X = q.X; p.ldx = q.ldx; p.x_idx = nullptr; p.nseg = 1; p.seg_len = q.K;
+            p.dW = q.dW; p.ldw = q.ldw; p.db = q.db; p.M = q.M; p.N = q.N; p.K = q.K;
+            p.tiles_n = cdiv(q.N, 128); p.tiles_k = cdiv(q.K, 128);
+            int splits = want;
+            const int max_splits = cdiv(q.M, 128);
+            if (splits > max_splits) splits = max_splits;
+            p.m_chunk = cdiv(cdiv(q.M, splits), 32) * 32;
+            splits = cdiv(q.M, p.m_chunk);
+            p.splits = splits; p.arrived = nullptr; p.partial = nullptr;
+            g.start[i] = blocks;
+            blocks += p.tiles_n * p.tiles_k * splits;
+            if (splits > 1) need += (size_t)splits * p.tiles_n * 128 * p.tiles_k * 128;
+            flops += 2.0 * q.M * (double)q.N * q.K;
+            bytes += 4.0 * ((double)q.M * q.N + (double)q.M * q.K + (double)q.N * q.K);
+        }
+        g.start[cnt] = blocks;
+        if (need) {
+            static float* scratch = nullptr;      // stream-ordered, grown on demand (as bigc_linear_dw_f32's)
+            static size_t cap = 0;
+            if (need > cap) {
+                if (scratch) { if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_dw_group: sync failed"); (void)hipFree(scratch); }
+                cap = need + need / 2;
+                if (hipMalloc((void**)&scratch, cap * sizeof(float)) != hipSuccess) { scratch = nullptr; cap = 0; return bigc_fail(BIGC_ERR_HIP, "linear_dw_group: hipMalloc of the split scratch failed"); }
+            }
+            size_t off = 0;
+            for (int i = 0; i < cnt; ++i) {
+                DwArgs& p = g.job[i];
+                if (p.splits > 1) { p.partial = scratch + off; off += (size_t)p.splits * p.tiles_n * 128 * p.tiles_k * 128; }
+            }
+        }
+        r = g;
+        for (int i = 0; i < cnt; ++i) {          // reduction launch: one workgroup per 2 K output elements of a job (two 16-byte quads per thread)
+            r.start[i] = rblocks;
+            if (g.job[i].partial) { const long e = (long)g.job[i].N * g.job[i].K; rblocks += (int)((e + 2047) / 2048); }
+        }
+        r.start[cnt] = rblocks;
+        ProfScope ps(stream, FAM_LINEAR_DW, flops, bytes);
+        hipLaunchKernelGGL(linear_dw_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+        BIGC_LAUNCH_CHECK("linear_dw_group");
+        if (rblocks > 0) {
+            hipLaunchKernelGGL(dw_reduce_group_kernel, dim3(rblocks), dim3(256), 0, (hipStream_t)stream, r);
+            BIGC_LAUNCH_CHECK("dw_reduce_group");
         }
     }
     return BIGC_OK;

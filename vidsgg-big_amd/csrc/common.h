@@ -35,6 +35,10 @@ int bigc_fail(int code, const char* fmt, ...);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// one weight-gradient product dW (N, K) += dY^T (M, N) X (M, K), db += column sums of dY (backward.hip: bigc_linear_dw_group)
+struct BigcDwJob { const float* dY; int ldy; const float* X; int ldx; float* dW; int ldw; float* db; int M, N, K; };
+int bigc_linear_dw_group(void* stream, const BigcDwJob* jobs, int n);
+
 // ---- dropout (training paths) ---------------------------------------------------------------------------------------------
 // Counter-based masks: element `idx` of dropout site `site` is kept iff hash(seed, site, idx) >= p * 2^32; kept values are
 // scaled by 1 / (1 - p).  The forward and the backward regenerate the same mask, nothing is stored.

@@ -70,6 +70,7 @@ struct TrainWork {
     // backward scratch
     float *gq, *ga, *gb, *gc, *gqk, *gvals, *gp2a, *ghead, *ghh, *gatt, *ds, *genco, *ge2e, *gx, *gy, *gz, *gqkv, *ge2a, *gi3d,
           *gpooled, *delta, *gconv, *G, *genti, *gh, *wT, *gconvw;
+    float* gd[8];      // decoder layer: one buffer per gradient that a deferred weight-gradient product reads (see the decoder loop)
 };
 
 struct TSizes { size_t R, NT, C, B, Q, BQ; };
@@ -116,6 +117,7 @@ bool train_layout(const bigc_model* m, const TSizes& z, Arena& a, TrainWork& w) 
     w.soid = a.take<int32_t>(z.B * 2 * z.Q);
     // backward scratch
     w.gq = a.take<float>(z.BQ * mx); w.ga = a.take<float>(z.BQ * mx); w.gb = a.take<float>(z.BQ * mx); w.gc = a.take<float>(z.BQ * mx);
+    for (int i = 0; i < 8; ++i) w.gd[i] = a.take<float>(z.BQ * mx);
     w.gqk = a.take<float>(z.BQ * 2 * dp);
     w.gvals = a.take<float>(2 * z.BQ * de);
     w.gp2a = a.take<float>(z.BQ * da);
@@ -158,13 +160,39 @@ float* grad_of(bigc_model* m, const std::string& key) {
 //   dW += dY^T X, db += colsum(dY), and (optionally) dX (=|+=) dY W.
 struct Bwd {
     bigc_model* m; void* s; TrainWork* w;
+    // Deferred weight gradients: while `defer` is on, lin() / dw() only record their product; flush() runs the recorded ones as ONE
+    // grouped launch (backward.hip: bigc_linear_dw_group).  The caller guarantees that nothing writes to a recorded dY / X before
+    // the flush (the decoder layer below hands every gradient a buffer of its own).
+    bool defer = false;
+    std::vector<BigcDwJob> pending;
+    int dw(const float* dY, int ldy, const float* X, int ldx, float* gw, int ldw, float* gb, int M, int N, int K) {
+        if (!gw) return BIGC_OK;
+        if (defer) { pending.push_back(BigcDwJob{dY, ldy, X, ldx, gw, ldw, gb, M, N, K}); return BIGC_OK; }
+        return bigc_linear_dw_f32(s, dY, ldy, X, ldx, nullptr, 1, K, gw, ldw, gb, M, N, K);
+    }
+    int flush() {
+        int rc = pending.empty() ? BIGC_OK : bigc_linear_dw_group(s, pending.data(), (int)pending.size());
+        pending.clear();
+        return rc;
+    }
     int lin(const std::string& key, const Lin& L, const float* dY, int ldy, const float* X, int ldx, int M, int N, int K,
             float* dX, int lddx, bool accumulate_dx) {
-        float* gw = grad_of(m, key + ".weight");
-        float* gb = grad_of(m, key + ".bias");
-        if (gw) TRY(bigc_linear_dw_f32(s, dY, ldy, X, ldx, nullptr, 1, K, gw, K, gb, M, N, K));
+        TRY(dw(dY, ldy, X, ldx, grad_of(m, key + ".weight"), K, grad_of(m, key + ".bias"), M, N, K));
         if (dX) TRY(dx(L.w, dY, ldy, M, N, K, dX, lddx, accumulate_dx));
         return BIGC_OK;
+    }
+    // as lin(), with dX = res + dY W written to a buffer of its own (res is left untouched)
+    int lin_res(const std::string& key, const Lin& L, const float* dY, int ldy, const float* X, int ldx, int M, int N, int K,
+                const float* res, float* dX, int lddx) {
+        TRY(dw(dY, ldy, X, ldx, grad_of(m, key + ".weight"), K, grad_of(m, key + ".bias"), M, N, K));
+        return dx_res(L.w, dY, ldy, M, N, K, res, dX, lddx);
+    }
+    int dx_res(const float* W, const float* dY, int ldy, int M, int N, int K, const float* res, float* dX, int lddx) {
+        const int n4 = round4(N);
+        BIGC_CHECK_ARG(ldy % 4 == 0 && ldy >= n4, "train: dY leading dimension %d must be a multiple of 4 and >= %d", ldy, n4);
+        const float* wT = nullptr;
+        TRY(bigc_weight_transposed((hipStream_t)s, W, N, K, K, &wT));
+        return bigc_linear_f32(s, dY, ldy, nullptr, 1, n4, wT, n4, nullptr, res, lddx, dX, lddx, M, K, n4, BIGC_ACT_NONE);
     }
     // dX[M,K] (=|+=) dY[M,N] W[N,K] through a transposed, 4-padded copy of W
     // (`parameter`: W is a model parameter, constant for the weights epoch: its transposed copy and split form are cached and
@@ -468,26 +496,33 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
     // ---- decoder, last layer first (models/model_0v10.py:178-225) --------------------------------------
     ZERO(w.genco, (size_t)NT * de);
     float* gpos = grad_of(m, "pos_embedding");
+    // Every gradient that a weight-gradient product of the layer reads has a buffer of its own (nothing is accumulated in place into
+    // a buffer such a product still needs), so the layer's eleven products run as ONE grouped launch at its end (bw.flush():
+    // 224 tiles with the whole B*Q contraction split in two, instead of eleven launches of 16 tiles x 32 splits + eleven reductions).
+    static const bool group_off = getenv("BIGC_DW_GROUP") && atoi(getenv("BIGC_DW_GROUP")) == 0;
+    bw.defer = !group_off && !bigc_linear_get_exact();
     for (int i = c.n_deco_layers - 1; i >= 0; --i) {
         const DecLayer& L = m->dec[i];
         DecS& S = w.dec[i];
         const std::string p = "decoder_layers." + std::to_string(i);
+        float *A1 = w.ga, *B1 = w.gb, *A2 = w.gd[0], *B2 = w.gd[1], *C1 = w.gc, *C0 = w.gd[2], *B3 = w.gd[3], *C2 = w.gd[4], *A3 = w.gd[5],
+              *V1 = w.gd[6], *A4 = w.gd[7];
         // w.gq = d qout
-        TRY(bigc_layernorm_bwd_f32(s, S.t3c, L.n3.g, w.gq, w.ga, grad_of(m, p + ".norm3.weight"), grad_of(m, p + ".norm3.bias"), BQ, dp, eps));
-        // ga = d t3c ; t3c = f W3^T + b + q3
-        TRY(bw.lin(p + ".fc2.3", L.f3, w.ga, dp, S.f, df, BQ, dp, df, w.gb, df, false));       // gb = d f
-        TRY(bigc_relu_bwd_f32(s, w.gb, S.f, (long)BQ * df));            // S.f is post-dropout: zero where dropped
-        if (dp_ > 0.f) TRY(bigc_scale_f32(hs, w.gb, (long)BQ * df, 1.0f / (1.0f - dp_)));
-        TRY(bw.lin(p + ".fc2.0", L.f0, w.gb, df, S.q3, dp, BQ, df, dp, w.ga, dp, true));       // ga = d q3 (residual + ffn path)
-        TRY(bigc_layernorm_bwd_f32(s, S.t3b, L.n2.g, w.ga, w.gb, grad_of(m, p + ".norm2.weight"), grad_of(m, p + ".norm2.bias"), BQ, dp, eps));
-        // gb = d t3b = d(rh1 W^T + b1 + rh0 W^T + b0 + q2)
-        TRY(bw.lin(p + ".fc_rolewise.1.2", L.role1[1], w.gb, dp, S.rh1, dp, BQ, dp, dp, w.gc, dp, false));   // gc = d rh1
-        TRY(bigc_relu_bwd_f32(s, w.gc, S.rh1, (long)BQ * dp));
-        TRY(bw.lin(p + ".fc_rolewise.1.0", L.role1[0], w.gc, dp, S.vals + (size_t)BQ * de, de, BQ, dp, de, w.gvals + (size_t)BQ * de, de, false));
-        TRY(bw.lin(p + ".fc_rolewise.0.2", L.role0[1], w.gb, dp, S.rh0, dp, BQ, dp, dp, w.gc, dp, false));   // gc = d rh0
-        TRY(bigc_relu_bwd_f32(s, w.gc, S.rh0, (long)BQ * dp));
-        TRY(bw.lin(p + ".fc_rolewise.0.0", L.role0[0], w.gc, dp, S.vals, de, BQ, dp, de, w.gvals, de, false));
-        // gb stays = d q2 (residual path); values = att @ enco
+        TRY(bigc_layernorm_bwd_f32(s, S.t3c, L.n3.g, w.gq, A1, grad_of(m, p + ".norm3.weight"), grad_of(m, p + ".norm3.bias"), BQ, dp, eps));
+        // A1 = d t3c ; t3c = f W3^T + b + q3
+        TRY(bw.lin(p + ".fc2.3", L.f3, A1, dp, S.f, df, BQ, dp, df, B1, df, false));           // B1 = d f
+        TRY(bigc_relu_bwd_f32(s, B1, S.f, (long)BQ * df));              // S.f is post-dropout: zero where dropped
+        if (dp_ > 0.f) TRY(bigc_scale_f32(hs, B1, (long)BQ * df, 1.0f / (1.0f - dp_)));
+        TRY(bw.lin_res(p + ".fc2.0", L.f0, B1, df, S.q3, dp, BQ, df, dp, A1, A2, dp));         // A2 = d q3 (residual + ffn path)
+        TRY(bigc_layernorm_bwd_f32(s, S.t3b, L.n2.g, A2, B2, grad_of(m, p + ".norm2.weight"), grad_of(m, p + ".norm2.bias"), BQ, dp, eps));
+        // B2 = d t3b = d(rh1 W^T + b1 + rh0 W^T + b0 + q2)
+        TRY(bw.lin(p + ".fc_rolewise.1.2", L.role1[1], B2, dp, S.rh1, dp, BQ, dp, dp, C1, dp, false));        // C1 = d rh1
+        TRY(bigc_relu_bwd_f32(s, C1, S.rh1, (long)BQ * dp));
+        TRY(bw.lin(p + ".fc_rolewise.1.0", L.role1[0], C1, dp, S.vals + (size_t)BQ * de, de, BQ, dp, de, w.gvals + (size_t)BQ * de, de, false));
+        TRY(bw.lin(p + ".fc_rolewise.0.2", L.role0[1], B2, dp, S.rh0, dp, BQ, dp, dp, C0, dp, false));        // C0 = d rh0
+        TRY(bigc_relu_bwd_f32(s, C0, S.rh0, (long)BQ * dp));
+        TRY(bw.lin(p + ".fc_rolewise.0.0", L.role0[0], C0, dp, S.vals, de, BQ, dp, de, w.gvals, de, false));
+        // B2 stays = d q2 (residual path); values = att @ enco
         const float* enco = w.enc[c.n_enco_layers - 1].out;
         TRY(bigc_role_small_gemm_f32(s, 0, nullptr, w.gvals, de, enco, de, w.gatt, 0, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
         if (i == c.n_deco_layers - 1) TRY(bigc_axpy_f32(s, w.gatt, datt, (long)2 * Q * NT));
@@ -495,44 +530,45 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
         TRY(bigc_role_attention_bwd_f32(s, S.p2a, da, S.e2a, da, w.gatt, w.ds, b->vid_trk_off, B, Q, da / 2, att_scale));
         TRY(bigc_role_small_gemm_f32(s, 2, w.ds, nullptr, 0, S.e2a, da, w.gp2a, da, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
         TRY(bigc_role_small_gemm_f32(s, 3, w.ds, S.p2a, da, nullptr, 0, w.ge2a, da, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
-        TRY(bw.lin(p + ".fc_pred2att", L.p2a, w.gp2a, da, S.q2, dp, BQ, da, dp, w.gb, dp, true));           // gb = d q2 total
+        TRY(bw.lin_res(p + ".fc_pred2att", L.p2a, w.gp2a, da, S.q2, dp, BQ, da, dp, B2, B3, dp));             // B3 = d q2 total
         TRY(bw.lin(p + ".fc_enti2att", L.e2a, w.ge2a, da, enco, de, NT, da, de, w.genco, de, true));
         // q2 = LN1(t2) + pos
-        if (gpos) TRY(bigc_reduce_periodic_f32(s, w.gb, gpos, BQ, dp, Q));
+        if (gpos) TRY(bigc_reduce_periodic_f32(s, B3, gpos, BQ, dp, Q));
         const int rows = (i == 0) ? Q : BQ, nseq = (i == 0) ? 1 : B;
-        const float* gt3 = w.gb;
+        const float* gt3 = B3;
         if (i == 0) {       // the self-attention block was evaluated once on Q rows and tiled: sum the gradient over the videos
-            ZERO(w.gc, (size_t)Q * dp);
-            TRY(bigc_reduce_periodic_f32(s, w.gb, w.gc, BQ, dp, Q));
-            gt3 = w.gc;
+            ZERO(C2, (size_t)Q * dp);
+            TRY(bigc_reduce_periodic_f32(s, B3, C2, BQ, dp, Q));
+            gt3 = C2;
         }
-        TRY(bigc_layernorm_bwd_f32(s, S.t2, L.n1.g, gt3, w.ga, grad_of(m, p + ".norm1.weight"), grad_of(m, p + ".norm1.bias"), rows, dp, eps));
-        // ga = d t2 ; t2 = ao2 Wo^T + b + qin
+        TRY(bigc_layernorm_bwd_f32(s, S.t2, L.n1.g, gt3, A3, grad_of(m, p + ".norm1.weight"), grad_of(m, p + ".norm1.bias"), rows, dp, eps));
+        // A3 = d t2 ; t2 = ao2 Wo^T + b + qin
         const float* qin = (i == 0) ? m->qinit : w.dec[i - 1].qout;
-        TRY(bw.lin(p + ".self_attn.out_proj", L.out_proj, w.ga, dp, S.ao2, dp, rows, dp, dp, w.gq, dp, false));   // gq = d ao2
-        float* gvv = w.gc;                                    // gb / gc are free again once LayerNorm-1 consumed gt3
+        TRY(bw.lin(p + ".self_attn.out_proj", L.out_proj, A3, dp, S.ao2, dp, rows, dp, dp, w.gq, dp, false));   // gq = d ao2 (d qout is consumed)
         TRY(bigc_mha_bwd_drop_f32(s, S.qk, 2 * dp, S.qk + dp, 2 * dp, S.vv, dp, S.ao2, dp, w.gq, dp, S.lse, w.delta, w.gqk, 2 * dp, w.gqk + dp,
-                                  2 * dp, gvv, dp, w.q_off, w.q_off, nseq, Q, Q, rows, H, dp / H, dp_, ds_, dec_site(i, 0)));
+                                  2 * dp, V1, dp, w.q_off, w.q_off, nseq, Q, Q, rows, H, dp / H, dp_, ds_, dec_site(i, 0)));
         // in_proj: [q;k] rows from qk_in, v rows from qin
         {
             float* gw = grad_of(m, p + ".self_attn.in_proj_weight");
             float* gbias = grad_of(m, p + ".self_attn.in_proj_bias");
             if (gw) {
-                TRY(bigc_linear_dw_f32(s, w.gqk, 2 * dp, S.qk_in, dp, nullptr, 1, dp, gw, dp, gbias, rows, 2 * dp, dp));
-                TRY(bigc_linear_dw_f32(s, gvv, dp, qin, dp, nullptr, 1, dp, gw + (size_t)2 * dp * dp, dp, gbias ? gbias + 2 * dp : nullptr, rows, dp, dp));
+                TRY(bw.dw(w.gqk, 2 * dp, S.qk_in, dp, gw, dp, gbias, rows, 2 * dp, dp));
+                TRY(bw.dw(V1, dp, qin, dp, gw + (size_t)2 * dp * dp, dp, gbias ? gbias + 2 * dp : nullptr, rows, dp, dp));
             }
         }
         // d qin = d t2 (residual) + d vv Wv + d qk_in ; d qk_in = d qk Wqk ; d pos += d qk_in
-        TRY(bw.dx(L.in_proj.w + (size_t)2 * dp * dp, gvv, dp, rows, dp, dp, w.ga, dp, true));
-        TRY(bw.dx(L.in_proj.w, w.gqk, 2 * dp, rows, 2 * dp, dp, w.gq, dp, false));                         // gq = d qk_in
+        TRY(bw.dx_res(L.in_proj.w + (size_t)2 * dp * dp, V1, dp, rows, dp, dp, A3, A4, dp));
+        TRY(bw.dx(L.in_proj.w, w.gqk, 2 * dp, rows, 2 * dp, dp, w.gq, dp, false));                         // gq = d qk_in (d ao2 is consumed)
         if (gpos) TRY(bigc_reduce_periodic_f32(s, w.gq, gpos, rows, dp, Q));
-        TRY(bigc_axpy_f32(s, w.ga, w.gq, (long)rows * dp));                                                  // ga = d qin
+        TRY(bigc_axpy_f32(s, A4, w.gq, (long)rows * dp));                                                    // A4 = d qin
+        TRY(bw.flush());                                                                                     // the layer's weight gradients
         if (i == 0) {
-            if (float* gqi = grad_of(m, "pred_query_init")) TRY(bigc_reduce_periodic_f32(s, w.ga, gqi, Q, dp, Q));
+            if (float* gqi = grad_of(m, "pred_query_init")) TRY(bigc_reduce_periodic_f32(s, A4, gqi, Q, dp, Q));
         } else {
-            float* t = w.gq; w.gq = w.ga; w.ga = t;                                                          // gq = d qout of layer i-1
+            float* t = w.gq; w.gq = w.gd[7]; w.gd[7] = t;                                                    // gq = d qout of layer i-1
         }
     }
+    bw.defer = false;
 
     // ---- encoder (models/model_0v10.py:103-117) ---------------------------------------------------------
     float* gx = w.genco;        // d output of the current encoder layer (NT, de); scratch: w.gx, w.gy, w.gz

@@ -373,10 +373,16 @@ def test_gradients_of_later_optimizer_steps_follow_the_updated_weights(name, fus
                     continue
                 ref = sdg[k].grad
                 worst[k] = float((p.grad.cpu() - ref).abs().max() / max(float(ref.abs().max()), 1e-4 * gmax))
+            # A stale derived buffer is wrong by 2e-2 .. 2e-1 in MANY parameters below it (measured: conv 0.19, fc_feat2enti.* 0.02-0.04).
+            # What the bound must let through is ONE ReLU unit whose pre-activation lies within f32 rounding of zero and takes the
+            # other branch than in the oracle (either is a valid subgradient): it moves the gradient of its own layer by up to 6e-3
+            # and nothing else above 3e-3 (seen at step 3 of the exp2-dims case in 4 of 10 runs -- the weights Adam produces differ in
+            # their last bits from run to run, the bias gradients being float atomics -- always as fc_feat2enti.2.weight 5.75e-3).
             bad = {k: v for k, v in worst.items() if v > 3e-3}
-            assert not bad, (step, sorted(bad.items(), key=lambda kv: -kv[1])[:10])
-            front = [v for k, v in worst.items() if k.startswith(("fc_bbox2enti", "fc_feat2enti"))]
-            assert front and max(front) < 2e-3, (step, front)
+            assert len(bad) <= 1 and all(v < 1.5e-2 for v in bad.values()), (step, sorted(bad.items(), key=lambda kv: -kv[1])[:10])
+            front = sorted(v for k, v in worst.items() if k.startswith(("fc_bbox2enti", "fc_feat2enti")))
+            assert len(front) >= 4 and front[-2] < 3e-3 and front[-1] < 1.5e-2, (step, front)
+            assert float(np.median(list(worst.values()))) < 2e-4, (step, sorted(worst.items(), key=lambda kv: -kv[1])[:10])
         opt.step()
 
 

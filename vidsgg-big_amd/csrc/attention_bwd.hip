@@ -405,6 +405,36 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallGemmArgs p) 
     int nt = 0;                                             // live 32-column tiles of this 128-column chunk
 #pragma unroll
     for (int t = 0; t < 4; ++t) nt += (j0 + t * 32 < n) ? 1 : 0;
+    // Both operands contiguous along the reduction (DATT: rows of dvals and of enco, 512 floats each): a lane reads 16 bytes = four k of
+    // its row per load instead of one float per k -- with one float per load every instruction touched 32 different cache lines for 4
+    // useful bytes each, and this product was the slowest of the four (105 us per decoder layer at 64 videos).  The two k-pairs of a
+    // quad go to two MFMAs; hi selects the k of its half-wave as before.
+    if (p.mode == SG_DATT && (p.lde & 3) == 0 && (kdim & 15) == 0) {
+        const float* Ap = A + (size_t)irow * sa_i;
+        constexpr int QU = 4;                                   // quads in flight per round
+        const int kq4 = kdim / 4;                               // this wave's quarter of the reduction, in whole quads
+        const int qb = wave * kq4, qe = qb + kq4;
+        for (int k4 = qb; k4 < qe; k4 += 4 * QU) {
+            f32x4 a4[QU], b4[QU][4];
+#pragma unroll
+            for (int u = 0; u < QU; ++u) {
+                const int kk = min(k4 + 4 * u, kdim - 4);
+                a4[u] = *(const f32x4*)(Ap + kk);
+                if (!(iok && k4 + 4 * u < qe)) a4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (t < nt) b4[u][t] = *(const f32x4*)(B + joff[t] + kk);
+            }
+#pragma unroll
+            for (int u = 0; u < QU; ++u)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const float av = hi ? a4[u][2 * pr + 1] : a4[u][2 * pr];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (t < nt) acc[t] = mfma32(av, hi ? b4[u][t][2 * pr + 1] : b4[u][t][2 * pr], acc[t]);
+                }
+        }
+        n_pass = 0;                                             // (skips the generic loop below)
+    }
     for (int pass = 0; pass < n_pass; ++pass) {
         const float* Ap = A + (p.mode == SG_DENCO ? (size_t)pass * nq * ne : 0) + (size_t)irow * sa_i;
         const float* Bp = B + (p.mode == SG_DENCO ? (size_t)pass * p.n_vid * nq * p.lde : 0);

@@ -320,6 +320,29 @@ extern "C" int bigc_linear_hr8out_f32(void* stream, const float* A, int lda, con
     return bigc_linear_hr8out(stream, A, lda, W, ldw, bias, residual, ldr, C, ldc, Cs, ldcs_bytes / 4, M, N, K, act, range_flag);
 }
 
+extern "C" int bigc_relu_bwd_f32(void* stream, float* dY, const float* Y, long n);      // backward.hip
+
+int bigc_linear_relu_masked(void* stream, const float* A, int lda, const float* W, int ldw, const float* relu_out, int ldm, float* C, int ldc,
+                            int M, int N, int K) {
+    BIGC_CHECK_ARG(A && W && relu_out && C && M >= 0 && N > 0 && K > 0, "linear_relu_masked: bad argument");
+    if (M == 0) return BIGC_OK;
+    // exact mode, K = 8, odd layouts: the plain product, then the mask as a pass of its own (needs dense rows)
+    if (bigc_linear_get_exact() || K == 8 || K % 4 || lda % 4 || ldw % 4) {
+        BIGC_CHECK_ARG(ldc == N && ldm == N, "linear_relu_masked: the two-pass form needs dense rows");
+        int rc = bigc_linear_f32(stream, A, lda, nullptr, 1, K, W, ldw, nullptr, nullptr, 0, C, ldc, M, N, K, BIGC_ACT_NONE);
+        if (rc != BIGC_OK) return rc;
+        return bigc_relu_bwd_f32(stream, C, relu_out, (long)M * N);
+    }
+    BIGC_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "linear_relu_masked: A and W must be 16-byte aligned");
+    LinearArgs p;
+    p.A = A; p.lda = lda; p.a_idx = nullptr; p.nseg = 1; p.seg_len = K;
+    p.W = W; p.ldw = ldw; p.bias = nullptr; p.res = relu_out; p.ldr = ldm; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.act = BIGC_ACT_RELU_MASK;
+    p.tiles_m = cdiv(M, BM); p.tiles_n = 0;
+    p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr; p.zero_row = nullptr;
+    return bigc_linear_split_launch((hipStream_t)stream, p, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + 2.0 * M * N));
+}
+
 bool bigc_linear_pre8_supported(int N, int K) {
     // Opt-in (BIGC_PRE8_FUSED=1).  Measured on the 256-video step: hb (1.19 GB written + read) disappears and so does the 0.29 ms
     // K = 8 kernel, but the 64 extra FMAs per staged quad sit in the MFMA-bound loop of a power-limited kernel: the fused GEMM

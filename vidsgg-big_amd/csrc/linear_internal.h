@@ -82,6 +82,12 @@ int bigc_linear_dwsep(void* stream, const float* X, int ldx, const float* dw_w, 
                       const float* W, int ldw, const float* bias, const float* res, int ldr, float* C, int ldc, int M, int N, int K, int act);
 // launches the split-operand kernel (and its W pre-split pass); returns BIGC_OK or an error code
 int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double bytes);
+// (internal) epilogue mode of linear_split_kernel: C = (res > 0) ? A W^T : 0 -- the backward of a ReLU whose output is `res`, folded
+// into the dX GEMM that produces its input gradient (train.hip); no residual is added in this mode
+#define BIGC_ACT_RELU_MASK 3
+// dX (M, N) = mask(dY (M, K) W^T) with W (N, K) and mask = relu_out > 0 (relu_out (M, N), pitch ldm); linear.hip
+int bigc_linear_relu_masked(void* stream, const float* A, int lda, const float* W, int ldw, const float* relu_out, int ldm, float* C, int ldc,
+                            int M, int N, int K);
 
 // ---- gemm_ps.hip: GEMM on operands stored as split f16 pairs ("hr8": per 8 consecutive k, 16 bytes of heads then 16 bytes of
 // scaled residuals; same footprint and row pitch as f32).  A is hr8 (optionally row-gathered) or f32 (split in the loop), W is

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
         colv[ni] = n0 + wn * 64 + ni * 32 + l31;
         bv[ni] = p.bias ? p.bias[min(colv[ni], p.N - 1)] : 0.f;
     }
-    const bool relu = p.act == BIGC_ACT_RELU, sigm = p.act == BIGC_ACT_SIGMOID;
+    const bool relu = p.act == BIGC_ACT_RELU, sigm = p.act == BIGC_ACT_SIGMOID, rmask = p.act == BIGC_ACT_RELU_MASK;
     constexpr int HP = 68;                      // pitch (floats) of the transposition corner of the split-form output
     constexpr float PS_SCALE = (float)(1 << PS_ACT_EXP);
     bool hr_oob = false;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
                     float v = (acc0[mi][ni][r] + acc1[mi][ni][r] * RINV) + bv[ni];
                     if (relu) v = fmaxf(v, 0.f);
                     if (sigm) v = 1.0f / (1.0f + expf(-v));
-                    v += rv[ni][r];
+                    if (rmask) v = rv[ni][r] > 0.f ? v : 0.f; else v += rv[ni][r];
                     if (row < p.M) cp[(size_t)row * p.ldc] = v;
                 }
             }
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
                 float v = (acc0[mi][ni][r] + acc1[mi][ni][r] * RINV) + bv[ni];
                 if (relu) v = fmaxf(v, 0.f);
                 if (sigm) v = 1.0f / (1.0f + expf(-v));
-                v += rv[ni][r];
+                if (rmask) v = rv[ni][r] > 0.f ? v : 0.f; else v += rv[ni][r];
                 if (p.C && colv[ni] < p.N && rbase + mfma_row(r, hi) < p.M) p.C[(size_t)(rbase + mfma_row(r, hi)) * p.ldc + colv[ni]] = v;
                 tr[mfma_row(r, hi) * HP + ni * 32 + l31] = v;
             }

@@ -181,6 +181,17 @@ struct Bwd {
         if (dX) TRY(dx(L.w, dY, ldy, M, N, K, dX, lddx, accumulate_dx));
         return BIGC_OK;
     }
+    // as lin() with dX = (relu_out > 0) ? dY W : 0 -- the layer's input X is the output of a ReLU (X = relu_out), whose backward is
+    // folded into the dX GEMM's epilogue instead of a pass of its own over dX (26 such passes per step, 0.9 ms at 64 videos)
+    int lin_relu(const std::string& key, const Lin& L, const float* dY, int ldy, const float* X, int ldx, int M, int N, int K,
+                 float* dX, int lddx) {
+        TRY(dw(dY, ldy, X, ldx, grad_of(m, key + ".weight"), K, grad_of(m, key + ".bias"), M, N, K));
+        const int n4 = round4(N);
+        BIGC_CHECK_ARG(ldy % 4 == 0 && ldy >= n4, "train: dY leading dimension %d must be a multiple of 4 and >= %d", ldy, n4);
+        const float* wT = nullptr;
+        TRY(bigc_weight_transposed((hipStream_t)s, L.w, N, K, K, &wT));
+        return bigc_linear_relu_masked(s, dY, ldy, wT, n4, X, ldx, dX, lddx, M, K, n4);
+    }
     // as lin(), with dX = res + dY W written to a buffer of its own (res is left untouched)
     int lin_res(const std::string& key, const Lin& L, const float* dY, int ldy, const float* X, int ldx, int M, int N, int K,
                 const float* res, float* dX, int lddx) {
@@ -264,14 +275,10 @@ static int frontend_train_backward(bigc_model* m, void* s, const bigc_batch* b, 
         if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: hipMalloc: %s", hipGetErrorString(e));
         TRY(bigc_repack_conv_weight_bwd(hs, m->conv.w, m->conv_w_bwd, de, 2 * de, 3));
     }
-    TRY(bigc_linear_f32(s, w.G, 3 * de, nullptr, 1, 3 * de, m->conv_w_bwd, 3 * de, nullptr, nullptr, 0, w.genti, 2 * de, R, 2 * de, 3 * de,
-                        BIGC_ACT_NONE));
-    TRY(bigc_relu_bwd_f32(s, w.genti, w.enti, (long)R * 2 * de));
-    TRY(bw.lin("fc_bbox2enti.2", m->bbox2, w.genti, 2 * de, w.hb, de, R, de, de, w.gh, de, false));
-    TRY(bigc_relu_bwd_f32(s, w.gh, w.hb, (long)R * de));
+    TRY(bigc_linear_relu_masked(s, w.G, 3 * de, m->conv_w_bwd, 3 * de, w.enti, 2 * de, w.genti, 2 * de, R, 2 * de, 3 * de));   // (+ ReLU of enti)
+    TRY(bw.lin_relu("fc_bbox2enti.2", m->bbox2, w.genti, 2 * de, w.hb, de, R, de, de, w.gh, de));
     TRY(bw.lin("fc_bbox2enti.0", m->bbox0, w.gh, de, w.bbox8, 8, R, de, 8, nullptr, 0, false));
-    TRY(bw.lin("fc_feat2enti.2", m->feat2, w.genti + de, 2 * de, w.hv, de, R, de, de, w.gh, de, false));
-    TRY(bigc_relu_bwd_f32(s, w.gh, w.hv, (long)R * de));
+    TRY(bw.lin_relu("fc_feat2enti.2", m->feat2, w.genti + de, 2 * de, w.hv, de, R, de, de, w.gh, de));
     TRY(bw.lin("fc_feat2enti.0", m->feat0, w.gh, de, b->feats, D, R, de, c.dim_feat, nullptr, 0, false));
     return BIGC_OK;
 }
@@ -510,17 +517,14 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
         // w.gq = d qout
         TRY(bigc_layernorm_bwd_f32(s, S.t3c, L.n3.g, w.gq, A1, grad_of(m, p + ".norm3.weight"), grad_of(m, p + ".norm3.bias"), BQ, dp, eps));
         // A1 = d t3c ; t3c = f W3^T + b + q3
-        TRY(bw.lin(p + ".fc2.3", L.f3, A1, dp, S.f, df, BQ, dp, df, B1, df, false));           // B1 = d f
-        TRY(bigc_relu_bwd_f32(s, B1, S.f, (long)BQ * df));              // S.f is post-dropout: zero where dropped
+        TRY(bw.lin_relu(p + ".fc2.3", L.f3, A1, dp, S.f, df, BQ, dp, df, B1, df));             // B1 = d f (S.f is post-dropout: zero where dropped)
         if (dp_ > 0.f) TRY(bigc_scale_f32(hs, B1, (long)BQ * df, 1.0f / (1.0f - dp_)));
         TRY(bw.lin_res(p + ".fc2.0", L.f0, B1, df, S.q3, dp, BQ, df, dp, A1, A2, dp));         // A2 = d q3 (residual + ffn path)
         TRY(bigc_layernorm_bwd_f32(s, S.t3b, L.n2.g, A2, B2, grad_of(m, p + ".norm2.weight"), grad_of(m, p + ".norm2.bias"), BQ, dp, eps));
         // B2 = d t3b = d(rh1 W^T + b1 + rh0 W^T + b0 + q2)
-        TRY(bw.lin(p + ".fc_rolewise.1.2", L.role1[1], B2, dp, S.rh1, dp, BQ, dp, dp, C1, dp, false));        // C1 = d rh1
-        TRY(bigc_relu_bwd_f32(s, C1, S.rh1, (long)BQ * dp));
+        TRY(bw.lin_relu(p + ".fc_rolewise.1.2", L.role1[1], B2, dp, S.rh1, dp, BQ, dp, dp, C1, dp));          // C1 = d rh1
         TRY(bw.lin(p + ".fc_rolewise.1.0", L.role1[0], C1, dp, S.vals + (size_t)BQ * de, de, BQ, dp, de, w.gvals + (size_t)BQ * de, de, false));
-        TRY(bw.lin(p + ".fc_rolewise.0.2", L.role0[1], B2, dp, S.rh0, dp, BQ, dp, dp, C0, dp, false));        // C0 = d rh0
-        TRY(bigc_relu_bwd_f32(s, C0, S.rh0, (long)BQ * dp));
+        TRY(bw.lin_relu(p + ".fc_rolewise.0.2", L.role0[1], B2, dp, S.rh0, dp, BQ, dp, dp, C0, dp));          // C0 = d rh0
         TRY(bw.lin(p + ".fc_rolewise.0.0", L.role0[0], C0, dp, S.vals, de, BQ, dp, de, w.gvals, de, false));
         // B2 stays = d q2 (residual path); values = att @ enco
         const float* enco = w.enc[c.n_enco_layers - 1].out;
@@ -585,8 +589,7 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
             TRY(bigc_dropout_f32(s, w.gz, NT, de, de, dp_, ds_, enc_site(i, 3)));
             g_l2 = w.gz;
         }
-        TRY(bw.lin(p + ".linear2", L.l2, g_l2, de, S.fh, df, NT, de, df, w.gy, df, false));          // gy = d fh
-        TRY(bigc_relu_bwd_f32(s, w.gy, S.fh, (long)NT * df));
+        TRY(bw.lin_relu(p + ".linear2", L.l2, g_l2, de, S.fh, df, NT, de, df, w.gy, df));            // gy = d fh
         if (dp_ > 0.f) TRY(bigc_scale_f32(hs, w.gy, (long)NT * df, 1.0f / (1.0f - dp_)));
         TRY(bw.lin(p + ".linear1", L.l1, w.gy, df, S.x1, de, NT, df, de, w.gx, de, true));           // gx = d x1
         TRY(bigc_layernorm_bwd_f32(s, S.t1, L.n1.g, w.gx, w.gy, grad_of(m, p + ".norm1.weight"), grad_of(m, p + ".norm1.bias"), NT, de, eps));

@@ -74,18 +74,18 @@ __global__ __launch_bounds__(256) void adaptive_maxpool_kernel(const float* __re
             const int p = it / ng, c = (it - p * ng) * 4;
             const int s = (p * To) / P, e = ((p + 1) * To + P - 1) / P;
             const float* src = conv + (size_t)c0 * d + c;
-            f32x4 m = *(const f32x4*)(src + (size_t)s * d);
-            int j = s + 1;
-            for (; j + 3 < e; j += 4) {
-                const f32x4 x0 = *(const f32x4*)(src + (size_t)j * d), x1 = *(const f32x4*)(src + (size_t)(j + 1) * d);
-                const f32x4 x2 = *(const f32x4*)(src + (size_t)(j + 2) * d), x3 = *(const f32x4*)(src + (size_t)(j + 3) * d);
+            // eight rows in flight per round, the last one repeated past the window's end (a repeated row changes no maximum): a window
+            // of the usual eight rows is ONE round of loads instead of three dependent ones (1 + 4 + 3 x 1)
+            f32x4 m;
+            for (int j = s; j < e; j += 8) {
+                f32x4 x[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(m[k], x0[k]), fmaxf(fmaxf(x1[k], x2[k]), x3[k]));
-            }
-            for (; j < e; ++j) {
-                const f32x4 x = *(const f32x4*)(src + (size_t)j * d);
+                for (int u = 0; u < 8; ++u) x[u] = *(const f32x4*)(src + (size_t)min(j + u, e - 1) * d);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], x[k]);
+                for (int k = 0; k < 4; ++k) {
+                    const float v = fmaxf(fmaxf(fmaxf(x[0][k], x[1][k]), fmaxf(x[2][k], x[3][k])), fmaxf(fmaxf(x[4][k], x[5][k]), fmaxf(x[6][k], x[7][k])));
+                    m[k] = j == s ? v : fmaxf(m[k], v);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) pooled[(size_t)t * d * P + (size_t)(c + k) * P + p] = m[k];

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void linear_k8_kernel(const LinearArgs p) {
     const bool relu = p.act == BIGC_ACT_RELU, sigm = p.act == BIGC_ACT_SIGMOID;
     const int r0 = blockIdx.x * SK_ROWS, r1 = min(r0 + SK_ROWS, p.M);
     bool oob = false;
+#pragma unroll 4
     for (int r = r0 + rl; r < r1; r += nrl) {
         const float* ap = p.A + (size_t)r * p.lda;
         const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4);
@@ -223,23 +224,23 @@ __global__ __launch_bounds__(256) void linear_k8_kernel(const LinearArgs p) {
             for (int j = 0; j < 4; ++j) y[j] = __shfl_xor(x[j], 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) oob = oob || !(fabsf(x[j]) < 32768.0f);
-            if ((c4 & 1) == 0) {
+            // the even lane of a pair stores the group's 16 bytes of heads, the odd lane its 16 bytes of residuals: every lane one
+            // 16-byte store, contiguous across the wave (before: the even lanes stored both halves, 16 bytes at a stride of 32)
+            {
                 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
                 typedef float f2_t __attribute__((ext_vector_type(2)));
-                uint4 hh, rr;
-                unsigned* hp = (unsigned*)&hh;
-                unsigned* rp = (unsigned*)&rr;
+                const bool odd = (c4 & 1) != 0;
+                const f32x4 lo = odd ? y : x, hi4 = odd ? x : y;          // the group's eight columns in order
+                uint4 out;
+                unsigned* op = (unsigned*)&out;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f2_t v2 = q < 2 ? f2_t{x[2 * q], x[2 * q + 1]} : f2_t{y[2 * q - 4], y[2 * q - 3]};
+                    const f2_t v2 = q < 2 ? f2_t{lo[2 * q], lo[2 * q + 1]} : f2_t{hi4[2 * q - 4], hi4[2 * q - 3]};
                     const h2_t h2 = __builtin_convertvector(v2, h2_t);
                     const h2_t r2 = __builtin_convertvector(v2 - __builtin_convertvector(h2, f2_t), h2_t);
-                    hp[q] = *(const unsigned*)&h2;
-                    rp[q] = *(const unsigned*)&r2;
+                    op[q] = odd ? *(const unsigned*)&r2 : *(const unsigned*)&h2;
                 }
-                uint4* yp = (uint4*)(p.Cs + (size_t)r * p.ldcs + (size_t)(c4 >> 1) * 32);
-                yp[0] = hh;
-                yp[1] = rr;
+                *(uint4*)(p.Cs + (size_t)r * p.ldcs + (size_t)c4 * 16) = out;
             }
         }
     }

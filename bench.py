@@ -28,6 +28,7 @@ Also printed in the same JSON line (rank 0; everything below runs OUTSIDE the ti
   vidor / grounding / train   the other BASELINE configs on the same GPU (N=1 only): VidOR-sized
                 classification (N=180 tracklets), the grounding scorer on its triplet queries, and
                 the BIG-C training step (forward + Hungarian + backward + all-reduce + clip + Adam)
+  batch_x2      the headline workload at twice the videos per step (decoder GEMMs on pre-split operands)
 """
 import argparse
 import json
@@ -58,7 +59,7 @@ def parse():
                                                              "reported beside with its Recall@50 gate (0 = skip)")
     ap.add_argument("--recall-steps", type=int, default=400, help="training iterations of the Recall@50 leg (0 = skip the leg)")
     ap.add_argument("--recall-videos", type=int, default=16, help="held-out videos the Recall@50 leg scores (HIP, HIP reduced precision, CPU oracle)")
-    ap.add_argument("--legs", default="vidor,grounding,train", help="extra workloads reported in the same line at N=1 ('' = none)")
+    ap.add_argument("--legs", default="vidor,grounding,train,batch512", help="extra workloads reported in the same line at N=1 ('' = none)")
     ap.add_argument("--vidor-videos", type=int, default=16, help="videos of the VidOR leg (SURVEY.md 8d: 16 x N = 180, L in [15, 1000))")
     ap.add_argument("--vidor-oracle-videos", type=int, default=2, help="of those, host-seeded ones that are also run through the CPU oracle (outside the timing)")
     ap.add_argument("--grd-one-video-per-call", action="store_true", help="grounding leg: the reference's one-video forward instead of the batched one")
@@ -528,6 +529,39 @@ def fast_mode_leg(args, lib, model, packed, step, ref_out, cfg, base, width, pai
                                                 note="GT = 12 of the parity mode's 100 best relations per video: a sensitivity figure; the gate is in `recall`"))
 
 
+def batch512_leg(args, lib, device):
+    """The same eval step on twice the headline's videos per step (2 x --videos, default 512): from this size on the decoder's GEMM
+    operands are written in the split form by their producers and the whole decoder runs on the pre-split-operand GEMM (automatic,
+    csrc/model.hip).  Not the headline -- the default step stays at the survey's 256-video set -- but in
+    the same line, so that the batch-size sensitivity is the driver's measurement and not a number in a document."""
+    cfg = dict(configs.CONFIG_V)
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 7, att_gain=8.0)
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    nv = 2 * args.videos
+    t0 = time.time()
+    props = [synthetic_proposal(70000 + v, n_trajs=args.n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"]).to(device) for v in range(nv)]
+    packed = PackedBatch(props, device)
+    props = None
+    packed.proposals = None
+    gen_s = time.time() - t0
+    model = build_model(cfg, sd, device)
+    pairs = packed.n_pairs()
+
+    def step():
+        return model.counts(model.forward_packed(packed, args.topk))
+
+    steps = 5
+    el, el_prof, fam = timed_with_events(lib, step, 3, steps)
+    roof = gemm_roofline(fam, steps, 1e3 * el_prof / steps)
+    out = dict(value=round(pairs * steps / el, 1), unit="pairs/s", videos_per_step=nv, ms_per_step=round(1e3 * el / steps, 3), steps=steps,
+               roofline=roof, setup_s=round(gen_s, 1),
+               note="same workload and model as the headline at twice the videos per step; decoder GEMMs on pre-split operands (automatic from 512 videos)")
+    model._engine = None
+    del model, packed
+    torch.cuda.empty_cache()
+    return out
+
+
 def recall_leg(args, lib, device):
     """BASELINE's metric, second half ("+ Recall@50 parity"), on relations that are actually FOUND: the exp2-dims model is trained for
     `--recall-steps` iterations of the HIP training step (the reference's loop body, tools/train_vidvrd.py:151-164) on the learnable
@@ -920,6 +954,9 @@ def main():
             torch.cuda.empty_cache()
         if "train" in want:
             legs["train"] = train_leg(args, lib, device)
+        if "batch512" in want and not EXACT_F32:
+            torch.cuda.empty_cache()
+            legs["batch_x2"] = batch512_leg(args, lib, device)
     line = {
         "metric": "tracklet_pairs_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

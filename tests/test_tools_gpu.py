@@ -99,7 +99,7 @@ def _bench(args, env=None):
 
 def test_bench_json_contract():
     """bench.py prints ONE JSON line with the keys the driver and the judge read (small workload, one GPU)"""
-    d = _bench(["--videos", "8", "--steps", "2", "--warmup", "1", "--cpu-videos", "4", "--exact-steps", "1", "--legs", "grounding,train",
+    d = _bench(["--videos", "8", "--steps", "2", "--warmup", "1", "--cpu-videos", "4", "--exact-steps", "1", "--legs", "grounding,train,batch512",
                 "--vidor-videos", "2", "--recall-steps", "150", "--recall-videos", "6"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline", "oracle_parity"):
@@ -130,7 +130,8 @@ def test_bench_json_contract():
     assert op["videos"] == 4 and n_all > 0 and n_same == n_all and op["videos_fully_identical"] == 4
     # per video: within 1e-4 of the f32 oracle, or of a float64 evaluation, or inside the video's own f32 noise floor (oracle/accuracy.py)
     assert op["videos_outside_1e_4_and_their_f32_noise_floor"] == 0 and len(op["videos_over_1e_4"]) <= 1
-    # the other BASELINE configs ride in the same line
+    # the other BASELINE configs ride in the same line, and the headline workload at twice the videos per step
+    assert d["batch_x2"]["videos_per_step"] == 16 and d["batch_x2"]["value"] > 0 and d["batch_x2"]["roofline"]["bound"] == "mfma"
     g, t = d["grounding"], d["train"]
     assert g["unit"] == "triplet-queries/s" and g["value"] > 0
     assert t["videos_8"]["value"] > 0 and t["videos_64"]["value"] > 0

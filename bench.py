@@ -6,9 +6,12 @@
 Metric (BASELINE.json / SURVEY.md section 8d): tracklet-pairs/sec = videos/s x N(N-1), whole job.
 Workload = BASELINE.json configs[1]: VidVRD-test classification-only, model_0v10 at the exp2
 dimensions (PKU RoI 2048-d + I3D 832-d), synthetic videos of N=64 tracklets (SURVEY.md 8d recipe,
-video v uses numpy RandomState(1234+v)), numpy-seeded weights.  One step = one pass of the HIP
-path over one resident batch of `--videos` videos (default 256) per GPU; inputs are packed in HBM
-before the timed region.  N>1: one process per GPU (torch.distributed / RCCL only for the barrier
+video v uses numpy RandomState(1234+v)), numpy-seeded weights.  One step = ONE CALL OF THE DROP-IN
+SIGNATURE, `model(proposal_list, topk)` (models/model_0v10.py:359-388), on `--videos` (default 256)
+device-resident TrajProposals per GPU: the ragged pack (one gather launch that writes the rows in the
+split form the forward reads), the forward, construct_triplet, the compaction to the reference's return
+types, the one D2H copy and the per-video result tuples are all inside the timed region.  The same
+forward on a batch that stays packed in HBM is reported beside it (`resident_packed_batch`).  N>1: one process per GPU (torch.distributed / RCCL only for the barrier
 and the max-over-ranks timing -- videos are independent, no data-path collective), weak scaling.
 Started without a torch.distributed.run environment, `--gpus N` (N>1) launches the N ranks itself
 (a child `python -m torch.distributed.run`, started before this process touches the GPU).
@@ -51,6 +54,8 @@ def parse():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--cpu-videos", type=int, default=256, help="videos of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="stop the CPU-baseline sample after this much oracle time")
+    ap.add_argument("--headline", choices=["api", "packed"], default="api", help="what `value` times: api = model(proposal_list, topk) on device-resident "
+                    "TrajProposals (pack + forward + results: the drop-in call), packed = the forward on a resident PackedBatch")
     ap.add_argument("--no-prof", action="store_true", help="do not record HIP events around the kernels")
     ap.add_argument("--mode", choices=["eval", "train"], default="eval", help="eval = headline metric; train = training-step throughput")
     ap.add_argument("--train-videos", type=int, default=8, help="videos per GPU per training step (reference batch size 8)")
@@ -315,8 +320,7 @@ def device_proposal(seed, n_trajs, feat_width, num_enti_cats, len_range, start_r
     boxes = torch.from_numpy(np.concatenate([xy, xy + wh], axis=1).astype(np.float32)).to(device)
     feats = torch.randn((total, feat_width), generator=gen, device=device, dtype=torch.float32)
     off = np.concatenate([[0], np.cumsum(lens)])
-    return TrajProposal("synth_%d" % seed, int((starts + lens).max()), (1280, 720), cat_ids, scores, duras,
-                        [boxes[off[i]:off[i + 1]] for i in range(n_trajs)], [feats[off[i]:off[i + 1]] for i in range(n_trajs)])
+    return TrajProposal.from_blocks("synth_%d" % seed, int((starts + lens).max()), (1280, 720), cat_ids, scores, duras, lens, boxes, feats)
 
 
 def vidor_grounding_legs(args, lib, device, want_vidor, want_grounding):
@@ -689,34 +693,28 @@ def main():
     props = [synthetic_proposal(base + v, n_trajs=args.n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"]).to(device)
              for v in range(args.videos)]
     torch.cuda.synchronize()
-    tp = time.perf_counter()
-    packed = PackedBatch(props, device)
-    torch.cuda.synchronize()
-    pack_ms = 1e3 * (time.perf_counter() - tp)
-    # the split-form copy of the RoI columns (fc_feat2enti.0's operand) is part of packing: written once per resident batch, outside the
-    # timed steps like the reference's proposal.to(device) -- and reported here so that nothing hides there (one pass: 4.7 GB read,
-    # 4.7 GB written per 256 videos)
-    pack_hr8_ms = 0.0
-    if os.environ.get("BIGC_FEAT_HR8", "1") != "0":
-        packed.split_features(cfg["dim_feat"])          # first call: loads the kernel, allocates the 4.7 GB
-        torch.cuda.synchronize()
-        packed.feats_hr8 = None                         # (its block goes back to torch's cache)
-        tp = time.perf_counter()
-        packed.split_features(cfg["dim_feat"])          # timed: allocation from torch's cache + the one pass
-        torch.cuda.synchronize()
-        pack_hr8_ms = 1e3 * (time.perf_counter() - tp)
-    props = None
-    packed.proposals = None
     n_cpu = min(args.cpu_videos, args.videos) if (rank == 0 and world == 1) else 0
     gen_s = time.time() - t0
     model = build_model(cfg, sd, device)
     lib = _lib.load()
+
+    # ---- the step that is timed: the drop-in call itself, model(proposal_list, topk) (models/model_0v10.py:359-388) on device-resident
+    # TrajProposals -- everything the product does per batch is inside: the ragged pack (ONE gather launch that writes the rows in the
+    # form the forward reads, csrc/ingest.hip), the forward, construct_triplet, the compaction to the reference's return types, the one
+    # D2H copy (row offsets + range flag) and the per-video result tuples
+    def api_step():
+        return model(props, topk=args.topk)
+
+    # ... and the same forward on a batch that stays packed in HBM (a resident PackedBatch, the engine-level entry point): what a
+    # loop over resident data pays per pass; reported as `resident_packed_batch`, never the headline
+    packed = PackedBatch(props, device, "lazy")
     pairs_per_step, rows_per_step = packed.n_pairs(), packed.n_rows
 
-    def step():
+    def packed_step():
         out = model.forward_packed(packed, args.topk)
-        return model.counts(out)       # the one D2H copy forward() needs (row counts + the GEMM range flag) -> host sync
+        return model.counts(out)       # the one D2H copy forward() needs (row offsets + the GEMM range flag) -> host sync
 
+    step = packed_step if args.headline == "packed" else api_step
     for _ in range(args.warmup):
         step()
     # ---- the timed region: K steps, no instrumentation
@@ -724,8 +722,10 @@ def main():
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
+    stamps = [t0]
     for _ in range(args.steps):
-        n_out = step()
+        last = step()
+        stamps.append(time.perf_counter())            # (every step ends with its own D2H copy: the stamps are step boundaries)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -733,6 +733,34 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    n_triplets_last = int(sum(r[0].shape[0] for r in last if r is not None)) if args.headline != "packed" else int(last.sum())
+
+    # the other of the two entry points, same K steps (rank 0, outside `value`)
+    other_leg = None
+    if rank == 0:
+        other = api_step if args.headline == "packed" else packed_step
+        for _ in range(max(1, args.warmup)):
+            other()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            other()
+        torch.cuda.synchronize()
+        el_o = time.perf_counter() - t1
+        other_leg = dict(value=round(pairs_per_step * args.steps / el_o, 1), unit="pairs/s (this GPU)", ms_per_step=round(1e3 * el_o / args.steps, 3), steps=args.steps)
+        # host-side cost of the API call, each measured on its own with the GPU idle: the tables of the pack, and the result tuples
+        tp = time.perf_counter()
+        for _ in range(3):
+            PackedBatch(props, device, "lazy")
+        torch.cuda.synchronize()
+        pack_host_ms = 1e3 * (time.perf_counter() - tp) / 3
+        o = model.forward_packed(packed, args.topk)
+        model.counts(o)
+        tp = time.perf_counter()
+        for _ in range(3):
+            model.unpack_results(packed.n_vid, list(range(packed.n_vid)), o)
+        unpack_host_ms = 1e3 * (time.perf_counter() - tp) / 3
+        del o
 
     # ---- the same K steps once more with a HIP event pair around every kernel launch (on the launch stream, inside the
     # library): per-family launch durations for the roofline.  Kept out of `value` because the ~300 event records per step
@@ -769,7 +797,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.exact_steps):
-            step()
+            packed_step()
         torch.cuda.synchronize()
         ex_elapsed = time.perf_counter() - t0
         lib.bigc_linear_set_exact(0)
@@ -794,7 +822,7 @@ def main():
 
     fast_leg = None
     if args.fast_steps > 0 and not EXACT_F32 and rank == 0 and world == 1 and not lib.bigc_linear_get_fast():
-        fast_leg = fast_mode_leg(args, lib, model, packed, step, ref_out, cfg, base, width, pairs_per_step, device)
+        fast_leg = fast_mode_leg(args, lib, model, packed, packed_step, ref_out, cfg, base, width, pairs_per_step, device)
 
     if rank != 0:
         if dist is not None:
@@ -943,8 +971,9 @@ def main():
     del ref_out
     legs = {}
     want = [x for x in args.legs.split(",") if x] if world == 1 else []
+    reads_split = bool(packed.feats_hr8 is not None)
     model._engine = None
-    del model, packed
+    del model, packed, props, last
     torch.cuda.empty_cache()
     if args.recall_steps > 0 and world == 1:
         legs["recall"] = recall_leg(args, lib, device)
@@ -972,10 +1001,17 @@ def main():
         "kernel_families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in families.items()},
         "videos_per_sec": round(args.videos * world * args.steps / elapsed, 1),
         "ms_per_step_median_each_step_synchronised": round(1e3 * float(np.median(per_step)), 3) if per_step else None,
-        "triplets_last_step": int(n_out.sum()), "setup_s": round(gen_s, 1),
-        "pack_ms_once_per_resident_batch": {"ragged_pack_of_device_proposals": round(pack_ms, 1), "hr8_copy_of_roi_columns": round(pack_hr8_ms, 2),
-                                            "note": "outside the timed steps (the batch stays resident, as the reference's proposal.to(device)); "
-                                                    "per step it would add %.1f %%" % (100.0 * pack_hr8_ms / (1e3 * elapsed / args.steps))},
+        "triplets_last_step": n_triplets_last, "setup_s": round(gen_s, 1),
+        "timed_steps_ms": [round(1e3 * (b - a), 2) for a, b in zip(stamps[:-1], stamps[1:])],
+        "timed_call": ("model(proposal_list, topk) on device-resident TrajProposals: ragged pack (one gather launch writing the split form) + forward + "
+                       "construct_triplet + compaction + one D2H copy + per-video result tuples" if args.headline == "api" else
+                       "model.forward_packed(resident PackedBatch, topk) + the one D2H copy"),
+        "forward_api": (dict(value=round(value, 1), unit="pairs/s", ms_per_step=round(ms_per_step, 3), steps=args.steps, note="= the headline") if args.headline == "api" else other_leg),
+        "resident_packed_batch": (other_leg if args.headline == "api" else dict(value=round(value, 1), unit="pairs/s", ms_per_step=round(ms_per_step, 3), steps=args.steps, note="= the headline")),
+        "api_host_ms": {"pack_tables_and_launches": round(pack_host_ms, 2), "result_tuples": round(unpack_host_ms, 2),
+                        "note": "host side of one model(proposal_list) call at this batch size, each measured alone with the GPU idle (inside the timed call)"},
+        "modes": {"BIGC_FEAT_HR8": os.environ.get("BIGC_FEAT_HR8", "1"), "BIGC_PRESPLIT": os.environ.get("BIGC_PRESPLIT", "auto"),
+                  "BIGC_CHAINED": os.environ.get("BIGC_CHAINED", "1"), "batch_reads_split_features": reads_split},
     }
     line.update(legs)
     print(json.dumps(line))

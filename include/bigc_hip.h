@@ -247,6 +247,12 @@ typedef struct {
      * int that pass raised when a feature was out of the form's range (|x| >= 4096, NaN, Inf).  With it the eval forward runs
      * fc_feat2enti.0 (models/model_0v10.py:447) on operands that are already split: the K = 2048 GEMM's loop is DMA + MFMA only. */
     const void* feats_hr8; int64_t ld_feats_hr8; const int32_t* feats_hr8_flag;
+    /* optional (NULL = absent): the last dim_extra columns of `feats` (I3D / classeme, read by the time-mean of
+     * models/model_0v10.py:470) as a tensor of their own, (R, dim_extra) f32 at pitch ld_extra floats.  A batch packed for the eval
+     * forward (bigc_pack_tracklets) carries feats_hr8 + extra and NO `feats` (NULL): a feature element then exists once in HBM.
+     * Every path that is not the default eval forward (training, exact / bf16 mode, BIGC_CHAINED=0; see bigc_forward_reads_hr8)
+     * needs `feats` and fails with BIGC_ERR_ARG without it. */
+    const float* extra; int64_t ld_extra;
 } bigc_batch;
 
 typedef struct {
@@ -265,6 +271,9 @@ typedef struct {
     int32_t* range_flag;
 } bigc_outputs;
 
+/* 1 if bigc_forward with a range_flag output, on this handle in its current arithmetic mode, reads the visual features in the split
+ * form (bigc_batch.feats_hr8) -- then a batch may be packed without the f32 copy of those columns --, else 0 */
+int bigc_forward_reads_hr8(const bigc_model* m);
 size_t bigc_workspace_bytes(const bigc_model* m, const bigc_batch* b);
 int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                  int topk, const bigc_outputs* out);
@@ -523,6 +532,28 @@ int bigc_bce_logits_f32(void* stream, const float* x, int ldx, const float* y, i
 int bigc_assemble_rows_f32(void* stream, const float* raw, int ld_raw, int col0, int width, const float* raw2, int ld_raw2,
                            int col02, int width2, const int32_t* src_a, const int32_t* src_b, const int32_t* step_i,
                            const int32_t* step_div, float* out, int ld_out, int n_rows);
+
+/* ---- ragged pack of a batch (the stacking half of models/model_0v10.py:391-430; the per-tracklet tensors are those of
+ * dataloaders/dataloader_vidvrd.py:14-77 `TrajProposal`, moved to the device one by one by its .to(), :66-77) --------------------
+ * ONE launch gathers every tracklet's rows into the packed store of bigc_batch.  Tables (device): feat_src[t] / box_src[t] =
+ * address of tracklet t's (L_t, width) feature rows / (L_t, 4) boxes, f32, unit column stride; feat_ld[t] = row pitch of the
+ * feature rows in floats (NULL: width); trk_row_off as in bigc_batch.  Outputs, each optional: feats (R, width) f32 at pitch
+ * ld_feats; feats_hr8: columns [0, dim_feat) in the split form of bigc_gemm_ps at pitch ld_hr8_bytes (range_flag is or-ed with 1
+ * when an element is outside its range); extra: columns [dim_feat, width) f32 at pitch ld_extra; boxes (R, 4).  feat_src may
+ * be NULL (boxes only).  vectorized = 1 promises 16-byte aligned sources / pitches (16-byte loads), 0 = any alignment. */
+int bigc_pack_tracklets(void* stream, const uint64_t* feat_src, const int32_t* feat_ld, const uint64_t* box_src,
+                        const int32_t* trk_row_off, int n_trk, long n_rows, int width, int dim_feat, int vectorized, float* feats, long ld_feats,
+                        void* feats_hr8, long ld_hr8_bytes, float* extra, long ld_extra, float* boxes, int32_t* range_flag);
+/* per-video metadata of the same containers: cat_ids (N_v) int64, scores (N_v) f32, traj_durations (N_v, 2) int64 at the
+ * addresses cat_src[v] / score_src[v] / dura_src[v] -> trk_cat int32, trk_score f32, trk_dura int32 of bigc_batch */
+int bigc_pack_video_meta(void* stream, const uint64_t* cat_src, const uint64_t* score_src, const uint64_t* dura_src,
+                         const int32_t* vid_trk_off, int n_vid, int32_t* trk_cat, float* trk_score, int32_t* trk_dura);
+/* padded outputs of bigc_construct_triplets / bigc_forward -> the reference's return types back to back
+ * (models/model_0v10.py:776-785: int64 quintuples, f32 scores, int64 duration intersections, int64 query ids per video):
+ * video v's n_out[v] rows at rows [out_off[v], out_off[v+1]) of the compact arrays (each sized for n_vid * cap rows) */
+int bigc_compact_triplets(void* stream, const int32_t* quint, const float* scores, const int32_t* dura, const int32_t* qid,
+                          const int32_t* n_out, int n_vid, int cap, int64_t* out_quint, float* out_scores, int64_t* out_dura,
+                          int64_t* out_qid, int32_t* out_off);
 
 /* ---- Base_C.construct_triplet (models/model_pairwise_baseline.py:314-395) for all videos of a batch ----------------------------
  * pair_logits (n_pairs, n_pred): logits of every ordered tracklet pair (bigc_pair_forward; video v's pairs start at vid_pair_off[v],

@@ -1,0 +1,156 @@
+"""The ragged pack of a batch (``bigc_pack_tracklets`` / ``bigc_pack_video_meta`` / ``bigc_compact_triplets``, csrc/ingest.hip,
+csrc/triplet.hip; reference: the stacking inside models/model_0v10.py:391-430 over the containers of
+dataloaders/dataloader_vidvrd.py:14-77): the one-launch gather is bit-exact against ``torch.cat`` over the tracklet tensors, the
+split form it writes is byte for byte what ``bigc_split_rows_f32`` makes of the f32 rows, and ``forward(proposal_list)`` through it
+returns what the f32-packed path returns."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from bigc_hip import _lib
+from bigc_hip.packed import PackedBatch
+from bigc_hip.synthetic import TrajProposal, bigc_state_shapes, seeded_state_dict, synthetic_proposal
+
+DEV = "cuda:0"
+
+
+def _foreign(p, dev, misalign=False, pitch=0):
+    """the same video as the reference's container holds it: one separately allocated tensor per tracklet (optionally at an
+    address that is not 16-byte aligned, or as a row-strided view)"""
+    q = TrajProposal.__new__(TrajProposal)
+    q.video_name, q.video_len, q.video_wh, q.num_proposals = p.video_name, p.video_len, p.video_wh, p.num_proposals
+    q.cat_ids, q.scores, q.traj_durations = p.cat_ids.to(dev), p.scores.to(dev), p.traj_durations.to(dev)
+    q.bboxes_list, q.features_list = [], []
+    for b, f in zip(p.bboxes_list, p.features_list):
+        b, f = b.to(dev), f.to(dev)
+        if misalign:
+            buf = torch.empty((f.numel() + 1,), dtype=torch.float32, device=dev)
+            buf[1:].copy_(f.reshape(-1))
+            f = buf[1:].view(f.shape)
+        elif pitch:
+            buf = torch.zeros((f.shape[0], f.shape[1] + pitch), dtype=torch.float32, device=dev)
+            buf[:, :f.shape[1]].copy_(f)
+            f = buf[:, :f.shape[1]]
+        else:
+            f = f.clone()
+        q.bboxes_list.append(b.clone())
+        q.features_list.append(f)
+    q.dim_feat = p.dim_feat
+    return q
+
+
+def _videos(width, n=(7, 3, 12), seeds=(11, 12, 13), len_range=(3, 40)):
+    return [synthetic_proposal(s, n_trajs=k, feat_width=width, len_range=len_range) for s, k in zip(seeds, n)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["blocks", "foreign", "misaligned", "pitched"])
+def test_gather_is_bit_exact_against_torch_cat(kind):
+    width, dim_feat = 96 + 40, 96
+    host = _videos(width)
+    want_f = torch.cat([f for p in host for f in p.features_list], 0)
+    want_b = torch.cat([b for p in host for b in p.bboxes_list], 0)
+    if kind == "blocks":
+        props = [p.to(DEV) for p in _videos(width)]
+    else:
+        props = [_foreign(p, DEV, misalign=kind == "misaligned", pitch=8 if kind == "pitched" else 0) for p in host]
+    pk = PackedBatch(props, DEV, "lazy")
+    assert pk._vectorized == (kind != "misaligned")
+    pk.materialize("f32")
+    assert torch.equal(pk.feats.cpu(), want_f) and torch.equal(pk.boxes.cpu(), want_b)
+    assert torch.equal(pk.trk_cat.cpu(), torch.cat([p.cat_ids for p in host]).int())
+    assert torch.equal(pk.trk_score.cpu(), torch.cat([p.scores for p in host]))
+    assert torch.equal(pk.trk_dura.cpu(), torch.cat([p.traj_durations for p in host]).int())
+    # the split form straight from the sources == the split of the gathered f32 rows, byte for byte; the other columns as f32
+    pk2 = PackedBatch(props, DEV, "lazy")
+    pk2.materialize("hr8", dim_feat)
+    assert pk2._feats is None and pk2.feats_hr8.shape == (pk.n_rows, 4 * dim_feat)
+    pk.materialize("hr8", dim_feat)                      # from its f32 rows (bigc_split_rows_f32)
+    assert torch.equal(pk2.feats_hr8, pk.feats_hr8)
+    assert torch.equal(pk2.extra.cpu(), want_f[:, dim_feat:]) and torch.equal(pk2.boxes.cpu(), want_b)
+    assert int(pk2.feats_hr8_flag.item()) == 0
+    # asked for later, the f32 rows are gathered from the sources again
+    assert torch.equal(pk2.feats.cpu(), want_f)
+
+
+@pytest.mark.gpu
+def test_gather_raises_the_range_flag_and_handles_long_tracklets():
+    width = 64
+    host = _videos(width, n=(2, 5), seeds=(5, 6), len_range=(300, 700))
+    host[1].features_list[3][17, 9] = 5000.0            # outside the split form's range (|x| >= 4096)
+    want_f = torch.cat([f for p in host for f in p.features_list], 0)
+    props = [p.to(DEV) for p in host]
+    pk = PackedBatch(props, DEV, "lazy")
+    pk.materialize("hr8", 64)
+    assert int(pk.feats_hr8_flag.item()) == 1 and pk.extra is None
+    assert torch.equal(pk.feats.cpu(), want_f)
+
+
+def _model(cfg_name="CONFIG_TINY", seed=5):
+    from models import BIG_C_vidvrd
+    cfg = cases.get_cfg(cfg_name)
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), seed, att_gain=4.0)
+    d = tempfile.mkdtemp()
+    np.save(d + "/b.npy", sd["bias_matrix"].numpy()); np.save(d + "/e.npy", sd["EntiNameEmb"].numpy())
+    model = BIG_C_vidvrd(dict(cfg, bias_matrix_path=d + "/b.npy", EntiNameEmb_path=d + "/e.npy"), is_train=False)
+    model.load_state_dict(sd)
+    return cfg, model.to(DEV)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", ["CONFIG_TINY", "CONFIG_V"])
+def test_forward_of_a_proposal_list_equals_the_f32_packed_forward(cfg_name):
+    """forward(proposal_list) gathers straight into the split form; a batch packed as f32 rows and split afterwards must give the
+    same bits, and the per-video tuples must be the padded arrays' rows in the reference's dtypes"""
+    cfg, model = _model(cfg_name)
+    width = cfg["dim_feat"] + (cfg.get("dim_i3d") or 0)
+    n = (9, 0, 17, 5) if cfg_name != "CONFIG_V" else (64, 33)
+    host = [synthetic_proposal(40 + i, n_trajs=k, feat_width=width, num_enti_cats=cfg["num_enti_cats"]) for i, k in enumerate(n)]
+    props = [p.to(DEV) for p in host]
+    res = model(props, topk=3)
+    live = [p for p in props if p.num_proposals > 0]
+    pk = PackedBatch(live, DEV)                                   # f32 rows
+    out = model.forward_packed(pk, 3)
+    cnt = model.counts(out).tolist()
+    j = 0
+    for p, r in zip(props, res):
+        if p.num_proposals == 0:
+            assert r is None
+            continue
+        k = cnt[j]
+        if k == 0:
+            assert r is None
+        else:
+            assert r[0].dtype == torch.int64 and r[2].dtype == torch.int64 and r[3].dtype == torch.int64 and r[1].dtype == torch.float32
+            assert torch.equal(r[0], out["quint"][j, :k].long()) and torch.equal(r[1], out["scores"][j, :k])
+            assert torch.equal(r[2], out["dura"][j, :k].long()) and torch.equal(r[3], out["qid"][j, :k].long())
+        j += 1
+    if model.engine().lib.bigc_forward_reads_hr8(model.engine().handle):
+        pk2 = PackedBatch(live, DEV, "lazy")
+        out2 = model.forward_packed(pk2, 3)
+        assert pk2._feats is None and pk2.feats_hr8 is not None           # gathered straight into the split form
+        assert torch.equal(out2["pred_logits"], out["pred_logits"]) and model.counts(out2).tolist() == cnt
+        for j, k in enumerate(cnt):                                       # (rows past a video's count are padding, never written)
+            assert torch.equal(out2["quint"][j, :k], out["quint"][j, :k]) and torch.equal(out2["scores"][j, :k], out["scores"][j, :k])
+
+
+@pytest.mark.gpu
+def test_out_of_range_feature_falls_back_to_the_exact_path_through_the_api():
+    cfg, model = _model("CONFIG_V")
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    host = [synthetic_proposal(77, n_trajs=12, feat_width=width, num_enti_cats=cfg["num_enti_cats"])]
+    host[0].features_list[2][3, 100] = 6000.0
+    props = [p.to(DEV) for p in host]
+    res = model(props, topk=3)
+    eng = model.engine()
+    eng.set_mode(1, -1)
+    try:
+        want = model(props, topk=3)
+    finally:
+        eng.set_mode(-1, -1)
+    for a, b in zip(res[0], want[0]):
+        assert torch.equal(a, b)

@@ -31,7 +31,8 @@ class bigc_batch(ctypes.Structure):
                 ("trk_conv_off", c_void_p), ("trk_vid", c_void_p), ("trk_dura", c_void_p),
                 ("trk_cat", c_void_p), ("trk_score", c_void_p), ("vid_trk_off", c_void_p),
                 ("vid_tmax", c_void_p), ("vid_wh", c_void_p),
-                ("feats_hr8", c_void_p), ("ld_feats_hr8", ctypes.c_int64), ("feats_hr8_flag", c_void_p)]
+                ("feats_hr8", c_void_p), ("ld_feats_hr8", ctypes.c_int64), ("feats_hr8_flag", c_void_p),
+                ("extra", c_void_p), ("ld_extra", ctypes.c_int64)]
 
 
 class bigc_outputs(ctypes.Structure):
@@ -92,6 +93,12 @@ _SIGS = {
                                     c_int, c_int, c_int, c_int, c_int, c_float]),
     "bigc_assemble_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int, c_int]),
+    "bigc_pack_tracklets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_long, c_int, c_int, c_int, c_void_p, ctypes.c_long,
+                                    c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_void_p, c_void_p]),
+    "bigc_pack_video_meta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "bigc_compact_triplets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
+    "bigc_forward_reads_hr8": (c_int, [c_void_p]),
     "bigc_bbox_feat_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "bigc_conv_index": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "bigc_adaptive_maxpool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),

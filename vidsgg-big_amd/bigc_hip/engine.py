@@ -137,22 +137,34 @@ class BigcEngine(object):
             out["scores"] = torch.empty((B, cap, 3), dtype=torch.float32, device=dev)
             out["dura"] = torch.empty((B, cap, 2), dtype=torch.int32, device=dev)
             out["qid"] = torch.empty((B, cap), dtype=torch.int32, device=dev)
-            # row counts and, behind them, the range flag of the split-operand GEMM path: ONE D2H copy returns both
-            out["_counts"] = torch.zeros((B + 1,), dtype=torch.int32, device=dev)
-            out["n_out"] = out["_counts"][:B]
-            out["range_flag"] = out["_counts"][B:]
+            out["n_out"] = torch.zeros((B,), dtype=torch.int32, device=dev)
+            # row offsets of the compacted results and, behind them, the range flag of the split-operand GEMM path: ONE D2H copy returns both
+            out["_counts"] = torch.zeros((B + 2,), dtype=torch.int32, device=dev)
+            out["range_flag"] = out["_counts"][B + 1:]
+            # the reference's return types, all videos back to back (bigc_compact_triplets): rows [off[v], off[v+1]) belong to video v
+            out["c_quint"] = torch.empty((B * cap, 5), dtype=torch.int64, device=dev)
+            out["c_scores"] = torch.empty((B * cap, 3), dtype=torch.float32, device=dev)
+            out["c_dura"] = torch.empty((B * cap, 2), dtype=torch.int64, device=dev)
+            out["c_qid"] = torch.empty((B * cap,), dtype=torch.int64, device=dev)
         o = _lib.bigc_outputs()
         for name, _ in _lib.bigc_outputs._fields_:
             setattr(o, name, out[name].data_ptr() if name in out else None)
-        # eval forwards read the visual features in the split form (written once per packed batch; BIGC_FEAT_HR8=0 switches it off)
-        if with_triplets and c.dim_feat % 32 == 0 and os.environ.get("BIGC_FEAT_HR8", "1") != "0":
-            packed.split_features(c.dim_feat)
-        b = packed.as_struct()
+        # The default eval forward reads the visual features in the split form: a batch that has no feature rows yet is gathered
+        # straight into it (one launch, csrc/ingest.hip); every other mode reads f32 rows.  BIGC_FEAT_HR8=0 switches the form off.
+        use_hr8 = bool(with_triplets and os.environ.get("BIGC_FEAT_HR8", "1") != "0" and self.lib.bigc_forward_reads_hr8(self.handle))
+        if use_hr8:
+            packed.materialize("hr8", c.dim_feat)
+        b = packed.as_struct(need_f32=not use_hr8)
         need = self.lib.bigc_workspace_bytes(self.handle, ctypes.byref(b))
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         _lib.check(self.lib.bigc_forward(self.handle, _lib.current_stream(), ctypes.byref(b), self._ws.data_ptr(),
                                          self._ws.numel(), int(topk), ctypes.byref(o)))
+        if with_triplets:
+            _lib.check(self.lib.bigc_compact_triplets(_lib.current_stream(), out["quint"].data_ptr(), out["scores"].data_ptr(), out["dura"].data_ptr(),
+                                                      out["qid"].data_ptr(), out["n_out"].data_ptr(), B, cap, out["c_quint"].data_ptr(),
+                                                      out["c_scores"].data_ptr(), out["c_dura"].data_ptr(), out["c_qid"].data_ptr(),
+                                                      out["_counts"].data_ptr()))
         return out
 
     def pair_forward(self, packed, keep_intermediates=False):

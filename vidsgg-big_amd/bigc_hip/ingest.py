@@ -110,6 +110,8 @@ def load_pku_tracklets(video_name, track_res, dim_boxfeature, min_frames_th, max
         return TrajProposal(video_name, video_len or 0, video_wh, [], [], [], [], [])
     feats = assemble_features(plan, track_res, dim_boxfeature, i3d_res, dim_i3d, device)
     lens = [int(b.shape[0]) for b in plan["boxes"]]
-    p = TrajProposal(video_name, video_len or (max(d[1] for d in plan["durations"]) + 1), video_wh, plan["cat_ids"], plan["scores"],
-                     plan["durations"], plan["boxes"], list(torch.split(feats, lens, 0)))
-    return p
+    # the tracklets stay views of the one assembled feature tensor (and of one box tensor): the batch packer reads their addresses
+    # off the block (TrajProposal.from_blocks)
+    boxes = torch.cat(plan["boxes"], 0).to(feats.device)
+    return TrajProposal.from_blocks(video_name, video_len or (max(d[1] for d in plan["durations"]) + 1), video_wh, plan["cat_ids"], plan["scores"],
+                                    plan["durations"], lens, boxes, feats)

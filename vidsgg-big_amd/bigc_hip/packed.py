@@ -2,10 +2,20 @@
 
 The reference keeps one small tensor per tracklet and stretches/stacks them inside
 ``forward`` (models/model_0v10.py:391-430).  Here the tracklets of a batch of videos are
-concatenated once into flat HBM buffers (features ``(sum L_i, D)``, boxes ``(sum L_i, 4)``)
-plus int32 offset tables, which is what ``bigc_forward`` consumes (``bigc_batch`` in
-``include/bigc_hip.h``).  Packing is the analogue of the reference's ``proposal.to(device)``;
-a packed batch can be kept resident and reused.
+gathered into flat HBM buffers plus int32 offset tables, which is what ``bigc_forward``
+consumes (``bigc_batch`` in ``include/bigc_hip.h``).
+
+Packing is ONE kernel launch (``bigc_pack_tracklets``, csrc/ingest.hip) over a table of
+per-tracklet source addresses -- not a ``torch.cat`` over thousands of tensors -- and writes
+the rows directly in the form the forward reads:
+
+* ``"hr8"`` (the eval forward's form): the visual (RoI) columns as f16 head / residual pairs
+  (the operand format of csrc/gemm_ps.hip, same footprint as f32) + the remaining columns
+  (I3D / classeme) as an f32 tensor of their own.  A feature element exists once in HBM.
+* ``"f32"``: full f32 rows (training, exact / bf16 arithmetic modes).
+
+The form is chosen at first use (``materialize``); a packed batch can be kept resident and
+reused.  Per-video metadata (categories, scores, durations) is gathered by a second small launch.
 """
 import numpy as np
 import torch
@@ -13,82 +23,240 @@ import torch
 from . import _lib
 
 
+def _block_table(base_ptr, lens, width):
+    """addresses of the tracklets of one contiguous (sum L, width) f32 block"""
+    off = np.zeros(len(lens), dtype=np.uint64)
+    np.cumsum(lens[:-1], out=off[1:])
+    return np.uint64(base_ptr) + off * np.uint64(4 * width)
+
+
+def tracklet_table(p, device):
+    """Per-video source table of a TrajProposal-like object: tracklet lengths, addresses and row pitches of the feature rows,
+    addresses of the boxes -- what ``bigc_pack_tracklets`` gathers from.  Cached on the object (``_bigc_pack``): containers
+    built by this package (``TrajProposal.from_blocks`` / ``.to()``, ``bigc_hip.ingest``) hold their tracklets as views of one
+    block per video and get the table by arithmetic; for foreign containers (the reference's own ``TrajProposal``) the
+    tensors are visited once.  The cache is checked against the lists' length and first / last addresses: replacing a
+    tensor in the middle of ``features_list`` after the first forward needs ``del proposal._bigc_pack``."""
+    c = getattr(p, "_bigc_pack", None)
+    if c is not None and "blocks" in c:
+        # a container of this package: its tracklets ARE views of two blocks (no per-tracklet tensor objects exist)
+        if c["device"] == device and c["blocks"] == (p._feat_block.data_ptr(), p._box_block.data_ptr()) and c["n"] == int(p.num_proposals):
+            return c
+        c = None
+    fl, bl = p.features_list, p.bboxes_list
+    n = len(bl)
+    assert n == len(fl) and n == int(p.num_proposals)
+    if c is not None and c["n"] == n and c["device"] == device and c["ends"] == (fl[0].data_ptr(), fl[-1].data_ptr(), bl[0].data_ptr(), bl[-1].data_ptr()):
+        return c
+    keep = []
+    width = int(fl[0].shape[1])
+
+    def usable(t, cols, contiguous):
+        assert t.dim() == 2 and t.shape[1] == cols
+        if t.dtype != torch.float32 or t.device != device or t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < cols) or \
+                (contiguous and not t.is_contiguous()):
+            t = t.to(device=device, dtype=torch.float32).contiguous()
+            keep.append(t)
+        return t
+
+    fl2, bl2 = [usable(f, width, False) for f in fl], [usable(b, 4, True) for b in bl]
+    lens = np.fromiter((b.shape[0] for b in bl2), dtype=np.int64, count=n)
+    flens = np.fromiter((f.shape[0] for f in fl2), dtype=np.int64, count=n)
+    assert (lens == flens).all() and lens.min() > 0, "every tracklet needs as many feature rows as boxes"
+    fptr = np.fromiter((f.data_ptr() for f in fl2), dtype=np.uint64, count=n)
+    bptr = np.fromiter((b.data_ptr() for b in bl2), dtype=np.uint64, count=n)
+    fld = np.fromiter((f.stride(0) if f.shape[0] > 1 else width for f in fl2), dtype=np.int64, count=n)
+    c = dict(n=n, device=device, width=width, lens=lens, fptr=fptr, bptr=bptr, fld=None if (fld == width).all() else fld.astype(np.int32),
+             aligned=bool(((fptr | bptr) % np.uint64(16) == 0).all() and (fld % 4 == 0).all()),
+             ends=(fl[0].data_ptr(), fl[-1].data_ptr(), bl[0].data_ptr(), bl[-1].data_ptr()), keep=keep)
+    try:
+        p._bigc_pack = c
+    except Exception:
+        pass
+    return c
+
+
 class PackedBatch(object):
-    def __init__(self, proposals, device):
-        """``proposals``: list of non-empty TrajProposal-like objects (see bigc_hip.synthetic.TrajProposal)."""
+    def __init__(self, proposals, device, features="f32"):
+        """``proposals``: list of non-empty TrajProposal-like objects (see bigc_hip.synthetic.TrajProposal).
+        ``features``: "f32" / "hr8" = gather the feature rows now in that form, "lazy" = at first use (the engine picks the form
+        its forward reads; ``dim_feat`` is only known there)."""
         assert len(proposals) > 0
         device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         self.proposals = proposals
         n_per_vid = [int(p.num_proposals) for p in proposals]
         assert min(n_per_vid) > 0, "empty videos must be filtered out before packing"
-        lens, tmax, wh = [], [], []
-        for p in proposals:
-            l = [int(b.shape[0]) for b in p.bboxes_list]
-            for b, f in zip(p.bboxes_list, p.features_list):
-                assert b.shape[0] == f.shape[0] and b.shape[1] == 4
-            lens.append(np.asarray(l, dtype=np.int64))
-            tmax.append(int(max(l)))
-            wh.append([float(p.video_wh[0]), float(p.video_wh[1])])
+        tabs = [tracklet_table(p, device) for p in proposals]
+        self._keep = [t["keep"] for t in tabs if t["keep"]]
+        self.feat_width = tabs[0]["width"]
+        assert all(t["width"] == self.feat_width for t in tabs), "all videos of a batch need the same feature width"
         self.n_vid = len(proposals)
         self.n_trk = int(sum(n_per_vid))
         self.max_trk = int(max(n_per_vid))
-        all_lens = np.concatenate(lens)
+        all_lens = np.concatenate([t["lens"] for t in tabs])
+        tmax = np.asarray([int(t["lens"].max()) for t in tabs])
+        wh = [[float(p.video_wh[0]), float(p.video_wh[1])] for p in proposals]
         self.n_rows = int(all_lens.sum())
         trk_vid = np.repeat(np.arange(self.n_vid), n_per_vid)
-        t_o = (np.asarray(tmax) - 1) // 2 + 1                     # conv k3/s2/p1 output length
+        t_o = (tmax - 1) // 2 + 1                                 # conv k3/s2/p1 output length
         self.n_conv = int((t_o[trk_vid]).sum())
         assert self.n_rows < 2 ** 31 and self.n_conv * 3 < 2 ** 31
-
-        def on_device(t):                                         # (a no-op .to() still costs microseconds; x 2 per tracklet)
-            return t if t.device == device else t.to(device)
-
-        # every offset table in ONE host-to-device copy
         self.vid_trk_off_host = np.concatenate([[0], np.cumsum(n_per_vid)]).astype(np.int64)
+        self._vectorized = all(t["aligned"] for t in tabs) and self.feat_width % 4 == 0
+
+        # per-video metadata: gathered on the device when the containers hold what the reference's do (int64 / f32 / int64)
+        meta_ok = device.type == "cuda" and all(
+            p.cat_ids.dtype == torch.int64 and p.scores.dtype == torch.float32 and p.traj_durations.dtype == torch.int64
+            and p.cat_ids.device == device and p.scores.device == device and p.traj_durations.device == device
+            and p.cat_ids.is_contiguous() and p.scores.is_contiguous() and p.traj_durations.is_contiguous() for p in proposals)
+
+        # every table in ONE host-to-device copy: [u64 feature addresses | u64 box addresses | u64 metadata addresses | int32 tables]
+        any_ld = any(t["fld"] is not None for t in tabs)
+        u64 = [np.concatenate([t["fptr"] for t in tabs]), np.concatenate([t["bptr"] for t in tabs])]
+        if meta_ok:
+            u64 += [np.asarray([p.cat_ids.data_ptr() for p in proposals], dtype=np.uint64),
+                    np.asarray([p.scores.data_ptr() for p in proposals], dtype=np.uint64),
+                    np.asarray([p.traj_durations.data_ptr() for p in proposals], dtype=np.uint64)]
         tables = [np.concatenate([[0], np.cumsum(all_lens)]), np.concatenate([[0], np.cumsum(t_o[trk_vid])]), trk_vid,
-                  self.vid_trk_off_host, np.asarray(tmax)]
-        sizes = [(len(a) + 3) // 4 * 4 for a in tables]          # 16-byte aligned starts
-        blob = np.zeros((sum(sizes),), dtype=np.int32)
-        starts = np.concatenate([[0], np.cumsum(sizes)])
-        for a, o in zip(tables, starts):
-            blob[o:o + len(a)] = a
+                  self.vid_trk_off_host, tmax]
+        if any_ld:
+            tables.append(np.concatenate([t["fld"] if t["fld"] is not None else np.full(t["n"], self.feat_width, np.int32) for t in tabs]))
+        n64 = [(len(a) + 1) // 2 * 2 for a in u64]                # 16-byte aligned starts
+        n32 = [(len(a) + 3) // 4 * 4 for a in tables]
+        blob = np.zeros((8 * sum(n64) + 4 * sum(n32),), dtype=np.uint8)
+        b64, b32 = blob[:8 * sum(n64)].view(np.uint64), blob[8 * sum(n64):].view(np.int32)
+        s64, s32 = np.concatenate([[0], np.cumsum(n64)]), np.concatenate([[0], np.cumsum(n32)])
+        for a, o in zip(u64, s64):
+            b64[o:o + len(a)] = a
+        for a, o in zip(tables, s32):
+            b32[o:o + len(a)] = a
         blob_d = _lib.upload(blob, device)
-        self.trk_row_off, self.trk_conv_off, self.trk_vid, self.vid_trk_off, self.vid_tmax = \
-            [blob_d[o:o + len(a)] for a, o in zip(tables, starts)]
+        d64, d32 = blob_d[:8 * sum(n64)].view(torch.int64), blob_d[8 * sum(n64):].view(torch.int32)
+        self._feat_src, self._box_src = d64[s64[0]:s64[0] + self.n_trk], d64[s64[1]:s64[1] + self.n_trk]
+        views = [d32[o:o + len(a)] for a, o in zip(tables, s32)]
+        self.trk_row_off, self.trk_conv_off, self.trk_vid, self.vid_trk_off, self.vid_tmax = views[:5]
+        self._feat_ld = views[5] if any_ld else None
         self.vid_wh = _lib.upload(np.asarray(wh, dtype=np.float32).reshape(-1, 2), device)
-        self.trk_dura = torch.cat([on_device(p.traj_durations) for p in proposals], 0).to(torch.int32).contiguous()
-        self.trk_cat = torch.cat([on_device(p.cat_ids) for p in proposals], 0).to(torch.int32).contiguous()
-        self.trk_score = torch.cat([on_device(p.scores) for p in proposals], 0).to(torch.float32).contiguous()
-        self.boxes = torch.cat([on_device(b) for p in proposals for b in p.bboxes_list], 0).to(torch.float32).contiguous()
-        self.feats = torch.cat([on_device(f) for p in proposals for f in p.features_list], 0).to(torch.float32).contiguous()
-        self.feat_width = int(self.feats.shape[1])
-        self.feats_hr8, self.feats_hr8_flag = None, None          # see split_features()
-        assert self.boxes.shape == (self.n_rows, 4) and self.feats.shape[0] == self.n_rows
+        if meta_ok:
+            self.trk_dura = torch.empty((self.n_trk, 2), dtype=torch.int32, device=device)
+            self.trk_cat = torch.empty((self.n_trk,), dtype=torch.int32, device=device)
+            self.trk_score = torch.empty((self.n_trk,), dtype=torch.float32, device=device)
+            srcs = [d64[s64[k]:s64[k] + self.n_vid] for k in (2, 3, 4)]
+            _lib.check(_lib.load().bigc_pack_video_meta(_lib.current_stream(), srcs[0].data_ptr(), srcs[1].data_ptr(), srcs[2].data_ptr(),
+                                                        self.vid_trk_off.data_ptr(), self.n_vid, self.trk_cat.data_ptr(), self.trk_score.data_ptr(),
+                                                        self.trk_dura.data_ptr()))
+        else:
+            def on_device(t):
+                return t if t.device == device else t.to(device)
+            self.trk_dura = torch.cat([on_device(p.traj_durations) for p in proposals], 0).to(torch.int32).contiguous()
+            self.trk_cat = torch.cat([on_device(p.cat_ids) for p in proposals], 0).to(torch.int32).contiguous()
+            self.trk_score = torch.cat([on_device(p.scores) for p in proposals], 0).to(torch.float32).contiguous()
+        self._blob = blob_d
+        self._feats, self._boxes, self.extra = None, None, None
+        self.feats_hr8, self.feats_hr8_flag = None, None
+        if features != "lazy":
+            assert features == "f32", "the split form needs dim_feat: PackedBatch(..., 'lazy') then materialize('hr8', dim_feat)"
+            self.materialize("f32")
+
+    # ---- the feature rows ---------------------------------------------------------------------------------------------------
+    def materialize(self, form, dim_feat=None):
+        """Gather the tracklets' rows (one launch; the boxes ride along the first time).  ``form`` "f32": full f32 rows;
+        "hr8": the first ``dim_feat`` columns in the split form + the rest as ``extra`` (f32).  Idempotent; a batch that
+        already holds f32 rows gets the split form from them (``bigc_split_rows_f32``), and one whose source containers were
+        dropped (``proposals = None``) cannot be re-gathered."""
+        dev, R, W = self.device, self.n_rows, self.feat_width
+        if form == "f32":
+            if self._feats is not None:
+                return
+        else:
+            assert form == "hr8" and dim_feat is not None and dim_feat % 8 == 0 and dim_feat <= W
+            if self.feats_hr8 is not None and self.feats_hr8.shape[1] == 4 * dim_feat:
+                return
+        if dev.type != "cuda":
+            # host-only use (tests of the offset tables): no kernels off the GPU
+            assert form == "f32", "the split form is written by the HIP library only"
+            self._boxes = torch.cat([b for p in self.proposals for b in p.bboxes_list], 0).to(torch.float32).contiguous()
+            self._feats = torch.cat([f for p in self.proposals for f in p.features_list], 0).to(torch.float32).contiguous()
+            return
+        lib = _lib.load()
+        if form == "hr8" and self._feats is not None:
+            self.feats_hr8 = torch.empty((R, 4 * dim_feat), dtype=torch.uint8, device=dev)
+            self.feats_hr8_flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+            _lib.check(lib.bigc_split_rows_f32(_lib.current_stream(), self._feats.data_ptr(), W, self.feats_hr8.data_ptr(), 4 * dim_feat,
+                                               R, dim_feat, self.feats_hr8_flag.data_ptr()))
+            return
+        assert self.proposals is not None, "the source containers of this batch were dropped: it cannot be gathered again in another form"
+        boxes = None
+        if self._boxes is None:
+            boxes = torch.empty((R, 4), dtype=torch.float32, device=dev)
+        feats = hr8 = extra = flag = None
+        if form == "f32":
+            feats = torch.empty((R, W), dtype=torch.float32, device=dev)
+        else:
+            hr8 = torch.empty((R, 4 * dim_feat), dtype=torch.uint8, device=dev)
+            flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+            if W > dim_feat:
+                extra = torch.empty((R, W - dim_feat), dtype=torch.float32, device=dev)
+        vec = self._vectorized and (form == "f32" or (dim_feat % 4 == 0 and (W - dim_feat) % 4 == 0))
+        _lib.check(lib.bigc_pack_tracklets(_lib.current_stream(), self._feat_src.data_ptr(), _lib.ptr(self._feat_ld), self._box_src.data_ptr(),
+                                           self.trk_row_off.data_ptr(), self.n_trk, R, W, dim_feat if form == "hr8" else W, 1 if vec else 0,
+                                           _lib.ptr(feats), W, _lib.ptr(hr8), 4 * (dim_feat or 0), _lib.ptr(extra), (W - dim_feat) if extra is not None else 0,
+                                           _lib.ptr(boxes), _lib.ptr(flag)))
+        if boxes is not None:
+            self._boxes = boxes
+        if form == "f32":
+            self._feats = feats
+        else:
+            self.feats_hr8, self.feats_hr8_flag, self.extra = hr8, flag, extra
 
     def split_features(self, dim_feat):
-        """The visual feature columns once more in the split form "hr8" (pairs of f16, same footprint as f32; csrc/gemm_ps.hip): an
-        eval forward then runs fc_feat2enti.0 on operands that are already split.  One pass over the features (read 4 B, write 4 B
-        per element; a real ingest path writes the form while it assembles the rows, csrc/ingest.hip).  Idempotent."""
-        if self.feats_hr8 is not None and self.feats_hr8.shape[1] == 4 * dim_feat:
-            return
-        assert dim_feat % 8 == 0 and dim_feat <= self.feat_width
-        lib = _lib.load()
-        self.feats_hr8 = torch.empty((self.n_rows, 4 * dim_feat), dtype=torch.uint8, device=self.device)
-        self.feats_hr8_flag = torch.zeros((1,), dtype=torch.int32, device=self.device)
-        _lib.check(lib.bigc_split_rows_f32(_lib.current_stream(), self.feats.data_ptr(), self.feat_width, self.feats_hr8.data_ptr(), 4 * dim_feat,
-                                           self.n_rows, dim_feat, self.feats_hr8_flag.data_ptr()))
+        """(kept name) the visual feature columns in the split form "hr8": see ``materialize``"""
+        self.materialize("hr8", dim_feat)
+
+    @property
+    def feats(self):
+        """(R, width) f32 rows, gathered at first use"""
+        if self._feats is None:
+            self.materialize("f32")
+        return self._feats
+
+    @property
+    def boxes(self):
+        if self._boxes is None:
+            if self.device.type != "cuda":
+                self.materialize("f32")
+            else:
+                self._boxes = torch.empty((self.n_rows, 4), dtype=torch.float32, device=self.device)
+                _lib.check(_lib.load().bigc_pack_tracklets(_lib.current_stream(), None, None, self._box_src.data_ptr(), self.trk_row_off.data_ptr(),
+                                                           self.n_trk, self.n_rows, self.feat_width, self.feat_width, 0, None, 0, None, 0, None, 0,
+                                                           self._boxes.data_ptr(), None))
+        return self._boxes
+
+    def drop_sources(self):
+        """forget the source containers (their tensors may then be freed); the gathered forms stay"""
+        self.proposals, self._keep = None, None
 
     def n_pairs(self):
         """tracklet-pairs of the batch: sum_v N_v (N_v - 1)."""
         n = np.diff(self.vid_trk_off_host)
         return int((n * (n - 1)).sum())
 
-    def as_struct(self):
+    def as_struct(self, need_f32=True):
+        """``need_f32``: the call reads ``bigc_batch.feats`` (everything but the default eval forward, which reads the split form
+        when the batch holds it)"""
+        if need_f32 or self.feats_hr8 is None:
+            self.materialize("f32")
         b = _lib.bigc_batch()
         b.n_vid, b.n_trk, b.n_rows, b.n_conv, b.max_trk = self.n_vid, self.n_trk, self.n_rows, self.n_conv, self.max_trk
-        for name in ("feats", "boxes", "trk_row_off", "trk_conv_off", "trk_vid", "trk_dura", "trk_cat",
-                     "trk_score", "vid_trk_off", "vid_tmax", "vid_wh"):
+        for name in ("trk_row_off", "trk_conv_off", "trk_vid", "trk_dura", "trk_cat", "trk_score", "vid_trk_off", "vid_tmax", "vid_wh"):
             setattr(b, name, getattr(self, name).data_ptr())
+        b.boxes = self.boxes.data_ptr()
+        b.feats = self._feats.data_ptr() if self._feats is not None else None
         if self.feats_hr8 is not None:
             b.feats_hr8, b.ld_feats_hr8, b.feats_hr8_flag = self.feats_hr8.data_ptr(), int(self.feats_hr8.shape[1]), self.feats_hr8_flag.data_ptr()
+            if self.extra is not None:
+                b.extra, b.ld_extra = self.extra.data_ptr(), int(self.extra.shape[1])
         return b

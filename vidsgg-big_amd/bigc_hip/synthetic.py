@@ -44,15 +44,97 @@ class TrajProposal(object):
             assert self.bboxes_list[i].shape == (n, 4)
             assert self.features_list[i].shape[0] == n
 
+    @classmethod
+    def from_blocks(cls, video_name, video_len, video_wh, cat_ids, scores, traj_durations, lens, box_block, feat_block):
+        """The same container with the tracklets as views of ONE (sum L, 4) box tensor and ONE (sum L, D) feature tensor per
+        video (what ``bigc_hip.ingest`` assembles and what ``.to()`` produces): the batch packer then gets every tracklet's
+        address by arithmetic instead of visiting the tensors."""
+        p = cls.__new__(cls)
+        p.video_name, p.video_len, p.video_wh = video_name, int(video_len), tuple(video_wh)
+        p.num_proposals = len(lens)
+        if p.num_proposals == 0:
+            return p
+        p.cat_ids = torch.as_tensor(cat_ids, dtype=torch.long)
+        p.scores = torch.as_tensor(scores, dtype=torch.float32)
+        p.traj_durations = torch.as_tensor(traj_durations, dtype=torch.long)
+        p._set_blocks(box_block, feat_block, [int(l) for l in lens])
+        p.dim_feat = int(feat_block.shape[1])
+        dev = feat_block.device
+        p.cat_ids, p.scores, p.traj_durations = p.cat_ids.to(dev), p.scores.to(dev), p.traj_durations.to(dev)
+        return p
+
+    def _set_blocks(self, box_block, feat_block, lens):
+        import numpy as np
+        assert box_block.dtype == torch.float32 and feat_block.dtype == torch.float32 and box_block.is_contiguous() and feat_block.is_contiguous()
+        assert box_block.shape == (sum(lens), 4) and feat_block.shape[0] == sum(lens)
+        # The per-tracklet tensors are views of the blocks, made when somebody asks for the lists (the properties below) and not kept:
+        # 256 resident videos would otherwise keep 33 000 tensor objects alive, and every full pass of Python's cyclic garbage collector
+        # over them stalls the calling thread for ~70 ms (measured: one model(proposal_list) call in 40 took 100 instead of 25 ms).
+        self._lists = None
+        self._box_block, self._feat_block, self._lens = box_block, feat_block, [int(l) for l in lens]
+        ln = np.asarray(lens, dtype=np.int64)
+        off = np.zeros(len(lens), dtype=np.uint64)
+        np.cumsum(ln[:-1], out=off[1:])
+        width = int(feat_block.shape[1])
+        fptr = np.uint64(feat_block.data_ptr()) + off * np.uint64(4 * width)
+        bptr = np.uint64(box_block.data_ptr()) + off * np.uint64(16)
+        # the source table the batch packer reads (bigc_hip.packed.tracklet_table): same fields, no per-tensor visit
+        self._bigc_pack = dict(n=len(lens), device=feat_block.device, width=width, lens=ln, fptr=fptr, bptr=bptr, fld=None,
+                               aligned=bool(feat_block.data_ptr() % 16 == 0 and box_block.data_ptr() % 16 == 0 and width % 4 == 0),
+                               blocks=(feat_block.data_ptr(), box_block.data_ptr()), keep=[])
+
+    @property
+    def features_list(self):
+        if self._lists is not None:
+            return self._lists[1]
+        return list(torch.split(self._feat_block, self._lens, 0))
+
+    @features_list.setter
+    def features_list(self, value):
+        self._own_lists()[1] = value
+
+    @property
+    def bboxes_list(self):
+        if self._lists is not None:
+            return self._lists[0]
+        return list(torch.split(self._box_block, self._lens, 0))
+
+    @bboxes_list.setter
+    def bboxes_list(self, value):
+        self._own_lists()[0] = value
+
+    def _own_lists(self):
+        """explicit lists (assigned by the caller) replace the blocks as the source of truth"""
+        if getattr(self, "_lists", None) is None:
+            blocks = getattr(self, "_feat_block", None)
+            self._lists = [None, None] if blocks is None else [list(torch.split(self._box_block, self._lens, 0)), list(torch.split(blocks, self._lens, 0))]
+            self._feat_block = self._box_block = None
+            if hasattr(self, "_bigc_pack"):
+                del self._bigc_pack
+        return self._lists
+
     def to(self, device):
+        """As the reference's ``TrajProposal.to`` (dataloaders/dataloader_vidvrd.py:66-77), which copies tensor by tensor; here the
+        boxes and the features of a video travel as ONE block each and the per-tracklet tensors become views of the blocks."""
         if self.num_proposals == 0:
             return self
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         self.cat_ids = self.cat_ids.to(device)
         self.scores = self.scores.to(device)
         self.traj_durations = self.traj_durations.to(device)
-        for i in range(self.num_proposals):
-            self.bboxes_list[i] = self.bboxes_list[i].to(device)
-            self.features_list[i] = self.features_list[i].to(device)
+        if self._lists is None:
+            if self._feat_block.device == device:
+                return self
+            lens = self._lens
+            bb, fb = self._box_block.to(device), self._feat_block.to(device)
+        else:
+            bl, fl = self._lists
+            lens = [int(b.shape[0]) for b in bl]
+            bb = torch.cat([b.to(torch.float32) for b in bl], 0).to(device)
+            fb = torch.cat([f.to(torch.float32) for f in fl], 0).to(device)
+        self._set_blocks(bb.contiguous(), fb.contiguous(), lens)
         return self
 
     def __repr__(self):

@@ -29,7 +29,7 @@ std::vector<hipEvent_t> g_free;
 FamStat g_stat[FAM_COUNT];
 const char* g_names[FAM_COUNT] = {"linear_f32", "mha_core", "role_attention", "role_values", "layernorm", "add_rows",
                                   "frontend", "head_gather", "construct_triplets", "grounding", "linear_dw", "backward_misc",
-                                  "attention_bwd", "loss", "linear_aux"};
+                                  "attention_bwd", "loss", "linear_aux", "pack"};
 
 hipEvent_t take_event() {
     if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }

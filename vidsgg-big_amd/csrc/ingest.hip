@@ -8,6 +8,7 @@
 // The vector is the concatenation [RoI feature | I3D feature] (:654), which matters for the any-step-zero rule.
 // HBM-bound: reads <= 2 source rows, writes 1 row; one 256-thread workgroup per output row.
 #include "common.h"
+#include "linear_internal.h"
 #include "prof.h"
 
 namespace {
@@ -56,5 +57,179 @@ extern "C" int bigc_assemble_rows_f32(void* stream, const float* raw, int ld_raw
     hipLaunchKernelGGL(assemble_rows_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, raw, ld_raw, col0, width, raw2, ld_raw2, col02,
                        width2, src_a, src_b, step_i, step_div, out, ld_out);
     BIGC_LAUNCH_CHECK("assemble_rows");
+    return BIGC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Ragged pack of a batch of videos (reference: the per-tracklet tensors of `TrajProposal`
+// -- dataloaders/dataloader_vidvrd.py:66-77 moves them one by one -- are stacked inside forward, models/model_0v10.py:391-430).
+// ONE launch copies every tracklet's rows from wherever its tensors live into the packed store of `bigc_batch`:
+//   boxes (R, 4) f32;  and the feature row in any of three forms, each optional:
+//     feats (R, width) f32                 -- training, exact mode
+//     hr8   (R, dim_feat) split form       -- the visual (RoI) columns as the f16 head / residual pairs that csrc/gemm_ps.hip reads by
+//                                             DMA (fc_feat2enti.0's operand): written here, there is no separate conversion pass
+//     extra (R, width - dim_feat) f32      -- the remaining columns (I3D / classeme) that the time-mean reads
+// HBM-bound: reads a row once, writes it once (4 bytes in, 4 bytes out per element in the eval form).
+// One 256-thread workgroup per tracklet, wave w takes rows w, w + 4, ...; a row's loads are issued before its stores.
+// VEC: every source pointer and pitch is 16-byte aligned (the normal case: torch allocations, widths that are multiples of 4);
+// otherwise the element-wise variant runs.
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+typedef _Float16 pk_h2 __attribute__((ext_vector_type(2)));
+typedef float pk_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void pk_split2(float x0, float x1, unsigned& h, unsigned& r) {
+    const pk_f2 v = {x0, x1};
+    const pk_h2 hh = __builtin_convertvector(v, pk_h2);
+    const pk_f2 d = v - __builtin_convertvector(hh, pk_f2);
+    const pk_h2 rr = __builtin_convertvector(d, pk_h2);
+    h = *(const unsigned*)&hh;
+    r = *(const unsigned*)&rr;
+}
+
+struct PackArgs {
+    const uint64_t* feat_src; const int32_t* feat_ld; const uint64_t* box_src; const int32_t* trk_row_off;
+    int width, dim_feat;
+    float* feats; long ld_feats; unsigned char* hr8; long ld_hr8; float* extra; long ld_extra; float* boxes; int* flag;
+    float act_scale;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void pack_tracklets_kernel(PackArgs a) {
+    const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = a.trk_row_off[t], n = a.trk_row_off[t + 1] - r0;
+    const float* src = (const float*)a.feat_src[t];
+    const long lds = a.feat_ld ? (long)a.feat_ld[t] : (long)a.width;
+    if (a.boxes && a.box_src) {
+        const float* bs = (const float*)a.box_src[t];
+        for (int i = threadIdx.x; i < 4 * n; i += 256) a.boxes[(size_t)r0 * 4 + i] = bs[i];
+    }
+    if (!src) return;
+    const int K8 = a.hr8 ? a.dim_feat / 8 : 0;
+    const int xw = a.width - a.dim_feat;
+    bool oob = false;
+    for (int i = wave; i < n; i += 4) {
+        const float* s = src + (size_t)i * lds;
+        const size_t r = (size_t)r0 + i;
+        if (VEC) {
+            if (a.hr8) {
+                uint4* yp = (uint4*)(a.hr8 + r * a.ld_hr8);
+                float* fo = a.feats ? a.feats + r * a.ld_feats : nullptr;
+                for (int g0 = 0; g0 < K8; g0 += 256) {                     // four groups of 8 per lane in flight
+                    f32x4 u[4], v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int g = g0 + 64 * q + lane;
+                        if (g < K8) { u[q] = *(const f32x4*)(s + 8 * g); v[q] = *(const f32x4*)(s + 8 * g + 4); }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int g = g0 + 64 * q + lane;
+                        if (g >= K8) continue;
+                        if (fo) { *(f32x4*)(fo + 8 * g) = u[q]; *(f32x4*)(fo + 8 * g + 4) = v[q]; }
+                        const f32x4 x = u[q] * a.act_scale, y = v[q] * a.act_scale;
+                        uint4 h, rr;
+                        pk_split2(x[0], x[1], h.x, rr.x); pk_split2(x[2], x[3], h.y, rr.y); pk_split2(y[0], y[1], h.z, rr.z); pk_split2(y[2], y[3], h.w, rr.w);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) oob = oob || !(fabsf(x[c]) < 32768.0f) || !(fabsf(y[c]) < 32768.0f);
+                        yp[2 * g] = h;
+                        yp[2 * g + 1] = rr;
+                    }
+                }
+            } else if (a.feats) {
+                float* fo = a.feats + r * a.ld_feats;
+                for (int c = 4 * lane; c < a.dim_feat; c += 256) *(f32x4*)(fo + c) = *(const f32x4*)(s + c);
+            }
+            if (xw > 0 && (a.extra || a.feats)) {
+                float* xo = a.extra ? a.extra + r * a.ld_extra : nullptr;
+                float* fo = a.feats ? a.feats + r * a.ld_feats + a.dim_feat : nullptr;
+                for (int c0 = 0; c0 < xw; c0 += 1024) {
+                    f32x4 u[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int c = c0 + 256 * q + 4 * lane; if (c < xw) u[q] = *(const f32x4*)(s + a.dim_feat + c); }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = c0 + 256 * q + 4 * lane;
+                        if (c >= xw) continue;
+                        if (xo) *(f32x4*)(xo + c) = u[q];
+                        if (fo) *(f32x4*)(fo + c) = u[q];
+                    }
+                }
+            }
+        } else {
+            for (int c = lane; c < a.width; c += 64) {
+                const float x = s[c];
+                if (a.feats) a.feats[r * a.ld_feats + c] = x;
+                if (c >= a.dim_feat && a.extra) a.extra[r * a.ld_extra + (c - a.dim_feat)] = x;
+            }
+            if (a.hr8) {
+                for (int g = lane; g < K8; g += 64) {
+                    float x[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { x[c] = s[8 * g + c] * a.act_scale; oob = oob || !(fabsf(x[c]) < 32768.0f); }
+                    uint4 h, rr;
+                    pk_split2(x[0], x[1], h.x, rr.x); pk_split2(x[2], x[3], h.y, rr.y); pk_split2(x[4], x[5], h.z, rr.z); pk_split2(x[6], x[7], h.w, rr.w);
+                    uint4* yp = (uint4*)(a.hr8 + r * a.ld_hr8);
+                    yp[2 * g] = h;
+                    yp[2 * g + 1] = rr;
+                }
+            }
+        }
+    }
+    if (oob && a.flag) atomicOr(a.flag, 1);
+}
+
+// per-video metadata: cat_ids (N) i64, scores (N) f32, traj_durations (N, 2) i64 of every video -> trk_cat i32, trk_score f32, trk_dura i32
+__global__ __launch_bounds__(256) void pack_video_meta_kernel(const uint64_t* __restrict__ cat_src, const uint64_t* __restrict__ score_src,
+                                                              const uint64_t* __restrict__ dura_src, const int32_t* __restrict__ vid_trk_off,
+                                                              int32_t* __restrict__ trk_cat, float* __restrict__ trk_score, int32_t* __restrict__ trk_dura) {
+    const int v = blockIdx.x, e0 = vid_trk_off[v], n = vid_trk_off[v + 1] - e0;
+    const int64_t* cs = (const int64_t*)cat_src[v];
+    const float* ss = (const float*)score_src[v];
+    const int64_t* ds = (const int64_t*)dura_src[v];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        trk_cat[e0 + i] = (int32_t)cs[i];
+        trk_score[e0 + i] = ss[i];
+        trk_dura[2 * (e0 + i)] = (int32_t)ds[2 * i];
+        trk_dura[2 * (e0 + i) + 1] = (int32_t)ds[2 * i + 1];
+    }
+}
+
+}  // namespace
+
+extern "C" int bigc_pack_tracklets(void* stream, const uint64_t* feat_src, const int32_t* feat_ld, const uint64_t* box_src,
+                                   const int32_t* trk_row_off, int n_trk, long n_rows, int width, int dim_feat, int vectorized, float* feats, long ld_feats,
+                                   void* feats_hr8, long ld_hr8_bytes, float* extra, long ld_extra, float* boxes, int32_t* range_flag) {
+    BIGC_CHECK_ARG(trk_row_off && (feat_src || box_src), "pack_tracklets: null pointer");
+    BIGC_CHECK_ARG(width > 0 && dim_feat >= 0 && dim_feat <= width, "pack_tracklets: dim_feat=%d outside [0, width=%d]", dim_feat, width);
+    BIGC_CHECK_ARG(!feats || ld_feats >= width, "pack_tracklets: ld_feats < width");
+    BIGC_CHECK_ARG(!feats_hr8 || (dim_feat % 8 == 0 && ld_hr8_bytes >= 4L * dim_feat && ld_hr8_bytes % 16 == 0 && range_flag),
+                   "pack_tracklets: the split form needs dim_feat %% 8 == 0, a 16-byte pitch and a range flag");
+    BIGC_CHECK_ARG(!extra || ld_extra >= width - dim_feat, "pack_tracklets: ld_extra < width - dim_feat");
+    BIGC_CHECK_ARG(!(boxes && !box_src), "pack_tracklets: boxes without box_src");
+    if (vectorized)
+        BIGC_CHECK_ARG(width % 4 == 0 && dim_feat % 4 == 0 && (!feats || (ld_feats % 4 == 0 && (uintptr_t)feats % 16 == 0)) &&
+                       (!extra || (ld_extra % 4 == 0 && (uintptr_t)extra % 16 == 0)) && (!feats_hr8 || (uintptr_t)feats_hr8 % 16 == 0),
+                       "pack_tracklets: vectorized copy needs widths / pitches that are multiples of 4 floats and 16-byte aligned outputs");
+    if (n_trk <= 0 || n_rows <= 0) return BIGC_OK;
+    PackArgs a{feat_src, feat_ld, box_src, trk_row_off, width, dim_feat, feats, ld_feats, (unsigned char*)feats_hr8, ld_hr8_bytes, extra, ld_extra, boxes,
+               range_flag, (float)(1 << PS_ACT_EXP)};
+    const double per_row = (feat_src ? 4.0 * width * (1 + (feats ? 1 : 0)) + (feats_hr8 ? 4.0 * dim_feat : 0) + (extra ? 4.0 * (width - dim_feat) : 0) : 0) + (boxes ? 32.0 : 0);
+    ProfScope ps(stream, FAM_PACK, 0.0, per_row * (double)n_rows);
+    if (vectorized) hipLaunchKernelGGL(pack_tracklets_kernel<true>, dim3(n_trk), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(pack_tracklets_kernel<false>, dim3(n_trk), dim3(256), 0, (hipStream_t)stream, a);
+    BIGC_LAUNCH_CHECK("pack_tracklets");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_pack_video_meta(void* stream, const uint64_t* cat_src, const uint64_t* score_src, const uint64_t* dura_src,
+                                    const int32_t* vid_trk_off, int n_vid, int32_t* trk_cat, float* trk_score, int32_t* trk_dura) {
+    BIGC_CHECK_ARG(cat_src && score_src && dura_src && vid_trk_off && trk_cat && trk_score && trk_dura, "pack_video_meta: null pointer");
+    if (n_vid <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_PACK, 0.0, 0.0);
+    hipLaunchKernelGGL(pack_video_meta_kernel, dim3(n_vid), dim3(256), 0, (hipStream_t)stream, cat_src, score_src, dura_src, vid_trk_off, trk_cat,
+                       trk_score, trk_dura);
+    BIGC_LAUNCH_CHECK("pack_video_meta");
     return BIGC_OK;
 }

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void linear_k8_kernel(const LinearArgs p) {
     const bool relu = p.act == BIGC_ACT_RELU, sigm = p.act == BIGC_ACT_SIGMOID;
     const int r0 = blockIdx.x * SK_ROWS, r1 = min(r0 + SK_ROWS, p.M);
     bool oob = false;
-#pragma unroll 4
+    // (no unroll request: the hr8 epilogue's lane exchange is a convergent operation, the compiler keeps this loop rolled)
     for (int r = r0 + rl; r < r1; r += nrl) {
         const float* ap = p.A + (size_t)r * p.lda;
         const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4);

@@ -139,6 +139,7 @@ int run_frontend(const bigc_model* m, void* s, const bigc_batch* b, const Work& 
         TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
         TRY(linear(s, w.hb, de, m->bbox2, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
     }
+    BIGC_CHECK_ARG(b->feats, "forward: this path reads the f32 features (bigc_batch.feats), which the batch was packed without");
     TRY(linear(s, b->feats, D, m->feat0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
     TRY(linear(s, w.hv, de, m->feat2, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
     TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
@@ -383,6 +384,7 @@ int run_frontend_chained(const bigc_model* m, void* s, const bigc_batch* b, cons
         TRY(ps(cx, b->feats_hr8, b->ld_feats_hr8 / 4, true, m->feat0, c.dim_feat, nullptr, 0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
         if (b->feats_hr8_flag) TRY(bigc_or_flag((hipStream_t)s, w.flag, b->feats_hr8_flag));
     } else {
+        BIGC_CHECK_ARG(b->feats, "forward: batch without f32 features and without a usable split form of them");
         TRY(bigc_linear_hr8out(s, b->feats, D, m->feat0.w, c.dim_feat, m->feat0.b, nullptr, 0, nullptr, 0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU, w.flag));
     }
     TRY(ps(cx, w.hv, de, true, m->feat2, de, nullptr, 0, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
@@ -415,6 +417,7 @@ int forward_ps(bigc_model* m, void* stream, const bigc_batch* b, const Work& w, 
     TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
     TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));                                         // K = 8: the store-bound FMA kernel, f32
     TRY(ps(cx, w.hb, de, false, m->bbox2, de, nullptr, 0, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
+    BIGC_CHECK_ARG(b->feats, "forward: BIGC_PS=1 reads the f32 features (bigc_batch.feats), which the batch was packed without");
     TRY(ps(cx, b->feats, D, false, m->feat0, c.dim_feat, nullptr, 0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
     TRY(ps(cx, w.hv, de, true, m->feat2, de, nullptr, 0, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
     TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
@@ -515,7 +518,7 @@ int forward_ps(bigc_model* m, void* stream, const bigc_batch* b, const Work& w, 
     int n_seg = 0;
     if (c.variant == 0) {
         if (c.dim_extra > 0) {
-            TRY(bigc_stretched_mean(s, b->feats, D, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, w.xmean, NT));
+            TRY(bigc_extra_mean(s, b, c, w.xmean, NT));
             TRY(linear(s, w.xmean, c.dim_extra, m->i3d, w.i3dfc, de, NT, de, c.dim_extra, BIGC_ACT_RELU));
             seg_src[n_seg] = w.i3dfc; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
             seg_src[n_seg] = e2e; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
@@ -530,7 +533,7 @@ int forward_ps(bigc_model* m, void* stream, const bigc_batch* b, const Work& w, 
                 seg_src[n_seg] = m->emb; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 1;
             } else {
                 BIGC_CHECK_ARG(c.dim_extra == c.dim_clsme, "forward: classeme width %d != dim_clsme %d", c.dim_extra, c.dim_clsme);
-                TRY(bigc_stretched_mean(s, b->feats, D, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, w.xmean, NT));
+                TRY(bigc_extra_mean(s, b, c, w.xmean, NT));
                 seg_src[n_seg] = w.xmean; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 0;
             }
         }
@@ -571,6 +574,17 @@ int forward_ps(bigc_model* m, void* stream, const bigc_batch* b, const Work& w, 
 
 }  // namespace
 
+// mirrors the path choice of bigc_forward below (chained mode) and of run_frontend_chained (the split features are usable)
+extern "C" int bigc_forward_reads_hr8(const bigc_model* m) {
+    if (!m || m->cfg.variant == 2) return 0;
+    ModeScope mode_scope(m->mode_exact, m->mode_fast);
+    static const bool ps_on = getenv("BIGC_PS") && atoi(getenv("BIGC_PS")) != 0;
+    static const bool chained_off = getenv("BIGC_CHAINED") && atoi(getenv("BIGC_CHAINED")) == 0;
+    const bigc_config& c = m->cfg;
+    if (ps_on || chained_off || bigc_linear_get_exact() || bigc_linear_get_fast() == 2 || !ps_config_ok(c)) return 0;
+    return c.dim_feat % 32 == 0 ? 1 : 0;
+}
+
 extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                             int topk, const bigc_outputs* out) {
     StaticWeights static_weights(m ? m->epoch : 0);
@@ -605,7 +619,6 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
     if (chained && hipMemsetAsync(w.flag, 0, sizeof(int32_t), hs) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: memset failed");
     const int NT = b->n_trk, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
     const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn;
-    const int D = c.dim_feat + c.dim_extra;
     const int H = c.n_att_head, hd = de / H;
     const float eps = 1e-5f;
 
@@ -755,7 +768,7 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
     int n_seg = 0;
     if (c.variant == 0) {
         if (c.dim_extra > 0) {
-            TRY(bigc_stretched_mean(s, b->feats, D, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, w.xmean, NT));
+            TRY(bigc_extra_mean(s, b, c, w.xmean, NT));
             TRY(linear(s, w.xmean, c.dim_extra, m->i3d, w.i3dfc, de, NT, de, c.dim_extra, BIGC_ACT_RELU));
             seg_src[n_seg] = w.i3dfc; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
             seg_src[n_seg] = e2e; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
@@ -770,7 +783,7 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
                 seg_src[n_seg] = m->emb; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 1;
             } else {
                 BIGC_CHECK_ARG(c.dim_extra == c.dim_clsme, "forward: classeme width %d != dim_clsme %d", c.dim_extra, c.dim_clsme);
-                TRY(bigc_stretched_mean(s, b->feats, D, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, w.xmean, NT));
+                TRY(bigc_extra_mean(s, b, c, w.xmean, NT));
                 seg_src[n_seg] = w.xmean; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 0;
             }
         }
@@ -866,7 +879,7 @@ extern "C" int bigc_pair_forward(bigc_model* m, void* stream, const bigc_batch* 
         if (c.has_enti_emb) {               // category embedding as classeme (:251-253)
             TRY(bigc_gather_rows(hs, m->emb, b->trk_cat, clsme, NT, dc));
         } else {                            // time-mean of the tracklet's classeme columns over the stretched frames (:191)
-            TRY(bigc_stretched_mean(s, b->feats, c.dim_feat + c.dim_extra, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, clsme, NT));
+            TRY(bigc_extra_mean(s, b, c, clsme, NT));
         }
         clsme_rows = clsme;
     }

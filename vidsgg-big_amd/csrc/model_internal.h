@@ -52,6 +52,14 @@ inline int linear(void* s, const float* A, int lda, const Lin& l, float* C, int 
     return bigc_linear_f32(s, A, lda, nullptr, 1, K, l.w, K, l.b, res, ldr, C, ldc, M, N, K, act);
 }
 
+// time-mean of the dim_extra columns (I3D / classeme; models/model_0v10.py:470): they are a tensor of their own in a batch packed
+// for the eval forward (bigc_batch.extra), else the tail of the f32 feature rows
+inline int bigc_extra_mean(void* s, const bigc_batch* b, const bigc_config& c, float* out, int n_trk) {
+    if (b->extra) return bigc_stretched_mean(s, b->extra, (int)b->ld_extra, 0, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, out, n_trk);
+    BIGC_CHECK_ARG(b->feats, "batch without f32 features (bigc_batch.feats) and without bigc_batch.extra");
+    return bigc_stretched_mean(s, b->feats, c.dim_feat + c.dim_extra, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, out, n_trk);
+}
+
 int bigc_fill_offsets(hipStream_t s, int32_t* p, int n, int step);
 int bigc_copy_cols(hipStream_t s, const float* src, int lds_, float* dst, int ldd, long rows, int cols);
 extern "C" int bigc_axpy_f32(void* stream, float* y, const float* x, long n);

@@ -5,7 +5,7 @@
 
 enum BigcFamily {
     FAM_LINEAR = 0, FAM_MHA, FAM_ROLE_ATT, FAM_ROLE_VAL, FAM_LAYERNORM, FAM_ADD_ROWS, FAM_FRONTEND,
-    FAM_HEAD_GATHER, FAM_TRIPLETS, FAM_GROUNDING, FAM_LINEAR_DW, FAM_BACKWARD, FAM_ATTN_BWD, FAM_LOSS, FAM_LINEAR_AUX, FAM_COUNT
+    FAM_HEAD_GATHER, FAM_TRIPLETS, FAM_GROUNDING, FAM_LINEAR_DW, FAM_BACKWARD, FAM_ATTN_BWD, FAM_LOSS, FAM_LINEAR_AUX, FAM_PACK, FAM_COUNT
 };
 
 struct ProfScope {

@@ -238,6 +238,7 @@ static int frontend_train_forward(bigc_model* m, void* s, const bigc_batch* b, T
     TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
     TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
     TRY(linear(s, w.hb, de, m->bbox2, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
+    BIGC_CHECK_ARG(b->feats, "train: the training step reads the f32 features (bigc_batch.feats), which the batch was packed without");
     TRY(linear(s, b->feats, D, m->feat0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
     TRY(linear(s, w.hv, de, m->feat2, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
     TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
@@ -336,7 +337,7 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
     hipStream_t hs = (hipStream_t)stream;
     TRY(bigc_linear_prepare(hs, m->train_jobs.data(), (int)m->train_jobs.size()));     // every weight changed since the last step: one batched re-split
     const int NT = b->n_trk, B = b->n_vid, Q = c.num_querys, BQ = B * Q;
-    const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn, D = c.dim_feat + c.dim_extra, H = c.n_att_head, hd = de / H;
+    const int de = c.dim_enti, dp = c.dim_pred, da = c.dim_att, df = c.dim_ffn, H = c.n_att_head, hd = de / H;
     const float eps = 1e-5f;
     const float dp_ = m->drop_p; const uint32_t ds_ = m->drop_seed;      // training-mode dropout (0 = off)
 
@@ -416,7 +417,7 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
     int n_seg = 0;
     if (c.variant == 0) {
         if (c.dim_extra > 0) {
-            TRY(bigc_stretched_mean(s, b->feats, D, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, w.xmean, NT));
+            TRY(bigc_extra_mean(s, b, c, w.xmean, NT));
             TRY(linear(s, w.xmean, c.dim_extra, m->i3d, w.i3dfc, de, NT, de, c.dim_extra, BIGC_ACT_RELU));
             seg_src[n_seg] = w.i3dfc; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
             seg_src[n_seg] = w.e2e; seg_w[n_seg] = de; seg_cat[n_seg++] = 0;
@@ -430,7 +431,7 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
             if (c.has_enti_emb) {
                 seg_src[n_seg] = m->emb; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 1;
             } else {
-                TRY(bigc_stretched_mean(s, b->feats, D, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, w.xmean, NT));
+                TRY(bigc_extra_mean(s, b, c, w.xmean, NT));
                 seg_src[n_seg] = w.xmean; seg_w[n_seg] = c.dim_clsme; seg_cat[n_seg++] = 0;
             }
         }
@@ -695,8 +696,7 @@ extern "C" int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_b
     const float* W1 = m->head0.w;
     if (dc > 0) {
         if (c.has_enti_emb) TRY(bigc_gather_rows(hs, m->emb, b->trk_cat, pw.clsme, NT, dc));                      // (:251-253)
-        else TRY(bigc_stretched_mean(s, b->feats, c.dim_feat + c.dim_extra, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax,
-                                     pw.clsme, NT));                                                               // (:201)
+        else TRY(bigc_extra_mean(s, b, c, pw.clsme, NT));                                                               // (:201)
         // column blocks of W1 (df, hk): [s_clsme | o_clsme | s_feat | o_feat] (:257)
         TRY(bigc_linear_f32(s, pw.clsme, dc, nullptr, 1, dc, W1, hk, m->head0.b, nullptr, 0, pw.U, df, NT, df, dc, BIGC_ACT_NONE));
         TRY(bigc_linear_f32(s, w.e2e, de, nullptr, 1, de, W1 + 2 * dc, hk, nullptr, pw.U, df, pw.U, df, NT, df, de, BIGC_ACT_NONE));

@@ -210,3 +210,53 @@ extern "C" int bigc_construct_triplets(void* stream, const float* logits, int n_
     BIGC_LAUNCH_CHECK("construct_triplets");
     return BIGC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Padded per-video outputs of construct_triplets -> the reference's return types, back to back (models/model_0v10.py:776-785 returns
+// int64 quintuples / durations / query ids and f32 scores per video): video v's n_out[v] rows go to rows [off[v], off[v+1]) of the
+// compact arrays, off = exclusive prefix sum of n_out (written to out_off, n_vid + 1 entries).  The host then needs ONE D2H copy
+// (the offsets) and one split per array instead of four slices per video.  One workgroup per video; every workgroup sums the
+// counts before its own (n_vid is a few hundred).
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void compact_triplets_kernel(const int32_t* __restrict__ quint, const float* __restrict__ scores,
+                                                               const int32_t* __restrict__ dura, const int32_t* __restrict__ qid,
+                                                               const int32_t* __restrict__ n_out, int n_vid, int cap, int64_t* __restrict__ o_quint,
+                                                               float* __restrict__ o_scores, int64_t* __restrict__ o_dura, int64_t* __restrict__ o_qid,
+                                                               int32_t* __restrict__ out_off) {
+    __shared__ int red[4];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    int part = 0;
+    for (int i = tid; i < v; i += 256) part += n_out[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const int off = red[0] + red[1] + red[2] + red[3];
+    const int n = n_out[v];
+    if (tid == 0) {
+        out_off[v] = off;
+        if (v == n_vid - 1) out_off[n_vid] = off + n;
+    }
+    const size_t ib = (size_t)v * cap;
+    for (int i = tid; i < 5 * n; i += 256) o_quint[(size_t)off * 5 + i] = (int64_t)quint[ib * 5 + i];
+    for (int i = tid; i < 3 * n; i += 256) o_scores[(size_t)off * 3 + i] = scores[ib * 3 + i];
+    for (int i = tid; i < 2 * n; i += 256) o_dura[(size_t)off * 2 + i] = (int64_t)dura[ib * 2 + i];
+    for (int i = tid; i < n; i += 256) o_qid[off + i] = (int64_t)qid[ib + i];
+}
+
+}  // namespace
+
+extern "C" int bigc_compact_triplets(void* stream, const int32_t* quint, const float* scores, const int32_t* dura, const int32_t* qid,
+                                     const int32_t* n_out, int n_vid, int cap, int64_t* out_quint, float* out_scores, int64_t* out_dura,
+                                     int64_t* out_qid, int32_t* out_off) {
+    BIGC_CHECK_ARG(quint && scores && dura && qid && n_out && out_quint && out_scores && out_dura && out_qid && out_off, "compact_triplets: null pointer");
+    BIGC_CHECK_ARG(cap > 0, "compact_triplets: cap=%d", cap);
+    if (n_vid <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_TRIPLETS, 0.0, 0.0);
+    hipLaunchKernelGGL(compact_triplets_kernel, dim3(n_vid), dim3(256), 0, (hipStream_t)stream, quint, scores, dura, qid, n_out, n_vid, cap, out_quint,
+                       out_scores, out_dura, out_qid, out_off);
+    BIGC_LAUNCH_CHECK("compact_triplets");
+    return BIGC_OK;
+}

@@ -140,7 +140,7 @@ class BigcBase(nn.Module):
             classes.setdefault(0 if n <= 64 else (1 if n <= single_pass else 2), []).append(i)
         res = [None] * len(proposal_list)
         for idx in classes.values():
-            packed = PackedBatch([proposal_list[i] for i in idx], device)
+            packed = PackedBatch([proposal_list[i] for i in idx], device, "lazy")      # the engine gathers the rows in the form its forward reads
             for i, r in zip(idx, self.unpack_results(len(idx), list(range(len(idx))), self.forward_checked(packed, topk))):
                 res[i] = r
         return res
@@ -232,15 +232,17 @@ class BigcBase(nn.Module):
 
     @staticmethod
     def counts(out):
-        """The one D2H copy (and host sync) of an eval step: triplet row counts per video.  The same copy carries the range
-        flag of the split-operand GEMM path (csrc/gemm_ps.hip): an operand that its f16 pair format cannot hold (|x| >= 4096,
-        NaN, Inf) invalidates the step -> ``OverflowError``; ``forward`` then repeats the step on the exact f32 kernels."""
+        """The one D2H copy (and host sync) of an eval step: the row offsets of the compacted results (-> triplet row counts per
+        video).  The same copy carries the range flag of the split-operand GEMM path (csrc/gemm_ps.hip): an operand that its f16
+        pair format cannot hold (|x| >= 4096, NaN, Inf) invalidates the step -> ``OverflowError``; ``forward`` then repeats the
+        step on the exact f32 kernels."""
         if "_host_counts" not in out:
             both = out["_counts"].cpu()
-            out["_host_counts"] = both
+            out["_host_off"] = both[:-1]
+            out["_host_counts"] = both[1:-1] - both[:-2]
             if int(both[-1]) != 0:
                 raise OverflowError("an operand left the range of the split-operand GEMM: repeat the step with bigc_linear_set_exact(1)")
-        return out["_host_counts"][:-1]
+        return out["_host_counts"]
 
     def forward_checked(self, packed, topk):
         """forward_packed + the count copy; a step whose range flag is raised is repeated on the exact f32 GEMM kernels"""
@@ -260,12 +262,13 @@ class BigcBase(nn.Module):
 
     @staticmethod
     def unpack_results(n_total, keep, out):
-        """Padded device outputs -> the reference's per-video list (one D2H copy of the counts)."""
-        n_out = (out["_host_counts"][:-1] if "_host_counts" in out else BigcBase.counts(out)).tolist()
-        quint, dura, qid = out["quint"].long(), out["dura"].long(), out["qid"].long()
+        """Device outputs -> the reference's per-video list: one D2H copy (the row offsets) and one split per array -- the library has
+        already laid the videos' rows out back to back in the reference's dtypes (``bigc_compact_triplets``)."""
+        sizes = BigcBase.counts(out).tolist()
+        total = int(out["_host_off"][-1])
+        parts = [out[k][:total].split(sizes) for k in ("c_quint", "c_scores", "c_dura", "c_qid")]
         res = [None] * n_total
         for j, i in enumerate(keep):
-            n = n_out[j]
-            if n > 0:
-                res[i] = (quint[j, :n], out["scores"][j, :n], dura[j, :n], qid[j, :n])
+            if sizes[j] > 0:
+                res[i] = (parts[0][j], parts[1][j], parts[2][j], parts[3][j])
         return res

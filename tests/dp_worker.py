@@ -1,6 +1,7 @@
 """Child process of tests/test_multi_rank_gpu.py: one RANK of a data-parallel HIP training step (the two ranks of the test share
-the one GPU of the box and exchange gradients through the host with gloo; RCCL cannot put two ranks on one device).
-    RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment; argv: golden case name, output file, batch size"""
+the one GPU of the box and exchange gradients through the host with gloo; RCCL cannot put two ranks on one device -- with
+argv[4] = "nccl" every rank takes its own GPU and the all-reduce runs on RCCL).
+    RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment; argv: golden case name, output file, batch size, [backend]"""
 import os
 import sys
 
@@ -17,11 +18,18 @@ from test_hip_train import build_train_model  # noqa: E402
 
 def main():
     name, out_path, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    backend = sys.argv[4] if len(sys.argv) > 4 else "gloo"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        # RCCL: one rank per device (torch.cuda.device_count() does not initialise the GPU; the group is created first)
+        assert torch.cuda.device_count() >= world, "the nccl variant needs one GPU per rank"
+        torch.cuda.set_device(rank)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     cfg, variant, sd, props, gts = cases.make_train_case(name)
     props, gts = props[:batch], gts[:batch]
     model = build_train_model(cfg, variant, sd)
+    if backend == "nccl":
+        model = model.to("cuda:%d" % rank)
     mine = shard_indices(len(props), rank, world)            # utils/DataParallel.py:80-92
     params = list(model.parameters())
     if mine:

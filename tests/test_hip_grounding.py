@@ -236,3 +236,43 @@ def test_grounding_batch_at_config_g_dims_equals_one_video_calls_and_splits_into
             assert int(a["status"].item()) == int(b["status"].item())
             for key in ("pooled_se", "bins_probs", "bins_mask"):
                 assert torch.equal(a[key], b[key]), (cap, v, key)
+
+
+def test_head_chain_out_of_range_operands_fall_back_to_f32():
+    """the LDS-resident three-head kernel (csrc/grounding_heads.hip) splits activations and weights into f16 pairs; an
+    operand outside that form (|x| >= 32768, NaN, Inf) must not yield silent garbage.  (a) activations made huge by one scaled-up
+    layer, (b) a point-wise weight beyond the range, (c) a NaN weight: the outputs must equal those of the exact-mode forward (the
+    layer-by-layer f32 path, models/grd_model_v5.py:182-193 arithmetic), NaN included."""
+    cfg = dict(cases.GRD_CASES["grd_g_n64"]["cfg"])
+    _, sd0, _ = cases.make_grd_case("grd_g_n64")
+    feat, (quint, dura, vl) = cases.make_grd_inputs(cfg, dict(seed=31, T=70, n=9, video_len=555))
+    for case in ("huge_activation", "huge_weight", "nan_weight", "in_range"):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        if case == "huge_activation":
+            sd["conf_head.0.0.point_wise.weight"] *= 3e5          # layer 0's output ~1e5: the operand of layer 1 leaves the split form
+            sd["conf_head.4.point_wise.weight"] *= 1e-5
+        elif case == "huge_weight":
+            sd["cls_head.2.0.point_wise.weight"][5, 7] = 5e4
+            sd["cls_head.4.point_wise.weight"] *= 1e-4
+        elif case == "nan_weight":
+            sd["conf_head.1.0.point_wise.weight"][3, 3] = float("nan")
+        model = build_model(dict(cfg, loss_factor=dict(classification=1.0, centerness=1.0, regression=1.0)), sd)
+        got = model.forward_raw(feat.to(DEV), quint, dura, vl, keep_intermediates=True, **cases.GRD_TH)
+        eng = model.engine()
+        eng.set_mode(1, -1)
+        try:
+            want = model.forward_raw(feat.to(DEV), quint, dura, vl, keep_intermediates=True, **cases.GRD_TH)
+        finally:
+            eng.set_mode(-1, -1)
+        if case == "nan_weight":
+            # a NaN weight poisons every output of its head, as in torch (relu(NaN) = NaN); the other heads are untouched.  (The layer-by-
+            # layer kernels clamp with max(x, 0), which drops a NaN at the next ReLU: no reference for this case.)
+            assert torch.isnan(got["conf"]).all() and not torch.isnan(got["cls"]).any() and not torch.isnan(got["regrs"]).any()
+            assert float((got["cls"] - want["cls"]).abs().max()) <= 2e-4 * float(want["cls"].abs().max())
+            continue
+        for key in ("regrs", "conf", "cls"):
+            g, w = got[key].cpu(), want[key].cpu()
+            assert torch.equal(torch.isnan(g), torch.isnan(w)), (case, key)
+            ok = ~torch.isnan(w)
+            scale = float(w[ok].abs().max()) if ok.any() else 1.0
+            assert float((g[ok] - w[ok]).abs().max()) <= 2e-4 * max(scale, 1e-6), (case, key, float((g[ok] - w[ok]).abs().max()), scale)

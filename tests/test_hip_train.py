@@ -386,6 +386,33 @@ def test_gradients_of_later_optimizer_steps_follow_the_updated_weights(name, fus
         opt.step()
 
 
+def test_eval_forward_after_a_fused_optimizer_step_uses_the_new_weights():
+    """``Adam(fused=True)`` does not bump the parameters' version counters, and an EVAL forward on the same module
+    (in-process validation: flip ``is_train``) does not pass ``force``.  The training backward now marks the engine's derived weight
+    buffers dirty, so the validation forward after the step must equal the forward of a fresh model built from the new state_dict."""
+    cfg, variant, sd, props, _ = cases.make_train_case("bigc_train_tiny")
+    model = build_train_model(cfg, variant, sd)
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3, fused=True)
+    model.is_train = False
+    before = model(props, topk=3)                       # the engine now holds the split copies of the INITIAL weights
+    model.is_train = True
+    loss, _ = model(props, cases.make_train_case("bigc_train_tiny")[4])
+    loss.backward()
+    opt.step()
+    model.is_train = False
+    after = model(props, topk=3)
+    fresh = build_train_model(cfg, variant, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    fresh.is_train = False
+    want = fresh(props, topk=3)
+    changed = False
+    for a, w, b in zip(after, want, before):
+        assert (a is None) == (w is None)
+        if a is not None:
+            assert all(torch.equal(x, y) for x, y in zip(a, w))
+            changed = changed or b is None or a[1].shape != b[1].shape or not torch.equal(a[1], b[1])
+    assert changed                                       # (the step did move the scores: the check above is not vacuous)
+
+
 @pytest.mark.parametrize("name", ["bigc_train_tiny", "bigc_train_v"])
 def test_train_step_exact_gemm_mode_every_gradient_within_1e_4(name):
     """The same golden with every GEMM on the exact f32 MFMA (bigc_linear_set_exact(1)): no ReLU sits on the other side of zero

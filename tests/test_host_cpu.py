@@ -188,3 +188,29 @@ def test_committed_pmc_traffic_belongs_to_the_current_kernel_sources():
     pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     assert pmc.get("csrc_sha16") == csrc_sha16(), "profiles/pmc_traffic.json is stale: re-run `TAG=r0X bash benchmarks/profile_bench.sh` on the GPU box"
     assert pmc["hbm_bytes_per_launch"] > 0 and pmc["whole_step_fetch_bytes_all_kernels"] > 0
+
+
+def test_video_index_loads_only_the_ranks_share():
+    """tools/_common.VideoIndex: the assignment of videos to ranks is computed from costs known WITHOUT loading (synthetic: the row
+    count replayed from the seed), and a rank loads exactly its share (the reference iterates a DataLoader, tools/eval_vidvrd.py:91-121)"""
+    sys.path.insert(0, os.path.join(ROOT, "vidsgg-big_amd", "tools"))
+    import _common as C
+    cfg = cases.get_cfg("CONFIG_TINY")
+    world, n = 3, 10
+    shares = []
+    for rank in range(world):
+        idx = C.synthetic_index(cfg, n, 6, seed=77)
+        assert len(idx) == n and idx.n_loaded == 0
+        mine, items = C.shard_for_inference(idx, idx.costs, rank, world)
+        assert idx.n_loaded == len(mine) == len(items)
+        for i, (p, g) in zip(mine, items):
+            assert p.video_name == idx.names[i] and sum(int(b.shape[0]) for b in p.bboxes_list) == idx.costs[i]     # the cost IS the row count
+        shares.append(mine)
+    assert sorted(i for s in shares for i in s) == list(range(n))
+    loads = [sum(C.synthetic_index(cfg, n, 6, seed=77).costs[i] for i in s) for s in shares]
+    assert max(loads) - min(loads) <= max(C.synthetic_index(cfg, n, 6, seed=77).costs)          # balanced to within one video
+    # a bounded cache (training): old items are dropped, reloading works
+    idx = C.synthetic_index(cfg, n, 6, seed=77, keep=2)
+    for i in (0, 1, 2, 0):
+        idx[i]
+    assert idx.n_loaded == 4 and len(idx._cache) == 2

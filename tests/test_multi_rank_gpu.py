@@ -91,22 +91,17 @@ def test_eval_vidor_both_stages_two_ranks_equal_one_process():
     assert a.keys() == b.keys() and all(a[k] == b[k] for k in a)
 
 
-@pytest.mark.parametrize("batch", [2, 1])
-def test_data_parallel_hip_training_step_equals_the_reference_semantics(batch):
-    """two ranks (two processes on the one GPU, gloo) x their chunk of the batch + the flat-gradient all-reduce, against ONE process
-    that evaluates the chunks one after the other and averages: per-replica loss means, mean over replicas (tools/train_vidvrd.py:155).
-    batch = 1: the second rank has no chunk, contributes zeros, and the mean is over the one replica that exists."""
+def _dp_step_equals_reference_semantics(name, batch, backend):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
     from bigc_hip.shard import shard_indices
     from test_hip_train import build_train_model
-    name = "bigc_train_v64"              # exp2 dims, two videos of N = 64 / 40
     out = os.path.join(tempfile.mkdtemp(), "dp.pt")
     port = free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), name, out, str(batch)], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), name, out, str(batch), backend], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
@@ -130,3 +125,21 @@ def test_data_parallel_hip_training_step_equals_the_reference_semantics(batch):
     for k in want:
         err = float((got["grads"][k] - want[k]).abs().max())
         assert err <= 1e-5 * max(float(want[k].abs().max()), 1e-4 * gmax), (k, err)
+
+
+@pytest.mark.parametrize("name,batch", [("bigc_train_v64", 2), ("bigc_train_v64", 1), ("bigo_train_o", 2)])
+def test_data_parallel_hip_training_step_equals_the_reference_semantics(name, batch):
+    """two ranks (two processes on the one GPU, gloo) x their chunk of the batch + the flat-gradient all-reduce, against ONE process
+    that evaluates the chunks one after the other and averages: per-replica loss means, mean over replicas (tools/train_vidvrd.py:155).
+    batch = 1: the second rank has no chunk, contributes zeros, and the mean is over the one replica that exists.
+    ``bigc_train_v64``: exp2 dims (VidVRD), two videos of N = 64 / 40; ``bigo_train_o``: exp5 dims (model_0v7, BASELINE configs[4]: VidOR
+    DP training)."""
+    _dp_step_equals_reference_semantics(name, batch, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL with more than one rank needs two GPUs (one per rank); this box shows %d" % torch.cuda.device_count())
+@pytest.mark.parametrize("name", ["bigc_train_v64", "bigo_train_o"])
+def test_data_parallel_hip_training_step_on_two_gpus_over_rccl(name):
+    """the same equivalence with the all-reduce on RCCL (backend "nccl", one rank per device): runs by itself wherever two devices
+    are visible -- fresh child processes, the group created before any GPU call"""
+    _dp_step_equals_reference_semantics(name, 2, "nccl")

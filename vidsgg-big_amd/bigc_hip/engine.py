@@ -37,6 +37,7 @@ class BigcEngine(object):
         self.handle = ctypes.c_void_p()
         _lib.check(self.lib.bigc_create(ctypes.byref(c), ctypes.byref(self.handle)))
         self._sig = None
+        self._dirty = False
         self._keep = None
         self._ws = None
         self._train_ws = None
@@ -59,7 +60,7 @@ class BigcEngine(object):
         items = [(k, t) for k, t in named_tensors]
         ptrs = tuple((k, t.data_ptr()) for k, t in items)
         sig = (ptrs, tuple(t._version for _, t in items))
-        if sig == self._sig and not force:
+        if sig == self._sig and not force and not self._dirty:
             return
         if self._sig is None or self._sig[0] != ptrs:       # a training step changes the versions only: nothing to re-register
             for k, t in items:
@@ -68,6 +69,7 @@ class BigcEngine(object):
                 _lib.check(self.lib.bigc_set_param(self.handle, k.encode(), t.data_ptr(), t.numel()))
         _lib.check(self.lib.bigc_finalize(self.handle, _lib.current_stream()))
         self._sig = sig
+        self._dirty = False
         self._keep = [t for _, t in items]
 
     def invalidate_weights(self):
@@ -78,6 +80,14 @@ class BigcEngine(object):
         without bumping ``_version``), which leave the version counter alone: call this after those.  (The training steps of this
         package refresh the weights on every forward themselves.)"""
         self._sig = None
+
+    def weights_will_change(self):
+        """Called at the end of every training backward of this package: an optimizer step follows, and a FUSED one
+        (``torch.optim.Adam(fused=True)``) updates the parameters without bumping their version counters.  The next ``engine()`` call
+        of ANY kind -- a training forward, but also an in-process validation forward, ``forward_packed``, the pairwise model -- then
+        rebuilds the derived weight buffers (split / transposed copies, ``role_cat``, ``qkpos``) instead of multiplying by the
+        copies of the previous weights.  The parameter pointers stay registered (only ``bigc_finalize`` runs again)."""
+        self._dirty = True
 
     def flat_gradients(self, trainable, device, set_grad="bigc_set_grad", rebase="bigc_rebase_grads"):
         """A fresh zeroed flat fp32 buffer holding one gradient per entry of ``trainable`` [(key, parameter)] back to back, and
@@ -195,7 +205,7 @@ class BigcEngine(object):
     def pair_triplets(self, packed, pair_out, topk, rt_topk):
         """Base_C.construct_triplet for every video of the batch in the HIP library (csrc/pair_triplet.hip).
         -> list (one per video) of None or (quintuples i64 (U,5), scores f32 (U,3), dura_inters i64 (U,2)); ONE D2H copy (the row
-        counts) for the whole batch."""
+        counts) for the whole batch (a second one, the durations, only when some video has no row at all: None vs empty)."""
         import numpy as np
         c = self.c
         dev = packed.device
@@ -231,11 +241,13 @@ class BigcEngine(object):
         cnt = counts.cpu().numpy()
         # The reference returns None only when NO ordered pair of the video overlaps in time (models/model_pairwise_baseline.py:373-377);
         # a video whose every surviving row is the background predicate gets a tuple of EMPTY tensors (:379-395).
-        dura_h = packed.trk_dura.cpu().numpy()
+        dura_h = None                                     # (downloaded only when some video produced no row: a second D2H copy otherwise saved)
         voff = packed.vid_trk_off_host
         res = []
         for v in range(B):
             if cnt[0, v] == 0:
+                if dura_h is None:
+                    dura_h = packed.trk_dura.cpu().numpy()
                 d = dura_h[voff[v]:voff[v + 1]]
                 ov = (np.maximum(d[:, None, 0], d[None, :, 0]) <= np.minimum(d[:, None, 1], d[None, :, 1]))
                 np.fill_diagonal(ov, False)

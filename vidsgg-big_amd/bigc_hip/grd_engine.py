@@ -45,7 +45,7 @@ class GrdEngine(object):
         """``force``: see BigcEngine.sync_params (a fused optimizer's update does not bump the version counters)"""
         items = [(k, t) for k, t in named_tensors]
         sig = tuple((k, t.data_ptr(), t._version) for k, t in items)
-        if sig == self._sig and not force:
+        if sig == self._sig and not force and not getattr(self, "_dirty", False):
             return
         for k, t in items:
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \
@@ -53,7 +53,13 @@ class GrdEngine(object):
             _lib.check(self.lib.grd_set_param(self.handle, k.encode(), t.data_ptr(), t.numel()))
         _lib.check(self.lib.grd_finalize(self.handle, _lib.current_stream()))
         self._sig = sig
+        self._dirty = False
         self._keep = [t for _, t in items]
+
+    def weights_will_change(self):
+        """see BigcEngine.weights_will_change: called at the end of the training backward, so that the next forward of any kind
+        re-finalizes even when a fused optimizer left the version counters alone"""
+        self._dirty = True
 
     def set_mode(self, exact=-1, fast=-1):
         """this handle's arithmetic mode (``grd_set_mode``), see BigcEngine.set_mode"""

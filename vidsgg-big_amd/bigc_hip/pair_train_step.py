@@ -125,4 +125,5 @@ class HipPairTrainStep(torch.autograd.Function):
         named = list(model.named_parameters())
         with torch.no_grad():
             grads = backward(model, ctx.engine, ctx.tctx, grad_terms, named)
+        ctx.engine.weights_will_change()           # an optimizer step follows (a fused one does not bump the parameters' versions)
         return (None, None, None, None) + tuple(grads)

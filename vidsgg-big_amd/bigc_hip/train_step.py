@@ -264,4 +264,5 @@ class HipTrainStep(torch.autograd.Function):
         ctx.engine.set_dropout(*ctx.tctx.dropout)          # the masks of THIS step's forward
         with torch.no_grad():
             grads = backward(model, ctx.engine, ctx.tctx, grad_terms, named)
+        ctx.engine.weights_will_change()           # an optimizer step follows (a fused one does not bump the parameters' versions)
         return (None, None, None) + tuple(grads)

@@ -151,7 +151,8 @@ struct PsArgs {
 // XCD-aware order and treats their K slabs as ONE stream: the DMA engine runs ahead of the MFMAs across tile boundaries, so a
 // tile's first slabs arrive while the previous tile's last MFMAs and its epilogue run (with 128 - 144 KB of LDS there is one
 // workgroup per CU: nothing else would hide a tile's pipeline fill).
-//   RB = 32-row blocks per wave: 2 -> TM = 128 rows, 3 LDS stages;  4 -> TM = 256 rows, 2 LDS stages.
+//   RB = 32-row blocks per wave: 2 -> TM = 128 rows, 3 LDS stages;  3 -> TM = 192 rows, 2 stages (M = 49 152, the decoder of a 256-video
+//   step: 256 x 2 tiles = two exact rounds of the 256 persistent workgroups);  4 -> TM = 256 rows, 2 LDS stages.
 //   FAST: reduced-precision mode (bigc_linear_set_fast): heads only, one MFMA per product; the residual chunks still travel
 //   with their rows (the format is the producers') but are not read from LDS.
 template <int AMODE, int RB, bool TRACE = false, bool FAST = false, bool BLOCKED = false>
@@ -341,9 +342,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     // Fragments are read and consumed in UNITS of 12 MFMAs: (k16 step s, row-block pair u) = the wave's 2 feature blocks x 2 of
     // its RB row blocks.  W fragments (2 blocks x head / residual) live per step, A fragments (2 blocks x head / residual) per
     // unit, each double-buffered: 64 registers whatever RB is.
-    constexpr int U = RB / 2, NU = 2 * U;                      // units per k16 step / per slab
+    // RB = 3: one unit per step of 2 x 3 blocks (18 MFMAs).
+    constexpr int UR = RB == 3 ? 3 : 2;                        // row blocks per unit
+    constexpr int U = RB / UR, NU = 2 * U;                     // units per k16 step / per slab
+    constexpr int MM = 6 * UR;                                 // MFMAs per unit
     struct WFrag { f16x8 h[2], l[2]; };
-    struct AFrag { f16x8 h[2], l[2]; };
+    struct AFrag { f16x8 h[UR], l[UR]; };
     WFrag WF[2];
     AFrag AF[2];
     auto rd_w = [&](int so, int s, WFrag& f) {
@@ -355,20 +359,20 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     };
     auto rd_a = [&](int so, int s, int u, AFrag& f) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f.h[i] = *(const AS3 f16x8*)(lds + so + rba + (2 * u + i) * 32 * ROWB + cs[s][0]);
-            if (!FAST) f.l[i] = *(const AS3 f16x8*)(lds + so + rba + (2 * u + i) * 32 * ROWB + cs[s][1]);
+        for (int i = 0; i < UR; ++i) {
+            f.h[i] = *(const AS3 f16x8*)(lds + so + rba + (UR * u + i) * 32 * ROWB + cs[s][0]);
+            if (!FAST) f.l[i] = *(const AS3 f16x8*)(lds + so + rba + (UR * u + i) * 32 * ROWB + cs[s][1]);
         }
     };
-    // MFMAs [m0, m1) of the 12 of unit u: term-major (head x head over the 4 blocks, then head x residual, residual x head), so
+    // MFMAs [m0, m1) of the MM of unit u: term-major (head x head over the 2 x UR blocks, then head x residual, residual x head), so
     // that consecutive MFMAs never accumulate into the same block
     auto mm = [&](const WFrag& w, const AFrag& a, int u, int m0, int m1) {
 #pragma unroll
-        for (int m = 0; m < 12; ++m) {
+        for (int m = 0; m < MM; ++m) {
             if (m < m0 || m >= m1) continue;
-            const int t = m >> 2, fi = (m >> 1) & 1, ri = m & 1;
+            const int t = m / (2 * UR), fi = (m % (2 * UR)) / UR, ri = m % UR;
             if (FAST && t > 0) continue;
-            acc[fi][2 * u + ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t == 2 ? w.l[fi] : w.h[fi], t == 1 ? a.l[ri] : a.h[ri], acc[fi][2 * u + ri], 0, 0, 0);
+            acc[fi][UR * u + ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t == 2 ? w.l[fi] : w.h[fi], t == 1 ? a.l[ri] : a.h[ri], acc[fi][UR * u + ri], 0, 0, 0);
         }
     };
 
@@ -526,18 +530,19 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            // the unit's other ten MFMAs, with up to six DMA pieces between them
-            const int pb = last ? 0 : FIRST + 6 * n, pe = last ? min(FIRST, NPCL) : min(NPCL, FIRST + 6 * (n + 1));
+            // the unit's other MM - 2 MFMAs, with up to NS DMA pieces between them (one after every second MFMA)
+            constexpr int NS = MM / 2;
+            const int pb = last ? 0 : FIRST + NS * n, pe = last ? min(FIRST, NPCL) : min(NPCL, FIRST + NS * (n + 1));
             const bool issuing = loader && (last ? open_now : opened);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
+            for (int k = 0; k < NS - 1; ++k) {
                 mm(WF[s & 1], AF[n & 1], u, 2 + 2 * k, 4 + 2 * k);
                 __builtin_amdgcn_sched_barrier(0);
                 if (pb + k < pe && issuing) issue_piece(pb + k, last ? so[0] : so[NST - 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (pb + 5 < pe && issuing) issue_piece(pb + 5, last ? so[0] : so[NST - 1]);
-            if (!last && opened && FIRST + 6 * (n + 1) >= NPCL) { issue_advance(); opened = false; }
+            if (pb + NS - 1 < pe && issuing) issue_piece(pb + NS - 1, last ? so[0] : so[NST - 1]);
+            if (!last && opened && FIRST + NS * (n + 1) >= NPCL) { issue_advance(); opened = false; }
             if (last) opened = open_now;
         }
         stamp(3);
@@ -646,7 +651,25 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     // 256-row tiles when they still give every CU at least three tiles (else the 128-row tiles fill the chip better)
     static const int force_rb = getenv("BIGC_PS_RB") ? atoi(getenv("BIGC_PS_RB")) : 0;
     static const bool want_blk = getenv("BIGC_PS_BLK") && atoi(getenv("BIGC_PS_BLK")) > 0;
-    const int rb = (want_blk && g.a_fmt == PS_HR8) ? 2 : (force_rb ? force_rb : (cdiv(g.M, 256) * p.tiles_n >= 3 * n_cu ? 4 : 2));
+    // Rows per tile: the persistent workgroups take ceil(tiles / CUs) rounds, a round costs one tile's time (~ its rows, over an efficiency
+    // that falls with the tile: a 128-row tile reads 1.33 x the LDS bytes per MFMA of a 256-row one) -> the cheapest of 256 / 192 / 128 rows.
+    // M = 49 152 (decoder, 256 videos) x N = 512: 384 tiles of 256 rows = 2 rounds x 4, 512 of 192 = 2 x 3 (exact), 768 of 128 = 3 x 2.
+    // The result does not depend on the choice (one accumulator per element, the same K order in every tiling).
+    int rb = 2;
+    if (want_blk && g.a_fmt == PS_HR8) rb = 2;
+    else if (force_rb) rb = force_rb;
+    else {
+        static const bool rb3_off = getenv("BIGC_PS_RB3") && atoi(getenv("BIGC_PS_RB3")) == 0;
+        double best = 0.0;
+        const int cand[3] = {4, 3, 2};
+        const double eff[3] = {1.0, 0.94, 0.82};
+        for (int i = 0; i < 3; ++i) {
+            if (cand[i] == 3 && (rb3_off || g.a_fmt == PS_F32)) continue;
+            const long tiles = (long)cdiv(g.M, 64 * cand[i]) * p.tiles_n;
+            const double cost = (double)((tiles + n_cu - 1) / n_cu) * cand[i] / eff[i];
+            if (best == 0.0 || cost < best * 0.999) { best = cost; rb = cand[i]; }
+        }
+    }
     p.tiles_m = cdiv(g.M, 64 * rb);
     p.range_flag = g.range_flag;
     // opt-in blocked accumulation (BIGC_PS_BLK = K slabs per block, a power of two): 128-row tiles, plain / gathered hr8 operand
@@ -698,6 +721,7 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
         if (!buf && hipMalloc((void**)&buf, 8 * 5 * 8 * 4096) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "gemm_ps: trace buffer");
         p.trace = buf;
         if (rb == 4) hipLaunchKernelGGL((gemm_ps_kernel<0, 4, true>), dim3(grid), dim3(512), 0, s, p);
+        else if (rb == 3) hipLaunchKernelGGL((gemm_ps_kernel<0, 3, true>), dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, true>), dim3(grid), dim3(512), 0, s, p);
         std::vector<unsigned long long> h((size_t)grid * 40);
         (void)hipStreamSynchronize(s);
@@ -711,18 +735,18 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     } else if (bigc_linear_get_fast()) {
 #define PS_LAUNCH_FAST(MODE, RBV) hipLaunchKernelGGL((gemm_ps_kernel<MODE, RBV, false, true>), dim3(grid), dim3(512), 0, s, p)
         if (g.a_fmt == PS_F32) { if (rb == 4) PS_LAUNCH_FAST(2, 4); else PS_LAUNCH_FAST(2, 2); }
-        else if (g.a_idx) { if (rb == 4) PS_LAUNCH_FAST(1, 4); else PS_LAUNCH_FAST(1, 2); }
-        else { if (rb == 4) PS_LAUNCH_FAST(0, 4); else PS_LAUNCH_FAST(0, 2); }
+        else if (g.a_idx) { if (rb == 4) PS_LAUNCH_FAST(1, 4); else if (rb == 3) PS_LAUNCH_FAST(1, 3); else PS_LAUNCH_FAST(1, 2); }
+        else { if (rb == 4) PS_LAUNCH_FAST(0, 4); else if (rb == 3) PS_LAUNCH_FAST(0, 3); else PS_LAUNCH_FAST(0, 2); }
 #undef PS_LAUNCH_FAST
     } else if (g.a_fmt == PS_F32) {
-        if (rb == 4) PS_LAUNCH(2, 4); else PS_LAUNCH(2, 2);
+        if (rb == 4) PS_LAUNCH(2, 4); else PS_LAUNCH(2, 2);        // (f32 operand: force_rb 3 falls to 128 rows)
     } else if (p.blk > 0) {
         if (g.a_idx) hipLaunchKernelGGL((gemm_ps_kernel<1, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
     } else if (g.a_idx) {
-        if (rb == 4) PS_LAUNCH(1, 4); else PS_LAUNCH(1, 2);
+        if (rb == 4) PS_LAUNCH(1, 4); else if (rb == 3) PS_LAUNCH(1, 3); else PS_LAUNCH(1, 2);
     } else {
-        if (rb == 4) PS_LAUNCH(0, 4); else PS_LAUNCH(0, 2);
+        if (rb == 4) PS_LAUNCH(0, 4); else if (rb == 3) PS_LAUNCH(0, 3); else PS_LAUNCH(0, 2);
     }
 #undef PS_LAUNCH
     BIGC_LAUNCH_CHECK("gemm_ps");

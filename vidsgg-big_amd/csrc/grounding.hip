@@ -312,6 +312,10 @@ __global__ __launch_bounds__(256) void coattention_kernel(const float* __restric
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// order of torch.max / argmax: a NaN is the maximum (the first one wins) -- with plain comparisons a sequence of NaN scores left the arg-max
+// at its initial value and the kernel read clip[0x7fffffff] (found by tests/test_hip_grounding.py: a NaN weight in a head)
+__device__ __forceinline__ bool score_gt(float a, float b) { return a > b || (a != a && b == b); }
+__device__ __forceinline__ bool score_eq(float a, float b) { return a == b || (a != a && b != b); }
 
 // reference: models/grd_model_v5.py:533-572, 697-737, 667-695; tIoU utils/utils_func.py:375-390
 __global__ __launch_bounds__(64) void postprocess_kernel(const float* __restrict__ regrs, const float* __restrict__ conf,
@@ -340,14 +344,15 @@ __global__ __launch_bounds__(64) void postprocess_kernel(const float* __restrict
         int bt = 0x7fffffff;
         for (int t = lane; t < T; t += 64) {
             const float sc = sigmoidf_(cf[t * k + b]) * sigmoidf_(cl[t * k + b]);
-            if (sc > bv || (sc == bv && t < bt)) { bv = sc; bt = t; }
+            if (score_gt(sc, bv) || (score_eq(sc, bv) && t < bt)) { bv = sc; bt = t; }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             const float ov = __shfl_xor(bv, o);
             const int ot = __shfl_xor(bt, o);
-            if (ov > bv || (ov == bv && ot < bt)) { bv = ov; bt = ot; }
+            if (score_gt(ov, bv) || (score_eq(ov, bv) && ot < bt)) { bv = ov; bt = ot; }
         }
+        if (bt >= T) bt = 0;                               // (T >= 1: cannot happen; keeps the reads below inside the sequence whatever the scores are)
         const float ts = clip[bt] - rg[bt * 2 * k + b], te = clip[bt] + rg[bt * 2 * k + k + b];
         const float thr = score_th * bv;
         float ps = INFINITY, pe = -INFINITY;

@@ -32,18 +32,65 @@ def load_checkpoint_into(model, ckpt_path, device):
     return ckpt
 
 
-def synthetic_source(model_config, n_videos, n_trajs, seed, with_gt=True, n_gt_trajs=8, n_preds=10):
-    """Synthetic proposals (+ GT graphs) shaped by ``model_config`` (SURVEY.md section 8d recipe)."""
+class VideoIndex(object):
+    """What a rank needs to take its share of a data set WITHOUT loading it: a cost and (where cheaply known) a name per video, and a
+    loader.  The reference iterates a DataLoader (tools/eval_vidvrd.py:91-121, tools/train_vidvrd.py:96-110), so a process only ever
+    holds the videos it works on; here the assignment of videos to ranks is computed from this index and ``index[i]`` loads video i on
+    first use -- an 8-GPU node reads and holds the data set once, not eight times.  ``keep``: how many loaded videos to hold on to
+    (None = all: evaluation touches each of its videos once; training passes a bound)."""
+
+    def __init__(self, costs, load, names=None, keep=None):
+        self.costs, self.names, self._load, self._keep = list(costs), names, load, keep
+        self._cache = {}
+        self.n_loaded = 0                                      # videos this process actually loaded (tests assert the share)
+
+    def __len__(self):
+        return len(self.costs)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __getitem__(self, i):
+        if not 0 <= i < len(self.costs):
+            raise IndexError(i)
+        if i not in self._cache:
+            if self._keep is not None and len(self._cache) >= self._keep:
+                self._cache.pop(next(iter(self._cache)))       # oldest first
+            self._cache[i] = self._load(i)
+            self.n_loaded += 1
+        return self._cache[i]
+
+
+def _synthetic_lens_cost(seed, n_trajs, len_range=(8, 64)):
+    """rows of ``synthetic_proposal(seed, ...)`` without generating it: its first draw is the tracklet lengths"""
+    return int(np.random.RandomState(seed).randint(len_range[0], len_range[1], size=n_trajs).sum()) if n_trajs else 1
+
+
+def synthetic_index(model_config, n_videos, n_trajs, seed, with_gt=True, n_gt_trajs=8, n_preds=10, keep=None):
+    """Synthetic proposals (+ GT graphs) shaped by ``model_config`` (SURVEY.md section 8d recipe), generated on demand."""
     from bigc_hip.synthetic import synthetic_gt_graph, synthetic_proposal
     width = model_config["dim_feat"] + (model_config.get("dim_i3d", None) or 0)
-    out = []
-    for v in range(n_videos):
+
+    def load(v):
         p = synthetic_proposal(seed + v, n_trajs=n_trajs, feat_width=width, num_enti_cats=model_config["num_enti_cats"],
                                name="synthetic_%05d" % v)
         g = synthetic_gt_graph(p, seed + 100000 + v, n_gt_trajs=n_gt_trajs, n_preds=n_preds,
                                num_pred_cats=model_config["num_pred_cats"]) if with_gt else None
-        out.append((p, g))
-    return out
+        return (p, g)
+
+    return VideoIndex([_synthetic_lens_cost(seed + v, n_trajs) for v in range(n_videos)], load, ["synthetic_%05d" % v for v in range(n_videos)], keep)
+
+
+def synthetic_source(model_config, n_videos, n_trajs, seed, with_gt=True, n_gt_trajs=8, n_preds=10):
+    """the same videos, all of them, as a list"""
+    idx = synthetic_index(model_config, n_videos, n_trajs, seed, with_gt, n_gt_trajs, n_preds)
+    return [idx[v] for v in range(n_videos)]
+
+
+def dataset_index(ds, convert=None, keep=None):
+    """One of the reference's ``torch.utils.data.Dataset`` classes (dataloaders/dataloader_vidvrd.py, dataloader_vidor_v3.py): ``ds[i]`` is
+    the loader; costs are unknown before loading (1 each: the assignment is then an even split by count)."""
+    return VideoIndex([1] * len(ds), (lambda i: convert(ds[i])) if convert else (lambda i: ds[i]), None, keep)
 
 
 def ensure_table_files(model_config, out_dir, seed=0):
@@ -63,14 +110,14 @@ def ensure_table_files(model_config, out_dir, seed=0):
     return cfg
 
 
-def synthetic_vidor_source(model_config, n_videos, n_trajs, seed, clip_dim=None, len_range=(15, 120), n_gt_trajs=8, n_preds=10):
+def synthetic_vidor_index(model_config, n_videos, n_trajs, seed, clip_dim=None, len_range=(15, 120), n_gt_trajs=8, n_preds=10, keep=None):
     """VidOR-shaped synthetic videos: RoI feature + 300-d classeme columns when ``use_clsme`` (models/model_0v7.py:331-340),
     and -- with ``clip_dim`` -- the clip features the grounding stage reads, ``T = ceil(video_len / 8)`` rows
-    (16-frame clips with overlap 0.5, experiments/grounding_weights/config_.py:22)."""
+    (16-frame clips with overlap 0.5, experiments/grounding_weights/config_.py:22).  Items (proposal, gt_graph, clip), on demand."""
     from bigc_hip.synthetic import synthetic_gt_graph, synthetic_proposal
     width = model_config.get("dim_feat", 1024) + (model_config.get("dim_clsme", 300) if model_config.get("use_clsme", True) else 0)
-    out = []
-    for v in range(n_videos):
+
+    def load(v):
         p = synthetic_proposal(seed + v, n_trajs=n_trajs, feat_width=width, num_enti_cats=model_config.get("num_enti_cats", 81),
                                len_range=len_range, start_range=(0, len_range[1]), name="synthetic_%05d" % v)
         g = synthetic_gt_graph(p, seed + 100000 + v, n_gt_trajs=n_gt_trajs, n_preds=n_preds, num_pred_cats=model_config.get("num_pred_cats", 51))
@@ -78,8 +125,14 @@ def synthetic_vidor_source(model_config, n_videos, n_trajs, seed, clip_dim=None,
         if clip_dim:
             rs = np.random.RandomState(seed + 200000 + v)
             clip = torch.from_numpy((0.1 * rs.standard_normal((-(-p.video_len // 8), clip_dim))).astype(np.float32))
-        out.append((p, g, clip))
-    return out
+        return (p, g, clip)
+
+    return VideoIndex([_synthetic_lens_cost(seed + v, n_trajs, len_range) for v in range(n_videos)], load, ["synthetic_%05d" % v for v in range(n_videos)], keep)
+
+
+def synthetic_vidor_source(model_config, n_videos, n_trajs, seed, clip_dim=None, len_range=(15, 120), n_gt_trajs=8, n_preds=10):
+    idx = synthetic_vidor_index(model_config, n_videos, n_trajs, seed, clip_dim, len_range, n_gt_trajs, n_preds)
+    return [idx[v] for v in range(n_videos)]
 
 
 def ensure_grounding_files(model_config, out_dir, seed=0):
@@ -119,7 +172,7 @@ def init_process(cuda=None):
 
 def shard_for_inference(data, costs, rank, world):
     """This rank's videos of an inference run: size-balanced over the ranks (bigc_hip.shard.balanced_assignment).
-    -> (indices into ``data``, the items)"""
+    -> (indices into ``data``, the items).  ``data`` may be a ``VideoIndex``: only this rank's videos are then loaded."""
     from bigc_hip.shard import balanced_assignment
     mine = balanced_assignment(costs, world)[rank]
     return mine, [data[i] for i in mine]
@@ -152,10 +205,18 @@ def training_loop(model, data, train_config, output_dir, save_tag, step, rank, w
         order = list(range(len(data)))
         random.Random(epoch).shuffle(order)                 # same permutation on every rank
         for b in range(n_iter):
-            batch = [data[i] for i in order[b * batch_size:(b + 1) * batch_size]]
-            if sort_key is not None:
-                batch = sorted(batch, key=sort_key)
-            mine = [batch[i] for i in shard_indices(len(batch), rank, world)]
+            ids = order[b * batch_size:(b + 1) * batch_size]
+            if isinstance(data, VideoIndex) and world > 1:
+                # each rank loads ITS chunk of the batch only.  (The collator's order inside a batch -- sort_key, dataloaders/
+                # dataloader_vidvrd.py:469 -- would need every video of the batch loaded on every rank; it only decides which videos
+                # share a replica, and the mean over equally sized replicas of per-replica means does not depend on that.)
+                batch = ids
+                mine = [data[ids[i]] for i in shard_indices(len(ids), rank, world)]
+            else:
+                batch = [data[i] for i in ids]
+                if sort_key is not None:
+                    batch = sorted(batch, key=sort_key)
+                mine = [batch[i] for i in shard_indices(len(batch), rank, world)]
             optimizer.zero_grad()
             if mine:
                 loss, terms = step(model, mine)

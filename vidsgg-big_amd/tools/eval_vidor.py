@@ -17,7 +17,7 @@ import time
 import torch
 
 from _common import (ensure_grounding_files, ensure_table_files, init_process, load_checkpoint_into, parse_config_py, shard_for_inference,
-                     synthetic_vidor_source)
+                     synthetic_vidor_index, dataset_index)
 
 from bigc_hip import evaluate as E
 from bigc_hip.pipeline import combine_with_grounding
@@ -26,12 +26,12 @@ from models import BIG_C_vidor, Base_C, DEBUG
 
 
 def _load_data(cfg, synthetic, n_trajs, clip_dim):
+    """the data set as an index of (proposal, gt_graph, clip features) items, loaded per rank on demand (_common.VideoIndex)"""
     if synthetic:
-        return synthetic_vidor_source(cfg["model_config"] if not clip_dim else {}, synthetic, n_trajs, seed=2468, clip_dim=clip_dim)
+        return synthetic_vidor_index(cfg["model_config"] if not clip_dim else {}, synthetic, n_trajs, seed=2468, clip_dim=clip_dim)
     from dataloaders.dataloader_vidor_v3 import Dataset                 # the reference's loader (tools/eval_vidor.py:11)
     ds = Dataset(**cfg["test_dataset_config"])
-    items = [ds[i] for i in range(len(ds))]
-    return [(it[1], it[2], it[0]) if len(it) == 3 else (it[0], it[1], None) for it in items]
+    return dataset_index(ds, lambda it: (it[1], it[2], it[0]) if len(it) == 3 else (it[0], it[1], None))
 
 
 def _report(groundtruth, predictions, output_dir, name, save_json, device=None):
@@ -63,26 +63,29 @@ def evaluate_cls_stage(cfg_path, ckpt_path=None, save_tag="", output_dir=None, c
     model.eval()
     data = _load_data(cfg, synthetic, n_trajs, None)
     predictions, groundtruth, raw = {}, {}, {}
-    costs = [sum(int(b.shape[0]) for b in p.bboxes_list) if p.num_proposals > 0 else 1 for p, _, _ in data]
-    mine, my_data = shard_for_inference(data, costs, rank, world)
+    mine, my_data = shard_for_inference(data, data.costs, rank, world)          # only this rank's videos are loaded
     t0 = time.time()
     my_results = []
     for p, g, _ in my_data:
         with torch.no_grad():
             r = model([p.to(device)], topk=topk)[0]
-        my_results.append(None if r is None else tuple(t.cpu() for t in r))
+        r = None if r is None else tuple(t.cpu() for t in r)
+        # VidOR vocabulary, video name reset to the id the ground-truth JSON is keyed by (utils/evaluate.py:26-38); converted by the
+        # rank that holds the video's tracklets
+        pred = E.to_eval_format(p.to(torch.device("cpu")), r, dataset_type="vidor")
+        # (real data is evaluated against datasets/GT_json_for_eval/VidORval_gts.json, _report)
+        gt = (E.reset_video_name(p.video_name, "vidor"), E.gt_to_eval_format(g, dataset_type="vidor")) if (g is not None and synthetic) else None
+        my_results.append((p.video_name, r, pred, gt))
     torch.cuda.synchronize()
     all_results = gather_results(my_results, mine, len(data), dist)
     if all_results is None:                                 # ranks other than 0 are done
         dist.destroy_process_group()
         return None
-    for (p, g, _), r in zip(data, all_results):
-        cpu = p.to(torch.device("cpu"))
-        raw[p.video_name] = None if r is None else list(r)
-        # VidOR vocabulary, video name reset to the id the ground-truth JSON is keyed by (utils/evaluate.py:26-38)
-        predictions.update(E.to_eval_format(cpu, r, dataset_type="vidor"))
-        if g is not None and synthetic:          # real data is evaluated against datasets/GT_json_for_eval/VidORval_gts.json (_report)
-            groundtruth[E.reset_video_name(p.video_name, "vidor")] = E.gt_to_eval_format(g, dataset_type="vidor")
+    for name, r, pred, gt in all_results:
+        raw[name] = None if r is None else list(r)
+        predictions.update(pred)
+        if gt is not None:
+            groundtruth[gt[0]] = gt[1]
     if dist is not None:
         dist.destroy_process_group()
     print("inference: %d videos in %.2f s on %d GPU(s)" % (len(data), time.time() - t0, world))
@@ -130,28 +133,36 @@ def evaluate_combined(cfg_path, ckpt_path, cls_stage_result_path, save_tag="", o
             my_relations.update(E.to_eval_format(p.to(torch.device("cpu")), combine_with_grounding(tuple(t.cpu() for t in res), out, p.video_len),
                                                  dataset_type="vidor"))
 
-    # the videos that have classification results, shared out by the work of the grounding stage: queries x clips
-    todo = []
-    for p, g, clip in data:
-        if g is not None and synthetic:
-            groundtruth[E.reset_video_name(p.video_name, "vidor")] = E.gt_to_eval_format(g, dataset_type="vidor")
-        res = cls_results.get(p.video_name)
-        if res is None or res[0] is None or res[0].shape[0] == 0:
-            continue
-        todo.append((p, res, clip))
-    costs = [int(res[0].shape[0]) * int(clip.shape[0]) for p, res, clip in todo]
-    mine, my_todo = shard_for_inference(todo, costs, rank, world)
+    # the videos that have classification results, shared out by the work of the grounding stage (queries x clips); the share is
+    # computed from the index (names + costs) and the classification results, and only this rank's videos are loaded
+    names = data.names if data.names is not None else [data[i][0].video_name for i in range(len(data))]
+    have = [i for i, nm in enumerate(names) if cls_results.get(nm) is not None and cls_results[nm][0] is not None and cls_results[nm][0].shape[0] > 0]
+    costs = [int(cls_results[names[i]][0].shape[0]) * int(data.costs[i]) for i in have]
+    from bigc_hip.shard import balanced_assignment
+    mine = balanced_assignment(costs, world)[rank] if have else []
+    rest = balanced_assignment([1] * len(names), world)[rank]          # ground truth of the synthetic videos: converted by an even split of ALL videos
+    my_gt = {}
+    if synthetic:
+        for i in rest:
+            p, g, _ = data[i]
+            if g is not None:
+                my_gt[E.reset_video_name(p.video_name, "vidor")] = E.gt_to_eval_format(g, dataset_type="vidor")
+    my_todo = []
+    for j in mine:
+        p, g, clip = data[have[j]]
+        my_todo.append((p, cls_results[p.video_name], clip))
     my_relations = {}
     for s0 in range(0, len(my_todo), grd_batch):
         flush(my_todo[s0:s0 + grd_batch])
     torch.cuda.synchronize()
-    parts = gather_results([(my_relations, n_skipped)], [rank], world, dist)       # one (relations, skipped) pair per rank
+    parts = gather_results([(my_relations, n_skipped, my_gt)], [rank], world, dist)       # one (relations, skipped, ground truth) triple per rank
     if parts is None:
         dist.destroy_process_group()
         return None
     n_skipped = 0
-    for rel, sk in parts:
+    for rel, sk, gt in parts:
         predictions.update(rel)
+        groundtruth.update(gt)
         n_skipped += sk
     if dist is not None:
         dist.destroy_process_group()

@@ -19,7 +19,8 @@ import time
 
 import torch
 
-from _common import ensure_table_files, init_process, load_checkpoint_into, parse_config_py, shard_for_inference, synthetic_source
+from _common import (VideoIndex, dataset_index, ensure_table_files, init_process, load_checkpoint_into, parse_config_py, shard_for_inference,
+                     synthetic_index)
 
 from bigc_hip import evaluate as E
 from bigc_hip.shard import gather_results
@@ -40,35 +41,38 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
     if ckpt_path:
         load_checkpoint_into(model, ckpt_path, device)
     model.eval()
+    # The data set as an INDEX (cost + loader per video): the assignment of videos to ranks is computed from it and every rank loads only
+    # its own share (the reference iterates a DataLoader, tools/eval_vidvrd.py:91-121; an 8-GPU node reads the data set once, not 8 times)
     if synthetic:
-        data = synthetic_source(model_config, synthetic, n_trajs, seed=1234)
+        data = synthetic_index(model_config, synthetic, n_trajs, seed=1234)
     elif tracking_dir:
         # raw tracking results (one `.npy` of per-box rows per video, PKU format): ingested here, feature rows assembled on the GPU
         import glob
         import numpy as np
         from bigc_hip.ingest import load_pku_tracklets
         ds_cfg = cfg["test_dataset_config"]
-        data = []
-        for path in sorted(glob.glob(os.path.join(tracking_dir, "*.npy"))):
-            name = os.path.splitext(os.path.basename(path))[0]
-            i3d = np.load(os.path.join(i3d_dir, name + ".npy")) if i3d_dir else None
-            data.append((load_pku_tracklets(name, np.load(path, allow_pickle=True), ds_cfg["dim_boxfeature"], ds_cfg["min_frames_th"],
-                                            ds_cfg["max_proposal"], i3d_res=i3d, dim_i3d=ds_cfg.get("dim_i3d", 0) if i3d_dir else 0,
-                                            device=device), None))
+        paths = sorted(glob.glob(os.path.join(tracking_dir, "*.npy")))
+        names = [os.path.splitext(os.path.basename(path))[0] for path in paths]
+
+        def load(i):
+            i3d = np.load(os.path.join(i3d_dir, names[i] + ".npy")) if i3d_dir else None
+            return (load_pku_tracklets(names[i], np.load(paths[i], allow_pickle=True), ds_cfg["dim_boxfeature"], ds_cfg["min_frames_th"],
+                                       ds_cfg["max_proposal"], i3d_res=i3d, dim_i3d=ds_cfg.get("dim_i3d", 0) if i3d_dir else 0,
+                                       device=device), None)
+        data = VideoIndex([max(1, os.path.getsize(path)) for path in paths], load, names)       # cost = file size ~ rows
     else:
         from dataloaders.dataloader_vidvrd import Dataset_pku_i3d, Dataset_pku, Dataset   # the reference's own loaders
         ds_cfg = cfg["test_dataset_config"]
         ds = (Dataset_pku_i3d if (use_pku and model_config.get("dim_i3d")) else Dataset_pku if use_pku else Dataset)(**ds_cfg)
-        data = [ds[i] for i in range(len(ds))]
+        data = dataset_index(ds)
     predictions, groundtruth, raw = {}, {}, {}
     # Real data: predictions are named with the dataset's vocabulary -- the PKU proposals number the categories differently
     # (utils/evaluate.py:79-82) -- and evaluated against datasets/GT_json_for_eval/VidVRDtest_gts.json as eval_relation_with_gt
     # does.  Synthetic videos have no JSON: their ground truth comes from the generated graphs, which share the proposals'
     # numbering, so both sides use the standard table.
     pku_names = use_pku and not synthetic
-    # this rank's share of the videos, balanced by the number of feature rows (sum of the tracklet lengths)
-    costs = [sum(int(b.shape[0]) for b in p.bboxes_list) if p.num_proposals > 0 else 1 for p, _ in data]
-    mine, my_data = shard_for_inference(data, costs, rank, world)
+    # this rank's share of the videos, balanced by the number of feature rows (sum of the tracklet lengths), loaded now
+    mine, my_data = shard_for_inference(data, data.costs, rank, world)
     t0 = time.time()
     my_results = []
     for s in range(0, len(my_data), batch_videos):
@@ -76,17 +80,23 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
         props = [p.to(device) for p, _ in chunk]
         with torch.no_grad():
             results = model(props, topk=topk)               # one packed HIP forward for the whole chunk
-        my_results += [None if r is None else tuple(t.cpu() for t in r) for r in results]
+        for (p, g), r in zip(chunk, results):
+            # converted to the evaluator's format HERE, by the rank that holds the video's tracklets: rank 0 receives per video
+            # (raw result, prediction entry, ground-truth entry) and never needs the other ranks' proposals
+            r = None if r is None else tuple(t.cpu() for t in r)
+            pred = E.to_eval_format(p.to(torch.device("cpu")), r, dataset_type="vidvrd", use_pku=pku_names)
+            gt = E.gt_to_eval_format(g, dataset_type="vidvrd") if (g is not None and synthetic) else None
+            my_results.append((p.video_name, r, pred, gt))
     torch.cuda.synchronize()
     all_results = gather_results(my_results, mine, len(data), dist)
     if all_results is None:                                 # ranks other than 0 are done
         dist.destroy_process_group()
         return None
-    for (p, g), r in zip(data, all_results):
-        predictions.update(E.to_eval_format(p.to(torch.device("cpu")), r, dataset_type="vidvrd", use_pku=pku_names))
-        raw[p.video_name] = None if r is None else list(r)
-        if g is not None and synthetic:
-            groundtruth[p.video_name] = E.gt_to_eval_format(g, dataset_type="vidvrd")
+    for name, r, pred, gt in all_results:
+        predictions.update(pred)
+        raw[name] = None if r is None else list(r)
+        if gt is not None:
+            groundtruth[name] = gt
     infer_s = time.time() - t0
     with open(os.path.join(output_dir, "VidVRDtest_infer_result_%s.pkl" % save_tag), "wb") as f:
         pickle.dump(raw, f)
@@ -98,7 +108,7 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
         with open(gt_json) as f:
             groundtruth = json.load(f)
     mean_ap, rec, prec = E.evaluate(groundtruth, predictions, device=device)     # vIoU overlaps from one batched HIP kernel
-    print("inference: %d videos in %.2f s on %d GPU(s)" % (len(data), infer_s, world))
+    print("inference: %d videos in %.2f s on %d GPU(s) (this rank loaded %d of them)" % (len(data), infer_s, world, data.n_loaded))
     print("detection mean AP (used in challenge): {}".format(mean_ap))
     print("detection recall: {}".format(rec))
     print("tagging precision: {}".format(prec))

@@ -9,15 +9,22 @@ import os
 
 import torch
 
-from _common import ensure_grounding_files, ensure_table_files, init_process, parse_config_py, synthetic_vidor_source, training_loop
+from _common import (VideoIndex, dataset_index, ensure_grounding_files, ensure_table_files, init_process, parse_config_py, synthetic_vidor_index,
+                     synthetic_vidor_source, training_loop)
 
 from models import BIG_C_vidor, DEBUG
 
 
-def _dataset(cfg):
+def _dataset(cfg, world=1, convert=None):
+    """the reference's data set as an index: a rank loads the videos of its own chunks only (_common.VideoIndex)"""
     from dataloaders.dataloader_vidor import Dataset                  # the reference's loader (tools/train_vidor.py:15)
     ds = Dataset(**cfg["train_dataset_config"])
-    return [ds[i] for i in range(len(ds))]
+    return dataset_index(ds, convert, keep=None if world == 1 else max(8, 2 * len(ds) // world))
+
+
+def _mapped(index, fn):
+    """the same index with every loaded item passed through ``fn``"""
+    return VideoIndex(index.costs, lambda i: fn(index[i]), index.names, index._keep)
 
 
 def train_cls_stage(cfg_path, output_dir=None, save_tag="", from_checkpoint=False, ckpt_path=None, synthetic=0, n_trajs=32, epochs=None):
@@ -28,13 +35,16 @@ def train_cls_stage(cfg_path, output_dir=None, save_tag="", from_checkpoint=Fals
     model_config = ensure_table_files(cfg["model_config"], output_dir)
     torch.manual_seed(0)
     model = BIG_C_vidor(model_config, is_train=True).to(device)
-    data = [(p, g) for p, g, _ in synthetic_vidor_source(model_config, synthetic, n_trajs, seed=8765)] if synthetic else _dataset(cfg)
-    gt_duras = {id(g): g.traj_durations.clone() for _, g in data}
+    keep = None if world == 1 else max(8, 2 * synthetic // world)
+    data = _mapped(synthetic_vidor_index(model_config, synthetic, n_trajs, seed=8765, keep=keep), lambda it: (it[0], it[1])) if synthetic \
+        else _dataset(cfg, world)
 
     def step(model, items):
         gts = [g for _, g in items]
         for g in gts:
-            g.traj_durations = gt_duras[id(g)].clone()      # the step decrements the GT end frames in place (models/model_0v7.py, as 0v10:567)
+            if not hasattr(g, "_dura0"):
+                g._dura0 = g.traj_durations.clone()         # as loaded
+            g.traj_durations = g._dura0.clone()             # the step decrements the GT end frames in place (models/model_0v7.py, as 0v10:567)
         return model([p.to(device) for p, _ in items], gts)
 
     return training_loop(model, data, cfg["train_config"], output_dir, save_tag, step, rank, world, device, dist,
@@ -83,9 +93,11 @@ def train_grounding_stage(cfg_path, output_dir=None, save_tag="", from_checkpoin
     torch.manual_seed(0)
     model = DEBUG(model_config, is_train=True).to(device)
     if synthetic:
-        data = [(clip, p, g) for p, g, clip in synthetic_vidor_source({}, synthetic, n_trajs, seed=9876, clip_dim=model_config["dim_feat"])]
+        keep = None if world == 1 else max(8, 2 * synthetic // world)
+        data = _mapped(synthetic_vidor_index({}, synthetic, n_trajs, seed=9876, clip_dim=model_config["dim_feat"], keep=keep),
+                       lambda it: (it[2], it[0], it[1]))
     else:
-        data = _dataset(cfg)                                 # (video_feature, proposal, gt_graph) with video_feature_dir set
+        data = _dataset(cfg, world)                          # (video_feature, proposal, gt_graph) with video_feature_dir set
     torch.manual_seed(1000 + rank)                          # negative predicates are drawn from the global RNG (models/grd_model_v5.py:285-303)
 
     def step(model, items):

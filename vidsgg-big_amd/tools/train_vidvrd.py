@@ -10,7 +10,7 @@ import os
 
 import torch
 
-from _common import ensure_table_files, init_process, parse_config_py, synthetic_source, training_loop
+from _common import dataset_index, ensure_table_files, init_process, parse_config_py, synthetic_index, training_loop
 
 from models import BIG_C_vidvrd
 
@@ -24,20 +24,23 @@ def train(cfg_path, output_dir=None, save_tag="", use_pku=False, from_checkpoint
     model_config = ensure_table_files(model_config, output_dir)
     torch.manual_seed(0)                                   # identical initial weights on every rank
     model = BIG_C_vidvrd(model_config, is_train=True).to(device)
+    # the data set as an index: every rank loads the videos of ITS chunks only, when it first needs them (the reference's DataLoader
+    # workers do the same, tools/train_vidvrd.py:96-110); at most one epoch's share is held
     if synthetic:
-        data = synthetic_source(model_config, synthetic, n_trajs, seed=4321)
+        data = synthetic_index(model_config, synthetic, n_trajs, seed=4321, keep=None if world == 1 else max(8, 2 * synthetic // world))
     else:
         from dataloaders.dataloader_vidvrd import Dataset_pku_i3d, Dataset_pku, Dataset
         ds_cfg = cfg["train_dataset_config"]
         ds = (Dataset_pku_i3d if (use_pku and model_config.get("dim_i3d")) else Dataset_pku if use_pku else Dataset)(**ds_cfg)
-        data = [ds[i] for i in range(len(ds))]
-    gt_duras = {id(g): g.traj_durations.clone() for _, g in data}
+        data = dataset_index(ds, keep=None if world == 1 else max(8, 2 * len(ds) // world))
 
     def step(model, items):
         props = [p.to(device) for p, _ in items]
         gts = [g for _, g in items]
         for g in gts:
-            g.traj_durations = gt_duras[id(g)].clone()      # keep the GT intact across epochs (the step decrements it in place)
+            if not hasattr(g, "_dura0"):
+                g._dura0 = g.traj_durations.clone()         # as loaded
+            g.traj_durations = g._dura0.clone()             # keep the GT intact across epochs (the step decrements it in place)
         return model(props, gts)
 
     return training_loop(model, data, train_config, output_dir, save_tag, step, rank, world, device, dist,

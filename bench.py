@@ -8,9 +8,10 @@ Workload = BASELINE.json configs[1]: VidVRD-test classification-only, model_0v10
 dimensions (PKU RoI 2048-d + I3D 832-d), synthetic videos of N=64 tracklets (SURVEY.md 8d recipe,
 video v uses numpy RandomState(1234+v)), numpy-seeded weights.  One step = ONE CALL OF THE DROP-IN
 SIGNATURE, `model(proposal_list, topk)` (models/model_0v10.py:359-388), on `--videos` (default 256)
-device-resident TrajProposals per GPU: the ragged pack (one gather launch that writes the rows in the
-split form the forward reads), the forward, construct_triplet, the compaction to the reference's return
-types, the one D2H copy and the per-video result tuples are all inside the timed region.  The same
+device-resident TrajProposals per GPU: the ragged batch's tables and boxes (the feature rows are read in
+place through a row-address table: no copy of them is made), the forward, construct_triplet, the
+compaction to the reference's return types, the one D2H copy and the per-video result tuples are all
+inside the timed region.  The same
 forward on a batch that stays packed in HBM is reported beside it (`resident_packed_batch`).  N>1: one process per GPU (torch.distributed / RCCL only for the barrier
 and the max-over-ranks timing -- videos are independent, no data-path collective), weak scaling.
 Started without a torch.distributed.run environment, `--gpus N` (N>1) launches the N ranks itself
@@ -699,15 +700,17 @@ def main():
     lib = _lib.load()
 
     # ---- the step that is timed: the drop-in call itself, model(proposal_list, topk) (models/model_0v10.py:359-388) on device-resident
-    # TrajProposals -- everything the product does per batch is inside: the ragged pack (ONE gather launch that writes the rows in the
-    # form the forward reads, csrc/ingest.hip), the forward, construct_triplet, the compaction to the reference's return types, the one
-    # D2H copy (row offsets + range flag) and the per-video result tuples
+    # TrajProposals -- everything the product does per batch is inside: the ragged batch's tables and boxes (the feature rows are read in
+    # place through a row-address table, csrc/linear_split.hip / frontend.hip), the forward, construct_triplet, the compaction to the
+    # reference's return types, the one D2H copy (row offsets + range flag) and the per-video result tuples
     def api_step():
         return model(props, topk=args.topk)
 
     # ... and the same forward on a batch that stays packed in HBM (a resident PackedBatch, the engine-level entry point): what a
     # loop over resident data pays per pass; reported as `resident_packed_batch`, never the headline
     packed = PackedBatch(props, device, "lazy")
+    if os.environ.get("BIGC_FEAT_HR8", "1") != "0":
+        packed.materialize("hr8", cfg["dim_feat"])      # the resident form: RoI columns as f16 pairs + I3D columns f32, gathered by one launch
     pairs_per_step, rows_per_step = packed.n_pairs(), packed.n_rows
 
     def packed_step():
@@ -788,7 +791,8 @@ def main():
         lib.bigc_prof_enable(0)
         families = collect_families(lib, args.steps)
 
-    ref_out = model.forward_packed(packed, args.topk, keep_intermediates=False) if rank == 0 else None
+    # the outputs that are compared with the oracle: those of the TIMED path (a batch gathered the way model(proposal_list) gathers it)
+    ref_out = model.forward_packed(PackedBatch(props, device, "lazy") if args.headline == "api" else packed, args.topk, keep_intermediates=False) if rank == 0 else None
     # the same step with every GEMM on the exact f32 MFMA kernel, outside the timed region, for comparison
     exact_leg = None
     if args.exact_steps > 0 and not EXACT_F32 and rank == 0:
@@ -1003,15 +1007,16 @@ def main():
         "ms_per_step_median_each_step_synchronised": round(1e3 * float(np.median(per_step)), 3) if per_step else None,
         "triplets_last_step": n_triplets_last, "setup_s": round(gen_s, 1),
         "timed_steps_ms": [round(1e3 * (b - a), 2) for a, b in zip(stamps[:-1], stamps[1:])],
-        "timed_call": ("model(proposal_list, topk) on device-resident TrajProposals: ragged pack (one gather launch writing the split form) + forward + "
-                       "construct_triplet + compaction + one D2H copy + per-video result tuples" if args.headline == "api" else
+        "timed_call": ("model(proposal_list, topk) on device-resident TrajProposals: tables + boxes of the ragged batch (the feature rows are read in place "
+                       "through a row-address table, no copy) + forward + construct_triplet + compaction + one D2H copy + per-video result tuples" if args.headline == "api" else
                        "model.forward_packed(resident PackedBatch, topk) + the one D2H copy"),
         "forward_api": (dict(value=round(value, 1), unit="pairs/s", ms_per_step=round(ms_per_step, 3), steps=args.steps, note="= the headline") if args.headline == "api" else other_leg),
         "resident_packed_batch": (other_leg if args.headline == "api" else dict(value=round(value, 1), unit="pairs/s", ms_per_step=round(ms_per_step, 3), steps=args.steps, note="= the headline")),
         "api_host_ms": {"pack_tables_and_launches": round(pack_host_ms, 2), "result_tuples": round(unpack_host_ms, 2),
                         "note": "host side of one model(proposal_list) call at this batch size, each measured alone with the GPU idle (inside the timed call)"},
         "modes": {"BIGC_FEAT_HR8": os.environ.get("BIGC_FEAT_HR8", "1"), "BIGC_PRESPLIT": os.environ.get("BIGC_PRESPLIT", "auto"),
-                  "BIGC_CHAINED": os.environ.get("BIGC_CHAINED", "1"), "batch_reads_split_features": reads_split},
+                  "BIGC_CHAINED": os.environ.get("BIGC_CHAINED", "1"), "BIGC_FEAT_IN_PLACE": os.environ.get("BIGC_FEAT_IN_PLACE", "1"),
+                  "resident_batch_holds_split_features": reads_split},
     }
     line.update(legs)
     print(json.dumps(line))

@@ -253,6 +253,12 @@ typedef struct {
      * Every path that is not the default eval forward (training, exact / bf16 mode, BIGC_CHAINED=0; see bigc_forward_reads_hr8)
      * needs `feats` and fails with BIGC_ERR_ARG without it. */
     const float* extra; int64_t ld_extra;
+    /* optional (NULL = absent), used when `feats` and `feats_hr8` are both NULL: address of every feature row of the batch, (R) entries,
+     * row r = the (dim_feat + dim_extra) f32 values at feat_row_ptr[r], 16-byte aligned (bigc_row_pointers builds the table from the
+     * per-tracklet addresses).  The default eval forward then reads the features IN PLACE from the callers' per-tracklet tensors --
+     * fc_feat2enti.0 (models/model_0v10.py:447) splits them on their way into the GEMM, the time-mean of :470 walks the rows -- and
+     * no packed copy of the features exists (the reference stacks them, :427-428). */
+    const uint64_t* feat_row_ptr;
 } bigc_batch;
 
 typedef struct {
@@ -271,8 +277,8 @@ typedef struct {
     int32_t* range_flag;
 } bigc_outputs;
 
-/* 1 if bigc_forward with a range_flag output, on this handle in its current arithmetic mode, reads the visual features in the split
- * form (bigc_batch.feats_hr8) -- then a batch may be packed without the f32 copy of those columns --, else 0 */
+/* 1 if bigc_forward with a range_flag output, on this handle in its current arithmetic mode, takes a batch WITHOUT the packed f32 rows
+ * (bigc_batch.feats == NULL): the visual features in the split form (feats_hr8 + extra) or read in place (feat_row_ptr); else 0 */
 int bigc_forward_reads_hr8(const bigc_model* m);
 size_t bigc_workspace_bytes(const bigc_model* m, const bigc_batch* b);
 int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
@@ -544,6 +550,12 @@ int bigc_assemble_rows_f32(void* stream, const float* raw, int ld_raw, int col0,
 int bigc_pack_tracklets(void* stream, const uint64_t* feat_src, const int32_t* feat_ld, const uint64_t* box_src,
                         const int32_t* trk_row_off, int n_trk, long n_rows, int width, int dim_feat, int vectorized, float* feats, long ld_feats,
                         void* feats_hr8, long ld_hr8_bytes, float* extra, long ld_extra, float* boxes, int32_t* range_flag);
+/* row_ptr[trk_row_off[t] + i] = feat_src[t] + 4 * i * (feat_ld ? feat_ld[t] : width): the per-row address table of bigc_batch.feat_row_ptr */
+int bigc_row_pointers(void* stream, const uint64_t* feat_src, const int32_t* feat_ld, int width, const int32_t* trk_row_off, int n_trk,
+                      uint64_t* row_ptr);
+/* bigc_stretched_mean over rows given by address: columns [col0, col0 + w) of row r at row_ptr[r] (16-byte aligned; col0, w multiples of 4) */
+int bigc_stretched_mean_rows(void* stream, const uint64_t* row_ptr, int col0, int w, const int32_t* trk_row_off, const int32_t* trk_vid,
+                             const int32_t* vid_tmax, float* out, int n_trk);
 /* per-video metadata of the same containers: cat_ids (N_v) int64, scores (N_v) f32, traj_durations (N_v, 2) int64 at the
  * addresses cat_src[v] / score_src[v] / dura_src[v] -> trk_cat int32, trk_score f32, trk_dura int32 of bigc_batch */
 int bigc_pack_video_meta(void* stream, const uint64_t* cat_src, const uint64_t* score_src, const uint64_t* dura_src,

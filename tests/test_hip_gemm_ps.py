@@ -85,7 +85,8 @@ def test_split_rows_roundtrip():
     assert int(flag.item()) == 1
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 256, 32), (300, 512, 512), (1000, 1536, 512), (77, 512, 2048), (4096 + 5, 1024, 512), (260, 8, 64), (256 * 3 * 256 // 2 + 77, 512, 128)])
+@pytest.mark.parametrize("M,N,K", [(128, 256, 32), (300, 512, 512), (1000, 1536, 512), (77, 512, 2048), (4096 + 5, 1024, 512), (260, 8, 64), (256 * 3 * 256 // 2 + 77, 512, 128),
+                                   (192 * 128 - 37, 512, 64)])          # the last one: 192-row tiles (one round of 256 workgroups; 128- and 256-row tilings cost more)
 @pytest.mark.parametrize("a_fmt", [0, 1])
 def test_gemm_ps_vs_float64(M, N, K, a_fmt):
     rs = np.random.RandomState(M + N + K + a_fmt)
@@ -108,6 +109,25 @@ def test_gemm_ps_vs_float64(M, N, K, a_fmt):
     C, _, _ = run(Ain, a_fmt, W, bias, None, 1, want_hr8=False)
     _, Cs, _ = run(Ain, a_fmt, W, bias, None, 1, want_f32=False)
     assert bool(((torch.from_numpy(hr8_decode(Cs, M, N)).to(DEV) - C.double()).abs() <= 2.0 ** -22.9 * C.double().abs() + 2.0 ** -28).all())
+
+
+def test_gemm_ps_result_does_not_depend_on_the_tiling():
+    """128-, 192- and 256-row tiles are chosen from the problem size (csrc/gemm_ps.hip: bigc_gemm_ps_launch); every output element is
+    ONE accumulator walked over K in the same order in all of them, so the first rows of a big problem equal, bit for bit, the same
+    rows computed as a small problem of their own -- a video's decoder rows do not depend on how many videos share the batch."""
+    rs = np.random.RandomState(9)
+    N, K = 512, 512
+    big = {3: 192 * 128, 4: 256 * 3 * 256 // 2, 2: 128 * 64}           # M -> the tiling the launcher's cost rule picks (rows / 64 per tile)
+    A = torch.from_numpy(rs.standard_normal((max(big.values()), K)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(DEV)
+    As = to_hr8(A)[0]
+    ref, _, _ = run(As[:200], 1, W, bias, None, 1, want_hr8=False)
+    for rb, M in big.items():
+        C, Cs, flag = run(As[:M], 1, W, bias, None, 1)
+        assert flag == 0 and torch.equal(C[:200], ref), rb
+        want = ref64(A[:M], W, bias, None, 1)
+        assert bool(((C.double() - want).abs() <= 6 * 2.0 ** -24 * budget(A[:M], W) + 2.0 ** -23 * want.abs() + 1e-7).all()), rb
 
 
 def test_gemm_ps_gather_segments():

@@ -103,9 +103,10 @@ def _model(cfg_name="CONFIG_TINY", seed=5):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg_name", ["CONFIG_TINY", "CONFIG_V"])
-def test_forward_of_a_proposal_list_equals_the_f32_packed_forward(cfg_name):
-    """forward(proposal_list) gathers straight into the split form; a batch packed as f32 rows and split afterwards must give the
-    same bits, and the per-video tuples must be the padded arrays' rows in the reference's dtypes"""
+def test_forward_of_a_proposal_list_reads_the_rows_in_place(cfg_name, monkeypatch):
+    """forward(proposal_list) makes NO copy of the features (a table of row addresses, csrc/linear_split.hip reads through it); the
+    per-video tuples are the padded arrays' rows in the reference's dtypes; gathered into the split form instead (BIGC_FEAT_IN_PLACE=0)
+    the batch gives, bit for bit, what an f32-packed batch gives; and the two forms agree within the logit tolerance"""
     cfg, model = _model(cfg_name)
     width = cfg["dim_feat"] + (cfg.get("dim_i3d") or 0)
     n = (9, 0, 17, 5) if cfg_name != "CONFIG_V" else (64, 33)
@@ -113,8 +114,12 @@ def test_forward_of_a_proposal_list_equals_the_f32_packed_forward(cfg_name):
     props = [p.to(DEV) for p in host]
     res = model(props, topk=3)
     live = [p for p in props if p.num_proposals > 0]
-    pk = PackedBatch(live, DEV)                                   # f32 rows
+    eng = model.engine()
+    if not eng.lib.bigc_forward_reads_hr8(eng.handle):
+        pytest.skip("this configuration's forward reads packed f32 rows")
+    pk = PackedBatch(live, DEV, "lazy")
     out = model.forward_packed(pk, 3)
+    assert pk._feats is None and pk.feats_hr8 is None and pk.feat_row_ptr is not None        # nothing was copied
     cnt = model.counts(out).tolist()
     j = 0
     for p, r in zip(props, res):
@@ -129,17 +134,31 @@ def test_forward_of_a_proposal_list_equals_the_f32_packed_forward(cfg_name):
             assert torch.equal(r[0], out["quint"][j, :k].long()) and torch.equal(r[1], out["scores"][j, :k])
             assert torch.equal(r[2], out["dura"][j, :k].long()) and torch.equal(r[3], out["qid"][j, :k].long())
         j += 1
-    if model.engine().lib.bigc_forward_reads_hr8(model.engine().handle):
-        pk2 = PackedBatch(live, DEV, "lazy")
-        out2 = model.forward_packed(pk2, 3)
-        assert pk2._feats is None and pk2.feats_hr8 is not None           # gathered straight into the split form
-        assert torch.equal(out2["pred_logits"], out["pred_logits"]) and model.counts(out2).tolist() == cnt
-        for j, k in enumerate(cnt):                                       # (rows past a video's count are padding, never written)
-            assert torch.equal(out2["quint"][j, :k], out["quint"][j, :k]) and torch.equal(out2["scores"][j, :k], out["scores"][j, :k])
+    # the split form: gathered straight from the sources == made from packed f32 rows
+    pk_f32 = PackedBatch(live, DEV)
+    out_f32 = model.forward_packed(pk_f32, 3)
+    monkeypatch.setenv("BIGC_FEAT_IN_PLACE", "0")
+    pk_hr8 = PackedBatch(live, DEV, "lazy")
+    out_hr8 = model.forward_packed(pk_hr8, 3)
+    assert pk_hr8._feats is None and pk_hr8.feats_hr8 is not None and pk_hr8.feat_row_ptr is None
+    assert torch.equal(out_hr8["pred_logits"], out_f32["pred_logits"]) and model.counts(out_hr8).tolist() == model.counts(out_f32).tolist()
+    for j, k in enumerate(model.counts(out_f32).tolist()):                # (rows past a video's count are padding, never written)
+        assert torch.equal(out_hr8["quint"][j, :k], out_f32["quint"][j, :k]) and torch.equal(out_hr8["scores"][j, :k], out_f32["scores"][j, :k])
+    # in place (fc_feat2enti.0 splits the rows in its loop, two accumulators) vs the split form (one accumulator): the same numbers to 1e-4
+    Q = cfg["num_querys"]
+    a, b = out["pred_logits"].reshape(len(live), Q, -1), out_f32["pred_logits"].reshape(len(live), Q, -1)
+    same = (out["soid"] == out_f32["soid"]).all(1)                       # (B, Q): queries whose attention arg-max agrees
+    rel = ((a - b).abs().amax(2) * same).amax(1) / b.abs().amax((1, 2))
+    assert float(rel.max()) < 1e-4 and float(same.float().mean()) > 0.99
 
 
 @pytest.mark.gpu
-def test_out_of_range_feature_falls_back_to_the_exact_path_through_the_api():
+@pytest.mark.parametrize("in_place", ["1", "0"])
+def test_feature_outside_the_split_forms_range_through_the_api(in_place, monkeypatch):
+    """a feature of 6000: outside the range of the STORED split form (|x| >= 4096: the gather raises the flag, the step is repeated on the
+    exact kernels and returns exactly what exact mode gives), inside the range of the in-loop split of the in-place path (|x| < 32768: the
+    result is a valid split-arithmetic result, close to the exact mode's)"""
+    monkeypatch.setenv("BIGC_FEAT_IN_PLACE", in_place)
     cfg, model = _model("CONFIG_V")
     width = cfg["dim_feat"] + cfg["dim_i3d"]
     host = [synthetic_proposal(77, n_trajs=12, feat_width=width, num_enti_cats=cfg["num_enti_cats"])]
@@ -152,5 +171,9 @@ def test_out_of_range_feature_falls_back_to_the_exact_path_through_the_api():
         want = model(props, topk=3)
     finally:
         eng.set_mode(-1, -1)
-    for a, b in zip(res[0], want[0]):
-        assert torch.equal(a, b)
+    if in_place == "0":
+        for a, b in zip(res[0], want[0]):
+            assert torch.equal(a, b)
+    else:
+        assert torch.equal(res[0][0], want[0][0]) and torch.equal(res[0][2], want[0][2])
+        assert float((res[0][1] - want[0][1]).abs().max()) < 1e-4

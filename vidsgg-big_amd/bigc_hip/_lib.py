@@ -32,7 +32,7 @@ class bigc_batch(ctypes.Structure):
                 ("trk_cat", c_void_p), ("trk_score", c_void_p), ("vid_trk_off", c_void_p),
                 ("vid_tmax", c_void_p), ("vid_wh", c_void_p),
                 ("feats_hr8", c_void_p), ("ld_feats_hr8", ctypes.c_int64), ("feats_hr8_flag", c_void_p),
-                ("extra", c_void_p), ("ld_extra", ctypes.c_int64)]
+                ("extra", c_void_p), ("ld_extra", ctypes.c_int64), ("feat_row_ptr", c_void_p)]
 
 
 class bigc_outputs(ctypes.Structure):
@@ -95,6 +95,8 @@ _SIGS = {
                                        c_void_p, c_void_p, c_int, c_int]),
     "bigc_pack_tracklets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_long, c_int, c_int, c_int, c_void_p, ctypes.c_long,
                                     c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_void_p, c_void_p]),
+    "bigc_row_pointers": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "bigc_stretched_mean_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "bigc_pack_video_meta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "bigc_compact_triplets": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),

@@ -161,9 +161,15 @@ class BigcEngine(object):
             setattr(o, name, out[name].data_ptr() if name in out else None)
         # The default eval forward reads the visual features in the split form: a batch that has no feature rows yet is gathered
         # straight into it (one launch, csrc/ingest.hip); every other mode reads f32 rows.  BIGC_FEAT_HR8=0 switches the form off.
+        # A batch that holds no feature rows yet (forward(proposal_list): seen once) is read IN PLACE -- a table of row addresses, no copy;
+        # a batch that already holds f32 rows (a resident PackedBatch, reused step after step) gets the split form once.
         use_hr8 = bool(with_triplets and os.environ.get("BIGC_FEAT_HR8", "1") != "0" and self.lib.bigc_forward_reads_hr8(self.handle))
         if use_hr8:
-            packed.materialize("hr8", c.dim_feat)
+            if packed._feats is None and packed.feats_hr8 is None and packed.can_read_in_place() and c.dim_feat % 4 == 0 and c.dim_extra % 4 == 0 \
+                    and os.environ.get("BIGC_FEAT_IN_PLACE", "1") != "0":
+                packed.rows_in_place()
+            else:
+                packed.materialize("hr8", c.dim_feat)
         b = packed.as_struct(need_f32=not use_hr8)
         need = self.lib.bigc_workspace_bytes(self.handle, ctypes.byref(b))
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:

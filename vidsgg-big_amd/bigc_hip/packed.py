@@ -13,6 +13,8 @@ the rows directly in the form the forward reads:
   (the operand format of csrc/gemm_ps.hip, same footprint as f32) + the remaining columns
   (I3D / classeme) as an f32 tensor of their own.  A feature element exists once in HBM.
 * ``"f32"``: full f32 rows (training, exact / bf16 arithmetic modes).
+* in place (``rows_in_place``): NO copy -- a per-row address table through which the default eval forward reads the tracklets' rows
+  where they are (one-shot batches: ``forward(proposal_list)``); only the boxes are gathered.
 
 The form is chosen at first use (``materialize``); a packed batch can be kept resident and
 reused.  Per-video metadata (categories, scores, durations) is gathered by a second small launch.
@@ -157,6 +159,7 @@ class PackedBatch(object):
         self._blob = blob_d
         self._feats, self._boxes, self.extra = None, None, None
         self.feats_hr8, self.feats_hr8_flag = None, None
+        self.feat_row_ptr = None
         if features != "lazy":
             assert features == "f32", "the split form needs dim_feat: PackedBatch(..., 'lazy') then materialize('hr8', dim_feat)"
             self.materialize("f32")
@@ -212,6 +215,19 @@ class PackedBatch(object):
         else:
             self.feats_hr8, self.feats_hr8_flag, self.extra = hr8, flag, extra
 
+    def can_read_in_place(self):
+        """the forward can read the feature rows where they are (16-byte aligned sources that are still alive)"""
+        return self.device.type == "cuda" and self._vectorized and self.proposals is not None
+
+    def rows_in_place(self):
+        """No copy of the features at all: the per-row address table (``bigc_batch.feat_row_ptr``) the default eval forward reads the
+        callers' per-tracklet rows through.  The source tensors must stay alive (``proposals`` holds them)."""
+        assert self.can_read_in_place()
+        if self.feat_row_ptr is None:
+            self.feat_row_ptr = torch.empty((self.n_rows,), dtype=torch.int64, device=self.device)
+            _lib.check(_lib.load().bigc_row_pointers(_lib.current_stream(), self._feat_src.data_ptr(), _lib.ptr(self._feat_ld), self.feat_width,
+                                                     self.trk_row_off.data_ptr(), self.n_trk, self.feat_row_ptr.data_ptr()))
+
     def split_features(self, dim_feat):
         """(kept name) the visual feature columns in the split form "hr8": see ``materialize``"""
         self.materialize("hr8", dim_feat)
@@ -246,8 +262,8 @@ class PackedBatch(object):
 
     def as_struct(self, need_f32=True):
         """``need_f32``: the call reads ``bigc_batch.feats`` (everything but the default eval forward, which reads the split form
-        when the batch holds it)"""
-        if need_f32 or self.feats_hr8 is None:
+        when the batch holds it, or the rows in place)"""
+        if need_f32 or (self.feats_hr8 is None and self.feat_row_ptr is None):
             self.materialize("f32")
         b = _lib.bigc_batch()
         b.n_vid, b.n_trk, b.n_rows, b.n_conv, b.max_trk = self.n_vid, self.n_trk, self.n_rows, self.n_conv, self.max_trk
@@ -259,4 +275,6 @@ class PackedBatch(object):
             b.feats_hr8, b.ld_feats_hr8, b.feats_hr8_flag = self.feats_hr8.data_ptr(), int(self.feats_hr8.shape[1]), self.feats_hr8_flag.data_ptr()
             if self.extra is not None:
                 b.extra, b.ld_extra = self.extra.data_ptr(), int(self.extra.shape[1])
+        elif self.feat_row_ptr is not None and self._feats is None:
+            b.feat_row_ptr = self.feat_row_ptr.data_ptr()
         return b

@@ -160,6 +160,60 @@ __global__ __launch_bounds__(256) void stretched_mean_kernel(const float* __rest
     }
 }
 
+// the same over rows given by address (row r of the batch at row_ptr[r], 16-byte aligned): the tracklets' rows are read in place from the
+// callers' tensors (bigc_batch.feat_row_ptr).  The row addresses are workgroup-uniform (scalar loads).
+__global__ __launch_bounds__(256) void stretched_mean_rows_kernel(const uint64_t* __restrict__ row_ptr, int col0, int w,
+                                                                  const int32_t* __restrict__ row_off, const int32_t* __restrict__ trk_vid,
+                                                                  const int32_t* __restrict__ vid_tmax, float* __restrict__ out) {
+    const int t = blockIdx.x;
+    const int r0 = row_off[t], L = row_off[t + 1] - r0;
+    const int M = vid_tmax[trk_vid[t]];
+    const int q = M / L, r = M - q * L;
+    const float inv = 1.0f / (float)M;
+    for (int c = threadIdx.x * 4; c < w; c += 1024) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int i = 0;
+        for (; i + 8 <= L; i += 8) {            // eight rows in flight, summed in row order (the order of stretched_mean_kernel)
+            f32x4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = *(const __attribute__((address_space(1))) f32x4*)((const __attribute__((address_space(1))) float*)row_ptr[r0 + i + u] + col0 + c);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float wt = (i + u < r) ? (float)(q + 1) : (float)q;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += wt * x[u][k];
+            }
+        }
+        for (; i + 4 <= L; i += 4) {
+            f32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = *(const __attribute__((address_space(1))) f32x4*)((const __attribute__((address_space(1))) float*)row_ptr[r0 + i + u] + col0 + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float wt = (i + u < r) ? (float)(q + 1) : (float)q;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += wt * x[u][k];
+            }
+        }
+        for (; i < L; ++i) {
+            const f32x4 x = *(const __attribute__((address_space(1))) f32x4*)((const __attribute__((address_space(1))) float*)row_ptr[r0 + i] + col0 + c);
+            const float wt = (i < r) ? (float)(q + 1) : (float)q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += wt * x[k];
+        }
+        *(f32x4*)(out + (size_t)t * w + c) = f32x4{s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv};
+    }
+}
+
+// row r0 + i of tracklet t starts at feat_src[t] + i * pitch: the per-row address table the in-place readers take
+__global__ __launch_bounds__(256) void row_pointers_kernel(const uint64_t* __restrict__ feat_src, const int32_t* __restrict__ feat_ld, int width,
+                                                           const int32_t* __restrict__ row_off, uint64_t* __restrict__ row_ptr) {
+    const int t = blockIdx.x;
+    const int r0 = row_off[t], L = row_off[t + 1] - r0;
+    const uint64_t base = feat_src[t], pitch = 4ull * (uint64_t)(feat_ld ? feat_ld[t] : width);
+    for (int i = threadIdx.x; i < L; i += 256) row_ptr[r0 + i] = base + (uint64_t)i * pitch;
+}
+
 // (n_out, n_in, taps) torch Conv1d weight -> (n_out, taps*n_in) tap-major rows for the implicit GEMM
 __global__ void repack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out, long total, int n_in, int taps) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -217,5 +271,25 @@ extern "C" int bigc_stretched_mean(void* stream, const float* feats, int ldf, in
     ProfScope ps(stream, FAM_FRONTEND, 0.0, 0.0);
     hipLaunchKernelGGL(stretched_mean_kernel, dim3(n_trk), dim3(256), 0, (hipStream_t)stream, feats, ldf, col0, w, trk_row_off, trk_vid, vid_tmax, out);
     BIGC_LAUNCH_CHECK("stretched_mean");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_stretched_mean_rows(void* stream, const uint64_t* row_ptr, int col0, int w, const int32_t* trk_row_off, const int32_t* trk_vid,
+                                        const int32_t* vid_tmax, float* out, int n_trk) {
+    BIGC_CHECK_ARG(row_ptr && trk_row_off && trk_vid && vid_tmax && out && w > 0 && w % 4 == 0 && col0 % 4 == 0, "stretched_mean_rows: bad argument");
+    if (n_trk <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_FRONTEND, 0.0, 0.0);
+    hipLaunchKernelGGL(stretched_mean_rows_kernel, dim3(n_trk), dim3(256), 0, (hipStream_t)stream, row_ptr, col0, w, trk_row_off, trk_vid, vid_tmax, out);
+    BIGC_LAUNCH_CHECK("stretched_mean_rows");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_row_pointers(void* stream, const uint64_t* feat_src, const int32_t* feat_ld, int width, const int32_t* trk_row_off, int n_trk,
+                                 uint64_t* row_ptr) {
+    BIGC_CHECK_ARG(feat_src && trk_row_off && row_ptr && width > 0, "row_pointers: bad argument");
+    if (n_trk <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_PACK, 0.0, 0.0);
+    hipLaunchKernelGGL(row_pointers_kernel, dim3(n_trk), dim3(256), 0, (hipStream_t)stream, feat_src, feat_ld, width, trk_row_off, row_ptr);
+    BIGC_LAUNCH_CHECK("row_pointers");
     return BIGC_OK;
 }

@@ -99,7 +99,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void pack_tracklets_kernel(PackArgs a) {
     const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = a.trk_row_off[t], n = a.trk_row_off[t + 1] - r0;
-    const float* src = (const float*)a.feat_src[t];
+    const float* src = a.feat_src ? (const float*)a.feat_src[t] : nullptr;          // (boxes only: no feature table)
     const long lds = a.feat_ld ? (long)a.feat_ld[t] : (long)a.width;
     if (a.boxes && a.box_src) {
         const float* bs = (const float*)a.box_src[t];

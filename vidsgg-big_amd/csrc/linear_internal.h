@@ -22,6 +22,9 @@ struct LinearArgs {
     // split kernel: also / instead of C, the result in the split form "hr8" of gemm_ps.hip (pitch in BYTES; N % 8 == 0); an
     // element that form cannot hold sets *range_flag
     unsigned char* Cs = nullptr; long ldcs = 0; int* range_flag = nullptr;
+    // split kernel, row-pointer mode: row m of A starts at address a_rowptr[m] (16-byte aligned) instead of A + m * lda -- the operand is
+    // read in place from rows that live in separate allocations (the per-tracklet feature tensors of a batch, bigc_batch.feat_row_ptr)
+    const uint64_t* a_rowptr = nullptr;
 };
 
 // Weights that stay constant between launches are split once and cached per (pointer, shape) for an "epoch": the model
@@ -71,6 +74,10 @@ int bigc_weight_transposed(hipStream_t s, const float* W, int N, int K, int ldw,
 // the producer side of a GEMM -> GEMM chain whose second GEMM runs on gemm_ps.hip
 int bigc_linear_hr8out(void* stream, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
                        float* C, int ldc, void* Cs, long ldcs, int M, int N, int K, int act, int* range_flag);
+// the same with the rows of A given by address (row m at row_ptr[m], 16-byte aligned, K floats each): csrc/model.hip reads the visual features
+// of a batch in place from the callers' per-tracklet tensors
+int bigc_linear_hr8out_rows(void* stream, const uint64_t* row_ptr, const float* W, int ldw, const float* bias, void* Cs, long ldcs, int M, int N, int K,
+                            int act, int* range_flag);
 // the K = 8 GEMM (linear_k8_kernel) with its output in the split form
 int bigc_linear_k8_hr8out(void* stream, const float* A, const float* W, const float* bias, void* Cs, long ldcs, int M, int N, int act, int* range_flag);
 // y = act(relu(x8 W0^T + b0) W^T + bias): the K = 8 layer folded into the staging of the next GEMM; false -> two launches

@@ -180,10 +180,17 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
     // Loads are unconditional (one basic block per K step, so that the scheduler can interleave the split arithmetic
     // with the MFMAs): rows past M / N are clamped to the last valid row -- their products land in accumulator rows /
     // columns that are never stored -- and only a ragged last slab (KTAIL) or a gather index of -1 (a zero row) select 0.
-    const float* arow[NA];
+    // (global-address-space pointers: a row address read from the row-pointer table would otherwise be a FLAT pointer, and flat loads
+    // count on the LDS counter too -- measured 4.42 instead of 3.94 ms on the K = 2048 GEMM)
+    typedef const __attribute__((address_space(1))) float* gfp;
+    typedef const __attribute__((address_space(1))) f32x4* gf4p;
+    gfp arow[NA];
     const u32x4* wrow[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) arow[i] = p.A + (size_t)min(m0 + lr + RPP * i, p.M - 1) * p.lda;
+    for (int i = 0; i < NA; ++i) {
+        const int row = min(m0 + lr + RPP * i, p.M - 1);
+        arow[i] = p.a_rowptr ? (gfp)p.a_rowptr[row] : (gfp)(p.A + (size_t)row * p.lda);
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) wrow[i] = p.Ws + (size_t)min(n0 + lr + RPP * i, p.N - 1) * p.ldws;
     // depth-wise-separable mode: per staged row, the element offset of every tap's row relative to the row itself, and which
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
                     const int src = p.a_idx[(size_t)min(m0 + lr + RPP * i, p.M - 1) * p.nseg + seg];
-                    arow[i] = src >= 0 ? p.A + (size_t)src * p.lda : p.zero_row;      // index -1: a row of zeros, no select needed
+                    arow[i] = (gfp)(src >= 0 ? p.A + (size_t)src * p.lda : p.zero_row);      // index -1: a row of zeros, no select needed
                 }
             }
         }
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
 #pragma unroll
                 for (int i = 0; i < RG; ++i)
 #pragma unroll
-                    for (int jj = 0; jj < DWN; ++jj) xv[i][jj] = *(const f32x4*)(arow[i0 + i] + dwoff[i0 + i][jj] + acol);
+                    for (int jj = 0; jj < DWN; ++jj) xv[i][jj] = *(gf4p)(arow[i0 + i] + dwoff[i0 + i][jj] + acol);
 #pragma unroll
                 for (int i = 0; i < RG; ++i) {
                     f32x4 acc = bq;
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            ra[i] = *(const f32x4*)(arow[i] + acol);
+            ra[i] = *(gf4p)(arow[i] + acol);
             if (KTAIL && !kval) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int mrow = min(m0 + wm * 64 + mi * 32 + l31, p.M - 1);
-                const float* src = p.A + (size_t)mrow * p.lda + kcl;
+                const float* src = (p.a_rowptr ? (const float*)(const __attribute__((address_space(1))) float*)p.a_rowptr[mrow] : p.A + (size_t)mrow * p.lda) + kcl;
                 bool zero = !kok;
                 if (GATHER) {
                     const int seg = kcl / p.seg_len;

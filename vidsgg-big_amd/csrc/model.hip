@@ -383,6 +383,9 @@ int run_frontend_chained(const bigc_model* m, void* s, const bigc_batch* b, cons
         // the features were split when the batch was packed (bigc_batch.feats_hr8): the K = dim_feat GEMM reads them by DMA
         TRY(ps(cx, b->feats_hr8, b->ld_feats_hr8 / 4, true, m->feat0, c.dim_feat, nullptr, 0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
         if (b->feats_hr8_flag) TRY(bigc_or_flag((hipStream_t)s, w.flag, b->feats_hr8_flag));
+    } else if (!b->feats && b->feat_row_ptr && c.dim_feat % 4 == 0) {
+        // the visual features read IN PLACE from the callers' per-tracklet rows (bigc_batch.feat_row_ptr): no packed copy of them exists
+        TRY(bigc_linear_hr8out_rows(s, b->feat_row_ptr, m->feat0.w, c.dim_feat, m->feat0.b, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU, w.flag));
     } else {
         BIGC_CHECK_ARG(b->feats, "forward: batch without f32 features and without a usable split form of them");
         TRY(bigc_linear_hr8out(s, b->feats, D, m->feat0.w, c.dim_feat, m->feat0.b, nullptr, 0, nullptr, 0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU, w.flag));
@@ -667,14 +670,13 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         // form -- the LayerNorms an hr8 twin, the attention core and the role attention ONLY the split form -- so that in_proj (one
         // q / k / v GEMM, build_qkpos), out_proj, the second role-wise linears, fc2.0 and fc2.3 run on csrc/gemm_ps.hip (K loop =
         // DMA + MFMA).  fc_pred2att / fc_enti2att, whose rounding the sharp attention amplifies, stay on the two-accumulator kernel.
-        // NOT the default: measured on the 256-video step (rocprofv3, profiles/r03_presplit_probe.log) the GEMM family takes 16.0 ms
-        // against 16.2 ms and the step 19.33 against 19.10 ms -- at M = 49152, N = 512 the 256-row tiles of gemm_ps are 384 for 256
-        // CUs (the launcher falls back to its 128-row kernel: 119 us per GEMM against 100 us for linear_split), the LayerNorms write a
-        // second output (+0.35 ms), and the one-accumulator GEMMs round coarser (oracle/accuracy.py).  It pays from 512 videos per step.
-        // BIGC_PRESPLIT = 1 / 0 forces it on / off; unset: on when the decoder's (B Q, dp) GEMMs fill the chip with 256-row tiles
-        // (512 videos per step: 55.4 -> 56.6 M pairs/s)
+        // Round 4: ON for every batch size.  csrc/gemm_ps.hip picks 128- / 192- / 256-row tiles per problem (M = 49152 = the decoder of a
+        // 256-video step: 192-row tiles, two exact rounds of the 256 persistent workgroups), the result of a GEMM does not depend on the
+        // tiling, and so a video's bits do not depend on how many videos share its batch (before, the form switched on at 512 videos).
+        // Measured (profiles/r04_presplit_ab.log): 256 videos 18.87 -> 18.69 ms (GEMM family 0.390 -> 0.401), 64 videos 6.79 -> 6.78,
+        // 8 videos 3.60 -> 3.63.  BIGC_PRESPLIT=0 switches it off.
         static const int presplit_env = getenv("BIGC_PRESPLIT") ? atoi(getenv("BIGC_PRESPLIT")) : -1;
-        const bool presplit_off = presplit_env == 0 || (presplit_env < 0 && (long)((BQ + 255) / 256) * ((dp + 255) / 256) < 3 * 256);
+        const bool presplit_off = presplit_env == 0;
         const bool presplit = chained && !presplit_off && fused && Q <= 192 && da / 2 <= 256 && (da / 2) % 128 == 0 && dp % 32 == 0 && dp <= de &&
                               dp / H == 64 && (dp == 512 || dp == 256 || dp == 128 || dp == 64) && df % 32 == 0;
         if (presplit && i > 0) {

@@ -56,6 +56,8 @@ inline int linear(void* s, const float* A, int lda, const Lin& l, float* C, int 
 // for the eval forward (bigc_batch.extra), else the tail of the f32 feature rows
 inline int bigc_extra_mean(void* s, const bigc_batch* b, const bigc_config& c, float* out, int n_trk) {
     if (b->extra) return bigc_stretched_mean(s, b->extra, (int)b->ld_extra, 0, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, out, n_trk);
+    if (!b->feats && b->feat_row_ptr && c.dim_feat % 4 == 0 && c.dim_extra % 4 == 0)         // in place, from the callers' rows
+        return bigc_stretched_mean_rows(s, b->feat_row_ptr, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, out, n_trk);
     BIGC_CHECK_ARG(b->feats, "batch without f32 features (bigc_batch.feats) and without bigc_batch.extra");
     return bigc_stretched_mean(s, b->feats, c.dim_feat + c.dim_extra, c.dim_feat, c.dim_extra, b->trk_row_off, b->trk_vid, b->vid_tmax, out, n_trk);
 }

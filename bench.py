@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--exact-steps", type=int, default=3, help="extra steps timed with the exact f32-MFMA GEMM kernel, reported beside (0 = skip)")
     ap.add_argument("--fast-steps", type=int, default=3, help="extra steps timed in the opt-in reduced-precision mode (one f16 MFMA per product), "
                                                              "reported beside with its Recall@50 gate (0 = skip)")
-    ap.add_argument("--recall-steps", type=int, default=400, help="training iterations of the Recall@50 leg (0 = skip the leg)")
+    ap.add_argument("--recall-steps", type=int, default=300, help="training iterations of the Recall@50 leg (0 = skip the leg)")
     ap.add_argument("--recall-videos", type=int, default=16, help="held-out videos the Recall@50 leg scores (HIP, HIP reduced precision, CPU oracle)")
     ap.add_argument("--legs", default="vidor,grounding,train,batch512", help="extra workloads reported in the same line at N=1 ('' = none)")
     ap.add_argument("--vidor-videos", type=int, default=16, help="videos of the VidOR leg (SURVEY.md 8d: 16 x N = 180, L in [15, 1000))")
@@ -582,7 +582,12 @@ def recall_leg(args, lib, device):
     sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 11, att_gain=1.0)
     torch.manual_seed(1234)
     trainee = build_model(cfg, sd, device, "vidvrd", is_train=True)
-    data = R.relational_set(cfg, 20000, 64, n_trajs=args.n_trajs)
+    # a HARD version of the set (round 4): weaker actor markers and 30 % label noise in the ground truth (training and held-out), so that a
+    # trained model's Recall@50 sits well inside (0, 1) -- about 1 - noise -- where a change of arithmetic can move it; without them every
+    # mode scored 1.0 and the gate could not tell them apart (benchmarks/probes/recall_probe.py: settings tried, incl. a motion-dependent
+    # predicate whose training outcome varied too much from run to run to gate on)
+    hard = dict(n_actors=4, marker=1.5, label_noise=0.3)
+    data = R.relational_set(cfg, 20000, 64, n_trajs=args.n_trajs, **hard)
     for p, _ in data:
         p.to(device)
     gen_s = time.perf_counter() - t0
@@ -594,7 +599,7 @@ def recall_leg(args, lib, device):
     del trainee, data
     torch.cuda.empty_cache()
     model = build_model(cfg, sd_t, device, "vidvrd", is_train=False)
-    held = R.relational_set(cfg, 30000, args.recall_videos, n_trajs=args.n_trajs)
+    held = R.relational_set(cfg, 30000, args.recall_videos, n_trajs=args.n_trajs, **hard)
     gts = R.ground_truth(held)
     props = [p for p, _ in held]
     dev_props = [copy.deepcopy(p).to(device) for p in props]
@@ -620,6 +625,8 @@ def recall_leg(args, lib, device):
                mean_ap_oracle=res["oracle"][0], mean_ap_hip=res["hip"][0],
                relations_oracle=sum(len(x) for x in rel["oracle"].values()), relations_hip=sum(len(x) for x in rel["hip"].values()),
                abs_diff_recall50_hip_vs_oracle=abs(res["hip"][1][50] - res["oracle"][1][50]),
+               relation_set="marked actors (marker 1.5), predicate = f(actor pair), 30 % of the ground-truth predicates replaced by random classes",
+               recall50_inside_the_discriminating_band_0p5_0p9=bool(0.5 <= res["oracle"][1][50] <= 0.9),
                parity_gate="|R@50(HIP) - R@50(oracle)| = 0 at R@50 > 0 (SURVEY.md 8d)",
                parity_gate_passed=bool(res["oracle"][1][50] > 0 and res["hip"][1][50] == res["oracle"][1][50] and res["hip"][1][100] == res["oracle"][1][100]),
                oracle_seconds=round(oracle_s, 1))

@@ -595,6 +595,12 @@ int bigc_pair_triplets(void* stream, const float* pair_logits, int n_pred, int t
 int bigc_gemm_ps(void* stream, const void* A, long lda_bytes, int a_fmt, const int32_t* a_idx, int nseg, const float* W, int ldw,
                  const float* bias, const float* residual, long ldr, float* C, long ldc, void* Cs, long ldcs_bytes,
                  int M, int N, int K, int act, int* range_flag);
+/* the same product with nn.LayerNorm over the N = 512 output features taken in the epilogue (models/model_0v10.py:188,211,223: the three
+ * norms of a decoder layer follow a GEMM + residual): C = LayerNorm(act(A W^T + bias) + residual) * gamma + beta (+ add[m % add_period],
+ * e.g. `+ pos_embedding`), Cs = the split form of the normalised rows (without the added table).  A must be in the split form. */
+int bigc_gemm_ps_ln(void* stream, const void* A, long lda_bytes, const float* W, int ldw, const float* bias, const float* residual, long ldr,
+                    const float* gamma, const float* beta, float eps, const float* add, int add_period, float* C, long ldc, void* Cs,
+                    long ldcs_bytes, int M, int N, int K, int act, int* range_flag);
 /* f32 rows (rows, K) -> hr8 rows; K % 8 == 0 */
 int bigc_split_rows_f32(void* stream, const float* X, long ldx, void* Y, long ldy_bytes, long rows, int K, int* range_flag);
 /* act(A W^T + bias) + residual on the default split-operand GEMM (f32 A, as bigc_linear_f32) with the result written in the split

@@ -229,3 +229,38 @@ def test_default_gemm_split_form_output_raises_the_range_flag():
                                           128, 16, 64, 0, flag.data_ptr()))
     torch.cuda.synchronize()
     assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("M,K,with_res,with_add,act", [(64 * 5, 512, True, False, 0), (49152 // 8 + 19, 512, True, True, 0), (700, 1024, True, False, 0),
+                                                       (100, 64, False, False, 1)])
+def test_gemm_ps_with_layernorm_epilogue(M, K, with_res, with_add, act):
+    """bigc_gemm_ps_ln: LayerNorm over the 512 output features taken in the GEMM's epilogue (the three norms of a decoder layer,
+    models/model_0v10.py:188,211,223) against float64: f32 output (with the optional periodic table added, `+ pos_embedding`), the split
+    twin = the normalised rows without the table; ragged M; several tiles per workgroup (the persistent loop) at the larger M"""
+    rs = np.random.RandomState(M + K)
+    N, period = 512, 192
+    A = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(DEV)
+    res = torch.from_numpy((2.0 * rs.standard_normal((M, N))).astype(np.float32)).to(DEV) if with_res else None
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, N).astype(np.float32)).to(DEV)
+    beta = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(DEV)
+    add = torch.from_numpy(rs.standard_normal((period, N)).astype(np.float32)).to(DEV) if with_add else None
+    As = to_hr8(A)[0]
+    C = torch.full((M, N), float("nan"), device=DEV)
+    Cs = torch.zeros((M, 4 * N), dtype=torch.uint8, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(_lib.load().bigc_gemm_ps_ln(_lib.current_stream(), As.data_ptr(), 4 * K, W.data_ptr(), K, bias.data_ptr(), _lib.ptr(res), N, gamma.data_ptr(),
+                                           beta.data_ptr(), 1e-5, _lib.ptr(add), period if with_add else 0, C.data_ptr(), N, Cs.data_ptr(), 4 * N, M, N, K, act,
+                                           flag.data_ptr()))
+    torch.cuda.synchronize()
+    x = ref64(A, W, bias, res, act)
+    want = torch.nn.functional.layer_norm(x, (N,), gamma.double(), beta.double(), 1e-5)
+    back = torch.from_numpy(hr8_decode(Cs, M, N)).to(DEV)
+    got = C.double() - (add.double()[torch.arange(M, device=DEV) % period] if with_add else 0.0)
+    # the pre-norm row carries the GEMM's round-off (a few 2^-24 of sum |a||w|), LayerNorm divides by the row's standard deviation
+    sd = x.std(1, unbiased=False, keepdim=True)
+    tol = (8 * 2.0 ** -24 * budget(A, W).amax(1, keepdim=True) + 2.0 ** -22 * x.abs().amax(1, keepdim=True)) / sd * gamma.double().abs() + 2.0 ** -22 * want.abs() + 1e-6
+    assert int(flag.item()) == 0
+    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
+    assert bool(((back - want).abs() <= tol + 2.0 ** -22.9 * want.abs()).all())

@@ -99,7 +99,10 @@ class PackedBatch(object):
         self.n_trk = int(sum(n_per_vid))
         self.max_trk = int(max(n_per_vid))
         all_lens = np.concatenate([t["lens"] for t in tabs])
-        tmax = np.asarray([int(t["lens"].max()) for t in tabs])
+        for t in tabs:
+            if "tmax" not in t:
+                t["tmax"] = int(t["lens"].max())                # (kept with the cached table: 256 small reductions per call otherwise)
+        tmax = np.asarray([t["tmax"] for t in tabs])
         wh = [[float(p.video_wh[0]), float(p.video_wh[1])] for p in proposals]
         self.n_rows = int(all_lens.sum())
         trk_vid = np.repeat(np.arange(self.n_vid), n_per_vid)
@@ -110,18 +113,23 @@ class PackedBatch(object):
         self._vectorized = all(t["aligned"] for t in tabs) and self.feat_width % 4 == 0
 
         # per-video metadata: gathered on the device when the containers hold what the reference's do (int64 / f32 / int64)
-        meta_ok = device.type == "cuda" and all(
-            p.cat_ids.dtype == torch.int64 and p.scores.dtype == torch.float32 and p.traj_durations.dtype == torch.int64
-            and p.cat_ids.device == device and p.scores.device == device and p.traj_durations.device == device
-            and p.cat_ids.is_contiguous() and p.scores.is_contiguous() and p.traj_durations.is_contiguous() for p in proposals)
+        def meta_usable(p, t):
+            key = (id(p.cat_ids), id(p.scores), id(p.traj_durations))
+            if t.get("meta_key") != key:                        # checked once per set of tensors (nine attribute reads per video otherwise)
+                t["meta_key"] = key
+                t["meta_ok"] = bool(p.cat_ids.dtype == torch.int64 and p.scores.dtype == torch.float32 and p.traj_durations.dtype == torch.int64
+                                    and p.cat_ids.device == device and p.scores.device == device and p.traj_durations.device == device
+                                    and p.cat_ids.is_contiguous() and p.scores.is_contiguous() and p.traj_durations.is_contiguous())
+                t["meta_ptr"] = (p.cat_ids.data_ptr(), p.scores.data_ptr(), p.traj_durations.data_ptr())
+            return t["meta_ok"]
+        meta_ok = device.type == "cuda" and all([meta_usable(p, t) for p, t in zip(proposals, tabs)])
 
         # every table in ONE host-to-device copy: [u64 feature addresses | u64 box addresses | u64 metadata addresses | int32 tables]
         any_ld = any(t["fld"] is not None for t in tabs)
         u64 = [np.concatenate([t["fptr"] for t in tabs]), np.concatenate([t["bptr"] for t in tabs])]
         if meta_ok:
-            u64 += [np.asarray([p.cat_ids.data_ptr() for p in proposals], dtype=np.uint64),
-                    np.asarray([p.scores.data_ptr() for p in proposals], dtype=np.uint64),
-                    np.asarray([p.traj_durations.data_ptr() for p in proposals], dtype=np.uint64)]
+            mp = np.asarray([t["meta_ptr"] for t in tabs], dtype=np.uint64)
+            u64 += [mp[:, 0], mp[:, 1], mp[:, 2]]
         tables = [np.concatenate([[0], np.cumsum(all_lens)]), np.concatenate([[0], np.cumsum(t_o[trk_vid])]), trk_vid,
                   self.vid_trk_off_host, tmax]
         if any_ld:

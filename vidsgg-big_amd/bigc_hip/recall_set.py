@@ -31,14 +31,14 @@ CONFIG_SMALL_O = dict(
 )
 
 
-def relational_set(cfg, seed0, n_videos, n_trajs=64, n_actors=4, marker=3.0, marker_width=None, feat_width=None):
+def relational_set(cfg, seed0, n_videos, n_trajs=64, n_actors=4, marker=3.0, marker_width=None, feat_width=None, label_noise=0.0, motion=False):
     """``n_videos`` (proposal, gt graph) pairs, seeds ``seed0 + v``, shaped by the model config ``cfg``"""
     width = feat_width if feat_width is not None else cfg["dim_feat"] + (cfg.get("dim_i3d", None) or 0) + \
         (cfg["dim_clsme"] if cfg.get("use_clsme", False) and cfg.get("EntiNameEmb_path", None) is None and "dim_i3d" not in cfg else 0)
     mw = marker_width if marker_width is not None else max(4, min(128, cfg["dim_feat"] // (2 * n_actors)))
     return [relational_video(seed0 + v, n_trajs=n_trajs, feat_width=width, num_enti_cats=cfg["num_enti_cats"],
                              num_pred_cats=cfg["num_pred_cats"], n_actors=n_actors, marker=marker, marker_width=mw,
-                             name="relational_%d" % (seed0 + v)) for v in range(n_videos)]
+                             name="relational_%d" % (seed0 + v), label_noise=label_noise, motion=motion) for v in range(n_videos)]
 
 
 def train(model, data, steps, batch=16, lr=1e-4, seed=0, log=None):

@@ -413,7 +413,7 @@ def synthetic_gt_graph(proposal, seed, n_gt_trajs=6, n_preds=5, num_pred_cats=13
 # --------------------------------------------------------------------------------------
 
 def relational_video(seed, n_trajs=64, feat_width=2048 + 832, num_enti_cats=36, num_pred_cats=133, n_actors=4, marker=3.0,
-                     marker_width=128, name=None):
+                     marker_width=128, name=None, label_noise=0.0, motion=False):
     """One synthetic video (SURVEY.md section 8d recipe) whose ground truth a model can LEARN, so that Recall@50 on held-out
     videos is far from zero after a few hundred training steps (with section 8d's random predicates every recall is 0 and a
     recall-parity gate compares 0 with 0).
@@ -422,11 +422,18 @@ def relational_video(seed, n_trajs=64, feat_width=2048 + 832, num_enti_cats=36, 
     ``[k * marker_width, (k + 1) * marker_width)`` of every one of its frames.  The ground truth is the ``n_actors *
     (n_actors - 1)`` ordered actor pairs (12 relations, as section 8d), predicate of (actor a, actor b) = ``1 + a * n_actors + b``,
     GT trajectories = the actors' own proposal boxes (vIoU = 1 when the model picks the pair), GT span = the overlap span.
+
+    Harder variants, so that a trained model's Recall@50 lands well inside (0, 1) and a change of arithmetic can move it:
+    ``motion``: every actor's boxes become a coherent left-to-right or right-to-left walk (a random direction bit per actor) and the
+    predicate also encodes whether subject and object walk the same way -- ``1 + a * n_actors + b + n_actors^2 * (dir_a != dir_b)`` --
+    which the model can only read off the BOX features (fc_bbox2enti, the 8 relative coordinates of models/model_0v10.py:401-420);
+    ``label_noise``: each ground-truth predicate is replaced by a random other class with this probability (irreducible error: a
+    perfect model's recall is about ``1 - label_noise``).
     -> (TrajProposal, VideoGraph)"""
     p = synthetic_proposal(seed, n_trajs=n_trajs, feat_width=feat_width, num_enti_cats=num_enti_cats, name=name)
     rs = np.random.RandomState(seed + 500009)
     duras = p.traj_durations.numpy()
-    assert n_actors * marker_width <= feat_width and 1 + n_actors * n_actors <= num_pred_cats
+    assert n_actors * marker_width <= feat_width and 1 + n_actors * n_actors * (2 if motion else 1) <= num_pred_cats
     # the frame most tracklets cover: all tracklets that cover it overlap pairwise
     cover = np.zeros(p.video_len + 1, dtype=np.int64)
     for s, e in duras:
@@ -438,6 +445,16 @@ def relational_video(seed, n_trajs=64, feat_width=2048 + 832, num_enti_cats=36, 
     rs.shuffle(actors)                                         # actor slot k is not tied to the score order
     for k, t in enumerate(actors):
         p.features_list[int(t)][:, k * marker_width:(k + 1) * marker_width] += marker
+    dirs = rs.randint(0, 2, size=n_actors) if motion else np.zeros(n_actors, dtype=np.int64)
+    if motion:
+        for k, t in enumerate(actors):
+            b = p.bboxes_list[int(t)]
+            L = b.shape[0]
+            x0 = float(rs.uniform(50, 250)) if dirs[k] == 0 else float(rs.uniform(850, 1050))
+            step = (1.0 if dirs[k] == 0 else -1.0) * float(rs.uniform(6, 12))
+            y0, w, h = float(rs.uniform(100, 500)), float(rs.uniform(40, 100)), float(rs.uniform(40, 100))
+            xs = x0 + step * torch.arange(L, dtype=torch.float32)
+            b[:, 0], b[:, 1], b[:, 2], b[:, 3] = xs, y0, xs + w, y0 + h
     pairs = [(a, b) for a in range(n_actors) for b in range(n_actors) if a != b]
     adj = np.zeros((2, len(pairs), n_actors), dtype=np.float32)
     spans, preds = [], []
@@ -446,7 +463,10 @@ def relational_video(seed, n_trajs=64, feat_width=2048 + 832, num_enti_cats=36, 
         adj[1, j, b] = 1.0
         da, db = duras[actors[a]], duras[actors[b]]
         spans.append([max(int(da[0]), int(db[0])), min(int(da[1]), int(db[1]))])
-        preds.append(1 + a * n_actors + b)
+        cls = 1 + a * n_actors + b + (n_actors * n_actors if (motion and dirs[a] != dirs[b]) else 0)
+        if label_noise > 0 and rs.uniform() < label_noise:
+            cls = 1 + (cls - 1 + int(rs.randint(1, num_pred_cats - 1))) % (num_pred_cats - 1)       # any OTHER class in [1, num_pred_cats)
+        preds.append(cls)
     g = VideoGraph(p.video_name, p.video_len, p.video_wh, p.cat_ids[actors].clone(), p.traj_durations[actors].clone(),
                    [p.bboxes_list[int(t)].clone() for t in actors], np.asarray(preds, dtype=np.int64), spans, adj)
     return p, g

@@ -1576,6 +1576,7 @@ int bigc_mha_core_hr8_launch(hipStream_t s, const float* q, int ldq, const float
     int* flag = hr8_dummy_flag();
     if (!flag) return 0;
     DropSpec drop = make_drop(0.f, 0, 0);
+    ProfScope ps((void*)s, FAM_MHA, 0.0, 0.0);
 #define LAUNCH_L16H(NW) hipLaunchKernelGGL((mha_core_lds16_kernel<NW, false>), dim3(n_seq * n_head), dim3(64 * NW), 0, s, q, ldq, k, ldk, v, ldv, (float*)nullptr, 0, q_off, n_head, scale, (float*)nullptr, drop, flag, run_id, (unsigned char*)os, ldos, range_flag)
     if (n_qt <= 2) LAUNCH_L16H(4); else LAUNCH_L16H(12);
 #undef LAUNCH_L16H
@@ -1592,6 +1593,7 @@ int bigc_role_fused_proj_hr8_launch(hipStream_t s, const float* p2a, int ldp, co
     const int run_id = g_hr8_run.fetch_add(1, std::memory_order_relaxed) + 1;
     int* flag = hr8_dummy_flag();
     if (!flag) return 0;
+    ProfScope ps((void*)s, FAM_ROLE_ATT, 0.0, 0.0);
     hipLaunchKernelGGL(role_fused_lds16_kernel, dim3(n_vid), dim3(768), 0, s, p2a, ldp, e2a, lde, rhs, ldrhs, att, (float*)nullptr, e_off, n_vid, nq, half, d,
                        scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, 0, (unsigned char*)vals_s, ldvs, range_flag);
     return 1;

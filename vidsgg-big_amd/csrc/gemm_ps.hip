@@ -54,7 +54,6 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TN = 256, TK = 32;
 constexpr int ROWB = 128;                                    // bytes of an LDS row: 32 k x (head, residual)
-constexpr int W_BYTES = TN * ROWB;
 constexpr float F16_LIMIT = 32768.0f;
 constexpr float ACT_SCALE = (float)(1 << PS_ACT_EXP), ACT_INV = 1.0f / ACT_SCALE;
 
@@ -138,6 +137,9 @@ struct PsArgs {
     const unsigned* whdr; int wbad_id;                // header of the split weight (bad id, max bits, 2^-Ew, 2^Ew)
     const float* bias; const float* res; long ldr;    // residual pitch in floats
     int res_period;                                   // > 0: the residual of output row m is row m % res_period of `res` (a table that repeats per sequence)
+    // LNM kernels: y = LayerNorm(act(A W^T + b) + res) * ln_g + ln_b (+ ln_add[m % ln_add_period]) over the N = 512 features of a row;
+    // C receives y (+ the added table), Cs the split form of y without the table
+    const float* ln_g; const float* ln_b; const float* ln_add; int ln_add_period; float ln_eps;
     float* C; long ldc;                               // f32 output (or null), pitch in floats
     unsigned char* Cs; long ldcs;                     // hr8 output (or null), pitch in bytes
     int M, N, K, act, tiles_m, tiles_n;
@@ -155,19 +157,27 @@ struct PsArgs {
 //   step: 256 x 2 tiles = two exact rounds of the 256 persistent workgroups);  4 -> TM = 256 rows, 2 LDS stages.
 //   FAST: reduced-precision mode (bigc_linear_set_fast): heads only, one MFMA per product; the residual chunks still travel
 //   with their rows (the format is the producers') but are not read from LDS.
-template <int AMODE, int RB, bool TRACE = false, bool FAST = false, bool BLOCKED = false>
+//   LNM: the tile spans ALL 512 output features (eight waves side by side, 64 features each, RB row blocks: TM = 32 RB rows), so that the
+//   epilogue can take a row's LayerNorm (models/model_0v10.py:188,211,223: norm1 / norm2 / norm3 of a decoder layer) before it stores:
+//   the f32 pre-norm tensor and the LayerNorm pass that read it disappear (one write + one read of (B Q, 512) f32 per LayerNorm).
+template <int AMODE, int RB, bool TRACE = false, bool FAST = false, bool BLOCKED = false, bool LNM = false>
 __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
-    constexpr int TM = 64 * RB;
-    constexpr int A_BYTES = TM * ROWB, STAGE_BYTES = A_BYTES + W_BYTES;
-    constexpr int NST = RB == 2 ? 3 : 2, D = NST - 1;         // LDS stages; slabs in flight beyond the one being read
-    constexpr int NL = RB;                                    // mode 2: f32x4 loads per thread and slab
+    static_assert(!LNM || (AMODE == 0 && (RB == 2 || RB == 3) && !BLOCKED && !TRACE), "LayerNorm epilogue: plain hr8 operand, 64- or 96-row tiles");
+    constexpr int TNK = LNM ? 512 : TN;                       // output features per tile
+    constexpr int NWF = TNK / 64, NWR = 8 / NWF;              // waves side by side over the features / stacked over the rows
+    constexpr int TM = 32 * RB * NWR;
+    constexpr int WB = TNK * ROWB;
+    constexpr int A_BYTES = TM * ROWB, STAGE_BYTES = A_BYTES + WB;
+    constexpr int NST = (RB == 2 && !LNM) ? 3 : 2, D = NST - 1;   // LDS stages; slabs in flight beyond the one being read
+    constexpr int NL = RB * NWR / 2;                          // mode 2: f32x4 loads per thread and slab
     constexpr int MAXSEG = 4;                                 // mode 1: K segments (gathered row tables) supported
     constexpr int IDX_OFF = NST * STAGE_BYTES;                // mode 1: behind the stages, a lane-private table of source rows (below)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES + (AMODE == 1 ? RB * MAXSEG * 2048 : 0)];
+    constexpr int LN_OFF = NST * STAGE_BYTES;                 // LNM: behind the stages, per row and wave the partial sums of the two LayerNorm passes
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES + (AMODE == 1 ? RB * MAXSEG * 2048 : 0) + (LNM ? 2 * TM * 8 * 4 : 0)];
     AS3 unsigned char* lds = (AS3 unsigned char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wf = wave & 3, wr = wave >> 2, hi = lane >> 5, l31 = lane & 31;
+    const int wf = wave % NWF, wr = wave / NWF, hi = lane >> 5, l31 = lane & 31;
     const int nk = p.K / TK;
 
     // ---- tile order.  Workgroup b runs on XCD b % 8 (observed placement; a speed matter only): the workgroups of an XCD take
@@ -190,8 +200,9 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     const int sw_src = (((wave & 1) << 2) + (lane >> 4)) & 7;             // ((8 blk + (l >> 3)) >> 1) & 7, same for blk and blk + 8 i
     const int coff = ((lane & 7) ^ sw_src) << 4;
     const int l8 = lane >> 3;
-    constexpr int NA = RB;                                                // A pieces per wave and slab (row blocks w + 8 i)
-    constexpr int NW = 4;                                                 // W pieces per wave and slab
+    constexpr int NBLK_A = TM / 8;                                        // 8-row blocks of an A slab
+    constexpr int NA = (NBLK_A + 7) / 8;                                  // A pieces per wave and slab (row blocks w + 8 i; LNM with 96 rows: 12 blocks, waves 4..7 skip their second)
+    constexpr int NW = NWF;                                               // W pieces per wave and slab
     constexpr int NPCL = (AMODE == 2 ? 0 : NA) + NW;                      // DMA pieces per wave and slab
     // issue-side state (runs ahead of the compute side)
     int ij = 0, ikt = 0;
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     }
     auto issue_tile_setup = [&]() {
         const int L = tile_of(ij), tm = L / p.tiles_n, tn = L - tm * p.tiles_n;
-        const int m0 = tm * TM, n0 = tn * TN;
+        const int m0 = tm * TM, n0 = tn * TNK;
         ia_base = p.A + (size_t)m0 * p.lda;
         iw_base = p.Ws + (size_t)n0 * p.ldw;
         a_lim = p.M - 1 - m0;
@@ -245,6 +256,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     };
     auto issue_a_piece = [&](int i, int so) {
         const int blk = wave + 8 * i;
+        if (NBLK_A % 8 != 0 && blk >= NBLK_A) return;
         if (AMODE == 1) {
             const int gi = *(const AS3 int*)(lds + IDX_OFF + ((i * MAXSEG + isg) * 512 + tid) * 4);
             const unsigned char* src = (gi >= 0 ? p.A + (size_t)gi * p.lda : p.zero_row) + coff + ichunk * ROWB;    // index -1: a row of zeros
@@ -383,7 +395,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     const float osc = ((const float*)p.whdr)[2] * ACT_INV;                  // 2^-(Ew + Ea)
     auto epilogue = [&](int j) {
         const int L = tile_of(j), tm = L / p.tiles_n, tn = L - tm * p.tiles_n;
-        const int m0 = tm * TM, n0 = tn * TN;
+        const int m0 = tm * TM, n0 = tn * TNK;
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi) {
             f32x4 bv[4];
@@ -434,6 +446,121 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                         const auto sx = __builtin_amdgcn_permlane32_swap(h0, r0, false, false);
                         const auto sy = __builtin_amdgcn_permlane32_swap(h1, r1, false, false);
                         if (ok) *(u32x4*)(p.Cs + (size_t)m * p.ldcs + (size_t)((nb + 8 * g) >> 3) * 32 + hi * 16) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- LNM epilogue: the tile holds whole rows (512 features over the eight waves).  Pass 0 turns the accumulators into the pre-norm values
+    // (bias, activation, residual) IN PLACE and sums each row; pass 1 sums the squared deviations (two passes, as torch's LayerNorm: no
+    // E[x^2] - mean^2 cancellation); pass 2 normalises and stores.  Row sums: registers -> the two half-waves (one shuffle) -> the eight
+    // waves (LDS, 8 floats per row, one barrier per pass).  Every wave of the workgroup reaches both barriers (rows past M compute garbage
+    // that is never stored).
+    auto epilogue_ln = [&](int j) {
+        const int m0 = tile_of(j) * TM;
+        AS3 float* red = (AS3 float*)(lds + LN_OFF);
+        float s1[RB], mean[RB], rstd[RB];
+#pragma unroll
+        for (int ri = 0; ri < RB; ++ri) s1[ri] = 0.f;
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {
+            const int nb = wf * 64 + fi * 32 + 4 * hi;
+            f32x4 bv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[g] = *(const f32x4*)(p.bias + nb + 8 * g);
+#pragma unroll
+            for (int ri = 0; ri < RB; ++ri) {
+                const int mc = min(m0 + ri * 32 + l31, p.M - 1);
+                f32x4 rv[4];
+                if (p.res) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rv[g] = *(const f32x4*)(p.res + (size_t)(p.res_period > 0 ? mc % p.res_period : mc) * p.ldr + nb + 8 * g);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float t = acc[fi][ri][4 * g + c] * osc + bv[g][c];
+                        t = fmaxf(t, lo);
+                        if (sigm) t = 1.0f / (1.0f + expf(-t));
+                        t += rv[g][c];
+                        acc[fi][ri][4 * g + c] = t;
+                        s1[ri] += t;
+                    }
+            }
+        }
+#pragma unroll
+        for (int ri = 0; ri < RB; ++ri) {
+            s1[ri] += __shfl_xor(s1[ri], 32);
+            if (hi == 0) red[(ri * 32 + l31) * 8 + wf] = s1[ri];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int ri = 0; ri < RB; ++ri) {
+            const f32x4 a = *(const AS3 f32x4*)(red + (ri * 32 + l31) * 8), b = *(const AS3 f32x4*)(red + (ri * 32 + l31) * 8 + 4);
+            mean[ri] = (((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]))) * (1.0f / (float)TNK);
+            float q = 0.f;
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float d = acc[fi][ri][r] - mean[ri]; q += d * d; }
+            q += __shfl_xor(q, 32);
+            if (hi == 0) red[TM * 8 + (ri * 32 + l31) * 8 + wf] = q;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int ri = 0; ri < RB; ++ri) {
+            const f32x4 a = *(const AS3 f32x4*)(red + TM * 8 + (ri * 32 + l31) * 8), b = *(const AS3 f32x4*)(red + TM * 8 + (ri * 32 + l31) * 8 + 4);
+            const float var = (((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]))) * (1.0f / (float)TNK);
+            rstd[ri] = 1.0f / sqrtf(var + p.ln_eps);
+        }
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {
+            const int nb = wf * 64 + fi * 32 + 4 * hi;
+            f32x4 gv[4], ev[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { gv[g] = *(const f32x4*)(p.ln_g + nb + 8 * g); ev[g] = *(const f32x4*)(p.ln_b + nb + 8 * g); }
+#pragma unroll
+            for (int ri = 0; ri < RB; ++ri) {
+                const int m = m0 + ri * 32 + l31;
+                const bool mok = m < p.M;
+                const int mc = min(m, p.M - 1);
+                f32x4 y[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) y[g][c] = (acc[fi][ri][4 * g + c] - mean[ri]) * rstd[ri] * gv[g][c] + ev[g][c];
+                if (p.C) {
+                    if (p.ln_add) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 ad = *(const f32x4*)(p.ln_add + (size_t)(mc % p.ln_add_period) * TNK + nb + 8 * g);
+                            if (mok) *(f32x4*)(p.C + (size_t)m * p.ldc + nb + 8 * g) = y[g] + ad;
+                        }
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (mok) *(f32x4*)(p.C + (size_t)m * p.ldc + nb + 8 * g) = y[g];
+                    }
+                }
+                if (p.Cs) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 x = y[g] * ACT_SCALE;
+                        unsigned h0, h1, r0, r1;
+                        split2(x[0], x[1], h0, r0);
+                        split2(x[2], x[3], h1, r1);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) oob |= mok && !(fabsf(x[c]) < F16_LIMIT);
+                        const auto sx = __builtin_amdgcn_permlane32_swap(h0, r0, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(h1, r1, false, false);
+                        if (mok) *(u32x4*)(p.Cs + (size_t)m * p.ldcs + (size_t)((nb + 8 * g) >> 3) * 32 + hi * 16) = u32x4{sx[0], sy[0], sx[1], sy[1]};
                     }
                 }
             }
@@ -552,7 +679,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         so[NST - 1] = t;
         if (++ckt == nk) {
             fold_block();
-            epilogue(cj);
+            if constexpr (LNM) epilogue_ln(cj); else epilogue(cj);
             zero_acc();
             ckt = 0; ++cj;
         } else if (BLOCKED && p.blk > 0 && (ckt & (p.blk - 1)) == 0) {
@@ -647,7 +774,13 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     p.seg_bytes = (g.K / p.nseg) * 4;
     p.bias = g.bias; p.res = g.res; p.ldr = g.ldr; p.res_period = g.res ? g.res_period : 0; p.C = g.C; p.ldc = g.ldc; p.Cs = (unsigned char*)g.Cs; p.ldcs = g.ldcs;
     p.M = g.M; p.N = g.N; p.K = g.K; p.act = g.act;
-    p.tiles_n = cdiv(g.N, TN);
+    const bool lnm = g.ln_g != nullptr;
+    if (lnm) {
+        BIGC_CHECK_ARG(g.N == 512 && g.a_fmt == PS_HR8 && !g.a_idx && g.ln_b && ((uintptr_t)g.ln_g & 15) == 0 && ((uintptr_t)g.ln_b & 15) == 0 &&
+                       (!g.ln_add || (g.ln_add_period > 0 && ((uintptr_t)g.ln_add & 15) == 0)), "gemm_ps: the LayerNorm epilogue needs N = 512, a plain hr8 operand, aligned gamma / beta");
+    }
+    p.ln_g = g.ln_g; p.ln_b = g.ln_b; p.ln_add = g.ln_add; p.ln_add_period = g.ln_add_period; p.ln_eps = g.ln_eps;
+    p.tiles_n = lnm ? 1 : cdiv(g.N, TN);
     // 256-row tiles when they still give every CU at least three tiles (else the 128-row tiles fill the chip better)
     static const int force_rb = getenv("BIGC_PS_RB") ? atoi(getenv("BIGC_PS_RB")) : 0;
     static const bool want_blk = getenv("BIGC_PS_BLK") && atoi(getenv("BIGC_PS_BLK")) > 0;
@@ -656,7 +789,8 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     // M = 49 152 (decoder, 256 videos) x N = 512: 384 tiles of 256 rows = 2 rounds x 4, 512 of 192 = 2 x 3 (exact), 768 of 128 = 3 x 2.
     // The result does not depend on the choice (one accumulator per element, the same K order in every tiling).
     int rb = 2;
-    if (want_blk && g.a_fmt == PS_HR8) rb = 2;
+    if (lnm) rb = 2;                                   // 64-row tiles spanning all 512 features (96-row tiles spill in the K loop: measured 19.7 vs 17.2 ms family time)
+    else if (want_blk && g.a_fmt == PS_HR8) rb = 2;
     else if (force_rb) rb = force_rb;
     else {
         static const bool rb3_off = getenv("BIGC_PS_RB3") && atoi(getenv("BIGC_PS_RB3")) == 0;
@@ -670,11 +804,11 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
             if (best == 0.0 || cost < best * 0.999) { best = cost; rb = cand[i]; }
         }
     }
-    p.tiles_m = cdiv(g.M, 64 * rb);
+    p.tiles_m = lnm ? cdiv(g.M, 32 * rb) : cdiv(g.M, 64 * rb);
     p.range_flag = g.range_flag;
     // opt-in blocked accumulation (BIGC_PS_BLK = K slabs per block, a power of two): 128-row tiles, plain / gathered hr8 operand
     static const int force_blk = getenv("BIGC_PS_BLK") ? atoi(getenv("BIGC_PS_BLK")) : 0;
-    p.blk = (force_blk > 0 && !(force_blk & (force_blk - 1)) && g.a_fmt == PS_HR8 && !bigc_linear_get_fast()) ? force_blk : 0;
+    p.blk = (force_blk > 0 && !(force_blk & (force_blk - 1)) && g.a_fmt == PS_HR8 && !bigc_linear_get_fast() && !lnm) ? force_blk : 0;
     static const int ablate = getenv("BIGC_PS_ABLATE") ? atoi(getenv("BIGC_PS_ABLATE")) : 0;
     p.ablate = ablate;
     static const int trace = getenv("BIGC_PS_TRACE") ? atoi(getenv("BIGC_PS_TRACE")) : 0;
@@ -710,13 +844,16 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
         if (!p.bias) p.bias = (const float*)g_zero_row;
     }
     const double flops = 2.0 * g.M * (double)g.N * g.K;
-    const double bytes = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * ((g.res ? 1 : 0) + (g.C ? 1 : 0) + (g.Cs ? 1 : 0)));
+    const double bytes = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * ((g.res && g.res_period <= 0 ? 1 : 0) + (g.C ? 1 : 0) + (g.Cs ? 1 : 0)));
     ProfScope ps((void*)s, FAM_LINEAR, flops, bytes);
     // persistent workgroups: one per CU (a multiple of 8 for the XCD-aware tile order), fewer when there are fewer tiles
     const int n_tiles = p.tiles_m * p.tiles_n;
     const int grid = n_tiles >= n_cu ? n_cu : cdiv(n_tiles, 8) * 8;
 #define PS_LAUNCH(MODE, RBV) hipLaunchKernelGGL((gemm_ps_kernel<MODE, RBV>), dim3(grid), dim3(512), 0, s, p)
-    if (trace && g.a_fmt == PS_HR8 && !g.a_idx) {
+    if (lnm) {
+        if (bigc_linear_get_fast()) hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, true, false, true>), dim3(grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+    } else if (trace && g.a_fmt == PS_HR8 && !g.a_idx) {
         static unsigned long long* buf = nullptr;
         if (!buf && hipMalloc((void**)&buf, 8 * 5 * 8 * 4096) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "gemm_ps: trace buffer");
         p.trace = buf;
@@ -774,6 +911,19 @@ extern "C" int bigc_gemm_ps(void* stream, const void* A, long lda_bytes, int a_f
     g.A = A; g.lda = lda_bytes; g.a_fmt = a_fmt ? PS_HR8 : PS_F32; g.a_idx = a_idx; g.nseg = a_idx ? nseg : 1; g.W = W; g.ldw = ldw;
     g.bias = bias; g.res = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Cs = Cs; g.ldcs = ldcs_bytes; g.M = M; g.N = N; g.K = K; g.act = act;
     g.range_flag = range_flag;
+    return bigc_gemm_ps_launch((hipStream_t)stream, g);
+}
+
+// LayerNorm(act(A W^T + bias) + residual) * gamma + beta (+ add[m % add_period]) in one launch (N = 512; A in the split form)
+extern "C" int bigc_gemm_ps_ln(void* stream, const void* A, long lda_bytes, const float* W, int ldw, const float* bias, const float* residual, long ldr,
+                               const float* gamma, const float* beta, float eps, const float* add, int add_period, float* C, long ldc, void* Cs,
+                               long ldcs_bytes, int M, int N, int K, int act, int* range_flag) {
+    BIGC_CHECK_ARG(A && W && gamma && beta && (C || Cs), "gemm_ps_ln: null pointer");
+    if (M == 0) return BIGC_OK;
+    PsGemm g;
+    g.A = A; g.lda = lda_bytes; g.a_fmt = PS_HR8; g.W = W; g.ldw = ldw; g.bias = bias; g.res = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Cs = Cs;
+    g.ldcs = ldcs_bytes; g.M = M; g.N = N; g.K = K; g.act = act; g.range_flag = range_flag;
+    g.ln_g = gamma; g.ln_b = beta; g.ln_eps = eps; g.ln_add = add; g.ln_add_period = add_period;
     return bigc_gemm_ps_launch((hipStream_t)stream, g);
 }
 

@@ -111,6 +111,8 @@ struct PsGemm {
     void* Cs = nullptr; long ldcs = 0;                               // pitch in BYTES
     int M = 0, N = 0, K = 0, act = 0;
     int* range_flag = nullptr;                                       // set to 1 when a split operand left the f16 range
+    // LayerNorm epilogue (N = 512, hr8 operand): y = LN(act(A W^T + b) + res) * ln_g + ln_b; C = y (+ ln_add[m % ln_add_period]), Cs = split(y)
+    const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 1e-5f; const float* ln_add = nullptr; int ln_add_period = 0;
 };
 bool bigc_gemm_ps_supported(const PsGemm& g);
 int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g);

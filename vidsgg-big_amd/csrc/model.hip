@@ -359,6 +359,17 @@ int ps(const PsCtx& c, const void* A, long lda, bool a_hr8, const Lin& l, int ld
     return bigc_gemm_ps_launch(c.s, g);
 }
 
+// C = LayerNorm(A W^T + b + res) g + beta (+ add[m % period]); Cs = the split twin of the normalised rows: the GEMM takes the row's LayerNorm in
+// its epilogue (gemm_ps.hip, N = 512).  A is in the split form.
+int ps_ln(const PsCtx& c, const void* A, long lda, const Lin& l, int ldw, float* C, long ldc, void* Cs, long ldcs, int M, int N, int K, const float* res, long ldr,
+          const LNp& n, float eps, const float* add = nullptr, int add_period = 0) {
+    PsGemm g;
+    g.A = A; g.lda = lda * 4; g.a_fmt = PS_HR8; g.W = l.w; g.ldw = ldw; g.bias = l.b; g.res = res; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Cs = Cs; g.ldcs = ldcs * 4;
+    g.M = M; g.N = N; g.K = K; g.act = BIGC_ACT_NONE; g.range_flag = c.flag;
+    g.ln_g = n.g; g.ln_b = n.b; g.ln_eps = eps; g.ln_add = add; g.ln_add_period = add_period;
+    return bigc_gemm_ps_launch(c.s, g);
+}
+
 bool ps_config_ok(const bigc_config& c) {
     // every GEMM of the path: K a multiple of 32, N a multiple of 8 (the logits GEMM, N = num_pred_cats, stays on linear_split)
     const int dims[] = {c.dim_enti, c.dim_pred, c.dim_att, c.dim_ffn, c.dim_feat};
@@ -679,6 +690,13 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         const bool presplit_off = presplit_env == 0;
         const bool presplit = chained && !presplit_off && fused && Q <= 192 && da / 2 <= 256 && (da / 2) % 128 == 0 && dp % 32 == 0 && dp <= de &&
                               dp / H == 64 && (dp == 512 || dp == 256 || dp == 128 || dp == 64) && df % 32 == 0;
+        // the three LayerNorms of the layer as epilogues of the GEMMs in front of them (dim_pred = 512: the tile spans the whole row); BIGC_LN_FUSED=0: separate passes
+        // OPT-IN (BIGC_LN_FUSED=1): measured on the 256-video step, the LayerNorm passes disappear (0.87 -> 0.07 ms) but the 64-row x 512-feature
+        // tiles the epilogue needs run the GEMMs LDS-bound (+0.63 ms over the 17 launches; 96-row tiles spill): 19.06 -> 18.86 ms resident,
+        // no gain through the API within the run-to-run noise.  Kept for the traffic it removes (3.4 GB per step) and as the starting point of a
+        // kernel that feeds W from registers instead of LDS.
+        static const bool ln_fused_on = getenv("BIGC_LN_FUSED") && atoi(getenv("BIGC_LN_FUSED")) != 0;
+        const bool ln_fused = presplit && ln_fused_on && dp == 512 && df % 32 == 0;
         if (presplit && i > 0) {
             TRY(build_qkpos(m, s));
             // w.querys = the split twin of w.query, written by the previous layer's last LayerNorm
@@ -686,8 +704,14 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
                    m->qkpos + (size_t)Q * 3 * dp * i, 3 * dp, nullptr, 1, Q));
             if (!bigc_mha_core_hr8_launch(hs, w.qk, 3 * dp, w.qk + dp, 3 * dp, w.qk + 2 * dp, 3 * dp, w.ao2, (long)dp * 4, w.q_off, B, Q, H, dp / H, w.flag))
                 return bigc_fail(BIGC_ERR_ARG, "forward: self-attention shape outside the split-output kernel");
-            TRY(ps(cx, w.ao2, dp, true, L.out_proj, dp, w.t2, dp, nullptr, 0, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
-            TRY(bigc_layernorm_add_f32(s, w.t2, L.n1.g, L.n1.b, w.query, BQ, dp, eps, m->pos, Q, nullptr));   // query += pos, kept (:189)
+            if (ln_fused) {
+                // out_proj, + query, norm1, + pos (:187-189) in ONE launch: the row's LayerNorm is the GEMM's epilogue (query is read as the
+                // residual and overwritten by the lane that read it)
+                TRY(ps_ln(cx, w.ao2, dp, L.out_proj, dp, w.query, dp, nullptr, 0, BQ, dp, dp, w.query, dp, L.n1, eps, m->pos, Q));
+            } else {
+                TRY(ps(cx, w.ao2, dp, true, L.out_proj, dp, w.t2, dp, nullptr, 0, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
+                TRY(bigc_layernorm_add_f32(s, w.t2, L.n1.g, L.n1.b, w.query, BQ, dp, eps, m->pos, Q, nullptr));   // query += pos, kept (:189)
+            }
         } else {
         // layers > 0: qk_in = query + pos was written by the previous layer's last LayerNorm
         if (i == 0) TRY(bigc_add_rows_f32(s, qin, m->pos, w.qk_in, rows, dp, Q));
@@ -714,6 +738,13 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
                 return bigc_fail(BIGC_ERR_ARG, "forward: role-attention shape outside the split-output kernel");
             const float* wc = m->role_cat + ((size_t)dp * 2 * dp + dp) * i;
             Lin rc{wc, wc + (size_t)dp * 2 * dp};
+            if (ln_fused) {
+                // (:209-211) query + role0.2(.) + role1.2(.), norm2 -> t2 and its split twin; (:218-223) fc2, + t2, norm3 -> query and its twin
+                TRY(ps_ln(cx, w.vals, 2 * dp, rc, 2 * dp, w.t2, dp, w.qkins, dp, BQ, dp, 2 * dp, w.query, dp, L.n2, eps));
+                TRY(ps(cx, w.qkins, dp, true, L.f0, dp, nullptr, 0, w.rh, df, BQ, df, dp, BIGC_ACT_RELU));
+                TRY(ps_ln(cx, w.rh, df, L.f3, df, w.query, dp, last ? nullptr : w.querys, dp, BQ, dp, df, w.t2, dp, L.n3, eps));
+                continue;
+            }
             TRY(ps(cx, w.vals, 2 * dp, true, rc, 2 * dp, w.t3, dp, nullptr, 0, BQ, dp, 2 * dp, BIGC_ACT_NONE, w.query, dp));
             TRY(bigc_layernorm_hr8(hs, w.t3, L.n2.g, L.n2.b, w.t2, w.qkins, (long)dp * 4, BQ, dp, eps, w.flag));           // t2 and its split twin
             TRY(ps(cx, w.qkins, dp, true, L.f0, dp, nullptr, 0, w.rh, df, BQ, df, dp, BIGC_ACT_RELU));

@@ -976,8 +976,8 @@ def main():
                                   "attention arg-max (subject, object) agrees, relative to max |logit| of the video; the benchmark model's sharp "
                                   "attention amplifies f32 round-off, so where two f32 evaluations differ by more than 1e-4 a float64 evaluation of "
                                   "the oracle is the truth, and a video on which HIP is more than 1e-4 from it is held against its own float32 noise floor: 4 x the rms "
-                                  "error of f32 evaluations of that video with inputs perturbed by one rounding, x 2 for the measured rounding-error ratio "
-                                  "of the HIP front-end GEMMs to the CPU GEMM (oracle/accuracy.py; per-stage evidence in "
+                                  "error of f32 evaluations of that video with inputs perturbed by one rounding, x 1.5 for the measured rounding-error ratio "
+                                  "of the HIP one-accumulator GEMMs to the CPU GEMM, capped at 3e-4 (oracle/accuracy.py; per-stage evidence in "
                                   "benchmarks/accuracy_layers.py / accuracy_mixed.py, DESIGN.md section 4)")
     del ref_out
     legs = {}

@@ -14,14 +14,21 @@ So a video whose HIP logits are more than 1e-4 from the f32 oracle's is arbitrat
      rounding (features and boxes multiplied by 1 + U(-2^-24, 2^-24) and rounded to f32) -- each a different realisation of the
      round-off of an f32 evaluation -- gives a sample of f32-level errors against the same float64 truth.
 
-The HIP path passes on that video if ``err_hip <= max(1e-4, 4 x NOISE_RATIO x rms(sample))``: it is within 1e-4 of the truth, or
-indistinguishable from an f32 evaluation of that video whose GEMMs round NOISE_RATIO = 2 times as coarsely as MKL's.  That factor is
-measured, not assumed (benchmarks/probes/gemm_error_stats.py, rms error in units of 2^-24 of rms(C)): torch's CPU GEMM 4.3 / 2.9 /
-3.2 at K = 2048 / 512 / 3072, the HIP two-accumulator kernel (linear_split.hip) 5.0 / 2.8 / 6.0, the HIP one-accumulator kernel on
-pre-split operands (gemm_ps.hip, the front-end GEMMs) 8.5 / 4.4 / 10.3 -- every MFMA rounds the accumulator once and that kernel
-issues three per k16 step into one accumulator; the blocked variant that removes the difference (2.9 / 2.3 / 3.0) does not fit the
-256-row tile's registers.  A defect of the HIP arithmetic (a stage less accurate than that) would put many
-videos outside their noise floor; an outlier of chance does not.
+The HIP path passes on that video if ``err_hip <= min(CAP, max(1e-4, 4 x NOISE_RATIO x rms(sample)))``: it is within 1e-4 of the truth,
+or indistinguishable from an f32 evaluation of that video whose GEMMs round NOISE_RATIO times as coarsely as MKL's -- and in no case
+more than CAP = 3e-4 away.  The factor is measured, not assumed (benchmarks/probes/gemm_error_stats.py, rms error in units of 2^-24
+of rms(C)): torch's CPU GEMM 4.3 / 2.9 / 3.2 at K = 2048 / 512 / 3072, the HIP two-accumulator kernel (linear_split.hip) 5.0 / 2.8 /
+6.0, the HIP one-accumulator kernel on pre-split operands (gemm_ps.hip) 8.5 / 4.4 / 10.3 -- every MFMA rounds the accumulator once
+and that kernel issues three per k16 step into one accumulator.
+
+Round 4: NOISE_RATIO 2.0 -> 1.5 and the cap.  ``forward(proposal_list)`` -- the timed path -- reads the features in place and runs the
+K = 2048 GEMM (the largest) on the TWO-accumulator kernel again (1.16 x MKL instead of 2 x); what still rounds coarser than MKL is the
+gathered conv GEMM (K = 3072, one accumulator: 3.2 x) and the K = 512 GEMMs on pre-split operands (1.5 x).  Measured over the 256
+benchmark videos (profiles/r04c_bench_n1.json.log): ONE video more than 1e-4 from float64 (1.59e-4, against a noise floor of 3.7e-5 rms
+and an f32 oracle at 5.8e-5; round 3: three, up to 2.12e-4), none above 2e-4, ONE on which HIP is the farther of the two f32
+evaluations (round 3: two).  At NOISE_RATIO = 1.0 that one video (bound 1.48e-4) would fail by 7 %: the remaining factor is the conv
+GEMM's single accumulator, which is what 1.5 stands for.  A defect of the HIP arithmetic (a stage less accurate than that) would put
+many videos outside their noise floor; an outlier of chance does not.
 """
 import copy
 
@@ -32,7 +39,8 @@ from . import bigc_oracle as O
 
 BOUND = 1e-4
 SIGMAS = 4.0
-NOISE_RATIO = 2.0      # rms rounding error of the HIP GEMMs relative to the CPU GEMM's on the front-end shapes (measured, see above)
+NOISE_RATIO = 1.5      # rms rounding error of the HIP GEMMs relative to the CPU GEMM's on the front-end shapes (measured, see above)
+CAP = 3e-4             # no video may be farther than this from float64, whatever its noise floor
 
 
 def to_f64(sd, p):
@@ -88,6 +96,6 @@ def arbitrate(sd, cfg, p, hip_logits, ref_logits, variant="vidvrd", sd64=None, r
         return out
     sample = f32_noise_floor(sd, cfg, p, ref64, variant, n=n, rows=rows) + [err_ref]
     rms = float(np.sqrt(np.mean(np.square(sample))))
-    bound = max(BOUND, SIGMAS * NOISE_RATIO * rms)
+    bound = min(CAP, max(BOUND, SIGMAS * NOISE_RATIO * rms))
     out.update(f32_noise_floor_sample=sample, f32_noise_floor_rms=rms, bound=bound, passed=bool(err_hip <= bound))
     return out

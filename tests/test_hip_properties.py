@@ -201,8 +201,8 @@ def test_benchmark_videos_vs_oracle_row_for_row():
 
     PER VIDEO: the HIP logits are within 1e-4 of the f32 oracle's; where they are not, a float64 evaluation of the oracle is the
     truth and the video passes if HIP is within 1e-4 of it -- or within the video's own float32 noise floor (oracle/accuracy.py:
-    4 x the rms error of f32 evaluations of that video with inputs perturbed by one rounding, x 2 for the measured
-    rounding-error ratio of the HIP front-end GEMMs to MKL's).  The benchmark model's attention is
+    4 x the rms error of f32 evaluations of that video with inputs perturbed by one rounding, x 1.5 for the measured
+    rounding-error ratio of the HIP one-accumulator GEMMs to MKL's, capped at 3e-4).  The benchmark model's attention is
     sharp by construction (scores of magnitude ~50): on a few videos a rounding error of 5e-7 in the encoder output moves the logits
     by 1e-4, for the f32 oracle (video 29: 2.1e-4 from float64 on 16 threads, 1.3e-4 on 8) as for the HIP path (video 28: 1.2e-4);
     benchmarks/accuracy_layers.py shows the per-layer error of the two to be equal and the difference to be amplification.
@@ -217,7 +217,8 @@ def test_benchmark_videos_vs_oracle_row_for_row():
     width = cfg["dim_feat"] + cfg["dim_i3d"]
     Q, P = cfg["num_querys"], cfg["num_pred_cats"]
     host = [synthetic_proposal(1234 + v, n_trajs=64, feat_width=width, num_enti_cats=cfg["num_enti_cats"]) for v in range(n_vid)]
-    packed = PackedBatch([synthetic_proposal(1234 + v, n_trajs=64, feat_width=width, num_enti_cats=cfg["num_enti_cats"]) for v in range(n_vid)], DEV)
+    # packed as model(proposal_list) packs: nothing gathered yet, the forward reads the feature rows in place (the timed path of bench.py)
+    packed = PackedBatch([synthetic_proposal(1234 + v, n_trajs=64, feat_width=width, num_enti_cats=cfg["num_enti_cats"]).to(DEV) for v in range(n_vid)], DEV, "lazy")
     out = model.forward_packed(packed, 10)
     res = model.unpack_results(n_vid, list(range(n_vid)), out)
     logits = out["pred_logits"].cpu().numpy().reshape(n_vid, Q, P)
@@ -247,5 +248,6 @@ def test_benchmark_videos_vs_oracle_row_for_row():
             assert np.array_equal(got[2], want[2].numpy()) and np.array_equal(got[3], want[3].numpy())
             assert np.abs(got[1] - want[1].numpy()).max() <= 2e-4      # softmax probability of logits that agree to 1e-4 of max |logit|
             rows += want[0].shape[0]
-    assert rows > 32 * 50 and len(arbitrated) <= 3, arbitrated
+    assert rows > 32 * 50 and len(arbitrated) <= 2, arbitrated          # (round 3: <= 3; the K = 2048 GEMM is back on two accumulators)
+    assert sum(1 for _, a in arbitrated if a["hip_vs_f64"] > 1e-4) <= 1 and all(a["hip_vs_f64"] <= 2e-4 for _, a in arbitrated), arbitrated
     assert np.mean(e_hips) <= 1.5 * np.mean(e_refs), "mean distance to float64: hip %.2e, f32 oracle %.2e" % (np.mean(e_hips), np.mean(e_refs))

@@ -1610,8 +1610,10 @@ int bigc_mha_core_hd16_lds_launch(hipStream_t s, const float* q, int ldq, const 
     // waves per workgroup by the longest sequence (the arithmetic of a sequence does not depend on it: wave w takes the query tiles
     // w, w + NW, ...): one wave for sequences of at most 32 rows (the query encoder's 3 tokens: 8784 workgroups of four waves, three
     // of them idle, took 203 us), two up to 64, four up to 128, eight above
-#define LAUNCH_HD16(NWV) do { static bool attr = false; \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)mha_core_hd16_lds_kernel<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; } \
+#define LAUNCH_HD16(NWV) do { static std::atomic<unsigned long long> attr{0}; int dev_ = 0; (void)hipGetDevice(&dev_);      /* one bit per device */ \
+        if (!((attr.load(std::memory_order_relaxed) >> (dev_ & 63)) & 1ull)) { \
+            (void)hipFuncSetAttribute((const void*)mha_core_hd16_lds_kernel<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+            attr.fetch_or(1ull << (dev_ & 63), std::memory_order_relaxed); } \
         hipLaunchKernelGGL(mha_core_hd16_lds_kernel<NWV>, dim3(n_seq * n_head), dim3(64 * NWV), lds, s, q, ldq, k, ldk, v, ldv, o, ldo, off, n_head, scale, tp, flag, run_id); } while (0)
     if (max_q <= 32) LAUNCH_HD16(1);
     else if (max_q <= 64) LAUNCH_HD16(2);

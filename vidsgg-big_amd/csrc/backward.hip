@@ -7,6 +7,7 @@
 // stretched-conv gather-sum, head scatter, periodic reduction for the shared query/pos embeddings).
 #include "common.h"
 #include "prof.h"
+#include <unordered_map>
 #include <stdlib.h>
 #include <string.h>
 
@@ -701,6 +702,24 @@ extern "C" int bigc_transpose_f32(void* stream, const float* in, float* out, int
     return BIGC_OK;
 }
 
+// Split-K scratch of the weight-gradient kernels: one buffer per (calling thread, device, slot), grown on demand after a sync of the
+// calling stream.  (the buffers used to be function-static -- two threads driving two devices, which the per-handle
+// arithmetic modes explicitly allow, would have shared one pointer and raced on the regrow.)
+static int dw_scratch(void* stream, size_t need_floats, int slot, float** out) {
+    struct Buf { float* p = nullptr; size_t cap = 0; };
+    thread_local std::unordered_map<int, Buf> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_dw: hipGetDevice failed");
+    Buf& b = bufs[dev * 2 + slot];
+    if (need_floats > b.cap) {
+        if (b.p) { if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_dw: sync failed"); (void)hipFree(b.p); }
+        b.cap = need_floats + need_floats / 2;
+        if (hipMalloc((void**)&b.p, b.cap * sizeof(float)) != hipSuccess) { b.p = nullptr; b.cap = 0; return bigc_fail(BIGC_ERR_HIP, "linear_dw: hipMalloc of the split scratch failed"); }
+    }
+    *out = b.p;
+    return BIGC_OK;
+}
+
 extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const float* X, int ldx, const int32_t* x_idx, int nseg,
                                   int seg_len, float* dW, int ldw, float* db, int M, int N, int K) {
     BIGC_CHECK_ARG(dY && X && dW && M >= 0 && N > 0 && K > 0, "linear_dw: bad argument");
@@ -721,15 +740,10 @@ extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const 
     p.partial = nullptr; p.arrived = nullptr;
     const size_t n_pad = (size_t)p.tiles_n * 128, k_pad = (size_t)p.tiles_k * 128;
     if (splits > 1) {
-        // stream-ordered scratch, grown on demand (one stream per process in this library's use)
-        static float* scratch = nullptr;
-        static size_t cap = 0;
+        // stream-ordered scratch, grown on demand, one per (thread, device): see dw_scratch
         const size_t need = (size_t)splits * n_pad * k_pad;
-        if (need > cap) {
-            if (scratch) { if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_dw: sync failed"); (void)hipFree(scratch); }
-            cap = need + need / 2;
-            if (hipMalloc((void**)&scratch, cap * sizeof(float)) != hipSuccess) { scratch = nullptr; cap = 0; return bigc_fail(BIGC_ERR_HIP, "linear_dw: hipMalloc of the split scratch failed"); }
-        }
+        float* scratch = nullptr;
+        if (int rc = dw_scratch(stream, need, 0, &scratch)) return rc;
         p.partial = scratch;
         // arrival counters of the in-kernel reduction (zero between launches)
         static int* arrived = nullptr;
@@ -810,13 +824,8 @@ int bigc_linear_dw_group(void* stream, const BigcDwJob* jobs, int n) {
         }
         g.start[cnt] = blocks;
         if (need) {
-            static float* scratch = nullptr;      // stream-ordered, grown on demand (as bigc_linear_dw_f32's)
-            static size_t cap = 0;
-            if (need > cap) {
-                if (scratch) { if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_dw_group: sync failed"); (void)hipFree(scratch); }
-                cap = need + need / 2;
-                if (hipMalloc((void**)&scratch, cap * sizeof(float)) != hipSuccess) { scratch = nullptr; cap = 0; return bigc_fail(BIGC_ERR_HIP, "linear_dw_group: hipMalloc of the split scratch failed"); }
-            }
+            float* scratch = nullptr;             // stream-ordered, grown on demand, one per (thread, device)
+            if (int rc = dw_scratch(stream, need, 1, &scratch)) return rc;
             size_t off = 0;
             for (int i = 0; i < cnt; ++i) {
                 DwArgs& p = g.job[i];

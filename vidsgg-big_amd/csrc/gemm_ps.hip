@@ -463,34 +463,31 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         float s1[RB], mean[RB], rstd[RB];
 #pragma unroll
         for (int ri = 0; ri < RB; ++ri) s1[ri] = 0.f;
+        // (small groups of loads, fenced: with all of a pass's loads hoisted to its top the 96-row tile spilled in the K loop)
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi) {
-            const int nb = wf * 64 + fi * 32 + 4 * hi;
-            f32x4 bv[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bv[g] = *(const f32x4*)(p.bias + nb + 8 * g);
+            for (int g = 0; g < 4; ++g) {
+                const int nb = wf * 64 + fi * 32 + 4 * hi + 8 * g;
+                const f32x4 bv = *(const f32x4*)(p.bias + nb);
+                f32x4 rv[RB];
 #pragma unroll
-            for (int ri = 0; ri < RB; ++ri) {
-                const int mc = min(m0 + ri * 32 + l31, p.M - 1);
-                f32x4 rv[4];
-                if (p.res) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) rv[g] = *(const f32x4*)(p.res + (size_t)(p.res_period > 0 ? mc % p.res_period : mc) * p.ldr + nb + 8 * g);
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) rv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int ri = 0; ri < RB; ++ri) {
+                    const int mc = min(m0 + ri * 32 + l31, p.M - 1);
+                    rv[ri] = p.res ? *(const f32x4*)(p.res + (size_t)(p.res_period > 0 ? mc % p.res_period : mc) * p.ldr + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int ri = 0; ri < RB; ++ri)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        float t = acc[fi][ri][4 * g + c] * osc + bv[g][c];
+                        float t = acc[fi][ri][4 * g + c] * osc + bv[c];
                         t = fmaxf(t, lo);
                         if (sigm) t = 1.0f / (1.0f + expf(-t));
-                        t += rv[g][c];
+                        t += rv[ri][c];
                         acc[fi][ri][4 * g + c] = t;
                         s1[ri] += t;
                     }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -522,37 +519,24 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         }
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi) {
-            const int nb = wf * 64 + fi * 32 + 4 * hi;
-            f32x4 gv[4], ev[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { gv[g] = *(const f32x4*)(p.ln_g + nb + 8 * g); ev[g] = *(const f32x4*)(p.ln_b + nb + 8 * g); }
+            for (int g = 0; g < 4; ++g) {
+                const int nb = wf * 64 + fi * 32 + 4 * hi + 8 * g;
+                const f32x4 gv = *(const f32x4*)(p.ln_g + nb), ev = *(const f32x4*)(p.ln_b + nb);
 #pragma unroll
-            for (int ri = 0; ri < RB; ++ri) {
-                const int m = m0 + ri * 32 + l31;
-                const bool mok = m < p.M;
-                const int mc = min(m, p.M - 1);
-                f32x4 y[4];
+                for (int ri = 0; ri < RB; ++ri) {
+                    const int m = m0 + ri * 32 + l31;
+                    const bool mok = m < p.M;
+                    f32x4 y;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) y[g][c] = (acc[fi][ri][4 * g + c] - mean[ri]) * rstd[ri] * gv[g][c] + ev[g][c];
-                if (p.C) {
-                    if (p.ln_add) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 ad = *(const f32x4*)(p.ln_add + (size_t)(mc % p.ln_add_period) * TNK + nb + 8 * g);
-                            if (mok) *(f32x4*)(p.C + (size_t)m * p.ldc + nb + 8 * g) = y[g] + ad;
-                        }
-                    } else {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            if (mok) *(f32x4*)(p.C + (size_t)m * p.ldc + nb + 8 * g) = y[g];
+                    for (int c = 0; c < 4; ++c) y[c] = (acc[fi][ri][4 * g + c] - mean[ri]) * rstd[ri] * gv[c] + ev[c];
+                    if (p.C) {
+                        f32x4 out = y;
+                        if (p.ln_add) out += *(const f32x4*)(p.ln_add + (size_t)(min(m, p.M - 1) % p.ln_add_period) * TNK + nb);
+                        if (mok) *(f32x4*)(p.C + (size_t)m * p.ldc + nb) = out;
                     }
-                }
-                if (p.Cs) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 x = y[g] * ACT_SCALE;
+                    if (p.Cs) {
+                        const f32x4 x = y * ACT_SCALE;
                         unsigned h0, h1, r0, r1;
                         split2(x[0], x[1], h0, r0);
                         split2(x[2], x[3], h1, r1);
@@ -560,9 +544,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                         for (int c = 0; c < 4; ++c) oob |= mok && !(fabsf(x[c]) < F16_LIMIT);
                         const auto sx = __builtin_amdgcn_permlane32_swap(h0, r0, false, false);
                         const auto sy = __builtin_amdgcn_permlane32_swap(h1, r1, false, false);
-                        if (mok) *(u32x4*)(p.Cs + (size_t)m * p.ldcs + (size_t)((nb + 8 * g) >> 3) * 32 + hi * 16) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+                        if (mok) *(u32x4*)(p.Cs + (size_t)m * p.ldcs + (size_t)(nb >> 3) * 32 + hi * 16) = u32x4{sx[0], sy[0], sx[1], sy[1]};
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -652,8 +637,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                     }
                     open_now = g + NST < n_flat && !(p.ablate & 1);
                     if (open_now && ikt == 0) issue_tile_setup();
-                    rd_w(so[1], 0, WF[0]);
-                    rd_a(so[1], 0, 0, AF[0]);
+                    // (LNM: at a tile's last slab the next slab's first fragments are read AFTER the epilogue -- held across it they sit on
+                    // top of the 96 accumulators that the LayerNorm keeps alive through its three passes, and the kernel spilled in this loop)
+                    if (!(LNM && ckt + 1 == nk)) {
+                        rd_w(so[1], 0, WF[0]);
+                        rd_a(so[1], 0, 0, AF[0]);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -679,7 +668,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         so[NST - 1] = t;
         if (++ckt == nk) {
             fold_block();
-            if constexpr (LNM) epilogue_ln(cj); else epilogue(cj);
+            if constexpr (LNM) {
+                epilogue_ln(cj);
+                if (more) { rd_w(so[0], 0, WF[0]); rd_a(so[0], 0, 0, AF[0]); }      // the new tile's first fragments (the stages were rotated above)
+            } else {
+                epilogue(cj);
+            }
             zero_acc();
             ckt = 0; ++cj;
         } else if (BLOCKED && p.blk > 0 && (ckt & (p.blk - 1)) == 0) {
@@ -762,6 +756,9 @@ bool bigc_gemm_ps_supported(const PsGemm& g) {
 
 int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     if (!bigc_gemm_ps_supported(g)) return bigc_fail(BIGC_ERR_ARG, "gemm_ps: unsupported shape / alignment (M=%d N=%d K=%d)", g.M, g.N, g.K);
+    // (the split form holds f16 heads, so this kernel has no bf16 arithmetic; in the literal bf16 mode the model keeps its GEMMs on
+    // bigc_linear_f32 -- the GEMM -> GEMM chains are off there, csrc/model.hip -- and a direct call is refused instead of silently running f16)
+    if (bigc_linear_get_fast() == 2) return bigc_fail(BIGC_ERR_ARG, "gemm_ps: no bf16 arithmetic on pre-split operands (bigc_linear_set_fast(2)): use bigc_linear_f32");
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;

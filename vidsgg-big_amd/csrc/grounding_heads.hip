@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void grd_head_prep_kernel(const HeadChainArgs a
     dst[64] = r;
 }
 
-__global__ __launch_bounds__(256) void grd_head_chain_kernel(const HeadChainArgs a) {
+__global__ __launch_bounds__(256, 2) void grd_head_chain_kernel(const HeadChainArgs a) {   // (two waves per SIMD = two workgroups per CU: the 69 KB of LDS allow it, the register allocation must too)
     __shared__ __attribute__((aligned(16))) float X[HD_CR * HD_XP];
     __shared__ __attribute__((aligned(16))) unsigned char Ah[HD_CR * HD_AP];
     __shared__ __attribute__((aligned(16))) unsigned char Ar[HD_CR * HD_AP];

@@ -463,11 +463,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         float s1[RB], mean[RB], rstd[RB];
 #pragma unroll
         for (int ri = 0; ri < RB; ++ri) s1[ri] = 0.f;
-        // (small groups of loads, fenced: with all of a pass's loads hoisted to its top the 96-row tile spilled in the K loop)
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                // (the column does not depend on the tile in this mode: the compiler hoists the loads of bias / gamma / beta -- 96 registers -- out of the
+                // persistent tile loop.  At 64-row tiles they fit and the epilogue is faster for it (measured: 17.2 vs 17.8 ms family time with the
+                // loads kept inside); at 96-row tiles they are what spills.)
                 const int nb = wf * 64 + fi * 32 + 4 * hi + 8 * g;
                 const f32x4 bv = *(const f32x4*)(p.bias + nb);
                 f32x4 rv[RB];
@@ -487,7 +489,6 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                         acc[fi][ri][4 * g + c] = t;
                         s1[ri] += t;
                     }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -547,7 +548,6 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                         if (mok) *(u32x4*)(p.Cs + (size_t)m * p.ldcs + (size_t)(nb >> 3) * 32 + hi * 16) = u32x4{sx[0], sy[0], sx[1], sy[1]};
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -601,6 +601,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     bool opened = false;                           // the slab under issue has its first pieces out
     for (int g = 0; g < n_flat; ++g) {
         const bool more = g + 1 < n_flat;
+        const bool tile_end = ckt + 1 == nk;          // this slab is the last of its tile (ONE value guards the deferred prefetch and the epilogue)
         stamp(4);
 #pragma unroll
         for (int n = 0; n < NU; ++n) {
@@ -637,12 +638,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                     }
                     open_now = g + NST < n_flat && !(p.ablate & 1);
                     if (open_now && ikt == 0) issue_tile_setup();
-                    // (LNM: at a tile's last slab the next slab's first fragments are read AFTER the epilogue -- held across it they sit on
-                    // top of the 96 accumulators that the LayerNorm keeps alive through its three passes, and the kernel spilled in this loop)
-                    if (!(LNM && ckt + 1 == nk)) {
-                        rd_w(so[1], 0, WF[0]);
-                        rd_a(so[1], 0, 0, AF[0]);
-                    }
+                    rd_w(so[1], 0, WF[0]);
+                    rd_a(so[1], 0, 0, AF[0]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -666,18 +663,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
 #pragma unroll
         for (int i = 0; i + 1 < NST; ++i) so[i] = so[i + 1];
         so[NST - 1] = t;
-        if (++ckt == nk) {
+        if (tile_end) {
             fold_block();
-            if constexpr (LNM) {
-                epilogue_ln(cj);
-                if (more) { rd_w(so[0], 0, WF[0]); rd_a(so[0], 0, 0, AF[0]); }      // the new tile's first fragments (the stages were rotated above)
-            } else {
-                epilogue(cj);
-            }
+            if constexpr (LNM) epilogue_ln(cj); else epilogue(cj);
             zero_acc();
             ckt = 0; ++cj;
-        } else if (BLOCKED && p.blk > 0 && (ckt & (p.blk - 1)) == 0) {
-            fold_block();
+        } else {
+            ++ckt;
+            if (BLOCKED && p.blk > 0 && (ckt & (p.blk - 1)) == 0) fold_block();
         }
     }
     if (TRACE && lane == 0) {
@@ -786,7 +779,8 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     // M = 49 152 (decoder, 256 videos) x N = 512: 384 tiles of 256 rows = 2 rounds x 4, 512 of 192 = 2 x 3 (exact), 768 of 128 = 3 x 2.
     // The result does not depend on the choice (one accumulator per element, the same K order in every tiling).
     int rb = 2;
-    if (lnm) rb = 2;                                   // 64-row tiles spanning all 512 features (96-row tiles spill in the K loop: measured 19.7 vs 17.2 ms family time)
+    static const int ln_rb = getenv("BIGC_LN_RB") ? atoi(getenv("BIGC_LN_RB")) : 2;
+    if (lnm) rb = ln_rb == 3 ? 3 : 2;                 // rows per tile = 32 rb, spanning all 512 features
     else if (want_blk && g.a_fmt == PS_HR8) rb = 2;
     else if (force_rb) rb = force_rb;
     else {
@@ -848,8 +842,13 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     const int grid = n_tiles >= n_cu ? n_cu : cdiv(n_tiles, 8) * 8;
 #define PS_LAUNCH(MODE, RBV) hipLaunchKernelGGL((gemm_ps_kernel<MODE, RBV>), dim3(grid), dim3(512), 0, s, p)
     if (lnm) {
-        if (bigc_linear_get_fast()) hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, true, false, true>), dim3(grid), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+        if (rb == 3) {
+            if (bigc_linear_get_fast()) hipLaunchKernelGGL((gemm_ps_kernel<0, 3, false, true, false, true>), dim3(grid), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((gemm_ps_kernel<0, 3, false, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+        } else {
+            if (bigc_linear_get_fast()) hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, true, false, true>), dim3(grid), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+        }
     } else if (trace && g.a_fmt == PS_HR8 && !g.a_idx) {
         static unsigned long long* buf = nullptr;
         if (!buf && hipMalloc((void**)&buf, 8 * 5 * 8 * 4096) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "gemm_ps: trace buffer");

@@ -177,3 +177,25 @@ def test_feature_outside_the_split_forms_range_through_the_api(in_place, monkeyp
     else:
         assert torch.equal(res[0][0], want[0][0]) and torch.equal(res[0][2], want[0][2])
         assert float((res[0][1] - want[0][1]).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_forward_async_returns_what_forward_returns_with_several_batches_in_flight():
+    """model.forward_async queues a batch and returns; .result() later gives, bit for bit, what model(proposal_list) gives -- also with three
+    batches queued before the first result is fetched, batches of mixed size classes, an empty video, and a batch whose range flag is raised"""
+    cfg, model = _model("CONFIG_V")
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    batches = []
+    for b, sizes in enumerate([(20, 0, 70), (64,), (5, 9, 31, 12)]):
+        host = [synthetic_proposal(300 + 10 * b + i, n_trajs=k, feat_width=width, num_enti_cats=cfg["num_enti_cats"]) for i, k in enumerate(sizes)]
+        batches.append([p.to(DEV) for p in host])
+    batches[2][1].features_list[0][0, 7] = 5.0e4          # |x| >= 32768: the in-loop split's own f32 fallback handles it (no flag), results stay valid
+    pend = [model.forward_async(b, topk=3) for b in batches]
+    got = [p.result() for p in pend]
+    for b, g in zip(batches, got):
+        want = model(b, topk=3)
+        assert len(g) == len(want)
+        for x, y in zip(g, want):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert all(torch.equal(u, v) for u, v in zip(x, y))

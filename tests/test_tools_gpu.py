@@ -111,6 +111,7 @@ def test_bench_json_contract():
     assert d["timed_call"].startswith("model(proposal_list, topk)") and d["forward_api"]["value"] == d["value"]
     assert d["resident_packed_batch"]["value"] > 0 and len(d["timed_steps_ms"]) == 2 and d["modes"]["resident_batch_holds_split_features"] is True
     assert d["kernel_families_ms_per_step"]["pack"] >= 0
+    assert d["forward_api_pipelined"]["value"] > 0 and d["forward_api_pipelined"]["results_identical_to_the_synchronous_call"] is True
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     c = d["cpu_baseline"]

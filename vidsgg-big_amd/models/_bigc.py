@@ -52,6 +52,57 @@ class _DecoderLayerParams(nn.Module):
         self.norm3 = nn.LayerNorm(d_pred)
 
 
+class _Pending(object):
+    """an eval forward that has been queued on the GPU (``BigcBase.forward_async``)"""
+
+    _pinned = {}            # device -> (ring of pinned int32 buffers, next slot): allocated once (every pinned allocation maps pages into the GPU)
+
+    def __init__(self, model, proposal_list, topk):
+        self.model, self.topk, self.n = model, topk, len(proposal_list)
+        self.parts = []                                # (indices into proposal_list, packed batch, outputs, event)
+        keep = [i for i, p in enumerate(proposal_list) if p.num_proposals > 0]
+        if not keep:
+            return
+        device = model.pred_query_init.device
+        hd = model.config["dim_enti"] // model.config["n_att_head"]
+        single_pass = 256 if hd in (8, 16) else 192
+        classes = {}
+        for i in keep:                                 # a video is only batched with videos of its own size class (see forward)
+            n = proposal_list[i].num_proposals
+            classes.setdefault(0 if n <= 64 else (1 if n <= single_pass else 2), []).append(i)
+        for idx in classes.values():
+            packed = PackedBatch([proposal_list[i] for i in idx], device, "lazy")
+            out = model.forward_packed(packed, topk)
+            host = self._pinned_buffer(device, out["_counts"].numel())
+            host.copy_(out["_counts"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            out["_host_pending"] = (lambda ev=ev, host=host: (ev.synchronize(), host.clone())[1])
+            self.parts.append((idx, packed, out))
+
+    @classmethod
+    def _pinned_buffer(cls, device, n):
+        ring = cls._pinned.get(device)
+        if ring is None or ring[0][0].numel() < n:
+            ring = cls._pinned[device] = ([torch.empty((max(4096, 2 * n),), dtype=torch.int32).pin_memory() for _ in range(8)], [0])
+        bufs, nxt = ring
+        buf = bufs[nxt[0] % len(bufs)][:n]
+        nxt[0] += 1
+        return buf
+
+    def result(self):
+        res = [None] * self.n
+        for idx, packed, out in self.parts:
+            try:
+                self.model.counts(out)
+            except OverflowError:                       # an operand left the split range: this batch once more on the exact kernels
+                out = self.model.forward_checked(packed, self.topk)
+            for i, r in zip(idx, self.model.unpack_results(len(idx), list(range(len(idx))), out)):
+                res[i] = r
+        self.parts = []
+        return res
+
+
 class BigcBase(nn.Module):
     variant = None          # "vidvrd" | "vidor"
     default_topk = 10
@@ -145,6 +196,23 @@ class BigcBase(nn.Module):
                 res[i] = r
         return res
 
+    def forward_async(self, proposal_list, topk=None):
+        """``forward`` in two halves, for loops over many batches (tools/eval_*.py): this call packs the batch and QUEUES everything on the
+        GPU -- forward, construct_triplet, compaction and a non-blocking copy of the row offsets into pinned memory -- and returns at once;
+        ``.result()`` of the returned object waits for that copy and builds the per-video tuples.  The host side of batch i + 1 (tables,
+        launches) then runs while the GPU works on batch i:
+
+            pending = model.forward_async(batches[0])
+            for nxt in batches[1:]:
+                upcoming = model.forward_async(nxt); results = pending.result(); pending = upcoming
+
+        The results are those of ``forward`` (same kernels, same bits; the exact-mode rerun of a step whose range flag is raised happens
+        inside ``.result()``)."""
+        if topk is None:
+            topk = self.default_topk
+        assert not self.is_train, "forward_async is an eval entry point"
+        return _Pending(self, proposal_list, topk)
+
     def _forward_train(self, proposal_list, gt_graph_list):
         """Training contract of the reference (models/model_0v10.py:510-556): returns
         ``(total_loss, {"cls_pos", "cls_neg", "adj"})``; ``total_loss.backward()`` runs the HIP backward and
@@ -237,7 +305,7 @@ class BigcBase(nn.Module):
         pair format cannot hold (|x| >= 4096, NaN, Inf) invalidates the step -> ``OverflowError``; ``forward`` then repeats the
         step on the exact f32 kernels."""
         if "_host_counts" not in out:
-            both = out["_counts"].cpu()
+            both = out.pop("_host_pending")() if "_host_pending" in out else out["_counts"].cpu()
             out["_host_off"] = both[:-1]
             out["_host_counts"] = both[1:-1] - both[:-2]
             if int(both[-1]) != 0:

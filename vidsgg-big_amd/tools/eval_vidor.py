@@ -66,9 +66,15 @@ def evaluate_cls_stage(cfg_path, ckpt_path=None, save_tag="", output_dir=None, c
     mine, my_data = shard_for_inference(data, data.costs, rank, world)          # only this rank's videos are loaded
     t0 = time.time()
     my_results = []
-    for p, g, _ in my_data:
-        with torch.no_grad():
-            r = model([p.to(device)], topk=topk)[0]
+    # one video per forward as the reference (tools/eval_vidor.py:91-121), two forwards in flight where the model offers it (BIG-C:
+    # forward_async -- the host side of video i + 1 runs while the GPU works on video i; Base_C scores synchronously)
+    asynchronous = hasattr(model, "forward_async")
+    from collections import deque
+    inflight = deque()
+
+    def finish(vi, head):
+        p, g, _ = my_data[vi]
+        r = (head.result() if asynchronous else head)[0]
         r = None if r is None else tuple(t.cpu() for t in r)
         # VidOR vocabulary, video name reset to the id the ground-truth JSON is keyed by (utils/evaluate.py:26-38); converted by the
         # rank that holds the video's tracklets
@@ -76,6 +82,15 @@ def evaluate_cls_stage(cfg_path, ckpt_path=None, save_tag="", output_dir=None, c
         # (real data is evaluated against datasets/GT_json_for_eval/VidORval_gts.json, _report)
         gt = (E.reset_video_name(p.video_name, "vidor"), E.gt_to_eval_format(g, dataset_type="vidor")) if (g is not None and synthetic) else None
         my_results.append((p.video_name, r, pred, gt))
+
+    for vi in range(len(my_data)):
+        pv = my_data[vi][0].to(device)
+        with torch.no_grad():
+            inflight.append((vi, model.forward_async([pv], topk=topk) if asynchronous else model([pv], topk=topk)))
+        if len(inflight) == 2:
+            finish(*inflight.popleft())
+    while inflight:
+        finish(*inflight.popleft())
     torch.cuda.synchronize()
     all_results = gather_results(my_results, mine, len(data), dist)
     if all_results is None:                                 # ranks other than 0 are done

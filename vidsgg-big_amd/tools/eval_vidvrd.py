@@ -75,11 +75,21 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
     mine, my_data = shard_for_inference(data, data.costs, rank, world)
     t0 = time.time()
     my_results = []
-    for s in range(0, len(my_data), batch_videos):
-        chunk = my_data[s:s + batch_videos]
-        props = [p.to(device) for p, _ in chunk]
-        with torch.no_grad():
-            results = model(props, topk=topk)               # one packed HIP forward for the whole chunk
+    # two chunks in flight: the host side of chunk i + 1 (moving it to the GPU, the batch tables, the launches) runs while the GPU works on
+    # chunk i (BigcBase.forward_async); the results are those of model(props, topk)
+    chunks = [my_data[s:s + batch_videos] for s in range(0, len(my_data), batch_videos)]
+    pending = None
+    for ci in range(len(chunks) + 1):
+        upcoming = None
+        if ci < len(chunks):
+            props = [p.to(device) for p, _ in chunks[ci]]
+            with torch.no_grad():
+                upcoming = model.forward_async(props, topk=topk)      # one packed HIP forward for the whole chunk, queued
+        if pending is None:
+            pending = upcoming
+            continue
+        chunk, results = chunks[ci - 1], pending.result()
+        pending = upcoming
         for (p, g), r in zip(chunk, results):
             # converted to the evaluator's format HERE, by the rank that holds the video's tracklets: rank 0 receives per video
             # (raw result, prediction entry, ground-truth entry) and never needs the other ranks' proposals

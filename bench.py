@@ -922,6 +922,7 @@ def main():
         torch.set_num_threads(usable_cores())
         cpu_pairs, n_done, cpu_s = 0, 0, 0.0
         rows_total, rows_same, vids_same, max_rel, other_argmax = 0, 0, 0, 0.0, 0
+        set_hip, set_ref = [], []           # distance to float64 of the first 32 videos: HIP and the f32 oracle side by side (a statement about the SET)
         over, over_worse, over_failed, sd64, row_diffs = [], 0, 0, None, []
 
         def f64_eval(p):
@@ -977,6 +978,12 @@ def main():
                 if same_so.any():
                     d = float(np.abs(hip_logits[v][same_so] - lg[same_so]).max() / np.abs(lg).max())
                     max_rel = max(max_rel, d)
+                    if v < 32:
+                        if sd64 is None:
+                            sd64 = {k: t.double() for k, t in sd.items()}
+                        r64 = A.f64_logits(sd, cfg, p, sd64=sd64)
+                        set_hip.append(float(np.abs(hip_logits[v][same_so].astype(np.float64) - r64[same_so]).max() / np.abs(r64).max()))
+                        set_ref.append(float(np.abs(lg[same_so].astype(np.float64) - r64[same_so]).max() / np.abs(r64).max()))
                     if d > 1e-4 and len(over) < 12:
                         # two f32 evaluations more than 1e-4 apart: a float64 evaluation of the oracle is the truth, and where HIP is more
                         # than 1e-4 from it, the video's own float32 noise floor decides (oracle/accuracy.py; outside the CPU timing)
@@ -995,6 +1002,8 @@ def main():
         oracle_parity = dict(videos=n_done, identical_triplet_rows="%d of %d" % (rows_same, rows_total), videos_fully_identical=vids_same,
                              max_logit_rel=max_rel, queries_with_other_argmax_entity=other_argmax,
                              videos_with_differing_rows=row_diffs,
+                             distance_to_float64_first_32_videos=(dict(hip_mean=float(np.mean(set_hip)), hip_max=float(np.max(set_hip)), f32_oracle_mean=float(np.mean(set_ref)),
+                                                                        f32_oracle_max=float(np.max(set_ref)), videos=len(set_hip)) if set_hip else None),
                              videos_over_1e_4=over, videos_over_1e_4_where_hip_is_farther_from_f64_than_the_f32_oracle=over_worse,
                              videos_outside_1e_4_and_their_f32_noise_floor=over_failed,
                              note="HIP output of the timed workload vs the CPU oracle on the same videos; logits compared on the queries whose "

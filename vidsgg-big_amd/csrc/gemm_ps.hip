@@ -39,6 +39,7 @@
 #include "prof.h"
 #include <atomic>
 #include <stdlib.h>
+#include <string.h>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -160,8 +161,12 @@ struct PsArgs {
 //   LNM: the tile spans ALL 512 output features (eight waves side by side, 64 features each, RB row blocks: TM = 32 RB rows), so that the
 //   epilogue can take a row's LayerNorm (models/model_0v10.py:188,211,223: norm1 / norm2 / norm3 of a decoder layer) before it stores:
 //   the f32 pre-norm tensor and the LayerNorm pass that read it disappear (one write + one read of (B Q, 512) f32 per LayerNorm).
-template <int AMODE, int RB, bool TRACE = false, bool FAST = false, bool BLOCKED = false, bool LNM = false>
+//   ACC2 (128-row tiles): the two correction terms of a product (head x residual, residual x head: 2^-11 of the leading term) go to a SECOND
+//   accumulator, so that the leading accumulator is rounded once per k16 step instead of three times -- the scheme of linear_split.hip; the
+//   residuals are unscaled in this format, so the two are simply added in the epilogue.  rms error 10.3 -> ~6 units of 2^-24 at K = 3072.
+template <int AMODE, int RB, bool TRACE = false, bool FAST = false, bool BLOCKED = false, bool LNM = false, bool ACC2 = false>
 __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
+    static_assert(!ACC2 || (RB == 2 && !FAST && !BLOCKED && !LNM), "second accumulator: 128-row tiles only (registers)");
     static_assert(!LNM || (AMODE == 0 && (RB == 2 || RB == 3) && !BLOCKED && !TRACE), "LayerNorm epilogue: plain hr8 operand, 64- or 96-row tiles");
     constexpr int TNK = LNM ? 512 : TN;                       // output features per tile
     constexpr int NWF = TNK / 64, NWR = 8 / NWF;              // waves side by side over the features / stacked over the rows
@@ -324,13 +329,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     // one-wave-per-SIMD layout (512 registers per wave).  Kept as the measuring instrument for what blocking buys.
     static_assert(!BLOCKED || (RB == 2 && !FAST), "blocked accumulation: 128-row tiles only");
     f32x16 tot[2][BLOCKED ? RB : 1];
+    f32x16 acc2[2][ACC2 ? RB : 1];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
             for (int ri = 0; ri < RB; ++ri)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[fi][ri][r] = 0.f; if (BLOCKED) tot[fi][ri][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { acc[fi][ri][r] = 0.f; if (BLOCKED) tot[fi][ri][r] = 0.f; if (ACC2) acc2[fi][ri][r] = 0.f; }
     };
     zero_acc();
     auto fold_block = [&]() {
@@ -384,7 +390,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
             if (m < m0 || m >= m1) continue;
             const int t = m / (2 * UR), fi = (m % (2 * UR)) / UR, ri = m % UR;
             if (FAST && t > 0) continue;
-            acc[fi][UR * u + ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t == 2 ? w.l[fi] : w.h[fi], t == 1 ? a.l[ri] : a.h[ri], acc[fi][UR * u + ri], 0, 0, 0);
+            if (ACC2 && t > 0)
+                acc2[fi][UR * u + ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t == 2 ? w.l[fi] : w.h[fi], t == 1 ? a.l[ri] : a.h[ri], acc2[fi][UR * u + ri], 0, 0, 0);
+            else
+                acc[fi][UR * u + ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t == 2 ? w.l[fi] : w.h[fi], t == 1 ? a.l[ri] : a.h[ri], acc[fi][UR * u + ri], 0, 0, 0);
         }
     };
 
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                 for (int g = 0; g < 4; ++g) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        float t = (BLOCKED ? tot[fi][ri][4 * g + c] : acc[fi][ri][4 * g + c]) * osc + bv[g][c];      // (blocked: the last block was folded in)
+                        float t = (BLOCKED ? tot[fi][ri][4 * g + c] : (ACC2 ? acc[fi][ri][4 * g + c] + acc2[fi][ri][4 * g + c] : acc[fi][ri][4 * g + c])) * osc + bv[g][c];      // (blocked: the last block was folded in)
                         t = fmaxf(t, lo);
                         if (sigm) t = 1.0f / (1.0f + expf(-t));
                         v[g][c] = t + rv[g][c];
@@ -778,9 +787,15 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     // that falls with the tile: a 128-row tile reads 1.33 x the LDS bytes per MFMA of a 256-row one) -> the cheapest of 256 / 192 / 128 rows.
     // M = 49 152 (decoder, 256 videos) x N = 512: 384 tiles of 256 rows = 2 rounds x 4, 512 of 192 = 2 x 3 (exact), 768 of 128 = 3 x 2.
     // The result does not depend on the choice (one accumulator per element, the same K order in every tiling).
+    // BIGC_PS_ACC2 = conv: the gathered GEMM (the temporal conv, K = 3 x 2 dim_enti) on 128-row tiles with a second accumulator; = all: also every
+    // plain hr8-operand GEMM with K >= 1024
+    static const char* acc2_env = getenv("BIGC_PS_ACC2");
+    const bool acc2 = acc2_env && !bigc_linear_get_fast() && g.a_fmt == PS_HR8 && !lnm && !want_blk &&
+                      ((g.a_idx && (!strcmp(acc2_env, "conv") || !strcmp(acc2_env, "all"))) || (!g.a_idx && !strcmp(acc2_env, "all") && g.K >= 1024));
     int rb = 2;
     static const int ln_rb = getenv("BIGC_LN_RB") ? atoi(getenv("BIGC_LN_RB")) : 2;
-    if (lnm) rb = ln_rb == 3 ? 3 : 2;                 // rows per tile = 32 rb, spanning all 512 features
+    if (acc2) rb = 2;
+    else if (lnm) rb = ln_rb == 3 ? 3 : 2;            // rows per tile = 32 rb, spanning all 512 features
     else if (want_blk && g.a_fmt == PS_HR8) rb = 2;
     else if (force_rb) rb = force_rb;
     else {
@@ -841,7 +856,10 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     const int n_tiles = p.tiles_m * p.tiles_n;
     const int grid = n_tiles >= n_cu ? n_cu : cdiv(n_tiles, 8) * 8;
 #define PS_LAUNCH(MODE, RBV) hipLaunchKernelGGL((gemm_ps_kernel<MODE, RBV>), dim3(grid), dim3(512), 0, s, p)
-    if (lnm) {
+    if (acc2) {
+        if (g.a_idx) hipLaunchKernelGGL((gemm_ps_kernel<1, 2, false, false, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, false, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+    } else if (lnm) {
         if (rb == 3) {
             if (bigc_linear_get_fast()) hipLaunchKernelGGL((gemm_ps_kernel<0, 3, false, true, false, true>), dim3(grid), dim3(512), 0, s, p);
             else hipLaunchKernelGGL((gemm_ps_kernel<0, 3, false, false, false, true>), dim3(grid), dim3(512), 0, s, p);

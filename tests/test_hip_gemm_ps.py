@@ -264,3 +264,15 @@ def test_gemm_ps_with_layernorm_epilogue(M, K, with_res, with_add, act):
     assert int(flag.item()) == 0
     assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
     assert bool(((back - want).abs() <= tol + 2.0 ** -22.9 * want.abs()).all())
+
+
+def test_second_accumulator_variant_in_its_own_process():
+    """BIGC_PS_ACC2=all routes the hr8-operand GEMMs with K >= 1024 (and the gathered form) to the 128-row kernel with a second accumulator
+    for the correction terms; the switch is read once per process, so the float64 and gather tests above are run again in a child"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_gemm_ps.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "vs_float64 or gather_segments or strided"], env=dict(os.environ, BIGC_PS_ACC2="all"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

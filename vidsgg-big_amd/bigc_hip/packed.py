@@ -71,10 +71,11 @@ def tracklet_table(p, device):
     c = dict(n=n, device=device, width=width, lens=lens, fptr=fptr, bptr=bptr, fld=None if (fld == width).all() else fld.astype(np.int32),
              aligned=bool(((fptr | bptr) % np.uint64(16) == 0).all() and (fld % 4 == 0).all()),
              ends=(fl[0].data_ptr(), fl[-1].data_ptr(), bl[0].data_ptr(), bl[-1].data_ptr()), keep=keep)
-    try:
-        p._bigc_pack = c
-    except Exception:
-        pass
+    if not keep:                  # (a table that points at converted COPIES is not kept: the caller may change its own tensors' values in place)
+        try:
+            p._bigc_pack = c
+        except Exception:
+            pass
     return c
 
 

@@ -28,6 +28,8 @@ struct bigc_model {
     unsigned long long role_cat_epoch = 0;   // weights epoch role_cat was built for (built lazily by the eval forward)
     float* role_cat = nullptr;         // per decoder layer: [W_role0.2 | W_role1.2] (dp, 2 dp) then b_role0.2 + b_role1.2 (dp), owned
     float* conv_w_bwd = nullptr;       // (2de, 3*de), owned (training)
+    unsigned long long enco_cat_epoch = 0;
+    float* enco_cat = nullptr;         // per decoder layer: [W_e2a; W_role0.0; W_role1.0] (da + 2 dp, de) then the bias [b_e2a | 0] (da + 2 dp), owned (model.hip: build_enco_cat)
     unsigned long long qkpos_epoch = 0;
     float* qkpos = nullptr;            // per decoder layer: (num_querys, 3 dp) rows [pos Wq^T | pos Wk^T | 0], owned (model.hip: build_qkpos)
     int head_k = 0;

@@ -207,7 +207,9 @@ class BigcBase(nn.Module):
                 upcoming = model.forward_async(nxt); results = pending.result(); pending = upcoming
 
         The results are those of ``forward`` (same kernels, same bits; the exact-mode rerun of a step whose range flag is raised happens
-        inside ``.result()``)."""
+        inside ``.result()``).  The feature rows are read IN PLACE while the batch is in flight: the pending object keeps the containers
+        alive, but their tensors must not be written before ``.result()`` returns.  At most eight forwards may be pending at a time (the
+        ring of pinned buffers the row offsets are copied into)."""
         if topk is None:
             topk = self.default_topk
         assert not self.is_train, "forward_async is an eval entry point"

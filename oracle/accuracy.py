@@ -24,7 +24,7 @@ and that kernel issues three per k16 step into one accumulator.
 Round 4: NOISE_RATIO 2.0 -> 1.5 and the cap.  ``forward(proposal_list)`` -- the timed path -- reads the features in place and runs the
 K = 2048 GEMM (the largest) on the TWO-accumulator kernel again (1.16 x MKL instead of 2 x); what still rounds coarser than MKL is the
 gathered conv GEMM (K = 3072, one accumulator: 3.2 x) and the K = 512 GEMMs on pre-split operands (1.5 x).  Measured over the 256
-benchmark videos (profiles/r04c_bench_n1.json.log): ONE video more than 1e-4 from float64 (1.59e-4, against a noise floor of 3.7e-5 rms
+benchmark videos (profiles/r04g_bench_n1.json.log): ONE video more than 1e-4 from float64 (1.59e-4, against a noise floor of 3.7e-5 rms
 and an f32 oracle at 5.8e-5; round 3: three, up to 2.12e-4), none above 2e-4, ONE on which HIP is the farther of the two f32
 evaluations (round 3: two).  At NOISE_RATIO = 1.0 that one video (bound 1.48e-4) would fail by 7 %: the remaining factor is the conv
 GEMM's single accumulator, which is what 1.5 stands for.  A defect of the HIP arithmetic (a stage less accurate than that) would put

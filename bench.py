@@ -758,6 +758,19 @@ def main():
         torch.cuda.synchronize()
         el_o = time.perf_counter() - t1
         other_leg = dict(value=round(pairs_per_step * args.steps / el_o, 1), unit="pairs/s (this GPU)", ms_per_step=round(1e3 * el_o / args.steps, 3), steps=args.steps)
+        if not args.no_prof:
+            # ... and its GEMM family with HIP events around every launch, as the headline's `roofline` (the two paths differ in the K = 2048
+            # GEMM: in-loop split of rows read in place vs the DMA-only kernel on the stored split form)
+            lib.bigc_prof_reset()
+            lib.bigc_prof_enable(1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                other()
+            torch.cuda.synchronize()
+            el_op = time.perf_counter() - t1
+            lib.bigc_prof_enable(0)
+            other_leg["roofline"] = gemm_roofline(collect_families(lib, args.steps), args.steps, 1e3 * el_op / args.steps)
         # the API in two halves (model.forward_async: the host side of call i + 1 -- tables, launches -- runs while the GPU works on call i),
         # as tools/eval_vidvrd.py loops over its chunks; same kernels, same results; a named extra, never the headline
         pend = None

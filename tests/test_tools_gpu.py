@@ -109,7 +109,7 @@ def test_bench_json_contract():
     assert d["value"] > 0 and abs(d["value"] - d["config"]["pairs_per_gpu_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     # the timed call is the drop-in signature (pack + forward + results inside); the resident-batch forward rides beside it
     assert d["timed_call"].startswith("model(proposal_list, topk)") and d["forward_api"]["value"] == d["value"]
-    assert d["resident_packed_batch"]["value"] > 0 and len(d["timed_steps_ms"]) == 2 and d["modes"]["resident_batch_holds_split_features"] is True
+    assert d["resident_packed_batch"]["roofline"]["bound"] == "mfma" and d["resident_packed_batch"]["value"] > 0 and len(d["timed_steps_ms"]) == 2 and d["modes"]["resident_batch_holds_split_features"] is True
     assert d["kernel_families_ms_per_step"]["pack"] >= 0
     assert d["forward_api_pipelined"]["value"] > 0 and d["forward_api_pipelined"]["results_identical_to_the_synchronous_call"] is True
     r = d["roofline"]

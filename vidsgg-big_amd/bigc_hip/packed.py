@@ -25,13 +25,6 @@ import torch
 from . import _lib
 
 
-def _block_table(base_ptr, lens, width):
-    """addresses of the tracklets of one contiguous (sum L, width) f32 block"""
-    off = np.zeros(len(lens), dtype=np.uint64)
-    np.cumsum(lens[:-1], out=off[1:])
-    return np.uint64(base_ptr) + off * np.uint64(4 * width)
-
-
 def tracklet_table(p, device):
     """Per-video source table of a TrajProposal-like object: tracklet lengths, addresses and row pitches of the feature rows,
     addresses of the boxes -- what ``bigc_pack_tracklets`` gathers from.  Cached on the object (``_bigc_pack``): containers

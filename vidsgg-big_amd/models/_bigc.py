@@ -55,7 +55,6 @@ class _DecoderLayerParams(nn.Module):
 class _Pending(object):
     """an eval forward that has been queued on the GPU (``BigcBase.forward_async``)"""
 
-    _pinned = {}            # device -> (ring of pinned int32 buffers, next slot): allocated once (every pinned allocation maps pages into the GPU)
 
     def __init__(self, model, proposal_list, topk):
         self.model, self.topk, self.n = model, topk, len(proposal_list)
@@ -73,18 +72,21 @@ class _Pending(object):
         for idx in classes.values():
             packed = PackedBatch([proposal_list[i] for i in idx], device, "lazy")
             out = model.forward_packed(packed, topk)
-            host = self._pinned_buffer(device, out["_counts"].numel())
+            host = self._pinned_buffer(model, out["_counts"].numel())
             host.copy_(out["_counts"], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(device))
             out["_host_pending"] = (lambda ev=ev, host=host: (ev.synchronize(), host.clone())[1])
             self.parts.append((idx, packed, out))
 
-    @classmethod
-    def _pinned_buffer(cls, device, n):
-        ring = cls._pinned.get(device)
+    @staticmethod
+    def _pinned_buffer(model, n):
+        """the next of the MODEL's eight pinned int32 buffers (allocated once: every pinned allocation maps pages into the GPU's address
+        space; per model, so that two models driven from two threads do not share them)"""
+        ring = model.__dict__.get("_pending_ring")
         if ring is None or ring[0][0].numel() < n:
-            ring = cls._pinned[device] = ([torch.empty((max(4096, 2 * n),), dtype=torch.int32).pin_memory() for _ in range(8)], [0])
+            ring = ([torch.empty((max(4096, 2 * n),), dtype=torch.int32).pin_memory() for _ in range(8)], [0])
+            object.__setattr__(model, "_pending_ring", ring)
         bufs, nxt = ring
         buf = bufs[nxt[0] % len(bufs)][:n]
         nxt[0] += 1

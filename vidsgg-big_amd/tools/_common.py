@@ -93,6 +93,14 @@ def dataset_index(ds, convert=None, keep=None):
     return VideoIndex([1] * len(ds), (lambda i: convert(ds[i])) if convert else (lambda i: ds[i]), None, keep)
 
 
+def _save_npy_atomic(path, array):
+    """write-then-rename: several ranks of a torch.distributed.run job may produce the same (seeded, identical) stand-in file at the same
+    time, and a reader must never see a half-written one (seen as a flaky `EOFError: No data left in file` in the two-rank tool tests)"""
+    tmp = "%s.%d.tmp.npy" % (path, os.getpid())
+    np.save(tmp, array)
+    os.replace(tmp, path)
+
+
 def ensure_table_files(model_config, out_dir, seed=0):
     """The model constructors load ``bias_matrix_path`` / ``EntiNameEmb_path`` ``.npy`` files (models/model_0v10.py:264-286).
     For synthetic runs without the prepared data, seeded stand-ins are written next to the outputs."""
@@ -101,11 +109,11 @@ def ensure_table_files(model_config, out_dir, seed=0):
     ne, npred = cfg["num_enti_cats"], cfg["num_pred_cats"]
     if not (cfg.get("bias_matrix_path") and os.path.exists(cfg["bias_matrix_path"])):
         path = os.path.join(out_dir, "synthetic_bias_matrix.npy")
-        np.save(path, rs.uniform(-7, 0, size=(ne, ne, npred)).astype(np.float32))
+        _save_npy_atomic(path, rs.uniform(-7, 0, size=(ne, ne, npred)).astype(np.float32))
         cfg["bias_matrix_path"] = path
     if "EntiNameEmb_path" in cfg and cfg["EntiNameEmb_path"] and not os.path.exists(cfg["EntiNameEmb_path"]):
         path = os.path.join(out_dir, "synthetic_EntiNameEmb.npy")
-        np.save(path, rs.normal(0, 0.4, size=(ne, cfg["dim_clsme"])).astype(np.float32))
+        _save_npy_atomic(path, rs.normal(0, 0.4, size=(ne, cfg["dim_clsme"])).astype(np.float32))
         cfg["EntiNameEmb_path"] = path
     return cfg
 
@@ -142,7 +150,7 @@ def ensure_grounding_files(model_config, out_dir, seed=0):
     for key, rows in (("EntiNameEmb_path", 81), ("PredNameEmb_path", 51)):
         if not (cfg.get(key) and os.path.exists(cfg[key])):
             path = os.path.join(out_dir, "synthetic_" + key[:-5] + ".npy")
-            np.save(path, rs.normal(0, 0.4, size=(rows, cfg["dim_clsme"])).astype(np.float32))
+            _save_npy_atomic(path, rs.normal(0, 0.4, size=(rows, cfg["dim_clsme"])).astype(np.float32))
             cfg[key] = path
     return cfg
 

@@ -199,3 +199,19 @@ def test_forward_async_returns_what_forward_returns_with_several_batches_in_flig
             assert (x is None) == (y is None)
             if x is not None:
                 assert all(torch.equal(u, v) for u, v in zip(x, y))
+
+
+@pytest.mark.gpu
+def test_forward_async_refuses_a_ninth_pending_forward():
+    """the row offsets of a pending forward wait in one of eight pinned buffers: a ninth pending forward would overwrite the first one's"""
+    cfg, model = _model("CONFIG_V")
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    batch = [synthetic_proposal(500, n_trajs=6, feat_width=width, num_enti_cats=cfg["num_enti_cats"]).to(DEV)]
+    want = model(batch, topk=3)
+    pend = [model.forward_async(batch, topk=3) for _ in range(8)]
+    with pytest.raises(AssertionError):
+        model.forward_async(batch, topk=3)
+    for p in pend:
+        got = p.result()
+        assert all(torch.equal(u, v) for u, v in zip(got[0], want[0]))
+    model.forward_async(batch, topk=3).result()          # the slots are free again

@@ -63,7 +63,10 @@ def tracklet_table(p, device):
     fld = np.fromiter((f.stride(0) if f.shape[0] > 1 else width for f in fl2), dtype=np.int64, count=n)
     c = dict(n=n, device=device, width=width, lens=lens, fptr=fptr, bptr=bptr, fld=None if (fld == width).all() else fld.astype(np.int32),
              aligned=bool(((fptr | bptr) % np.uint64(16) == 0).all() and (fld % 4 == 0).all()),
-             ends=(fl[0].data_ptr(), fl[-1].data_ptr(), bl[0].data_ptr(), bl[-1].data_ptr()), keep=keep)
+             ends=(fl[0].data_ptr(), fl[-1].data_ptr(), bl[0].data_ptr(), bl[-1].data_ptr()), keep=keep,
+             # the table holds raw addresses: it keeps the tensors they point into alive for as long as it exists (a caller that drops a
+             # tensor from the middle of its list must not leave the forward reading freed memory)
+             sources=(list(fl2), list(bl2)))
     if not keep:                  # (a table that points at converted COPIES is not kept: the caller may change its own tensors' values in place)
         try:
             p._bigc_pack = c

@@ -72,6 +72,9 @@ class _Pending(object):
         for idx in classes.values():
             packed = PackedBatch([proposal_list[i] for i in idx], device, "lazy")
             out = model.forward_packed(packed, topk)
+            open_now = model.__dict__.get("_pending_open", 0)
+            assert open_now < 8, "more than eight forwards pending: call .result() on the earlier ones first (their row offsets travel through a ring of eight pinned buffers)"
+            object.__setattr__(model, "_pending_open", open_now + 1)
             host = self._pinned_buffer(model, out["_counts"].numel())
             host.copy_(out["_counts"], non_blocking=True)
             ev = torch.cuda.Event()
@@ -92,8 +95,13 @@ class _Pending(object):
         nxt[0] += 1
         return buf
 
+    def __del__(self):
+        if getattr(self, "parts", None):                # dropped without .result(): its slot count must not leak
+            self.model.__dict__["_pending_open"] = max(0, self.model.__dict__.get("_pending_open", 0) - len(self.parts))
+
     def result(self):
         res = [None] * self.n
+        self.model.__dict__["_pending_open"] = max(0, self.model.__dict__.get("_pending_open", 0) - len(self.parts))
         for idx, packed, out in self.parts:
             try:
                 self.model.counts(out)

@@ -32,7 +32,10 @@ Also printed in the same JSON line (rank 0; everything below runs OUTSIDE the ti
   vidor / grounding / train   the other BASELINE configs on the same GPU (N=1 only): VidOR-sized
                 classification (N=180 tracklets), the grounding scorer on its triplet queries, and
                 the BIG-C training step (forward + Hungarian + backward + all-reduce + clip + Adam)
-  batch_x2      the headline workload at twice the videos per step (decoder GEMMs on pre-split operands)
+  batch_x2      the headline workload at twice the videos per step
+  forward_api / resident_packed_batch / forward_api_pipelined   the timed call (= value), the same forward on a batch that stays packed
+                in HBM (with its own GEMM roofline), and the call in two halves (model.forward_async / .result(), two calls in flight)
+  api_host_ms, modes, timed_steps_ms   host side of one call measured alone, the BIGC_* switches in effect, every timed call's duration
 """
 import argparse
 import json

@@ -214,3 +214,29 @@ def test_video_index_loads_only_the_ranks_share():
     for i in (0, 1, 2, 0):
         idx[i]
     assert idx.n_loaded == 4 and len(idx._cache) == 2
+
+
+def test_block_backed_proposal_keeps_the_list_contract():
+    """bigc_hip.synthetic.TrajProposal keeps a video's tracklets as views of two blocks (made on demand); the reference's list contract
+    (dataloaders/dataloader_vidvrd.py:14-77) must still hold: reading, element assignment (what the reference's own .to() does), list
+    assignment, in-place writes through a view, deepcopy, and .to() back into blocks"""
+    import copy
+    p = synthetic_proposal(3, n_trajs=6, feat_width=12, len_range=(4, 9)).to("cpu")
+    assert p._lists is None and len(p.features_list) == 6 and p.features_list[0].shape[1] == 12
+    want = [f.clone() for f in p.features_list]
+    p.features_list[1][0, 0] = 7.0                                   # a write through a view lands in the block
+    want[1][0, 0] = 7.0
+    assert torch.equal(p.features_list[1], want[1]) and p._lists is None
+    q = copy.deepcopy(p)
+    pk = PackedBatch([q], "cpu")                                     # (the copied address table is stale: rebuilt from the copy's own tensors)
+    assert torch.equal(pk.feats, torch.cat(want, 0))
+    x = torch.full_like(want[4], 3.0)
+    p.features_list[4] = x                                           # element assignment: the container now owns explicit lists
+    want[4] = x
+    assert p._lists is not None and not hasattr(p, "_bigc_pack")
+    assert all(torch.equal(a, b) for a, b in zip(p.features_list, want))
+    assert torch.equal(PackedBatch([p], "cpu").feats, torch.cat(want, 0))
+    p.to("cpu")                                                      # back into blocks
+    assert p._lists is None and all(torch.equal(a, b) for a, b in zip(p.features_list, want))
+    p.bboxes_list = [b + 1.0 for b in p.bboxes_list]                 # list assignment
+    assert p._lists is not None and torch.equal(PackedBatch([p], "cpu").boxes, torch.cat(p.bboxes_list, 0))

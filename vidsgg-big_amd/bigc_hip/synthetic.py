@@ -14,6 +14,20 @@ import numpy as np
 import torch
 
 
+class _ViewList(list):
+    """The per-tracklet views of a block-backed ``TrajProposal``, made on demand.  Reading is a plain list; ASSIGNING an element
+    (``proposal.features_list[i] = x``, what the reference's own ``.to()`` does, dataloaders/dataloader_vidvrd.py:73-75) must not be lost:
+    it turns the container into one that owns explicit lists (the blocks stop being the source of truth) and writes there."""
+
+    def __init__(self, owner, which, items):
+        super().__init__(items)
+        self._owner, self._which = owner, which
+
+    def __setitem__(self, i, value):
+        self._owner._own_lists()[self._which][i] = value
+        super().__setitem__(i, value)
+
+
 class TrajProposal(object):
     """Duck-typed stand-in for the reference's per-video tracklet container.
 
@@ -87,7 +101,7 @@ class TrajProposal(object):
     def features_list(self):
         if self._lists is not None:
             return self._lists[1]
-        return list(torch.split(self._feat_block, self._lens, 0))
+        return _ViewList(self, 1, torch.split(self._feat_block, self._lens, 0))
 
     @features_list.setter
     def features_list(self, value):
@@ -97,7 +111,7 @@ class TrajProposal(object):
     def bboxes_list(self):
         if self._lists is not None:
             return self._lists[0]
-        return list(torch.split(self._box_block, self._lens, 0))
+        return _ViewList(self, 0, torch.split(self._box_block, self._lens, 0))
 
     @bboxes_list.setter
     def bboxes_list(self, value):

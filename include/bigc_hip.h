@@ -347,6 +347,28 @@ int bigc_loss_grad(void* stream, const float* logits, int n_pcat, const float* a
                    float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight,
                    float gs_pos, float gs_neg, float gs_adj, /* upstream gradients of the three loss terms */
                    float* loss_out, float* dlogits, int ldg, float* datt);
+/* bigc_loss_grad with the three upstream gradients read from device memory (upstream3[0..2]): the backward of a step that does not
+ *   wait for the GPU (autograd hands them over as a device tensor) */
+int bigc_loss_grad_dev(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
+                       const float* gt_adj, const int64_t* adj_off, const int32_t* target, const int32_t* match_g, int n_vid, int nq,
+                       float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight, const float* upstream3,
+                       float* loss_out, float* dlogits, int ldg, float* datt);
+/* The host half of the reference's matching, on the device.
+ * bigc_align_adjacency: the tail of enti_viou_align (models/model_0v10.py:583-602): viou (B, max_trk, t_max) as written by
+ *   bigc_viou_matrix, adj_raw = per video the GT adjacency (2, G_v, T_v) f32 at float offset raw_off[v] (T_v = gt_traj_off[v+1] -
+ *   gt_traj_off[v] GT trajectories) -> gt_adj per video (2, G_v, N_v) at float offset adj_off[v], re-indexed by proposals: a proposal
+ *   takes the column of its best-overlapping GT trajectory if it passes viou_th for some trajectory or is the best proposal of a
+ *   trajectory nobody passes for, else zeros.
+ * bigc_hungarian: scipy.optimize.linear_sum_assignment (models/model_0v10.py:637) on cost[v, :, :G_v] (B, nq, g_max) of every video, G_v <
+ *   nq: the shortest-augmenting-path algorithm scipy implements (Crouse 2016), in float64 and in scipy's candidate order, so the
+ *   assignment is scipy's also where the optimum is not unique.  -> target (B*nq) = class of the GT predicate matched to the query or 0,
+ *   match_g (B*nq) = its index or -1.  bad[0] |= 1 when a video's costs hold NaN / -inf or admit no assignment (scipy raises
+ *   ValueError there); that video is left unmatched. */
+int bigc_align_adjacency(void* stream, const float* viou, int max_trk, int t_max, const int32_t* e_off, const int32_t* gt_traj_off,
+                         const float* adj_raw, const int64_t* raw_off, const int32_t* g_off, const int64_t* adj_off, int n_vid,
+                         float viou_th, float* gt_adj);
+int bigc_hungarian(void* stream, const float* cost, const int32_t* g_off, const int32_t* gt_pred, int n_vid, int nq, int g_max,
+                   int32_t* target, int32_t* match_g, int* bad);
 
 /* gradient destination of a trainable parameter (accumulated; NULL unregisters). Frozen parameters are never registered. */
 int bigc_set_grad(bigc_model* m, const char* key, float* ptr);
@@ -560,6 +582,12 @@ int bigc_stretched_mean_rows(void* stream, const uint64_t* row_ptr, int col0, in
  * addresses cat_src[v] / score_src[v] / dura_src[v] -> trk_cat int32, trk_score f32, trk_dura int32 of bigc_batch */
 int bigc_pack_video_meta(void* stream, const uint64_t* cat_src, const uint64_t* score_src, const uint64_t* dura_src,
                          const int32_t* vid_trk_off, int n_vid, int32_t* trk_cat, float* trk_score, int32_t* trk_dura);
+/* host -> device copy by a kernel on `stream`: src_mapped is page-locked host memory mapped into the device's address space
+ * (torch pin_memory() / hipHostMalloc); ordered like any other launch, no use of the runtime's copy queues */
+int bigc_copy_mapped(void* stream, void* dst, const void* src_mapped, long nbytes);
+/* progress mark: mapped_word[0] = value (8-byte aligned page-locked host memory, mapped) once everything queued on `stream` before
+ * the call has run; when or_flag (device int, may be NULL) is non-zero, mapped_word[1] = value as well.  The host polls the word. */
+int bigc_stamp(void* stream, void* mapped_word, unsigned long long value, const int* or_flag);
 /* padded outputs of bigc_construct_triplets / bigc_forward -> the reference's return types back to back
  * (models/model_0v10.py:776-785: int64 quintuples, f32 scores, int64 duration intersections, int64 query ids per video):
  * video v's n_out[v] rows at rows [out_off[v], out_off[v+1]) of the compact arrays (each sized for n_vid * cap rows) */

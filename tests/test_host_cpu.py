@@ -240,3 +240,45 @@ def test_block_backed_proposal_keeps_the_list_contract():
     assert p._lists is None and all(torch.equal(a, b) for a, b in zip(p.features_list, want))
     p.bboxes_list = [b + 1.0 for b in p.bboxes_list]                 # list assignment
     assert p._lists is not None and torch.equal(PackedBatch([p], "cpu").boxes, torch.cat(p.bboxes_list, 0))
+
+
+def test_the_restated_assignment_algorithm_is_scipys():
+    """oracle/lsap.py restates csrc/loss.hip: hungarian_kernel (Crouse's shortest augmenting paths with scipy's choice among equal
+    candidates written as an order-free rule); scipy.optimize.linear_sum_assignment is what the reference calls
+    (models/model_0v10.py:637).  Equal assignments also where the optimum is not unique; the same inputs rejected."""
+    from scipy.optimize import linear_sum_assignment
+    from oracle import lsap
+    rs = np.random.RandomState(0)
+    checked = rejected = 0
+    for trial in range(250):
+        nq = int(rs.choice([5, 8, 17, 32, 48]))
+        g = int(rs.randint(1, nq))
+        kind = trial % 5
+        if kind == 0:
+            c = rs.rand(nq, g)
+        elif kind == 1:
+            c = rs.randint(0, 3, (nq, g)).astype(float)
+        elif kind == 2:
+            c = rs.rand(nq, g)[:, rs.randint(0, g, g)]                 # duplicated GT predicates
+        elif kind == 3:
+            c = rs.randint(0, 4, (nq, g)).astype(float)
+            c[rs.rand(nq, g) < (0.3 if trial % 2 else 0.85)] = np.inf          # (0.85: some of these have no assignment at all)
+        else:
+            c = np.zeros((nq, g))
+        try:
+            iq, ig = linear_sum_assignment(c)
+        except ValueError:
+            with pytest.raises(ValueError):
+                lsap.assign(c)
+            rejected += 1
+            continue
+        want = -np.ones(nq, dtype=np.int64)
+        want[iq] = ig
+        assert np.array_equal(lsap.assign(c), want), (trial, kind)
+        checked += 1
+    assert checked > 180 and rejected > 0, (checked, rejected)
+    for bad in (np.nan, -np.inf):
+        c = rs.rand(6, 3)
+        c[1, 1] = bad
+        with pytest.raises(ValueError):
+            lsap.assign(c)

@@ -155,6 +155,14 @@ _SIGS = {
     "bigc_loss_grad": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
                                c_void_p, c_void_p, c_int, c_void_p]),
+    "bigc_loss_grad_dev": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p,
+                                   c_void_p, c_void_p, c_int, c_void_p]),
+    "bigc_align_adjacency": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_float, c_void_p]),
+    "bigc_hungarian": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "bigc_copy_mapped": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long]),
+    "bigc_stamp": (c_int, [c_void_p, c_void_p, ctypes.c_ulonglong, c_void_p]),
     "bigc_set_grad": (c_int, [c_void_p, c_char_p, c_void_p]),
     "bigc_rebase_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "bigc_set_dropout": (c_int, [c_void_p, c_float, ctypes.c_uint32]),
@@ -215,6 +223,7 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    fit_threads_to_cpu_quota()
     return lib
 
 
@@ -251,7 +260,7 @@ class _Staging(object):
         self.half, self.off, self.cur, self.events = nbytes // 2, 0, 0, [None, None]
         self.down = {}
 
-    def put(self, t, device):
+    def put(self, t, device, by_kernel=False):
         import torch
         n = t.numel() * t.element_size()
         n_al = (n + 255) & ~255
@@ -267,10 +276,15 @@ class _Staging(object):
                 self.events[self.cur].synchronize()
         start = self.cur * self.half + self.off
         view = self.buf[start:start + n].view(t.dtype).view(t.shape)
-        view.copy_(t)
+        ctypes.memmove(view.data_ptr(), t.data_ptr(), n)          # (not view.copy_(t): from 32 K elements on that is a job for torch's thread pool)
         self.off += n_al
         with torch.cuda.device(device):               # the copy goes to the current stream of `device`, whatever the caller's current device is
-            return view.to(device, non_blocking=True)
+            if not by_kernel:
+                return view.to(device, non_blocking=True)
+            # a kernel reads the pinned block through its mapping into the device's address space (csrc/ingest.hip: bigc_copy_mapped)
+            out = torch.empty(t.shape, dtype=t.dtype, device=device)
+            check(load().bigc_copy_mapped(current_stream(), out.data_ptr(), view.data_ptr(), n))
+            return out
 
     def download_buffer(self, shape, dtype, slot="default"):
         """a pinned host tensor for device-to-host copies whose result the host consumes before the slot's next use"""
@@ -282,6 +296,50 @@ class _Staging(object):
         if cur is None or cur.numel() < n or cur.dtype != dtype:
             cur = self.down[slot] = torch.empty((max(2 * n, 1 << 16),), dtype=dtype).pin_memory()
         return cur[:n].view(shape)
+
+
+def cpu_quota():
+    """CPUs this process may keep busy: the smaller of its affinity mask and its cgroup's CPU quota (cgroup v2 ``cpu.max``, v1
+    ``cpu.cfs_quota_us`` / ``cpu.cfs_period_us``); None when nothing limits it"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    return n if quota is None else min(n, max(1, int(quota)))
+
+
+_threads_fitted = [False]
+
+
+def fit_threads_to_cpu_quota():
+    """torch sizes its intra-op (OpenMP) pool by the CPUs of the MACHINE; in a container with a CPU quota (this pool's GPU boxes:
+    256 CPUs visible, a quota of 16) every CPU-side tensor operation of 32 K elements or more then spins up to 128 threads, the
+    cgroup's quota for the 100 ms scheduling period is spent in a few milliseconds and the kernel freezes the whole process until the
+    next period -- the Python thread, HIP's submission threads, everything: measured as random 40-95 ms holes in the GPU's timeline
+    whenever the host staged an upload beyond 128 KB (benchmarks/probes/upload_probe2.py: ``nr_throttled`` of the cgroup counts them).
+    Called once when the library is loaded: if the pool is larger than the quota it is cut to half the quota (at most 8: what this
+    package does on the host is packing and bookkeeping); BIGC_KEEP_TORCH_THREADS=1 leaves it alone."""
+    if _threads_fitted[0] or os.environ.get("BIGC_KEEP_TORCH_THREADS", "0") == "1":
+        return
+    _threads_fitted[0] = True
+    import torch
+    n = cpu_quota()
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(max(1, min(8, n // 2)))
 
 
 _staging = {}
@@ -303,13 +361,19 @@ def upload(host, device):
     t = torch.from_numpy(np.ascontiguousarray(host)) if isinstance(host, np.ndarray) else host.contiguous()
     if torch.device(device).type != "cuda" or os.environ.get("BIGC_UPLOAD_BLOCKING", "0") == "1":
         return t.to(device)
-    # Larger uploads take the blocking route: queued as asynchronous copies they made the runtime evict and restore the process's
-    # GPU queues now and then (a doorbell write, hsa_signal_store_screlease, blocked for 40-65 ms with the GPU idle; seen from
-    # 32 videos per step up, where the adjacency upload passes 128 KB) -- measured 65 -> 21 ms per 32-video step with this cap.
+    # Beyond the cap the copy is done by a kernel of the library that reads the pinned block directly (no copy queue involved, the
+    # host does not wait); BIGC_UPLOAD_KERNEL=0 restores the blocking copy from pageable memory that rounds 2-3 used there.  (What
+    # made asynchronous uploads of that size stall for 40-95 ms then was not the copy: staging 32 K elements or more with
+    # ``Tensor.copy_`` wakes torch's intra-op thread pool -- one thread per CPU the machine has -- inside a container whose CPU quota
+    # is a fraction of that, and the kernel then throttles the whole process, HIP's threads included, until the next scheduling
+    # period: ``fit_threads_to_cpu_quota`` below, benchmarks/probes/upload_probe2.py.)
     cap = int(os.environ.get("BIGC_UPLOAD_ASYNC_MAX", "65536"))
-    if t.numel() * t.element_size() > cap:
+    if not t.numel():
         return t.to(device)
-    out = staging(device).put(t, device) if t.numel() else None
+    if t.numel() * t.element_size() > cap:
+        out = staging(device).put(t, device, by_kernel=True) if os.environ.get("BIGC_UPLOAD_KERNEL", "1") != "0" else None
+        return out if out is not None else t.to(device)
+    out = staging(device).put(t, device)
     return out if out is not None else t.to(device)
 
 

@@ -49,7 +49,7 @@ def adj_from_viou(vi, adj, viou_th):
     return adj[:, :, pick] * has[None, None, :].to(adj.dtype)
 
 
-def viou_tables_launch(lib, packed, gt_graph_list):
+def viou_tables_launch(lib, packed, gt_graph_list, download=True):
     """Queues the vIoU kernel (``bigc_viou_matrix``: every proposal against every GT trajectory of its video; the reference loops
     over pairs in Python, models/model_0v10.py:576-581, tools/train_vidor.py:110-121) and the copy of its result into pinned host
     memory on the current stream, and returns without waiting: the tables depend on the boxes only, so the step queues them BEFORE
@@ -66,6 +66,8 @@ def viou_tables_launch(lib, packed, gt_graph_list):
     _lib.check(lib.bigc_viou_matrix(_lib.current_stream(), packed.boxes.data_ptr(), packed.trk_row_off.data_ptr(), packed.trk_dura.data_ptr(),
                                     packed.vid_trk_off.data_ptr(), gt_boxes.data_ptr(), gt_row_off.data_ptr(), gt_dura.data_ptr(),
                                     gt_traj_off.data_ptr(), packed.n_vid, packed.max_trk, g_max, out.data_ptr()))
+    if not download:                                     # the tables stay on the device (``bigc_align_adjacency`` thresholds them there)
+        return None, None, n_traj, (out, gt_boxes, gt_row_off, gt_dura, gt_traj_off)
     host = _lib.staging(dev).download_buffer(out.shape, torch.float32, "viou")
     host.copy_(out, non_blocking=True)
     done = torch.cuda.Event()
@@ -85,12 +87,12 @@ def viou_tables(lib, packed, gt_graph_list):
     return viou_tables_wait(packed, viou_tables_launch(lib, packed, gt_graph_list))
 
 
-def align_launch(lib, packed, gt_graph_list):
+def align_launch(lib, packed, gt_graph_list, download=True):
     """First half of ``enti_viou_align`` for every video of the batch: reproduces the reference's in-place
     ``gt_graph.traj_durations[:, 1] -= 1`` (:567) and queues the vIoU tables."""
     for g in gt_graph_list:
         g.traj_durations[:, 1] -= 1
-    return viou_tables_launch(lib, packed, gt_graph_list)
+    return viou_tables_launch(lib, packed, gt_graph_list, download)
 
 
 def align_finish(packed, gt_graph_list, pending, viou_th):
@@ -107,8 +109,42 @@ class TrainContext(object):
     pass
 
 
+class MatchIndices(object):
+    """``model.last_match_indices`` of a step matched on the device: the list of ``(query indices, GT indices)`` per video that
+    ``scipy.optimize.linear_sum_assignment`` returns (query indices ascending), downloaded when somebody looks at it."""
+
+    def __init__(self, match_g, n_vid, n_query, check):
+        self._m, self._shape, self._check, self._list = match_g, (n_vid, n_query), check, None
+
+    def _get(self):
+        if self._list is None:
+            m = self._m.cpu().numpy().reshape(self._shape)
+            self._check(wait=True)
+            self._list = [(np.nonzero(r >= 0)[0], r[r >= 0].astype(np.int64)) for r in m]
+            self._m = None
+        return self._list
+
+    def __len__(self):
+        return self._shape[0]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+
+def match_on_device(gt_graph_list, n_query):
+    """The device matching (``bigc_align_adjacency`` + ``bigc_hungarian``) covers what training batches look like: every video
+    has GT trajectories and fewer GT predicates than the model has queries (then every GT predicate is matched and the loss
+    normalisers are known without looking at the assignment).  Anything else, or BIGC_MATCH_ON_HOST=1, takes the host route."""
+    if os.environ.get("BIGC_MATCH_ON_HOST", "0") == "1":
+        return False
+    return all(0 < int(g.adj_matrix.shape[1]) < n_query and len(g.traj_bboxes) > 0 for g in gt_graph_list)
+
+
 def forward(model, engine, packed, gt_graph_list):
-    """Device forward + host matching. Returns (loss_terms (3,) device tensor, ctx)."""
+    """Device forward + matching. Returns (loss_terms (3,) device tensor, ctx)."""
     lib, c = engine.lib, engine.c
     dev = packed.device
     B, NT, Q, P = packed.n_vid, packed.n_trk, c.num_querys, c.num_pred_cats
@@ -120,18 +156,14 @@ def forward(model, engine, packed, gt_graph_list):
     ctx.ws = torch.empty((need,), dtype=torch.uint8, device=dev)
     ctx.logits = torch.empty((B * Q, P), dtype=torch.float32, device=dev)
     ctx.att = torch.empty((2 * Q * NT,), dtype=torch.float32, device=dev)
+    ctx.on_device = match_on_device(gt_graph_list, Q)
     stream = _lib.current_stream()
     mark("fwd: buffers")
-    pending = align_launch(lib, packed, gt_graph_list)          # vIoU tables first: their host half overlaps the model forward
+    engine.check_match_flags()                                  # (an invalid cost matrix of an EARLIER device-matched step raises here)
+    pending = align_launch(lib, packed, gt_graph_list, download=not ctx.on_device)      # vIoU tables first: they depend on the boxes only
     mark("fwd: vIoU launch + GT upload")
-    _lib.check(lib.bigc_train_forward(engine.handle, stream, ctypes.byref(ctx.batch), ctx.ws.data_ptr(), ctx.ws.numel(),
-                                      ctx.logits.data_ptr(), ctx.att.data_ptr()))
-    mark("fwd: bigc_train_forward launches")
-    # ground truth, aligned to the proposals on the host
     n_trk = np.diff(packed.vid_trk_off_host)
-    adjs = align_finish(packed, gt_graph_list, pending, model.positive_vIoU_th)
-    mark("fwd: vIoU wait + thresholds (host)")
-    n_gt = [int(a.shape[1]) for a in adjs]
+    n_gt = [int(g.adj_matrix.shape[1]) for g in gt_graph_list]
     assert min(n_gt) > 0, "every training video needs at least one GT predicate"
     g_off = np.concatenate([[0], np.cumsum(n_gt)])
     adj_off = np.concatenate([[0], np.cumsum([2 * g * int(n) for g, n in zip(n_gt, n_trk)])]).astype(np.int64)
@@ -142,32 +174,71 @@ def forward(model, engine, packed, gt_graph_list):
     ints[n_off:] = gt_pred_host
     ints = _lib.upload(ints, dev)
     ctx.g_off, ctx.gt_pred = ints[:B + 1], ints[n_off:]
-    ctx.adj_off = _lib.upload(adj_off[:-1].copy(), dev)
-    ctx.gt_adj = _lib.upload(torch.cat([a.reshape(-1) for a in adjs]), dev)
     g_max = int(max(n_gt))
+    if ctx.on_device:
+        # the GT adjacency as given (2, G_v, T_v) goes up; the thresholding of the vIoU tables into the aligned adjacency runs on the
+        # device, queued BEFORE the model forward like the tables themselves
+        n_traj = pending[2]
+        raw_off = np.concatenate([[0], np.cumsum([2 * g * t for g, t in zip(n_gt, n_traj)])]).astype(np.int64)
+        for g, t in zip(gt_graph_list, n_traj):
+            assert tuple(g.adj_matrix.shape) == (2, int(g.adj_matrix.shape[1]), t), "adj_matrix must be (2, n GT predicates, n GT trajectories)"
+        offs = _lib.upload(np.concatenate([adj_off[:-1], raw_off[:-1]]), dev)
+        ctx.adj_off, raw_off_dev = offs[:B], offs[B:]
+        raw = _lib.upload(torch.cat([g.adj_matrix.detach().cpu().float().reshape(-1) for g in gt_graph_list]), dev)
+        ctx.gt_adj = torch.empty((int(adj_off[-1]),), dtype=torch.float32, device=dev)
+        viou_dev, _gt_boxes, _gt_row_off, _gt_dura, gt_traj_off = pending[3]
+        _lib.check(lib.bigc_align_adjacency(stream, viou_dev.data_ptr(), int(viou_dev.shape[1]), int(viou_dev.shape[2]), packed.vid_trk_off.data_ptr(),
+                                            gt_traj_off.data_ptr(), raw.data_ptr(), raw_off_dev.data_ptr(), ctx.g_off.data_ptr(), ctx.adj_off.data_ptr(),
+                                            B, float(model.positive_vIoU_th), ctx.gt_adj.data_ptr()))
+        mark("fwd: GT adjacency upload + align launch")
+    _lib.check(lib.bigc_train_forward(engine.handle, stream, ctypes.byref(ctx.batch), ctx.ws.data_ptr(), ctx.ws.numel(),
+                                      ctx.logits.data_ptr(), ctx.att.data_ptr()))
+    mark("fwd: bigc_train_forward launches")
+    if not ctx.on_device:
+        # ground truth, aligned to the proposals on the host while the forward runs
+        adjs = align_finish(packed, gt_graph_list, pending, model.positive_vIoU_th)
+        mark("fwd: vIoU wait + thresholds (host)")
+        assert [int(a.shape[1]) for a in adjs] == n_gt
+        ctx.adj_off = _lib.upload(adj_off[:-1].copy(), dev)
+        ctx.gt_adj = _lib.upload(torch.cat([a.reshape(-1) for a in adjs]), dev)
     cost = torch.zeros((B, Q, g_max), dtype=torch.float32, device=dev)
     _lib.check(lib.bigc_match_cost(stream, ctx.logits.data_ptr(), P, ctx.att.data_ptr(), packed.vid_trk_off.data_ptr(), ctx.g_off.data_ptr(),
                                    ctx.gt_pred.data_ptr(), ctx.gt_adj.data_ptr(), ctx.adj_off.data_ptr(), B, Q, g_max,
                                    float(model.cost_factor["classification"]), float(model.cost_factor["adj_matrix"]), cost.data_ptr()))
     mark("fwd: adjacency upload + cost launch")
-    cost_host = _lib.download(cost, "cost").numpy()      # D2H sync, as the reference's cost_all.cpu() (:637)
-    mark("fwd: WAIT for the forward (cost.cpu())")
-    target = np.zeros((B, Q), dtype=np.int32)
-    match_g = np.full((B, Q), -1, dtype=np.int32)
-    ctx.indices = []
-    n_adj = 0
-    for v in range(B):
-        iq, ig = linear_sum_assignment(cost_host[v, :, :n_gt[v]])
-        ctx.indices.append((iq, ig))
-        target[v, iq] = gt_pred_host[g_off[v] + ig].numpy()
-        match_g[v, iq] = ig
-        n_adj += 2 * len(iq) * int(n_trk[v])
-    mark("fwd: Hungarian (host)")
-    ctx.n_pos = float((target != 0).sum())
-    ctx.n_neg = float(max(1, (target == 0).sum()))
-    ctx.n_adj = float(n_adj)
-    both = _lib.upload(np.stack([target.reshape(-1), match_g.reshape(-1)]), dev)
-    ctx.target, ctx.match_g = both[0], both[1]
+    if ctx.on_device:
+        # scipy's algorithm on the device: the host neither waits for the forward nor sees the assignment.  Every GT predicate is
+        # matched (G_v < Q), so the normalisers of the three means are those of the ground truth.
+        ctx.target = torch.empty((B * Q,), dtype=torch.int32, device=dev)
+        ctx.match_g = torch.empty((B * Q,), dtype=torch.int32, device=dev)
+        _lib.check(lib.bigc_hungarian(stream, cost.data_ptr(), ctx.g_off.data_ptr(), ctx.gt_pred.data_ptr(), B, Q, g_max,
+                                      ctx.target.data_ptr(), ctx.match_g.data_ptr(), engine.match_flag(dev).data_ptr()))
+        engine.queue_match_flag_check(dev)
+        ctx.indices = MatchIndices(ctx.match_g, B, Q, engine.check_match_flags)
+        n_pos = int((gt_pred_host != 0).sum())
+        ctx.n_pos = float(n_pos)
+        ctx.n_neg = float(max(1, B * Q - n_pos))
+        ctx.n_adj = float(sum(2 * g * int(n) for g, n in zip(n_gt, n_trk)))
+        mark("fwd: Hungarian launch (device)")
+    else:
+        cost_host = _lib.download(cost, "cost").numpy()      # D2H sync, as the reference's cost_all.cpu() (:637)
+        mark("fwd: WAIT for the forward (cost.cpu())")
+        target = np.zeros((B, Q), dtype=np.int32)
+        match_g = np.full((B, Q), -1, dtype=np.int32)
+        ctx.indices = []
+        n_adj = 0
+        for v in range(B):
+            iq, ig = linear_sum_assignment(cost_host[v, :, :n_gt[v]])
+            ctx.indices.append((iq, ig))
+            target[v, iq] = gt_pred_host[g_off[v] + ig].numpy()
+            match_g[v, iq] = ig
+            n_adj += 2 * len(iq) * int(n_trk[v])
+        mark("fwd: Hungarian (host)")
+        ctx.n_pos = float((target != 0).sum())
+        ctx.n_neg = float(max(1, (target == 0).sum()))
+        ctx.n_adj = float(n_adj)
+        both = _lib.upload(np.stack([target.reshape(-1), match_g.reshape(-1)]), dev)
+        ctx.target, ctx.match_g = both[0], both[1]
     ctx.ldg = (P + 3) // 4 * 4
     ctx.dlogits = torch.zeros((B * Q, ctx.ldg), dtype=torch.float32, device=dev)
     ctx.datt = torch.empty_like(ctx.att)
@@ -177,8 +248,17 @@ def forward(model, engine, packed, gt_graph_list):
     return ctx.loss.clone(), ctx
 
 
-def loss_grad(model, engine, ctx, gs_pos, gs_neg, gs_adj):
+def loss_grad(model, engine, ctx, gs_pos, gs_neg, gs_adj, upstream=None):
+    """loss terms + d logits / d att; ``upstream`` = the three upstream gradients as a (3,) f32 DEVICE tensor instead of host floats"""
     c, packed = engine.c, ctx.packed
+    if upstream is not None:
+        _lib.check(engine.lib.bigc_loss_grad_dev(
+            _lib.current_stream(), ctx.logits.data_ptr(), c.num_pred_cats, ctx.att.data_ptr(), packed.vid_trk_off.data_ptr(),
+            ctx.g_off.data_ptr(), ctx.gt_adj.data_ptr(), ctx.adj_off.data_ptr(), ctx.target.data_ptr(), ctx.match_g.data_ptr(),
+            packed.n_vid, c.num_querys, ctx.n_pos, ctx.n_neg, ctx.n_adj, float(model.loss_factor["classification"]),
+            float(model.loss_factor["adj_matrix"]), float(model.neg_weight), upstream.data_ptr(),
+            ctx.loss.data_ptr(), ctx.dlogits.data_ptr(), ctx.ldg, ctx.datt.data_ptr()))
+        return
     _lib.check(engine.lib.bigc_loss_grad(
         _lib.current_stream(), ctx.logits.data_ptr(), c.num_pred_cats, ctx.att.data_ptr(), packed.vid_trk_off.data_ptr(),
         ctx.g_off.data_ptr(), ctx.gt_adj.data_ptr(), ctx.adj_off.data_ptr(), ctx.target.data_ptr(), ctx.match_g.data_ptr(),
@@ -213,9 +293,14 @@ def backward(model, engine, ctx, grad_terms, named_params):
     """Runs the HIP backward; returns one gradient tensor per entry of ``named_params`` (views of a single flat
     buffer -- the message of the data-parallel all-reduce), ``None`` for frozen parameters."""
     mark("autograd glue between forward and backward")
-    g = [float(x) for x in grad_terms.detach().cpu().tolist()]
-    mark("bwd: WAIT for the upstream gradient (.cpu())")
-    loss_grad(model, engine, ctx, g[0], g[1], g[2])
+    if grad_terms.is_cuda and os.environ.get("BIGC_UPSTREAM_ON_HOST", "0") != "1":
+        up = grad_terms.detach().to(torch.float32).contiguous()           # read by the kernel where it lies: no wait for the forward
+        loss_grad(model, engine, ctx, 1.0, 1.0, 1.0, upstream=up)
+        mark("bwd: loss gradient launch (upstream on the device)")
+    else:
+        g = [float(x) for x in grad_terms.detach().cpu().tolist()]
+        mark("bwd: WAIT for the upstream gradient (.cpu())")
+        loss_grad(model, engine, ctx, g[0], g[1], g[2])
     # The backward GEMMs split their f32 operands into two f16 (csrc/linear_split.hip): exact for magnitudes inside the
     # f16 range, so the seed gradients are brought to a magnitude of ~8 by a power of two (exact) and the parameter
     # gradients scaled back at the end -- the loss scaling of mixed-precision training, here only to keep f32 accuracy.

@@ -233,3 +233,48 @@ extern "C" int bigc_pack_video_meta(void* stream, const uint64_t* cat_src, const
     BIGC_LAUNCH_CHECK("pack_video_meta");
     return BIGC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Host -> device copy done by a kernel: `src` is page-locked host memory mapped into the device's address space (what
+// torch's pin_memory() / hipHostMalloc return), read by the GPU over the host link: 300 KB in 10 us, ordered on the compute stream like
+// every other launch, no copy queue or copy engine involved (bigc_hip/_lib.py: upload).
+namespace {
+__global__ __launch_bounds__(256) void copy_mapped_kernel(unsigned char* __restrict__ dst, const unsigned char* __restrict__ src, long n16, long nbytes) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) ((u32x4*)dst)[i] = __builtin_nontemporal_load((const u32x4*)src + i);
+    for (long i = n16 * 16 + (long)blockIdx.x * 256 + threadIdx.x; i < nbytes; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" int bigc_copy_mapped(void* stream, void* dst, const void* src_mapped, long nbytes) {
+    BIGC_CHECK_ARG(dst && src_mapped, "copy_mapped: null pointer");
+    if (nbytes <= 0) return BIGC_OK;
+    const bool al = ((((uintptr_t)dst) | ((uintptr_t)src_mapped)) & 15) == 0;
+    const long n16 = al ? nbytes / 16 : 0;
+    const long units = al ? n16 + 15 : nbytes;
+    const int grid = (int)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048);
+    ProfScope ps(stream, FAM_PACK, 0.0, 2.0 * (double)nbytes);
+    hipLaunchKernelGGL(copy_mapped_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned char*)dst, (const unsigned char*)src_mapped, n16, nbytes);
+    BIGC_LAUNCH_CHECK("copy_mapped");
+    return BIGC_OK;
+}
+
+// A progress mark the host can read without asking the runtime: *mapped_word = value once everything queued on `stream` before this
+// call has run (mapped_word: page-locked host memory mapped into the device's address space): the host polls a word instead of
+// creating, recording and waiting on an event per step.
+// or_flag (device, may be null): when *or_flag != 0, mapped_word[1] = value too -- the error flag of a step travels with its mark.
+namespace {
+__global__ void stamp_kernel(volatile unsigned long long* mapped_word, unsigned long long value, const int* __restrict__ or_flag) {
+    if (or_flag && *or_flag) mapped_word[1] = value;
+    __threadfence_system();
+    mapped_word[0] = value;
+    __threadfence_system();
+}
+}  // namespace
+
+extern "C" int bigc_stamp(void* stream, void* mapped_word, unsigned long long value, const int* or_flag) {
+    BIGC_CHECK_ARG(mapped_word && (((uintptr_t)mapped_word) & 7) == 0, "stamp: null or misaligned pointer");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (volatile unsigned long long*)mapped_word, value, or_flag);
+    BIGC_LAUNCH_CHECK("stamp");
+    return BIGC_OK;
+}

@@ -62,9 +62,11 @@ __global__ __launch_bounds__(64) void loss_grad_kernel(const float* __restrict__
                                                        const float* __restrict__ gt_adj, const int64_t* __restrict__ adj_off,
                                                        const int32_t* __restrict__ target, const int32_t* __restrict__ match_g, int nq,
                                                        float n_pos, float n_neg, float n_adj, float fc, float fa, float neg_weight,
-                                                       float gs_pos, float gs_neg, float gs_adj, float* __restrict__ loss_out, float* __restrict__ dlogits, int ldg,
+                                                       float gs_pos, float gs_neg, float gs_adj, const float* __restrict__ gs_dev,
+                                                       float* __restrict__ loss_out, float* __restrict__ dlogits, int ldg,
                                                        float* __restrict__ datt) {
     const int row = blockIdx.x, lane = threadIdx.x;
+    if (gs_dev) { gs_pos = gs_dev[0]; gs_neg = gs_dev[1]; gs_adj = gs_dev[2]; }
     const int v = row / nq, q = row - v * nq;
     const int e0 = e_off[v], ne = e_off[v + 1] - e0;
     if (ne <= 0) return;
@@ -111,10 +113,10 @@ extern "C" int bigc_match_cost(void* stream, const float* logits, int n_pcat, co
     return BIGC_OK;
 }
 
-extern "C" int bigc_loss_grad(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
-                              const float* gt_adj, const int64_t* adj_off, const int32_t* target, const int32_t* match_g, int n_vid, int nq,
-                              float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight, float gs_pos, float gs_neg, float gs_adj,
-                              float* loss_out, float* dlogits, int ldg, float* datt) {
+static int loss_grad_launch(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
+                            const float* gt_adj, const int64_t* adj_off, const int32_t* target, const int32_t* match_g, int n_vid, int nq,
+                            float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight, float gs_pos, float gs_neg, float gs_adj,
+                            const float* gs_dev, float* loss_out, float* dlogits, int ldg, float* datt) {
     BIGC_CHECK_ARG(logits && att && e_off && g_off && gt_adj && adj_off && target && match_g && loss_out && dlogits && datt,
                    "loss_grad: null pointer");
     hipError_t e = hipMemsetAsync(loss_out, 0, 3 * sizeof(float), (hipStream_t)stream);
@@ -122,9 +124,28 @@ extern "C" int bigc_loss_grad(void* stream, const float* logits, int n_pcat, con
     if (n_vid <= 0) return BIGC_OK;
     ProfScope ps(stream, FAM_LOSS, 0.0, 0.0);
     hipLaunchKernelGGL(loss_grad_kernel, dim3(n_vid * nq), dim3(64), 0, (hipStream_t)stream, logits, n_pcat, att, e_off, g_off, gt_adj,
-                       adj_off, target, match_g, nq, n_pos, n_neg, n_adj, loss_cls, loss_adj, neg_weight, gs_pos, gs_neg, gs_adj, loss_out, dlogits, ldg, datt);
+                       adj_off, target, match_g, nq, n_pos, n_neg, n_adj, loss_cls, loss_adj, neg_weight, gs_pos, gs_neg, gs_adj, gs_dev, loss_out, dlogits, ldg, datt);
     BIGC_LAUNCH_CHECK("loss_grad");
     return BIGC_OK;
+}
+
+extern "C" int bigc_loss_grad(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
+                              const float* gt_adj, const int64_t* adj_off, const int32_t* target, const int32_t* match_g, int n_vid, int nq,
+                              float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight, float gs_pos, float gs_neg, float gs_adj,
+                              float* loss_out, float* dlogits, int ldg, float* datt) {
+    return loss_grad_launch(stream, logits, n_pcat, att, e_off, g_off, gt_adj, adj_off, target, match_g, n_vid, nq, n_pos, n_neg, n_adj, loss_cls, loss_adj,
+                            neg_weight, gs_pos, gs_neg, gs_adj, nullptr, loss_out, dlogits, ldg, datt);
+}
+
+// the same with the three upstream gradients (d loss / d cls_pos, cls_neg, adj) read from device memory: the backward of a step that
+// never waits for the GPU (bigc_hip/train_step.py)
+extern "C" int bigc_loss_grad_dev(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
+                                  const float* gt_adj, const int64_t* adj_off, const int32_t* target, const int32_t* match_g, int n_vid, int nq,
+                                  float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight, const float* upstream3,
+                                  float* loss_out, float* dlogits, int ldg, float* datt) {
+    BIGC_CHECK_ARG(upstream3, "loss_grad_dev: null pointer");
+    return loss_grad_launch(stream, logits, n_pcat, att, e_off, g_off, gt_adj, adj_off, target, match_g, n_vid, nq, n_pos, n_neg, n_adj, loss_cls, loss_adj,
+                            neg_weight, 1.f, 1.f, 1.f, upstream3, loss_out, dlogits, ldg, datt);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -256,5 +277,200 @@ extern "C" int bigc_viou_matrix(void* stream, const float* boxes, const int32_t*
     hipLaunchKernelGGL(viou_matrix_kernel, dim3(g_max, max_trk, n_vid), dim3(64), 0, (hipStream_t)stream, boxes, trk_row_off, trk_dura, e_off,
                        gt_boxes, gt_row_off, gt_dura, gt_traj_off, max_trk, g_max, out);
     BIGC_LAUNCH_CHECK("viou_matrix");
+    return BIGC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The host half of the reference's matching, on the device (bigc_hip/train_step.py: a training step without a host round trip).
+//
+// align_adjacency: the tail of ``enti_viou_align`` (models/model_0v10.py:583-602).  From the vIoU table vi (n proposals, nt GT
+// trajectories) of a video: mask = vi > th; a GT trajectory no proposal passes for takes its best proposal; has[p] = any(mask[p, :]);
+// pick[p] = argmax_g vi[p, g]; out[r, g, p] = adj[r, g, pick[p]] * has[p].  torch.argmax returns the first maximum.  One workgroup per video.
+namespace {
+__global__ __launch_bounds__(256) void align_adjacency_kernel(const float* __restrict__ viou, int max_trk, int t_max, const int32_t* __restrict__ e_off,
+                                                              const int32_t* __restrict__ gt_traj_off, const float* __restrict__ adj_raw,
+                                                              const int64_t* __restrict__ raw_off, const int32_t* __restrict__ g_off,
+                                                              const int64_t* __restrict__ adj_off, float th, float* __restrict__ out) {
+    extern __shared__ int align_sm[];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const int ne = e_off[v + 1] - e_off[v], nt = gt_traj_off[v + 1] - gt_traj_off[v], ng = g_off[v + 1] - g_off[v];
+    if (ne <= 0 || nt <= 0) return;
+    int* pick = align_sm;
+    int* has = align_sm + ne;
+    const float* vi = viou + (size_t)v * max_trk * t_max;
+    for (int p = tid; p < ne; p += 256) {
+        const float* r = vi + (size_t)p * t_max;
+        int best = 0, any = 0;
+        float bv = r[0];
+        for (int g = 0; g < nt; ++g) {
+            const float x = r[g];
+            any |= x > th;
+            if (x > bv) { bv = x; best = g; }
+        }
+        pick[p] = best;
+        has[p] = any;
+    }
+    __syncthreads();
+    for (int g = tid; g < nt; g += 256) {
+        int best = 0, cnt = 0;
+        float bv = vi[g];
+        for (int p = 0; p < ne; ++p) {
+            const float x = vi[(size_t)p * t_max + g];
+            cnt += x > th;
+            if (x > bv) { bv = x; best = p; }
+        }
+        if (cnt == 0) has[best] = 1;                     // (several trajectories may write the same 1)
+    }
+    __syncthreads();
+    const float* adj = adj_raw + raw_off[v];
+    float* o = out + adj_off[v];
+    const long total = (long)2 * ng * ne;
+    for (long i = tid; i < total; i += 256) {
+        const long rg = i / ne;
+        const int p = (int)(i - rg * ne);
+        o[i] = adj[rg * nt + pick[p]] * (has[p] ? 1.f : 0.f);
+    }
+}
+
+// hungarian: scipy.optimize.linear_sum_assignment (the reference's call, models/model_0v10.py:637) on cost[v, :, :n_gt[v]] of every
+// video.  scipy 1.x solves the rectangular problem with the shortest-augmenting-path algorithm of Crouse, "On implementing 2D
+// rectangular assignment algorithms" (IEEE T-AES 2016), in float64, transposing so that rows are the smaller side: here rows = the
+// n_gt < nq GT predicates, columns = the queries.  This kernel restates that algorithm step for step, including the order in which
+// equal candidates are taken (scipy scans the not-yet-visited columns in the order of its `remaining` list -- initially nc-1 .. 0,
+// the last entry moved into a visited column's slot -- and among equal lowest reduced costs keeps the first one met, except that a
+// later UNASSIGNED column replaces it), so the assignment is scipy's also where the optimum is not unique (duplicated GT predicates).
+// The additions are done in the same order in IEEE float64.  One wave per video; every lane holds the scalars of the scan, the
+// column scan and the arg-min reduction are spread over the lanes.
+// bad[0] |= 1: a cost is NaN / -inf (scipy: ValueError "matrix contains invalid numeric entries") or the problem is infeasible; the
+// video is then left unmatched (target 0, match -1).
+struct Cand { double val; int un; int it; };
+__device__ __forceinline__ bool cand_better(const Cand& a, const Cand& b) {       // a before b in scipy's scan result
+    if (a.val != b.val) return a.val < b.val;
+    if (a.un != b.un) return a.un > b.un;
+    return a.un ? a.it > b.it : a.it < b.it;
+}
+
+__global__ __launch_bounds__(64) void hungarian_kernel(const float* __restrict__ cost, const int32_t* __restrict__ g_off,
+                                                       const int32_t* __restrict__ gt_pred, int nq, int g_max, int stage_cost,
+                                                       int32_t* __restrict__ target, int32_t* __restrict__ match_g, int* __restrict__ bad) {
+    extern __shared__ double hung_sm[];
+    const int v = blockIdx.x, lane = threadIdx.x;
+    const int g0 = g_off[v], nr = g_off[v + 1] - g0, nc = nq;
+    double* u = hung_sm;                        // nq each (nr < nq)
+    double* vv = u + nq;
+    double* sp = vv + nq;
+    int* path = (int*)(sp + nq);
+    int* row4col = path + nq;
+    int* col4row = row4col + nq;
+    int* remaining = col4row + nq;
+    int* SR = remaining + nq;
+    int* SC = SR + nq;
+    float* cl = (float*)(SC + nq);              // nr x nc, when staged
+    const float* cv = cost + (size_t)v * nq * g_max;
+    int invalid = 0;
+    for (int j = lane; j < nc; j += 64) {
+        vv[j] = 0.0; row4col[j] = -1;
+        for (int i = 0; i < nr; ++i) {
+            const float x = cv[(size_t)j * g_max + i];
+            invalid |= (x != x) || (x == -INFINITY);
+            if (stage_cost) cl[i * nc + j] = x;
+        }
+    }
+    for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+    invalid = __any(invalid);
+    __syncthreads();
+    for (int cur = 0; cur < nr && !invalid; ++cur) {
+        double minVal = 0.0;
+        int num_remaining = nc, i = cur, sink = -1;
+        for (int it = lane; it < nc; it += 64) { remaining[it] = nc - it - 1; SC[it] = 0; sp[it] = INFINITY; }
+        for (int r = lane; r < nr; r += 64) SR[r] = 0;
+        __syncthreads();
+        while (sink == -1) {
+            if (lane == 0) SR[i] = 1;
+            const double ui = u[i];
+            Cand best{INFINITY, 0, 0x7fffffff};
+            bool have = false;
+            for (int it = lane; it < num_remaining; it += 64) {
+                const int j = remaining[it];
+                const double c = (double)(stage_cost ? cl[i * nc + j] : cv[(size_t)j * g_max + i]);
+                const double r = minVal + c - ui - vv[j];
+                double s = sp[j];
+                if (r < s) { path[j] = i; sp[j] = r; s = r; }
+                const Cand x{s, row4col[j] == -1, it};
+                // scipy's scan starts from lowest = inf, index = -1: a candidate at +inf is only taken when its column is unassigned
+                if (!have) { if (s < INFINITY || x.un) { best = x; have = true; } }
+                else if (cand_better(x, best)) best = x;
+            }
+            // reduction over the lanes (lanes without a candidate carry val = inf, un = 0, it = int max: they lose against every real one,
+            // and an all-inf assigned scan leaves index -1 = infeasible below)
+            if (!have) best = Cand{INFINITY, -1, 0x7fffffff};
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                Cand y;
+                y.val = __shfl_xor(best.val, o); y.un = __shfl_xor(best.un, o); y.it = __shfl_xor(best.it, o);
+                if (y.un >= 0 && (best.un < 0 || cand_better(y, best))) best = y;
+            }
+            if (best.un < 0 || !(best.val < INFINITY)) { invalid = 1; break; }
+            minVal = best.val;
+            const int j = remaining[best.it];
+            const int r4 = row4col[j];
+            __syncthreads();                                 // every lane has read remaining[] / row4col[] before lane 0 rewrites them
+            if (r4 == -1) sink = j; else i = r4;
+            --num_remaining;
+            if (lane == 0) { SC[j] = 1; remaining[best.it] = remaining[num_remaining]; }
+            __syncthreads();
+        }
+        if (invalid) break;
+        // dual update, then the augmentation along the path
+        if (lane == 0) u[cur] += minVal;
+        for (int r = lane; r < nr; r += 64) if (SR[r] && r != cur) u[r] += minVal - sp[col4row[r]];
+        for (int j = lane; j < nc; j += 64) if (SC[j]) vv[j] -= minVal - sp[j];
+        __syncthreads();
+        if (lane == 0) {
+            int j = sink;
+            while (true) {
+                const int r = path[j];
+                row4col[j] = r;
+                const int t = col4row[r]; col4row[r] = j; j = t;
+                if (r == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    if (invalid && lane == 0) atomicOr(bad, 1);
+    for (int j = lane; j < nc; j += 64) {
+        const int r = invalid ? -1 : row4col[j];
+        match_g[(size_t)v * nq + j] = r;
+        target[(size_t)v * nq + j] = r >= 0 ? gt_pred[g0 + r] : 0;
+    }
+}
+}  // namespace
+
+extern "C" int bigc_align_adjacency(void* stream, const float* viou, int max_trk, int t_max, const int32_t* e_off, const int32_t* gt_traj_off,
+                                    const float* adj_raw, const int64_t* raw_off, const int32_t* g_off, const int64_t* adj_off, int n_vid,
+                                    float viou_th, float* gt_adj) {
+    BIGC_CHECK_ARG(viou && e_off && gt_traj_off && adj_raw && raw_off && g_off && adj_off && gt_adj, "align_adjacency: null pointer");
+    BIGC_CHECK_ARG(max_trk > 0 && max_trk <= 8192, "align_adjacency: max_trk=%d outside (0, 8192]", max_trk);
+    if (n_vid <= 0) return BIGC_OK;
+    ProfScope ps(stream, FAM_LOSS, 0.0, 0.0);
+    hipLaunchKernelGGL(align_adjacency_kernel, dim3(n_vid), dim3(256), 2 * max_trk * sizeof(int), (hipStream_t)stream, viou, max_trk, t_max, e_off,
+                       gt_traj_off, adj_raw, raw_off, g_off, adj_off, viou_th, gt_adj);
+    BIGC_LAUNCH_CHECK("align_adjacency");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_hungarian(void* stream, const float* cost, const int32_t* g_off, const int32_t* gt_pred, int n_vid, int nq, int g_max,
+                              int32_t* target, int32_t* match_g, int* bad) {
+    BIGC_CHECK_ARG(cost && g_off && gt_pred && target && match_g && bad, "hungarian: null pointer");
+    BIGC_CHECK_ARG(nq > 0 && nq <= 1024, "hungarian: nq=%d outside (0, 1024]", nq);
+    BIGC_CHECK_ARG(g_max > 0 && g_max < nq, "hungarian: g_max=%d must be in (0, nq=%d): every video needs fewer GT predicates than queries", g_max, nq);
+    if (n_vid <= 0) return BIGC_OK;
+    const size_t base = (size_t)nq * (3 * sizeof(double) + 6 * sizeof(int));
+    const size_t staged = (size_t)nq * g_max * sizeof(float);
+    const int stage = base + staged <= 60 * 1024;
+    ProfScope ps(stream, FAM_LOSS, 0.0, 0.0);
+    hipLaunchKernelGGL(hungarian_kernel, dim3(n_vid), dim3(64), base + (stage ? staged : 0), (hipStream_t)stream, cost, g_off, gt_pred, nq, g_max, stage,
+                       target, match_g, bad);
+    BIGC_LAUNCH_CHECK("hungarian");
     return BIGC_OK;
 }

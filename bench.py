@@ -257,7 +257,7 @@ def train_step_fn(model, props, gts, gt_duras, opt, dist):
 
 def train_main(args):
     """`--mode train`: the training step of BASELINE configs[4] (BIG-C DP training) on synthetic videos:
-    zero_grad, HIP forward + host Hungarian, HIP backward, one flat-gradient all-reduce over RCCL (N>1),
+    zero_grad, HIP forward + matching (scipy's assignment algorithm as a device kernel), HIP backward, one flat-gradient all-reduce over RCCL (N>1),
     clip_grad_norm_(5), Adam -- the loop body of tools/train_vidvrd.py:151-164. Not the headline metric."""
     from bigc_hip.shard import allreduce_gradients, max_over_ranks
     rank, world, device, dist = init_dist(args)
@@ -680,7 +680,7 @@ def train_leg(args, lib, device):
                                        kernel_families_ms_per_step={k: round(v["ms"] / steps, 3) for k, v in fam.items()})
         del model, props, gts, opt
         torch.cuda.empty_cache()
-    out["workload"] = ("BIG-C model_0v10 training step (exp2 dims, dropout on), synthetic videos x N=%d: zero_grad + forward + host Hungarian + "
+    out["workload"] = ("BIG-C model_0v10 training step (exp2 dims, dropout on), synthetic videos x N=%d: zero_grad + forward + matching on the device (GT alignment + scipy's assignment algorithm, no host round trip) + "
                        "backward + clip_grad_norm_ + Adam (tools/train_vidvrd.py:151-164)" % args.n_trajs)
     return out
 

@@ -341,7 +341,7 @@ int bigc_match_cost(void* stream, const float* logits, int n_pcat, const float* 
                     float cost_cls, float cost_adj, float* cost);
 /* Loss terms (models/model_0v10.py:648-703) and their gradients. target (B*nq) = matched GT predicate class or 0,
  *   match_g (B*nq) = matched GT index or -1; n_pos/n_neg/n_adj = element counts of the three means.
- *   loss_out[3] = {cls_pos, cls_neg, adj}; dlogits (B*nq, ldg) (pad columns untouched), datt like att. */
+ *   loss_out[3] = {cls_pos, cls_neg, adj}; dlogits (B*nq, ldg) (pad columns untouched), datt like att; both NULL: the loss terms only. */
 int bigc_loss_grad(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
                    const float* gt_adj, const int64_t* adj_off, const int32_t* target, const int32_t* match_g, int n_vid, int nq,
                    float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight,

@@ -252,3 +252,22 @@ def test_invalid_costs_of_a_device_matched_step_raise_at_the_next_look(monkeypat
     model(props, gts)
     with pytest.raises(ValueError):
         list(model.last_match_indices)
+
+
+def test_stamp_marks_progress_in_a_pinned_word():
+    lib = _lib.load()
+    words = torch.zeros((2,), dtype=torch.int64).pin_memory()
+    flag = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    a = torch.randn(2048, 2048, device=DEV)
+    for _ in range(6):
+        a @ a
+    _lib.check(lib.bigc_stamp(S(), words.data_ptr(), 7, flag.data_ptr()))
+    flag.fill_(1)
+    _lib.check(lib.bigc_stamp(S(), words.data_ptr(), 8, flag.data_ptr()))
+    _lib.check(lib.bigc_stamp(S(), words.data_ptr(), 9, None))
+    w = words.numpy()
+    while w[0] < 9:                                        # the host polls; no runtime call
+        pass
+    assert int(w[0]) == 9 and int(w[1]) == 8               # the flag was down at mark 7, up at mark 8, not looked at by mark 9
+    with pytest.raises(AssertionError):
+        _lib.check(lib.bigc_stamp(S(), words.data_ptr() + 4, 1, None))

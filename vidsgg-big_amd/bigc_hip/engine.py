@@ -90,36 +90,32 @@ class BigcEngine(object):
         self._dirty = True
 
     # ---- the error flag of the device matching (bigc_hungarian): scipy raises ValueError on a cost matrix with NaN / -inf or without
-    # an assignment; a step matched on the device does not wait for the GPU, so the flag travels to a pinned word behind the step and
-    # is looked at when the next step starts (or when somebody reads ``model.last_match_indices``)
+    # an assignment; a step matched on the device does not wait for the GPU, so the flag travels behind the step into a pinned word
+    # (``bigc_stamp``: word 0 = number of the last step the GPU has finished matching, word 1 = a step at which the flag was up) and is
+    # looked at when the next step starts (or when somebody reads ``model.last_match_indices``)
     def match_flag(self, device):
         if getattr(self, "_match_flag", None) is None or self._match_flag.device != torch.device(device):
             self._match_flag = torch.zeros((1,), dtype=torch.int32, device=device)
-            self._match_host = torch.zeros((4,), dtype=torch.int32).pin_memory()
-            self._match_pending, self._match_slot = [], 0
+            self._match_words = torch.zeros((2,), dtype=torch.int64).pin_memory()
+            self._match_np = self._match_words.numpy()
+            self._match_seq = 0
         return self._match_flag
 
     def queue_match_flag_check(self, device):
-        slot = self._match_slot
-        self._match_slot = (slot + 1) % 4
-        if len(self._match_pending) >= 4:                # the ring of four words: the oldest copy has to be seen before its word is reused
-            self.check_match_flags(wait=True)
-        self._match_host[slot:slot + 1].copy_(self._match_flag, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        self._match_pending.append((ev, slot))
+        self._match_seq += 1
+        with torch.cuda.device(device):
+            _lib.check(self.lib.bigc_stamp(_lib.current_stream(), self._match_words.data_ptr(), self._match_seq, self._match_flag.data_ptr()))
 
     def check_match_flags(self, wait=False):
-        pend = getattr(self, "_match_pending", None)
-        while pend and (wait or pend[0][0].query()):
-            ev, slot = pend.pop(0)
-            ev.synchronize()
-            if int(self._match_host[slot]) != 0:
-                self._match_flag.zero_()
-                self._match_host.zero_()
-                del pend[:]
-                raise ValueError("matrix contains invalid numeric entries, or cost matrix is infeasible (linear_sum_assignment of a training "
-                                 "step matched on the device; BIGC_MATCH_ON_HOST=1 raises inside the step itself)")
+        if getattr(self, "_match_flag", None) is None:
+            return
+        while wait and self._match_np[0] < self._match_seq:
+            pass
+        if self._match_np[1] != 0:
+            self._match_flag.zero_()
+            self._match_np[1] = 0
+            raise ValueError("matrix contains invalid numeric entries, or cost matrix is infeasible (linear_sum_assignment of a training "
+                             "step matched on the device; BIGC_MATCH_ON_HOST=1 raises inside the step itself)")
 
     def flat_gradients(self, trainable, device, set_grad="bigc_set_grad", rebase="bigc_rebase_grads"):
         """A fresh zeroed flat fp32 buffer holding one gradient per entry of ``trainable`` [(key, parameter)] back to back, and

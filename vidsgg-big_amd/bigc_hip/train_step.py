@@ -240,8 +240,7 @@ def forward(model, engine, packed, gt_graph_list):
         both = _lib.upload(np.stack([target.reshape(-1), match_g.reshape(-1)]), dev)
         ctx.target, ctx.match_g = both[0], both[1]
     ctx.ldg = (P + 3) // 4 * 4
-    ctx.dlogits = torch.zeros((B * Q, ctx.ldg), dtype=torch.float32, device=dev)
-    ctx.datt = torch.empty_like(ctx.att)
+    ctx.dlogits = ctx.datt = None                        # the forward wants the three loss terms only; the gradients are the backward's
     ctx.loss = torch.zeros((3,), dtype=torch.float32, device=dev)
     loss_grad(model, engine, ctx, 1.0, 1.0, 1.0)
     mark("fwd: targets upload + loss launch")
@@ -251,20 +250,21 @@ def forward(model, engine, packed, gt_graph_list):
 def loss_grad(model, engine, ctx, gs_pos, gs_neg, gs_adj, upstream=None):
     """loss terms + d logits / d att; ``upstream`` = the three upstream gradients as a (3,) f32 DEVICE tensor instead of host floats"""
     c, packed = engine.c, ctx.packed
+    dl, da = (ctx.dlogits.data_ptr(), ctx.datt.data_ptr()) if ctx.dlogits is not None else (None, None)
     if upstream is not None:
         _lib.check(engine.lib.bigc_loss_grad_dev(
             _lib.current_stream(), ctx.logits.data_ptr(), c.num_pred_cats, ctx.att.data_ptr(), packed.vid_trk_off.data_ptr(),
             ctx.g_off.data_ptr(), ctx.gt_adj.data_ptr(), ctx.adj_off.data_ptr(), ctx.target.data_ptr(), ctx.match_g.data_ptr(),
             packed.n_vid, c.num_querys, ctx.n_pos, ctx.n_neg, ctx.n_adj, float(model.loss_factor["classification"]),
             float(model.loss_factor["adj_matrix"]), float(model.neg_weight), upstream.data_ptr(),
-            ctx.loss.data_ptr(), ctx.dlogits.data_ptr(), ctx.ldg, ctx.datt.data_ptr()))
+            ctx.loss.data_ptr(), dl, ctx.ldg, da))
         return
     _lib.check(engine.lib.bigc_loss_grad(
         _lib.current_stream(), ctx.logits.data_ptr(), c.num_pred_cats, ctx.att.data_ptr(), packed.vid_trk_off.data_ptr(),
         ctx.g_off.data_ptr(), ctx.gt_adj.data_ptr(), ctx.adj_off.data_ptr(), ctx.target.data_ptr(), ctx.match_g.data_ptr(),
         packed.n_vid, c.num_querys, ctx.n_pos, ctx.n_neg, ctx.n_adj, float(model.loss_factor["classification"]),
         float(model.loss_factor["adj_matrix"]), float(model.neg_weight), float(gs_pos), float(gs_neg), float(gs_adj),
-        ctx.loss.data_ptr(), ctx.dlogits.data_ptr(), ctx.ldg, ctx.datt.data_ptr()))
+        ctx.loss.data_ptr(), dl, ctx.ldg, da))
 
 
 def grad_scale(*seeds, target_log2=3):
@@ -293,6 +293,9 @@ def backward(model, engine, ctx, grad_terms, named_params):
     """Runs the HIP backward; returns one gradient tensor per entry of ``named_params`` (views of a single flat
     buffer -- the message of the data-parallel all-reduce), ``None`` for frozen parameters."""
     mark("autograd glue between forward and backward")
+    dev = ctx.packed.device
+    ctx.dlogits = torch.zeros((ctx.packed.n_vid * engine.c.num_querys, ctx.ldg), dtype=torch.float32, device=dev)
+    ctx.datt = torch.empty_like(ctx.att)
     if grad_terms.is_cuda and os.environ.get("BIGC_UPSTREAM_ON_HOST", "0") != "1":
         up = grad_terms.detach().to(torch.float32).contiguous()           # read by the kernel where it lies: no wait for the forward
         loss_grad(model, engine, ctx, 1.0, 1.0, 1.0, upstream=up)

@@ -76,11 +76,13 @@ __global__ __launch_bounds__(64) void loss_grad_kernel(const float* __restrict__
     const int tgt = target[row];
     const bool pos = tgt != 0;
     const float wcls = fc / (pos ? n_pos : n_neg);
-    for (int c = lane; c < P; c += 64) dlogits[(size_t)row * ldg + c] = (expf(lp[c] - lse) - (c == tgt ? 1.f : 0.f)) * wcls * (pos ? gs_pos : gs_neg);
+    if (dlogits)
+        for (int c = lane; c < P; c += 64) dlogits[(size_t)row * ldg + c] = (expf(lp[c] - lse) - (c == tgt ? 1.f : 0.f)) * wcls * (pos ? gs_pos : gs_neg);
     if (lane == 0) atomicAdd(&loss_out[pos ? 0 : 1], (lse - lp[tgt]) * wcls);
     const int mg = match_g[row];
     const size_t abase = (size_t)2 * nq * e0;
     float s = 0.f;
+    if (!datt && mg < 0) return;                          // loss terms only: an unmatched query adds nothing to the adjacency term
     for (int r = 0; r < 2; ++r) {
         const size_t arow = abase + ((size_t)r * nq + q) * ne;
         const float* t = gt_adj + adj_off[v] + ((size_t)r * ng + (mg >= 0 ? mg : 0)) * ne;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(64) void loss_grad_kernel(const float* __restrict__
                 s += w * bce(a, tt);
                 g = w * (a - tt) / fmaxf((1.f - a) * a, 1e-12f) * (fa / n_adj) * gs_adj;
             }
-            datt[arow + n] = g;
+            if (datt) datt[arow + n] = g;
         }
     }
     s = wave_sum(s);
@@ -117,8 +119,8 @@ static int loss_grad_launch(void* stream, const float* logits, int n_pcat, const
                             const float* gt_adj, const int64_t* adj_off, const int32_t* target, const int32_t* match_g, int n_vid, int nq,
                             float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight, float gs_pos, float gs_neg, float gs_adj,
                             const float* gs_dev, float* loss_out, float* dlogits, int ldg, float* datt) {
-    BIGC_CHECK_ARG(logits && att && e_off && g_off && gt_adj && adj_off && target && match_g && loss_out && dlogits && datt,
-                   "loss_grad: null pointer");
+    BIGC_CHECK_ARG(logits && att && e_off && g_off && gt_adj && adj_off && target && match_g && loss_out, "loss_grad: null pointer");
+    BIGC_CHECK_ARG((dlogits != nullptr) == (datt != nullptr), "loss_grad: dlogits and datt are given together (both NULL: the loss terms only)");
     hipError_t e = hipMemsetAsync(loss_out, 0, 3 * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "loss_grad: memset: %s", hipGetErrorString(e));
     if (n_vid <= 0) return BIGC_OK;

@@ -347,6 +347,11 @@ int bigc_loss_grad(void* stream, const float* logits, int n_pcat, const float* a
                    float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight,
                    float gs_pos, float gs_neg, float gs_adj, /* upstream gradients of the three loss terms */
                    float* loss_out, float* dlogits, int ldg, float* datt);
+/* 1 when a training step of this handle (in its current arithmetic mode) can take a batch without packed f32 rows (bigc_batch.feats
+ *   NULL) and read the tracklets' feature rows in place through bigc_batch.feat_row_ptr, like the default eval forward: the first
+ *   visual-feature GEMM (models/model_0v10.py:447), its weight gradient and the time-mean of the I3D / classeme columns (:470) then
+ *   walk the callers' tensors; 0: pack f32 rows (exact-GEMM mode, the pairwise baseline, feature widths that are not multiples of 4) */
+int bigc_train_reads_rows(const bigc_model* m);
 /* bigc_loss_grad with the three upstream gradients read from device memory (upstream3[0..2]): the backward of a step that does not
  *   wait for the GPU (autograd hands them over as a device tensor) */
 int bigc_loss_grad_dev(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,

@@ -271,3 +271,39 @@ def test_stamp_marks_progress_in_a_pinned_word():
     assert int(w[0]) == 9 and int(w[1]) == 8               # the flag was down at mark 7, up at mark 8, not looked at by mark 9
     with pytest.raises(AssertionError):
         _lib.check(lib.bigc_stamp(S(), words.data_ptr() + 4, 1, None))
+
+
+@pytest.mark.parametrize("name", ["bigc_train_tiny", "bigo_train_tiny", "bigc_train_v64"])
+def test_training_step_that_reads_the_feature_rows_in_place_equals_the_one_on_packed_rows(name, monkeypatch):
+    """fc_feat2enti.0 (models/model_0v10.py:447), its weight gradient and the time-mean of the I3D / classeme columns (:470) through the
+    row-address table of the callers' tensors (bigc_train_reads_rows) against the same step on packed f32 rows"""
+    from test_hip_train import build_train_model
+    cfg, variant, sd, props, gts = cases.make_train_case(name)
+    model = build_train_model(cfg, variant, sd)
+    props = [p.to(torch.device(DEV)) for p in props]
+    duras = [g.traj_durations.clone() for g in gts]
+    assert _lib.load().bigc_train_reads_rows(model.engine().handle) == 1
+    seen = []
+    real = TS.PackedBatch.rows_in_place
+    monkeypatch.setattr(TS.PackedBatch, "rows_in_place", lambda self: (seen.append(1), real(self))[1])
+    monkeypatch.setenv("BIGC_FEAT_IN_PLACE", "0")
+    t0, terms0, idx0, g0 = _step(model, props, gts, duras)
+    assert not seen
+    monkeypatch.setenv("BIGC_FEAT_IN_PLACE", "1")
+    t1, terms1, idx1, g1 = _step(model, props, gts, duras)
+    assert seen, "the step did not take the in-place route"
+    for (a, b), (c, d) in zip(idx0, idx1):
+        assert np.array_equal(a, c) and np.array_equal(b, d)
+    assert abs(t0 - t1) <= 2e-6 * abs(t0)
+    _same_gradients(g0, g1)
+    # exact-GEMM mode: the dense kernels read packed rows -- the step falls back by itself
+    eng = model.engine()
+    prev = eng.mode
+    eng.set_mode(1, prev[1])
+    try:
+        assert _lib.load().bigc_train_reads_rows(eng.handle) == 0
+        del seen[:]
+        _step(model, props, gts, duras)
+        assert not seen
+    finally:
+        eng.set_mode(*prev)

@@ -149,7 +149,14 @@ def forward(model, engine, packed, gt_graph_list):
     dev = packed.device
     B, NT, Q, P = packed.n_vid, packed.n_trk, c.num_querys, c.num_pred_cats
     ctx = TrainContext()
-    ctx.packed, ctx.batch = packed, packed.as_struct()
+    # the feature rows: read in place from the callers' per-tracklet tensors when the batch holds no copy yet and the handle's mode allows
+    # it (the first visual-feature GEMM, its weight gradient and the time-mean of the extra columns walk an address table, as the eval
+    # forward does), else packed into f32 rows (0.7 ms and 1.1 GB per 64-video step)
+    in_place = packed._feats is None and packed.feats_hr8 is None and packed.can_read_in_place() and \
+        os.environ.get("BIGC_FEAT_IN_PLACE", "1") != "0" and bool(lib.bigc_train_reads_rows(engine.handle))
+    if in_place:
+        packed.rows_in_place()
+    ctx.packed, ctx.batch = packed, packed.as_struct(need_f32=not in_place)
     need = lib.bigc_train_workspace_bytes(engine.handle, ctypes.byref(ctx.batch))
     # the saved activations belong to THIS step: a second forward before this step's backward (gradient accumulation over
     # micro-batches, loss1 + loss2) must not overwrite them; torch's caching allocator recycles the block after the backward

@@ -39,7 +39,15 @@ struct DwArgs {
     float* partial;        // when the M range is split: (splits, tiles_n*128, tiles_k*128) partial products
     int* arrived;          // per tile: how many of its splits have stored their partial product (nullptr: a second kernel sums them)
     int splits;
+    // row m of X starts at x_rowptr[m] (16-byte aligned, K floats) instead of X + m * ldx: the operand is read in place from rows that live
+    // in separate allocations (bigc_batch.feat_row_ptr; split kernel, no gather)
+    const uint64_t* x_rowptr = nullptr;
 };
+typedef const __attribute__((address_space(1))) float* dw_gptr;
+template <bool ROWS>
+__device__ __forceinline__ float dw_x_at(const DwArgs& p, int m, int k) {
+    return ROWS ? ((dw_gptr)p.x_rowptr[m])[k] : p.X[(size_t)m * p.ldx + k];
+}
 
 // Split-M tiles without a second launch: every workgroup stores its partial tile, and the one that arrives LAST at a tile adds
 // all of them to dW in split order -- which workgroup does the summing varies from run to run, the order of the sum does not, so
@@ -186,7 +194,7 @@ __device__ __forceinline__ void dw_split16(const float (&x)[16], unsigned char* 
     }
 }
 
-template <bool GATHER>
+template <bool GATHER, bool ROWS = false>
 __device__ __forceinline__ void linear_dw_split_body(const DwArgs& p, const int bid) {
     // [buffer][dY^T head | dY^T resid | X^T head | X^T resid][128 rows][64 bytes = 32 m]
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][4][128 * 64];
@@ -245,6 +253,9 @@ __device__ __forceinline__ void linear_dw_split_body(const DwArgs& p, const int 
                     const float xv = p.X[(size_t)max(ridx[j], 0) * p.ldx + kin];
                     rx[j] = ridx[j] < 0 ? 0.f : xv;
                 }
+            } else if (ROWS) {                       // sixteen scalar address loads per wave and slab
+#pragma unroll
+                for (int j = 0; j < 16; ++j) rx[j] = ((dw_gptr)p.x_rowptr[mb + j])[kcol];
             } else {
                 const float* xp = p.X + (size_t)mb * p.ldx + kcol;
 #pragma unroll
@@ -263,7 +274,7 @@ __device__ __forceinline__ void linear_dw_split_body(const DwArgs& p, const int 
                 xv = p.X[(size_t)max(ridx[j], 0) * p.ldx + kin];
                 if (ridx[j] < 0) xv = 0.f;
             } else {
-                xv = p.X[(size_t)mc * p.ldx + kcol];
+                xv = dw_x_at<ROWS>(p, mc, kcol);
             }
             ry[j] = mv ? y : 0.f;                    // rows past the M range contribute nothing
             rx[j] = mv ? xv : 0.f;
@@ -334,7 +345,7 @@ __device__ __forceinline__ void linear_dw_split_body(const DwArgs& p, const int 
                     const int src = p.x_idx[(size_t)mc * p.nseg + sg];
                     bv[a] = (mv && src >= 0) ? p.X[(size_t)max(src, 0) * p.ldx + (k - sg * p.seg_len)] : 0.f;
                 } else {
-                    bv[a] = mv ? p.X[(size_t)mc * p.ldx + k] : 0.f;
+                    bv[a] = mv ? dw_x_at<ROWS>(p, mc, k) : 0.f;
                 }
             }
 #pragma unroll
@@ -361,8 +372,8 @@ __device__ __forceinline__ void linear_dw_split_body(const DwArgs& p, const int 
     if (p.partial && p.arrived) dw_finish_tile(p, tile, n0, k0);
 }
 
-template <bool GATHER>
-__global__ __launch_bounds__(256, 2) void linear_dw_split_kernel(const DwArgs p) { linear_dw_split_body<GATHER>(p, blockIdx.x); }
+template <bool GATHER, bool ROWS = false>
+__global__ __launch_bounds__(256, 2) void linear_dw_split_kernel(const DwArgs p) { linear_dw_split_body<GATHER, ROWS>(p, blockIdx.x); }
 
 // Several weight-gradient products in ONE launch (the eleven of a decoder layer: 512 x 512 .. 1024 x 512 outputs whose
 // contraction over the B*Q rows has to be split to fill the chip -- one by one they were 16 tiles x 32 splits of twelve slabs
@@ -720,12 +731,14 @@ static int dw_scratch(void* stream, size_t need_floats, int slot, float** out) {
     return BIGC_OK;
 }
 
-extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const float* X, int ldx, const int32_t* x_idx, int nseg,
-                                  int seg_len, float* dW, int ldw, float* db, int M, int N, int K) {
-    BIGC_CHECK_ARG(dY && X && dW && M >= 0 && N > 0 && K > 0, "linear_dw: bad argument");
+static int dw_launch(void* stream, const float* dY, int ldy, const float* X, int ldx, const int32_t* x_idx, int nseg, int seg_len, float* dW, int ldw,
+                     float* db, int M, int N, int K, const uint64_t* x_rowptr) {
+    BIGC_CHECK_ARG(dY && (X || x_rowptr) && dW && M >= 0 && N > 0 && K > 0, "linear_dw: bad argument");
     if (M == 0) return BIGC_OK;
     if (x_idx) BIGC_CHECK_ARG(nseg >= 1 && nseg * seg_len == K, "linear_dw: K=%d != nseg*seg_len", K);
+    if (x_rowptr) BIGC_CHECK_ARG(!x_idx && !bigc_linear_get_exact(), "linear_dw: the row-pointer operand is read by the split-operand kernel only, without a gather");
     DwArgs p;
+    p.x_rowptr = x_rowptr;
     p.dY = dY; p.ldy = ldy; p.X = X; p.ldx = ldx; p.x_idx = x_idx; p.nseg = x_idx ? nseg : 1; p.seg_len = x_idx ? seg_len : K;
     p.dW = dW; p.ldw = ldw; p.db = db; p.M = M; p.N = N; p.K = K;
     p.tiles_n = cdiv(N, 128); p.tiles_k = cdiv(K, 128);
@@ -764,6 +777,7 @@ extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const 
         ProfScope ps(stream, FAM_LINEAR_DW, 2.0 * M * (double)N * K, 4.0 * ((double)M * N + (double)M * K + (double)N * K));
         if (bigc_linear_get_exact()) hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
         else if (x_idx) hipLaunchKernelGGL(linear_dw_split_kernel<true>, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
+        else if (x_rowptr) hipLaunchKernelGGL((linear_dw_split_kernel<false, true>), dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(linear_dw_split_kernel<false>, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
         BIGC_LAUNCH_CHECK("linear_dw");
         if (splits > 1 && !p.arrived) {
@@ -773,6 +787,17 @@ extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const 
         }
     }
     return BIGC_OK;
+}
+
+extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const float* X, int ldx, const int32_t* x_idx, int nseg,
+                                  int seg_len, float* dW, int ldw, float* db, int M, int N, int K) {
+    return dw_launch(stream, dY, ldy, X, ldx, x_idx, nseg, seg_len, dW, ldw, db, M, N, K, nullptr);
+}
+
+// the same with the rows of X given by address (row m at x_rowptr[m], 16-byte aligned, K floats): the weight gradient of the first
+// visual-feature layer read in place from the callers' per-tracklet tensors (train.hip)
+int bigc_linear_dw_rows(void* stream, const float* dY, int ldy, const uint64_t* x_rowptr, float* dW, int ldw, float* db, int M, int N, int K) {
+    return dw_launch(stream, dY, ldy, nullptr, 0, nullptr, 1, K, dW, ldw, db, M, N, K, x_rowptr);
 }
 
 // Grouped form of bigc_linear_dw_f32 (no gather): jobs[i] = {dY, ldy, X, ldx, dW, ldw, db, M, N, K}.  The operands must stay

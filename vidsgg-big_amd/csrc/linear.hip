@@ -315,6 +315,22 @@ int bigc_linear_hr8out_rows(void* stream, const uint64_t* row_ptr, const float* 
     return bigc_linear_split_launch((hipStream_t)stream, p, flops, bytes);
 }
 
+// C (f32) = act(A W^T + bias) with the rows of A given by address: the first visual-feature layer of the TRAINING forward read in place (train.hip)
+int bigc_linear_rows_f32(void* stream, const uint64_t* row_ptr, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K, int act) {
+    BIGC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && row_ptr && W && C, "linear_rows: bad argument");
+    BIGC_CHECK_ARG(K % 4 == 0 && ldw % 4 == 0 && ldc % 4 == 0 && ldc >= N && ((uintptr_t)C & 15) == 0 && ((uintptr_t)W & 15) == 0, "linear_rows: alignment");
+    BIGC_CHECK_ARG(bigc_linear_get_exact() == 0, "linear_rows: not available in exact mode");
+    if (M == 0) return BIGC_OK;
+    LinearArgs p;
+    p.A = nullptr; p.lda = 0; p.a_idx = nullptr; p.nseg = 1; p.seg_len = K; p.a_rowptr = row_ptr;
+    p.W = W; p.ldw = ldw; p.bias = bias; p.res = nullptr; p.ldr = 0; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.act = act;
+    p.tiles_m = cdiv(M, BM); p.tiles_n = 0;
+    p.Ws = nullptr; p.ldws = 0; p.wbad = nullptr; p.zero_row = nullptr;
+    const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N);
+    return bigc_linear_split_launch((hipStream_t)stream, p, flops, bytes);
+}
+
 int bigc_linear_k8_hr8out(void* stream, const float* A, const float* W, const float* bias, void* Cs, long ldcs, int M, int N, int act, int* range_flag) {
     BIGC_CHECK_ARG(A && W && Cs && M >= 0 && N % 8 == 0 && N <= 1024 && 256 % (N / 4) == 0 && ((uintptr_t)Cs & 15) == 0 && ldcs % 4 == 0 &&
                    (!bias || ((uintptr_t)bias & 15) == 0), "linear_k8_hr8out: bad argument");

@@ -78,6 +78,9 @@ int bigc_linear_hr8out(void* stream, const float* A, int lda, const float* W, in
 // of a batch in place from the callers' per-tracklet tensors
 int bigc_linear_hr8out_rows(void* stream, const uint64_t* row_ptr, const float* W, int ldw, const float* bias, void* Cs, long ldcs, int M, int N, int K,
                             int act, int* range_flag);
+// f32 output, rows of A by address (training forward, in place); backward.hip: its weight gradient with the rows of X by address
+int bigc_linear_rows_f32(void* stream, const uint64_t* row_ptr, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K, int act);
+int bigc_linear_dw_rows(void* stream, const float* dY, int ldy, const uint64_t* x_rowptr, float* dW, int ldw, float* db, int M, int N, int K);
 // the K = 8 GEMM (linear_k8_kernel) with its output in the split form
 int bigc_linear_k8_hr8out(void* stream, const float* A, const float* W, const float* bias, void* Cs, long ldcs, int M, int N, int act, int* range_flag);
 // y = act(relu(x8 W0^T + b0) W^T + bias): the K = 8 layer folded into the staging of the next GEMM; false -> two launches

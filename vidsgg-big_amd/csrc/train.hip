@@ -229,6 +229,16 @@ struct Bwd {
 #define ZERO(ptr, count) do { hipError_t e_ = hipMemsetAsync((ptr), 0, sizeof(float) * (size_t)(count), hs); \
     if (e_ != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: memset: %s", hipGetErrorString(e_)); } while (0)
 
+// may a training step of this handle, in its current arithmetic mode, take a batch WITHOUT packed f32 feature rows and read the callers'
+// rows in place (bigc_batch.feat_row_ptr)?  The split-operand kernels do (forward GEMM, weight gradient, the time-mean of the extra
+// columns); the exact f32 kernels read a dense matrix.
+extern "C" int bigc_train_reads_rows(const bigc_model* m) {
+    if (!m || m->cfg.variant == 2) return 0;
+    ModeScope mode_scope(m->mode_exact, m->mode_fast);
+    if (bigc_linear_get_exact()) return 0;
+    return (m->cfg.dim_feat % 4 == 0 && m->cfg.dim_extra % 4 == 0) ? 1 : 0;
+}
+
 // a1-a4 with every activation kept (models/model_0v10.py:391-458; the same front-end in model_0v7.py and
 // model_pairwise_baseline.py:184-199): w.e2e = enti2enco
 static int frontend_train_forward(bigc_model* m, void* s, const bigc_batch* b, TrainWork& w) {
@@ -238,8 +248,13 @@ static int frontend_train_forward(bigc_model* m, void* s, const bigc_batch* b, T
     TRY(bigc_bbox_feat_f32(s, b->boxes, b->trk_row_off, b->trk_vid, b->vid_wh, w.bbox8, NT));
     TRY(linear(s, w.bbox8, 8, m->bbox0, w.hb, de, R, de, 8, BIGC_ACT_RELU));
     TRY(linear(s, w.hb, de, m->bbox2, w.enti, 2 * de, R, de, de, BIGC_ACT_RELU));
-    BIGC_CHECK_ARG(b->feats, "train: the training step reads the f32 features (bigc_batch.feats), which the batch was packed without");
-    TRY(linear(s, b->feats, D, m->feat0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
+    if (b->feats) {
+        TRY(linear(s, b->feats, D, m->feat0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
+    } else {                        // in place: the rows of the callers' per-tracklet tensors through the address table (as the eval forward)
+        BIGC_CHECK_ARG(b->feat_row_ptr && bigc_train_reads_rows(m), "train: a batch without f32 features (bigc_batch.feats) needs bigc_batch.feat_row_ptr "
+                       "and a mode / configuration that reads rows in place (bigc_train_reads_rows)");
+        TRY(bigc_linear_rows_f32(s, b->feat_row_ptr, m->feat0.w, c.dim_feat, m->feat0.b, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
+    }
     TRY(linear(s, w.hv, de, m->feat2, w.enti + de, 2 * de, R, de, de, BIGC_ACT_RELU));
     TRY(bigc_conv_index(s, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.conv_idx, NT));
     TRY(bigc_linear_f32(s, w.enti, 2 * de, w.conv_idx, 3, 2 * de, m->conv_w_tapmajor, 6 * de, m->conv.b, nullptr, 0, w.conv, de, C, de,
@@ -280,7 +295,12 @@ static int frontend_train_backward(bigc_model* m, void* s, const bigc_batch* b, 
     TRY(bw.lin_relu("fc_bbox2enti.2", m->bbox2, w.genti, 2 * de, w.hb, de, R, de, de, w.gh, de));
     TRY(bw.lin("fc_bbox2enti.0", m->bbox0, w.gh, de, w.bbox8, 8, R, de, 8, nullptr, 0, false));
     TRY(bw.lin_relu("fc_feat2enti.2", m->feat2, w.genti + de, 2 * de, w.hv, de, R, de, de, w.gh, de));
-    TRY(bw.lin("fc_feat2enti.0", m->feat0, w.gh, de, b->feats, D, R, de, c.dim_feat, nullptr, 0, false));
+    if (b->feats) {
+        TRY(bw.lin("fc_feat2enti.0", m->feat0, w.gh, de, b->feats, D, R, de, c.dim_feat, nullptr, 0, false));
+    } else if (float* gw = grad_of(m, "fc_feat2enti.0.weight")) {
+        TRY(bw.flush());
+        TRY(bigc_linear_dw_rows(s, w.gh, de, b->feat_row_ptr, gw, c.dim_feat, grad_of(m, "fc_feat2enti.0.bias"), R, de, c.dim_feat));
+    }
     return BIGC_OK;
 }
 

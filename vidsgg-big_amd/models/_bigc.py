@@ -235,7 +235,7 @@ class BigcBase(nn.Module):
         assert all(p.num_proposals > 0 for p in proposal_list), "videos without proposals are filtered out before training"
         from bigc_hip.train_step import mark
         mark("step glue (zero_grad ...)")
-        packed = PackedBatch(list(proposal_list), self.pred_query_init.device)
+        packed = PackedBatch(list(proposal_list), self.pred_query_init.device, "lazy")      # the step picks the form of the feature rows
         mark("pack the batch")
         terms = HipTrainStep.apply(self, packed, list(gt_graph_list), *[p for _, p in self.named_parameters()])
         loss_dict = {"cls_pos": terms[0], "cls_neg": terms[1], "adj": terms[2]}

@@ -113,6 +113,17 @@ HBM_PEAK_GBS = 8000.0           # same table, HBM3E peak
 EXACT_F32 = os.environ.get("BIGC_LINEAR_EXACT", "0") not in ("", "0")     # run the whole benchmark on the exact f32-MFMA GEMM kernel
 
 
+def throttled_periods():
+    """scheduling periods in which the cgroup's CPU quota froze this container so far (None without cgroup v2 accounting)"""
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("nr_throttled"):
+                return int(line.split()[1])
+    except OSError:
+        pass
+    return None
+
+
 def usable_cores():
     """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota
     (the GPU boxes report 256 CPUs but run under a 16-core quota; 256 threads there is ~900x slower)."""
@@ -734,6 +745,7 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    thr0, cpu0 = throttled_periods(), time.process_time()
     t0 = time.perf_counter()
     stamps = [t0]
     for _ in range(args.steps):
@@ -741,6 +753,11 @@ def main():
         stamps.append(time.perf_counter())            # (every step ends with its own D2H copy: the stamps are step boundaries)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # what the host was doing meanwhile (diagnostics, outside `value`): CPU seconds of ALL threads of this process per second of wall
+    # clock, and how often the container's CPU quota froze the process during the timed steps (cgroup cpu.stat, see bigc_hip/_lib.py)
+    host_diag = {"cpu_threads_busy": round((time.process_time() - cpu0) / max(elapsed, 1e-9), 2), "cpu_quota": usable_cores(),
+                 "torch_threads": torch.get_num_threads(), "quota_throttled_periods_during_timed_steps": (throttled_periods() - thr0) if thr0 is not None else None,
+                 "load_average_1min": round(os.getloadavg()[0], 1)}
     if dist is not None:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -1064,6 +1081,7 @@ def main():
         "ms_per_step_median_each_step_synchronised": round(1e3 * float(np.median(per_step)), 3) if per_step else None,
         "triplets_last_step": n_triplets_last, "setup_s": round(gen_s, 1),
         "timed_steps_ms": [round(1e3 * (b - a), 2) for a, b in zip(stamps[:-1], stamps[1:])],
+        "host": host_diag,
         "timed_call": ("model(proposal_list, topk) on device-resident TrajProposals: tables + boxes of the ragged batch (the feature rows are read in place "
                        "through a row-address table, no copy) + forward + construct_triplet + compaction + one D2H copy + per-video result tuples" if args.headline == "api" else
                        "model.forward_packed(resident PackedBatch, topk) + the one D2H copy"),

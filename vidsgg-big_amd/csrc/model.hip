@@ -110,7 +110,7 @@ bool layout(const bigc_model* m, const Sizes& z, Arena& a, Work& w) {
     w.encos = a.take<float>(z.NT * de);
     w.querys = a.take<float>(z.BQ * dp);
     w.qkins = a.take<float>(z.BQ * dp);
-    w.ecat = a.take<float>(z.NT * (da + 2 * dp));     // [e2a | role0 projection | role1 projection] of the entity rows, one GEMM (build_enco_cat)
+    w.ecat = a.take<float>(z.NT * (da + 2 * dp) * (size_t)(c.n_deco_layers > 0 ? c.n_deco_layers : 1));     // per decoder layer [e2a | role0 projection | role1 projection] of the entity rows, ONE GEMM for all layers (build_enco_cat)
     w.flag = a.take<int32_t>(64);
     return !a.overflow;
 }
@@ -310,22 +310,23 @@ static int build_role_cat(bigc_model* m, void* stream) {
 // times for two.  Every output element is the same accumulation as before (bit-identical).
 static int build_enco_cat(bigc_model* m, void* stream) {
     const bigc_config& c = m->cfg;
-    const int dp = c.dim_pred, da = c.dim_att, de = c.dim_enti, W = da + 2 * dp;
-    if (m->enco_cat_epoch == m->epoch || c.n_deco_layers == 0) return BIGC_OK;
-    const size_t per = (size_t)W * de + W;
+    const int dp = c.dim_pred, da = c.dim_att, de = c.dim_enti, W = da + 2 * dp, NL = c.n_deco_layers;
+    if (m->enco_cat_epoch == m->epoch || NL == 0) return BIGC_OK;
+    // (NL W, de) weights -- layer i's [W_e2a; W_role0.0; W_role1.0] are rows i W .. (i + 1) W - 1 -- then the (NL W) biases [b_e2a | 0 | 0] per layer
+    const size_t total = (size_t)NL * W * de + (size_t)NL * W;
     if (!m->enco_cat) {
-        hipError_t e = hipMalloc((void**)&m->enco_cat, sizeof(float) * per * c.n_deco_layers);
+        hipError_t e = hipMalloc((void**)&m->enco_cat, sizeof(float) * total);
         if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: hipMalloc: %s", hipGetErrorString(e));
     }
-    if (hipMemsetAsync(m->enco_cat, 0, sizeof(float) * per * c.n_deco_layers, (hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: memset failed");
-    for (int i = 0; i < c.n_deco_layers; ++i) {
+    if (hipMemsetAsync(m->enco_cat, 0, sizeof(float) * total, (hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: memset failed");
+    float* bias = m->enco_cat + (size_t)NL * W * de;
+    for (int i = 0; i < NL; ++i) {
         const DecLayer& L = m->dec[i];
-        float* wc = m->enco_cat + per * i;
-        float* bc = wc + (size_t)W * de;
+        float* wc = m->enco_cat + (size_t)i * W * de;
         TRY(bigc_copy_cols((hipStream_t)stream, L.e2a.w, de, wc, de, da, de));
         TRY(bigc_copy_cols((hipStream_t)stream, L.role0[0].w, de, wc + (size_t)da * de, de, dp, de));
         TRY(bigc_copy_cols((hipStream_t)stream, L.role1[0].w, de, wc + (size_t)(da + dp) * de, de, dp, de));
-        TRY(bigc_copy_cols((hipStream_t)stream, L.e2a.b, da, bc, da, 1, da));
+        TRY(bigc_copy_cols((hipStream_t)stream, L.e2a.b, da, bias + (size_t)i * W, da, 1, da));
     }
     m->enco_cat_epoch = m->epoch;
     return BIGC_OK;
@@ -760,12 +761,14 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         TRY(linear(s, w.query, dp, L.p2a, w.p2a, da, BQ, da, dp, BIGC_ACT_NONE));
         if (presplit) {
             // fc_enti2att and the two role projections of the entity rows: one GEMM into [e2a | ew0 | ew1] rows (build_enco_cat)
-            TRY(build_enco_cat(m, s));
-            const int EW = da + 2 * dp;
-            const float* ecw = m->enco_cat + ((size_t)EW * de + EW) * i;
-            TRY(bigc_linear_f32(s, enco, de, nullptr, 1, de, ecw, de, ecw + (size_t)EW * de, nullptr, 0, w.ecat, EW, NT, EW, de, BIGC_ACT_NONE));
+            const int EW = da + 2 * dp, EP = EW * c.n_deco_layers;            // this layer's columns of w.ecat, and the pitch of its rows
+            if (i == 0) {
+                TRY(build_enco_cat(m, s));
+                TRY(bigc_linear_f32(s, enco, de, nullptr, 1, de, m->enco_cat, de, m->enco_cat + (size_t)EP * de, nullptr, 0, w.ecat, EP, NT, EP, de, BIGC_ACT_NONE));
+            }
+            const float* ec = w.ecat + (size_t)i * EW;
             TRY(build_role_cat(m, s));
-            if (!bigc_role_fused_proj_hr8_launch(hs, w.p2a, da, w.ecat, EW, w.ecat + da, EW, (long)dp, L.role0[0].b, L.role1[0].b, 1, last ? out->att : nullptr,
+            if (!bigc_role_fused_proj_hr8_launch(hs, w.p2a, da, ec, EP, ec + da, EP, (long)dp, L.role0[0].b, L.role1[0].b, 1, last ? out->att : nullptr,
                                                  w.vals, (long)2 * dp * 4, dp, b->vid_trk_off, B, Q, b->max_trk, da / 2, dp, att_scale, w.flag))
                 return bigc_fail(BIGC_ERR_ARG, "forward: role-attention shape outside the split-output kernel");
             const float* wc = m->role_cat + ((size_t)dp * 2 * dp + dp) * i;

@@ -29,7 +29,7 @@ struct bigc_model {
     float* role_cat = nullptr;         // per decoder layer: [W_role0.2 | W_role1.2] (dp, 2 dp) then b_role0.2 + b_role1.2 (dp), owned
     float* conv_w_bwd = nullptr;       // (2de, 3*de), owned (training)
     unsigned long long enco_cat_epoch = 0;
-    float* enco_cat = nullptr;         // per decoder layer: [W_e2a; W_role0.0; W_role1.0] (da + 2 dp, de) then the bias [b_e2a | 0] (da + 2 dp), owned (model.hip: build_enco_cat)
+    float* enco_cat = nullptr;         // all decoder layers: [W_e2a; W_role0.0; W_role1.0] (n_layers (da + 2 dp), de), then the biases [b_e2a | 0] per layer, owned (model.hip: build_enco_cat)
     unsigned long long qkpos_epoch = 0;
     float* qkpos = nullptr;            // per decoder layer: (num_querys, 3 dp) rows [pos Wq^T | pos Wk^T | 0], owned (model.hip: build_qkpos)
     int head_k = 0;

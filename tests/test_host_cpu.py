@@ -282,3 +282,21 @@ def test_the_restated_assignment_algorithm_is_scipys():
         c[1, 1] = bad
         with pytest.raises(ValueError):
             lsap.assign(c)
+
+
+def test_device_matching_is_only_chosen_where_it_reproduces_scipy(monkeypatch):
+    """bigc_hungarian restates scipy for FEWER GT predicates than queries (scipy then works on the transposed matrix and every predicate
+    is matched, so the loss normalisers are known without the assignment); anything else -- or BIGC_MATCH_ON_HOST=1 -- stays on scipy"""
+    from types import SimpleNamespace as NS
+    from bigc_hip import train_step as TS
+
+    def g(n_pred, n_traj):
+        return NS(adj_matrix=torch.zeros(2, n_pred, n_traj), traj_bboxes=[torch.zeros(3, 4)] * n_traj)
+    monkeypatch.delenv("BIGC_MATCH_ON_HOST", raising=False)
+    assert TS.match_on_device([g(4, 5), g(11, 2)], 12)
+    assert not TS.match_on_device([g(4, 5), g(12, 2)], 12)          # as many predicates as queries: scipy does not transpose
+    assert not TS.match_on_device([g(4, 5), g(40, 2)], 12)
+    assert not TS.match_on_device([g(4, 0)], 12)                    # no GT trajectory: the alignment has nothing to arg-max over
+    assert not TS.match_on_device([g(0, 3)], 12)
+    monkeypatch.setenv("BIGC_MATCH_ON_HOST", "1")
+    assert not TS.match_on_device([g(4, 5)], 12)

@@ -109,8 +109,10 @@ class BigcEngine(object):
     def check_match_flags(self, wait=False):
         if getattr(self, "_match_flag", None) is None:
             return
-        while wait and self._match_np[0] < self._match_seq:
-            pass
+        if wait and self._match_np[0] < self._match_seq:
+            torch.cuda.synchronize(self._match_flag.device)       # the marks are kernels on the step's stream: after this they have run
+            if self._match_np[0] < self._match_seq:
+                raise _lib.BigcError("the progress mark of a device-matched training step did not arrive (bigc_stamp)")
         if self._match_np[1] != 0:
             self._match_flag.zero_()
             self._match_np[1] = 0

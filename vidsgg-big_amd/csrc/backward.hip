@@ -543,7 +543,15 @@ __global__ __launch_bounds__(256) void reduce_periodic_kernel(const float* __res
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int pr = e / d, c = e - pr * d;
         float s = 0.f;
-        for (int r = pr; r < rows; r += period) s += x[(size_t)r * d + c];
+        int r = pr;
+        for (; r + 7 * period < rows; r += 8 * period) {          // eight rows in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(r + u * period) * d + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < rows; r += period) s += x[(size_t)r * d + c];
         out[e] += s;
     }
 }
@@ -579,6 +587,29 @@ __global__ __launch_bounds__(256) void conv_gather_bwd_kernel(const float* __res
     const int c0 = conv_off[t], To = conv_off[t + 1] - c0;
     const int M = vid_tmax[trk_vid[t]];
     const int q = M / L, r = M - q * L;
+    if ((d & 3) == 0) {
+        // one (source frame, tap) pair per wave and pass, four channels per lane: the frame arithmetic is wave-uniform, the rows move as
+        // 16-byte accesses (before: one float and two integer divisions per thread and element -- 546 us per 64-video step for the
+        // 890 MB it writes); the sums run over the same frames in the same order
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
+        for (int pair = wave; pair < L * 3; pair += 4) {
+            const int i = pair / 3, k = pair - 3 * i;
+            const int fa = i < r ? i * (q + 1) : r * (q + 1) + (i - r) * q;
+            const int fb = fa + (i < r ? q + 1 : q);
+            f32x4* out = (f32x4*)(G + ((size_t)(r0 + i) * 3 + k) * d);
+            for (int c = lane; c < d4; c += 64) {
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+                for (int f = fa; f < fb; ++f) {
+                    const int num = f + 1 - k;
+                    if (num < 0 || (num & 1)) continue;
+                    const int j = num >> 1;
+                    if (j < To) s4 += ((const f32x4*)(dconv + (size_t)(c0 + j) * d))[c];
+                }
+                out[c] = s4;
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < L * 3 * d; e += 256) {
         const int ch = e % d, k = (e / d) % 3, i = e / (3 * d);
         // stretched frames of source frame i: [fa, fb)
@@ -618,14 +649,38 @@ __global__ __launch_bounds__(256) void head_gather_bwd_kernel(const float* __res
     const int v = trk_vid[t];
     const int lt = t - e_off[v];
     const int32_t* so = soid + (size_t)v * 2 * nq;
+    // The (query, role) pairs that picked this tracklet, in the order the sums were always taken in (query ascending, subject before
+    // object): about six of the 2 nq candidates.  One wave compacts them (ballot + prefix count keeps the order); before, every thread
+    // walked all nq queries for every segment and column chunk -- 800 dependent index loads per workgroup, 540 us per 64-video step.
+    __shared__ int hits[2048];
+    __shared__ int n_hits;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int n = 0;
+        for (int base = 0; base < 2 * nq; base += 64) {
+            const int e = base + lane;                              // e = 2 query + role
+            const bool hit = e < 2 * nq && so[(e & 1) * nq + (e >> 1)] == lt;
+            const unsigned long long m = __ballot(hit);
+            if (hit) hits[n + __popcll(m & ((1ull << lane) - 1ull))] = e;
+            n += __popcll(m);
+        }
+        if (lane == 0) n_hits = n;
+    }
+    __syncthreads();
+    const int nh = n_hits;
     for (int s = 0; s < segs.n; ++s) {
         const int w = segs.width[s];
         for (int c = threadIdx.x; c < w; c += 256) {
             float acc = 0.f;
-            for (int qi = 0; qi < nq; ++qi) {
-                const float* row = dhead + (size_t)(v * nq + qi) * ld + segs.col[s];
-                if (so[qi] == lt) acc += row[c];
-                if (so[nq + qi] == lt) acc += row[w + c];
+            for (int i0 = 0; i0 < nh; i0 += 8) {              // eight rows in flight, added in list order
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = hits[min(i0 + u, nh - 1)];
+                    x[u] = dhead[(size_t)(v * nq + (e >> 1)) * ld + segs.col[s] + (e & 1) * w + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (i0 + u < nh) ? x[u] : 0.f;
             }
             segs.dst[s][(size_t)t * w + c] += acc;
         }
@@ -967,6 +1022,7 @@ int bigc_head_gather_bwd(hipStream_t s, const float* dhead, int ld, const int32_
     segs.n = n_seg;
     for (int i = 0; i < 4; ++i) { segs.dst[i] = i < n_seg ? dst[i] : nullptr; segs.width[i] = i < n_seg ? width[i] : 0; segs.col[i] = i < n_seg ? col[i] : 0; }
     if (n_trk <= 0 || n_seg <= 0) return BIGC_OK;
+    BIGC_CHECK_ARG(nq <= 1024, "head_gather_bwd: nq=%d > 1024", nq);
     hipLaunchKernelGGL(head_gather_bwd_kernel, dim3(n_trk), dim3(256), 0, s, dhead, ld, soid, e_off, trk_vid, nq, segs);
     BIGC_LAUNCH_CHECK("head_gather_bwd");
     return BIGC_OK;

@@ -57,48 +57,66 @@ __global__ __launch_bounds__(64) void match_cost_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(64) void loss_grad_kernel(const float* __restrict__ logits, int P, const float* __restrict__ att,
-                                                       const int32_t* __restrict__ e_off, const int32_t* __restrict__ g_off,
-                                                       const float* __restrict__ gt_adj, const int64_t* __restrict__ adj_off,
-                                                       const int32_t* __restrict__ target, const int32_t* __restrict__ match_g, int nq,
-                                                       float n_pos, float n_neg, float n_adj, float fc, float fa, float neg_weight,
-                                                       float gs_pos, float gs_neg, float gs_adj, const float* __restrict__ gs_dev,
-                                                       float* __restrict__ loss_out, float* __restrict__ dlogits, int ldg,
-                                                       float* __restrict__ datt) {
-    const int row = blockIdx.x, lane = threadIdx.x;
+// One wave per (video, query) row, LG_ROWS rows per workgroup of four waves: the three loss terms are summed in registers and LDS first
+// and reach loss_out as ONE atomic per term and workgroup (before: two atomics per row, 24 576 of them on three addresses -- the L2
+// serialises those; 168 us per launch at 64 videos for a few MB of traffic).
+constexpr int LG_ROWS = 16;
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ logits, int P, const float* __restrict__ att,
+                                                        const int32_t* __restrict__ e_off, const int32_t* __restrict__ g_off,
+                                                        const float* __restrict__ gt_adj, const int64_t* __restrict__ adj_off,
+                                                        const int32_t* __restrict__ target, const int32_t* __restrict__ match_g, int nq, int n_rows,
+                                                        float n_pos, float n_neg, float n_adj, float fc, float fa, float neg_weight,
+                                                        float gs_pos, float gs_neg, float gs_adj, const float* __restrict__ gs_dev,
+                                                        float* __restrict__ loss_out, float* __restrict__ dlogits, int ldg,
+                                                        float* __restrict__ datt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (gs_dev) { gs_pos = gs_dev[0]; gs_neg = gs_dev[1]; gs_adj = gs_dev[2]; }
-    const int v = row / nq, q = row - v * nq;
-    const int e0 = e_off[v], ne = e_off[v + 1] - e0;
-    if (ne <= 0) return;
-    const int ng = g_off[v + 1] - g_off[v];
-    const float* lp = logits + (size_t)row * P;
-    const float lse = row_lse(lp, P, lane);
-    const int tgt = target[row];
-    const bool pos = tgt != 0;
-    const float wcls = fc / (pos ? n_pos : n_neg);
-    if (dlogits)
-        for (int c = lane; c < P; c += 64) dlogits[(size_t)row * ldg + c] = (expf(lp[c] - lse) - (c == tgt ? 1.f : 0.f)) * wcls * (pos ? gs_pos : gs_neg);
-    if (lane == 0) atomicAdd(&loss_out[pos ? 0 : 1], (lse - lp[tgt]) * wcls);
-    const int mg = match_g[row];
-    const size_t abase = (size_t)2 * nq * e0;
-    float s = 0.f;
-    if (!datt && mg < 0) return;                          // loss terms only: an unmatched query adds nothing to the adjacency term
-    for (int r = 0; r < 2; ++r) {
-        const size_t arow = abase + ((size_t)r * nq + q) * ne;
-        const float* t = gt_adj + adj_off[v] + ((size_t)r * ng + (mg >= 0 ? mg : 0)) * ne;
-        for (int n = lane; n < ne; n += 64) {
-            float g = 0.f;
-            if (mg >= 0) {
-                const float a = att[arow + n], tt = t[n];
-                const float w = tt != 0.f ? 1.f : neg_weight;
-                s += w * bce(a, tt);
-                g = w * (a - tt) / fmaxf((1.f - a) * a, 1e-12f) * (fa / n_adj) * gs_adj;
+    float part[3] = {0.f, 0.f, 0.f};                      // this wave's share of {cls_pos, cls_neg, adj} (lane 0)
+    for (int rr = wave; rr < LG_ROWS; rr += 4) {
+        const int row = blockIdx.x * LG_ROWS + rr;
+        if (row >= n_rows) break;
+        const int v = row / nq, q = row - v * nq;
+        const int e0 = e_off[v], ne = e_off[v + 1] - e0;
+        if (ne <= 0) continue;
+        const int ng = g_off[v + 1] - g_off[v];
+        const float* lp = logits + (size_t)row * P;
+        const float lse = row_lse(lp, P, lane);
+        const int tgt = target[row];
+        const bool pos = tgt != 0;
+        const float wcls = fc / (pos ? n_pos : n_neg);
+        if (dlogits)
+            for (int c = lane; c < P; c += 64) dlogits[(size_t)row * ldg + c] = (expf(lp[c] - lse) - (c == tgt ? 1.f : 0.f)) * wcls * (pos ? gs_pos : gs_neg);
+        const float ce = (lse - lp[tgt]) * wcls;
+        part[0] += pos ? ce : 0.f;
+        part[1] += pos ? 0.f : ce;
+        const int mg = match_g[row];
+        if (!datt && mg < 0) continue;                        // loss terms only: an unmatched query adds nothing to the adjacency term
+        const size_t abase = (size_t)2 * nq * e0;
+        float s = 0.f;
+        for (int r = 0; r < 2; ++r) {
+            const size_t arow = abase + ((size_t)r * nq + q) * ne;
+            const float* t = gt_adj + adj_off[v] + ((size_t)r * ng + (mg >= 0 ? mg : 0)) * ne;
+            for (int n = lane; n < ne; n += 64) {
+                float g = 0.f;
+                if (mg >= 0) {
+                    const float a = att[arow + n], tt = t[n];
+                    const float w = tt != 0.f ? 1.f : neg_weight;
+                    s += w * bce(a, tt);
+                    g = w * (a - tt) / fmaxf((1.f - a) * a, 1e-12f) * (fa / n_adj) * gs_adj;
+                }
+                if (datt) datt[arow + n] = g;
             }
-            if (datt) datt[arow + n] = g;
         }
+        s = wave_sum(s);
+        if (mg >= 0) part[2] += s * fa / n_adj;
     }
-    s = wave_sum(s);
-    if (lane == 0 && mg >= 0) atomicAdd(&loss_out[2], s * fa / n_adj);
+    __shared__ float red[4][3];
+    if (lane == 0) { red[wave][0] = part[0]; red[wave][1] = part[1]; red[wave][2] = part[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (tot != 0.f) atomicAdd(&loss_out[threadIdx.x], tot);
+    }
 }
 
 }  // namespace
@@ -125,8 +143,8 @@ static int loss_grad_launch(void* stream, const float* logits, int n_pcat, const
     if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "loss_grad: memset: %s", hipGetErrorString(e));
     if (n_vid <= 0) return BIGC_OK;
     ProfScope ps(stream, FAM_LOSS, 0.0, 0.0);
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(n_vid * nq), dim3(64), 0, (hipStream_t)stream, logits, n_pcat, att, e_off, g_off, gt_adj,
-                       adj_off, target, match_g, nq, n_pos, n_neg, n_adj, loss_cls, loss_adj, neg_weight, gs_pos, gs_neg, gs_adj, gs_dev, loss_out, dlogits, ldg, datt);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3((n_vid * nq + LG_ROWS - 1) / LG_ROWS), dim3(256), 0, (hipStream_t)stream, logits, n_pcat, att, e_off, g_off, gt_adj,
+                       adj_off, target, match_g, nq, n_vid * nq, n_pos, n_neg, n_adj, loss_cls, loss_adj, neg_weight, gs_pos, gs_neg, gs_adj, gs_dev, loss_out, dlogits, ldg, datt);
     BIGC_LAUNCH_CHECK("loss_grad");
     return BIGC_OK;
 }

@@ -562,6 +562,31 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
                                                           const float* __restrict__ dpooled, float* __restrict__ dconv, int d, int P) {
     const int t = blockIdx.x;
     const int c0 = conv_off[t], To = conv_off[t + 1] - c0;
+    if (To <= 32) {
+        // the channel's column in registers: To independent loads in one burst instead of a chain of dependent compares on loads (the
+        // kernel was latency-bound: 176 us per 64-video step for 300 MB), the same first-maximum rule, one store per row
+        for (int c = threadIdx.x; c < d; c += 256) {
+            float v[32], g[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) { v[j] = j < To ? conv[(size_t)(c0 + j) * d + c] : 0.f; g[j] = 0.f; }
+            for (int p = 0; p < P; ++p) {
+                const int s = (p * To) / P, e = ((p + 1) * To + P - 1) / P;
+                float m = 0.f;
+                int am = s;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    if (j == s) m = v[j];
+                    if (j > s && j < e && v[j] > m) { m = v[j]; am = j; }
+                }
+                const float up = dpooled[(size_t)t * d * P + (size_t)c * P + p];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) g[j] += (j == am) ? up : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j) if (j < To) dconv[(size_t)(c0 + j) * d + c] = g[j];
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < d; c += 256) {
         for (int j = 0; j < To; ++j) dconv[(size_t)(c0 + j) * d + c] = 0.f;
         for (int p = 0; p < P; ++p) {

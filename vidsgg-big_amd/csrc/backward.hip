@@ -744,6 +744,35 @@ __global__ void conv_grad_unpack_kernel(const float* __restrict__ g, float* __re
     out[i] += g[o * per_out + (long)k * n_in + c];
 }
 
+// tap-by-output conv weight gradient (taps*n_out, n_in) -- row k*n_out + o, column c -- -> torch layout (n_out, n_in, taps), accumulated
+__global__ void conv_grad_unpack_tapout_kernel(const float* __restrict__ g, float* __restrict__ out, long total, int n_out, int n_in, int taps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long per_out = (long)n_in * taps;
+    const long o = i / per_out;
+    const int rem = (int)(i - o * per_out);
+    const int c = rem / taps, k = rem - c * taps;
+    out[i] += g[((long)k * n_out + o) * n_in + c];
+}
+
+// out[c] += sum over the rows of x (rows, d): chunks of 256 rows per workgroup, one atomic per column and workgroup
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int d) {
+    const long r0 = (long)blockIdx.x * 256, r1 = r0 + 256 < rows ? r0 + 256 : rows;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float s = 0.f;
+        long r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(r + u) * d + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < r1; ++r) s += x[(size_t)r * d + c];
+        atomicAdd(&out[c], s);
+    }
+}
+
 // out (cols, ld_out) = in (rows, cols)^T with the columns [rows, ld_out) zero-filled
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int ld_out) {
     __shared__ float tile[32][33];
@@ -1086,6 +1115,20 @@ int bigc_conv_grad_unpack(hipStream_t s, const float* g_tapmajor, float* g_torch
     const long total = (long)n_out * n_in * taps;
     hipLaunchKernelGGL(conv_grad_unpack_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, g_tapmajor, g_torch, total, n_in, taps);
     BIGC_LAUNCH_CHECK("conv_grad_unpack");
+    return BIGC_OK;
+}
+
+int bigc_conv_grad_unpack_tapout(hipStream_t s, const float* g_tapout, float* g_torch, int n_out, int n_in, int taps) {
+    const long total = (long)n_out * n_in * taps;
+    hipLaunchKernelGGL(conv_grad_unpack_tapout_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, g_tapout, g_torch, total, n_out, n_in, taps);
+    BIGC_LAUNCH_CHECK("conv_grad_unpack_tapout");
+    return BIGC_OK;
+}
+
+int bigc_col_sum(hipStream_t s, const float* x, float* out, long rows, int d) {
+    if (rows <= 0) return BIGC_OK;
+    hipLaunchKernelGGL(col_sum_kernel, dim3((int)((rows + 255) / 256)), dim3(256), 0, s, x, out, rows, d);
+    BIGC_LAUNCH_CHECK("col_sum");
     return BIGC_OK;
 }
 

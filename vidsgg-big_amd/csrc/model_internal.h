@@ -71,3 +71,5 @@ int bigc_head_pick(hipStream_t s, const float* att, const int32_t* e_off, const 
                    const float* V, int lduv, const float* bias_matrix, int n_ecat, int n_pcat, int32_t* soid, float* acc);
 int bigc_repack_conv_weight(hipStream_t s, const float* w, float* out, int n_out, int n_in, int taps);
 int bigc_repack_conv_weight_bwd(hipStream_t s, const float* w, float* out, int n_out, int n_in, int taps);     // backward.hip
+int bigc_conv_grad_unpack_tapout(hipStream_t s, const float* g_tapout, float* g_torch, int n_out, int n_in, int taps);   // backward.hip
+int bigc_col_sum(hipStream_t s, const float* x, float* out, long rows, int d);                                          // backward.hip

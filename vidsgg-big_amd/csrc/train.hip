@@ -279,13 +279,23 @@ static int frontend_train_backward(bigc_model* m, void* s, const bigc_batch* b, 
     TRY(bw.lin("fc_enti2enco.0", m->enco0, geh, de, w.pooled, de * c.enco_pool_len, NT, de, de * c.enco_pool_len, w.gpooled,
                de * c.enco_pool_len, false));
     TRY(bigc_maxpool_bwd_f32(s, w.conv, b->trk_conv_off, w.gpooled, w.gconv, NT, de, c.enco_pool_len));
+    TRY(bigc_conv_gather_bwd_f32(s, w.gconv, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.G, NT, de));
+    static const bool conv_dw_gathered = getenv("BIGC_CONV_DW_GATHERED") && atoi(getenv("BIGC_CONV_DW_GATHERED")) != 0;
     if (float* gcw = grad_of(m, "conv_feat2enti.weight")) {
         ZERO(w.gconvw, (size_t)de * 6 * de);
-        TRY(bigc_linear_dw_f32(s, w.gconv, de, w.enti, 2 * de, w.conv_idx, 3, 2 * de, w.gconvw, 6 * de, grad_of(m, "conv_feat2enti.bias"),
-                               C, de, 6 * de));
-        TRY(bigc_conv_grad_unpack(hs, w.gconvw, gcw, de, 2 * de, 3));
+        if (conv_dw_gathered || bigc_linear_get_exact()) {
+            TRY(bigc_linear_dw_f32(s, w.gconv, de, w.enti, 2 * de, w.conv_idx, 3, 2 * de, w.gconvw, 6 * de, grad_of(m, "conv_feat2enti.bias"),
+                                   C, de, 6 * de));
+            TRY(bigc_conv_grad_unpack(hs, w.gconvw, gcw, de, 2 * de, 3));
+        } else {
+            // dW[o, c, k] = sum_j dconv[j, o] x[src(j, k), c] regrouped by SOURCE row: = sum_r G[r, k, o] x[r, c] with G the scatter of dconv
+            // that the dX product below needs anyway -- a plain (3 de) x (2 de) weight-gradient product over the R packed rows instead of
+            // a gathered one over the conv rows (the gathered kernel pays per-lane index arithmetic and selects: 80 TFLOP/s against 250)
+            TRY(bigc_linear_dw_f32(s, w.G, 3 * de, w.enti, 2 * de, nullptr, 1, 2 * de, w.gconvw, 2 * de, nullptr, R, 3 * de, 2 * de));
+            TRY(bigc_conv_grad_unpack_tapout(hs, w.gconvw, gcw, de, 2 * de, 3));
+            if (float* gcb = grad_of(m, "conv_feat2enti.bias")) TRY(bigc_col_sum(hs, w.gconv, gcb, C, de));
+        }
     }
-    TRY(bigc_conv_gather_bwd_f32(s, w.gconv, b->trk_row_off, b->trk_conv_off, b->trk_vid, b->vid_tmax, w.G, NT, de));
     if (!m->conv_w_bwd) {       // first backward of this model: later steps find it repacked by bigc_finalize (before the re-split)
         hipError_t e = hipMalloc((void**)&m->conv_w_bwd, sizeof(float) * (size_t)2 * de * 3 * de);
         if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: hipMalloc: %s", hipGetErrorString(e));

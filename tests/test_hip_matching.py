@@ -307,3 +307,39 @@ def test_training_step_that_reads_the_feature_rows_in_place_equals_the_one_on_pa
         assert not seen
     finally:
         eng.set_mode(*prev)
+
+
+def test_device_matched_training_step_never_waits_for_the_gpu(monkeypatch):
+    """forward + backward + clip + fused Adam of a device-matched step: no device-to-host copy, no synchronize -- the host can run a step
+    ahead (the reference's step downloads the cost matrix for scipy and aligns the GT adjacency on the host, models/model_0v10.py:583-637)"""
+    from test_hip_train import build_train_model
+    cfg, variant, sd, props, gts = cases.make_train_case("bigc_train_tiny")
+    model = build_train_model(cfg, variant, sd)
+    props = [p.to(torch.device(DEV)) for p in props]
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    duras = [g.traj_durations.clone() for g in gts]
+
+    def step():
+        for g, d in zip(gts, duras):
+            g.traj_durations = d.clone()
+        opt.zero_grad()
+        total, _terms = model(props, gts)
+        total.mean().backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5)
+        opt.step()
+        return total
+    step()                                                  # (first step: weight preparation, allocator warm-up)
+    torch.cuda.synchronize()
+    waits = []
+    real_cpu, real_item, real_tolist = torch.Tensor.cpu, torch.Tensor.item, torch.Tensor.tolist
+    monkeypatch.setattr(torch.Tensor, "cpu", lambda self, *a, **k: (waits.append("cpu") if self.is_cuda else None, real_cpu(self, *a, **k))[1])
+    monkeypatch.setattr(torch.Tensor, "item", lambda self: (waits.append("item") if self.is_cuda else None, real_item(self))[1])
+    monkeypatch.setattr(torch.Tensor, "tolist", lambda self: (waits.append("tolist") if self.is_cuda else None, real_tolist(self))[1])
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: waits.append("synchronize"))
+    monkeypatch.setattr(torch.cuda.Event, "synchronize", lambda self: waits.append("event.synchronize"))
+    monkeypatch.setattr(torch.cuda.Stream, "synchronize", lambda self: waits.append("stream.synchronize"))
+    total = step()
+    monkeypatch.undo()
+    assert waits == [], waits
+    torch.cuda.synchronize()
+    assert float(total) == float(total)                     # (a finite loss came out of the queued work)

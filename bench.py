@@ -287,7 +287,12 @@ def train_main(args):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dist, device)
+    elapsed_this_rank = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_this_rank, dist, device)
+    from bigc_hip.shard import flat_gradient_view, rank_report, time_allreduce
+    ranks = rank_report(dist, device, elapsed_this_rank, args.steps)
+    # the flat-gradient all-reduce alone (every rank takes part): microseconds, algorithmic and bus GB/s over the 111 MB buffer
+    allreduce_alone = time_allreduce(flat_gradient_view([p for p in model.parameters() if p.grad is not None]), dist)
     families = {}
     if not args.no_prof:        # per-family kernel time from a few extra steps: the event pairs around every launch slow the host down
         n_prof = min(args.steps, 5)
@@ -307,8 +312,9 @@ def train_main(args):
                                      "parallelism": "dp%d" % world}, "last_loss": round(float(last), 4),
                           "allreduce": {"backend": "nccl (RCCL)" if dist is not None else None,
                                         "flat_buffer_reduced_in_place": allreduce_gradients.last_in_place,
-                                        "bytes": 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)},
-                          "kernel_families_ms_per_step": families}))
+                                        "bytes": 4 * sum(p.numel() for p in model.parameters() if p.requires_grad),
+                                        "alone": allreduce_alone},
+                          "ranks": ranks, "kernel_families_ms_per_step": families}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -758,11 +764,16 @@ def main():
     host_diag = {"cpu_threads_busy": round((time.process_time() - cpu0) / max(elapsed, 1e-9), 2), "cpu_quota": usable_cores(),
                  "torch_threads": torch.get_num_threads(), "quota_throttled_periods_during_timed_steps": (throttled_periods() - thr0) if thr0 is not None else None,
                  "load_average_1min": round(os.getloadavg()[0], 1)}
+    elapsed_this_rank = elapsed
     if dist is not None:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # who took part (a collective on every rank): rank, host, device ordinal + UUID, each rank's own step time -- the N > 1 line proves
+    # through the job's own RCCL group that it ran one process per distinct GPU
+    from bigc_hip.shard import rank_report
+    ranks = rank_report(dist, device, elapsed_this_rank, args.steps)
     n_triplets_last = int(sum(r[0].shape[0] for r in last if r is not None)) if args.headline != "packed" else int(last.sum())
 
     # the other of the two entry points, same K steps (rank 0, outside `value`)
@@ -1081,7 +1092,7 @@ def main():
         "ms_per_step_median_each_step_synchronised": round(1e3 * float(np.median(per_step)), 3) if per_step else None,
         "triplets_last_step": n_triplets_last, "setup_s": round(gen_s, 1),
         "timed_steps_ms": [round(1e3 * (b - a), 2) for a, b in zip(stamps[:-1], stamps[1:])],
-        "host": host_diag,
+        "host": host_diag, "ranks": ranks,
         "timed_call": ("model(proposal_list, topk) on device-resident TrajProposals: tables + boxes of the ragged batch (the feature rows are read in place "
                        "through a row-address table, no copy) + forward + construct_triplet + compaction + one D2H copy + per-video result tuples" if args.headline == "api" else
                        "model.forward_packed(resident PackedBatch, topk) + the one D2H copy"),

@@ -628,6 +628,13 @@ int bigc_pair_triplets(void* stream, const float* pair_logits, int n_pred, int t
 int bigc_gemm_ps(void* stream, const void* A, long lda_bytes, int a_fmt, const int32_t* a_idx, int nseg, const float* W, int ldw,
                  const float* bias, const float* residual, long ldr, float* C, long ldc, void* Cs, long ldcs_bytes,
                  int M, int N, int K, int act, int* range_flag);
+/* The same product with the rows of A given by ADDRESS (row_ptr[m] -> K floats, 16-byte aligned): the first visual-feature layer
+ * fc_feat2enti.0 (models/model_0v10.py:446, on `features[:, :dim_feat]` of :438) reading the callers' per-tracklet tensors where they
+ * are -- the reference stacks them first (:391-430, utils/utils_func.py:49-91).  The raw f32 rows travel HBM -> LDS by DMA and are split
+ * in LDS.  two_acc != 0: the correction terms of the split products go to a second accumulator (128-row tiles), i.e. the rounding
+ * behaviour of the library's in-loop-split GEMM; results do not depend on anything else.  C and / or Cs as above. */
+int bigc_gemm_ps_rows(void* stream, const uint64_t* row_ptr, const float* W, int ldw, const float* bias, float* C, long ldc, void* Cs,
+                      long ldcs_bytes, int M, int N, int K, int act, int two_acc, int* range_flag);
 /* the same product with nn.LayerNorm over the N = 512 output features taken in the epilogue (models/model_0v10.py:188,211,223: the three
  * norms of a decoder layer follow a GEMM + residual): C = LayerNorm(act(A W^T + bias) + residual) * gamma + beta (+ add[m % add_period],
  * e.g. `+ pos_embedding`), Cs = the split form of the normalised rows (without the added table).  A must be in the split form. */

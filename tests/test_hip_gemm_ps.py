@@ -276,3 +276,74 @@ def test_second_accumulator_variant_in_its_own_process():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_gemm_ps.py"), "-q", "-m", "gpu", "-x", "-k",
                         "vs_float64 or gather_segments or strided"], env=dict(os.environ, BIGC_PS_ACC2="all"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("M,N,K,two_acc", [(700, 512, 2048, 1), (700, 512, 2048, 0), (256 * 300 + 13, 512, 128, 0), (256 * 300 + 13, 256, 64, 1), (5, 64, 32, 1)])
+def test_gemm_ps_rows_by_address(M, N, K, two_acc):
+    """bigc_gemm_ps_rows: the A rows given by ADDRESS (fc_feat2enti.0 reading the callers' per-tracklet tensors in place,
+    models/model_0v10.py:438,446): raw f32 rows by DMA, split in LDS.  Rows live in separately allocated blocks of different lengths and
+    pitches (the visual columns are the first K of wider rows), in shuffled order; against float64; the split twin = the f32 output
+    rounded; with / without the second accumulator; the result does not depend on how the rows are scattered."""
+    lib = _lib.load()
+    rs = np.random.RandomState(M + N + K + two_acc)
+    W = torch.from_numpy((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(DEV)
+    blocks, ptrs, rows, left = [], [], [], M
+    while left > 0:
+        n = int(min(left, rs.randint(1, 400)))
+        pitch = K + 4 * int(rs.randint(0, 50))                  # wider rows: the GEMM reads the first K floats of each
+        blk = torch.from_numpy(rs.standard_normal((n, pitch)).astype(np.float32)).to(DEV)
+        blocks.append(blk)
+        ptrs += [blk.data_ptr() + 4 * pitch * i for i in range(n)]
+        rows.append(blk[:, :K])
+        left -= n
+    order = rs.permutation(M)
+    A = torch.cat(rows)[torch.from_numpy(order).to(DEV)]
+    table = torch.from_numpy(np.asarray(ptrs, dtype=np.uint64)[order].view(np.int64)).to(DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    Cs = torch.zeros((M, 4 * N), dtype=torch.uint8, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(lib.bigc_gemm_ps_rows(_lib.current_stream(), table.data_ptr(), W.data_ptr(), K, bias.data_ptr(), C.data_ptr(), N, Cs.data_ptr(), 4 * N,
+                                     M, N, K, 1, two_acc, flag.data_ptr()))
+    torch.cuda.synchronize()
+    want = ref64(A, W, bias, None, 1)
+    tol = 6 * 2.0 ** -24 * budget(A, W) + 2.0 ** -23 * want.abs() + 1e-7
+    err = (C.double() - want).abs()
+    assert int(flag.item()) == 0
+    assert bool((err <= tol).all()), "max err/tol %.2f" % float((err / tol).max())
+    back = torch.from_numpy(hr8_decode(Cs, M, N)).to(DEV)
+    assert bool(((back - C.double()).abs() <= 2.0 ** -22.9 * C.double().abs() + 2.0 ** -28).all())
+    # the same rows as ONE dense matrix through bigc_gemm_ps (f32 operand): bit-identical when the tiling is the same (two_acc = 0 picks it from M alone)
+    if not two_acc:
+        C2, _, _ = run(A.contiguous(), 0, W, bias, None, 1, want_hr8=False)
+        assert torch.equal(C2, C)
+    # a NaN / an out-of-range value among the rows raises the flag
+    blocks[0][0, 1] = float("nan")
+    _lib.check(lib.bigc_gemm_ps_rows(_lib.current_stream(), table.data_ptr(), W.data_ptr(), K, bias.data_ptr(), C.data_ptr(), N, None, 0, M, N, K, 1, two_acc, flag.data_ptr()))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+    blocks[0][0, 1] = 4096.0
+    flag.zero_()
+    _lib.check(lib.bigc_gemm_ps_rows(_lib.current_stream(), table.data_ptr(), W.data_ptr(), K, bias.data_ptr(), C.data_ptr(), N, None, 0, M, N, K, 1, two_acc, flag.data_ptr()))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+
+
+def test_gemm_ps_two_accumulators_round_less():
+    """PsGemm.two_acc (the K >= 1024 GEMMs of the model: conv, fc_feat2enti.0): rms rounding error against float64 no larger than the
+    one-accumulator kernel's on the same operands, and within 7 units of 2^-24 rms(C) at K = 2048 (measured 5.0; torch's CPU GEMM 4.3)"""
+    lib = _lib.load()
+    rs = np.random.RandomState(3)
+    M, N, K = 2048, 512, 2048
+    A = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rs.standard_normal((N, K)) * (2.0 / (N + K)) ** 0.5).astype(np.float32)).to(DEV)
+    ref = A.double() @ W.double().t()
+    unit = float(ref.pow(2).mean().sqrt()) * 2.0 ** -24
+    table = torch.from_numpy((A.data_ptr() + 4 * K * np.arange(M, dtype=np.int64))).to(DEV)
+    out = {}
+    for two in (0, 1):
+        C = torch.empty((M, N), device=DEV)
+        _lib.check(lib.bigc_gemm_ps_rows(_lib.current_stream(), table.data_ptr(), W.data_ptr(), K, None, C.data_ptr(), N, None, 0, M, N, K, 0, two, None))
+        torch.cuda.synchronize()
+        out[two] = float((C.double() - ref).pow(2).mean().sqrt()) / unit
+    assert out[1] < out[0] and out[1] < 7.0, out

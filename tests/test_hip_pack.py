@@ -215,3 +215,58 @@ def test_forward_async_refuses_a_ninth_pending_forward():
         got = p.result()
         assert all(torch.equal(u, v) for u, v in zip(got[0], want[0]))
     model.forward_async(batch, topk=3).result()          # the slots are free again
+
+
+class _RefStyleProposal(object):
+    """A container that behaves like the reference's ``TrajProposal`` (dataloaders/dataloader_vidvrd.py:14-77): one tensor per tracklet
+    in plain lists, and ``.to(device)`` REPLACES the list items one by one and returns self."""
+
+    def __init__(self, p):
+        self.video_name, self.video_len, self.video_wh, self.num_proposals = p.video_name, p.video_len, p.video_wh, p.num_proposals
+        self.cat_ids, self.scores, self.traj_durations = p.cat_ids.clone(), p.scores.clone(), p.traj_durations.clone()
+        self.bboxes_list = [b.clone() for b in p.bboxes_list]
+        self.features_list = [f.clone() for f in p.features_list]
+        self.dim_feat = p.dim_feat
+
+    def to(self, device):
+        for i in range(self.num_proposals):
+            self.bboxes_list[i] = self.bboxes_list[i].to(device)
+            self.features_list[i] = self.features_list[i].to(device)
+        self.cat_ids, self.scores, self.traj_durations = self.cat_ids.to(device), self.scores.to(device), self.traj_durations.to(device)
+        return self
+
+
+@pytest.mark.gpu
+def test_eval_loop_over_reference_style_containers_does_not_retain_gpu_features():
+    """the eval tools move a video to the GPU, queue its forward, then ``p.to(cpu)`` -- and keep every proposal alive.  The
+    source table cached on the proposal used to hold the per-tracklet GPU tensors, so every evaluated video's features stayed allocated
+    until the run ended.  The cache holds addresses only now: allocated memory stays flat over the loop, and a video moved back to the
+    GPU (new addresses) is read correctly."""
+    cfg, model = _model("CONFIG_V")
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    vids = [_RefStyleProposal(synthetic_proposal(700 + i, n_trajs=24, feat_width=width, num_enti_cats=cfg["num_enti_cats"], len_range=(20, 40))) for i in range(6)]
+    per_video = sum(f.numel() * 4 for f in vids[0].features_list)
+    assert per_video > 2e6
+    # warm-up (workspace, weights): one video through the whole cycle
+    want0 = model([vids[0].to(DEV)], topk=3)[0]
+    want0 = tuple(t.cpu() for t in want0)
+    vids[0].to("cpu")
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    pend = None
+    for p in vids:
+        nxt = (p, model.forward_async([p.to(DEV)], topk=3))
+        if pend is not None:
+            pend[1].result()
+            pend[0].to("cpu")
+        pend = nxt
+    pend[1].result()
+    pend[0].to("cpu")
+    del pend, nxt
+    torch.cuda.synchronize()
+    grown = torch.cuda.memory_allocated() - base
+    assert grown < per_video, "GPU memory grew by %.1f MB over 6 videos of %.1f MB each" % (grown / 1e6, per_video / 1e6)
+    assert all(not f.is_cuda for p in vids for f in p.features_list)
+    # the first video once more on the GPU: fresh allocations, the stale table (other addresses) must not be used
+    got = model([vids[0].to(DEV)], topk=3)[0]
+    assert all(torch.equal(u.cpu(), v) for u, v in zip(got, want0))

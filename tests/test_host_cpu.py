@@ -298,5 +298,7 @@ def test_device_matching_is_only_chosen_where_it_reproduces_scipy(monkeypatch):
     assert not TS.match_on_device([g(4, 5), g(40, 2)], 12)
     assert not TS.match_on_device([g(4, 0)], 12)                    # no GT trajectory: the alignment has nothing to arg-max over
     assert not TS.match_on_device([g(0, 3)], 12)
+    # what the device kernels refuse takes the host route too (alignment: 8192 proposals per video in LDS; assignment: 1024 queries)
+    assert TS.match_on_device([g(4, 5)], 1024, max_trk=8192) and not TS.match_on_device([g(4, 5)], 1025) and not TS.match_on_device([g(4, 5)], 12, max_trk=8193)
     monkeypatch.setenv("BIGC_MATCH_ON_HOST", "1")
     assert not TS.match_on_device([g(4, 5)], 12)

@@ -109,3 +109,73 @@ def test_two_rank_gloo_matches_single_process():
         assert p.exitcode == 0
     assert ok
     assert slow == 2.0
+
+
+def _worker4(rank, world, port, q):
+    """World 4, an uneven batch of 6 videos: ranks 0 and 1 own two videos each, ranks 2 and 3 one (utils/DataParallel.py:80-92 asserts
+    divisibility; the remainder goes to the first ranks here).  A second batch of 3 leaves rank 3 without a chunk: it contributes zeros and
+    the mean runs over the three ranks that had one (`contributing`), as the reference's DataParallel makes one replica per chunk (:65-69)."""
+    import torch.distributed as dist
+    from bigc_hip.shard import rank_report, time_allreduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["LOCAL_RANK"] = str(rank), str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    B = 6
+    mine = shard_indices(B, rank, world)
+    assert mine == [[0, 1], [2, 3], [4], [5]][rank]
+    # per-video "gradients": video i contributes (i + 1) everywhere; a rank's gradient is the MEAN over its own chunk (the loss means are per
+    # replica, models/model_0v10.py:648-703), the job's gradient the mean over the ranks
+    buf = torch.full((10,), sum(i + 1.0 for i in mine) / len(mine))
+    ps = [torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(6))]
+    ps[0].grad, ps[1].grad = buf[:4], buf[4:]
+    flat = allreduce_gradients(ps, dist, contributing=min(B, world))
+    want = (1.5 + 3.5 + 5.0 + 6.0) / 4
+    assert allreduce_gradients.last_in_place is True and flat.data_ptr() == buf.data_ptr() and torch.allclose(buf, torch.full((10,), want))
+    # batch of 3 on 4 ranks: the empty rank takes part with zeros, the mean is over 3
+    B2 = 3
+    mine2 = shard_indices(B2, rank, world)
+    assert mine2 == ([rank] if rank < 3 else [])
+    qs = [torch.nn.Parameter(torch.zeros(5))]
+    if mine2:
+        qs[0].grad = torch.full((5,), float(10 * (rank + 1)))
+    else:
+        zero_gradients(qs)
+    allreduce_gradients(qs, dist, contributing=min(B2, world))
+    assert torch.allclose(qs[0].grad, torch.full((5,), 20.0))
+    # the self-proving fields of bench.py's N > 1 lines, and the all-reduce timed alone
+    rep = rank_report(dist, None, seconds=0.010 * (rank + 1), steps=2)
+    tim = time_allreduce(torch.ones(1 << 16), dist, repeats=2)
+    res = gather_results([("v%d" % i,) for i in mine], mine, B, dist)
+    if rank == 0:
+        q.put((rep, tim, res))
+    dist.destroy_process_group()
+
+
+def test_four_rank_gloo_uneven_batch_and_rank_report():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    rep, tim, res = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert rep["world"] == 4 and rep["ranks_seen"] == [0, 1, 2, 3] and rep["backend"] == "gloo" and len(rep["devices"]) == 4
+    assert len({d["pid"] for d in rep["devices"]}) == 4                          # four processes
+    assert rep["ms_per_step_min"] == 5.0 and rep["ms_per_step_max"] == 20.0      # each rank's own step time, min / max over ranks
+    assert tim["world"] == 4 and tim["bytes"] == 4 << 16 and tim["us"] > 0 and abs(tim["bus_gb_per_s"] - 1.5 * tim["algorithmic_gb_per_s"]) < 0.02
+    assert res == [("v%d" % i,) for i in range(6)]
+
+
+def test_rank_report_without_a_group():
+    from bigc_hip.shard import rank_report, time_allreduce
+    rep = rank_report(None, None, seconds=0.5, steps=10)
+    assert rep["world"] == 1 and rep["ranks_seen"] == [0] and rep["distinct_devices"] == 1 and rep["ms_per_step_max"] == 50.0
+    assert time_allreduce(torch.ones(4), None) is None

@@ -139,6 +139,10 @@ def test_bench_json_contract():
     assert d["batch_x2"]["videos_per_step"] == 16 and d["batch_x2"]["value"] > 0 and d["batch_x2"]["roofline"]["bound"] == "mfma"
     g, t = d["grounding"], d["train"]
     assert g["unit"] == "triplet-queries/s" and g["value"] > 0
+    # who took part: one rank on one device here; at N > 1 the same object lists every rank's device UUID and its own step time
+    rk = d["ranks"]
+    assert rk["world"] == 1 and rk["ranks_seen"] == [0] and rk["distinct_devices"] == 1 and rk["devices"][0]["uuid"] and rk["devices"][0]["name"]
+    assert abs(rk["ms_per_step_max"] - d["ms_per_step"]) < 1e-2 and rk["ms_per_step_min"] == rk["ms_per_step_max"]
     assert t["videos_8"]["value"] > 0 and t["videos_64"]["value"] > 0
 
 
@@ -149,6 +153,9 @@ def test_bench_train_mode_runs_rccl_allreduce_on_one_rank():
     assert d["metric"] == "train_tracklet_pairs_per_sec" and d["value"] > 0 and d["n_gpus"] == 1
     a = d["allreduce"]
     assert a["backend"].startswith("nccl") and a["flat_buffer_reduced_in_place"] is True and a["bytes"] > 100e6
+    # the all-reduce timed alone over the same flat buffer, and the ranks that took part (gathered through the RCCL group)
+    assert a["alone"]["bytes"] == a["bytes"] and a["alone"]["us"] > 0 and a["alone"]["world"] == 1
+    assert d["ranks"]["backend"] == "nccl" and d["ranks"]["ranks_seen"] == [0] and d["ranks"]["devices"][0]["uuid"]
     assert d["last_loss"] == d["last_loss"]          # finite
 
 
@@ -158,3 +165,4 @@ def test_bench_eval_mode_with_rccl_group_and_self_launch():
     d = _bench(["--videos", "4", "--steps", "2", "--warmup", "1", "--cpu-videos", "0", "--exact-steps", "0", "--legs", "", "--no-prof", "--recall-steps", "0"],
                env={"BIGC_BENCH_FORCE_DIST": "1", "BIGC_BENCH_SELF_LAUNCH": "1"})
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+    assert d["ranks"]["backend"] == "nccl" and d["ranks"]["world"] == 1 and d["ranks"]["distinct_devices"] == 1

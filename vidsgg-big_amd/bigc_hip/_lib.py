@@ -69,6 +69,8 @@ _SIGS = {
                                 c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "bigc_gemm_ps": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, ctypes.c_long,
                              c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p]),
+    "bigc_gemm_ps_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p]),
     "bigc_gemm_ps_ln": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_void_p, c_int, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_float, c_void_p, c_int,
                                 c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "bigc_split_rows_f32": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, ctypes.c_long, c_int, c_void_p]),

@@ -31,8 +31,18 @@ def tracklet_table(p, device):
     built by this package (``TrajProposal.from_blocks`` / ``.to()``, ``bigc_hip.ingest``) hold their tracklets as views of one
     block per video and get the table by arithmetic; for foreign containers (the reference's own ``TrajProposal``) the
     tensors are visited once.  The cache is checked against the lists' length and first / last addresses: replacing a
-    tensor in the middle of ``features_list`` after the first forward needs ``del proposal._bigc_pack``."""
+    tensor in the middle of ``features_list`` after the first forward needs ``del proposal._bigc_pack``.
+    The cached table holds ADDRESSES only, never tensors (a table that kept its sources alive pinned every evaluated
+    video's GPU features for the whole run once the reference's ``TrajProposal.to(cpu)`` had replaced the list items); what keeps the
+    memory behind the addresses alive while a forward reads it is the ``PackedBatch`` (``_sources``), for as long as IT lives.  A table
+    made for another device is dropped."""
     c = getattr(p, "_bigc_pack", None)
+    if c is not None and c.get("device") != device:
+        try:
+            del p._bigc_pack
+        except Exception:
+            pass
+        c = None
     if c is not None and "blocks" in c:
         # a container of this package: its tracklets ARE views of two blocks (no per-tracklet tensor objects exist)
         if c["device"] == device and c["blocks"] == (p._feat_block.data_ptr(), p._box_block.data_ptr()) and c["n"] == int(p.num_proposals):
@@ -42,7 +52,8 @@ def tracklet_table(p, device):
     n = len(bl)
     assert n == len(fl) and n == int(p.num_proposals)
     if c is not None and c["n"] == n and c["device"] == device and c["ends"] == (fl[0].data_ptr(), fl[-1].data_ptr(), bl[0].data_ptr(), bl[-1].data_ptr()):
-        return c
+        # the caller's lists as they are NOW keep the rows alive for this batch (64 references per video; nothing is stored on `p`)
+        return dict(c, sources=(list(fl), list(bl)))
     keep = []
     width = int(fl[0].shape[1])
 
@@ -63,16 +74,15 @@ def tracklet_table(p, device):
     fld = np.fromiter((f.stride(0) if f.shape[0] > 1 else width for f in fl2), dtype=np.int64, count=n)
     c = dict(n=n, device=device, width=width, lens=lens, fptr=fptr, bptr=bptr, fld=None if (fld == width).all() else fld.astype(np.int32),
              aligned=bool(((fptr | bptr) % np.uint64(16) == 0).all() and (fld % 4 == 0).all()),
-             ends=(fl[0].data_ptr(), fl[-1].data_ptr(), bl[0].data_ptr(), bl[-1].data_ptr()), keep=keep,
-             # the table holds raw addresses: it keeps the tensors they point into alive for as long as it exists (a caller that drops a
-             # tensor from the middle of its list must not leave the forward reading freed memory)
-             sources=(list(fl2), list(bl2)))
+             ends=(fl[0].data_ptr(), fl[-1].data_ptr(), bl[0].data_ptr(), bl[-1].data_ptr()), keep=[])
     if not keep:                  # (a table that points at converted COPIES is not kept: the caller may change its own tensors' values in place)
         try:
-            p._bigc_pack = c
+            p._bigc_pack = c      # addresses only
         except Exception:
             pass
-    return c
+    # the copy handed to the PackedBatch carries the references that keep the addressed memory alive (a caller that drops a tensor from
+    # the middle of its list while the batch is in flight must not leave the forward reading freed memory)
+    return dict(c, keep=keep, sources=(list(fl2), list(bl2)))
 
 
 class PackedBatch(object):
@@ -90,6 +100,7 @@ class PackedBatch(object):
         assert min(n_per_vid) > 0, "empty videos must be filtered out before packing"
         tabs = [tracklet_table(p, device) for p in proposals]
         self._keep = [t["keep"] for t in tabs if t["keep"]]
+        self._sources = [t["sources"] for t in tabs if "sources" in t]      # foreign containers: their tensors, for the life of THIS batch
         self.feat_width = tabs[0]["width"]
         assert all(t["width"] == self.feat_width for t in tabs), "all videos of a batch need the same feature width"
         self.n_vid = len(proposals)
@@ -111,8 +122,9 @@ class PackedBatch(object):
 
         # per-video metadata: gathered on the device when the containers hold what the reference's do (int64 / f32 / int64)
         def meta_usable(p, t):
-            key = (id(p.cat_ids), id(p.scores), id(p.traj_durations))
-            if t.get("meta_key") != key:                        # checked once per set of tensors (nine attribute reads per video otherwise)
+            # keyed on the tensors' ADDRESSES (id() of a freed tensor object can come back for a new one: ADVICE r04)
+            key = (p.cat_ids.data_ptr(), p.scores.data_ptr(), p.traj_durations.data_ptr(), p.cat_ids.device, p.cat_ids.dtype, p.scores.dtype)
+            if t.get("meta_key") != key:                        # checked once per set of tensors
                 t["meta_key"] = key
                 t["meta_ok"] = bool(p.cat_ids.dtype == torch.int64 and p.scores.dtype == torch.float32 and p.traj_durations.dtype == torch.int64
                                     and p.cat_ids.device == device and p.scores.device == device and p.traj_durations.device == device
@@ -258,7 +270,7 @@ class PackedBatch(object):
 
     def drop_sources(self):
         """forget the source containers (their tensors may then be freed); the gathered forms stay"""
-        self.proposals, self._keep = None, None
+        self.proposals, self._keep, self._sources = None, None, None
 
     def n_pairs(self):
         """tracklet-pairs of the batch: sum_v N_v (N_v - 1)."""

@@ -74,6 +74,61 @@ def max_over_ranks(seconds, dist=None, device=None):
     return float(t.item())
 
 
+def rank_report(dist=None, device=None, seconds=None, steps=1):
+    """What the N > 1 lines of bench.py print so that they prove themselves: every rank's (rank, local rank, host, device ordinal, device
+    UUID / name, its own step time) gathered on ALL ranks through the job's process group -- RCCL on the GPU boxes, gloo in the CPU tests.
+    -> dict(world, ranks_seen, distinct_devices, devices=[...], ms_per_step_min / _max over ranks).  A line whose ``ranks_seen`` or
+    ``distinct_devices`` is smaller than ``n_gpus`` did not run one process per GPU."""
+    import os
+    import socket
+    me = dict(rank=int(os.environ.get("RANK", 0)), local_rank=int(os.environ.get("LOCAL_RANK", 0)), host=socket.gethostname(), pid=os.getpid(),
+              device=None, uuid=None, name=None, ms_per_step=None if seconds is None else 1e3 * float(seconds) / max(1, steps))
+    if device is not None and torch.device(device).type == "cuda":
+        idx = torch.device(device).index
+        idx = torch.cuda.current_device() if idx is None else idx
+        prop = torch.cuda.get_device_properties(idx)
+        me.update(device=int(idx), uuid=str(getattr(prop, "uuid", "")), name=prop.name)
+    active = dist is not None and dist.is_initialized()
+    if active:
+        me["rank"] = dist.get_rank()
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, me)
+    else:
+        everyone = [me]
+    everyone = sorted(everyone, key=lambda d: d["rank"])
+    devs = {(d["host"], d["uuid"] if d["uuid"] else d["device"]) for d in everyone}
+    ms = [d["ms_per_step"] for d in everyone if d["ms_per_step"] is not None]
+    return dict(world=len(everyone), ranks_seen=sorted({d["rank"] for d in everyone}), distinct_devices=len(devs),
+                backend=(dist.get_backend() if active else None), devices=everyone,
+                ms_per_step_min=round(min(ms), 3) if ms else None, ms_per_step_max=round(max(ms), 3) if ms else None)
+
+
+def time_allreduce(flat, dist=None, repeats=5):
+    """The flat-gradient all-reduce ALONE (bench.py --mode train): ``repeats`` all-reduces of ``flat`` (a scratch copy: the gradients
+    are left alone) bracketed by device synchronisation -> dict(us, bytes, algorithmic GB/s = bytes / time, bus GB/s = 2 (n-1)/n of
+    that: what each rank moves over its links in a ring / direct reduce-scatter + all-gather)."""
+    import time
+    if flat is None or dist is None or not dist.is_initialized():
+        return None
+    buf = flat.clone()
+    sync = torch.cuda.synchronize if buf.is_cuda else (lambda: None)
+    dist.all_reduce(buf)                     # warm-up (communicator set-up)
+    sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        dist.all_reduce(buf)
+    sync()
+    el = (time.perf_counter() - t0) / repeats
+    t = torch.tensor([el], dtype=torch.float64, device=buf.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    n = dist.get_world_size()
+    nbytes = buf.numel() * buf.element_size()
+    return dict(us=round(1e6 * el, 1), bytes=int(nbytes), world=n, algorithmic_gb_per_s=round(nbytes / el / 1e9, 2),
+                bus_gb_per_s=round(nbytes / el / 1e9 * 2 * (n - 1) / n, 2), repeats=repeats)
+
+
 def flat_gradient_view(params):
     """The gradients of ``params`` as ONE flat tensor WITHOUT copying, when they already live back to back in a single
     storage -- which is how the HIP backward hands them out (bigc_hip/train_step.py: every ``.grad`` is a view of one

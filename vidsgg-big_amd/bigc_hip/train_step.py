@@ -134,11 +134,15 @@ class MatchIndices(object):
         return self._get()[i]
 
 
-def match_on_device(gt_graph_list, n_query):
+def match_on_device(gt_graph_list, n_query, max_trk=0):
     """The device matching (``bigc_align_adjacency`` + ``bigc_hungarian``) covers what training batches look like: every video
     has GT trajectories and fewer GT predicates than the model has queries (then every GT predicate is matched and the loss
-    normalisers are known without looking at the assignment).  Anything else, or BIGC_MATCH_ON_HOST=1, takes the host route."""
+    normalisers are known without looking at the assignment).  Anything else, or BIGC_MATCH_ON_HOST=1, takes the host route --
+    including what the kernels themselves refuse: ``bigc_align_adjacency`` keeps a video's per-proposal arg-max table in
+    LDS (at most 8192 proposals), ``bigc_hungarian`` spreads the queries over one workgroup's lanes (at most 1024 queries)."""
     if os.environ.get("BIGC_MATCH_ON_HOST", "0") == "1":
+        return False
+    if n_query > 1024 or max_trk > 8192:
         return False
     return all(0 < int(g.adj_matrix.shape[1]) < n_query and len(g.traj_bboxes) > 0 for g in gt_graph_list)
 
@@ -163,7 +167,7 @@ def forward(model, engine, packed, gt_graph_list):
     ctx.ws = torch.empty((need,), dtype=torch.uint8, device=dev)
     ctx.logits = torch.empty((B * Q, P), dtype=torch.float32, device=dev)
     ctx.att = torch.empty((2 * Q * NT,), dtype=torch.float32, device=dev)
-    ctx.on_device = match_on_device(gt_graph_list, Q)
+    ctx.on_device = match_on_device(gt_graph_list, Q, packed.max_trk)
     stream = _lib.current_stream()
     mark("fwd: buffers")
     engine.check_match_flags()                                  # (an invalid cost matrix of an EARLIER device-matched step raises here)

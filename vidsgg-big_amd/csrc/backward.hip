@@ -755,8 +755,10 @@ __global__ void conv_grad_unpack_tapout_kernel(const float* __restrict__ g, floa
     out[i] += g[((long)k * n_out + o) * n_in + c];
 }
 
-// out[c] += sum over the rows of x (rows, d): chunks of 256 rows per workgroup, one atomic per column and workgroup
-__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int d) {
+// out[c] += sum over the rows of x (rows, d): chunks of 256 rows per workgroup -> one partial row per workgroup, summed IN BLOCK ORDER by
+// col_sum_finish_kernel (one float atomic per column and workgroup made the low bits of conv_feat2enti.bias.grad vary from run
+// to run; every other gradient of this file has a fixed summation order)
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, float* __restrict__ partial, long rows, int d) {
     const long r0 = (long)blockIdx.x * 256, r1 = r0 + 256 < rows ? r0 + 256 : rows;
     for (int c = threadIdx.x; c < d; c += 256) {
         float s = 0.f;
@@ -769,8 +771,25 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
             for (int u = 0; u < 8; ++u) s += v[u];
         }
         for (; r < r1; ++r) s += x[(size_t)r * d + c];
-        atomicAdd(&out[c], s);
+        partial[(size_t)blockIdx.x * d + c] = s;
     }
+}
+
+// out[c] += partial[0][c] + partial[1][c] + ... (one thread per column, eight rows in flight, the additions in block order)
+__global__ __launch_bounds__(64) void col_sum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int blocks, int d) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= d) return;
+    float s = 0.f;
+    int b = 0;
+    for (; b + 8 <= blocks; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + u) * d + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < blocks; ++b) s += partial[(size_t)b * d + c];
+    out[c] += s;
 }
 
 // out (cols, ld_out) = in (rows, cols)^T with the columns [rows, ld_out) zero-filled
@@ -851,7 +870,7 @@ static int dw_scratch(void* stream, size_t need_floats, int slot, float** out) {
     thread_local std::unordered_map<int, Buf> bufs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_dw: hipGetDevice failed");
-    Buf& b = bufs[dev * 2 + slot];
+    Buf& b = bufs[dev * 4 + slot];
     if (need_floats > b.cap) {
         if (b.p) { if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_dw: sync failed"); (void)hipFree(b.p); }
         b.cap = need_floats + need_floats / 2;
@@ -888,8 +907,12 @@ static int dw_launch(void* stream, const float* dY, int ldy, const float* X, int
         float* scratch = nullptr;
         if (int rc = dw_scratch(stream, need, 0, &scratch)) return rc;
         p.partial = scratch;
-        // arrival counters of the in-kernel reduction (zero between launches)
-        static int* arrived = nullptr;
+        // arrival counters of the in-kernel reduction (zero between launches); one set per (calling thread, device) like the scratch
+        // (a function-static pointer was shared by threads driving different devices)
+        thread_local std::unordered_map<int, int*> arrived_of;
+        int dev_now = 0;
+        if (hipGetDevice(&dev_now) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_dw: hipGetDevice failed");
+        int*& arrived = arrived_of[dev_now];
         // (measured, 8-video training step: the in-kernel form costs 99 us per launch against 19 + 6 us for the two launches --
         // every workgroup pays a device-scope release, an L2 write-back on this chip -- so it is the opt-in, BIGC_DW_REDUCE=inline)
         static const bool two_launches = !(getenv("BIGC_DW_REDUCE") && !strcmp(getenv("BIGC_DW_REDUCE"), "inline"));
@@ -1127,7 +1150,11 @@ int bigc_conv_grad_unpack_tapout(hipStream_t s, const float* g_tapout, float* g_
 
 int bigc_col_sum(hipStream_t s, const float* x, float* out, long rows, int d) {
     if (rows <= 0) return BIGC_OK;
-    hipLaunchKernelGGL(col_sum_kernel, dim3((int)((rows + 255) / 256)), dim3(256), 0, s, x, out, rows, d);
+    const int blocks = (int)((rows + 255) / 256);
+    float* partial = nullptr;
+    if (int rc = dw_scratch((void*)s, (size_t)blocks * d, 2, &partial)) return rc;
+    hipLaunchKernelGGL(col_sum_kernel, dim3(blocks), dim3(256), 0, s, x, partial, rows, d);
+    hipLaunchKernelGGL(col_sum_finish_kernel, dim3(cdiv(d, 64)), dim3(64), 0, s, partial, out, blocks, d);
     BIGC_LAUNCH_CHECK("col_sum");
     return BIGC_OK;
 }

@@ -28,7 +28,15 @@
 //
 // A modes: 0 = hr8 rows by DMA; 1 = hr8 rows gathered through an index table (the stride-2 temporal conv over the virtual
 // stretch: 3 segments of 2*dim_enti; index -1 = a row of zeros); 2 = f32 rows (raw input features, attention outputs):
-// loaded to registers one slab ahead, split in the loop and written to LDS with ds_write_b64, W still by DMA.
+// loaded to registers one slab ahead, split in the loop and written to LDS with ds_write_b64, W still by DMA;
+// 3 = f32 rows by DMA, split IN PLACE in LDS (round 5): a K = 32 slab of an f32 row is 128 bytes, exactly the size of its split form, so
+// the raw row goes HBM -> LDS by the same DMA pieces as an hr8 row (same swizzled chunk addresses: raw chunk c = floats 4 c .. 4 c + 3),
+// and the wave that issued a piece later turns its 16 bytes per lane into 8 bytes of heads + 8 bytes of residuals and writes them over
+// the piece (chunk pair (2 g, 2 g + 1) = [8 heads | 8 residuals] of floats 8 g .. 8 g + 7: a lane holding floats 8 g + 4 p .. + 3 writes
+// its heads into half p of chunk 2 g and its residuals into half p of chunk 2 g + 1 -- its own 16-byte slot and its lane neighbour's).
+// One ds_read_b128, ~14 VALU and two ds_write_b64 per lane and piece, no registers across the loop, no barrier of its own (a wave converts
+// only what its own DMA brought, after its own vmcnt).  Row bases come from a table of addresses (bigc_batch.feat_row_ptr: the callers'
+// per-tracklet rows read where they are, models/model_0v10.py:436-448) or A + m lda, kept per lane in LDS behind the stages.
 //
 // Range: an element with |X| >= 32768, NaN or Inf cannot be split.  Whoever splits (epilogue, A mode 2, the weight pre-pass)
 // raises *range_flag; results are then invalid and the caller re-runs the step on the exact f32 path (bigc_hip/engine.py does,
@@ -131,7 +139,8 @@ __global__ __launch_bounds__(256) void split_rows_hr8_kernel(const float* __rest
 }
 
 struct PsArgs {
-    const unsigned char* A; long lda;                 // A rows: hr8 (modes 0, 1) or f32 (mode 2); pitch in BYTES
+    const unsigned char* A; long lda;                 // A rows: hr8 (modes 0, 1) or f32 (modes 2, 3); pitch in BYTES
+    const unsigned long long* a_rowptr;               // mode 3: address of row m (16-byte aligned, K floats) instead of A + m * lda, or null
     const int32_t* a_idx; int nseg; int seg_bytes;    // mode 1: source row of (output row, segment), -1 = zeros; bytes of a segment
     const unsigned char* zero_row;
     const unsigned char* Ws; long ldw;                // hr8 weights (N, K), pitch in bytes
@@ -167,6 +176,7 @@ struct PsArgs {
 template <int AMODE, int RB, bool TRACE = false, bool FAST = false, bool BLOCKED = false, bool LNM = false, bool ACC2 = false>
 __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     static_assert(!ACC2 || (RB == 2 && !FAST && !BLOCKED && !LNM), "second accumulator: 128-row tiles only (registers)");
+    static_assert(AMODE != 3 || (RB != 3 && !LNM && !BLOCKED), "in-LDS split of DMA'd f32 rows: 128- or 256-row tiles");
     static_assert(!LNM || (AMODE == 0 && (RB == 2 || RB == 3) && !BLOCKED && !TRACE), "LayerNorm epilogue: plain hr8 operand, 64- or 96-row tiles");
     constexpr int TNK = LNM ? 512 : TN;                       // output features per tile
     constexpr int NWF = TNK / 64, NWR = 8 / NWF;              // waves side by side over the features / stacked over the rows
@@ -178,7 +188,9 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     constexpr int MAXSEG = 4;                                 // mode 1: K segments (gathered row tables) supported
     constexpr int IDX_OFF = NST * STAGE_BYTES;                // mode 1: behind the stages, a lane-private table of source rows (below)
     constexpr int LN_OFF = NST * STAGE_BYTES;                 // LNM: behind the stages, per row and wave the partial sums of the two LayerNorm passes
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES + (AMODE == 1 ? RB * MAXSEG * 2048 : 0) + (LNM ? 2 * TM * 8 * 4 : 0)];
+    constexpr int PTR_OFF = NST * STAGE_BYTES;                // mode 3: behind the stages, a lane-private table of row base addresses (u64)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES + (AMODE == 1 ? RB * MAXSEG * 2048 : 0) + (LNM ? 2 * TM * 8 * 4 : 0) +
+                                                                 (AMODE == 3 ? ((TM / 8 + 7) / 8) * 4096 : 0)];
     AS3 unsigned char* lds = (AS3 unsigned char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -239,6 +251,17 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         iw_base = p.Ws + (size_t)n0 * p.ldw;
         a_lim = p.M - 1 - m0;
         w_lim = p.N - 1 - n0;
+        if (AMODE == 3) {
+            // row base addresses of this lane's rows of the tile's NA pieces (one batch of table reads per tile)
+            unsigned long long v[NA];
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int row = min(m0 + (wave + 8 * q) * 8 + l8, p.M - 1);
+                v[q] = p.a_rowptr ? p.a_rowptr[row] : (unsigned long long)(p.A + (size_t)row * p.lda);
+            }
+#pragma unroll
+            for (int q = 0; q < NA; ++q) *(AS3 unsigned long long*)(lds + PTR_OFF + (q * 512 + tid) * 8) = v[q];
+        }
         if (AMODE == 1) {
             // one batch of table reads per tile (the wait in front of the ds_writes also waits for the slabs in flight)
             int v[NA * MAXSEG];
@@ -262,7 +285,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     auto issue_a_piece = [&](int i, int so) {
         const int blk = wave + 8 * i;
         if (NBLK_A % 8 != 0 && blk >= NBLK_A) return;
-        if (AMODE == 1) {
+        if (AMODE == 3) {
+            const unsigned long long rb = *(const AS3 unsigned long long*)(lds + PTR_OFF + (i * 512 + tid) * 8);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const unsigned char*)rb + (size_t)ikt * ROWB + coff), (AS3 void*)(lds + so + blk * 1024), 16, 0, 0);
+        } else if (AMODE == 1) {
             const int gi = *(const AS3 int*)(lds + IDX_OFF + ((i * MAXSEG + isg) * 512 + tid) * 4);
             const unsigned char* src = (gi >= 0 ? p.A + (size_t)gi * p.lda : p.zero_row) + coff + ichunk * ROWB;    // index -1: a row of zeros
             __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(lds + so + blk * 1024), 16, 0, 0);
@@ -314,6 +340,25 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
             *(AS3 u32x2*)(lds + so + wof[i]) = u32x2{h0, h1};
             *(AS3 u32x2*)(lds + so + (wof[i] ^ 16)) = u32x2{r0, r1};
         }
+    };
+    // mode 3: piece i of the slab in stage `so` (this wave's own DMA, landed: the caller waited on vmcnt) from raw f32 to the split form, in
+    // place.  conv_read fetches the lane's 16 bytes, conv_write splits them and stores heads / residuals (see the header comment).
+    const int pbit = ((lane & 7) ^ sw_src) & 1;                            // this lane's chunk holds floats 8 g + 4 pbit .. + 3 of its group
+    f32x4 cv[AMODE == 3 ? NA : 1];
+    auto conv_read = [&](int i, int so) {
+        const int blk = wave + 8 * i;
+        cv[i] = *(const AS3 f32x4*)(lds + so + blk * 1024 + lane * 16);
+    };
+    auto conv_write = [&](int i, int so) {
+        const int blk = wave + 8 * i;
+        unsigned h0, h1, r0, r1;
+        split2(cv[i][0] * ACT_SCALE, cv[i][1] * ACT_SCALE, h0, r0);
+        split2(cv[i][2] * ACT_SCALE, cv[i][3] * ACT_SCALE, h1, r1);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(cv[i][0]), fabsf(cv[i][1])), fmaxf(fabsf(cv[i][2]), fabsf(cv[i][3]))));
+        asm volatile("v_fmac_f32 %0, 0, %1" : "+v"(nanacc) : "v"((cv[i][0] + cv[i][1]) + (cv[i][2] + cv[i][3])));     // NaN / Inf x 0 = NaN (fmaxf drops NaNs)
+        const int a = so + blk * 1024 + lane * 16;
+        *(AS3 u32x2*)(lds + (a ^ (pbit << 4)) + 8 * pbit) = u32x2{h0, h1};
+        *(AS3 u32x2*)(lds + (a ^ ((pbit ^ 1) << 4)) + 8 * pbit) = u32x2{r0, r1};
     };
     bool oob = false;
 
@@ -585,6 +630,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     } else {
         issue_slab(so[0]); issue_advance();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (AMODE == 3) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) conv_read(i, so[0]);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) conv_write(i, so[0]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -620,10 +672,21 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
             if (n == 0 && (p.ablate & 8) && wave >= 4) __builtin_amdgcn_s_setprio(0);
             mm(WF[s & 1], AF[n & 1], u, 0, 2);
             bool open_now = false;
+            // mode 3: slab g + 1's A pieces (this wave's own DMA) are converted during unit CONV_N of slab g, one unit or more ahead of
+            // barrier_g.  What may still be in flight behind them: 128-row tiles (three stages): their slab's W pieces and all of slab g + 2;
+            // 256-row tiles (two stages): their slab's W pieces (issued during unit 0).
+            constexpr int CONV_N = NU == 2 ? 0 : 2;
+            const bool conv_now = AMODE == 3 && n == CONV_N && more;
             if (!last) {
                 // fragments of the next unit of this slab
                 if (u == U - 1) rd_w(so[0], s + 1, WF[(s + 1) & 1]);
                 rd_a(so[0], (n + 1) / U, (n + 1) % U, AF[(n + 1) & 1]);
+                if (conv_now) {
+                    if (D > 1 && g + 2 < n_flat) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPCL + NW) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NW) : "memory");
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) conv_read(i, so[1]);
+                }
             } else {
                 if (more) {
                     if (AMODE == 2) {
@@ -661,6 +724,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
                 mm(WF[s & 1], AF[n & 1], u, 2 + 2 * k, 4 + 2 * k);
                 __builtin_amdgcn_sched_barrier(0);
                 if (pb + k < pe && issuing) issue_piece(pb + k, last ? so[0] : so[NST - 1]);
+                if (AMODE == 3 && conv_now && k >= 1 && k - 1 < NA) conv_write(k - 1, so[1]);         // one piece per MFMA pair, from the third pair on
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (pb + NS - 1 < pe && issuing) issue_piece(pb + NS - 1, last ? so[0] : so[NST - 1]);
@@ -686,7 +750,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         for (int i = 0; i < 5; ++i) p.trace[((size_t)blockIdx.x * 8 + wave) * 5 + i] = tr[i];
     }
     if ((int)p.whdr[0] == p.wbad_id) oob = true;
-    if (AMODE == 2) oob |= !(amax * ACT_SCALE < F16_LIMIT) || !(nanacc == 0.f);
+    if (AMODE == 2 || AMODE == 3) oob |= !(amax * ACT_SCALE < F16_LIMIT) || !(nanacc == 0.f);
     if (__builtin_amdgcn_ballot_w64(oob) != 0 && lane == 0 && p.range_flag) atomicOr(p.range_flag, 1);
 }
 
@@ -746,13 +810,15 @@ void bigc_gemm_ps_cache_forget(const float* w) {
 
 bool bigc_gemm_ps_supported(const PsGemm& g) {
     if (g.M <= 0 || g.N < 8 || g.K < TK || g.K % TK != 0 || g.N % 8 != 0) return false;
-    if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15) || g.lda % 16 != 0 || g.ldw % 4 != 0) return false;
+    if (g.a_rowptr) { if (g.a_fmt != PS_F32 || g.a_idx) return false; }
+    else if (((uintptr_t)g.A & 15) || g.lda % 16 != 0) return false;
+    if (((uintptr_t)g.W & 15) || g.ldw % 4 != 0) return false;
     if (g.bias && ((uintptr_t)g.bias & 15)) return false;
     if (g.res && (((uintptr_t)g.res & 15) || g.ldr % 4 != 0)) return false;
     if (g.C && (((uintptr_t)g.C & 15) || g.ldc % 4 != 0)) return false;
     if (g.Cs && (((uintptr_t)g.Cs & 15) || g.ldcs % 16 != 0)) return false;
     if (g.a_idx && (g.a_fmt != PS_HR8 || g.nseg > 4 || g.nseg < 1 || (g.K / g.nseg) % TK != 0)) return false;
-    if ((double)g.lda * 256.0 >= 4294967296.0 || (double)g.K * 4.0 * 256.0 >= 4294967296.0) return false;     // 32-bit in-tile offsets
+    if ((!g.a_rowptr && (double)g.lda * 256.0 >= 4294967296.0) || (double)g.K * 4.0 * 256.0 >= 4294967296.0) return false;     // 32-bit in-tile offsets
     return g.C || g.Cs;
 }
 
@@ -769,7 +835,7 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
         n_cu = prop.multiProcessorCount >= 8 ? (prop.multiProcessorCount / 8) * 8 : 8;
     }
     PsArgs p;
-    p.A = (const unsigned char*)g.A; p.lda = g.lda; p.a_idx = g.a_idx; p.nseg = g.a_idx ? g.nseg : 1;
+    p.A = (const unsigned char*)g.A; p.lda = g.lda; p.a_idx = g.a_idx; p.nseg = g.a_idx ? g.nseg : 1; p.a_rowptr = g.a_rowptr;
     p.seg_bytes = (g.K / p.nseg) * 4;
     p.bias = g.bias; p.res = g.res; p.ldr = g.ldr; p.res_period = g.res ? g.res_period : 0; p.C = g.C; p.ldc = g.ldc; p.Cs = (unsigned char*)g.Cs; p.ldcs = g.ldcs;
     p.M = g.M; p.N = g.N; p.K = g.K; p.act = g.act;
@@ -789,14 +855,23 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     // The result does not depend on the choice (one accumulator per element, the same K order in every tiling).
     // BIGC_PS_ACC2 = conv: the gathered GEMM (the temporal conv, K = 3 x 2 dim_enti) on 128-row tiles with a second accumulator; = all: also every
     // plain hr8-operand GEMM with K >= 1024
+    // The caller asks for it per GEMM (PsGemm.two_acc: the model does for its K >= 1024 GEMMs -- conv, fc_feat2enti.0 -- so that no GEMM of the
+    // path rounds coarser than the two-accumulator kernel of linear_split.hip); BIGC_PS_ACC2 = 0 turns that off, = all extends it to every K >= 1024.
     static const char* acc2_env = getenv("BIGC_PS_ACC2");
-    const bool acc2 = acc2_env && !bigc_linear_get_fast() && g.a_fmt == PS_HR8 && !lnm && !want_blk &&
-                      ((g.a_idx && (!strcmp(acc2_env, "conv") || !strcmp(acc2_env, "all"))) || (!g.a_idx && !strcmp(acc2_env, "all") && g.K >= 1024));
+    const bool acc2_off = acc2_env && !strcmp(acc2_env, "0");
+    const bool acc2_want = g.two_acc || (acc2_env && ((g.a_idx && (!strcmp(acc2_env, "conv") || !strcmp(acc2_env, "all"))) || (!g.a_idx && !strcmp(acc2_env, "all") && g.K >= 1024)));
+    // f32 rows: by DMA with the split in LDS (mode 3) unless BIGC_PS_F32_DMA=0 (mode 2: through registers); a row-address table needs mode 3
+    static const bool f32_dma = !(getenv("BIGC_PS_F32_DMA") && atoi(getenv("BIGC_PS_F32_DMA")) == 0);
+    const bool mode3 = g.a_fmt == PS_F32 && (f32_dma || g.a_rowptr) && !lnm && !want_blk;
+    const bool acc2 = acc2_want && !acc2_off && !bigc_linear_get_fast() && (g.a_fmt == PS_HR8 || mode3) && !lnm && !want_blk;
+    static const int blk_mink_early = getenv("BIGC_PS_BLK_MINK") ? atoi(getenv("BIGC_PS_BLK_MINK")) : 0;
+    static const long blk_minm_early = getenv("BIGC_PS_BLK_MINM") ? atol(getenv("BIGC_PS_BLK_MINM")) : 0;
+    static const long blk_maxm_early = getenv("BIGC_PS_BLK_MAXM") ? atol(getenv("BIGC_PS_BLK_MAXM")) : 0;
     int rb = 2;
     static const int ln_rb = getenv("BIGC_LN_RB") ? atoi(getenv("BIGC_LN_RB")) : 2;
     if (acc2) rb = 2;
     else if (lnm) rb = ln_rb == 3 ? 3 : 2;            // rows per tile = 32 rb, spanning all 512 features
-    else if (want_blk && g.a_fmt == PS_HR8) rb = 2;
+    else if (want_blk && g.a_fmt == PS_HR8 && g.K >= blk_mink_early && g.M >= blk_minm_early && (blk_maxm_early == 0 || g.M <= blk_maxm_early)) rb = 2;
     else if (force_rb) rb = force_rb;
     else {
         static const bool rb3_off = getenv("BIGC_PS_RB3") && atoi(getenv("BIGC_PS_RB3")) == 0;
@@ -804,7 +879,7 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
         const int cand[3] = {4, 3, 2};
         const double eff[3] = {1.0, 0.94, 0.82};
         for (int i = 0; i < 3; ++i) {
-            if (cand[i] == 3 && (rb3_off || g.a_fmt == PS_F32)) continue;
+            if (cand[i] == 3 && (rb3_off || g.a_fmt == PS_F32)) continue;            // (f32 rows: 128- or 256-row tiles)
             const long tiles = (long)cdiv(g.M, 64 * cand[i]) * p.tiles_n;
             const double cost = (double)((tiles + n_cu - 1) / n_cu) * cand[i] / eff[i];
             if (best == 0.0 || cost < best * 0.999) { best = cost; rb = cand[i]; }
@@ -814,7 +889,12 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     p.range_flag = g.range_flag;
     // opt-in blocked accumulation (BIGC_PS_BLK = K slabs per block, a power of two): 128-row tiles, plain / gathered hr8 operand
     static const int force_blk = getenv("BIGC_PS_BLK") ? atoi(getenv("BIGC_PS_BLK")) : 0;
-    p.blk = (force_blk > 0 && !(force_blk & (force_blk - 1)) && g.a_fmt == PS_HR8 && !bigc_linear_get_fast() && !lnm) ? force_blk : 0;
+    // (experiments: BIGC_PS_BLK_MINK / _MINM / _MAXM restrict the blocked kernel to GEMMs with K >= / M >= / M <= the given value)
+    static const int blk_mink = getenv("BIGC_PS_BLK_MINK") ? atoi(getenv("BIGC_PS_BLK_MINK")) : 0;
+    static const long blk_minm = getenv("BIGC_PS_BLK_MINM") ? atol(getenv("BIGC_PS_BLK_MINM")) : 0;
+    static const long blk_maxm = getenv("BIGC_PS_BLK_MAXM") ? atol(getenv("BIGC_PS_BLK_MAXM")) : 0;
+    const bool blk_here = g.K >= blk_mink && g.M >= blk_minm && (blk_maxm == 0 || g.M <= blk_maxm);
+    p.blk = (force_blk > 0 && !(force_blk & (force_blk - 1)) && g.a_fmt == PS_HR8 && !bigc_linear_get_fast() && !lnm && blk_here) ? force_blk : 0;
     static const int ablate = getenv("BIGC_PS_ABLATE") ? atoi(getenv("BIGC_PS_ABLATE")) : 0;
     p.ablate = ablate;
     static const int trace = getenv("BIGC_PS_TRACE") ? atoi(getenv("BIGC_PS_TRACE")) : 0;
@@ -857,7 +937,8 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     const int grid = n_tiles >= n_cu ? n_cu : cdiv(n_tiles, 8) * 8;
 #define PS_LAUNCH(MODE, RBV) hipLaunchKernelGGL((gemm_ps_kernel<MODE, RBV>), dim3(grid), dim3(512), 0, s, p)
     if (acc2) {
-        if (g.a_idx) hipLaunchKernelGGL((gemm_ps_kernel<1, 2, false, false, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+        if (mode3) hipLaunchKernelGGL((gemm_ps_kernel<3, 2, false, false, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+        else if (g.a_idx) hipLaunchKernelGGL((gemm_ps_kernel<1, 2, false, false, false, false, true>), dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, false, false, false, true>), dim3(grid), dim3(512), 0, s, p);
     } else if (lnm) {
         if (rb == 3) {
@@ -885,12 +966,15 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
                 seg[1] / slabs, seg[2] / slabs, seg[3] / slabs, seg[4] / slabs);
     } else if (bigc_linear_get_fast()) {
 #define PS_LAUNCH_FAST(MODE, RBV) hipLaunchKernelGGL((gemm_ps_kernel<MODE, RBV, false, true>), dim3(grid), dim3(512), 0, s, p)
-        if (g.a_fmt == PS_F32) { if (rb == 4) PS_LAUNCH_FAST(2, 4); else PS_LAUNCH_FAST(2, 2); }
+        if (mode3) { if (rb == 4) PS_LAUNCH_FAST(3, 4); else PS_LAUNCH_FAST(3, 2); }
+        else if (g.a_fmt == PS_F32) { if (rb == 4) PS_LAUNCH_FAST(2, 4); else PS_LAUNCH_FAST(2, 2); }
         else if (g.a_idx) { if (rb == 4) PS_LAUNCH_FAST(1, 4); else if (rb == 3) PS_LAUNCH_FAST(1, 3); else PS_LAUNCH_FAST(1, 2); }
         else { if (rb == 4) PS_LAUNCH_FAST(0, 4); else if (rb == 3) PS_LAUNCH_FAST(0, 3); else PS_LAUNCH_FAST(0, 2); }
 #undef PS_LAUNCH_FAST
+    } else if (mode3) {
+        if (rb == 4) PS_LAUNCH(3, 4); else PS_LAUNCH(3, 2);        // (f32 operand: force_rb 3 falls to 128 rows)
     } else if (g.a_fmt == PS_F32) {
-        if (rb == 4) PS_LAUNCH(2, 4); else PS_LAUNCH(2, 2);        // (f32 operand: force_rb 3 falls to 128 rows)
+        if (rb == 4) PS_LAUNCH(2, 4); else PS_LAUNCH(2, 2);
     } else if (p.blk > 0) {
         if (g.a_idx) hipLaunchKernelGGL((gemm_ps_kernel<1, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
@@ -925,6 +1009,17 @@ extern "C" int bigc_gemm_ps(void* stream, const void* A, long lda_bytes, int a_f
     g.A = A; g.lda = lda_bytes; g.a_fmt = a_fmt ? PS_HR8 : PS_F32; g.a_idx = a_idx; g.nseg = a_idx ? nseg : 1; g.W = W; g.ldw = ldw;
     g.bias = bias; g.res = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Cs = Cs; g.ldcs = ldcs_bytes; g.M = M; g.N = N; g.K = K; g.act = act;
     g.range_flag = range_flag;
+    return bigc_gemm_ps_launch((hipStream_t)stream, g);
+}
+
+// A given by row addresses (f32 rows read in place: DMA + split in LDS)
+extern "C" int bigc_gemm_ps_rows(void* stream, const uint64_t* row_ptr, const float* W, int ldw, const float* bias, float* C, long ldc, void* Cs,
+                                 long ldcs_bytes, int M, int N, int K, int act, int two_acc, int* range_flag) {
+    BIGC_CHECK_ARG(row_ptr && W && (C || Cs), "gemm_ps_rows: null pointer");
+    if (M == 0) return BIGC_OK;
+    PsGemm g;
+    g.a_rowptr = (const unsigned long long*)row_ptr; g.a_fmt = PS_F32; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.Cs = Cs; g.ldcs = ldcs_bytes;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.range_flag = range_flag; g.two_acc = two_acc != 0;
     return bigc_gemm_ps_launch((hipStream_t)stream, g);
 }
 

@@ -107,6 +107,8 @@ enum { PS_F32 = 0, PS_HR8 = 1 };
 struct PsGemm {
     const void* A = nullptr; long lda = 0; int a_fmt = PS_F32;      // pitch in BYTES
     const int32_t* a_idx = nullptr; int nseg = 1;                    // hr8 only: source row per (output row, K segment), -1 = zeros
+    const unsigned long long* a_rowptr = nullptr;                    // f32 only: address of row m (16-byte aligned, K floats) instead of A + m * lda
+    bool two_acc = false;                                            // f32-accurate accumulation wanted (128-row tiles, second accumulator): the K >= 1024 GEMMs
     const float* W = nullptr; int ldw = 0;                           // (N, K) f32, pitch in floats
     const float* bias = nullptr; const float* res = nullptr; long ldr = 0;
     int res_period = 0;                                              // > 0: residual row of output row m = m % res_period (e.g. W pos_embedding per query)

@@ -5,6 +5,7 @@
 // One wave per (video, query); latency-bound integer/transcendental work.
 #include "common.h"
 #include "prof.h"
+#include <unordered_map>
 
 namespace {
 
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ target, const int32_t* __restrict__ match_g, int nq, int n_rows,
                                                         float n_pos, float n_neg, float n_adj, float fc, float fa, float neg_weight,
                                                         float gs_pos, float gs_neg, float gs_adj, const float* __restrict__ gs_dev,
-                                                        float* __restrict__ loss_out, float* __restrict__ dlogits, int ldg,
+                                                        float* __restrict__ loss_partial, float* __restrict__ dlogits, int ldg,
                                                         float* __restrict__ datt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (gs_dev) { gs_pos = gs_dev[0]; gs_neg = gs_dev[1]; gs_adj = gs_dev[2]; }
@@ -113,9 +114,20 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
     __shared__ float red[4][3];
     if (lane == 0) { red[wave][0] = part[0]; red[wave][1] = part[1]; red[wave][2] = part[2]; }
     __syncthreads();
-    if (threadIdx.x < 3) {
-        const float tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (tot != 0.f) atomicAdd(&loss_out[threadIdx.x], tot);
+    // one partial per term and workgroup; loss_finish_kernel adds them in a fixed order (float atomics here made the low bits
+    // of the reported loss terms vary from run to run)
+    if (threadIdx.x < 3) loss_partial[(size_t)blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// loss_out[t] = sum over the workgroups' partials of term t: lane l adds the partials l, l + 64, ... in order, then the 64 lane sums are
+// folded in a fixed butterfly -- the same order in every run
+__global__ __launch_bounds__(64) void loss_finish_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ loss_out) {
+    const int lane = threadIdx.x;
+    for (int t = 0; t < 3; ++t) {
+        float s = 0.f;
+        for (int b = lane; b < blocks; b += 64) s += partial[(size_t)b * 3 + t];
+        s = wave_sum(s);
+        if (lane == 0) loss_out[t] = s;
     }
 }
 
@@ -143,8 +155,21 @@ static int loss_grad_launch(void* stream, const float* logits, int n_pcat, const
     if (e != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "loss_grad: memset: %s", hipGetErrorString(e));
     if (n_vid <= 0) return BIGC_OK;
     ProfScope ps(stream, FAM_LOSS, 0.0, 0.0);
-    hipLaunchKernelGGL(loss_grad_kernel, dim3((n_vid * nq + LG_ROWS - 1) / LG_ROWS), dim3(256), 0, (hipStream_t)stream, logits, n_pcat, att, e_off, g_off, gt_adj,
-                       adj_off, target, match_g, nq, n_vid * nq, n_pos, n_neg, n_adj, loss_cls, loss_adj, neg_weight, gs_pos, gs_neg, gs_adj, gs_dev, loss_out, dlogits, ldg, datt);
+    const int blocks = (n_vid * nq + LG_ROWS - 1) / LG_ROWS;
+    // per-workgroup partial terms: a stream-ordered scratch per (calling thread, device), grown on demand
+    struct Buf { float* p = nullptr; size_t cap = 0; };
+    thread_local std::unordered_map<int, Buf> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "loss_grad: hipGetDevice failed");
+    Buf& b = bufs[dev];
+    if ((size_t)blocks * 3 > b.cap) {
+        if (b.p) { if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "loss_grad: sync failed"); (void)hipFree(b.p); }
+        b.cap = (size_t)blocks * 6;
+        if (hipMalloc((void**)&b.p, b.cap * sizeof(float)) != hipSuccess) { b.p = nullptr; b.cap = 0; return bigc_fail(BIGC_ERR_HIP, "loss_grad: hipMalloc of the partial terms failed"); }
+    }
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, n_pcat, att, e_off, g_off, gt_adj,
+                       adj_off, target, match_g, nq, n_vid * nq, n_pos, n_neg, n_adj, loss_cls, loss_adj, neg_weight, gs_pos, gs_neg, gs_adj, gs_dev, b.p, dlogits, ldg, datt);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)b.p, blocks, loss_out);
     BIGC_LAUNCH_CHECK("loss_grad");
     return BIGC_OK;
 }

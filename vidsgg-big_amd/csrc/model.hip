@@ -426,8 +426,16 @@ int run_frontend_chained(const bigc_model* m, void* s, const bigc_batch* b, cons
         TRY(ps(cx, b->feats_hr8, b->ld_feats_hr8 / 4, true, m->feat0, c.dim_feat, nullptr, 0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU));
         if (b->feats_hr8_flag) TRY(bigc_or_flag((hipStream_t)s, w.flag, b->feats_hr8_flag));
     } else if (!b->feats && b->feat_row_ptr && c.dim_feat % 4 == 0) {
-        // the visual features read IN PLACE from the callers' per-tracklet rows (bigc_batch.feat_row_ptr): no packed copy of them exists
-        TRY(bigc_linear_hr8out_rows(s, b->feat_row_ptr, m->feat0.w, c.dim_feat, m->feat0.b, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU, w.flag));
+        // the visual features read IN PLACE from the callers' per-tracklet rows (bigc_batch.feat_row_ptr): no packed copy of them exists.
+        // Round 5: the raw f32 rows go HBM -> LDS by DMA through the address table and are split in LDS by the wave that fetched them
+        // (gemm_ps.hip, A mode 3; two accumulators as the in-loop-split kernel it replaces); BIGC_FEAT0_SPLITLOOP=1: that kernel
+        // (linear_split_kernel with a_rowptr: loads to registers, split, ds_write)
+        static const bool split_loop = getenv("BIGC_FEAT0_SPLITLOOP") && atoi(getenv("BIGC_FEAT0_SPLITLOOP")) != 0;
+        PsGemm g;
+        g.a_rowptr = (const unsigned long long*)b->feat_row_ptr; g.a_fmt = PS_F32; g.W = m->feat0.w; g.ldw = c.dim_feat; g.bias = m->feat0.b;
+        g.Cs = w.hv; g.ldcs = (long)de * 4; g.M = R; g.N = de; g.K = c.dim_feat; g.act = BIGC_ACT_RELU; g.range_flag = w.flag; g.two_acc = true;
+        if (!split_loop && c.dim_feat % 32 == 0 && bigc_gemm_ps_supported(g) && bigc_linear_get_fast() != 2) TRY(bigc_gemm_ps_launch((hipStream_t)s, g));
+        else TRY(bigc_linear_hr8out_rows(s, b->feat_row_ptr, m->feat0.w, c.dim_feat, m->feat0.b, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU, w.flag));
     } else {
         BIGC_CHECK_ARG(b->feats, "forward: batch without f32 features and without a usable split form of them");
         TRY(bigc_linear_hr8out(s, b->feats, D, m->feat0.w, c.dim_feat, m->feat0.b, nullptr, 0, nullptr, 0, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU, w.flag));

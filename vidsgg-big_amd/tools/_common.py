@@ -215,9 +215,14 @@ def training_loop(model, data, train_config, output_dir, save_tag, step, rank, w
         for b in range(n_iter):
             ids = order[b * batch_size:(b + 1) * batch_size]
             if isinstance(data, VideoIndex) and world > 1:
-                # each rank loads ITS chunk of the batch only.  (The collator's order inside a batch -- sort_key, dataloaders/
-                # dataloader_vidvrd.py:469 -- would need every video of the batch loaded on every rank; it only decides which videos
-                # share a replica, and the mean over equally sized replicas of per-replica means does not depend on that.)
+                # each rank loads ITS chunk of the batch only.  The collator orders a batch by the GT graphs' max_frames (sort_key,
+                # dataloaders/dataloader_vidvrd.py:469), which would need every video of the batch loaded on every rank; the order
+                # matters -- it decides which videos share a replica, and each replica's cls_pos / cls_neg / adj terms are ratios
+                # over its OWN n_pos / n_neg / n_adj, so the mean of the per-replica terms depends on the grouping --
+                # so the batch is ordered by the index's per-video cost instead (the row count: what the index knows without
+                # loading a video; ties keep the shuffled order).  Equally valid, but NOT the reference's composition of the
+                # replicas, nor the world == 1 path's on the same seed: multi-rank runs follow their own gradient sequence.
+                ids = sorted(ids, key=lambda i: data.costs[i])
                 batch = ids
                 mine = [data[ids[i]] for i in shard_indices(len(ids), rank, world)]
             else:

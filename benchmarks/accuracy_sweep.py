@@ -36,6 +36,12 @@ VARIANTS = {
     "blk4_small": {"BIGC_PS_BLK": "4", "BIGC_PS_BLK_MAXM": "100000"},
     "blk4_decoder": {"BIGC_PS_BLK": "4", "BIGC_PS_BLK_MINM": "20000", "BIGC_PS_BLK_MAXM": "100000"},
     "rb2": {"BIGC_PS_RB": "2"},
+    "plain": {"BIGC_ACCUM": "plain"},
+    "k1024": {"BIGC_ACCUM": "k1024"},
+    "front": {"BIGC_ACCUM": "front"},
+    "nodecoder": {"BIGC_ACCUM": "nodecoder"},
+    "blocked": {"BIGC_ACCUM": "blocked"},
+    "blocked_splitloop": {"BIGC_ACCUM": "blocked", "BIGC_FEAT0_SPLITLOOP": "1"},
     "resident": {"ACC_SWEEP_RESIDENT": "1"},
     "resident_blk4": {"ACC_SWEEP_RESIDENT": "1", "BIGC_PS_BLK": "4"},
 }

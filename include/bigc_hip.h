@@ -93,6 +93,15 @@ int bigc_linear_get_exact(void);
  * on.  bigc_linear_set_fast returns the previous mode; bigc_linear_get_fast the mode in effect (0, 1 or 2). */
 int bigc_linear_set_fast(int fast);
 int bigc_linear_get_fast(void);
+/* Accumulation policy of the model forwards' GEMMs on pre-split operands (bigc_forward, the nn.Linear / nn.Conv1d products of
+ * models/model_0v10.py:446-458,178-225; process-wide, also env BIGC_ACCUM = plain | k1024 | front | nodecoder | blocked):
+ * 4 = blocked (default): every such GEMM sums K in blocks of 128 that are folded into a running total, so that no product of the path
+ * rounds coarser than a blocked CPU GEMM (the reference's) -- every video of the benchmark set within 1e-4 of a float64 evaluation;
+ * 0 = plain: one f32 accumulator per element on the largest tiles (faster: 19.6 against 20.7 ms per 256 videos; up to 2e-4 from
+ * float64 on the videos whose sharp attention amplifies round-off); 1 / 2 / 3: blocked for K >= 1024 only / for M >= 100 000 rows only /
+ * for all but the decoder's GEMMs.  Returns the previous policy. */
+int bigc_set_accum_policy(int policy);
+int bigc_get_accum_policy(void);
 
 /* y[r, :] = LayerNorm(x[r, :]) * gamma + beta over d columns, eps inside the sqrt
  *   (torch.nn.LayerNorm, models/model_0v10.py:81-82,171-173). d <= 2048, d % 4 == 0. */
@@ -631,10 +640,12 @@ int bigc_gemm_ps(void* stream, const void* A, long lda_bytes, int a_fmt, const i
 /* The same product with the rows of A given by ADDRESS (row_ptr[m] -> K floats, 16-byte aligned): the first visual-feature layer
  * fc_feat2enti.0 (models/model_0v10.py:446, on `features[:, :dim_feat]` of :438) reading the callers' per-tracklet tensors where they
  * are -- the reference stacks them first (:391-430, utils/utils_func.py:49-91).  The raw f32 rows travel HBM -> LDS by DMA and are split
- * in LDS.  two_acc != 0: the correction terms of the split products go to a second accumulator (128-row tiles), i.e. the rounding
- * behaviour of the library's in-loop-split GEMM; results do not depend on anything else.  C and / or Cs as above. */
+ * in LDS.  accum: 0 = one f32 accumulator per element (tile size chosen for speed); 1 = the correction terms of the split products in a
+ * second accumulator (the rounding behaviour of the library's in-loop-split GEMM); 2 = blocked accumulation (partial sums over K = 128
+ * folded into a running total; needs K % 128 == 0, else as 0): rounds no coarser than a blocked CPU GEMM.  1 and 2 run on 128-row tiles.
+ * C and / or Cs as above. */
 int bigc_gemm_ps_rows(void* stream, const uint64_t* row_ptr, const float* W, int ldw, const float* bias, float* C, long ldc, void* Cs,
-                      long ldcs_bytes, int M, int N, int K, int act, int two_acc, int* range_flag);
+                      long ldcs_bytes, int M, int N, int K, int act, int accum, int* range_flag);
 /* the same product with nn.LayerNorm over the N = 512 output features taken in the epilogue (models/model_0v10.py:188,211,223: the three
  * norms of a decoder layer follow a GEMM + residual): C = LayerNorm(act(A W^T + bias) + residual) * gamma + beta (+ add[m % add_period],
  * e.g. `+ pos_embedding`), Cs = the split form of the normalised rows (without the added table).  A must be in the split form. */

@@ -78,6 +78,8 @@ _SIGS = {
                                        c_int, c_int, c_int, c_int, c_void_p]),
     "bigc_set_mode": (c_int, [c_void_p, c_int, c_int]),
     "grd_set_mode": (c_int, [c_void_p, c_int, c_int]),
+    "bigc_set_accum_policy": (c_int, [c_int]),
+    "bigc_get_accum_policy": (c_int, []),
     "bigc_linear_set_exact": (c_int, [c_int]),
     "bigc_linear_get_exact": (c_int, []),
     "bigc_linear_set_fast": (c_int, [c_int]),

@@ -51,6 +51,7 @@
 #include <mutex>
 #include <unordered_map>
 #include <vector>
+#include <type_traits>
 
 namespace {
 
@@ -176,7 +177,7 @@ struct PsArgs {
 template <int AMODE, int RB, bool TRACE = false, bool FAST = false, bool BLOCKED = false, bool LNM = false, bool ACC2 = false>
 __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     static_assert(!ACC2 || (RB == 2 && !FAST && !BLOCKED && !LNM), "second accumulator: 128-row tiles only (registers)");
-    static_assert(AMODE != 3 || (RB != 3 && !LNM && !BLOCKED), "in-LDS split of DMA'd f32 rows: 128- or 256-row tiles");
+    static_assert(AMODE != 3 || (RB != 3 && !LNM), "in-LDS split of DMA'd f32 rows: 128- or 256-row tiles");
     static_assert(!LNM || (AMODE == 0 && (RB == 2 || RB == 3) && !BLOCKED && !TRACE), "LayerNorm epilogue: plain hr8 operand, 64- or 96-row tiles");
     constexpr int TNK = LNM ? 512 : TN;                       // output features per tile
     constexpr int NWF = TNK / 64, NWR = 8 / NWF;              // waves side by side over the features / stacked over the rows
@@ -344,21 +345,37 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     // mode 3: piece i of the slab in stage `so` (this wave's own DMA, landed: the caller waited on vmcnt) from raw f32 to the split form, in
     // place.  conv_read fetches the lane's 16 bytes, conv_write splits them and stores heads / residuals (see the header comment).
     const int pbit = ((lane & 7) ^ sw_src) & 1;                            // this lane's chunk holds floats 8 g + 4 pbit .. + 3 of its group
-    f32x4 cv[AMODE == 3 ? NA : 1];
+    // (ONE register set: piece i + 1 is fetched after piece i has been converted; four pieces' worth of registers spilled in the 256-row
+    // kernel, and a spill reload in the loop is a scratch load, i.e. an s_waitcnt vmcnt(0) that drains the DMAs)
+    // Register sets: CVS = 2 at 128-row tiles (both pieces are fetched at the start of the unit and converted ten MFMAs later: an LDS read
+    // under the load of eight waves' fragment reads and the DMA writes takes several hundred cycles, and a wave that waits for it issues no
+    // MFMAs -- fetched one MFMA pair ahead of its use the conversion cost 0.95 ms on the K = 2048 GEMM); CVS = 1 at 256-row tiles (no
+    // registers left: piece i + 1 is fetched after piece i has been converted).
+    constexpr int CVS = RB == 2 ? 2 : 1;
+    f32x4 cv[CVS];
+    const int conv_base = lane * 16;
     auto conv_read = [&](int i, int so) {
         const int blk = wave + 8 * i;
-        cv[i] = *(const AS3 f32x4*)(lds + so + blk * 1024 + lane * 16);
+        cv[i % CVS] = *(const AS3 f32x4*)(lds + so + blk * 1024 + conv_base);
     };
     auto conv_write = [&](int i, int so) {
         const int blk = wave + 8 * i;
+        const f32x4 x = cv[i % CVS];
         unsigned h0, h1, r0, r1;
-        split2(cv[i][0] * ACT_SCALE, cv[i][1] * ACT_SCALE, h0, r0);
-        split2(cv[i][2] * ACT_SCALE, cv[i][3] * ACT_SCALE, h1, r1);
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(cv[i][0]), fabsf(cv[i][1])), fmaxf(fabsf(cv[i][2]), fabsf(cv[i][3]))));
-        asm volatile("v_fmac_f32 %0, 0, %1" : "+v"(nanacc) : "v"((cv[i][0] + cv[i][1]) + (cv[i][2] + cv[i][3])));     // NaN / Inf x 0 = NaN (fmaxf drops NaNs)
-        const int a = so + blk * 1024 + lane * 16;
-        *(AS3 u32x2*)(lds + (a ^ (pbit << 4)) + 8 * pbit) = u32x2{h0, h1};
-        *(AS3 u32x2*)(lds + (a ^ ((pbit ^ 1) << 4)) + 8 * pbit) = u32x2{r0, r1};
+        split2(x[0] * ACT_SCALE, x[1] * ACT_SCALE, h0, r0);
+        split2(x[2] * ACT_SCALE, x[3] * ACT_SCALE, h1, r1);
+        asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(x[0]), "v"(x[1]));
+        asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(x[2]), "v"(x[3]));
+        asm volatile("v_fmac_f32 %0, 0, %1" : "+v"(nanacc) : "v"((x[0] + x[1]) + (x[2] + x[3])));     // NaN / Inf x 0 = NaN (v_max3 drops NaNs)
+        const int a = so + blk * 1024 + conv_base;
+        // The stores are issued from inline asm: as plain stores the compiler puts an s_waitcnt vmcnt(0) in front of each of them (a store to
+        // LDS while LDS-DMAs are in flight might overlap one of them for all it knows), which drains the W pieces of the slab under issue
+        // once per piece: 4.31 instead of 3.40 ms on the K = 2048 GEMM.  They target this wave's own, landed pieces; nothing reads them
+        // before the s_waitcnt lgkmcnt(0) + barrier that close the slab (cdna_hip_programming.md 5.7: a store has no destination
+        // register, hidden LDS operations only make the compiler's own lgkmcnt waits more conservative).
+        const unsigned ah = (unsigned)(unsigned long)(lds + (a ^ (pbit << 4)) + 8 * pbit), ar = (unsigned)(unsigned long)(lds + (a ^ ((pbit ^ 1) << 4)) + 8 * pbit);
+        const u32x2 hv = {h0, h1}, rv = {r0, r1};
+        asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %2, %3" :: "v"(ah), "v"(hv), "v"(ar), "v"(rv) : "memory");
     };
     bool oob = false;
 
@@ -369,10 +386,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     // the result against 6.0 for the two-accumulator kernel of linear_split.hip and 3.2 for torch's CPU GEMM (benchmarks/probes/
     // gemm_error_stats.py).  With BLOCKED, `acc` only ever holds the partial sum of p.blk slabs (small, so its roundings are small)
     // and is folded into the running total `tot` once per block: measured 2.97 (K = 3072), 2.87 (K = 2048), 2.28 (K = 512) -- below
-    // the CPU GEMM's.  It is not the default because the second register set does not fit: the 128-row kernel goes from 181 to
-    // 256 registers + 55 spilled in the K loop (60 TFLOP/s), and the 256-row kernel has no room at all; a blocked kernel needs the
-    // one-wave-per-SIMD layout (512 registers per wave).  Kept as the measuring instrument for what blocking buys.
-    static_assert(!BLOCKED || (RB == 2 && !FAST), "blocked accumulation: 128-row tiles only");
+    // the CPU GEMM's.  Round 5: blocks of BLKC = 4 slabs (K = 128) with the fold behind an inner loop of fixed length (below): 217 - 241
+    // registers at 128-row tiles, no spills (as a conditional in the slab loop: 256 + 100 spilled, 60 TFLOP/s).  The 192- and 256-row
+    // tiles have no room for the second register set (70 / 163 spilled).  Over the 256 benchmark videos it is what brings EVERY video
+    // within 1e-4 of a float64 evaluation (max 7.8e-5; one accumulator: 1.65e-4, second accumulator for the correction terms: 1.78e-4;
+    // benchmarks/accuracy_sweep.py, profiles/r05a_accuracy_sweep.jsonl).
+    static_assert(!BLOCKED || (RB == 2 && !FAST && !LNM && !ACC2), "blocked accumulation: 128-row tiles only");
     f32x16 tot[2][BLOCKED ? RB : 1];
     f32x16 acc2[2][ACC2 ? RB : 1];
     auto zero_acc = [&]() {
@@ -389,7 +408,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
 #pragma unroll
             for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-                for (int ri = 0; ri < RB; ++ri) { tot[fi][ri] += acc[fi][ri]; acc[fi][ri] = acc[fi][ri] - acc[fi][ri]; }
+                for (int ri = 0; ri < RB; ++ri) tot[fi][ri] += acc[fi][ri];
         }
     };
 
@@ -429,7 +448,9 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     };
     // MFMAs [m0, m1) of the MM of unit u: term-major (head x head over the 2 x UR blocks, then head x residual, residual x head), so
     // that consecutive MFMAs never accumulate into the same block
-    auto mm = [&](const WFrag& w, const AFrag& a, int u, int m0, int m1) {
+    // `fresh`: the head x head MFMA of each block starts a NEW sum (C = 0, an inline constant) instead of continuing acc -- the first k16 step of
+    // an accumulation block's first slab (BLOCKED): the fold then only adds acc to tot and nothing has to be zeroed
+    auto mm = [&](const WFrag& w, const AFrag& a, int u, int m0, int m1, bool fresh = false) {
 #pragma unroll
         for (int m = 0; m < MM; ++m) {
             if (m < m0 || m >= m1) continue;
@@ -437,7 +458,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
             if (FAST && t > 0) continue;
             if (ACC2 && t > 0)
                 acc2[fi][UR * u + ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t == 2 ? w.l[fi] : w.h[fi], t == 1 ? a.l[ri] : a.h[ri], acc2[fi][UR * u + ri], 0, 0, 0);
-            else
+            else if (BLOCKED && fresh && t == 0) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[fi][UR * u + ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h[fi], a.h[ri], zero, 0, 0, 0);
+            } else
                 acc[fi][UR * u + ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t == 2 ? w.l[fi] : w.h[fi], t == 1 ? a.l[ri] : a.h[ri], acc[fi][UR * u + ri], 0, 0, 0);
         }
     };
@@ -632,9 +656,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (AMODE == 3) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) conv_read(i, so[0]);
-#pragma unroll
-            for (int i = 0; i < NA; ++i) conv_write(i, so[0]);
+            for (int i = 0; i < NA; ++i) { conv_read(i, so[0]); conv_write(i, so[0]); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
@@ -660,9 +682,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     // the MFMAs of the unit that holds the barrier (one after every second MFMA), the rest in the unit that follows.
     constexpr int FIRST = NU == 2 ? 6 : 4;
     bool opened = false;                           // the slab under issue has its first pieces out
-    for (int g = 0; g < n_flat; ++g) {
+    constexpr int BLKC = 4;                        // BLOCKED: K slabs per accumulation block (K = 128); the launcher guarantees nk % BLKC == 0
+    auto slab = [&](int g, auto fresh_c) {
+        constexpr bool FRESH = decltype(fresh_c)::value;           // BLOCKED: this slab opens an accumulation block
         const bool more = g + 1 < n_flat;
-        const bool tile_end = ckt + 1 == nk;          // this slab is the last of its tile (ONE value guards the deferred prefetch and the epilogue)
         stamp(4);
 #pragma unroll
         for (int n = 0; n < NU; ++n) {
@@ -670,20 +693,22 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
             const bool last = n == NU - 1;
             if (n == NU / 2 && (p.ablate & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);
             if (n == 0 && (p.ablate & 8) && wave >= 4) __builtin_amdgcn_s_setprio(0);
-            mm(WF[s & 1], AF[n & 1], u, 0, 2);
+            mm(WF[s & 1], AF[n & 1], u, 0, 2, FRESH && s == 0);
             bool open_now = false;
             // mode 3: slab g + 1's A pieces (this wave's own DMA) are converted during unit CONV_N of slab g, one unit or more ahead of
             // barrier_g.  What may still be in flight behind them: 128-row tiles (three stages): their slab's W pieces and all of slab g + 2;
             // 256-row tiles (two stages): their slab's W pieces (issued during unit 0).
             constexpr int CONV_N = NU == 2 ? 0 : 2;
-            const bool conv_now = AMODE == 3 && n == CONV_N && more;
+            const bool conv_now = AMODE == 3 && n == CONV_N && more && !(p.ablate & 16);      // (ablate 16: timing without the in-LDS split, results wrong)
             if (!last) {
                 // fragments of the next unit of this slab
                 if (u == U - 1) rd_w(so[0], s + 1, WF[(s + 1) & 1]);
                 rd_a(so[0], (n + 1) / U, (n + 1) % U, AF[(n + 1) & 1]);
-                if (conv_now) {
+                if (conv_now && !(p.ablate & 32)) {                                  // (ablate 32: timing without this wait, results wrong)
                     if (D > 1 && g + 2 < n_flat) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPCL + NW) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NW) : "memory");
+                }
+                if (conv_now && !(p.ablate & 64) && CVS > 1) {
 #pragma unroll
                     for (int i = 0; i < NA; ++i) conv_read(i, so[1]);
                 }
@@ -721,10 +746,18 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
             const bool issuing = loader && (last ? open_now : opened);
 #pragma unroll
             for (int k = 0; k < NS - 1; ++k) {
-                mm(WF[s & 1], AF[n & 1], u, 2 + 2 * k, 4 + 2 * k);
+                mm(WF[s & 1], AF[n & 1], u, 2 + 2 * k, 4 + 2 * k, FRESH && s == 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (pb + k < pe && issuing) issue_piece(pb + k, last ? so[0] : so[NST - 1]);
-                if (AMODE == 3 && conv_now && k >= 1 && k - 1 < NA) conv_write(k - 1, so[1]);         // one piece per MFMA pair, from the third pair on
+                // one piece per MFMA pair: piece k - 1 is converted, then piece k fetched (one pair = 64+ matrix-pipe cycles ahead of its use)
+                if (AMODE == 3 && conv_now && !(p.ablate & 64)) {                         // (ablate 64: the wait without the conversion)
+                    if (CVS > 1) {
+                        if (k >= NS - 1 - NA) conv_write(k - (NS - 1 - NA), so[1]);           // the unit's last NA pairs
+                    } else {
+                        if (k >= 1 && k - 1 < NA) conv_write(k - 1, so[1]);
+                        if (k < NA) conv_read(k, so[1]);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (pb + NS - 1 < pe && issuing) issue_piece(pb + NS - 1, last ? so[0] : so[NST - 1]);
@@ -736,14 +769,33 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
 #pragma unroll
         for (int i = 0; i + 1 < NST; ++i) so[i] = so[i + 1];
         so[NST - 1] = t;
-        if (tile_end) {
+    };
+    if constexpr (BLOCKED) {
+        // blocks of BLKC slabs: the fold sits behind an inner loop of fixed length, so that it is unconditional code (as a conditional inside
+        // the slab loop it made the compiler merge two versions of all 128 accumulator registers: 100 spilled)
+        for (int g0 = 0; g0 < n_flat; g0 += BLKC) {
+            slab(g0, std::true_type{});                    // its first MFMAs start the block's sums from zero
+#pragma unroll 1
+            for (int gi = 1; gi < BLKC; ++gi) slab(g0 + gi, std::false_type{});
             fold_block();
-            if constexpr (LNM) epilogue_ln(cj); else epilogue(cj);
-            zero_acc();
-            ckt = 0; ++cj;
-        } else {
-            ++ckt;
-            if (BLOCKED && p.blk > 0 && (ckt & (p.blk - 1)) == 0) fold_block();
+            ckt += BLKC;
+            if (ckt == nk) {
+                epilogue(cj);
+                zero_acc();                                // (tot; acc restarts by itself)
+                ckt = 0; ++cj;
+            }
+        }
+    } else {
+        for (int g = 0; g < n_flat; ++g) {
+            const bool tile_end = ckt + 1 == nk;          // this slab is the last of its tile
+            slab(g, std::false_type{});
+            if (tile_end) {
+                if constexpr (LNM) epilogue_ln(cj); else epilogue(cj);
+                zero_acc();
+                ckt = 0; ++cj;
+            } else {
+                ++ckt;
+            }
         }
     }
     if (TRACE && lane == 0) {
@@ -848,7 +900,10 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     p.tiles_n = lnm ? 1 : cdiv(g.N, TN);
     // 256-row tiles when they still give every CU at least three tiles (else the 128-row tiles fill the chip better)
     static const int force_rb = getenv("BIGC_PS_RB") ? atoi(getenv("BIGC_PS_RB")) : 0;
-    static const bool want_blk = getenv("BIGC_PS_BLK") && atoi(getenv("BIGC_PS_BLK")) > 0;
+    // blocked accumulation: asked for per GEMM (PsGemm.accum == 2: the model's policy, csrc/model.hip), or for every GEMM by BIGC_PS_BLK=1
+    // (experiments; BIGC_PS_BLK=0 turns the model's requests off)
+    static const int blk_env = getenv("BIGC_PS_BLK") ? atoi(getenv("BIGC_PS_BLK")) : -1;
+    const bool want_blk = blk_env > 0 || (blk_env != 0 && g.accum == 2);
     // Rows per tile: the persistent workgroups take ceil(tiles / CUs) rounds, a round costs one tile's time (~ its rows, over an efficiency
     // that falls with the tile: a 128-row tile reads 1.33 x the LDS bytes per MFMA of a 256-row one) -> the cheapest of 256 / 192 / 128 rows.
     // M = 49 152 (decoder, 256 videos) x N = 512: 384 tiles of 256 rows = 2 rounds x 4, 512 of 192 = 2 x 3 (exact), 768 of 128 = 3 x 2.
@@ -859,10 +914,10 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     // path rounds coarser than the two-accumulator kernel of linear_split.hip); BIGC_PS_ACC2 = 0 turns that off, = all extends it to every K >= 1024.
     static const char* acc2_env = getenv("BIGC_PS_ACC2");
     const bool acc2_off = acc2_env && !strcmp(acc2_env, "0");
-    const bool acc2_want = g.two_acc || (acc2_env && ((g.a_idx && (!strcmp(acc2_env, "conv") || !strcmp(acc2_env, "all"))) || (!g.a_idx && !strcmp(acc2_env, "all") && g.K >= 1024)));
+    const bool acc2_want = g.accum == 1 || (acc2_env && ((g.a_idx && (!strcmp(acc2_env, "conv") || !strcmp(acc2_env, "all"))) || (!g.a_idx && !strcmp(acc2_env, "all") && g.K >= 1024)));
     // f32 rows: by DMA with the split in LDS (mode 3) unless BIGC_PS_F32_DMA=0 (mode 2: through registers); a row-address table needs mode 3
     static const bool f32_dma = !(getenv("BIGC_PS_F32_DMA") && atoi(getenv("BIGC_PS_F32_DMA")) == 0);
-    const bool mode3 = g.a_fmt == PS_F32 && (f32_dma || g.a_rowptr) && !lnm && !want_blk;
+    const bool mode3 = g.a_fmt == PS_F32 && (f32_dma || g.a_rowptr) && !lnm;
     const bool acc2 = acc2_want && !acc2_off && !bigc_linear_get_fast() && (g.a_fmt == PS_HR8 || mode3) && !lnm && !want_blk;
     static const int blk_mink_early = getenv("BIGC_PS_BLK_MINK") ? atoi(getenv("BIGC_PS_BLK_MINK")) : 0;
     static const long blk_minm_early = getenv("BIGC_PS_BLK_MINM") ? atol(getenv("BIGC_PS_BLK_MINM")) : 0;
@@ -871,7 +926,7 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     static const int ln_rb = getenv("BIGC_LN_RB") ? atoi(getenv("BIGC_LN_RB")) : 2;
     if (acc2) rb = 2;
     else if (lnm) rb = ln_rb == 3 ? 3 : 2;            // rows per tile = 32 rb, spanning all 512 features
-    else if (want_blk && g.a_fmt == PS_HR8 && g.K >= blk_mink_early && g.M >= blk_minm_early && (blk_maxm_early == 0 || g.M <= blk_maxm_early)) rb = 2;
+    else if (want_blk && (g.a_fmt == PS_HR8 || mode3) && (g.K / TK) % 4 == 0 && g.K >= blk_mink_early && g.M >= blk_minm_early && (blk_maxm_early == 0 || g.M <= blk_maxm_early)) rb = 2;
     else if (force_rb) rb = force_rb;
     else {
         static const bool rb3_off = getenv("BIGC_PS_RB3") && atoi(getenv("BIGC_PS_RB3")) == 0;
@@ -888,13 +943,13 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
     p.tiles_m = lnm ? cdiv(g.M, 32 * rb) : cdiv(g.M, 64 * rb);
     p.range_flag = g.range_flag;
     // opt-in blocked accumulation (BIGC_PS_BLK = K slabs per block, a power of two): 128-row tiles, plain / gathered hr8 operand
-    static const int force_blk = getenv("BIGC_PS_BLK") ? atoi(getenv("BIGC_PS_BLK")) : 0;
+    const int force_blk = want_blk ? 1 : 0;
     // (experiments: BIGC_PS_BLK_MINK / _MINM / _MAXM restrict the blocked kernel to GEMMs with K >= / M >= / M <= the given value)
     static const int blk_mink = getenv("BIGC_PS_BLK_MINK") ? atoi(getenv("BIGC_PS_BLK_MINK")) : 0;
     static const long blk_minm = getenv("BIGC_PS_BLK_MINM") ? atol(getenv("BIGC_PS_BLK_MINM")) : 0;
     static const long blk_maxm = getenv("BIGC_PS_BLK_MAXM") ? atol(getenv("BIGC_PS_BLK_MAXM")) : 0;
     const bool blk_here = g.K >= blk_mink && g.M >= blk_minm && (blk_maxm == 0 || g.M <= blk_maxm);
-    p.blk = (force_blk > 0 && !(force_blk & (force_blk - 1)) && g.a_fmt == PS_HR8 && !bigc_linear_get_fast() && !lnm && blk_here) ? force_blk : 0;
+    p.blk = (force_blk > 0 && (g.a_fmt == PS_HR8 || mode3) && !bigc_linear_get_fast() && !lnm && blk_here && (g.K / TK) % 4 == 0) ? force_blk : 0;
     static const int ablate = getenv("BIGC_PS_ABLATE") ? atoi(getenv("BIGC_PS_ABLATE")) : 0;
     p.ablate = ablate;
     static const int trace = getenv("BIGC_PS_TRACE") ? atoi(getenv("BIGC_PS_TRACE")) : 0;
@@ -971,13 +1026,14 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
         else if (g.a_idx) { if (rb == 4) PS_LAUNCH_FAST(1, 4); else if (rb == 3) PS_LAUNCH_FAST(1, 3); else PS_LAUNCH_FAST(1, 2); }
         else { if (rb == 4) PS_LAUNCH_FAST(0, 4); else if (rb == 3) PS_LAUNCH_FAST(0, 3); else PS_LAUNCH_FAST(0, 2); }
 #undef PS_LAUNCH_FAST
+    } else if (p.blk > 0) {
+        if (mode3) hipLaunchKernelGGL((gemm_ps_kernel<3, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+        else if (g.a_idx) hipLaunchKernelGGL((gemm_ps_kernel<1, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
     } else if (mode3) {
         if (rb == 4) PS_LAUNCH(3, 4); else PS_LAUNCH(3, 2);        // (f32 operand: force_rb 3 falls to 128 rows)
     } else if (g.a_fmt == PS_F32) {
         if (rb == 4) PS_LAUNCH(2, 4); else PS_LAUNCH(2, 2);
-    } else if (p.blk > 0) {
-        if (g.a_idx) hipLaunchKernelGGL((gemm_ps_kernel<1, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
     } else if (g.a_idx) {
         if (rb == 4) PS_LAUNCH(1, 4); else if (rb == 3) PS_LAUNCH(1, 3); else PS_LAUNCH(1, 2);
     } else {
@@ -1019,7 +1075,7 @@ extern "C" int bigc_gemm_ps_rows(void* stream, const uint64_t* row_ptr, const fl
     if (M == 0) return BIGC_OK;
     PsGemm g;
     g.a_rowptr = (const unsigned long long*)row_ptr; g.a_fmt = PS_F32; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.Cs = Cs; g.ldcs = ldcs_bytes;
-    g.M = M; g.N = N; g.K = K; g.act = act; g.range_flag = range_flag; g.two_acc = two_acc != 0;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.range_flag = range_flag; g.accum = two_acc;            // 0 / 1 / 2 (PsGemm.accum)
     return bigc_gemm_ps_launch((hipStream_t)stream, g);
 }
 

@@ -279,6 +279,20 @@ extern "C" int bigc_linear_get_fast(void) {
     return bigc_mode_fast_override >= 0 ? bigc_mode_fast_override : g_fast_mode.load();
 }
 
+// Accumulation policy of the model forwards' GEMMs on pre-split operands (csrc/model.hip ps_accum, csrc/gemm_ps.hip PsGemm.accum):
+//   0 plain    one f32 accumulator per element, tile sizes chosen for speed (rounds 2 - 3 x as coarsely as a blocked CPU GEMM at K >= 1024)
+//   1 k1024    blocked accumulation for the K >= 1024 GEMMs only        2 front      ... for the GEMMs with M >= 100 000 rows only
+//   3 nodecoder ... for every GEMM but the decoder's                    4 blocked    ... for every GEMM (DEFAULT: every benchmark video within
+//   1e-4 of a float64 evaluation).  Initial value from BIGC_ACCUM (the names above).
+static int accum_from_env() {
+    const char* e = getenv("BIGC_ACCUM");
+    if (!e) return 4;
+    return !strcmp(e, "plain") ? 0 : !strcmp(e, "k1024") ? 1 : !strcmp(e, "front") ? 2 : !strcmp(e, "nodecoder") ? 3 : 4;
+}
+static std::atomic<int> g_accum_policy{accum_from_env()};
+extern "C" int bigc_set_accum_policy(int policy) { return g_accum_policy.exchange(policy < 0 ? 0 : (policy > 4 ? 4 : policy)); }
+extern "C" int bigc_get_accum_policy(void) { return g_accum_policy.load(); }
+
 int bigc_linear_hr8out(void* stream, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
                        float* C, int ldc, void* Cs, long ldcs, int M, int N, int K, int act, int* range_flag) {
     BIGC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && A && W && Cs, "linear_hr8out: bad argument");

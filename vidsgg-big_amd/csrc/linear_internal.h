@@ -30,6 +30,7 @@ struct LinearArgs {
 // Weights that stay constant between launches are split once and cached per (pointer, shape) for an "epoch": the model
 // entry points open a StaticWeights scope with the epoch they drew at finalize time; outside such a scope (epoch 0, e.g.
 // the raw bigc_linear_f32 entry point or the transposed weight copies of the backward pass) W is split on every launch.
+extern "C" int bigc_get_accum_policy(void);    // linear.hip: accumulation policy of the model forwards' pre-split GEMMs (0 plain .. 4 blocked)
 extern "C" int bigc_linear_get_fast(void);     // linear.hip: 1 = reduced-precision mode (one f16 MFMA per product)
 // per-call override of the process-wide arithmetic mode (linear.hip): -1 = follow the process default
 extern thread_local int bigc_mode_exact_override, bigc_mode_fast_override;
@@ -108,7 +109,9 @@ struct PsGemm {
     const void* A = nullptr; long lda = 0; int a_fmt = PS_F32;      // pitch in BYTES
     const int32_t* a_idx = nullptr; int nseg = 1;                    // hr8 only: source row per (output row, K segment), -1 = zeros
     const unsigned long long* a_rowptr = nullptr;                    // f32 only: address of row m (16-byte aligned, K floats) instead of A + m * lda
-    bool two_acc = false;                                            // f32-accurate accumulation wanted (128-row tiles, second accumulator): the K >= 1024 GEMMs
+    // accumulation (gemm_ps.hip): 0 = one accumulator per element, tile size chosen for speed; 1 = the correction terms in a second accumulator;
+    // 2 = blocked (partial sums of K = 128 folded into a running total: rounds like a well-blocked CPU GEMM).  1 and 2 run on 128-row tiles.
+    int accum = 0;
     const float* W = nullptr; int ldw = 0;                           // (N, K) f32, pitch in floats
     const float* bias = nullptr; const float* res = nullptr; long ldr = 0;
     int res_period = 0;                                              // > 0: residual row of output row m = m % res_period (e.g. W pos_embedding per query)

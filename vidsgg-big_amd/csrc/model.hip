@@ -11,6 +11,7 @@
 //   * everything is stream-ordered on the caller's HIP stream, no host synchronisation.
 #include "model_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -371,13 +372,29 @@ int bigc_layernorm_hr8(hipStream_t hs, const float* x, const float* gamma, const
 
 namespace {
 
-struct PsCtx { hipStream_t s; int* flag; };
+struct PsCtx { hipStream_t s; int* flag; bool decoder = false; };
 
 __global__ void or_flag_kernel(int* dst, const int32_t* src) { if (*src) atomicOr(dst, 1); }
 int bigc_or_flag(hipStream_t s, int* dst, const int32_t* src) {
     hipLaunchKernelGGL(or_flag_kernel, dim3(1), dim3(1), 0, s, dst, src);
     BIGC_LAUNCH_CHECK("or_flag");
     return BIGC_OK;
+}
+
+// Accumulation policy of the eval path's GEMMs on pre-split operands (PsGemm.accum, csrc/gemm_ps.hip).  Default "blocked": every such GEMM
+// sums K in blocks of 128 folded into a running total -- over the 256 benchmark videos this is what brings every video's logits within 1e-4
+// of a float64 evaluation (max 7.8e-5; one accumulator 1.65e-4: benchmarks/accuracy_sweep.py) -- at the price of 128-row tiles.
+// BIGC_ACCUM = plain | k1024 (K >= 1024 only) | front (M >= 100 000 rows only) | nodecoder (all but the decoder's) | blocked.
+int ps_accum(long M, int K, bool decoder = false) {
+    const int mode = bigc_get_accum_policy();                  // bigc_set_accum_policy / BIGC_ACCUM (csrc/linear.hip)
+    if (K % 128 != 0) return 0;
+    switch (mode) {
+        case 0: return 0;
+        case 1: return K >= 1024 ? 2 : 0;
+        case 2: return M >= 100000 ? 2 : 0;
+        case 3: return decoder ? 0 : 2;
+        default: return 2;
+    }
 }
 
 // C / Cs = act(A W^T + b) + res;  a_hr8: A is in split form.  Pitches in floats (the hr8 form has the same pitch in bytes / 4).
@@ -387,6 +404,7 @@ int ps(const PsCtx& c, const void* A, long lda, bool a_hr8, const Lin& l, int ld
     g.res_period = res_period;
     g.A = A; g.lda = lda * 4; g.a_fmt = a_hr8 ? PS_HR8 : PS_F32; g.a_idx = a_idx; g.nseg = nseg; g.W = l.w; g.ldw = ldw; g.bias = l.b;
     g.res = res; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Cs = Cs; g.ldcs = ldcs * 4; g.M = M; g.N = N; g.K = K; g.act = act; g.range_flag = c.flag;
+    g.accum = ps_accum(M, K, c.decoder);
     return bigc_gemm_ps_launch(c.s, g);
 }
 
@@ -430,10 +448,16 @@ int run_frontend_chained(const bigc_model* m, void* s, const bigc_batch* b, cons
         // Round 5: the raw f32 rows go HBM -> LDS by DMA through the address table and are split in LDS by the wave that fetched them
         // (gemm_ps.hip, A mode 3; two accumulators as the in-loop-split kernel it replaces); BIGC_FEAT0_SPLITLOOP=1: that kernel
         // (linear_split_kernel with a_rowptr: loads to registers, split, ds_write)
-        static const bool split_loop = getenv("BIGC_FEAT0_SPLITLOOP") && atoi(getenv("BIGC_FEAT0_SPLITLOOP")) != 0;
+        // Which of the two wins depends on the accumulation policy (measured, 256 videos, same box): with plain accumulation the DMA kernel runs
+        // 256-row tiles, 3.67 against 3.95 ms; with blocked accumulation it is bound to 128-row tiles, where the in-LDS split costs issue slots
+        // beside half as many MFMAs per slab: 4.24 ms against the in-loop-split kernel's 3.95 (two accumulators: 5.0 units of 2^-24 at K = 2048
+        // against 2.9 blocked and 8.5 plain; the whole step stays within 1e-4 of float64 on every benchmark video either way: 7.8e-5 / 6.7e-5).
+        // Default: the faster one for the policy in effect; BIGC_FEAT0_SPLITLOOP = 1 / 0 forces the in-loop-split / the DMA kernel.
+        static const int split_env = getenv("BIGC_FEAT0_SPLITLOOP") ? atoi(getenv("BIGC_FEAT0_SPLITLOOP")) : -1;
+        const bool split_loop = split_env >= 0 ? split_env != 0 : ps_accum(R, c.dim_feat) != 0;
         PsGemm g;
         g.a_rowptr = (const unsigned long long*)b->feat_row_ptr; g.a_fmt = PS_F32; g.W = m->feat0.w; g.ldw = c.dim_feat; g.bias = m->feat0.b;
-        g.Cs = w.hv; g.ldcs = (long)de * 4; g.M = R; g.N = de; g.K = c.dim_feat; g.act = BIGC_ACT_RELU; g.range_flag = w.flag; g.two_acc = true;
+        g.Cs = w.hv; g.ldcs = (long)de * 4; g.M = R; g.N = de; g.K = c.dim_feat; g.act = BIGC_ACT_RELU; g.range_flag = w.flag; g.accum = ps_accum(R, c.dim_feat);
         if (!split_loop && c.dim_feat % 32 == 0 && bigc_gemm_ps_supported(g) && bigc_linear_get_fast() != 2) TRY(bigc_gemm_ps_launch((hipStream_t)s, g));
         else TRY(bigc_linear_hr8out_rows(s, b->feat_row_ptr, m->feat0.w, c.dim_feat, m->feat0.b, w.hv, de, R, de, c.dim_feat, BIGC_ACT_RELU, w.flag));
     } else {
@@ -508,6 +532,7 @@ int forward_ps(bigc_model* m, void* stream, const bigc_batch* b, const Work& w, 
     TRY(bigc_fill_offsets(hs, w.q_off, B + 1, Q));
     if (c.n_deco_layers == 0) TRY(bigc_add_rows_f32(s, nullptr, m->qinit, w.query, BQ, dp, Q));
     const float att_scale = 1.0f / sqrtf((float)de);
+    cx.decoder = true;
     for (int i = 0; i < c.n_deco_layers; ++i) {
         const DecLayer& L = m->dec[i];
         Lin qkp{L.in_proj.w, L.in_proj.b};
@@ -705,6 +730,7 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
     TRY(bigc_fill_offsets(hs, w.q_off, B + 1, Q));
     if (c.n_deco_layers == 0) TRY(bigc_add_rows_f32(s, nullptr, m->qinit, w.query, BQ, dp, Q));
     const float att_scale = 1.0f / sqrtf((float)de);
+    cx.decoder = true;
     for (int i = 0; i < c.n_deco_layers; ++i) {
         const DecLayer& L = m->dec[i];
         Lin qkp{L.in_proj.w, L.in_proj.b};

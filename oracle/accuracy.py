@@ -29,6 +29,13 @@ and an f32 oracle at 5.8e-5; round 3: three, up to 2.12e-4), none above 2e-4, ON
 evaluations (round 3: two).  At NOISE_RATIO = 1.0 that one video (bound 1.48e-4) would fail by 7 %: the remaining factor is the conv
 GEMM's single accumulator, which is what 1.5 stands for.  A defect of the HIP arithmetic (a stage less accurate than that) would put
 many videos outside their noise floor; an outlier of chance does not.
+
+Round 5: every GEMM of the eval path accumulates in blocks of K = 128 folded into a running total (csrc/gemm_ps.hip, PsGemm.accum = 2; the
+in-loop-split kernel keeps its two accumulators): measured rms rounding 2.9 / 2.3 / 3.0 units at K = 2048 / 512 / 3072 -- BELOW the CPU GEMM's
+4.3 / 2.9 / 3.2 -- and over all 256 benchmark videos the HIP logits are within 1e-4 of the float64 evaluation on EVERY video (max 6.7e-5 to
+7.8e-5, mean 8e-6 to 9e-6; the f32 oracle: max 2.1e-4, mean 1.15e-5; benchmarks/accuracy_sweep.py, profiles/r05a_accuracy_sweep.jsonl).
+NOISE_RATIO is therefore 1.0 and the tests assert ``hip_vs_f64 <= 1e-4`` outright; this arbitration remains for the opt-in plain
+accumulation (bigc_set_accum_policy(0)) and as bench.py's diagnostic where two f32 evaluations differ by more than 1e-4.
 """
 import copy
 
@@ -39,7 +46,7 @@ from . import bigc_oracle as O
 
 BOUND = 1e-4
 SIGMAS = 4.0
-NOISE_RATIO = 1.5      # rms rounding error of the HIP GEMMs relative to the CPU GEMM's on the front-end shapes (measured, see above)
+NOISE_RATIO = 1.0      # rms rounding error of the HIP GEMMs relative to the CPU GEMM's: <= 1 since round 5 (blocked accumulation, see below)
 CAP = 3e-4             # no video may be farther than this from float64, whatever its noise floor
 
 

@@ -199,14 +199,13 @@ def test_benchmark_videos_vs_oracle_row_for_row():
     identical, predicate logits within 1e-4 relative -- index parity at full size against the ORACLE (pinned to the reference by
     tests/golden/bigc_v_n64 / bigc_v_n100), not against the path's own second GEMM mode.
 
-    PER VIDEO: the HIP logits are within 1e-4 of the f32 oracle's; where they are not, a float64 evaluation of the oracle is the
-    truth and the video passes if HIP is within 1e-4 of it -- or within the video's own float32 noise floor (oracle/accuracy.py:
-    4 x the rms error of f32 evaluations of that video with inputs perturbed by one rounding, x 1.5 for the measured
-    rounding-error ratio of the HIP one-accumulator GEMMs to MKL's, capped at 3e-4).  The benchmark model's attention is
-    sharp by construction (scores of magnitude ~50): on a few videos a rounding error of 5e-7 in the encoder output moves the logits
-    by 1e-4, for the f32 oracle (video 29: 2.1e-4 from float64 on 16 threads, 1.3e-4 on 8) as for the HIP path (video 28: 1.2e-4);
-    benchmarks/accuracy_layers.py shows the per-layer error of the two to be equal and the difference to be amplification.
-    Over the SET, HIP's mean distance to float64 must not exceed 1.5 x the f32 oracle's."""
+    PER VIDEO (round 5): the HIP logits are within 1e-4 of a FLOAT64 evaluation of the oracle, max-norm relative to max |logit| of the
+    video -- asserted outright, no noise-floor criterion.  The benchmark model's attention is sharp by construction (scores of magnitude
+    ~50) and amplifies round-off: an f32 evaluation whose GEMMs round like MKL's is up to 2.1e-4 from float64 on this set (the f32 oracle
+    on video 29), and so was the HIP path while its GEMMs summed K in one accumulator (1.65e-4 on video 117, 1.59e-4 on 172).  With blocked
+    accumulation in every GEMM (csrc/gemm_ps.hip) the maximum over all 256 benchmark videos is 6.7e-5 to 7.8e-5.  Where HIP and the f32
+    oracle differ by more than 1e-4 the f32 oracle must be the farther one from float64.
+    Over the SET, HIP's mean distance to float64 must not exceed 1.1 x the f32 oracle's (measured 0.7 - 0.8 x)."""
     from oracle import accuracy as A
     from oracle import bigc_oracle as O
     n_vid = 32
@@ -237,17 +236,19 @@ def test_benchmark_videos_vs_oracle_row_for_row():
             ref64 = A.f64_logits(sd, cfg, p, sd64=sd64)
             e_hips.append(A.rel_err(logits[v], ref64))
             e_refs.append(A.rel_err(ref, ref64))
+            # north_star's bound, by arithmetic (round 5: blocked accumulation in every GEMM of the path): within 1e-4 of the float64
+            # evaluation on EVERY video -- no noise-floor criterion.  Where two f32 evaluations are more than 1e-4 apart it is then the f32
+            # oracle that sits far from float64 (video 29 of this set: 2.1e-4), which is recorded, not excused.
+            assert e_hips[-1] <= 1e-4, "video %d: HIP logits %.2e from the float64 oracle (f32 oracle: %.2e)" % (v, e_hips[-1], e_refs[-1])
             if np.abs(logits[v] - ref).max() / np.abs(ref).max() > 1e-4:
-                a = A.arbitrate(sd, cfg, p, logits[v], ref, sd64=sd64)
-                arbitrated.append((v, a))
-                assert a["passed"], "video %d: HIP logits %.2e from float64, bound %.2e (f32 oracle %.2e, f32 noise floor %s)" % (
-                    v, a["hip_vs_f64"], a["bound"], a["f32_oracle_vs_f64"], a.get("f32_noise_floor_sample"))
+                arbitrated.append((v, dict(hip_vs_f64=e_hips[-1], f32_oracle_vs_f64=e_refs[-1])))
+                assert e_refs[-1] > e_hips[-1], "video %d: HIP and the f32 oracle differ by more than 1e-4 and HIP is the farther from float64" % v
             if want is None:
                 continue
             assert np.array_equal(got[0], want[0].numpy()), "video %d: quintuples differ" % v
             assert np.array_equal(got[2], want[2].numpy()) and np.array_equal(got[3], want[3].numpy())
             assert np.abs(got[1] - want[1].numpy()).max() <= 2e-4      # softmax probability of logits that agree to 1e-4 of max |logit|
             rows += want[0].shape[0]
-    assert rows > 32 * 50 and len(arbitrated) <= 2, arbitrated          # (round 3: <= 3; the K = 2048 GEMM is back on two accumulators)
-    assert sum(1 for _, a in arbitrated if a["hip_vs_f64"] > 1e-4) <= 1 and all(a["hip_vs_f64"] <= 2e-4 for _, a in arbitrated), arbitrated
-    assert np.mean(e_hips) <= 1.5 * np.mean(e_refs), "mean distance to float64: hip %.2e, f32 oracle %.2e" % (np.mean(e_hips), np.mean(e_refs))
+    assert rows > 32 * 50 and len(arbitrated) <= 2, arbitrated
+    assert max(e_hips) <= 1e-4 and np.mean(e_hips) <= 1.1 * np.mean(e_refs), "distance to float64: hip max %.2e mean %.2e, f32 oracle mean %.2e" % (
+        max(e_hips), np.mean(e_hips), np.mean(e_refs))

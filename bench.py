@@ -227,6 +227,32 @@ def gemm_roofline(fam, steps, step_ms=None):
     return r
 
 
+def family_rooflines(fam, steps, step_ms, mfma_peak_tflops=None):
+    """Every kernel family of a leg against the roof that bounds it: the longer of flops / MFMA peak and bytes / HBM peak decides the bound
+    (families whose launches carry neither -- index tables, sorts -- are listed with their time only).  -> (dict per family, share of
+    the instrumented step that has a roofline, total GFLOP per step, total algorithmic GB per step)"""
+    peak_f = (F32_MFMA_PEAK_TFLOPS if EXACT_F32 else F16_MFMA_PEAK_TFLOPS / 3) if mfma_peak_tflops is None else mfma_peak_tflops
+    out, covered, flops_all, bytes_all = {}, 0.0, 0.0, 0.0
+    for name, v in fam.items():
+        sec = v["ms"] * 1e-3
+        r = dict(ms_per_step=round(v["ms"] / steps, 4), launches_per_step=v["launches"] // steps)
+        if sec > 0 and (v["flops"] > 0 or v["bytes"] > 0):
+            t_mfma, t_hbm = v["flops"] / (peak_f * 1e12), v["bytes"] / (HBM_PEAK_GBS * 1e9)
+            if t_hbm >= t_mfma:
+                a = v["bytes"] / sec / 1e9
+                r.update(bound="hbm", achieved=round(a, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(a / HBM_PEAK_GBS, 4))
+            else:
+                a = v["flops"] / sec / 1e12
+                r.update(bound="mfma", achieved=round(a, 2), peak=round(peak_f, 1), unit="TFLOP/s", frac=round(a / peak_f, 4))
+            r.update(gflop_per_step=round(v["flops"] / steps / 1e9, 2), gbytes_per_step=round(v["bytes"] / steps / 1e9, 4))
+            covered += v["ms"]
+            flops_all += v["flops"]
+            bytes_all += v["bytes"]
+        out[name] = r
+    share = covered / steps / step_ms if step_ms else None
+    return out, (round(share, 3) if share is not None else None), flops_all / steps / 1e9, bytes_all / steps / 1e9
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # --mode train: the training step as its own benchmark line
 # ---------------------------------------------------------------------------------------------------------------------
@@ -498,7 +524,20 @@ def vidor_grounding_legs(args, lib, device, want_vidor, want_grounding):
         del outs
     gsteps = 5
     el, el_prof, fam = timed_with_events(lib, grd_step, 2, gsteps)
-    legs["grounding"] = dict(value=round(n_q * gsteps / el, 1), unit="triplet-queries/s", ms_per_step=round(1e3 * el / gsteps, 3),
+    by_fam, share, gflop_step, gbyte_step = family_rooflines(fam, gsteps, 1e3 * el_prof / gsteps)
+    clip_bytes = sum(int(j[0].numel()) * 4 for j in jobs)
+    weight_bytes = 4 * sum(int(v.numel()) for v in gsd.values())
+    out_bytes = n_q * (gcfg["num_bins"] + 1) * (2 * 4 + 4 + 1)
+    # ~23 GFLOP per video of 200 queries x 120 clips; this leg's videos have other n x T, so the figure is scaled by sum n T
+    nt_sum = sum(int(j[1].shape[0]) * int(j[0].shape[0]) for j in jobs)
+    grd_step = dict(gflop_per_step_counted=round(gflop_step, 1), gflop_per_step_survey_8d_scaled=round(23.0 * nt_sum / (200 * 120), 1),
+                    algorithmic_gbytes_per_step_all_launches=round(gbyte_step, 3),
+                    compulsory_bytes=dict(clip_features=clip_bytes, weights=weight_bytes, outputs=out_bytes, total=clip_bytes + weight_bytes + out_bytes),
+                    roofline_share_of_step=share,
+                    note="every family of the leg with its own bound (rooflines_by_family): the d = 128 GEMMs, depth-wise stages, LayerNorm and attention are "
+                         "HBM-bound on the INTERMEDIATES they exchange (32 flop per byte at d = 128); against the compulsory bytes alone (clip features + weights + outputs) "
+                         "the step would take %.1f us at 8 TB/s" % (1e6 * (clip_bytes + weight_bytes + out_bytes) / (HBM_PEAK_GBS * 1e9)))
+    legs["grounding"] = dict(value=round(n_q * gsteps / el, 1), unit="triplet-queries/s", ms_per_step=round(1e3 * el / gsteps, 3), rooflines_by_family=by_fam, step=grd_step,
                              ms_per_video=round(1e3 * el / gsteps / len(jobs), 3), steps=gsteps,
                              workload="grounding stage (BASELINE configs[2]/[3]): grd_model_v5 DEBUG eval forward incl. temporal pooling + NMS, "
                                       "config G, %d videos, %d queries (<=200 per video), T = ceil(video_len/8) in [%d,%d]"
@@ -727,9 +766,11 @@ def train_leg(args, lib, device):
                                 launches_per_step=dw["launches"] // steps, gflop_per_step=round(dw["flops"] / steps / 1e9, 1), ms_per_step=round(dw["ms"] / steps, 3)),
                         share_of_step=round(both_ms / steps / (1e3 * el_prof / steps), 3), traffic=None,
                         measured="HIP events around each launch over %d instrumented steps" % steps)
+        by_fam, share, gflop_step, _ = family_rooflines(fam, steps, 1e3 * el_prof / steps)
         out["videos_%d" % nvid] = dict(value=round(pairs * steps / el, 1), unit="pairs/s", ms_per_step=round(1e3 * el / steps, 3), steps=steps,
                                        kernel_ms_per_step=round(kern_ms, 3), kernel_share_of_step=round(kern_ms / (1e3 * el / steps), 3),
                                        instrumented_ms_per_step=round(1e3 * el_prof / steps, 3), roofline=roof,
+                                       rooflines_by_family={k: v for k, v in by_fam.items() if "bound" in v}, roofline_share_of_step=share,
                                        kernel_families_ms_per_step={k: round(v["ms"] / steps, 3) for k, v in fam.items()})
         del model, props, gts, opt
         torch.cuda.empty_cache()

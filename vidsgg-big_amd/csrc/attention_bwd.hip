@@ -516,7 +516,9 @@ extern "C" int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, cons
     if (n_seq <= 0 || max_q <= 0 || max_k <= 0) return BIGC_OK;
     hipStream_t s = (hipStream_t)stream;
     const float scale = 1.0f / sqrtf((float)hd);
-    ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
+    // algorithmic work of the attention-core gradient: five L_q x L_k x hd products per (sequence, head) -- the scores recomputed, dP = dO V^T,
+    // dV = P^T dO, dQ = dS K, dK = dS^T Q -- with sum L_q L_k >= rows^2 / n_seq (the equal-length value); q, k, v, o, dO read and dq, dk, dv written once
+    ProfScope ps(stream, FAM_ATTN_BWD, 10.0 * (double)total_q_rows * ((double)total_q_rows / n_seq) * n_head * hd, 32.0 * (double)total_q_rows * n_head * hd);
     // head_dim 64 (the BIG-C encoder / decoder layers): split-operand f16 MFMA kernels first; the f32-MFMA kernels behind them run only if
     // an operand was out of the split's range
     int* run_flag = nullptr;

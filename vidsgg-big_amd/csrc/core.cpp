@@ -39,7 +39,12 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
+static thread_local double g_hint_flops = 0.0, g_hint_bytes = 0.0;
+void bigc_prof_hint(double flops, double bytes) { g_hint_flops = flops; g_hint_bytes = bytes; }
+
 ProfScope::ProfScope(void* stream, int family, double flops, double bytes) : s((hipStream_t)stream), slot(-1) {
+    if (flops == 0.0 && bytes == 0.0) { flops = g_hint_flops; bytes = g_hint_bytes; }
+    g_hint_flops = g_hint_bytes = 0.0;
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Pending p{take_event(), take_event(), family, flops, bytes};

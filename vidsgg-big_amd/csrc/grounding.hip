@@ -657,6 +657,8 @@ int qanet(void* s, const Enc& E, const float* x, const float* pos, const Seqs& q
     GTRY(glinear(s, ln, d, E.in_proj, w.qkv, 3 * d, rows, 3 * d, d, BIGC_ACT_NONE));
     const int32_t* off = q.off;
     if (!q.info) { GTRY(bigc_fill_offsets((hipStream_t)s, w.off, q.n_seq + 1, q.T)); off = w.off; }
+    // (profiling: 4 L^2 d flop per sequence -- sum L^2 >= rows^2 / n_seq, the equal-length value --, q / k / v read and the output written once)
+    bigc_prof_hint(4.0 * (double)rows * ((double)rows / q.n_seq) * d, 16.0 * rows * (double)d);
     GTRY(bigc_mha_core_f32(s, w.qkv, 3 * d, w.qkv + d, 3 * d, w.qkv + 2 * d, 3 * d, w.att, d, off, off, q.n_seq, q.max_T, 8, d / 8, nullptr));
     GTRY(glinear(s, w.att, d, E.out_proj, nxt, d, rows, d, d, BIGC_ACT_NONE, res, d));        // attn + res
     res = nxt;

@@ -10,6 +10,7 @@
 //     :376), attention kernels take per-video row offsets;
 //   * everything is stream-ordered on the caller's HIP stream, no host synchronisation.
 #include "model_internal.h"
+#include "prof.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -512,6 +513,7 @@ int forward_ps(bigc_model* m, void* stream, const bigc_batch* b, const Work& w, 
     for (int i = 0; i < c.n_enco_layers; ++i) {
         const EncLayer& L = m->enc[i];
         TRY(ps(cx, xs, de, true, L.in_proj, de, w.qkv, 3 * de, nullptr, 0, NT, 3 * de, de, BIGC_ACT_NONE));
+        bigc_prof_hint(4.0 * NT * ((double)NT / B) * de, 16.0 * NT * (double)de);      // encoder: B sequences of ~NT / B tracklets
         TRY(bigc_mha_core_f32(s, w.qkv, 3 * de, w.qkv + de, 3 * de, w.qkv + 2 * de, 3 * de, w.ao, de, b->vid_trk_off, b->vid_trk_off,
                               B, b->max_trk, H, hd, nullptr));
         TRY(ps(cx, w.ao, de, false, L.out_proj, de, w.t1, de, nullptr, 0, NT, de, de, BIGC_ACT_NONE, x, de));
@@ -709,6 +711,7 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
     for (int i = 0; i < c.n_enco_layers; ++i) {
         const EncLayer& L = m->enc[i];
         TRY(linear(s, x, de, L.in_proj, w.qkv, 3 * de, NT, 3 * de, de, BIGC_ACT_NONE));
+        bigc_prof_hint(4.0 * NT * ((double)NT / B) * de, 16.0 * NT * (double)de);      // encoder: B sequences of ~NT / B tracklets
         TRY(bigc_mha_core_f32(s, w.qkv, 3 * de, w.qkv + de, 3 * de, w.qkv + 2 * de, 3 * de, w.ao, de, b->vid_trk_off, b->vid_trk_off,
                               B, b->max_trk, H, hd, nullptr));
         TRY(linear(s, w.ao, de, L.out_proj, w.t1, de, NT, de, de, BIGC_ACT_NONE, x, de));
@@ -767,6 +770,7 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
             // w.querys = the split twin of w.query, written by the previous layer's last LayerNorm
             TRY(ps(cx, w.querys, dp, true, L.in_proj, dp, w.qk, 3 * dp, nullptr, 0, BQ, 3 * dp, dp, BIGC_ACT_NONE,
                    m->qkpos + (size_t)Q * 3 * dp * i, 3 * dp, nullptr, 1, Q));
+            bigc_prof_hint(4.0 * BQ * (double)Q * dp, 16.0 * BQ * (double)dp);          // B sequences of Q queries: 4 Q^2 dp flop each; q | k | v read, o written
             if (!bigc_mha_core_hr8_launch(hs, w.qk, 3 * dp, w.qk + dp, 3 * dp, w.qk + 2 * dp, 3 * dp, w.ao2, (long)dp * 4, w.q_off, B, Q, H, dp / H, w.flag))
                 return bigc_fail(BIGC_ERR_ARG, "forward: self-attention shape outside the split-output kernel");
             if (ln_fused) {
@@ -802,6 +806,8 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
             }
             const float* ec = w.ecat + (size_t)i * EW;
             TRY(build_role_cat(m, s));
+            // (profiling: per video and role Q x N scores over da / 2 and Q x N x dp values; N ~ NT / B; reads p2a + the entity rows, writes 2 dp per query)
+            bigc_prof_hint(2.0 * 2.0 * BQ * ((double)NT / B) * (da / 2 + dp), 4.0 * (BQ * (double)da + (double)NT * (da + 2 * dp) + BQ * 2.0 * dp));
             if (!bigc_role_fused_proj_hr8_launch(hs, w.p2a, da, ec, EP, ec + da, EP, (long)dp, L.role0[0].b, L.role1[0].b, 1, last ? out->att : nullptr,
                                                  w.vals, (long)2 * dp * 4, dp, b->vid_trk_off, B, Q, b->max_trk, da / 2, dp, att_scale, w.flag))
                 return bigc_fail(BIGC_ERR_ARG, "forward: role-attention shape outside the split-output kernel");

@@ -26,12 +26,19 @@ Also printed in the same JSON line (rank 0; everything below runs OUTSIDE the ti
                 op sequence: kind "port") timed on the host cores, N=1 only, on a bounded sample of the
                 same videos
   oracle_parity the oracle outputs of that sample compared row for row with the HIP outputs of the
-                same videos: triplet rows identical, predicate logits max relative difference
+                same videos: triplet rows identical, predicate logits max relative difference; and a FLOAT64 evaluation
+                of the oracle for every sampled video (`distance_to_float64`: max / mean over the videos of the HIP path's
+                and the f32 oracle's distance to it, videos above 1e-4, the per-query-row figure)
+  plain_accumulation   the same call with bigc_set_accum_policy(0) (one accumulator per element, largest tiles): what the default's
+                blocked accumulation costs and what it buys (its own distance to float64)
+  ranks         who took part: rank, host, device ordinal + UUID and own step time of every rank, gathered through the job's process group
   exact_f32_gemm_mode / fast_f16_gemm_mode   the same step with every GEMM on the exact f32 MFMA, and in the opt-in
                 reduced-precision mode (one f16 MFMA per product) with its Recall@50 gate
   vidor / grounding / train   the other BASELINE configs on the same GPU (N=1 only): VidOR-sized
-                classification (N=180 tracklets), the grounding scorer on its triplet queries, and
-                the BIG-C training step (forward + Hungarian + backward + all-reduce + clip + Adam)
+                classification (N=180 tracklets; 8 host-seeded videos also through the CPU oracle), the grounding scorer on its
+                triplet queries (a roofline per kernel family covering the step, step GFLOP against SURVEY.md 8d, compulsory bytes,
+                two of its videos through the CPU oracle), and the BIG-C training step (forward + Hungarian + backward + all-reduce
+                + clip + Adam; GEMM, dW and attention-backward rooflines)
   batch_x2      the headline workload at twice the videos per step
   forward_api / resident_packed_batch / forward_api_pipelined   the timed call (= value), the same forward on a batch that stays packed
                 in HBM (with its own GEMM roofline), and the call in two halves (model.forward_async / .result(), two calls in flight)
@@ -632,7 +639,7 @@ def fast_mode_leg(args, lib, model, packed, step, ref_out, cfg, base, width, pai
 def batch512_leg(args, lib, device):
     """The same eval step on twice the headline's videos per step (2 x --videos, default 512): from this size on the decoder's GEMM
     operands are written in the split form by their producers and the whole decoder runs on the pre-split-operand GEMM (automatic,
-    csrc/model.hip).  Not the headline -- the default step stays at the survey's 256-video set -- but in
+    csrc/model.hip; profiles/HISTORY_rounds1-4.md section 5 round 3).  Not the headline -- the default step stays at the survey's 256-video set -- but in
     the same line, so that the batch-size sensitivity is the driver's measurement and not a number in a document."""
     cfg = dict(configs.CONFIG_V)
     sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 7, att_gain=8.0)

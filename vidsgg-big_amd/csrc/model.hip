@@ -687,7 +687,7 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
     void* s = stream;
     // opt-in (BIGC_PS=1): the GEMMs on pre-split operands (csrc/gemm_ps.hip), when the caller can be told about an out-of-range
     // operand and the dimensions fit.  Measured on the benchmark step: 23.4 ms against 21.1 ms for the default path below
-    // ("gemm_ps"), so it is not the default.
+    // (profiles/HISTORY_rounds1-4.md section 3, "gemm_ps"), so it is not the default.
     static const bool ps_on = getenv("BIGC_PS") && atoi(getenv("BIGC_PS")) != 0;
     if (out->range_flag && ps_on && !bigc_linear_get_exact() && bigc_linear_get_fast() != 2 && ps_config_ok(c)) return forward_ps(m, stream, b, w, topk, out);
     if (out->range_flag && hipMemsetAsync(out->range_flag, 0, sizeof(int32_t), hs) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "forward: memset failed");

@@ -471,7 +471,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     const bool sigm = p.act == BIGC_ACT_SIGMOID;
     const float lo = p.act == BIGC_ACT_RELU ? 0.f : -INFINITY;
     const float osc = ((const float*)p.whdr)[2] * ACT_INV;                  // 2^-(Ew + Ea)
-    auto epilogue = [&](int j) {
+    auto epilogue = [&](int j) __attribute__((always_inline)) {
         const int L = tile_of(j), tm = L / p.tiles_n, tn = L - tm * p.tiles_n;
         const int m0 = tm * TM, n0 = tn * TNK;
 #pragma unroll
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     // E[x^2] - mean^2 cancellation); pass 2 normalises and stores.  Row sums: registers -> the two half-waves (one shuffle) -> the eight
     // waves (LDS, 8 floats per row, one barrier per pass).  Every wave of the workgroup reaches both barriers (rows past M compute garbage
     // that is never stored).
-    auto epilogue_ln = [&](int j) {
+    auto epilogue_ln = [&](int j) __attribute__((always_inline)) {
         const int m0 = tile_of(j) * TM;
         AS3 float* red = (AS3 float*)(lds + LN_OFF);
         float s1[RB], mean[RB], rstd[RB];
@@ -639,34 +639,36 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     // pieces of slab g + NST go out between the MFMAs of the units that follow (three per unit).
     // Mode 2 runs the A operand through registers instead: slab g + 1 is split into its stage before barrier_g (its f32 rows
     // were loaded before barrier_{g-1}).
-    int so[NST];
-#pragma unroll
-    for (int i = 0; i < NST; ++i) so[i] = i * STAGE_BYTES;                   // so[0] = stage of slab g, so[1] of g + 1, ...
+    // stage offsets as three scalars (an array rotated inside several loops ended up in scratch memory: a scratch load in the K loop is a
+    // vector-memory load, and its wait drains the DMAs): so0 = stage of slab g, so1 of g + 1, so2 of g + 2 (three-stage kernels)
+    int so0 = 0, so1 = STAGE_BYTES, so2 = (NST - 1) * STAGE_BYTES;
+    auto so_last = [&]() { return NST == 3 ? so2 : so1; };
+    auto so_at = [&](int i) { return i == 0 ? so0 : (i == 1 ? so1 : so2); };
     issue_tile_setup();
     int ikt_a = 0, ij_a = 0;                                                   // mode 2: (tile, slab) of the f32 rows in the registers
     if (AMODE == 2) {
         load_f32_at(0, 0);
-        issue_slab(so[0]); issue_advance();
-        split_store(so[0]);
+        issue_slab(so0); issue_advance();
+        split_store(so0);
         if (n_flat > 1) { ikt_a = nk > 1 ? 1 : 0; ij_a = nk > 1 ? 0 : 1; load_f32_at(ij_a, ikt_a); }
         if (n_flat > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NL) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     } else {
-        issue_slab(so[0]); issue_advance();
+        issue_slab(so0); issue_advance();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (AMODE == 3) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) { conv_read(i, so[0]); conv_write(i, so[0]); }
+            for (int i = 0; i < NA; ++i) { conv_read(i, so0); conv_write(i, so0); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int d = 1; d <= D; ++d) {
-        if (d < n_flat) { if (ikt == 0) issue_tile_setup(); issue_slab(so[d]); issue_advance(); }
+        if (d < n_flat) { if (ikt == 0) issue_tile_setup(); issue_slab(so_at(d)); issue_advance(); }
     }
-    rd_w(so[0], 0, WF[0]);
-    rd_a(so[0], 0, 0, AF[0]);
+    rd_w(so0, 0, WF[0]);
+    rd_a(so0, 0, 0, AF[0]);
     int ckt = 0, cj = 0;
     unsigned long long tr[5] = {0, 0, 0, 0, 0}, tp = 0;
     auto stamp = [&](int seg) {
@@ -683,100 +685,121 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     constexpr int FIRST = NU == 2 ? 6 : 4;
     bool opened = false;                           // the slab under issue has its first pieces out
     constexpr int BLKC = 4;                        // BLOCKED: K slabs per accumulation block (K = 128); the launcher guarantees nk % BLKC == 0
-    auto slab = [&](int g, auto fresh_c) {
+    // STEADY: the slab is neither the stream's first nor among its last NST, and no ablation switch is set: everything the generic body decides at
+    // run time (is there a next slab, does the barrier open a new one, is one under issue) is TRUE at compile time.  The generic body guards every
+    // DMA piece with a branch -- 10 to 14 s_cbranch per slab between the MFMAs; the steady body has none but the once-per-tile table setup.
+    auto slab = [&](int g, auto fresh_c, auto steady_c) __attribute__((always_inline)) {
         constexpr bool FRESH = decltype(fresh_c)::value;           // BLOCKED: this slab opens an accumulation block
-        const bool more = g + 1 < n_flat;
+        constexpr bool STEADY = decltype(steady_c)::value;
+        const bool more = STEADY || g + 1 < n_flat;
+        const bool two_more = STEADY || g + 2 < n_flat;
+        const int abl = STEADY ? 0 : p.ablate;
+        bool op = STEADY ? true : opened;                          // a slab is under issue (its first pieces went out in the previous slab's last unit)
         stamp(4);
 #pragma unroll
         for (int n = 0; n < NU; ++n) {
             const int s = n / U, u = n % U;
             const bool last = n == NU - 1;
-            if (n == NU / 2 && (p.ablate & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);
-            if (n == 0 && (p.ablate & 8) && wave >= 4) __builtin_amdgcn_s_setprio(0);
+            if (n == NU / 2 && (abl & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+            if (n == 0 && (abl & 8) && wave >= 4) __builtin_amdgcn_s_setprio(0);
             mm(WF[s & 1], AF[n & 1], u, 0, 2, FRESH && s == 0);
             bool open_now = false;
             // mode 3: slab g + 1's A pieces (this wave's own DMA) are converted during unit CONV_N of slab g, one unit or more ahead of
             // barrier_g.  What may still be in flight behind them: 128-row tiles (three stages): their slab's W pieces and all of slab g + 2;
             // 256-row tiles (two stages): their slab's W pieces (issued during unit 0).
             constexpr int CONV_N = NU == 2 ? 0 : 2;
-            const bool conv_now = AMODE == 3 && n == CONV_N && more && !(p.ablate & 16);      // (ablate 16: timing without the in-LDS split, results wrong)
+            const bool conv_now = AMODE == 3 && n == CONV_N && more && !(abl & 16);      // (ablate 16: timing without the in-LDS split, results wrong)
             if (!last) {
                 // fragments of the next unit of this slab
-                if (u == U - 1) rd_w(so[0], s + 1, WF[(s + 1) & 1]);
-                rd_a(so[0], (n + 1) / U, (n + 1) % U, AF[(n + 1) & 1]);
-                if (conv_now && !(p.ablate & 32)) {                                  // (ablate 32: timing without this wait, results wrong)
-                    if (D > 1 && g + 2 < n_flat) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPCL + NW) : "memory");
+                if (u == U - 1) rd_w(so0, s + 1, WF[(s + 1) & 1]);
+                rd_a(so0, (n + 1) / U, (n + 1) % U, AF[(n + 1) & 1]);
+                if (conv_now && !(abl & 32)) {                                  // (ablate 32: timing without this wait, results wrong)
+                    if (D > 1 && two_more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPCL + NW) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NW) : "memory");
                 }
-                if (conv_now && !(p.ablate & 64) && CVS > 1) {
+                if (conv_now && !(abl & 64) && CVS > 1) {
 #pragma unroll
-                    for (int i = 0; i < NA; ++i) conv_read(i, so[1]);
+                    for (int i = 0; i < NA; ++i) conv_read(i, so1);
                 }
             } else {
                 if (more) {
                     if (AMODE == 2) {
-                        split_store(so[1]);                      // slab g + 1 (the compiler waits for its loads here)
+                        split_store(so1);                      // slab g + 1 (the compiler waits for its loads here)
                         __builtin_amdgcn_sched_barrier(0);       // the split's last use of the registers stays ahead of the loads that refill them
-                        if (g + 2 < n_flat) {
+                        if (two_more) {
                             if (++ikt_a == nk) { ikt_a = 0; ++ij_a; }
                             load_f32_at(ij_a, ikt_a);            // slab g + 2
                         }
                         // W of slab g + 1 landed: behind it at most the W pieces of slab g + 2 (D = 2) and the loads just issued
-                        if (g + 2 < n_flat) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((D - 1) * NPCL + NL) : "memory");
+                        if (two_more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((D - 1) * NPCL + NL) : "memory");
                         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                     } else {
                         stamp(0);
-                        if (D > 1 && g + 2 < n_flat) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((D - 1) * NPCL) : "memory");
+                        if (D > 1 && two_more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((D - 1) * NPCL) : "memory");
                         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         stamp(1);
                         __builtin_amdgcn_s_barrier();
                         stamp(2);
                     }
-                    open_now = g + NST < n_flat && !(p.ablate & 1);
+                    open_now = STEADY || (g + NST < n_flat && !(abl & 1));
                     if (open_now && ikt == 0) issue_tile_setup();
-                    rd_w(so[1], 0, WF[0]);
-                    rd_a(so[1], 0, 0, AF[0]);
+                    rd_w(so1, 0, WF[0]);
+                    rd_a(so1, 0, 0, AF[0]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             // the unit's other MM - 2 MFMAs, with up to NS DMA pieces between them (one after every second MFMA)
             constexpr int NS = MM / 2;
             const int pb = last ? 0 : FIRST + NS * n, pe = last ? min(FIRST, NPCL) : min(NPCL, FIRST + NS * (n + 1));
-            const bool issuing = loader && (last ? open_now : opened);
+            const bool issuing = loader && (last ? open_now : op);
 #pragma unroll
             for (int k = 0; k < NS - 1; ++k) {
                 mm(WF[s & 1], AF[n & 1], u, 2 + 2 * k, 4 + 2 * k, FRESH && s == 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (pb + k < pe && issuing) issue_piece(pb + k, last ? so[0] : so[NST - 1]);
+                if (pb + k < pe && issuing) issue_piece(pb + k, last ? so0 : so_last());
                 // one piece per MFMA pair: piece k - 1 is converted, then piece k fetched (one pair = 64+ matrix-pipe cycles ahead of its use)
-                if (AMODE == 3 && conv_now && !(p.ablate & 64)) {                         // (ablate 64: the wait without the conversion)
+                if (AMODE == 3 && conv_now && !(abl & 64)) {                         // (ablate 64: the wait without the conversion)
                     if (CVS > 1) {
-                        if (k >= NS - 1 - NA) conv_write(k - (NS - 1 - NA), so[1]);           // the unit's last NA pairs
+                        if (k >= NS - 1 - NA) conv_write(k - (NS - 1 - NA), so1);           // the unit's last NA pairs
                     } else {
-                        if (k >= 1 && k - 1 < NA) conv_write(k - 1, so[1]);
-                        if (k < NA) conv_read(k, so[1]);
+                        if (k >= 1 && k - 1 < NA) conv_write(k - 1, so1);
+                        if (k < NA) conv_read(k, so1);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (pb + NS - 1 < pe && issuing) issue_piece(pb + NS - 1, last ? so[0] : so[NST - 1]);
-            if (!last && opened && FIRST + NS * (n + 1) >= NPCL) { issue_advance(); opened = false; }
-            if (last) opened = open_now;
+            if (pb + NS - 1 < pe && issuing) issue_piece(pb + NS - 1, last ? so0 : so_last());
+            if (!last && op && FIRST + NS * (n + 1) >= NPCL) { issue_advance(); op = false; }
+            if (last) op = open_now;
         }
         stamp(3);
-        const int t = so[0];
-#pragma unroll
-        for (int i = 0; i + 1 < NST; ++i) so[i] = so[i + 1];
-        so[NST - 1] = t;
+        const int t = so0;
+        so0 = so1;
+        if (NST == 3) { so1 = so2; so2 = t; } else { so1 = t; }
+        opened = op;
     };
+    const bool steady_ok = p.ablate == 0 && !TRACE && !(AMODE == 3 && BLOCKED);      // (f32 rows + blocked: the steady bodies on top do not fit the registers)
     if constexpr (BLOCKED) {
         // blocks of BLKC slabs: the fold sits behind an inner loop of fixed length, so that it is unconditional code (as a conditional inside
         // the slab loop it made the compiler merge two versions of all 128 accumulator registers: 100 spilled)
         for (int g0 = 0; g0 < n_flat; g0 += BLKC) {
-            slab(g0, std::true_type{});                    // its first MFMAs start the block's sums from zero
+            if (steady_ok && g0 >= BLKC && g0 + BLKC - 1 + NST < n_flat) {
+                slab(g0, std::true_type{}, std::true_type{});     // its first MFMAs start the block's sums from zero
 #pragma unroll 1
-            for (int gi = 1; gi < BLKC; ++gi) slab(g0 + gi, std::false_type{});
+                for (int gi = 1; gi < BLKC; ++gi) slab(g0 + gi, std::false_type{}, std::true_type{});
+            } else {
+                // the stream's first and last blocks run the generic body; their sums start from explicitly zeroed accumulators (one body fewer
+                // to compile into this kernel: with four the gathered and the f32-row variants spilled)
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                    for (int ri = 0; ri < RB; ++ri)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[fi][ri][r] = 0.f;
+#pragma unroll 1
+                for (int gi = 0; gi < BLKC; ++gi) slab(g0 + gi, std::false_type{}, std::false_type{});
+            }
             fold_block();
             ckt += BLKC;
             if (ckt == nk) {
@@ -786,17 +809,19 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
             }
         }
     } else {
-        for (int g = 0; g < n_flat; ++g) {
-            const bool tile_end = ckt + 1 == nk;          // this slab is the last of its tile
-            slab(g, std::false_type{});
-            if (tile_end) {
-                if constexpr (LNM) epilogue_ln(cj); else epilogue(cj);
-                zero_acc();
-                ckt = 0; ++cj;
-            } else {
-                ++ckt;
-            }
+        // three loops -- the stream's first slab, its steady middle, its last NST slabs -- each with its own copy of the tile-end code (a choice
+        // between the two bodies INSIDE one loop makes the compiler merge two versions of the accumulators: hundreds of spilled registers)
+#define PS_TILE_END(te) \
+        if (te) { if constexpr (LNM) epilogue_ln(cj); else epilogue(cj); zero_acc(); ckt = 0; ++cj; } else { ++ckt; }
+        int g = 0;
+        if (n_flat > 0) { const bool te = ckt + 1 == nk; slab(g, std::false_type{}, std::false_type{}); PS_TILE_END(te) ++g; }
+        if (steady_ok) {
+#pragma unroll 1
+            for (; g + NST < n_flat; ++g) { const bool te = ckt + 1 == nk; slab(g, std::false_type{}, std::true_type{}); PS_TILE_END(te) }
         }
+#pragma unroll 1
+        for (; g < n_flat; ++g) { const bool te = ckt + 1 == nk; slab(g, std::false_type{}, std::false_type{}); PS_TILE_END(te) }
+#undef PS_TILE_END
     }
     if (TRACE && lane == 0) {
         for (int i = 0; i < 5; ++i) p.trace[((size_t)blockIdx.x * 8 + wave) * 5 + i] = tr[i];

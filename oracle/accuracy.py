@@ -33,7 +33,7 @@ many videos outside their noise floor; an outlier of chance does not.
 Round 5: every GEMM of the eval path accumulates in blocks of K = 128 folded into a running total (csrc/gemm_ps.hip, PsGemm.accum = 2; the
 in-loop-split kernel keeps its two accumulators): measured rms rounding 2.9 / 2.3 / 3.0 units at K = 2048 / 512 / 3072 -- BELOW the CPU GEMM's
 4.3 / 2.9 / 3.2 -- and over all 256 benchmark videos the HIP logits are within 1e-4 of the float64 evaluation on EVERY video (max 6.7e-5 to
-7.8e-5, mean 8e-6 to 9e-6; the f32 oracle: max 2.1e-4, mean 1.15e-5; benchmarks/accuracy_sweep.py, profiles/r05a_accuracy_sweep.jsonl).
+7.8e-5, mean 8e-6 to 9e-6; the f32 oracle: max 2.1e-4, mean 1.15e-5; benchmarks/accuracy_sweep.py, profiles/r05a_accuracy_sweep_policies.jsonl).
 NOISE_RATIO is therefore 1.0 and the tests assert ``hip_vs_f64 <= 1e-4`` outright; this arbitration remains for the opt-in plain
 accumulation (bigc_set_accum_policy(0)) and as bench.py's diagnostic where two f32 evaluations differ by more than 1e-4.
 """

@@ -36,6 +36,8 @@ VARIANTS = {
     "blk4_small": {"BIGC_PS_BLK": "4", "BIGC_PS_BLK_MAXM": "100000"},
     "blk4_decoder": {"BIGC_PS_BLK": "4", "BIGC_PS_BLK_MINM": "20000", "BIGC_PS_BLK_MAXM": "100000"},
     "rb2": {"BIGC_PS_RB": "2"},
+    "ln_fused": {"BIGC_LN_FUSED": "1"},
+    "ln_fused_resident": {"BIGC_LN_FUSED": "1", "ACC_SWEEP_RESIDENT": "1"},
     "plain": {"BIGC_ACCUM": "plain"},
     "k1024": {"BIGC_ACCUM": "k1024"},
     "front": {"BIGC_ACCUM": "front"},

@@ -2,7 +2,7 @@
 #   bash benchmarks/step_seq.sh [extra bench.py arguments]        (on the GPU box; output on stdout)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/seq -o bench -- python3 $R/bench.py --cpu-videos 0 --exact-steps 0 --fast-steps 0 --legs none --no-prof --steps 4 --warmup 2 "$@" > /tmp/seq.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/seq -o bench -- python3 $R/bench.py --cpu-videos 0 --exact-steps 0 --fast-steps 0 --legs none --recall-steps 0 --no-prof --steps 4 --warmup 2 "$@" > /tmp/seq.log 2>&1
 tail -1 /tmp/seq.log | cut -c1-160
 python3 - <<PY
 import csv, re

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     // registers at 128-row tiles, no spills (as a conditional in the slab loop: 256 + 100 spilled, 60 TFLOP/s).  The 192- and 256-row
     // tiles have no room for the second register set (70 / 163 spilled).  Over the 256 benchmark videos it is what brings EVERY video
     // within 1e-4 of a float64 evaluation (max 7.8e-5; one accumulator: 1.65e-4, second accumulator for the correction terms: 1.78e-4;
-    // benchmarks/accuracy_sweep.py, profiles/r05a_accuracy_sweep.jsonl).
+    // benchmarks/accuracy_sweep.py, profiles/r05a_accuracy_sweep_policies.jsonl).
     static_assert(!BLOCKED || (RB == 2 && !FAST && !LNM && !ACC2), "blocked accumulation: 128-row tiles only");
     f32x16 tot[2][BLOCKED ? RB : 1];
     f32x16 acc2[2][ACC2 ? RB : 1];

@@ -802,6 +802,8 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
             const int EW = da + 2 * dp, EP = EW * c.n_deco_layers;            // this layer's columns of w.ecat, and the pitch of its rows
             if (i == 0) {
                 TRY(build_enco_cat(m, s));
+                // (round 5, measured and dropped: this N = 6 x 1536 product on the pre-split-operand kernel -- enco_output converted once, blocked
+                // accumulation -- is 0.29 ms SLOWER per step than the in-loop-split kernel here (17.45 vs 17.16 ms of GEMM time, same box))
                 TRY(bigc_linear_f32(s, enco, de, nullptr, 1, de, m->enco_cat, de, m->enco_cat + (size_t)EP * de, nullptr, 0, w.ecat, EP, NT, EP, de, BIGC_ACT_NONE));
             }
             const float* ec = w.ecat + (size_t)i * EW;

@@ -25,6 +25,20 @@ struct LinearArgs {
     // split kernel, row-pointer mode: row m of A starts at address a_rowptr[m] (16-byte aligned) instead of A + m * lda -- the operand is
     // read in place from rows that live in separate allocations (the per-tracklet feature tensors of a batch, bigc_batch.feat_row_ptr)
     const uint64_t* a_rowptr = nullptr;
+    // split kernel, split-K (set by the launcher for small grids inside a SplitKScope): workgroup (tile, blockIdx.y) sums the K slabs
+    // [blockIdx.y * nkp, ...) and stores the raw partial tile to part[blockIdx.y] (M x N, dense); splitk_reduce_kernel adds the partials
+    // in split order and applies bias / activation / residual
+    int splits = 1; float* part = nullptr;
+};
+
+// Split-K is allowed for the launches of the calling thread while a scope is open (the TRAINING forward / backward: at the reference's
+// batch of 8 videos a decoder GEMM is 24 - 48 tiles on 256 CUs and its time is the latency of 16 K slabs).  The eval forwards never open
+// one: there a GEMM's result must not depend on how many rows share the launch (a video's bits do not depend on its company).
+extern thread_local int bigc_splitk_allowed;
+struct SplitKScope {
+    int prev;
+    SplitKScope() : prev(bigc_splitk_allowed) { bigc_splitk_allowed = 1; }
+    ~SplitKScope() { bigc_splitk_allowed = prev; }
 };
 
 // Weights that stay constant between launches are split once and cached per (pointer, shape) for an "epoch": the model

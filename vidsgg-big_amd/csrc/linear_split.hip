@@ -219,7 +219,11 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
     u32x4 rb[NB];
     int cur_seg = -1;
     float chk = 0.f, amax = 0.f;
-    const int nk = (p.K + BK - 1) / BK;
+    // split-K: this workgroup owns the slabs [kofs, kofs + nk) of the nk_tot slabs (p.splits == 1: all of them)
+    const int nk_tot = (p.K + BK - 1) / BK;
+    const int nkp = (nk_tot + p.splits - 1) / p.splits;
+    const int kofs = (int)blockIdx.y * nkp;
+    const int nk = min(nk_tot, kofs + nkp) - kofs;
 
     auto slab_cols = [&](int kt, int& kc, int& acol, bool& kval) {
         const int k0 = kt * BK;
@@ -374,8 +378,8 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
     // (slabs past the end repeat the last one: loaded and stored into the idle buffer, never read)
     auto step = [&](int kt, f32x4 (&ld)[NA], const f32x4 (&sp)[NA]) {
         const int buf = kt & 1;
-        load_w(min(kt + 1, nk - 1));
-        load_a(min(kt + 2, nk - 1), ld);
+        load_w(kofs + min(kt + 1, nk - 1));
+        load_a(kofs + min(kt + 2, nk - 1), ld);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 a1[2], a2[2], b1[2], b2[2];
@@ -404,9 +408,9 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
         __syncthreads();
     };
 
-    load_a(0, ra0);
-    load_w(0);
-    load_a(min(1, nk - 1), ra1);
+    load_a(kofs, ra0);
+    load_w(kofs);
+    load_a(kofs + min(1, nk - 1), ra1);
     store_tiles(0, ra0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc0[mi][ni][r] = 0.f; acc1[mi][ni][r] = 0.f; }
         // lane (l31, hi) of block mi / ni owns row m / n and the k quads 8c + 4hi .. + 3
-        for (int k8 = 0; k8 < p.K; k8 += 8) {
+        for (int k8 = kofs * BK; k8 < min(p.K, (kofs + nk) * BK); k8 += 8) {
             const int kq = k8 + 4 * hi;
             const bool kok = kq < p.K;
             const int kcl = min(kq, p.K - 4);
@@ -484,6 +488,23 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
         }
     }
 
+    if (p.splits > 1) {
+        // split-K: the raw partial tile (no bias, activation or residual: splitk_reduce_kernel applies them to the sum)
+        float* part = p.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int col = n0 + wn * 64 + ni * 32 + l31;
+                if (col >= p.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + mi * 32 + mfma_row(r, hi);
+                    if (row < p.M) part[(size_t)row * p.N + col] = acc0[mi][ni][r] + acc1[mi][ni][r] * RINV;
+                }
+            }
+        return;
+    }
     int colv[2];
     float bv[2];
 #pragma unroll
@@ -567,6 +588,33 @@ __global__ __launch_bounds__(128 * WN, (WN == 2 && DWK == 0) ? 2 : 1) void linea
         __builtin_amdgcn_wave_barrier();
     }
     if (p.Cs && hr_oob && p.range_flag) atomicOr(p.range_flag, 1);
+}
+
+// C[m, n] = epilogue(sum over the splits of part[s][m][n] + bias[n]), the partials added in split order (the same order in every run);
+// four columns per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, long M, int N, const float* __restrict__ bias,
+                                                            int act, const float* __restrict__ res, int ldr, float* __restrict__ C, int ldc) {
+    const int n4 = N / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * n4) return;
+    const long m = i / n4;
+    const int c = (int)(i - m * n4) * 4;
+    const size_t plane = (size_t)M * N;
+    const float* pp = part + (size_t)m * N + c;
+    f32x4 v = *(const f32x4*)pp;
+    for (int s = 1; s < splits; ++s) v += *(const f32x4*)(pp + (size_t)s * plane);
+    if (bias) v += *(const f32x4*)(bias + c);
+    f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+    if (res) rv = *(const f32x4*)(res + (size_t)m * ldr + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float t = v[j];
+        if (act == BIGC_ACT_RELU) t = fmaxf(t, 0.f);
+        if (act == BIGC_ACT_SIGMOID) t = 1.0f / (1.0f + expf(-t));
+        if (act == BIGC_ACT_RELU_MASK) t = rv[j] > 0.f ? t : 0.f; else t += rv[j];
+        v[j] = t;
+    }
+    *(f32x4*)(C + (size_t)m * ldc + c) = v;
 }
 
 // split weights: one allocation per (pointer, shape) = [int bad | pad to 256 B | N x K/4 groups]; re-split in place when the
@@ -724,6 +772,7 @@ void bigc_weight_cache_forget(const float* w) {
 }
 
 thread_local unsigned long long bigc_static_weights_epoch = 0;
+thread_local int bigc_splitk_allowed = 0;
 unsigned long long bigc_next_weights_epoch() { return ++g_epoch_seq; }
 thread_local std::vector<SplitJob>* bigc_split_recorder = nullptr;
 
@@ -800,6 +849,39 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
     const int wn = p.dw_w ? 2 : (force_wn ? (force_wn == 4 ? 4 : 2) : ((p.N > 192 && (rem == 0 || rem > 128) && !few) ? 4 : 2));
     p.tiles_n = cdiv(p.N, 64 * wn);
     const int grid2 = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
+    // split-K for small grids (inside a SplitKScope only: the training step; see linear_internal.h): enough splits to give every CU a
+    // workgroup, each at least four slabs long, at most eight; partial tiles go to a stream-ordered scratch (one per thread and device)
+    p.splits = 1; p.part = nullptr;
+    static const bool sk_off = getenv("BIGC_SPLITK") && atoi(getenv("BIGC_SPLITK")) == 0;
+    {
+        const long tiles = (long)p.tiles_m * p.tiles_n;
+        const int nk_tot = cdiv(p.K, BK);
+        const bool aligned = p.C && !p.Cs && p.N % 4 == 0 && p.ldc % 4 == 0 && ((uintptr_t)p.C & 15) == 0 && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
+                             (!p.res || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
+        if (bigc_splitk_allowed && !sk_off && aligned && !p.pre_x && !p.dw_w && tiles * 2 <= 256 && nk_tot >= 8) {
+            static const int min_slabs = getenv("BIGC_SPLITK_MINSLABS") ? atoi(getenv("BIGC_SPLITK_MINSLABS")) : 4;
+            int want = (int)(256 / tiles);
+            if (want > nk_tot / min_slabs) want = nk_tot / min_slabs;
+            if (want > 8) want = 8;
+            if (want >= 2) {
+                const int nkp = cdiv(nk_tot, want);
+                p.splits = cdiv(nk_tot, nkp);
+                struct Buf { float* p = nullptr; size_t cap = 0; };
+                thread_local std::unordered_map<int, Buf> bufs;
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_split: hipGetDevice failed");
+                Buf& b = bufs[dev];
+                const size_t need = (size_t)p.splits * p.M * p.N;
+                if (need > b.cap) {
+                    if (b.p) { if (hipStreamSynchronize(s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_split: sync failed"); (void)hipFree(b.p); }
+                    b.cap = need + need / 2;
+                    if (hipMalloc((void**)&b.p, b.cap * sizeof(float)) != hipSuccess) { b.p = nullptr; b.cap = 0; return bigc_fail(BIGC_ERR_HIP, "linear_split: hipMalloc of the split-K scratch failed"); }
+                }
+                p.part = b.p;
+            }
+        }
+    }
+    const dim3 grid3(grid2, p.splits);
     if (p.pre_x) {
         if (p.a_idx || ktail || p.dw_w) return bigc_fail(BIGC_ERR_ARG, "linear_split: preceding-layer mode needs K %% 32 == 0, no gather");
         if (wn == 4) hipLaunchKernelGGL((linear_split_kernel<false, false, 4, 0, true>), dim3(grid2), dim3(512), 0, s, p);
@@ -814,9 +896,9 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
         BIGC_LAUNCH_CHECK("linear_split (dwsep)");
         return BIGC_OK;
     }
-#define LAUNCH_SPLIT(G, T, W) do { if (fast == 2) hipLaunchKernelGGL((linear_split_kernel<G, T, W, 0, false, 2>), dim3(grid2), dim3(128 * W), 0, s, p); \
-                                   else if (fast) hipLaunchKernelGGL((linear_split_kernel<G, T, W, 0, false, 1>), dim3(grid2), dim3(128 * W), 0, s, p); \
-                                   else hipLaunchKernelGGL((linear_split_kernel<G, T, W>), dim3(grid2), dim3(128 * W), 0, s, p); } while (0)
+#define LAUNCH_SPLIT(G, T, W) do { if (fast == 2) hipLaunchKernelGGL((linear_split_kernel<G, T, W, 0, false, 2>), grid3, dim3(128 * W), 0, s, p); \
+                                   else if (fast) hipLaunchKernelGGL((linear_split_kernel<G, T, W, 0, false, 1>), grid3, dim3(128 * W), 0, s, p); \
+                                   else hipLaunchKernelGGL((linear_split_kernel<G, T, W>), grid3, dim3(128 * W), 0, s, p); } while (0)
     const int fast = bigc_linear_get_fast();
     if (wn == 4) {
         if (p.a_idx) { if (ktail) LAUNCH_SPLIT(true, true, 4); else LAUNCH_SPLIT(true, false, 4); }
@@ -827,5 +909,11 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
     }
 #undef LAUNCH_SPLIT
     BIGC_LAUNCH_CHECK("linear_split");
+    if (p.splits > 1) {
+        const long quads = (long)p.M * (p.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)((quads + 255) / 256)), dim3(256), 0, s, (const float*)p.part, p.splits, (long)p.M, p.N, p.bias, p.act,
+                           p.res, p.ldr, p.C, p.ldc);
+        BIGC_LAUNCH_CHECK("splitk_reduce");
+    }
     return BIGC_OK;
 }

@@ -354,6 +354,7 @@ static int open_arena(const bigc_model* m, const bigc_batch* b, void* workspace,
 
 extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                                   float* pred_logits, float* att_out) {
+    SplitKScope splitk;          // small-grid GEMMs of the step may split K (linear_internal.h)
     StaticWeights static_weights(m ? m->epoch : 0);
     ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     SplitRecorder recorder(m ? &m->train_jobs : nullptr);
@@ -483,6 +484,7 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
 
 extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                                    const float* dlogits, int ldg, const float* datt) {
+    SplitKScope splitk;          // small-grid GEMMs of the step may split K (linear_internal.h)
     StaticWeights static_weights(m ? m->epoch : 0);
     ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     SplitRecorder recorder(m ? &m->train_jobs : nullptr);
@@ -708,6 +710,7 @@ int open_pair_arena(const bigc_model* m, const bigc_batch* b, long n_pairs, void
 
 extern "C" int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
                                        size_t workspace_bytes, float* pair_logits) {
+    SplitKScope splitk;          // small-grid GEMMs of the step may split K (linear_internal.h)
     StaticWeights static_weights(m ? m->epoch : 0);
     ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     SplitRecorder recorder(m ? &m->train_jobs : nullptr);
@@ -744,6 +747,7 @@ extern "C" int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_b
 
 extern "C" int bigc_pair_train_backward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
                                         size_t workspace_bytes, const float* dlogits, int ldg) {
+    SplitKScope splitk;          // small-grid GEMMs of the step may split K (linear_internal.h)
     StaticWeights static_weights(m ? m->epoch : 0);
     ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     SplitRecorder recorder(m ? &m->train_jobs : nullptr);

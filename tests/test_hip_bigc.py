@@ -341,3 +341,32 @@ def test_chained_gemms_range_flag_reruns_the_step_on_the_exact_path():
     assert torch.equal(got["pred_logits"], want["pred_logits"]) and torch.equal(got["n_out"], want["n_out"])
     n = int(want["n_out"][0])      # rows past the count are padding, never written
     assert n > 0 and torch.equal(got["quint"][0, :n], want["quint"][0, :n]) and torch.equal(got["qid"][0, :n], want["qid"][0, :n])
+
+
+@pytest.mark.parametrize("policy", [0, 1, 2, 3, 4])
+def test_accumulation_policies_reproduce_the_reference_goldens(policy):
+    """bigc_set_accum_policy (csrc/linear.hip; 4 = blocked accumulation in every pre-split GEMM, the default; 0 = one accumulator per element on
+    the largest tiles): whatever the policy, the full-size reference goldens hold -- logits within 1e-4, attention arg-max and every triplet row
+    identical -- and the policy in effect before is handed back.  A video's bits depend on the policy, not on its company: the same video
+    alone and inside a batch of three gives identical logits under each policy."""
+    lib = _lib.load()
+    name = "bigc_v_n64"
+    g = np.load(os.path.join(cases.GOLDEN_DIR, name + ".npz"))
+    cfg, variant, sd, props, topk = cases.make_case(name)
+    model = build_model(cfg, variant, sd)
+    prev = lib.bigc_set_accum_policy(policy)
+    try:
+        assert lib.bigc_get_accum_policy() == policy
+        p = props[0]
+        res = model([p], topk=topk)
+        check_tuple_exact(res[0], g["v0_quintuples"], g["v0_scores"], g["v0_dura_inters"], g["v0_query_ids"])
+        out = model.forward_packed(PackedBatch([p], DEV), topk)
+        alone = out["pred_logits"].clone()
+        assert rel(alone.cpu().numpy(), g["v0_pred_logits"]) < LOGIT_RTOL
+        assert np.array_equal(out["soid"].cpu().numpy()[0], np.argmax(g["v0_att"], -1))
+        import copy
+        trio = model.forward_packed(PackedBatch([copy.deepcopy(p).to(DEV) for _ in range(3)], DEV), topk)["pred_logits"]
+        Q = cfg["num_querys"]
+        assert torch.equal(trio[:Q], alone) and torch.equal(trio[2 * Q:3 * Q], alone)
+    finally:
+        assert lib.bigc_set_accum_policy(prev) == policy

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void role_attention_kernel(const float* __rest
                                                              int n_vid, int nq, int n_qt, int half, float scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const long item = (long)blockIdx.x * 4 + wave;
+    const long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;          // one to four waves per workgroup (the launcher spreads small batches over more CUs)
     if (item >= (long)n_vid * n_qt) return;
     const int qt = item % n_qt, vid = item / n_qt;
     const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
@@ -680,9 +680,11 @@ extern "C" int bigc_role_attention_f32(void* stream, const float* p2a, int ldp, 
     BIGC_CHECK_ARG(half % 8 == 0 && ldp % 4 == 0 && lde % 4 == 0, "role_attention: half=%d must be a multiple of 8", half);
     if (n_vid <= 0) return BIGC_OK;
     const int n_qt = cdiv(nq, 32);
-    const int grid = cdiv(n_vid * n_qt, 4);
+    // small batches (the training step at 8 videos: 48 items): one wave per workgroup, so that the items spread over 48 CUs instead of 12
+    const int wpb = n_vid * n_qt <= 512 ? 1 : 4;
+    const int grid = cdiv(n_vid * n_qt, wpb);
     ProfScope ps(stream, FAM_ROLE_ATT, 0.0, 0.0);
-    hipLaunchKernelGGL(role_attention_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, att, e_off,
+    hipLaunchKernelGGL(role_attention_kernel, dim3(grid), dim3(64 * wpb), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, att, e_off,
                        n_vid, nq, n_qt, half, scale);
     BIGC_LAUNCH_CHECK("role_attention");
     return BIGC_OK;

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void role_attention_bwd_kernel(const float* __
                                                                  float scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const long item = (long)blockIdx.x * 4 + wave;
+    const long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;
     if (item >= (long)n_vid * n_qt) return;
     const int qt = item % n_qt, vid = item / n_qt;
     const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
@@ -554,7 +554,8 @@ extern "C" int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int l
     if (n_vid <= 0) return BIGC_OK;
     const int n_qt = cdiv(nq, 32);
     ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
-    hipLaunchKernelGGL(role_attention_bwd_kernel, dim3(cdiv(n_vid * n_qt, 4)), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, datt, ds,
+    const int wpb = n_vid * n_qt <= 512 ? 1 : 4;                 // small batches: one wave per workgroup (more CUs)
+    hipLaunchKernelGGL(role_attention_bwd_kernel, dim3(cdiv(n_vid * n_qt, wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, datt, ds,
                        e_off, n_vid, nq, n_qt, half, scale);
     BIGC_LAUNCH_CHECK("role_attention_bwd");
     return BIGC_OK;

@@ -174,24 +174,30 @@ struct PsArgs {
 //   ACC2 (128-row tiles): the two correction terms of a product (head x residual, residual x head: 2^-11 of the leading term) go to a SECOND
 //   accumulator, so that the leading accumulator is rounded once per k16 step instead of three times -- the scheme of linear_split.hip; the
 //   residuals are unscaled in this format, so the two are simply added in the epilogue.  rms error 10.3 -> ~6 units of 2^-24 at K = 3072.
-template <int AMODE, int RB, bool TRACE = false, bool FAST = false, bool BLOCKED = false, bool LNM = false, bool ACC2 = false>
-__global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
+//   NWV (round 5): waves per workgroup.  8 = two waves per SIMD, 256 registers each (everything above).  4 = ONE wave per SIMD with the
+//   whole 512-register file: tile 256 features x 128 rows, four waves side by side over the features, each a 64 x 128 patch (RB = 4) -- the
+//   fragment-read economy of the 256-row tile (0.25 ds_read_b128 pairs per MFMA instead of 0.33) with room for the second register set of the
+//   blocked accumulation (128 + 128 accumulator registers) and for addresses the 256-register kernels recompute per slab.
+template <int AMODE, int RB, bool TRACE = false, bool FAST = false, bool BLOCKED = false, bool LNM = false, bool ACC2 = false, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV, 1) void gemm_ps_kernel(const PsArgs p) {
+    static_assert(NWV == 8 || (NWV == 4 && RB == 4 && BLOCKED && !LNM && !TRACE && !ACC2 && AMODE <= 1), "four-wave form: blocked accumulation, hr8 operands, 64 x 128 wave patches");
+    constexpr int NTHR = 64 * NWV;
     static_assert(!ACC2 || (RB == 2 && !FAST && !BLOCKED && !LNM), "second accumulator: 128-row tiles only (registers)");
     static_assert(AMODE != 3 || (RB != 3 && !LNM), "in-LDS split of DMA'd f32 rows: 128- or 256-row tiles");
     static_assert(!LNM || (AMODE == 0 && (RB == 2 || RB == 3) && !BLOCKED && !TRACE), "LayerNorm epilogue: plain hr8 operand, 64- or 96-row tiles");
     constexpr int TNK = LNM ? 512 : TN;                       // output features per tile
-    constexpr int NWF = TNK / 64, NWR = 8 / NWF;              // waves side by side over the features / stacked over the rows
+    constexpr int NWF = TNK / 64, NWR = NWV / NWF;            // waves side by side over the features / stacked over the rows
     constexpr int TM = 32 * RB * NWR;
     constexpr int WB = TNK * ROWB;
     constexpr int A_BYTES = TM * ROWB, STAGE_BYTES = A_BYTES + WB;
-    constexpr int NST = (RB == 2 && !LNM) ? 3 : 2, D = NST - 1;   // LDS stages; slabs in flight beyond the one being read
+    constexpr int NST = ((RB == 2 && !LNM) || NWV == 4) ? 3 : 2, D = NST - 1;   // LDS stages (48 KB ones: three); slabs in flight beyond the one being read
     constexpr int NL = RB * NWR / 2;                          // mode 2: f32x4 loads per thread and slab
     constexpr int MAXSEG = 4;                                 // mode 1: K segments (gathered row tables) supported
     constexpr int IDX_OFF = NST * STAGE_BYTES;                // mode 1: behind the stages, a lane-private table of source rows (below)
     constexpr int LN_OFF = NST * STAGE_BYTES;                 // LNM: behind the stages, per row and wave the partial sums of the two LayerNorm passes
     constexpr int PTR_OFF = NST * STAGE_BYTES;                // mode 3: behind the stages, a lane-private table of row base addresses (u64)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES + (AMODE == 1 ? RB * MAXSEG * 2048 : 0) + (LNM ? 2 * TM * 8 * 4 : 0) +
-                                                                 (AMODE == 3 ? ((TM / 8 + 7) / 8) * 4096 : 0)];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE_BYTES + (AMODE == 1 ? ((TM / 8 + NWV - 1) / NWV) * MAXSEG * NTHR * 4 : 0) +
+                                                                 (LNM ? 2 * TM * 8 * 4 : 0) + (AMODE == 3 ? ((TM / 8 + 7) / 8) * 4096 : 0)];
     AS3 unsigned char* lds = (AS3 unsigned char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,8 +225,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     const int coff = ((lane & 7) ^ sw_src) << 4;
     const int l8 = lane >> 3;
     constexpr int NBLK_A = TM / 8;                                        // 8-row blocks of an A slab
-    constexpr int NA = (NBLK_A + 7) / 8;                                  // A pieces per wave and slab (row blocks w + 8 i; LNM with 96 rows: 12 blocks, waves 4..7 skip their second)
-    constexpr int NW = NWF;                                               // W pieces per wave and slab
+    constexpr int NA = (NBLK_A + NWV - 1) / NWV;                          // A pieces per wave and slab (row blocks w + NWV i; LNM with 96 rows: 12 blocks, waves 4..7 skip their second)
+    constexpr int NW = TNK / 8 / NWV;                                     // W pieces per wave and slab
     constexpr int NPCL = (AMODE == 2 ? 0 : NA) + NW;                      // DMA pieces per wave and slab
     // issue-side state (runs ahead of the compute side)
     int ij = 0, ikt = 0;
@@ -257,40 +263,40 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
             unsigned long long v[NA];
 #pragma unroll
             for (int q = 0; q < NA; ++q) {
-                const int row = min(m0 + (wave + 8 * q) * 8 + l8, p.M - 1);
+                const int row = min(m0 + (wave + NWV * q) * 8 + l8, p.M - 1);
                 v[q] = p.a_rowptr ? p.a_rowptr[row] : (unsigned long long)(p.A + (size_t)row * p.lda);
             }
 #pragma unroll
-            for (int q = 0; q < NA; ++q) *(AS3 unsigned long long*)(lds + PTR_OFF + (q * 512 + tid) * 8) = v[q];
+            for (int q = 0; q < NA; ++q) *(AS3 unsigned long long*)(lds + PTR_OFF + (q * NTHR + tid) * 8) = v[q];
         }
         if (AMODE == 1) {
             // one batch of table reads per tile (the wait in front of the ds_writes also waits for the slabs in flight)
             int v[NA * MAXSEG];
 #pragma unroll
             for (int q = 0; q < NA; ++q) {
-                const int32_t* ip = p.a_idx + (size_t)min(m0 + (wave + 8 * q) * 8 + l8, p.M - 1) * p.nseg;
+                const int32_t* ip = p.a_idx + (size_t)min(m0 + (wave + NWV * q) * 8 + l8, p.M - 1) * p.nseg;
 #pragma unroll
                 for (int sg = 0; sg < MAXSEG; ++sg) v[q * MAXSEG + sg] = ip[min(sg, p.nseg - 1)];
             }
 #pragma unroll
-            for (int q = 0; q < NA * MAXSEG; ++q) *(AS3 int*)(lds + IDX_OFF + (q * 512 + tid) * 4) = v[q];
+            for (int q = 0; q < NA * MAXSEG; ++q) *(AS3 int*)(lds + IDX_OFF + (q * NTHR + tid) * 4) = v[q];
         }
     };
     // (`so` = byte offset of an LDS stage, a wave-uniform runtime value)
     auto issue_w_piece = [&](int i, int so) {
-        const int blk = wave + 8 * i;
+        const int blk = wave + NWV * i;
         const unsigned vo = (unsigned)(min(blk * 8 + l8, w_lim) * (int)p.ldw + coff);
         const size_t kb = AMODE == 1 ? (size_t)isg * p.seg_bytes + (size_t)ichunk * ROWB : (size_t)ikt * ROWB;      // K offset of the slab in a W row
         __builtin_amdgcn_global_load_lds((const AS1 void*)(iw_base + kb + vo), (AS3 void*)(lds + so + A_BYTES + blk * 1024), 16, 0, 0);
     };
     auto issue_a_piece = [&](int i, int so) {
-        const int blk = wave + 8 * i;
-        if (NBLK_A % 8 != 0 && blk >= NBLK_A) return;
+        const int blk = wave + NWV * i;
+        if (NBLK_A % NWV != 0 && blk >= NBLK_A) return;
         if (AMODE == 3) {
-            const unsigned long long rb = *(const AS3 unsigned long long*)(lds + PTR_OFF + (i * 512 + tid) * 8);
+            const unsigned long long rb = *(const AS3 unsigned long long*)(lds + PTR_OFF + (i * NTHR + tid) * 8);
             __builtin_amdgcn_global_load_lds((const AS1 void*)((const unsigned char*)rb + (size_t)ikt * ROWB + coff), (AS3 void*)(lds + so + blk * 1024), 16, 0, 0);
         } else if (AMODE == 1) {
-            const int gi = *(const AS3 int*)(lds + IDX_OFF + ((i * MAXSEG + isg) * 512 + tid) * 4);
+            const int gi = *(const AS3 int*)(lds + IDX_OFF + ((i * MAXSEG + isg) * NTHR + tid) * 4);
             const unsigned char* src = (gi >= 0 ? p.A + (size_t)gi * p.lda : p.zero_row) + coff + ichunk * ROWB;    // index -1: a row of zeros
             __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(lds + so + blk * 1024), 16, 0, 0);
         } else {
@@ -355,11 +361,11 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     f32x4 cv[CVS];
     const int conv_base = lane * 16;
     auto conv_read = [&](int i, int so) {
-        const int blk = wave + 8 * i;
+        const int blk = wave + NWV * i;
         cv[i % CVS] = *(const AS3 f32x4*)(lds + so + blk * 1024 + conv_base);
     };
     auto conv_write = [&](int i, int so) {
-        const int blk = wave + 8 * i;
+        const int blk = wave + NWV * i;
         const f32x4 x = cv[i % CVS];
         unsigned h0, h1, r0, r1;
         split2(x[0] * ACT_SCALE, x[1] * ACT_SCALE, h0, r0);
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ps_kernel(const PsArgs p) {
     // tiles have no room for the second register set (70 / 163 spilled).  Over the 256 benchmark videos it is what brings EVERY video
     // within 1e-4 of a float64 evaluation (max 7.8e-5; one accumulator: 1.65e-4, second accumulator for the correction terms: 1.78e-4;
     // benchmarks/accuracy_sweep.py, profiles/r05a_accuracy_sweep_policies.jsonl).
-    static_assert(!BLOCKED || (RB == 2 && !FAST && !LNM && !ACC2), "blocked accumulation: 128-row tiles only");
+    static_assert(!BLOCKED || ((RB == 2 || NWV == 4) && !FAST && !LNM && !ACC2), "blocked accumulation: 128-row tiles only");
     f32x16 tot[2][BLOCKED ? RB : 1];
     f32x16 acc2[2][ACC2 ? RB : 1];
     auto zero_acc = [&]() {
@@ -1052,6 +1058,9 @@ int bigc_gemm_ps_launch(hipStream_t s, const PsGemm& g) {
         else { if (rb == 4) PS_LAUNCH_FAST(0, 4); else if (rb == 3) PS_LAUNCH_FAST(0, 3); else PS_LAUNCH_FAST(0, 2); }
 #undef PS_LAUNCH_FAST
     } else if (p.blk > 0) {
+        // (the four-wave form -- gemm_ps_kernel<MODE, 4, false, false, true, false, false, 4>, 256 threads, same tile, same results -- was built and
+        // measured: correct, and SLOWER than two waves per SIMD on every shape: conv GEMM 5.15 vs 4.68 ms, K = 512 at M = 579 295 1.25 vs 1.22 ms,
+        // decoder 512 x 512 110 vs 101 us.  With one wave per SIMD nothing covers the wave's own waits; not instantiated.)
         if (mode3) hipLaunchKernelGGL((gemm_ps_kernel<3, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
         else if (g.a_idx) hipLaunchKernelGGL((gemm_ps_kernel<1, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_ps_kernel<0, 2, false, false, true>), dim3(grid), dim3(512), 0, s, p);

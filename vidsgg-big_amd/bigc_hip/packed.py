@@ -122,10 +122,12 @@ class PackedBatch(object):
 
         # per-video metadata: gathered on the device when the containers hold what the reference's do (int64 / f32 / int64)
         def meta_usable(p, t):
-            # keyed on the tensors' ADDRESSES (id() of a freed tensor object can come back for a new one: ADVICE r04)
-            key = (p.cat_ids.data_ptr(), p.scores.data_ptr(), p.traj_durations.data_ptr(), p.cat_ids.device, p.cat_ids.dtype, p.scores.dtype)
-            if t.get("meta_key") != key:                        # checked once per set of tensors
-                t["meta_key"] = key
+            # the cache holds REFERENCES to the three (small) metadata tensors and compares identities: id() alone could come back for a new
+            # object after the old one was freed; three data_ptr() calls per video cost 0.15 ms per 256-video call
+            a, b_, c_ = p.cat_ids, p.scores, p.traj_durations
+            key = t.get("meta_key")
+            if key is None or key[0] is not a or key[1] is not b_ or key[2] is not c_:          # checked once per set of tensors
+                t["meta_key"] = (a, b_, c_)
                 t["meta_ok"] = bool(p.cat_ids.dtype == torch.int64 and p.scores.dtype == torch.float32 and p.traj_durations.dtype == torch.int64
                                     and p.cat_ids.device == device and p.scores.device == device and p.traj_durations.device == device
                                     and p.cat_ids.is_contiguous() and p.scores.is_contiguous() and p.traj_durations.is_contiguous())

@@ -623,9 +623,22 @@ int dwsep(void* s, const float* x, const DW& c, float* dw, float* out, int ldo, 
 
 // QANetEncoderLayer.forward, eval mode (models/grd_model_v5.py:110-137). x (rows, d) -> out (same shape).
 // Uses w.b0..b3, w.qkv, w.att, w.off; `out` may be one of the caller's buffers but not b0..b3.
-int qanet(void* s, const Enc& E, const float* x, const float* pos, const Seqs& q, int d, const GWork& w, float* out) {
+int qanet(void* s, grd_model* m, int which, const Enc& E, const float* x, const float* pos, const Seqs& q, int d, const GWork& w, float* out) {
     const int rows = (int)q.rows;
     float *res = w.b0, *ln = w.b1, *dw = w.b2, *nxt = w.b3;
+    if (grd_enc_chain_supported(d, E.ks)) {
+        // the convolution stack in one launch and the two GEMMs behind the attention in another (csrc/grounding_encoder.hip)
+        if (!m->enc_frag[which] && hipMalloc(&m->enc_frag[which], grd_enc_frag_bytes()) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_forward: hipMalloc failed");
+        const bool refresh = m->enc_frag_epoch[which] != m->epoch;
+        GTRY(grd_enc_chain((hipStream_t)s, E, x, pos, q.rows, q.T, q.info, m->enc_frag[which], refresh, res, ln));
+        m->enc_frag_epoch[which] = m->epoch;
+        GTRY(glinear(s, ln, d, E.in_proj, w.qkv, 3 * d, rows, 3 * d, d, BIGC_ACT_NONE));
+        const int32_t* off = q.off;
+        if (!q.info) { GTRY(bigc_fill_offsets((hipStream_t)s, w.off, q.n_seq + 1, q.T)); off = w.off; }
+        bigc_prof_hint(4.0 * (double)rows * ((double)rows / q.n_seq) * d, 16.0 * rows * (double)d);
+        GTRY(bigc_mha_core_f32(s, w.qkv, 3 * d, w.qkv + d, 3 * d, w.qkv + 2 * d, 3 * d, w.att, d, off, off, q.n_seq, q.max_T, 8, d / 8, nullptr));
+        return grd_attn_tail((hipStream_t)s, E, w.att, res, q.rows, m->enc_frag[which], out);
+    }
     if (!q.info) {
         GTRY(bigc_add_rows_f32(s, x, pos, res, rows, d, q.T));                 // out = x + pos ; res = out
     } else {
@@ -723,8 +736,8 @@ int forward_impl(grd_model* m, void* stream, const float* video_feat, int T, con
     // a13: the two encoders, co-attention, fusion, combined encoder, three heads (:341-372)
     float* venc = out->video_enc ? out->video_enc : w.venc;
     float* qenc = out->query_enc ? out->query_enc : w.qenc;
-    GTRY(qanet(s, m->video_enc, vemb, pos_video, sv, d, w, venc));
-    GTRY(qanet(s, m->query_enc, qemb, pos_query, sq, d, w, qenc));
+    GTRY(qanet(s, m, 0, m->video_enc, vemb, pos_video, sv, d, w, venc));
+    GTRY(qanet(s, m, 1, m->query_enc, qemb, pos_query, sq, d, w, qenc));
     GTRY(glinear(s, venc, d, m->proj2sim, w.proj, d, (int)total_T, d, d, BIGC_ACT_NONE));
     if (!b) {
         GTRY(grd_coattention_f32(s, venc, w.proj, qenc, w.comb, n, T, d));
@@ -740,7 +753,7 @@ int forward_impl(grd_model* m, void* stream, const float* video_feat, int T, con
     float* cenc = out->combined_enc ? out->combined_enc : w.comb;     // comb (rows*4d) is free again
     // qanet reads its input into b0 first, and w.att is only rewritten by the attention step, after
     // the input has been consumed
-    GTRY(qanet(s, m->comb_enc, cin, pos_video, sc, d, w, cenc));
+    GTRY(qanet(s, m, 2, m->comb_enc, cin, pos_video, sc, d, w, cenc));
     float* regrs = out->regrs ? out->regrs : w.regrs;
     float* conf = out->conf ? out->conf : w.conf;
     float* cls = out->cls ? out->cls : w.cls;
@@ -795,6 +808,7 @@ extern "C" void grd_destroy(grd_model* m) {
     if (m->wq) (void)hipFree(m->wq);
     if (m->bq) (void)hipFree(m->bq);
     if (m->head_frag) (void)hipFree(m->head_frag);
+    for (int i = 0; i < 3; ++i) if (m->enc_frag[i]) (void)hipFree(m->enc_frag[i]);
     delete m;
 }
 

@@ -22,6 +22,7 @@ struct grd_model {
     float* bq = nullptr;   // (d) owned: query_fc.bias + temp_fc.bias
     int kq = 0;
     void* head_frag = nullptr; unsigned long long head_frag_epoch = 0;   // the heads' point-wise weights in MFMA fragment order (grounding_heads.hip), owned
+    void* enc_frag[3] = {nullptr, nullptr, nullptr}; unsigned long long enc_frag_epoch[3] = {0, 0, 0};   // per encoder (video, query, combined): its six 128 x 128 weights in fragment order (grounding_encoder.hip), owned
     std::vector<SplitJob> train_jobs;  // as bigc_model::train_jobs
 };
 
@@ -30,3 +31,10 @@ bool grd_head_chain_supported(int d, const Head& a, const Head& b, const Head& c
 size_t grd_head_frag_bytes();
 int grd_head_chain(hipStream_t s, const float* x, long rows, int T, const int2* info, const Head* const heads[3], float* const outs[3], const int acts[3],
                    void* frag, bool refresh);
+
+// csrc/grounding_encoder.hip: a QANet encoder layer around its attention core in two launches, the convolution stack's intermediates in LDS
+bool grd_enc_chain_supported(int d, int ks);
+size_t grd_enc_frag_bytes();
+int grd_enc_chain(hipStream_t s, const Enc& E, const float* x, const float* pos, long rows, int T, const int2* info, void* frag, bool refresh,
+                  float* out, float* ln_out);
+int grd_attn_tail(hipStream_t s, const Enc& E, const float* att, const float* res, long rows, void* frag, float* out);

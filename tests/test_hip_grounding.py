@@ -276,3 +276,61 @@ def test_head_chain_out_of_range_operands_fall_back_to_f32():
             ok = ~torch.isnan(w)
             scale = float(w[ok].abs().max()) if ok.any() else 1.0
             assert float((g[ok] - w[ok]).abs().max()) <= 2e-4 * max(scale, 1e-6), (case, key, float((g[ok] - w[ok]).abs().max()), scale)
+
+
+def test_encoder_chain_out_of_range_operands_fall_back_to_f32():
+    """The LDS-resident QANet encoder kernels (csrc/grounding_encoder.hip: convolution stack and the two GEMMs behind the attention) split
+    their GEMM operands into f16 pairs as the head chain does: an operand outside that form (|x| >= 32768, NaN) must raise the flag that
+    makes the f32 instantiation launched behind them redo the launch.  (a) a depth-wise weight that makes the point-wise operand huge,
+    (b) a point-wise weight beyond the range, (c) attention values that make the operand of out_proj huge: the encoders' outputs equal
+    those of the exact-mode forward (layer by layer in f32, models/grd_model_v5.py:110-137 arithmetic); (d) a NaN weight poisons its
+    output feature in every row, as relu(NaN) + res does in torch."""
+    cfg = dict(cases.GRD_CASES["grd_g_n64"]["cfg"])
+    _, sd0, _ = cases.make_grd_case("grd_g_n64")
+    feat, (quint, dura, vl) = cases.make_grd_inputs(cfg, dict(seed=33, T=70, n=9, video_len=557))
+    d = cfg["dim_hidden"]
+    for case in ("huge_depth_wise", "huge_weight", "huge_attention", "nan_weight", "in_range"):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        if case == "huge_depth_wise":
+            sd["combined_encoder.convs.1.depth_wise.weight"] *= 1e6
+            sd["combined_encoder.convs.1.point_wise.weight"] *= 1e-6
+        elif case == "huge_weight":
+            sd["video_encoder.convs.2.point_wise.weight"][5, 7] = 5e4
+        elif case == "huge_attention":
+            sd["combined_encoder.mh_attn.in_proj_weight"][2 * d:] *= 1e6
+            sd["combined_encoder.mh_attn.out_proj.weight"] *= 1e-6
+        elif case == "nan_weight":
+            sd["video_encoder.fc.weight"][3, 3] = float("nan")
+        model = build_model(dict(cfg, loss_factor=dict(classification=1.0, centerness=1.0, regression=1.0)), sd)
+        got = model.forward_raw(feat.to(DEV), quint, dura, vl, keep_intermediates=True, **cases.GRD_TH)
+        if case == "nan_weight":
+            assert torch.isnan(got["video_enc"][:, 3]).all() and not torch.isnan(got["query_enc"]).any()
+            continue
+        eng = model.engine()
+        eng.set_mode(1, -1)
+        try:
+            want = model.forward_raw(feat.to(DEV), quint, dura, vl, keep_intermediates=True, **cases.GRD_TH)
+        finally:
+            eng.set_mode(-1, -1)
+        for key in ("video_enc", "query_enc", "combined_enc", "regrs", "conf", "cls"):
+            g, w = got[key].cpu(), want[key].cpu()
+            assert not torch.isnan(g).any() and not torch.isnan(w).any(), (case, key)
+            assert float((g - w).abs().max()) <= 2e-4 * max(float(w.abs().max()), 1e-6), (case, key, float((g - w).abs().max()), float(w.abs().max()))
+
+
+def test_encoder_chain_rows_do_not_depend_on_their_tile():
+    """A row's result must not depend on where its sequence lies in the launch (tiles of the LDS-resident encoder kernels are cut from
+    the row-major activation of ALL sequences): the same video scored alone, as first and as last of a batch -> identical bits."""
+    cfg = dict(cases.GRD_CASES["grd_g_n64"]["cfg"])
+    _, sd, _ = cases.make_grd_case("grd_g_n64")
+    model = build_model(dict(cfg, loss_factor=dict(classification=1.0, centerness=1.0, regression=1.0)), sd)
+    jobs = []
+    for v, (T, n) in enumerate([(61, 7), (38, 11), (97, 3)]):
+        feat, (quint, dura, vl) = cases.make_grd_inputs(cfg, dict(seed=700 + v, T=T, n=n, video_len=8 * T - 3))
+        jobs.append((feat.to(DEV), quint, dura, vl))
+    alone = model.forward_raw(*jobs[0], keep_intermediates=True, **cases.GRD_TH)
+    for order in ([0, 1, 2], [2, 1, 0], [1, 0, 2]):
+        outs = model.forward_raw_batch([jobs[i] for i in order], **cases.GRD_TH)
+        o = outs[order.index(0)]
+        for key in ("pooled_se", "bins_probs", "bins_mask"):
+            assert torch.equal(o[key], alone[key]), (order, key)

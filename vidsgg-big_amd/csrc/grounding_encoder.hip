@@ -37,6 +37,7 @@ constexpr long EC_FRAG_ELEMS = (long)EC_LAYERS * 4 * 8 * 2 * 64;            // a
 struct EncChainArgs {
     const float* x; const float* pos; const float* res; long rows; int T; const int2* info;
     const a16x8* frag; const int* frag_bad; int* act_bad;
+    const float* dwt; int ks;                             // depth-wise weights as (layer, tap (8), channel): prepared with the fragments
     const float* ln_g[6]; const float* ln_b[6];           // [0..3] in front of convolution i, [4] in front of the attention, [5] in front of fc
     const float* dw_w[4]; const float* dw_b[4];
     const float* pw_w[EC_LAYERS]; const float* pw_b[EC_LAYERS];
@@ -63,6 +64,15 @@ __device__ __forceinline__ void ec_store_split(const f32x4 v, unsigned char* Ah,
 __global__ __launch_bounds__(64) void grd_enc_prep_kernel(const EncChainArgs a, a16x8* frag, int* frag_bad) {
     const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
     const int s = blockIdx.x & 7, wave = (blockIdx.x >> 3) & 3, layer = blockIdx.x >> 5;
+    if (layer >= EC_LAYERS) {                   // four more workgroups: the depth-wise weights (channel, tap) -> (tap, channel), a 16-byte load per tap and lane
+        const int dl = blockIdx.x - EC_LAYERS * 32;
+        float* dwt = (float*)a.dwt + (size_t)dl * 8 * EC_D;
+        for (int i = lane; i < 8 * EC_D; i += 64) {
+            const int j = i / EC_D, c = i - j * EC_D;
+            dwt[i] = j < a.ks ? a.dw_w[dl][(size_t)c * a.ks + j] : 0.f;
+        }
+        return;
+    }
     const int n = wave * 32 + l31;
     float x8[8];
     bool bad = false;
@@ -221,17 +231,15 @@ __global__ __launch_bounds__(256, 2) void grd_enc_chain_kernel(const EncChainArg
     bool bad = false;
 #pragma unroll 1
     for (int layer = 0; layer < 4; ++layer) {
+        f32x4 wt[KS];                                        // (requested ahead of the statistics: in flight across them and the barrier)
+#pragma unroll
+        for (int j = 0; j < KS; ++j) wt[j] = *(const f32x4*)(a.dwt + ((size_t)layer * 8 + j) * EC_D + 4 * cq);
+        const f32x4 bb = *(const f32x4*)(a.dw_b[layer] + 4 * cq);
+        const f32x4 gg = *(const f32x4*)(a.ln_g[layer] + 4 * cq), be = *(const f32x4*)(a.ln_b[layer] + 4 * cq);
         ec_stats(S, tid, a.eps);
         __syncthreads();
         // ---- LayerNorm -> depth-wise k taps along the rows of a sequence, zero padded -> the point-wise GEMM's operand
         {
-            float wt[4][KS];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int j = 0; j < KS; ++j) wt[c][j] = a.dw_w[layer][(size_t)(4 * cq + c) * KS + j];
-            const f32x4 bb = *(const f32x4*)(a.dw_b[layer] + 4 * cq);
-            const f32x4 gg = *(const f32x4*)(a.ln_g[layer] + 4 * cq), be = *(const f32x4*)(a.ln_b[layer] + 4 * cq);
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             auto ln_row = [&](int r) {
                 if (r < 0 || r >= EC_CR) return zero;            // (only the rim rows see these)
@@ -258,14 +266,14 @@ __global__ __launch_bounds__(256, 2) void grd_enc_chain_kernel(const EncChainArg
 #pragma unroll
                     for (int j = 0; j < KS; ++j)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[c] = fmaf(wt[c][j], win[j][c], acc[c]);
+                        for (int c = 0; c < 4; ++c) acc[c] = fmaf(wt[j][c], win[j][c], acc[c]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < KS; ++j) {
                         const int tt = ri.x + j - H;
                         const bool in = tt >= 0 && tt < ri.y;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[c] = in ? fmaf(wt[c][j], win[j][c], acc[c]) : acc[c];
+                        for (int c = 0; c < 4; ++c) acc[c] = in ? fmaf(wt[j][c], win[j][c], acc[c]) : acc[c];
                     }
                 }
                 if (ri.y == 0) acc = zero;
@@ -377,7 +385,7 @@ bool grd_enc_chain_supported(int d, int ks) {
     return !off && d == EC_D && (ks == 3 || ks == 7) && !bigc_linear_get_exact() && !bigc_linear_get_fast();
 }
 
-size_t grd_enc_frag_bytes() { return (size_t)EC_FRAG_ELEMS * sizeof(a16x8) + 256; }      // + the flag words behind the fragments
+size_t grd_enc_frag_bytes() { return (size_t)EC_FRAG_ELEMS * sizeof(a16x8) + 256 + sizeof(float) * 4 * 8 * EC_D; }      // + the flag words + the depth-wise weights by tap
 
 namespace {
 void enc_args(const Enc& E, long rows, int T, const int2* info, void* frag, EncChainArgs& a) {
@@ -385,6 +393,7 @@ void enc_args(const Enc& E, long rows, int T, const int2* info, void* frag, EncC
     int* flags = (int*)((char*)frag + (size_t)EC_FRAG_ELEMS * sizeof(a16x8));
     a.frag_bad = flags;
     a.act_bad = flags + 1;
+    a.dwt = (const float*)((char*)flags + 256); a.ks = E.ks;
     const Lin* ln[6] = {&E.normb, &E.norm_seq[0], &E.norm_seq[1], &E.norm_seq[2], &E.norm_seq[3], &E.norme};
     for (int i = 0; i < 6; ++i) { a.ln_g[i] = ln[i]->w; a.ln_b[i] = ln[i]->b; }
     for (int i = 0; i < 4; ++i) {
@@ -406,7 +415,7 @@ int grd_enc_chain(hipStream_t s, const Enc& E, const float* x, const float* pos,
     if (hipMemsetAsync(a.act_bad, 0, sizeof(int), s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_enc_chain: memset failed");
     if (refresh) {
         if (hipMemsetAsync((void*)a.frag_bad, 0, sizeof(int), s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_enc_chain: memset failed");
-        hipLaunchKernelGGL(grd_enc_prep_kernel, dim3(EC_LAYERS * 4 * 8), dim3(64), 0, s, a, (a16x8*)frag, (int*)a.frag_bad);
+        hipLaunchKernelGGL(grd_enc_prep_kernel, dim3(EC_LAYERS * 32 + 4), dim3(64), 0, s, a, (a16x8*)frag, (int*)a.frag_bad);
         BIGC_LAUNCH_CHECK("grd_enc_prep");
     }
     const int tr = EC_CR - 8 * (E.ks / 2);

@@ -114,18 +114,21 @@ __global__ __launch_bounds__(256, 2) void grd_head_chain_kernel(const HeadChainA
     };
     a16x8 wcur[16];
     load_w(0, wcur);
+    // depth-wise taps and bias of the current layer (channels 4 cq .. + 3); those of the next layer are requested while this layer's MFMAs run
+    f32x4 w0, w1, w2, bb;
+    auto load_dw = [&](int layer) {
+        const float* dw = H.dw_w[layer] + (size_t)4 * cq * 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { w0[c] = dw[3 * c]; w1[c] = dw[3 * c + 1]; w2[c] = dw[3 * c + 2]; }
+        bb = *(const f32x4*)(H.dw_b[layer] + 4 * cq);
+    };
+    load_dw(0);
 #pragma unroll
     for (int layer = 0; layer < 5; ++layer) {
         const int n_out = layer < 4 ? HD_D : H.c_out;
         const bool mm_wave = wave * 32 < n_out;             // the last layer's few features: the first wave(s) only
-        a16x8 wnext[16];
         // ---- depth-wise k = 3 along the rows of a sequence, zero padded (models/grd_model_v5.py:44), then split into the two planes
         {
-            const float* dw = H.dw_w[layer] + (size_t)4 * cq * 3;
-            f32x4 w0, w1, w2;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { w0[c] = dw[3 * c]; w1[c] = dw[3 * c + 1]; w2[c] = dw[3 * c + 2]; }
-            const f32x4 bb = *(const f32x4*)(H.dw_b[layer] + 4 * cq);
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             f32x4 xm = rg > 0 ? *(const f32x4*)(X + (8 * rg - 1) * HD_XP + 4 * cq) : zero;
             f32x4 x0 = *(const f32x4*)(X + (8 * rg) * HD_XP + 4 * cq);
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void grd_head_chain_kernel(const HeadChainA
             }
         }
         __syncthreads();
-        if (layer < 4) load_w(layer + 1, wnext);
+        if (layer < 4) load_dw(layer + 1);
         // ---- point-wise: out[row][n] = sum_k act[row][k] W[n][k] + b[n]; weights = MFMA A operand, activations = B operand
         if (mm_wave) {
             // both 32-row blocks in one sweep over k: four independent accumulator chains keep the matrix pipe fed
@@ -169,32 +172,43 @@ __global__ __launch_bounds__(256, 2) void grd_head_chain_kernel(const HeadChainA
                     acc1[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[2 * s + 1], bh, acc1[rb], 0, 0, 0);
                 }
             }
-            float bias[16];
+            // the next layer's slice into the same registers, right behind the MFMAs: it lands while the epilogue and the next depth-wise stage run
+            if (layer < 4) load_w(layer + 1, wcur);
+            if (layer < 4) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bias[r] = H.pw_b[layer][min(wave * 32 + mfma_row(r, hi), n_out - 1)];
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int nn0 = wave * 32 + 8 * r4 + 4 * hi;
+                    const f32x4 bias = *(const f32x4*)(H.pw_b[layer] + nn0);
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const int row = rb * 32 + l31;
-                const long g = g0 + row;
+                    for (int rb = 0; rb < 2; ++rb) {
+                        f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int nn = wave * 32 + mfma_row(r, hi);
-                    if (nn >= n_out) continue;
-                    float v = (acc0[rb][r] + acc1[rb][r] * HD_RI) + bias[r];
-                    if (layer < 4) {
-                        X[row * HD_XP + nn] = fmaxf(v, 0.f);
-                    } else if (row >= HD_HALO && row < HD_CR - HD_HALO && g >= 0 && g < a.rows) {
-                        if (H.act == BIGC_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-                        H.out[g * H.c_out + nn] = v;
+                        for (int c = 0; c < 4; ++c) v[c] = fmaxf((acc0[rb][4 * r4 + c] + acc1[rb][4 * r4 + c] * HD_RI) + bias[c], 0.f);
+                        *(f32x4*)(X + (rb * 32 + l31) * HD_XP + nn0) = v;
+                    }
+                }
+            } else {
+                float bias[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bias[r] = H.pw_b[layer][min(wave * 32 + mfma_row(r, hi), n_out - 1)];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const int row = rb * 32 + l31;
+                    const long g = g0 + row;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int nn = wave * 32 + mfma_row(r, hi);
+                        if (nn >= n_out) continue;
+                        float v = (acc0[rb][r] + acc1[rb][r] * HD_RI) + bias[r];
+                        if (row >= HD_HALO && row < HD_CR - HD_HALO && g >= 0 && g < a.rows) {
+                            if (H.act == BIGC_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                            H.out[g * H.c_out + nn] = v;
+                        }
                     }
                 }
             }
         }
         __syncthreads();
-        if (layer < 4) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) wcur[i] = wnext[i];
-        }
     }
 
     if (bad) atomicOr(a.act_bad, 1);          // -> grd_head_exact_kernel, launched right behind, redoes the launch in plain f32

@@ -331,6 +331,12 @@ int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int ldp, const f
  *   2: dp2a = ds @ e2a; 3: de2a = ds^T @ p2a. d = dim_enti, half = dim_att/2. */
 int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1, const float* enco_or_e2a,
                              int ld2, float* out, int ldo, const int32_t* e_off, int n_vid, int nq, int d, int half, int max_trk);
+/* two of those products in ONE launch (they are independent and each fills a fraction of the chip at training batch sizes):
+ *   pair 0: datt = dvals @ enco^T -> out_a and denco += att^T @ dvals -> out_b (x = att, y = dvals, z = enco; ld_y == ld_z);
+ *   pair 1: dp2a = ds @ e2a -> out_a and de2a = ds^T @ p2a -> out_b (x = ds, y = p2a, z = e2a); ldo_b: leading dimension of out_b (and of
+ *   out_a in pair 1).  Same arithmetic as the single calls, bit for bit. */
+int bigc_role_small_gemm_pair_f32(void* stream, int pair, const float* x, const float* y, int ld_y, const float* z, int ld_z, float* out_a,
+                                  float* out_b, int ldo_b, const int32_t* e_off, int n_vid, int nq, int d, int half, int max_trk);
 /* vIoU of every (proposal, GT trajectory) pair (vIoU_ts utils/utils_func.py:437-471 as used by enti_viou_align,
  *   models/model_0v10.py:569-581): out (B, max_trk, g_max), 0 where the closed durations do not overlap or the pair
  *   does not exist. GT trajectories are packed like the proposals: gt_boxes (sum frames, 4), gt_row_off (G+1),

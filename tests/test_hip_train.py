@@ -217,6 +217,18 @@ def test_role_attention_backward_chain(nq, half, d, ns):
     assert rel(genco, enco.grad) < 2e-5
     assert rel(gp, p2a.grad) < 5e-5
     assert rel(ge, e2a.grad) < 5e-5
+    # the paired launches the training step uses (two products per launch): the same bits as the single calls
+    gatt2 = torch.full((2 * nq * NT,), float("nan"), device=DEV)
+    genco2 = torch.zeros(NT, d, device=DEV)
+    _lib.check(lib.bigc_role_small_gemm_pair_f32(S(), 0, att.data_ptr(), gvd.data_ptr(), d, xd.data_ptr(), d, gatt2.data_ptr(), genco2.data_ptr(), d,
+                                                 offd.data_ptr(), B, nq, d, half, mt))
+    _lib.check(lib.bigc_axpy_f32(S(), gatt2.data_ptr(), extra.data_ptr(), gatt2.numel()))
+    gp2 = torch.full((B * nq, 2 * half), float("nan"), device=DEV)
+    ge2 = torch.full((NT, 2 * half), float("nan"), device=DEV)
+    _lib.check(lib.bigc_role_small_gemm_pair_f32(S(), 1, ds.data_ptr(), pd.data_ptr(), 2 * half, ed.data_ptr(), 2 * half, gp2.data_ptr(), ge2.data_ptr(),
+                                                 2 * half, offd.data_ptr(), B, nq, d, half, mt))
+    torch.cuda.synchronize()
+    assert torch.equal(gatt2, gatt) and torch.equal(genco2, genco) and torch.equal(gp2, gp) and torch.equal(ge2, ge)
 
 
 def test_pool_conv_gather_periodic_transpose_relu():

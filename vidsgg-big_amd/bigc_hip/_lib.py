@@ -152,6 +152,8 @@ _SIGS = {
                                             c_int, c_float]),
     "bigc_role_small_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                          c_int, c_int, c_int, c_int, c_int]),
+    "bigc_role_small_gemm_pair_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                              c_int, c_int, c_int, c_int, c_int]),
     "bigc_viou_matrix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_void_p]),
     "bigc_viou_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

@@ -340,7 +340,10 @@ struct SmallGemmArgs {
     float* out; int ldo; const int32_t* e_off; int max_rows; int n_cc;
 };
 
-__global__ __launch_bounds__(256) void small_gemm_kernel(const SmallGemmArgs p) {
+// Two of the four products in one launch (blockIdx.y selects): DATT with DENCO and DP2A with DE2A are independent of each other and each
+// fills a fraction of the chip at training batch sizes (8 videos: a few hundred workgroups of dependent loads and MFMAs).
+__global__ __launch_bounds__(256) void small_gemm_kernel(const SmallGemmArgs p0, const SmallGemmArgs p1) {
+    const SmallGemmArgs& p = blockIdx.y ? p1 : p0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     // problem enumeration: (video, role) for DATT/DP2A/DE2A, (video) for DENCO (roles are summed inside)
@@ -561,17 +564,12 @@ extern "C" int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int l
     return BIGC_OK;
 }
 
-// mode 0: datt = dvals @ enco^T; 1: denco += att^T @ dvals; 2: dp2a = ds @ e2a; 3: de2a = ds^T @ p2a
-extern "C" int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1,
-                                        const float* enco_or_e2a, int ld2, float* out, int ldo, const int32_t* e_off, int n_vid, int nq,
-                                        int d, int half, int max_trk) {
-    BIGC_CHECK_ARG(mode >= 0 && mode <= 3 && out && e_off, "role_small_gemm: bad argument");
-    if (n_vid <= 0) return BIGC_OK;
-    SmallGemmArgs p;
+namespace {
+long small_gemm_args(SmallGemmArgs& p, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1, const float* enco_or_e2a, int ld2,
+                     float* out, int ldo, const int32_t* e_off, int n_vid, int nq, int d, int half, int max_trk) {
     p.mode = mode; p.n_vid = n_vid; p.nq = nq; p.d = d; p.half = half;
     p.att = att_or_ds; p.ds = att_or_ds; p.dvals = dvals_or_p2a; p.p2a = dvals_or_p2a; p.ldp = ld1;
     p.enco = enco_or_e2a; p.e2a = enco_or_e2a; p.lde = (mode <= 1) ? ld2 : 0; p.lda = ld2;
-    if (mode <= 1) p.lde = ld2;
     p.out = out; p.ldo = ldo; p.e_off = e_off;
     int rows, cols, n_role;
     if (mode == SG_DATT) { rows = nq; cols = max_trk; n_role = 2; }
@@ -580,9 +578,43 @@ extern "C" int bigc_role_small_gemm_f32(void* stream, int mode, const float* att
     else { rows = max_trk; cols = half; n_role = 2; }
     p.max_rows = rows;
     p.n_cc = cdiv(cols, 128);
-    const long items = (long)n_vid * n_role * cdiv(rows, 32) * p.n_cc;
+    return (long)n_vid * n_role * cdiv(rows, 32) * p.n_cc;
+}
+}  // namespace
+
+// mode 0: datt = dvals @ enco^T; 1: denco += att^T @ dvals; 2: dp2a = ds @ e2a; 3: de2a = ds^T @ p2a
+extern "C" int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1,
+                                        const float* enco_or_e2a, int ld2, float* out, int ldo, const int32_t* e_off, int n_vid, int nq,
+                                        int d, int half, int max_trk) {
+    BIGC_CHECK_ARG(mode >= 0 && mode <= 3 && out && e_off, "role_small_gemm: bad argument");
+    if (n_vid <= 0) return BIGC_OK;
+    SmallGemmArgs p;
+    const long items = small_gemm_args(p, mode, att_or_ds, dvals_or_p2a, ld1, enco_or_e2a, ld2, out, ldo, e_off, n_vid, nq, d, half, max_trk);
     ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((int)items), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((int)items, 1), dim3(256), 0, (hipStream_t)stream, p, p);
     BIGC_LAUNCH_CHECK("role_small_gemm");
+    return BIGC_OK;
+}
+
+// Two of them in one launch: pair 0 = (datt = dvals @ enco^T -> out_a (ld unused), denco += att^T @ dvals -> out_b (ldo_b));
+// pair 1 = (dp2a = ds @ e2a -> out_a, de2a = ds^T @ p2a -> out_b), both with leading dimension ldo_b.  x = att (pair 0) / ds (pair 1),
+// y = dvals (ld_y) / p2a (ld_y), z = enco (ld_z) / e2a (ld_z).
+extern "C" int bigc_role_small_gemm_pair_f32(void* stream, int pair, const float* x, const float* y, int ld_y, const float* z, int ld_z,
+                                             float* out_a, float* out_b, int ldo_b, const int32_t* e_off, int n_vid, int nq, int d, int half,
+                                             int max_trk) {
+    BIGC_CHECK_ARG((pair == 0 || pair == 1) && out_a && out_b && e_off, "role_small_gemm_pair: bad argument");
+    if (n_vid <= 0) return BIGC_OK;
+    SmallGemmArgs p0, p1;
+    long i0, i1;
+    if (pair == 0) {
+        i0 = small_gemm_args(p0, SG_DATT, nullptr, y, ld_y, z, ld_z, out_a, 0, e_off, n_vid, nq, d, half, max_trk);
+        i1 = small_gemm_args(p1, SG_DENCO, x, y, ld_y, nullptr, ld_z, out_b, ldo_b, e_off, n_vid, nq, d, half, max_trk);
+    } else {
+        i0 = small_gemm_args(p0, SG_DP2A, x, nullptr, 0, z, ld_z, out_a, ldo_b, e_off, n_vid, nq, d, half, max_trk);
+        i1 = small_gemm_args(p1, SG_DE2A, x, y, ld_y, nullptr, 0, out_b, ldo_b, e_off, n_vid, nq, d, half, max_trk);
+    }
+    ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((int)(i0 > i1 ? i0 : i1), 2), dim3(256), 0, (hipStream_t)stream, p0, p1);
+    BIGC_LAUNCH_CHECK("role_small_gemm_pair");
     return BIGC_OK;
 }

@@ -849,6 +849,9 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
     const int wn = p.dw_w ? 2 : (force_wn ? (force_wn == 4 ? 4 : 2) : ((p.N > 192 && (rem == 0 || rem > 128) && !few) ? 4 : 2));
     p.tiles_n = cdiv(p.N, 64 * wn);
     const int grid2 = cdiv(p.tiles_m, 8) * 8 * p.tiles_n;
+    // (The partial tiles are summed by a second launch.  Summing them in the kernel -- last workgroup to arrive at a tile, the scheme of
+    // dw_finish_tile -- was built and measured: 14.4 instead of 9.4 ms per training step, the device-scope release every workgroup then
+    // needs writes back its L2.)
     // split-K for small grids (inside a SplitKScope only: the training step; see linear_internal.h): enough splits to give every CU a
     // workgroup, each at least four slabs long, at most eight; partial tiles go to a stream-ordered scratch (one per thread and device)
     p.splits = 1; p.part = nullptr;

@@ -40,6 +40,8 @@ extern "C" int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int l
 extern "C" int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1,
                                         const float* enco_or_e2a, int ld2, float* out, int ldo, const int32_t* e_off, int n_vid, int nq,
                                         int d, int half, int max_trk);
+extern "C" int bigc_role_small_gemm_pair_f32(void* stream, int pair, const float* x, const float* y, int ld_y, const float* z, int ld_z, float* out_a,
+                                             float* out_b, int ldo_b, const int32_t* e_off, int n_vid, int nq, int d, int half, int max_trk);
 
 extern "C" int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                       float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
@@ -561,12 +563,11 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
         TRY(bw.lin(p + ".fc_rolewise.0.0", L.role0[0], C0, dp, S.vals, de, BQ, dp, de, w.gvals, de, false));
         // B2 stays = d q2 (residual path); values = att @ enco
         const float* enco = w.enc[c.n_enco_layers - 1].out;
-        TRY(bigc_role_small_gemm_f32(s, 0, nullptr, w.gvals, de, enco, de, w.gatt, 0, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
+        // d att = d vals @ enco^T and d enco += att^T @ d vals in one launch, then d p2a = ds @ e2a and d e2a = ds^T @ p2a in another
+        TRY(bigc_role_small_gemm_pair_f32(s, 0, S.att, w.gvals, de, enco, de, w.gatt, w.genco, de, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
         if (i == c.n_deco_layers - 1) TRY(bigc_axpy_f32(s, w.gatt, datt, (long)2 * Q * NT));
-        TRY(bigc_role_small_gemm_f32(s, 1, S.att, w.gvals, de, nullptr, de, w.genco, de, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
         TRY(bigc_role_attention_bwd_f32(s, S.p2a, da, S.e2a, da, w.gatt, w.ds, b->vid_trk_off, B, Q, da / 2, att_scale));
-        TRY(bigc_role_small_gemm_f32(s, 2, w.ds, nullptr, 0, S.e2a, da, w.gp2a, da, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
-        TRY(bigc_role_small_gemm_f32(s, 3, w.ds, S.p2a, da, nullptr, 0, w.ge2a, da, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
+        TRY(bigc_role_small_gemm_pair_f32(s, 1, w.ds, S.p2a, da, S.e2a, da, w.gp2a, w.ge2a, da, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
         TRY(bw.lin_res(p + ".fc_pred2att", L.p2a, w.gp2a, da, S.q2, dp, BQ, da, dp, B2, B3, dp));             // B3 = d q2 total
         TRY(bw.lin(p + ".fc_enti2att", L.e2a, w.ge2a, da, enco, de, NT, da, de, w.genco, de, true));
         // q2 = LN1(t2) + pos

@@ -183,9 +183,14 @@ __device__ __forceinline__ void dw_split16(const float (&x)[16], unsigned char* 
         for (int j = 0; j < 4; ++j) {
             const float a = x[8 * g + 2 * j], b = x[8 * g + 2 * j + 1];
             hh.h[j] = bigc_pk_rtn(a, b);
-            const float ra = (a - (float)hh.h[j][0]) * 2048.0f, rb = (b - (float)hh.h[j][1]) * 2048.0f;
+            // (a - h) 2048 as ONE mixed-precision FMA on the f16 head: a 2048 - h 2048, every step exact (a - h has at most 13 significant
+            // bits), so the same bits as convert, subtract, scale -- three VALU instructions per element on a loop that is VALU-bound
+            float ra, rb;
+            const float a2 = a * 2048.0f, b2 = b * 2048.0f;
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hh.h[j]), "v"(-2048.0f), "v"(a2));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hh.h[j]), "v"(-2048.0f), "v"(b2));
             rr.h[j] = bigc_pk_rtn(ra, rb);
-            chk += ra + rb;
+            // range: |x| >= 32768 or Inf shows in amax; a NaN operand (which v_max3 drops) makes its products NaN on either path
             asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(amax) : "v"(amax), "v"(a), "v"(b));
         }
         const int off = row * 64 + dw_swz(2 * mh + g, row) * 16;
@@ -230,6 +235,10 @@ __device__ __forceinline__ void linear_dw_split_body(const DwArgs& p, const int 
         }
 
     float ry[16], rx[16];
+    // (offsets inside a split must fit the 32-bit scalar offset of a buffer load)
+    const bool buf_ok = (size_t)(m_end - m_begin + 32) * (size_t)max(p.ldy, (GATHER || ROWS) ? 0 : p.ldx) * 4 < ((size_t)1 << 31);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dY + (size_t)m_begin * p.ldy), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((GATHER || ROWS) ? p.dY : p.X + (size_t)m_begin * p.ldx), 0, 0x7fffffff, 0x00020000);
     int ridx[16];                                   // gather mode: source rows of the NEXT slab to load (fetched one slab ahead,
                                                     // so the data loads never wait on their own index loads)
     float bsum = 0.f, chk = 0.f, amax = 0.f;
@@ -244,9 +253,18 @@ __device__ __forceinline__ void linear_dw_split_body(const DwArgs& p, const int 
     auto load_slab = [&](int m0) {
         const int mb = m0 + mh * 16;
         if (mb + 16 <= m_end) {
-            const float* yp = p.dY + (size_t)mb * p.ldy + ncol;
+            if (buf_ok) {
+                // buffer loads: descriptor of this split's rows in scalar registers, the lane's column as the vector offset, the row as the
+                // scalar offset -- no vector address arithmetic (plain pointers cost a 64-bit vector add per load: a fifth of the VALU
+                // instructions of a loop that is VALU-bound)
+                const int ro = (mb - m_begin) * p.ldy * 4;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) ry[j] = yp[(size_t)j * p.ldy];
+                for (int j = 0; j < 16; ++j) ry[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, ncol * 4, ro + j * p.ldy * 4, 0));
+            } else {
+                const float* yp = p.dY + (size_t)mb * p.ldy + ncol;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ry[j] = yp[(size_t)j * p.ldy];
+            }
             if (GATHER) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
@@ -257,9 +275,15 @@ __device__ __forceinline__ void linear_dw_split_body(const DwArgs& p, const int 
 #pragma unroll
                 for (int j = 0; j < 16; ++j) rx[j] = ((dw_gptr)p.x_rowptr[mb + j])[kcol];
             } else {
-                const float* xp = p.X + (size_t)mb * p.ldx + kcol;
+                if (buf_ok) {
+                    const int ro = (mb - m_begin) * p.ldx * 4;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) rx[j] = xp[(size_t)j * p.ldx];
+                    for (int j = 0; j < 16; ++j) rx[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, kcol * 4, ro + j * p.ldx * 4, 0));
+                } else {
+                    const float* xp = p.X + (size_t)mb * p.ldx + kcol;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) rx[j] = xp[(size_t)j * p.ldx];
+                }
             }
             return;
         }

@@ -371,10 +371,18 @@ __global__ __launch_bounds__(256, 2) void grd_attn_tail_kernel(const EncChainArg
         }
     }
     __syncthreads();
+    // (through the tile, then out by whole rows: stored straight from the accumulator layout every instruction touched 64 different lines)
     ec_pointwise<EXACT>(a, S, 5, wcur, -1, tid, [&](int row, int nn0, const f32x4 v) {
-        const long g = g0 + row;
-        if (g < a.rows) *(f32x4*)(a.out + g * EC_D + nn0) = ec_relu(v) + *(const f32x4*)(S.X + row * EC_XP + nn0);      // relu(fc) + res (:135-136)
+        f32x4* xp = (f32x4*)(S.X + row * EC_XP + nn0);
+        *xp = ec_relu(v) + *xp;                                  // relu(fc) + res (:135-136)
     });
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = rg + 8 * i;
+        const long g = g0 + row;
+        if (g < a.rows) *(f32x4*)(a.out + g * EC_D + 4 * cq) = *(const f32x4*)(S.X + row * EC_XP + 4 * cq);
+    }
     if (!EXACT && bad) atomicOr(a.act_bad, 1);
 }
 

@@ -747,6 +747,24 @@ def recall_leg(args, lib, device):
     return out
 
 
+def train_pmc_traffic(args, nvid):
+    """HBM bytes per GEMM launch and per whole training step from the committed rocprofv3 --pmc passes of `bench.py --mode train
+    --train-videos nvid` (profiles/pmc_traffic.json, section "train"; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes) -- only when they
+    were measured on these kernel sources and this workload; else (None, reason)"""
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(pmc_path) or args.n_trajs != 64:
+        return None, "no committed counter pass for this workload"
+    pmc = json.load(open(pmc_path))
+    sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+    from pmc_summary import csrc_sha16
+    if pmc.get("csrc_sha16") != csrc_sha16():
+        return None, "profiles/pmc_traffic.json was measured on other kernel sources (csrc fingerprint differs): not reported"
+    t = (pmc.get("train") or {}).get("videos_%d" % nvid)
+    if not t or "error" in t:
+        return None, "no training pass in profiles/pmc_traffic.json"
+    return t, "not measured in this run: profiles/pmc_traffic.json (%s), rocprofv3 --pmc passes of `bench.py --mode train --train-videos %d` on these kernel sources" % (pmc.get("tag", ""), nvid)
+
+
 def train_leg(args, lib, device):
     """BASELINE configs[4] on one GPU: the BIG-C training step at 8 and 64 videos per step"""
     out = {}
@@ -773,6 +791,13 @@ def train_leg(args, lib, device):
                                 launches_per_step=dw["launches"] // steps, gflop_per_step=round(dw["flops"] / steps / 1e9, 1), ms_per_step=round(dw["ms"] / steps, 3)),
                         share_of_step=round(both_ms / steps / (1e3 * el_prof / steps), 3), traffic=None,
                         measured="HIP events around each launch over %d instrumented steps" % steps)
+            tpmc, tsrc = train_pmc_traffic(args, nvid)
+            roof["traffic_source"] = tsrc
+            if tpmc:
+                roof["traffic"] = round(tpmc["gemm_hbm_bytes_per_launch"])
+                roof["traffic_launches_per_step"] = tpmc["gemm_launches_per_step"]
+                roof["algorithmic_bytes_per_launch"] = round((lin["bytes"] + dw["bytes"]) / max(1, lin["launches"] + dw["launches"]))
+                roof["step_traffic_all_kernels"] = dict(hbm_bytes=tpmc["whole_step_fetch_bytes_all_kernels"] + tpmc["whole_step_write_bytes_all_kernels"])
         by_fam, share, gflop_step, _ = family_rooflines(fam, steps, 1e3 * el_prof / steps)
         out["videos_%d" % nvid] = dict(value=round(pairs * steps / el, 1), unit="pairs/s", ms_per_step=round(1e3 * el / steps, 3), steps=steps,
                                        kernel_ms_per_step=round(kern_ms, 3), kernel_share_of_step=round(kern_ms / (1e3 * el / steps), 3),

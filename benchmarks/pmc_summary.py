@@ -61,6 +61,38 @@ def in_step(d, span):
     return [i for i in sorted(d) if span[0] <= i < span[1]]
 
 
+TRAIN_GEMM = ("linear_split_kernel", "linear_dw_split_kernel", "linear_dw_group_kernel", "linear_dw_kernel", "gemm_ps_kernel")
+
+
+def train_traffic(src):
+    """HBM bytes of ONE training step (bench.py --mode train --train-videos V): the GEMM kernels (forward + dX: linear_split; dW: linear_dw_*)
+    per launch, and every kernel of the step -> {"videos_8": {...}, "videos_64": {...}} (absent passes are skipped)"""
+    out = {}
+    for v in (8, 64):
+        fp = os.path.join(src, "pmc_train%d_FETCH_SIZE" % v, "pmc_counter_collection.csv")
+        wp = os.path.join(src, "pmc_train%d_WRITE_SIZE" % v, "pmc_counter_collection.csv")
+        if not (os.path.exists(fp) and os.path.exists(wp)):
+            continue
+        try:
+            gf, _ = per_dispatch(fp, TRAIN_GEMM)
+            gw, _ = per_dispatch(wp, TRAIN_GEMM)
+            af, _ = per_dispatch(fp, "")
+            aw, _ = per_dispatch(wp, "")
+            sf, sw = one_step(fp), one_step(wp)
+            fi, wi = in_step(gf, sf), in_step(gw, sw)
+            fetch = sum(gf[i]["FETCH_SIZE"] for i in fi) * 1024 * 2
+            write = sum(gw[i]["WRITE_SIZE"] for i in wi) * 1024
+            step_f = sum(af[i]["FETCH_SIZE"] for i in in_step(af, sf)) * 1024 * 2
+            step_w = sum(aw[i]["WRITE_SIZE"] for i in in_step(aw, sw)) * 1024
+            out["videos_%d" % v] = {"gemm_launches_per_step": len(fi), "gemm_fetch_bytes_per_step": fetch, "gemm_write_bytes_per_step": write,
+                                    "gemm_hbm_bytes_per_launch": (fetch + write) / max(1, len(fi)),
+                                    "whole_step_fetch_bytes_all_kernels": step_f, "whole_step_write_bytes_all_kernels": step_w,
+                                    "kernels": " + ".join(TRAIN_GEMM)}
+        except Exception as e:                      # a missing or short trace must not lose the eval summary
+            out["videos_%d" % v] = {"error": repr(e)}
+    return out
+
+
 def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_bench_kernel_stats.csv"))
@@ -96,7 +128,8 @@ def main():
                 n = re.sub(r"\(anonymous namespace\)::", "", names.get(a, "?"))
                 n = re.sub(r"\(.*", "", n).replace("void ", "")
                 f.write("%d,%s,%.1f,%.1f\n" % (i, n.replace(",", ";"), all_f[a]["FETCH_SIZE"] * 2048 / 1e6, all_w[b]["WRITE_SIZE"] * 1024 / 1e6))
-    json.dump({"kernel": " + ".join(KERNEL), "launches_per_step": len(fid), "fetch_bytes_per_step": tot_f, "write_bytes_per_step": tot_w,
+    json.dump({"train": train_traffic(src),
+               "kernel": " + ".join(KERNEL), "launches_per_step": len(fid), "fetch_bytes_per_step": tot_f, "write_bytes_per_step": tot_w,
                "hbm_bytes_per_launch": (tot_f + tot_w) / len(fid),
                "whole_step_fetch_bytes_all_kernels": step_f, "whole_step_write_bytes_all_kernels": step_w,
                "csrc_sha16": csrc_sha16(), "tag": tag,

@@ -19,6 +19,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 --kernel-trace --output-format csv -d $O/pmc_sq1 -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-prof $HEAD > $O/pmc_sq1.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc_sq2 -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-prof $HEAD > $O/pmc_sq2.log 2>&1
+# (3) HBM traffic of the training step (8 and 64 videos), same two separate passes
+for v in 8 64; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_train${v}_$c -o pmc -- python3 bench.py --mode train --train-videos $v --steps 3 --warmup 2 --no-prof > $O/pmc_train${v}_$c.log 2>&1
+  done
+done
 python3 benchmarks/pmc_summary.py $O $S $TAG > $S/${TAG}_pmc_summary.json 2> $S/pmc_summary.err
 cp $O/stats_full/bench_kernel_stats.csv $S/${TAG}_bench_full_kernel_stats.csv 2>/dev/null
 tail -1 $O/stats_stdout.log > $S/${TAG}_bench_under_rocprof.json.log

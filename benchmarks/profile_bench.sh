@@ -27,6 +27,6 @@ for v in 8 64; do
 done
 python3 benchmarks/pmc_summary.py $O $S $TAG > $S/${TAG}_pmc_summary.json 2> $S/pmc_summary.err
 cp $O/stats_full/bench_kernel_stats.csv $S/${TAG}_bench_full_kernel_stats.csv 2>/dev/null
-tail -1 $O/stats_stdout.log > $S/${TAG}_bench_under_rocprof.json.log
+grep "^{" $O/stats_stdout.log | tail -1 > $S/${TAG}_bench_under_rocprof.json.log
 ls -la $S
 du -sh $O

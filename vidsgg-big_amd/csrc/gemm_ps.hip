@@ -231,8 +231,16 @@ __global__ __launch_bounds__(64 * NWV, 1) void gemm_ps_kernel(const PsArgs p) {
     // issue-side state (runs ahead of the compute side)
     int ij = 0, ikt = 0;
     const unsigned char* ia_base = nullptr;                               // A + m0 * lda of the tile being issued
-    const unsigned char* iw_base = nullptr;                               // Ws + n0 * ldw
-    int a_lim = 0, w_lim = 0;                                             // last valid row of the tile, relative to its first
+    // The DMA pieces of W (every mode) and of a plain hr8 A (mode 0) are BUFFER loads: descriptor in scalar registers (W: the whole
+    // matrix; A: from the tile's first row on), the lane's (row in block, swizzled chunk) as a 32-bit vector offset that never changes,
+    // and tile / slab / block as the scalar offset -- no vector address arithmetic per piece (with global_load_lds every piece paid a
+    // clamp, a multiply and a 64-bit add: 3.5 VALU instructions per MFMA on the conv GEMM, whose matrix pipe was 60 % busy).  Rows past
+    // the matrix fail the descriptor's range check and read as zeros (their products are never stored).
+    constexpr int RSRC_FLAGS = 0x00020000;
+    const size_t w_bytes = (size_t)p.N * p.ldw;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ws, 0, (int)(w_bytes < 0xffffffffull ? w_bytes : 0xffffffffull), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t a_rsrc = w_rsrc;                               // mode 0: set per tile
+    int iw_off = 0;                                                       // n0 * ldw
     // mode 1: source row of this lane's row of piece i in K segment sg (-1 = zeros).  The slabs of a gathered GEMM are walked
     // SEGMENT-INTERLEAVED -- slab ikt = (chunk ikt / nseg, segment ikt % nseg) -- so that the taps of the temporal conv, which
     // read the same source rows (output position t reads the stretched frames 2t-1, 2t, 2t+1: neighbouring positions share a
@@ -255,9 +263,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void gemm_ps_kernel(const PsArgs p) {
         const int L = tile_of(ij), tm = L / p.tiles_n, tn = L - tm * p.tiles_n;
         const int m0 = tm * TM, n0 = tn * TNK;
         ia_base = p.A + (size_t)m0 * p.lda;
-        iw_base = p.Ws + (size_t)n0 * p.ldw;
-        a_lim = p.M - 1 - m0;
-        w_lim = p.N - 1 - n0;
+        iw_off = n0 * (int)p.ldw;
+        if (AMODE == 0) {
+            const size_t a_bytes = (size_t)(p.M - m0) * p.lda;
+            a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ia_base, 0, (int)(a_bytes < 0xffffffffull ? a_bytes : 0xffffffffull), RSRC_FLAGS);
+        }
         if (AMODE == 3) {
             // row base addresses of this lane's rows of the tile's NA pieces (one batch of table reads per tile)
             unsigned long long v[NA];
@@ -283,11 +293,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void gemm_ps_kernel(const PsArgs p) {
         }
     };
     // (`so` = byte offset of an LDS stage, a wave-uniform runtime value)
+    const int w_vo = (wave * 8 + l8) * (int)p.ldw + coff, a_vo = (wave * 8 + l8) * (int)p.lda + coff;       // the lane's part of every W / A piece address
     auto issue_w_piece = [&](int i, int so) {
         const int blk = wave + NWV * i;
-        const unsigned vo = (unsigned)(min(blk * 8 + l8, w_lim) * (int)p.ldw + coff);
-        const size_t kb = AMODE == 1 ? (size_t)isg * p.seg_bytes + (size_t)ichunk * ROWB : (size_t)ikt * ROWB;      // K offset of the slab in a W row
-        __builtin_amdgcn_global_load_lds((const AS1 void*)(iw_base + kb + vo), (AS3 void*)(lds + so + A_BYTES + blk * 1024), 16, 0, 0);
+        const int kb = AMODE == 1 ? isg * p.seg_bytes + ichunk * ROWB : ikt * ROWB;      // K offset of the slab in a W row
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (AS3 void*)(lds + so + A_BYTES + blk * 1024), 16, w_vo, iw_off + kb + i * (NWV * 8) * (int)p.ldw, 0, 0);
     };
     auto issue_a_piece = [&](int i, int so) {
         const int blk = wave + NWV * i;
@@ -300,8 +310,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void gemm_ps_kernel(const PsArgs p) {
             const unsigned char* src = (gi >= 0 ? p.A + (size_t)gi * p.lda : p.zero_row) + coff + ichunk * ROWB;    // index -1: a row of zeros
             __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(lds + so + blk * 1024), 16, 0, 0);
         } else {
-            const unsigned vo = (unsigned)min(blk * 8 + l8, a_lim) * (unsigned)p.lda + coff;
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(ia_base + (size_t)ikt * ROWB + vo), (AS3 void*)(lds + so + blk * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (AS3 void*)(lds + so + blk * 1024), 16, a_vo, ikt * ROWB + i * (NWV * 8) * (int)p.lda, 0, 0);
         }
     };
     // piece k of the slab being issued: modes 0 / 1: A pieces then W pieces; mode 2: W pieces only

@@ -22,6 +22,7 @@
 #include "grounding_internal.h"
 #include "prof.h"
 #include <stdlib.h>
+#include <atomic>
 
 typedef _Float16 a16x8 __attribute__((ext_vector_type(8)));
 
@@ -36,7 +37,7 @@ constexpr long EC_FRAG_ELEMS = (long)EC_LAYERS * 4 * 8 * 2 * 64;            // a
 
 struct EncChainArgs {
     const float* x; const float* pos; const float* res; long rows; int T; const int2* info;
-    const a16x8* frag; const int* frag_bad; int* act_bad;
+    const a16x8* frag; const int* frag_bad; int* act_bad; int run_id;     // act_bad holds the id of the last launch that met an out-of-range operand (no memset per launch)
     const float* dwt; int ks;                             // depth-wise weights as (layer, tap (8), channel): prepared with the fragments
     const float* ln_g[6]; const float* ln_b[6];           // [0..3] in front of convolution i, [4] in front of the attention, [5] in front of fc
     const float* dw_w[4]; const float* dw_b[4];
@@ -201,7 +202,7 @@ __device__ __forceinline__ f32x4 ec_relu(const f32x4 v) {                    // 
 
 template <int KS, bool EXACT>
 __global__ __launch_bounds__(256, 2) void grd_enc_chain_kernel(const EncChainArgs a) {
-    if (EXACT && a.act_bad[0] == 0 && a.frag_bad[0] == 0) return;
+    if (EXACT && a.act_bad[0] != a.run_id && a.frag_bad[0] == 0) return;
     constexpr int H = KS / 2, HALO = 4 * H, TR = EC_CR - 2 * HALO;
     __shared__ __attribute__((aligned(16))) EcSmem S;
     unsigned char* Ah = S.A2;
@@ -312,13 +313,13 @@ __global__ __launch_bounds__(256, 2) void grd_enc_chain_kernel(const EncChainArg
             *(f32x4*)(a.ln_out + g * EC_D + 4 * cq) = o;
         }
     }
-    if (!EXACT && bad) atomicOr(a.act_bad, 1);
+    if (!EXACT && bad) atomicMax(a.act_bad, a.run_id);
 }
 
 // r = out_proj(att) + res;  y = relu(fc(LayerNorm_e(r))) + r      (x = att, res = the chain's `out`, out = y; row-local)
 template <bool EXACT>
 __global__ __launch_bounds__(256, 2) void grd_attn_tail_kernel(const EncChainArgs a) {
-    if (EXACT && a.act_bad[0] == 0 && a.frag_bad[0] == 0) return;
+    if (EXACT && a.act_bad[0] != a.run_id && a.frag_bad[0] == 0) return;
     __shared__ __attribute__((aligned(16))) EcSmem S;
     unsigned char* Ah = S.A2;
     unsigned char* Ar = S.A2 + EC_CR * EC_AP;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void grd_attn_tail_kernel(const EncChainArg
         const long g = g0 + row;
         if (g < a.rows) *(f32x4*)(a.out + g * EC_D + 4 * cq) = *(const f32x4*)(S.X + row * EC_XP + 4 * cq);
     }
-    if (!EXACT && bad) atomicOr(a.act_bad, 1);
+    if (!EXACT && bad) atomicMax(a.act_bad, a.run_id);
 }
 
 }  // namespace
@@ -401,6 +402,8 @@ void enc_args(const Enc& E, long rows, int T, const int2* info, void* frag, EncC
     int* flags = (int*)((char*)frag + (size_t)EC_FRAG_ELEMS * sizeof(a16x8));
     a.frag_bad = flags;
     a.act_bad = flags + 1;
+    static std::atomic<int> g_run{0};
+    a.run_id = g_run.fetch_add(1, std::memory_order_relaxed) + 1;
     a.dwt = (const float*)((char*)flags + 256); a.ks = E.ks;
     const Lin* ln[6] = {&E.normb, &E.norm_seq[0], &E.norm_seq[1], &E.norm_seq[2], &E.norm_seq[3], &E.norme};
     for (int i = 0; i < 6; ++i) { a.ln_g[i] = ln[i]->w; a.ln_b[i] = ln[i]->b; }
@@ -420,9 +423,8 @@ int grd_enc_chain(hipStream_t s, const Enc& E, const float* x, const float* pos,
     EncChainArgs a;
     enc_args(E, rows, T, info, frag, a);
     a.x = x; a.pos = pos; a.res = nullptr; a.out = out; a.ln_out = ln_out;
-    if (hipMemsetAsync(a.act_bad, 0, sizeof(int), s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_enc_chain: memset failed");
-    if (refresh) {
-        if (hipMemsetAsync((void*)a.frag_bad, 0, sizeof(int), s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_enc_chain: memset failed");
+    if (refresh) {                             // (also the first use of the buffer: both flag words start at zero)
+        if (hipMemsetAsync((void*)a.frag_bad, 0, 2 * sizeof(int), s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_enc_chain: memset failed");
         hipLaunchKernelGGL(grd_enc_prep_kernel, dim3(EC_LAYERS * 32 + 4), dim3(64), 0, s, a, (a16x8*)frag, (int*)a.frag_bad);
         BIGC_LAUNCH_CHECK("grd_enc_prep");
     }
@@ -446,7 +448,6 @@ int grd_attn_tail(hipStream_t s, const Enc& E, const float* att, const float* re
     EncChainArgs a;
     enc_args(E, rows, 1, nullptr, frag, a);
     a.x = att; a.pos = nullptr; a.res = res; a.out = out; a.ln_out = nullptr;
-    if (hipMemsetAsync(a.act_bad, 0, sizeof(int), s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_attn_tail: memset failed");
     const long tiles = (rows + EC_CR - 1) / EC_CR;
     ProfScope ps((void*)s, FAM_GROUNDING, 2.0 * rows * EC_D * 2.0 * EC_D, 4.0 * rows * 3.0 * EC_D);
     hipLaunchKernelGGL((grd_attn_tail_kernel<false>), dim3((unsigned)tiles), dim3(256), 0, s, a);

@@ -16,11 +16,12 @@
 //
 // Arithmetic: the point-wise layers run on the f16 matrix cores with exactly split f32 operands, three MFMAs per product in two
 // accumulators (the scheme of csrc/linear_split.hip); the depth-wise taps are f32 FMAs.  The weights are the MFMA's A operand: a wave
-// owns 32 output features and holds its slice of the layer's weight (split once per layer, 64 registers) while it walks the tile's two
-// 32-row blocks; an output lane owns one data row.
+// owns 32 output features and one of the tile's two 32-row blocks and holds its slice of the layer's weight (pre-split fragments,
+// 64 registers) during the layer's MFMAs; an output lane owns one data row.
 #include "grounding_internal.h"
 #include "prof.h"
 #include <stdlib.h>
+#include <atomic>
 
 typedef _Float16 a16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 a16x4 __attribute__((ext_vector_type(4)));
@@ -45,7 +46,7 @@ __device__ __forceinline__ void hd_split8(const float (&x)[8], a16x8& h, a16x8& 
 }
 
 struct HeadChainHead { const float* dw_w[5]; const float* dw_b[5]; const float* pw_w[5]; const float* pw_b[5]; float* out; int c_out; int act; };
-struct HeadChainArgs { const float* x; long rows; int T; const int2* info; const a16x8* frag; const int* frag_bad; int* act_bad; HeadChainHead h[3]; };
+struct HeadChainArgs { const float* x; long rows; int T; const int2* info; const a16x8* frag; const int* frag_bad; int* act_bad; int run_id; HeadChainHead h[3]; };
 constexpr float HD_LIM = 32768.0f;
 
 // The point-wise weights in the order the kernel consumes them: per (head, layer, wave, k16 step, plane) 64 lanes x 16 bytes -- lane
@@ -73,27 +74,28 @@ __global__ __launch_bounds__(64) void grd_head_prep_kernel(const HeadChainArgs a
     dst[64] = r;
 }
 
-__global__ __launch_bounds__(256, 2) void grd_head_chain_kernel(const HeadChainArgs a) {   // (two waves per SIMD = two workgroups per CU: the 69 KB of LDS allow it, the register allocation must too)
+// EIGHT waves per 64-row tile: wave = (feature block, 32-row block), one accumulator pair per wave, four rows per 32-lane group in the
+// depth-wise stage, 128 registers -- four waves per SIMD.  (Round 5; the four-wave form with two 32-row blocks per wave and the next
+// layer's weights requested a layer ahead ran 670 against 639 us on the same box; with ONE four-wave workgroup per CU it was 1023 us.
+// What bounds the kernel is LDS traffic next to the MFMAs: every wave reads the whole tile's operand planes for its 32 features,
+// 240 KB per tile and layer = 1900 clocks of the LDS pipe beside 1536 of the matrix pipe.)
+__global__ __launch_bounds__(512, 4) void grd_head_chain_kernel(const HeadChainArgs a) {
     __shared__ __attribute__((aligned(16))) float X[HD_CR * HD_XP];
     __shared__ __attribute__((aligned(16))) unsigned char Ah[HD_CR * HD_AP];
     __shared__ __attribute__((aligned(16))) unsigned char Ar[HD_CR * HD_AP];
     __shared__ int2 rinfo[HD_CR];
     const HeadChainHead& H = a.h[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int fb = wave & 3, rbw = wave >> 2;               // this wave's 32 output features and 32 rows in the point-wise stage
     const long g0 = (long)blockIdx.x * HD_TR - HD_HALO;
-
-    // ---- the tile: 64 rows x 128 floats, rows outside the tensor are zeros of length 0
-    auto load_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 5, c4 = idx & 31;
-            const long g = g0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (g >= 0 && g < a.rows) v = *(const f32x4*)(a.x + g * HD_D + 4 * c4);
-            *(f32x4*)(X + row * HD_XP + 4 * c4) = v;
-        }
-    };
-    load_tile();
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 512 * i, row = idx >> 5, c4 = idx & 31;
+        const long g = g0 + row;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (g >= 0 && g < a.rows) v = *(const f32x4*)(a.x + g * HD_D + 4 * c4);
+        *(f32x4*)(X + row * HD_XP + 4 * c4) = v;
+    }
     bool bad = false;
     if (tid < HD_CR) {
         const long g = g0 + tid;
@@ -103,38 +105,28 @@ __global__ __launch_bounds__(256, 2) void grd_head_chain_kernel(const HeadChainA
     }
     __syncthreads();
 
-    const int cq = tid & 31, rg = tid >> 5;                 // depth-wise stage: channels 4 cq .. + 3 of rows 8 rg .. + 7
-    // this wave's slice of a layer's point-wise weight, already split (grd_head_prep_kernel): 16 coalesced 16-byte loads per lane.  The
-    // slice of layer l + 1 is requested at the start of layer l's MFMA stage and lands while that stage and the next depth-wise stage
-    // run (with four waves per workgroup nothing else would hide an L2 round trip per layer)
+    const int cq = tid & 31, rg = tid >> 5;                 // depth-wise stage: channels 4 cq .. + 3 of rows 4 rg .. + 3
     auto load_w = [&](int layer, a16x8 (&w)[16]) {
-        const a16x8* wf = a.frag + ((((long)(blockIdx.y * 5 + layer) * 4 + wave) * 8) * 2) * 64 + lane;
+        const a16x8* wf = a.frag + ((((long)(blockIdx.y * 5 + layer) * 4 + fb) * 8) * 2) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < 16; ++i) w[i] = wf[i * 64];
     };
-    a16x8 wcur[16];
-    load_w(0, wcur);
-    // depth-wise taps and bias of the current layer (channels 4 cq .. + 3); those of the next layer are requested while this layer's MFMAs run
-    f32x4 w0, w1, w2, bb;
-    auto load_dw = [&](int layer) {
-        const float* dw = H.dw_w[layer] + (size_t)4 * cq * 3;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { w0[c] = dw[3 * c]; w1[c] = dw[3 * c + 1]; w2[c] = dw[3 * c + 2]; }
-        bb = *(const f32x4*)(H.dw_b[layer] + 4 * cq);
-    };
-    load_dw(0);
-#pragma unroll
+#pragma unroll 1
     for (int layer = 0; layer < 5; ++layer) {
         const int n_out = layer < 4 ? HD_D : H.c_out;
-        const bool mm_wave = wave * 32 < n_out;             // the last layer's few features: the first wave(s) only
-        // ---- depth-wise k = 3 along the rows of a sequence, zero padded (models/grd_model_v5.py:44), then split into the two planes
+        const bool mm_wave = fb * 32 < n_out;
         {
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            f32x4 xm = rg > 0 ? *(const f32x4*)(X + (8 * rg - 1) * HD_XP + 4 * cq) : zero;
-            f32x4 x0 = *(const f32x4*)(X + (8 * rg) * HD_XP + 4 * cq);
+            const float* dw = H.dw_w[layer] + (size_t)4 * cq * 3;
+            f32x4 w0, w1, w2;
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int row = 8 * rg + rr;
+            for (int c = 0; c < 4; ++c) { w0[c] = dw[3 * c]; w1[c] = dw[3 * c + 1]; w2[c] = dw[3 * c + 2]; }
+            const f32x4 bb = *(const f32x4*)(H.dw_b[layer] + 4 * cq);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            f32x4 xm = rg > 0 ? *(const f32x4*)(X + (4 * rg - 1) * HD_XP + 4 * cq) : zero;
+            f32x4 x0 = *(const f32x4*)(X + (4 * rg) * HD_XP + 4 * cq);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = 4 * rg + rr;
                 const f32x4 xp = row + 1 < HD_CR ? *(const f32x4*)(X + (row + 1) * HD_XP + 4 * cq) : zero;
                 const int2 ri = rinfo[row];
                 const f32x4 lo = ri.x > 0 ? xm : zero, up = ri.x + 1 < ri.y ? xp : zero;
@@ -152,66 +144,50 @@ __global__ __launch_bounds__(256, 2) void grd_head_chain_kernel(const HeadChainA
             }
         }
         __syncthreads();
-        if (layer < 4) load_dw(layer + 1);
-        // ---- point-wise: out[row][n] = sum_k act[row][k] W[n][k] + b[n]; weights = MFMA A operand, activations = B operand
         if (mm_wave) {
-            // both 32-row blocks in one sweep over k: four independent accumulator chains keep the matrix pipe fed
-            f32x16 acc0[2], acc1[2];
+            // (requested here, not a layer ahead: 64 registers that must not live through the depth-wise stage at 128 per wave; the other
+            // three waves of the SIMD cover the L2 round trip)
+            a16x8 wcur[16];
+            load_w(layer, wcur);
+            f32x16 acc0, acc1;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { acc0[rb][r] = 0.f; acc1[rb][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    const a16x8 bh = *(const a16x8*)(Ah + (rb * 32 + l31) * HD_AP + 16 * hi + 32 * s);
-                    const a16x8 br = *(const a16x8*)(Ar + (rb * 32 + l31) * HD_AP + 16 * hi + 32 * s);
-                    acc0[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[2 * s], bh, acc0[rb], 0, 0, 0);
-                    acc1[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[2 * s], br, acc1[rb], 0, 0, 0);
-                    acc1[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[2 * s + 1], bh, acc1[rb], 0, 0, 0);
-                }
+                const a16x8 bh = *(const a16x8*)(Ah + (rbw * 32 + l31) * HD_AP + 16 * hi + 32 * s);
+                const a16x8 br = *(const a16x8*)(Ar + (rbw * 32 + l31) * HD_AP + 16 * hi + 32 * s);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[2 * s], bh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[2 * s], br, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[2 * s + 1], bh, acc1, 0, 0, 0);
             }
-            // the next layer's slice into the same registers, right behind the MFMAs: it lands while the epilogue and the next depth-wise stage run
-            if (layer < 4) load_w(layer + 1, wcur);
+            const int row = rbw * 32 + l31;
             if (layer < 4) {
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const int nn0 = wave * 32 + 8 * r4 + 4 * hi;
+                    const int nn0 = fb * 32 + 8 * r4 + 4 * hi;
                     const f32x4 bias = *(const f32x4*)(H.pw_b[layer] + nn0);
+                    f32x4 v;
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) {
-                        f32x4 v;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = fmaxf((acc0[rb][4 * r4 + c] + acc1[rb][4 * r4 + c] * HD_RI) + bias[c], 0.f);
-                        *(f32x4*)(X + (rb * 32 + l31) * HD_XP + nn0) = v;
-                    }
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf((acc0[4 * r4 + c] + acc1[4 * r4 + c] * HD_RI) + bias[c], 0.f);
+                    *(f32x4*)(X + row * HD_XP + nn0) = v;
                 }
             } else {
-                float bias[16];
+                const long g = g0 + row;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) bias[r] = H.pw_b[layer][min(wave * 32 + mfma_row(r, hi), n_out - 1)];
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    const int row = rb * 32 + l31;
-                    const long g = g0 + row;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int nn = wave * 32 + mfma_row(r, hi);
-                        if (nn >= n_out) continue;
-                        float v = (acc0[rb][r] + acc1[rb][r] * HD_RI) + bias[r];
-                        if (row >= HD_HALO && row < HD_CR - HD_HALO && g >= 0 && g < a.rows) {
-                            if (H.act == BIGC_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-                            H.out[g * H.c_out + nn] = v;
-                        }
+                for (int r = 0; r < 16; ++r) {
+                    const int nn = fb * 32 + mfma_row(r, hi);
+                    if (nn >= n_out) continue;
+                    float v = (acc0[r] + acc1[r] * HD_RI) + H.pw_b[layer][nn];
+                    if (row >= HD_HALO && row < HD_CR - HD_HALO && g >= 0 && g < a.rows) {
+                        if (H.act == BIGC_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                        H.out[g * H.c_out + nn] = v;
                     }
                 }
             }
         }
         __syncthreads();
     }
-
-    if (bad) atomicOr(a.act_bad, 1);          // -> grd_head_exact_kernel, launched right behind, redoes the launch in plain f32
+    if (bad) atomicMax(a.act_bad, a.run_id);
 }
 
 // Range fallback of the kernel above, launched behind it with the same grid: returns at once unless an activation (flag raised by the chain
@@ -219,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void grd_head_chain_kernel(const HeadChainA
 // through all five layers with plain f32 FMAs from the f32 weights, so that NaN / Inf / huge values come out as the reference's f32
 // arithmetic gives them.
 __global__ __launch_bounds__(256) void grd_head_exact_kernel(const HeadChainArgs a) {
-    if (a.act_bad[0] == 0 && a.frag_bad[0] == 0) return;
+    if (a.act_bad[0] != a.run_id && a.frag_bad[0] == 0) return;
     __shared__ __attribute__((aligned(16))) float X[HD_CR * HD_XP];
     __shared__ __attribute__((aligned(16))) float Dw[HD_CR * HD_XP];              // the depth-wise result of the current layer
     __shared__ int2 rinfo[HD_CR];
@@ -299,7 +275,8 @@ int grd_head_chain(hipStream_t s, const float* x, long rows, int T, const int2* 
     int* frag_bad = (int*)((char*)frag + (size_t)HD_FRAG_ELEMS * sizeof(a16x8));
     a.frag_bad = frag_bad;
     a.act_bad = frag_bad + 1;
-    if (hipMemsetAsync(a.act_bad, 0, sizeof(int), s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_head_chain: memset failed");
+    static std::atomic<int> g_run{0};
+    a.run_id = g_run.fetch_add(1, std::memory_order_relaxed) + 1;
     for (int i = 0; i < 3; ++i) {
         for (int l = 0; l < 5; ++l) {
             a.h[i].dw_w[l] = heads[i]->layer[l].dw_w; a.h[i].dw_b[l] = heads[i]->layer[l].dw_b;
@@ -308,7 +285,7 @@ int grd_head_chain(hipStream_t s, const float* x, long rows, int T, const int2* 
         a.h[i].out = outs[i]; a.h[i].c_out = heads[i]->c_out; a.h[i].act = acts[i];
     }
     if (refresh) {
-        if (hipMemsetAsync(frag_bad, 0, sizeof(int), s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_head_chain: memset failed");
+        if (hipMemsetAsync(frag_bad, 0, 2 * sizeof(int), s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_head_chain: memset failed");      // (both flag words)
         hipLaunchKernelGGL(grd_head_prep_kernel, dim3(3 * 5 * 4 * 8), dim3(64), 0, s, a, (a16x8*)frag, frag_bad);
         BIGC_LAUNCH_CHECK("grd_head_prep");
     }
@@ -316,7 +293,7 @@ int grd_head_chain(hipStream_t s, const float* x, long rows, int T, const int2* 
     double flops = 0.0;
     for (int i = 0; i < 3; ++i) flops += 2.0 * rows * HD_D * (4.0 * HD_D + heads[i]->c_out);
     ProfScope ps((void*)s, FAM_GROUNDING, flops, 4.0 * rows * (3.0 * HD_D + heads[0]->c_out + heads[1]->c_out + heads[2]->c_out));
-    hipLaunchKernelGGL(grd_head_chain_kernel, dim3((unsigned)tiles, 3), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(grd_head_chain_kernel, dim3((unsigned)tiles, 3), dim3(512), 0, s, a);
     BIGC_LAUNCH_CHECK("grd_head_chain");
     hipLaunchKernelGGL(grd_head_exact_kernel, dim3((unsigned)tiles, 3), dim3(256), 0, s, a);       // gated: returns at once when no flag is up
     BIGC_LAUNCH_CHECK("grd_head_exact");

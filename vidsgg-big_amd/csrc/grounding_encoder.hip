@@ -99,19 +99,20 @@ __device__ __forceinline__ void ec_load_w(const a16x8* frag, int layer, int wave
     for (int i = 0; i < 16; ++i) w[i] = wf[i * 64];
 }
 
-// acc (feature 32 wave + mfma_row(r, hi), data row 32 rb + l31) = sum_k W[feature][k] act[row][k]: both 32-row blocks in one sweep over k
-__device__ __forceinline__ void ec_mm(const unsigned char* Ah, const unsigned char* Ar, const a16x8 (&w)[16], int l31, int hi,
-                                      f32x16 (&acc0)[2], f32x16 (&acc1)[2]) {
+// acc[i] (feature 32 fb + mfma_row(r, hi), data row 32 (rb0 + i) + l31) = sum_k W[feature][k] act[row][k]: NRB 32-row blocks in one sweep over k
+template <int NRB>
+__device__ __forceinline__ void ec_mm(const unsigned char* Ah, const unsigned char* Ar, const a16x8 (&w)[16], int rb0, int l31, int hi,
+                                      f32x16 (&acc0)[NRB], f32x16 (&acc1)[NRB]) {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[rb][r] = 0.f; acc1[rb][r] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const a16x8 bh = *(const a16x8*)(Ah + (rb * 32 + l31) * EC_AP + 16 * hi + 32 * s);
-            const a16x8 br = *(const a16x8*)(Ar + (rb * 32 + l31) * EC_AP + 16 * hi + 32 * s);
+        for (int rb = 0; rb < NRB; ++rb) {
+            const a16x8 bh = *(const a16x8*)(Ah + ((rb0 + rb) * 32 + l31) * EC_AP + 16 * hi + 32 * s);
+            const a16x8 br = *(const a16x8*)(Ar + ((rb0 + rb) * 32 + l31) * EC_AP + 16 * hi + 32 * s);
             acc0[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * s], bh, acc0[rb], 0, 0, 0);
             acc1[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * s], br, acc1[rb], 0, 0, 0);
             acc1[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * s + 1], bh, acc1[rb], 0, 0, 0);
@@ -136,6 +137,7 @@ __device__ __forceinline__ float ec_quad_sum(float t) {
 // LayerNorm statistics of the tile's 64 rows -> S.stat: four threads per row, 32 channels each, two-pass in f32 (mean, then the squared
 // deviations from it), biased variance, eps inside the root (torch.nn.LayerNorm)
 __device__ __forceinline__ void ec_stats(EcSmem& S, int tid, float eps) {
+    if (tid >= 4 * EC_CR) return;                 // (eight-wave workgroups: the first four waves)
     const int row = tid >> 2, q = tid & 3;
     const float* xp = S.X + row * EC_XP + 32 * q;
     f32x4 v[8];
@@ -152,34 +154,44 @@ __device__ __forceinline__ void ec_stats(EcSmem& S, int tid, float eps) {
     if (q == 0) S.stat[row] = make_float2(mean, rstd);
 }
 
-// one point-wise layer on the tile: S.A2 (operand) x W[layer] -> epilogue(row, first feature nn0 of a quad, the four results + bias)
-// `next` >= 0: the wave's weight slice of that layer is requested into `wcur` right behind the MFMAs (it lands while the epilogue and the
-// next layer's row-wise stages run: with two waves per SIMD nothing else would hide an L2 round trip per layer)
-template <bool EXACT, typename Epi>
+// one point-wise layer on the tile: S.A2 (operand) x W[layer] -> epilogue(row, first feature nn0 of a quad, the four results + bias).
+// NW = 4 waves: a wave owns 32 features and both 32-row blocks, and `next` >= 0 requests the wave's weight slice of that layer into `wcur`
+// right behind the MFMAs (it lands while the epilogue and the next layer's row-wise stages run: with two waves per SIMD nothing else would
+// hide an L2 round trip per layer).  NW = 8 waves: a wave owns 32 features and ONE 32-row block and fetches its slice where it uses it
+// (64 registers that must not live through the row-wise stages at 128 per wave; the other three waves of the SIMD cover the round trip).
+template <bool EXACT, int NW, typename Epi>
 __device__ __forceinline__ void ec_pointwise(const EncChainArgs& a, EcSmem& S, int layer, a16x8 (&wcur)[16], int next, int tid, Epi epi) {
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    constexpr int NRB = 8 / NW;
+    const int fb = wave & 3, rb0 = NW == 8 ? wave >> 2 : 0;
     if (!EXACT) {
         unsigned char* Ah = S.A2;
         unsigned char* Ar = S.A2 + EC_CR * EC_AP;
-        f32x16 acc0[2], acc1[2];
-        ec_mm(Ah, Ar, wcur, l31, hi, acc0, acc1);
-        if (next >= 0) ec_load_w(a.frag, next, wave, lane, wcur);
+        f32x16 acc0[NRB], acc1[NRB];
+        if (NW == 8) {
+            a16x8 w[16];
+            ec_load_w(a.frag, layer, fb, lane, w);
+            ec_mm<NRB>(Ah, Ar, w, rb0, l31, hi, acc0, acc1);
+        } else {
+            ec_mm<NRB>(Ah, Ar, wcur, rb0, l31, hi, acc0, acc1);
+            if (next >= 0) ec_load_w(a.frag, next, fb, lane, wcur);
+        }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            const int nn0 = wave * 32 + 8 * r4 + 4 * hi;
+            const int nn0 = fb * 32 + 8 * r4 + 4 * hi;
             const f32x4 bias = *(const f32x4*)(a.pw_b[layer] + nn0);
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
+            for (int rb = 0; rb < NRB; ++rb) {
                 f32x4 v;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = (acc0[rb][4 * r4 + c] + acc1[rb][4 * r4 + c] * EC_RI) + bias[c];
-                epi(rb * 32 + l31, nn0, v);
+                epi((rb0 + rb) * 32 + l31, nn0, v);
             }
         }
     } else {
         const float* Dw = (const float*)S.A2;
         const int row = tid & 63;                         // a wave shares the output features (its weight rows are wave-uniform)
-        for (int nn0 = 4 * (tid >> 6); nn0 < EC_D; nn0 += 16) {
+        for (int nn0 = 4 * (tid >> 6); nn0 < EC_D; nn0 += 4 * NW) {
             f32x4 v;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -200,21 +212,22 @@ __device__ __forceinline__ f32x4 ec_relu(const f32x4 v) {                    // 
     return o;
 }
 
-template <int KS, bool EXACT>
-__global__ __launch_bounds__(256, 2) void grd_enc_chain_kernel(const EncChainArgs a) {
+template <int KS, bool EXACT, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void grd_enc_chain_kernel(const EncChainArgs a) {
+    constexpr int NG = 2 * NW, RPG = EC_CR / NG;           // 32-lane groups of the row-wise stages; consecutive rows per group
     if (EXACT && a.act_bad[0] != a.run_id && a.frag_bad[0] == 0) return;
     constexpr int H = KS / 2, HALO = 4 * H, TR = EC_CR - 2 * HALO;
     __shared__ __attribute__((aligned(16))) EcSmem S;
     unsigned char* Ah = S.A2;
     unsigned char* Ar = S.A2 + EC_CR * EC_AP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cq = tid & 31, rg = tid >> 5;                 // row-wise stages: channels 4 cq .. + 3 of rows 8 rg .. + 7
+    const int cq = tid & 31, rg = tid >> 5;                 // row-wise stages: channels 4 cq .. + 3 of rows RPG rg .. + RPG - 1
     const long g0 = (long)blockIdx.x * TR - HALO;
 
     // ---- the tile: x + pos[position in the sequence] (:124), rows outside the tensor are zeros of length 0
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = rg + 8 * i;
+    for (int i = 0; i < RPG; ++i) {
+        const int row = rg + NG * i;
         const long g = g0 + row;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         int2 ri = {0, 0};
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void grd_enc_chain_kernel(const EncChainArg
     __syncthreads();
 
     a16x8 wcur[16];
-    if (!EXACT) ec_load_w(a.frag, 0, wave, lane, wcur);
+    if (!EXACT && NW == 4) ec_load_w(a.frag, 0, wave, lane, wcur);
     bool bad = false;
 #pragma unroll 1
     for (int layer = 0; layer < 4; ++layer) {
@@ -253,10 +266,10 @@ __global__ __launch_bounds__(256, 2) void grd_enc_chain_kernel(const EncChainArg
             };
             f32x4 win[KS];                                    // win[j] = normalised row (row + j - H)
 #pragma unroll
-            for (int j = 1; j < KS; ++j) win[j] = ln_row(8 * rg + j - 1 - H);
+            for (int j = 1; j < KS; ++j) win[j] = ln_row(RPG * rg + j - 1 - H);
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int row = 8 * rg + rr;
+            for (int rr = 0; rr < RPG; ++rr) {
+                const int row = RPG * rg + rr;
 #pragma unroll
                 for (int j = 0; j + 1 < KS; ++j) win[j] = win[j + 1];
                 win[KS - 1] = ln_row(row + H);
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void grd_enc_chain_kernel(const EncChainArg
             }
         }
         __syncthreads();
-        ec_pointwise<EXACT>(a, S, layer, wcur, layer < 3 ? layer + 1 : -1, tid, [&](int row, int nn0, const f32x4 v) {
+        ec_pointwise<EXACT, NW>(a, S, layer, wcur, layer < 3 ? layer + 1 : -1, tid, [&](int row, int nn0, const f32x4 v) {
             f32x4* xp = (f32x4*)(S.X + row * EC_XP + nn0);
             *xp = ec_relu(v) + *xp;                              // relu(conv) + res  (:130-131)
         });
@@ -300,8 +313,8 @@ __global__ __launch_bounds__(256, 2) void grd_enc_chain_kernel(const EncChainArg
     {
         const f32x4 gg = *(const f32x4*)(a.ln_g[4] + 4 * cq), be = *(const f32x4*)(a.ln_b[4] + 4 * cq);
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int row = rg + 8 * rr;
+        for (int rr = 0; rr < RPG; ++rr) {
+            const int row = rg + NG * rr;
             const long g = g0 + row;
             if (row < HALO || row >= EC_CR - HALO || g < 0 || g >= a.rows) continue;
             const f32x4 v = *(const f32x4*)(S.X + row * EC_XP + 4 * cq);
@@ -317,8 +330,9 @@ __global__ __launch_bounds__(256, 2) void grd_enc_chain_kernel(const EncChainArg
 }
 
 // r = out_proj(att) + res;  y = relu(fc(LayerNorm_e(r))) + r      (x = att, res = the chain's `out`, out = y; row-local)
-template <bool EXACT>
-__global__ __launch_bounds__(256, 2) void grd_attn_tail_kernel(const EncChainArgs a) {
+template <bool EXACT, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void grd_attn_tail_kernel(const EncChainArgs a) {
+    constexpr int NG = 2 * NW, RPG = EC_CR / NG;
     if (EXACT && a.act_bad[0] != a.run_id && a.frag_bad[0] == 0) return;
     __shared__ __attribute__((aligned(16))) EcSmem S;
     unsigned char* Ah = S.A2;
@@ -327,12 +341,12 @@ __global__ __launch_bounds__(256, 2) void grd_attn_tail_kernel(const EncChainArg
     const int cq = tid & 31, rg = tid >> 5;
     const long g0 = (long)blockIdx.x * EC_CR;
     a16x8 wcur[16];
-    if (!EXACT) ec_load_w(a.frag, 4, wave, lane, wcur);
+    if (!EXACT && NW == 4) ec_load_w(a.frag, 4, wave, lane, wcur);
     bool bad = false;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = rg + 8 * i;
+    for (int i = 0; i < RPG; ++i) {
+        const int row = rg + NG * i;
         const long g = g0 + row;
         f32x4 v = zero, r = zero;
         if (g < a.rows) { v = *(const f32x4*)(a.x + g * EC_D + 4 * cq); r = *(const f32x4*)(a.res + g * EC_D + 4 * cq); }
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void grd_attn_tail_kernel(const EncChainArg
         }
     }
     __syncthreads();
-    ec_pointwise<EXACT>(a, S, 4, wcur, 5, tid, [&](int row, int nn0, const f32x4 v) {
+    ec_pointwise<EXACT, NW>(a, S, 4, wcur, 5, tid, [&](int row, int nn0, const f32x4 v) {
         f32x4* xp = (f32x4*)(S.X + row * EC_XP + nn0);
         *xp = v + *xp;                                           // attn + res (:134)
     });
@@ -355,8 +369,8 @@ __global__ __launch_bounds__(256, 2) void grd_attn_tail_kernel(const EncChainArg
     {
         const f32x4 gg = *(const f32x4*)(a.ln_g[5] + 4 * cq), be = *(const f32x4*)(a.ln_b[5] + 4 * cq);
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int row = rg + 8 * rr;
+        for (int rr = 0; rr < RPG; ++rr) {
+            const int row = rg + NG * rr;
             const f32x4 v = *(const f32x4*)(S.X + row * EC_XP + 4 * cq);
             const float2 st = S.stat[row];
             f32x4 o;
@@ -373,14 +387,14 @@ __global__ __launch_bounds__(256, 2) void grd_attn_tail_kernel(const EncChainArg
     }
     __syncthreads();
     // (through the tile, then out by whole rows: stored straight from the accumulator layout every instruction touched 64 different lines)
-    ec_pointwise<EXACT>(a, S, 5, wcur, -1, tid, [&](int row, int nn0, const f32x4 v) {
+    ec_pointwise<EXACT, NW>(a, S, 5, wcur, -1, tid, [&](int row, int nn0, const f32x4 v) {
         f32x4* xp = (f32x4*)(S.X + row * EC_XP + nn0);
         *xp = ec_relu(v) + *xp;                                  // relu(fc) + res (:135-136)
     });
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = rg + 8 * i;
+    for (int i = 0; i < RPG; ++i) {
+        const int row = rg + NG * i;
         const long g = g0 + row;
         if (g < a.rows) *(f32x4*)(a.out + g * EC_D + 4 * cq) = *(const f32x4*)(S.X + row * EC_XP + 4 * cq);
     }
@@ -431,12 +445,15 @@ int grd_enc_chain(hipStream_t s, const Enc& E, const float* x, const float* pos,
     const int tr = EC_CR - 8 * (E.ks / 2);
     const long tiles = (rows + tr - 1) / tr;
     ProfScope ps((void*)s, FAM_GROUNDING, 2.0 * rows * EC_D * 4.0 * EC_D, 4.0 * rows * 3.0 * EC_D);
+    static const int waves = getenv("BIGC_ENC_WAVES") ? atoi(getenv("BIGC_ENC_WAVES")) : 8;
     if (E.ks == 7) {
-        hipLaunchKernelGGL((grd_enc_chain_kernel<7, false>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((grd_enc_chain_kernel<7, true>), dim3((unsigned)tiles), dim3(256), 0, s, a);     // gated: returns at once when no flag is up
+        if (waves == 8) hipLaunchKernelGGL((grd_enc_chain_kernel<7, false, 8>), dim3((unsigned)tiles), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((grd_enc_chain_kernel<7, false, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((grd_enc_chain_kernel<7, true, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);     // gated: returns at once when no flag is up
     } else {
-        hipLaunchKernelGGL((grd_enc_chain_kernel<3, false>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((grd_enc_chain_kernel<3, true>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+        if (waves == 8) hipLaunchKernelGGL((grd_enc_chain_kernel<3, false, 8>), dim3((unsigned)tiles), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((grd_enc_chain_kernel<3, false, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((grd_enc_chain_kernel<3, true, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     }
     BIGC_LAUNCH_CHECK("grd_enc_chain");
     return BIGC_OK;
@@ -450,8 +467,10 @@ int grd_attn_tail(hipStream_t s, const Enc& E, const float* att, const float* re
     a.x = att; a.pos = nullptr; a.res = res; a.out = out; a.ln_out = nullptr;
     const long tiles = (rows + EC_CR - 1) / EC_CR;
     ProfScope ps((void*)s, FAM_GROUNDING, 2.0 * rows * EC_D * 2.0 * EC_D, 4.0 * rows * 3.0 * EC_D);
-    hipLaunchKernelGGL((grd_attn_tail_kernel<false>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((grd_attn_tail_kernel<true>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    static const int waves = getenv("BIGC_ENC_WAVES") ? atoi(getenv("BIGC_ENC_WAVES")) : 8;
+    if (waves == 8) hipLaunchKernelGGL((grd_attn_tail_kernel<false, 8>), dim3((unsigned)tiles), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((grd_attn_tail_kernel<false, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((grd_attn_tail_kernel<true, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     BIGC_LAUNCH_CHECK("grd_attn_tail");
     return BIGC_OK;
 }

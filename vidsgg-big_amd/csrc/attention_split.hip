@@ -315,12 +315,16 @@ __global__ __launch_bounds__(256, 2) void mha_core_h16_long_kernel(const float* 
 // sequence's result does not depend on what else is in the launch.  LDS: K as f16 head / residual planes [key][16] (32 bytes a key),
 // V transposed [column][keys + 8] with the keys of a 32-key tile permuted so that a lane's eight k-slots of the P V MFMA are one
 // 16-byte read.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void mha_core_hd16_lds_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+// CHK: key tiles per chunk of the running maximum (the arithmetic of a sequence is a function of CHK, not of its length or its company);
+// MINW: waves per SIMD the register allocation must allow.  Long sequences run <4, 4, 3>: three four-wave workgroups per CU (50 KB of LDS
+// each at 376 keys) where the eight-wave form with its 8 x 16 score registers fitted one (256 registers): the kernel is VALU-bound and
+// the SIMDs were busy 55 % of the time.
+template <int NW, int CHK = 8, int MINW = 1>
+__global__ __launch_bounds__(64 * NW, MINW) void mha_core_hd16_lds_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                                     const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
                                                                     const int32_t* __restrict__ off, int n_head, float scale, int tp_max,
                                                                     int* __restrict__ flag, int run_id) {
-    constexpr int HD = 16, CH = 8, NTH = 64 * NW;
+    constexpr int HD = 16, CH = CHK, NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char hd16_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int h = blockIdx.x % n_head, s = blockIdx.x / n_head;
@@ -1616,15 +1620,23 @@ int bigc_mha_core_hd16_lds_launch(hipStream_t s, const float* q, int ldq, const 
     // waves per workgroup by the longest sequence (the arithmetic of a sequence does not depend on it: wave w takes the query tiles
     // w, w + NW, ...): one wave for sequences of at most 32 rows (the query encoder's 3 tokens: 8784 workgroups of four waves, three
     // of them idle, took 203 us), two up to 64, four up to 128, eight above
-#define LAUNCH_HD16(NWV) do { static std::atomic<unsigned long long> attr{0}; int dev_ = 0; (void)hipGetDevice(&dev_);      /* one bit per device */ \
+#define LAUNCH_HD16(NWV, ...) do { static std::atomic<unsigned long long> attr{0}; int dev_ = 0; (void)hipGetDevice(&dev_);      /* one bit per device */ \
         if (!((attr.load(std::memory_order_relaxed) >> (dev_ & 63)) & 1ull)) { \
-            (void)hipFuncSetAttribute((const void*)mha_core_hd16_lds_kernel<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+            (void)hipFuncSetAttribute((const void*)mha_core_hd16_lds_kernel<NWV, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
             attr.fetch_or(1ull << (dev_ & 63), std::memory_order_relaxed); } \
-        hipLaunchKernelGGL(mha_core_hd16_lds_kernel<NWV>, dim3(n_seq * n_head), dim3(64 * NWV), lds, s, q, ldq, k, ldk, v, ldv, o, ldo, off, n_head, scale, tp, flag, run_id); } while (0)
+        hipLaunchKernelGGL((mha_core_hd16_lds_kernel<NWV, ##__VA_ARGS__>), dim3(n_seq * n_head), dim3(64 * NWV), lds, s, q, ldq, k, ldk, v, ldv, o, ldo, off, n_head, scale, tp, flag, run_id); } while (0)
+    // (the chunk length is part of a sequence's arithmetic: it must not depend on the batch.  max_q > 128 is a property of the LAUNCH, so
+    // both forms for long launches use the SAME chunk length 4; launches of short sequences only -- the video and the query encoder -- keep 8,
+    // where a sequence of at most 128 keys has at most 4 tiles: one chunk either way, the same bits)
+    // (which of the two long forms runs is a matter of speed only -- a wave does the same work on a query tile in both: eight waves per
+    // sequence when the launch would not fill the chip with four (the video encoder's 8 x 8 workgroups: 20 vs 33 us), four otherwise
+    // (the combined encoder: 314 vs 419 us))
+    static const int long_form = getenv("BIGC_MHA_HD16_LONG") ? atoi(getenv("BIGC_MHA_HD16_LONG")) : 0;
     if (max_q <= 32) LAUNCH_HD16(1);
     else if (max_q <= 64) LAUNCH_HD16(2);
     else if (max_q <= 128) LAUNCH_HD16(4);
-    else LAUNCH_HD16(8);
+    else if (long_form == 8 || (long_form == 0 && (long)n_seq * n_head < 3 * 256)) LAUNCH_HD16(8, 4, 2);
+    else LAUNCH_HD16(4, 4, 3);
 #undef LAUNCH_HD16
     return 1;
 }

@@ -117,6 +117,13 @@ int bigc_layernorm_add_f32(void* stream, const float* x, const float* gamma, con
  * bytes at pitch ldys_bytes); d in {64, 128, 256, 512}; an element with |y| >= 4096 sets *range_flag */
 int bigc_layernorm_hr8_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y, void* ys, long ldys_bytes,
                            int rows, int d, float eps, int* range_flag);
+/* nn.LayerNorm(x + pre): the post-norm residual of a transformer sublayer (`norm1(query + self_attn(..))`, `norm2(query + roles)`,
+ *   `norm3(t2 + ffn(t2))`, models/model_0v10.py:187-188,209-212,218-223) added by the LayerNorm, which reads it by whole rows, instead of by
+ *   the GEMM in front of it (whose lanes own data rows: 16 bytes from each of 32 rows per load).  One f32 addition per element either way:
+ *   the same bits.  y (f32; + add[r % period] when add != NULL, then ys must be NULL) and / or ys (hr8, pitch ldys_bytes); pre may alias y;
+ *   d in {64, 128, 256, 512}. */
+int bigc_layernorm_res_f32(void* stream, const float* x, const float* pre, const float* gamma, const float* beta, float* y, void* ys,
+                           long ldys_bytes, int rows, int d, float eps, const float* add, int period, int* range_flag);
 
 /* y[r, :] = x[r, :] + p[r % period, :]   (query + pos_embedding broadcast over the videos of a batch,
  *   models/model_0v10.py:182,189); x == NULL means zeros (tiles pred_query_init over the batch, :465) */

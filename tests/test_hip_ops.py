@@ -148,6 +148,35 @@ def test_layernorm_add_is_layernorm_then_add_rows(lib, rows, d, period, both):
         assert torch.equal(plain, ln)
 
 
+@pytest.mark.parametrize("rows,d,period", [(1000, 512, 192), (77, 128, 0), (3, 64, 2), (257, 256, 0)])
+def test_layernorm_of_a_sum_is_the_sum_then_layernorm(lib, rows, d, period):
+    """bigc_layernorm_res_f32 (the residual added by the LayerNorm): bit-identical to an f32 addition followed by bigc_layernorm_add_f32 /
+    bigc_layernorm_hr8_f32, also in place (pre aliases y)"""
+    g = torch.Generator().manual_seed(rows + d + period)
+    x, pre, w, b = dev(torch.randn(rows, d, generator=g) * 2), dev(torch.randn(rows, d, generator=g)), dev(torch.randn(d, generator=g)), dev(torch.randn(d, generator=g))
+    summed = x + pre
+    if period:
+        p = dev(torch.randn(period, d, generator=g))
+        want = torch.empty(rows, d, device=DEV)
+        _lib.check(lib.bigc_layernorm_add_f32(S(), summed.data_ptr(), w.data_ptr(), b.data_ptr(), want.data_ptr(), rows, d, 1e-5, p.data_ptr(), period, None))
+        y = pre.clone()                                  # in place: the residual is overwritten by the result
+        _lib.check(lib.bigc_layernorm_res_f32(S(), x.data_ptr(), y.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, 0, rows, d, 1e-5,
+                                              p.data_ptr(), period, None))
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)
+        return
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    want, want_s = torch.empty(rows, d, device=DEV), torch.zeros(rows, 4 * d, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.bigc_layernorm_hr8_f32(S(), summed.data_ptr(), w.data_ptr(), b.data_ptr(), want.data_ptr(), want_s.data_ptr(), 4 * d, rows, d, 1e-5, flag.data_ptr()))
+    y, ys = torch.empty(rows, d, device=DEV), torch.zeros(rows, 4 * d, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.bigc_layernorm_res_f32(S(), x.data_ptr(), pre.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), ys.data_ptr(), 4 * d, rows, d, 1e-5,
+                                          None, 0, flag.data_ptr()))
+    plain = torch.empty(rows, d, device=DEV)
+    _lib.check(lib.bigc_layernorm_res_f32(S(), x.data_ptr(), pre.data_ptr(), w.data_ptr(), b.data_ptr(), plain.data_ptr(), None, 0, rows, d, 1e-5, None, 0, None))
+    torch.cuda.synchronize()
+    assert torch.equal(y, want) and torch.equal(ys, want_s) and torch.equal(plain, want)
+
+
 def test_add_rows(lib):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(36, 16, generator=g)

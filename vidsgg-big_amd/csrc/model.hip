@@ -370,6 +370,8 @@ int bigc_role_fused_proj_hr8_launch(hipStream_t s, const float* p2a, int ldp, co
                                     const int32_t* e_off, int n_vid, int nq, int max_trk, int half, int d, float scale, int* range_flag);
 int bigc_layernorm_hr8(hipStream_t hs, const float* x, const float* gamma, const float* beta, float* y, void* ys, long ldys, int rows, int d,
                        float eps, int* range_flag);
+int bigc_layernorm_res(hipStream_t hs, const float* x, const float* pre, const float* gamma, const float* beta, float* y, void* ys, long ldys,
+                       int rows, int d, float eps, const float* add, int period, int* range_flag);
 
 namespace {
 
@@ -763,6 +765,7 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         // tiles the epilogue needs run the GEMMs LDS-bound (+0.63 ms over the 17 launches; 96-row tiles spill): 19.06 -> 18.86 ms resident,
         // no gain through the API within the run-to-run noise.  Kept for the traffic it removes (3.4 GB per step) and as the starting point of a
         // kernel that feeds W from registers instead of LDS.
+        static const bool ln_res = !(getenv("BIGC_LN_RES") && atoi(getenv("BIGC_LN_RES")) == 0);
         static const bool ln_fused_on = getenv("BIGC_LN_FUSED") && atoi(getenv("BIGC_LN_FUSED")) != 0;
         const bool ln_fused = presplit && ln_fused_on && dp == 512 && df % 32 == 0;
         if (presplit && i > 0) {
@@ -778,8 +781,15 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
                 // residual and overwritten by the lane that read it)
                 TRY(ps_ln(cx, w.ao2, dp, L.out_proj, dp, w.query, dp, nullptr, 0, BQ, dp, dp, w.query, dp, L.n1, eps, m->pos, Q));
             } else {
-                TRY(ps(cx, w.ao2, dp, true, L.out_proj, dp, w.t2, dp, nullptr, 0, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
-                TRY(bigc_layernorm_add_f32(s, w.t2, L.n1.g, L.n1.b, w.query, BQ, dp, eps, m->pos, Q, nullptr));   // query += pos, kept (:189)
+                // (the residual of the three sublayers is added by the LayerNorm behind them, which reads it by whole rows: see layernorm_rows_kernel;
+                // BIGC_LN_RES=0: by the GEMMs' epilogues, the same bits)
+                if (ln_res) {
+                    TRY(ps(cx, w.ao2, dp, true, L.out_proj, dp, w.t2, dp, nullptr, 0, BQ, dp, dp, BIGC_ACT_NONE));
+                    TRY(bigc_layernorm_res(hs, w.t2, w.query, L.n1.g, L.n1.b, w.query, nullptr, 0, BQ, dp, eps, m->pos, Q, nullptr));   // LN(t2 + query) + pos, kept (:187-189)
+                } else {
+                    TRY(ps(cx, w.ao2, dp, true, L.out_proj, dp, w.t2, dp, nullptr, 0, BQ, dp, dp, BIGC_ACT_NONE, w.query, dp));
+                    TRY(bigc_layernorm_add_f32(s, w.t2, L.n1.g, L.n1.b, w.query, BQ, dp, eps, m->pos, Q, nullptr));   // query += pos, kept (:189)
+                }
             }
         } else {
         // layers > 0: qk_in = query + pos was written by the previous layer's last LayerNorm
@@ -820,6 +830,14 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
                 TRY(ps_ln(cx, w.vals, 2 * dp, rc, 2 * dp, w.t2, dp, w.qkins, dp, BQ, dp, 2 * dp, w.query, dp, L.n2, eps));
                 TRY(ps(cx, w.qkins, dp, true, L.f0, dp, nullptr, 0, w.rh, df, BQ, df, dp, BIGC_ACT_RELU));
                 TRY(ps_ln(cx, w.rh, df, L.f3, df, w.query, dp, last ? nullptr : w.querys, dp, BQ, dp, df, w.t2, dp, L.n3, eps));
+                continue;
+            }
+            if (ln_res) {
+                TRY(ps(cx, w.vals, 2 * dp, true, rc, 2 * dp, w.t3, dp, nullptr, 0, BQ, dp, 2 * dp, BIGC_ACT_NONE));
+                TRY(bigc_layernorm_res(hs, w.t3, w.query, L.n2.g, L.n2.b, w.t2, w.qkins, (long)dp * 4, BQ, dp, eps, nullptr, 0, w.flag));      // LN(t3 + query) -> t2 and its split twin
+                TRY(ps(cx, w.qkins, dp, true, L.f0, dp, nullptr, 0, w.rh, df, BQ, df, dp, BIGC_ACT_RELU));
+                TRY(ps(cx, w.rh, df, true, L.f3, df, w.t3, dp, nullptr, 0, BQ, dp, df, BIGC_ACT_NONE));
+                TRY(bigc_layernorm_res(hs, w.t3, w.t2, L.n3.g, L.n3.b, w.query, last ? nullptr : w.querys, (long)dp * 4, BQ, dp, eps, nullptr, 0, w.flag));   // LN(t3 + t2) -> query (and its split twin)
                 continue;
             }
             TRY(ps(cx, w.vals, 2 * dp, true, rc, 2 * dp, w.t3, dp, nullptr, 0, BQ, dp, 2 * dp, BIGC_ACT_NONE, w.query, dp));

@@ -75,7 +75,11 @@ template <int G, int NVL, int UNR, bool ADD, bool HR8 = false>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                              float* __restrict__ y, int rows, float eps,
                                                              const float* __restrict__ add, int period, float* __restrict__ y_plain,
-                                                             unsigned char* __restrict__ ys = nullptr, long ldys = 0, int* __restrict__ range_flag = nullptr) {
+                                                             unsigned char* __restrict__ ys = nullptr, long ldys = 0, int* __restrict__ range_flag = nullptr,
+                                                             const float* __restrict__ pre = nullptr) {
+    // pre != nullptr: the rows are x + pre (a GEMM's output and its residual, models/model_0v10.py:188,211,223: LayerNorm(query + sublayer)).
+    // The sum used to be the GEMM's epilogue; there a lane owns a data ROW, so the residual came in as 16 bytes from each of 32 rows per
+    // load instruction -- 34 of the 129 us of a decoder 512 x 512 GEMM -- while here a row is read by whole lines.  Same f32 addition, same bits.
     constexpr int RPW = 64 / G;                    // rows per wave pass
     constexpr int D4 = G * NVL;                    // float4 per row
     bool oob = false;
@@ -89,6 +93,14 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
         const f32x4* xp = (const f32x4*)x + (size_t)row * D4;
 #pragma unroll
         for (int j = 0; j < NVL; ++j) v[u][j] = xp[gl + G * j];
+    }
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const f32x4* pp = (const f32x4*)pre + (size_t)min(row0 + u * RPW, rows - 1) * D4;
+#pragma unroll
+            for (int j = 0; j < NVL; ++j) v[u][j] += pp[gl + G * j];
+        }
     }
     f32x4 gg[NVL], bb[NVL];
 #pragma unroll
@@ -210,6 +222,34 @@ int bigc_layernorm_hr8(hipStream_t hs, const float* x, const float* gamma, const
 #undef LN_HR8
     BIGC_LAUNCH_CHECK("layernorm_hr8");
     return BIGC_OK;
+}
+
+// LayerNorm(x + pre) -> y (f32, + add[row % period] when `add` is given) and / or ys (split form); `pre` may alias y (a row is read before it
+// is written, by the lanes that write it).  d in {64, 128, 256, 512}.
+int bigc_layernorm_res(hipStream_t hs, const float* x, const float* pre, const float* gamma, const float* beta, float* y, void* ys, long ldys,
+                       int rows, int d, float eps, const float* add, int period, int* range_flag) {
+    BIGC_CHECK_ARG(x && pre && gamma && beta && (y || ys) && !(add && ys) && (!add || period > 0), "layernorm_res: bad argument");
+    BIGC_CHECK_ARG(d == 512 || d == 256 || d == 128 || d == 64, "layernorm_res: d=%d not in {64, 128, 256, 512}", d);
+    BIGC_CHECK_ARG(!ys || (ldys % 16 == 0 && ldys >= 4L * d), "layernorm_res: bad split-form pitch");
+    if (rows <= 0) return BIGC_OK;
+    ProfScope ps((void*)hs, FAM_LAYERNORM, 0.0, ((y && ys) ? 16.0 : 12.0) * rows * (double)d);
+#define LN_RES(G, NVL, UNR) do { \
+        const dim3 grid(cdiv(rows, 4 * (64 / G) * UNR)); \
+        if (ys) hipLaunchKernelGGL((layernorm_rows_kernel<G, NVL, UNR, false, true>), grid, dim3(256), 0, hs, x, gamma, beta, y, rows, eps, nullptr, 0, nullptr, (unsigned char*)ys, ldys, range_flag, pre); \
+        else if (add) hipLaunchKernelGGL((layernorm_rows_kernel<G, NVL, UNR, true, false>), grid, dim3(256), 0, hs, x, gamma, beta, y, rows, eps, add, period, nullptr, nullptr, 0L, nullptr, pre); \
+        else hipLaunchKernelGGL((layernorm_rows_kernel<G, NVL, UNR, false, false>), grid, dim3(256), 0, hs, x, gamma, beta, y, rows, eps, nullptr, 0, nullptr, nullptr, 0L, nullptr, pre); } while (0)
+    if (d == 512) LN_RES(64, 2, 4);
+    else if (d == 256) LN_RES(64, 1, 4);
+    else if (d == 128) LN_RES(32, 1, 4);
+    else LN_RES(16, 1, 4);
+#undef LN_RES
+    BIGC_LAUNCH_CHECK("layernorm_res");
+    return BIGC_OK;
+}
+
+extern "C" int bigc_layernorm_res_f32(void* stream, const float* x, const float* pre, const float* gamma, const float* beta, float* y, void* ys,
+                                      long ldys_bytes, int rows, int d, float eps, const float* add, int period, int* range_flag) {
+    return bigc_layernorm_res((hipStream_t)stream, x, pre, gamma, beta, y, ys, ldys_bytes, rows, d, eps, add, period, range_flag);
 }
 
 extern "C" int bigc_layernorm_hr8_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y, void* ys, long ldys_bytes,

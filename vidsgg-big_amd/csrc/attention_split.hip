@@ -824,7 +824,11 @@ __global__ __launch_bounds__(64 * NW) void mha_core_lds16_kernel(const float* __
                                                                  const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
                                                                  const int32_t* __restrict__ off, int n_head, float scale,
                                                                  float* __restrict__ lse, const DropSpec drop, int* __restrict__ flag, int run_id,
-                                                                 unsigned char* __restrict__ os = nullptr, long ldos = 0, int* __restrict__ range_flag = nullptr) {
+                                                                 unsigned char* __restrict__ os = nullptr, long ldos = 0, int* __restrict__ range_flag = nullptr,
+                                                                 const float* __restrict__ qpos = nullptr, const float* __restrict__ kpos = nullptr, int ldpos = 0) {
+    // qpos / kpos != nullptr: q and k are read as q + qpos[position in the sequence], k + kpos[position] (the decoder's `q = k = query + pos`,
+    // models/model_0v10.py:181-183, as W query + W pos: the second term used to enter the q / k / v GEMM as a per-video periodic residual, 16
+    // bytes from each of 32 rows per load in a kernel whose lanes own data rows; here a row is read whole.  One f32 addition either way.)
     // os != nullptr: the output goes out in the split form "hr8" of csrc/gemm_ps.hip (row pitch ldos bytes) INSTEAD of f32 -- its only
     // reader is the out_proj GEMM -- and an operand or result outside the form's range raises *range_flag (the step is then redone on
     // the exact path, there is no f32 fallback launch behind this one)
@@ -854,6 +858,11 @@ __global__ __launch_bounds__(64 * NW) void mha_core_lds16_kernel(const float* __
             const float* kp = kb + (size_t)min(key, nq - 1) * ldk + 8 * c;
             kraw[r][0] = *(const f32x4*)kp;
             kraw[r][1] = *(const f32x4*)(kp + 4);
+            if (kpos) {
+                const float* pp = kpos + (size_t)min(key, nq - 1) * ldpos + h * HD + 8 * c;
+                kraw[r][0] += *(const f32x4*)pp;
+                kraw[r][1] += *(const f32x4*)(pp + 4);
+            }
         }
 #pragma unroll
         for (int r = 0; r < VGROUPS; ++r) {
@@ -895,7 +904,12 @@ __global__ __launch_bounds__(64 * NW) void mha_core_lds16_kernel(const float* __
         const float* qp = q + (size_t)(q0 + qrow) * ldq + h * HD + 8 * g;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            const f32x4 t0 = *(const f32x4*)(qp + 32 * st), t1 = *(const f32x4*)(qp + 32 * st + 4);
+            f32x4 t0 = *(const f32x4*)(qp + 32 * st), t1 = *(const f32x4*)(qp + 32 * st + 4);
+            if (qpos) {
+                const float* pp = qpos + (size_t)qrow * ldpos + h * HD + 8 * g + 32 * st;
+                t0 += *(const f32x4*)pp;
+                t1 += *(const f32x4*)(pp + 4);
+            }
             const float x[8] = {t0[0] * scale, t0[1] * scale, t0[2] * scale, t0[3] * scale, t1[0] * scale, t1[1] * scale, t1[2] * scale, t1[3] * scale};
             split8(x, qh[st], qr[st], chk, amax);
         }
@@ -1578,7 +1592,8 @@ int bigc_mha_core_h16_launch(hipStream_t s, const float* q, int ldq, const float
 // Self-attention core (head_dim 64, at most 192 keys per sequence) with the output in the split form "hr8" for the out_proj GEMM on
 // pre-split operands; returns 0 when the shape is outside what the LDS kernel covers (the caller then uses the f32 path)
 int bigc_mha_core_hr8_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, void* os, long ldos,
-                             const int32_t* q_off, int n_seq, int max_q, int n_head, int hd, int* range_flag) {
+                             const int32_t* q_off, int n_seq, int max_q, int n_head, int hd, int* range_flag,
+                             const float* qpos, const float* kpos, int ldpos) {
     const int n_qt = (max_q + 31) / 32;
     if (hd != 64 || n_qt > 6 || n_seq <= 0 || !os || ldos % 16 != 0) return 0;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -1587,7 +1602,7 @@ int bigc_mha_core_hr8_launch(hipStream_t s, const float* q, int ldq, const float
     if (!flag) return 0;
     DropSpec drop = make_drop(0.f, 0, 0);
     ProfScope ps((void*)s, FAM_MHA, 0.0, 0.0);
-#define LAUNCH_L16H(NW) hipLaunchKernelGGL((mha_core_lds16_kernel<NW, false>), dim3(n_seq * n_head), dim3(64 * NW), 0, s, q, ldq, k, ldk, v, ldv, (float*)nullptr, 0, q_off, n_head, scale, (float*)nullptr, drop, flag, run_id, (unsigned char*)os, ldos, range_flag)
+#define LAUNCH_L16H(NW) hipLaunchKernelGGL((mha_core_lds16_kernel<NW, false>), dim3(n_seq * n_head), dim3(64 * NW), 0, s, q, ldq, k, ldk, v, ldv, (float*)nullptr, 0, q_off, n_head, scale, (float*)nullptr, drop, flag, run_id, (unsigned char*)os, ldos, range_flag, qpos, kpos, ldpos)
     if (n_qt <= 2) LAUNCH_L16H(4); else LAUNCH_L16H(12);
 #undef LAUNCH_L16H
     return 1;

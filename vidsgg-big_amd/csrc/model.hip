@@ -364,7 +364,8 @@ static int build_qkpos(bigc_model* m, void* stream) {
 // (LayerNorm, attention, max-pool, the raw features) enter a GEMM through its in-loop split (A mode 2).
 // ------------------------------------------------------------------------------------------------
 int bigc_mha_core_hr8_launch(hipStream_t s, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, void* os, long ldos,
-                             const int32_t* q_off, int n_seq, int max_q, int n_head, int hd, int* range_flag);
+                             const int32_t* q_off, int n_seq, int max_q, int n_head, int hd, int* range_flag,
+                             const float* qpos = nullptr, const float* kpos = nullptr, int ldpos = 0);
 int bigc_role_fused_proj_hr8_launch(hipStream_t s, const float* p2a, int ldp, const float* e2a, int lde, const float* rhs, int ldrhs, long role_stride,
                                     const float* vbias0, const float* vbias1, int relu, float* att, void* vals_s, long ldvs, long out_role_stride,
                                     const int32_t* e_off, int n_vid, int nq, int max_trk, int half, int d, float scale, int* range_flag);
@@ -771,10 +772,15 @@ extern "C" int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, vo
         if (presplit && i > 0) {
             TRY(build_qkpos(m, s));
             // w.querys = the split twin of w.query, written by the previous layer's last LayerNorm
-            TRY(ps(cx, w.querys, dp, true, L.in_proj, dp, w.qk, 3 * dp, nullptr, 0, BQ, 3 * dp, dp, BIGC_ACT_NONE,
-                   m->qkpos + (size_t)Q * 3 * dp * i, 3 * dp, nullptr, 1, Q));
+            // (W pos, the position term of q and k, is added where q and k are READ -- the attention core stages whole rows -- instead of by
+            // the GEMM's epilogue as a periodic residual; BIGC_QKPOS_MHA=0: by the epilogue, the same bits)
+            static const bool qkpos_mha = !(getenv("BIGC_QKPOS_MHA") && atoi(getenv("BIGC_QKPOS_MHA")) == 0);
+            const float* qkp_i = m->qkpos + (size_t)Q * 3 * dp * i;
+            if (qkpos_mha) TRY(ps(cx, w.querys, dp, true, L.in_proj, dp, w.qk, 3 * dp, nullptr, 0, BQ, 3 * dp, dp, BIGC_ACT_NONE));
+            else TRY(ps(cx, w.querys, dp, true, L.in_proj, dp, w.qk, 3 * dp, nullptr, 0, BQ, 3 * dp, dp, BIGC_ACT_NONE, qkp_i, 3 * dp, nullptr, 1, Q));
             bigc_prof_hint(4.0 * BQ * (double)Q * dp, 16.0 * BQ * (double)dp);          // B sequences of Q queries: 4 Q^2 dp flop each; q | k | v read, o written
-            if (!bigc_mha_core_hr8_launch(hs, w.qk, 3 * dp, w.qk + dp, 3 * dp, w.qk + 2 * dp, 3 * dp, w.ao2, (long)dp * 4, w.q_off, B, Q, H, dp / H, w.flag))
+            if (!bigc_mha_core_hr8_launch(hs, w.qk, 3 * dp, w.qk + dp, 3 * dp, w.qk + 2 * dp, 3 * dp, w.ao2, (long)dp * 4, w.q_off, B, Q, H, dp / H, w.flag,
+                                          qkpos_mha ? qkp_i : nullptr, qkpos_mha ? qkp_i + dp : nullptr, 3 * dp))
                 return bigc_fail(BIGC_ERR_ARG, "forward: self-attention shape outside the split-output kernel");
             if (ln_fused) {
                 // out_proj, + query, norm1, + pos (:187-189) in ONE launch: the row's LayerNorm is the GEMM's epilogue (query is read as the

@@ -218,6 +218,36 @@ def test_mha_core(lib, hd, H, lens):
     assert rel_err(o, want) < 5e-6
 
 
+def test_mha_core_hd16_sequence_does_not_depend_on_its_launch(lib):
+    """head_dim 16 (the grounding scorer's attention): a sequence's output must not depend on what else is in the launch -- the launcher
+    picks the waves per workgroup from the longest sequence and, for long launches, from the NUMBER of sequences (eight waves per
+    sequence for small launches, four above 96 sequences of 8 heads), and walks the keys in chunks whose length is fixed per class.  The
+    same three sequences (200, 130 and 90 keys) alone, and as the first three of 120: identical bits."""
+    hd, H = 16, 8
+    d = hd * H
+    g = torch.Generator().manual_seed(77)
+    base = [200, 130, 90]
+    many = base + [int(v) for v in torch.randint(129, 380, (117,), generator=g)]
+    qkv = torch.randn(sum(many), 3 * d, generator=g)
+    qd = dev(qkv)
+
+    def run(lens):
+        n = sum(lens)
+        off = i32(np.concatenate([[0], np.cumsum(lens)]))
+        o = torch.full((n, d), float("nan"), device=DEV)
+        _lib.check(lib.bigc_mha_core_f32(S(), qd.data_ptr(), 3 * d, qd.data_ptr() + 4 * d, 3 * d, qd.data_ptr() + 8 * d, 3 * d,
+                                         o.data_ptr(), d, off.data_ptr(), off.data_ptr(), len(lens), max(lens), H, hd, None))
+        torch.cuda.synchronize()
+        return o
+    few, lots = run(base), run(many)
+    assert not torch.isnan(lots).any()
+    assert torch.equal(few, lots[:sum(base)])
+    # ... and a short sequence (<= 128 keys: one chunk in every class) next to long ones equals the same sequence in a launch of short ones
+    short_alone = run([90])            # rows 0 .. 89 of qkv = the first 90 rows of the 200-key sequence: another sequence, same kernel class check
+    mixed = run([90, 200])
+    assert torch.equal(short_alone, mixed[:90])
+
+
 @pytest.mark.parametrize("lens", [[40, 64], [150, 20]])
 def test_mha_core_out_of_range_falls_back_to_f32(lib, lens):
     """head_dim 64 runs on split f16 operands; a value beyond the f16 range (here 1e5 in v, 4e4 in k) must hand the

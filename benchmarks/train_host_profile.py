@@ -10,7 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
+import bench  # noqa: E402  (bench re-exports make_train_job / train_step_fn from benchmarks/legs/train.py)
 
 
 def main():

@@ -28,6 +28,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: the functions marked BIGC_API below are its ONLY dynamic symbols
+ * (tests/test_host_cpu.py compares `nm -D --defined-only` with this header's list, both ways). */
+#define BIGC_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -40,20 +44,20 @@ typedef enum {
     BIGC_ERR_WORKSPACE = -4  /* workspace too small */
 } bigc_status;
 
-const char* bigc_last_error(void);
+BIGC_API const char* bigc_last_error(void);
 /* "bigc_hip gfx950 ... <build id>" -- lets the host verify it loaded the HIP build */
-const char* bigc_build_info(void);
+BIGC_API const char* bigc_build_info(void);
 
 /* Optional per-kernel-family timing with HIP events recorded on the caller's stream around every
  * launch (bench.py's roofline figure). Off by default; bigc_prof_collect() must be called after the
  * stream has been synchronised, it folds the recorded pairs into per-family totals.
  * bigc_prof_get: ms = summed launch durations, flops/bytes = summed ALGORITHMIC work of those launches. */
-void bigc_prof_enable(int on);
-void bigc_prof_reset(void);
-int bigc_prof_collect(void);
-int bigc_prof_get(int family, double* ms, long long* launches, double* flops, double* bytes);
-int bigc_prof_family_count(void);
-const char* bigc_prof_family_name(int family);
+BIGC_API void bigc_prof_enable(int on);
+BIGC_API void bigc_prof_reset(void);
+BIGC_API int bigc_prof_collect(void);
+BIGC_API int bigc_prof_get(int family, double* ms, long long* launches, double* flops, double* bytes);
+BIGC_API int bigc_prof_family_count(void);
+BIGC_API const char* bigc_prof_family_name(int family);
 
 /* ------------------------------------------------------------------------------------
  * Kernel-level entry points (one per hand-written kernel family).  The model-level
@@ -75,7 +79,7 @@ const char* bigc_prof_family_name(int family);
  *   W is row-major (N, K) with leading dimension ldw (the torch weight layout).
  *   bias / residual may be NULL. The residual is added AFTER the activation.
  *   K must be a multiple of 4; lda, ldw multiples of 4; A and W 16-byte aligned. */
-int bigc_linear_f32(void* stream, const float* A, int lda, const int32_t* a_idx, int nseg, int seg_len,
+BIGC_API int bigc_linear_f32(void* stream, const float* A, int lda, const int32_t* a_idx, int nseg, int seg_len,
                     const float* W, int ldw, const float* bias, const float* residual, int ldr,
                     float* C, int ldc, int M, int N, int K, int act);
 
@@ -83,16 +87,16 @@ int bigc_linear_f32(void* stream, const float* A, int lda, const int32_t* a_idx,
  * matrix cores on exactly split f32 operands (default; f32-level error, see csrc/linear_split.hip, csrc/attention_split.hip),
  * 1 = the exact f32 MFMA kernels.  Initial value from the environment variable
  * BIGC_LINEAR_EXACT.  bigc_linear_set_exact returns the previous mode. */
-int bigc_linear_set_exact(int exact);
-int bigc_linear_get_exact(void);
+BIGC_API int bigc_linear_set_exact(int exact);
+BIGC_API int bigc_linear_get_exact(void);
 /* Opt-in reduced-precision modes of the GEMMs (never the default; also env BIGC_FAST = 1 | f16 | 2 | bf16): fast = 1: operands rounded
  * to ONE f16 each (11-bit mantissa), one f16 MFMA per product instead of three, f32 accumulation; fast = 2: the literal bf16
  * arithmetic (operands rounded to one bf16, one bf16 MFMA per product; model forwards then do not chain GEMMs through the f16 split
  * form).  These are the "bf16 fast mode" of the survey's build plan (BASELINE configs[1]): they do NOT
  * meet the 1e-4 logit tolerance and are gated on Recall@50 parity instead (tests/test_hip_fast.py).  Ignored while the exact mode is
  * on.  bigc_linear_set_fast returns the previous mode; bigc_linear_get_fast the mode in effect (0, 1 or 2). */
-int bigc_linear_set_fast(int fast);
-int bigc_linear_get_fast(void);
+BIGC_API int bigc_linear_set_fast(int fast);
+BIGC_API int bigc_linear_get_fast(void);
 /* Accumulation policy of the model forwards' GEMMs on pre-split operands (bigc_forward, the nn.Linear / nn.Conv1d products of
  * models/model_0v10.py:446-458,178-225; process-wide, also env BIGC_ACCUM = plain | k1024 | front | nodecoder | blocked):
  * 4 = blocked (default): every such GEMM sums K in blocks of 128 that are folded into a running total, so that no product of the path
@@ -100,34 +104,34 @@ int bigc_linear_get_fast(void);
  * 0 = plain: one f32 accumulator per element on the largest tiles (faster: 19.6 against 20.7 ms per 256 videos; up to 2e-4 from
  * float64 on the videos whose sharp attention amplifies round-off); 1 / 2 / 3: blocked for K >= 1024 only / for M >= 100 000 rows only /
  * for all but the decoder's GEMMs.  Returns the previous policy. */
-int bigc_set_accum_policy(int policy);
-int bigc_get_accum_policy(void);
+BIGC_API int bigc_set_accum_policy(int policy);
+BIGC_API int bigc_get_accum_policy(void);
 
 /* y[r, :] = LayerNorm(x[r, :]) * gamma + beta over d columns, eps inside the sqrt
  *   (torch.nn.LayerNorm, models/model_0v10.py:81-82,171-173). d <= 2048, d % 4 == 0. */
-int bigc_layernorm_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y,
+BIGC_API int bigc_layernorm_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y,
                        int rows, int d, float eps);
 
 /* LayerNorm fused with the decoder's broadcast add: y[r, :] = LayerNorm(x[r, :]) + add[r % period, :] and, when y_plain is
  *   not NULL, y_plain[r, :] = LayerNorm(x[r, :]) as well  (norm1 followed by `query + pos_embedding`, models/model_0v10.py:187-189;
  *   norm3 of layer i feeding `q = k = query + pos` of layer i + 1, :181).  add == NULL: plain LayerNorm (y_plain must be NULL). */
-int bigc_layernorm_add_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y, int rows, int d,
+BIGC_API int bigc_layernorm_add_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y, int rows, int d,
                            float eps, const float* add, int period, float* y_plain);
 /* nn.LayerNorm whose result the next GEMM reads in the split form "hr8" of bigc_gemm_ps: y (f32, may be NULL) and ys (hr8 rows of d * 4
  * bytes at pitch ldys_bytes); d in {64, 128, 256, 512}; an element with |y| >= 4096 sets *range_flag */
-int bigc_layernorm_hr8_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y, void* ys, long ldys_bytes,
+BIGC_API int bigc_layernorm_hr8_f32(void* stream, const float* x, const float* gamma, const float* beta, float* y, void* ys, long ldys_bytes,
                            int rows, int d, float eps, int* range_flag);
 /* nn.LayerNorm(x + pre): the post-norm residual of a transformer sublayer (`norm1(query + self_attn(..))`, `norm2(query + roles)`,
  *   `norm3(t2 + ffn(t2))`, models/model_0v10.py:187-188,209-212,218-223) added by the LayerNorm, which reads it by whole rows, instead of by
  *   the GEMM in front of it (whose lanes own data rows: 16 bytes from each of 32 rows per load).  One f32 addition per element either way:
  *   the same bits.  y (f32; + add[r % period] when add != NULL, then ys must be NULL) and / or ys (hr8, pitch ldys_bytes); pre may alias y;
  *   d in {64, 128, 256, 512}. */
-int bigc_layernorm_res_f32(void* stream, const float* x, const float* pre, const float* gamma, const float* beta, float* y, void* ys,
+BIGC_API int bigc_layernorm_res_f32(void* stream, const float* x, const float* pre, const float* gamma, const float* beta, float* y, void* ys,
                            long ldys_bytes, int rows, int d, float eps, const float* add, int period, int* range_flag);
 
 /* y[r, :] = x[r, :] + p[r % period, :]   (query + pos_embedding broadcast over the videos of a batch,
  *   models/model_0v10.py:182,189); x == NULL means zeros (tiles pred_query_init over the batch, :465) */
-int bigc_add_rows_f32(void* stream, const float* x, const float* p, float* y, int rows, int d, int period);
+BIGC_API int bigc_add_rows_f32(void* stream, const float* x, const float* p, float* y, int rows, int d, int period);
 
 /* Multi-head attention core for ragged sequences (torch.nn.MultiheadAttention after the
  *   in-projection and before out_proj: softmax(q k^T / sqrt(hd)) v, models/model_0v10.py:109,183;
@@ -135,7 +139,7 @@ int bigc_add_rows_f32(void* stream, const float* x, const float* p, float* y, in
  *   rows [k_off[s], k_off[s+1]) of k/v; head h uses columns [h*hd, (h+1)*hd).
  *   hd in {8, 16, 32, 64}. lse (total query rows, n_head), optional: log-sum-exp of the scaled scores
  *   (saved for bigc_mha_bwd_f32). */
-int bigc_mha_core_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+BIGC_API int bigc_mha_core_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                       float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
                       int n_head, int hd, float* lse);
 
@@ -144,18 +148,18 @@ int bigc_mha_core_f32(void* stream, const float* q, int ldq, const float* k, int
  *   att_r = softmax_n(s_r) * softmax_r(s)[r]
  *   Video v owns query rows [v*nq, (v+1)*nq) of p2a and entity rows [e_off[v], e_off[v+1]) of e2a;
  *   att is stored per video as (2, nq, N_v) at float offset 2*nq*e_off[v]. */
-int bigc_role_attention_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, float* att,
+BIGC_API int bigc_role_attention_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, float* att,
                             const int32_t* e_off, int n_vid, int nq, int half, float scale);
 
 /* values[r][v*nq + q, :] = att_v[r, q, :] @ enco[e_off[v]:e_off[v+1], :]   (models/model_0v10.py:211)
  *   values is (2, n_vid*nq, d) contiguous. */
-int bigc_role_values_f32(void* stream, const float* att, const float* enco, int lde, float* values,
+BIGC_API int bigc_role_values_f32(void* stream, const float* att, const float* enco, int lde, float* values,
                          const int32_t* e_off, int n_vid, int nq, int d);
 
 /* role attention and its values in one launch for videos of at most 64 entities (max_ent = the largest entity count of
  * the batch): same results as bigc_role_attention_f32 followed by bigc_role_values_f32; att may be NULL when only the
  * values are needed (every decoder layer but the last, models/model_0v10.py:467). */
-int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc,
+BIGC_API int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* enco, int ldenc,
                         float* att, float* values, const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d, float scale);
 /* The same with the first role-wise linear folded in (models/model_0v10.py:204-208): values_r = act(att_r @ proj_r + bias_r),
  * where proj_r = enco_output W_r^T was computed by the caller on the n_trk entity rows ((att_r @ enco) W^T = att_r @ (enco W^T));
@@ -163,7 +167,7 @@ int bigc_role_fused_f32(void* stream, const float* p2a, int ldp, const float* e2
  * values row (v, q) of role r is written at values + r * out_role_stride + (v * nq + q) * ldval (ldval = 0: the role planes
  * (2, n_vid * nq, d) of bigc_role_fused_f32; out_role_stride = d, ldval = 2 d: the two roles side by side in one row, the A operand
  * of a K = 2 d GEMM).  nq <= 192 and half <= 256 take the split-operand LDS kernel, anything else (and exact mode) the f32-MFMA kernel. */
-int bigc_role_fused_proj_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* proj, int ldproj,
+BIGC_API int bigc_role_fused_proj_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* proj, int ldproj,
                              long role_stride, const float* bias0, const float* bias1, int relu, float* att, float* values,
                              long out_role_stride, int ldval, const int32_t* e_off, int n_vid, int nq, int max_ent, int half, int d,
                              float scale);
@@ -173,7 +177,7 @@ int bigc_role_fused_proj_f32(void* stream, const float* p2a, int ldp, const floa
 /* (R,4) xyxy pixel boxes -> (R,8) [cx,dcx,cy,dcy,w,dw,h,dh], boxes divided by the video's (w,h),
  *   forward differences inside each tracklet with 0 at the tracklet's last frame
  *   (models/model_0v10.py:401-420). trk_row_off (NT+1), trk_vid (NT), vid_wh (B,2). */
-int bigc_bbox_feat_f32(void* stream, const float* boxes, const int32_t* trk_row_off, const int32_t* trk_vid,
+BIGC_API int bigc_bbox_feat_f32(void* stream, const float* boxes, const int32_t* trk_row_off, const int32_t* trk_vid,
                        const float* vid_wh, float* out, int n_trk);
 
 /* Row gather table of the stride-2 k=3 temporal conv over the virtually stretched sequence
@@ -181,18 +185,18 @@ int bigc_bbox_feat_f32(void* stream, const float* boxes, const int32_t* trk_row_
  *   (0 <= j < T_o = (Tmax-1)/2+1), tap c in {0,1,2}: stretched frame f = 2j-1+c; entry is -1 when
  *   f < 0 or f >= Tmax, else trk_row_off[t] + src(f) with src the stretch map.
  *   conv_idx is (C,3) with C = trk_conv_off[n_trk]. */
-int bigc_conv_index(void* stream, const int32_t* trk_row_off, const int32_t* trk_conv_off, const int32_t* trk_vid,
+BIGC_API int bigc_conv_index(void* stream, const int32_t* trk_row_off, const int32_t* trk_conv_off, const int32_t* trk_vid,
                     const int32_t* vid_tmax, int32_t* conv_idx, int n_trk);
 
 /* adaptive_max_pool1d(T_o -> P) per tracklet and channel, stored channel-major (index c*P+p)
  *   (models/model_0v10.py:456-457). conv (C, d) row-major; pooled (NT, d*P). */
-int bigc_adaptive_maxpool(void* stream, const float* conv, const int32_t* trk_conv_off, float* pooled,
+BIGC_API int bigc_adaptive_maxpool(void* stream, const float* conv, const int32_t* trk_conv_off, float* pooled,
                           int n_trk, int d, int P);
 
 /* Mean over the Tmax stretched frames of columns [col0, col0+w) of the tracklet's feature rows
  *   (models/model_0v10.py:470 I3D mean; models/model_0v7.py:473 classeme mean): a weighted mean
  *   with the stretch repeat counts. out (NT, w). */
-int bigc_stretched_mean(void* stream, const float* feats, int ldf, int col0, int w, const int32_t* trk_row_off,
+BIGC_API int bigc_stretched_mean(void* stream, const float* feats, int ldf, int col0, int w, const int32_t* trk_row_off,
                         const int32_t* trk_vid, const int32_t* vid_tmax, float* out, int n_trk);
 
 /* Prediction-head gather (models/model_0v10.py:485-503, models/model_0v7.py:485-508):
@@ -200,7 +204,7 @@ int bigc_stretched_mean(void* stream, const float* feats, int ldf, int col0, int
  *   [query | seg_1[s] | seg_1[o] | seg_2[s] | seg_2[o] | ...] is written to head_in, where segment i
  *   is a per-tracklet table (src[i], width[i]) indexed by the tracklet (by_cat[i]==0) or a per-category
  *   table indexed by cat id (by_cat[i]==1); bias_out[row, :] = bias_matrix[cat_s, cat_o, :]. */
-int bigc_head_gather(void* stream, const float* att, const int32_t* e_off, const int32_t* trk_cat, int n_vid, int nq,
+BIGC_API int bigc_head_gather(void* stream, const float* att, const int32_t* e_off, const int32_t* trk_cat, int n_vid, int nq,
                      const float* query, int dq, int n_seg, const float* const* seg_src_host, const int32_t* seg_width_host,
                      const int32_t* seg_by_cat_host, const float* bias_matrix, int n_ecat, int n_pcat,
                      int32_t* soid, float* head_in, int ld_head, float* bias_out);
@@ -211,7 +215,7 @@ int bigc_head_gather(void* stream, const float* att, const int32_t* e_off, const
  *   highest-probability candidate as representative, background predicate (0) dropped.
  *   Outputs are padded to cap = nq*topk rows per video; n_out[v] rows are valid (0 => the reference
  *   returns None).  quint (B,cap,5) i32, scores (B,cap,3) f32, dura (B,cap,2) i32, qid (B,cap) i32. */
-int bigc_construct_triplets(void* stream, const float* logits, int n_pcat, const int32_t* soid, const int32_t* e_off,
+BIGC_API int bigc_construct_triplets(void* stream, const float* logits, int n_pcat, const int32_t* soid, const int32_t* e_off,
                             const int32_t* trk_dura, const int32_t* trk_cat, const float* trk_score, int n_vid, int nq,
                             int topk, int32_t* quint, float* scores, int32_t* dura, int32_t* qid, int32_t* n_out);
 
@@ -231,17 +235,17 @@ typedef struct {
 
 typedef struct bigc_model bigc_model;
 
-int bigc_create(const bigc_config* cfg, bigc_model** out);
-void bigc_destroy(bigc_model* m);
+BIGC_API int bigc_create(const bigc_config* cfg, bigc_model** out);
+BIGC_API void bigc_destroy(bigc_model* m);
 /* register a parameter by its reference state_dict key; the pointer must stay valid */
-int bigc_set_param(bigc_model* m, const char* key, const float* ptr, int64_t numel);
+BIGC_API int bigc_set_param(bigc_model* m, const char* key, const float* ptr, int64_t numel);
 /* resolve all keys, build derived device tables (tap-major conv weight); call again after weights change */
-int bigc_finalize(bigc_model* m, void* stream);
+BIGC_API int bigc_finalize(bigc_model* m, void* stream);
 /* This handle's arithmetic mode: exact (1 = every GEMM / attention kernel on the f32 MFMA) and fast (1 / 2 = the opt-in f16 / bf16
  * reduced-precision GEMMs), each -1 to follow the process-wide default of bigc_linear_set_exact / bigc_linear_set_fast.  The mode applies to the calls
  * made THROUGH the handle (bigc_forward, bigc_train_*, bigc_pair_*), on the calling thread only: handles are independent of each
  * other (one per GPU and thread, as the reference's DataParallel runs its replicas, utils/DataParallel.py:68). */
-int bigc_set_mode(bigc_model* m, int exact, int fast);
+BIGC_API int bigc_set_mode(bigc_model* m, int exact, int fast);
 
 /* One packed batch of videos: the device-resident ragged tracklet store. */
 typedef struct {
@@ -295,9 +299,9 @@ typedef struct {
 
 /* 1 if bigc_forward with a range_flag output, on this handle in its current arithmetic mode, takes a batch WITHOUT the packed f32 rows
  * (bigc_batch.feats == NULL): the visual features in the split form (feats_hr8 + extra) or read in place (feat_row_ptr); else 0 */
-int bigc_forward_reads_hr8(const bigc_model* m);
-size_t bigc_workspace_bytes(const bigc_model* m, const bigc_batch* b);
-int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
+BIGC_API int bigc_forward_reads_hr8(const bigc_model* m);
+BIGC_API size_t bigc_workspace_bytes(const bigc_model* m, const bigc_batch* b);
+BIGC_API int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                  int topk, const bigc_outputs* out);
 
 /* ------------------------------------------------------------------------------------
@@ -307,64 +311,64 @@ int bigc_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspa
  * ---------------------------------------------------------------------------------- */
 
 /* out (cols, rows) = in (rows, cols)^T */
-int bigc_transpose_f32(void* stream, const float* in, float* out, int rows, int cols);
+BIGC_API int bigc_transpose_f32(void* stream, const float* in, float* out, int rows, int cols);
 /* dW[n,k] += sum_m dY[m,n] X'[m,k] (X' optionally segment-gathered like bigc_linear_f32) and, if db != NULL,
  *   db[n] += sum_m dY[m,n]: weight/bias gradient of every nn.Linear / the conv; fp32 atomic accumulation. */
-int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const float* X, int ldx, const int32_t* x_idx, int nseg, int seg_len,
+BIGC_API int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const float* X, int ldx, const int32_t* x_idx, int nseg, int seg_len,
                        float* dW, int ldw, float* db, int M, int N, int K);
 /* dY *= (Y > 0) with Y the post-ReLU activation; n % 4 == 0 */
-int bigc_relu_bwd_f32(void* stream, float* dY, const float* Y, long n);
+BIGC_API int bigc_relu_bwd_f32(void* stream, float* dY, const float* Y, long n);
 /* y += x; n % 4 == 0 */
-int bigc_axpy_f32(void* stream, float* y, const float* x, long n);
+BIGC_API int bigc_axpy_f32(void* stream, float* y, const float* x, long n);
 /* nn.LayerNorm backward: dx (rows,d); dgamma, dbeta accumulated */
-int bigc_layernorm_bwd_f32(void* stream, const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
+BIGC_API int bigc_layernorm_bwd_f32(void* stream, const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
                            int rows, int d, float eps);
 /* out[r % period, :] += x[r, :] summed over r (gradients of pos_embedding / pred_query_init, shared by all videos) */
-int bigc_reduce_periodic_f32(void* stream, const float* x, float* out, int rows, int d, int period);
+BIGC_API int bigc_reduce_periodic_f32(void* stream, const float* x, float* out, int rows, int d, int period);
 /* adaptive_max_pool1d backward (first maximum of each window); dconv (C,d) is fully overwritten */
-int bigc_maxpool_bwd_f32(void* stream, const float* conv, const int32_t* trk_conv_off, const float* dpooled, float* dconv, int n_trk, int d, int P);
+BIGC_API int bigc_maxpool_bwd_f32(void* stream, const float* conv, const int32_t* trk_conv_off, const float* dpooled, float* dconv, int n_trk, int d, int P);
 /* inverse of bigc_conv_index: G[s, k, :] = sum of the dconv rows whose tap k reads packed row s; G (R, 3, d) */
-int bigc_conv_gather_bwd_f32(void* stream, const float* dconv, const int32_t* trk_row_off, const int32_t* trk_conv_off,
+BIGC_API int bigc_conv_gather_bwd_f32(void* stream, const float* dconv, const int32_t* trk_row_off, const int32_t* trk_conv_off,
                              const int32_t* trk_vid, const int32_t* vid_tmax, float* G, int n_trk, int d);
 /* backward of bigc_mha_core_f32 from the saved output o and log-sum-exp lse; delta_scratch (total_q_rows, n_head) */
-int bigc_mha_bwd_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+BIGC_API int bigc_mha_bwd_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                      const float* dO, int lddo, const float* lse, float* delta_scratch, float* dq, int lddq, float* dk, int lddk,
                      float* dv, int lddv, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
                      int n_head, int hd);
 /* d(raw role scores) (same layout as att) from d att; already multiplied by `scale` */
-int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt, float* ds,
+BIGC_API int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt, float* ds,
                                 const int32_t* e_off, int n_vid, int nq, int half, float scale);
 /* per-video products around the role attention. mode 0: datt = dvals @ enco^T; 1: denco += att^T @ dvals (both roles);
  *   2: dp2a = ds @ e2a; 3: de2a = ds^T @ p2a. d = dim_enti, half = dim_att/2. */
-int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1, const float* enco_or_e2a,
+BIGC_API int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1, const float* enco_or_e2a,
                              int ld2, float* out, int ldo, const int32_t* e_off, int n_vid, int nq, int d, int half, int max_trk);
 /* two of those products in ONE launch (they are independent and each fills a fraction of the chip at training batch sizes):
  *   pair 0: datt = dvals @ enco^T -> out_a and denco += att^T @ dvals -> out_b (x = att, y = dvals, z = enco; ld_y == ld_z);
  *   pair 1: dp2a = ds @ e2a -> out_a and de2a = ds^T @ p2a -> out_b (x = ds, y = p2a, z = e2a); ldo_b: leading dimension of out_b (and of
  *   out_a in pair 1).  Same arithmetic as the single calls, bit for bit. */
-int bigc_role_small_gemm_pair_f32(void* stream, int pair, const float* x, const float* y, int ld_y, const float* z, int ld_z, float* out_a,
+BIGC_API int bigc_role_small_gemm_pair_f32(void* stream, int pair, const float* x, const float* y, int ld_y, const float* z, int ld_z, float* out_a,
                                   float* out_b, int ldo_b, const int32_t* e_off, int n_vid, int nq, int d, int half, int max_trk);
 /* vIoU of every (proposal, GT trajectory) pair (vIoU_ts utils/utils_func.py:437-471 as used by enti_viou_align,
  *   models/model_0v10.py:569-581): out (B, max_trk, g_max), 0 where the closed durations do not overlap or the pair
  *   does not exist. GT trajectories are packed like the proposals: gt_boxes (sum frames, 4), gt_row_off (G+1),
  *   gt_dura (G,2) closed, gt_traj_off (B+1). */
-int bigc_viou_matrix(void* stream, const float* boxes, const int32_t* trk_row_off, const int32_t* trk_dura, const int32_t* e_off,
+BIGC_API int bigc_viou_matrix(void* stream, const float* boxes, const int32_t* trk_row_off, const int32_t* trk_dura, const int32_t* e_off,
                      const float* gt_boxes, const int32_t* gt_row_off, const int32_t* gt_dura, const int32_t* gt_traj_off,
                      int n_vid, int max_trk, int g_max, float* out);
 /* vIoU of n_pairs listed pairs (a, b) of trajectory slices: slice i of side A = boxes_a rows [seg_a[3i], seg_a[3i] + seg_a[3i+2]) covering
  *   the frames [seg_a[3i+1], seg_a[3i+1] + seg_a[3i+2]); same for side B.  The evaluator's `viou` (VidVRDhelperEvalAPIs/common.py:65-106),
  *   f32 accumulation.  out (n_pairs). */
-int bigc_viou_pairs(void* stream, const float* boxes_a, const int32_t* seg_a, const float* boxes_b, const int32_t* seg_b,
+BIGC_API int bigc_viou_pairs(void* stream, const float* boxes_a, const int32_t* seg_a, const float* boxes_b, const int32_t* seg_b,
                     const int32_t* pairs, int n_pairs, float* out);
 /* Hungarian cost (models/model_0v10.py:617-636): cost[v,q,g] (B, nq, g_max) = cost_cls * CE + cost_adj * mean BCE;
  *   g_off (B+1) prefix of GT predicates per video, gt_pred (sum G), gt_adj per video (2, G_v, N_v) at float offset adj_off[v]. */
-int bigc_match_cost(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
+BIGC_API int bigc_match_cost(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
                     const int32_t* gt_pred, const float* gt_adj, const int64_t* adj_off, int n_vid, int nq, int g_max,
                     float cost_cls, float cost_adj, float* cost);
 /* Loss terms (models/model_0v10.py:648-703) and their gradients. target (B*nq) = matched GT predicate class or 0,
  *   match_g (B*nq) = matched GT index or -1; n_pos/n_neg/n_adj = element counts of the three means.
  *   loss_out[3] = {cls_pos, cls_neg, adj}; dlogits (B*nq, ldg) (pad columns untouched), datt like att; both NULL: the loss terms only. */
-int bigc_loss_grad(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
+BIGC_API int bigc_loss_grad(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
                    const float* gt_adj, const int64_t* adj_off, const int32_t* target, const int32_t* match_g, int n_vid, int nq,
                    float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight,
                    float gs_pos, float gs_neg, float gs_adj, /* upstream gradients of the three loss terms */
@@ -373,10 +377,10 @@ int bigc_loss_grad(void* stream, const float* logits, int n_pcat, const float* a
  *   NULL) and read the tracklets' feature rows in place through bigc_batch.feat_row_ptr, like the default eval forward: the first
  *   visual-feature GEMM (models/model_0v10.py:447), its weight gradient and the time-mean of the I3D / classeme columns (:470) then
  *   walk the callers' tensors; 0: pack f32 rows (exact-GEMM mode, the pairwise baseline, feature widths that are not multiples of 4) */
-int bigc_train_reads_rows(const bigc_model* m);
+BIGC_API int bigc_train_reads_rows(const bigc_model* m);
 /* bigc_loss_grad with the three upstream gradients read from device memory (upstream3[0..2]): the backward of a step that does not
  *   wait for the GPU (autograd hands them over as a device tensor) */
-int bigc_loss_grad_dev(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
+BIGC_API int bigc_loss_grad_dev(void* stream, const float* logits, int n_pcat, const float* att, const int32_t* e_off, const int32_t* g_off,
                        const float* gt_adj, const int64_t* adj_off, const int32_t* target, const int32_t* match_g, int n_vid, int nq,
                        float n_pos, float n_neg, float n_adj, float loss_cls, float loss_adj, float neg_weight, const float* upstream3,
                        float* loss_out, float* dlogits, int ldg, float* datt);
@@ -391,25 +395,25 @@ int bigc_loss_grad_dev(void* stream, const float* logits, int n_pcat, const floa
  *   assignment is scipy's also where the optimum is not unique.  -> target (B*nq) = class of the GT predicate matched to the query or 0,
  *   match_g (B*nq) = its index or -1.  bad[0] |= 1 when a video's costs hold NaN / -inf or admit no assignment (scipy raises
  *   ValueError there); that video is left unmatched. */
-int bigc_align_adjacency(void* stream, const float* viou, int max_trk, int t_max, const int32_t* e_off, const int32_t* gt_traj_off,
+BIGC_API int bigc_align_adjacency(void* stream, const float* viou, int max_trk, int t_max, const int32_t* e_off, const int32_t* gt_traj_off,
                          const float* adj_raw, const int64_t* raw_off, const int32_t* g_off, const int64_t* adj_off, int n_vid,
                          float viou_th, float* gt_adj);
-int bigc_hungarian(void* stream, const float* cost, const int32_t* g_off, const int32_t* gt_pred, int n_vid, int nq, int g_max,
+BIGC_API int bigc_hungarian(void* stream, const float* cost, const int32_t* g_off, const int32_t* gt_pred, int n_vid, int nq, int g_max,
                    int32_t* target, int32_t* match_g, int* bad);
 
 /* gradient destination of a trainable parameter (accumulated; NULL unregisters). Frozen parameters are never registered. */
-int bigc_set_grad(bigc_model* m, const char* key, float* ptr);
+BIGC_API int bigc_set_grad(bigc_model* m, const char* key, float* ptr);
 /* moves every registered gradient destination from the buffer [old_base, old_base + numel) to the same offset of new_base: the
  * host side lays all gradients out in one flat buffer, allocates a fresh one per step and keeps the layout (one call per step
  * instead of one bigc_set_grad per parameter) */
-int bigc_rebase_grads(bigc_model* m, float* old_base, float* new_base, int64_t numel);
-size_t bigc_train_workspace_bytes(const bigc_model* m, const bigc_batch* b);
+BIGC_API int bigc_rebase_grads(bigc_model* m, float* old_base, float* new_base, int64_t numel);
+BIGC_API size_t bigc_train_workspace_bytes(const bigc_model* m, const bigc_batch* b);
 /* forward keeping every activation the backward needs inside `workspace` (which must stay untouched until
  * bigc_train_backward); pred_logits (B*Q, P), att (2*Q*NT) of the last decoder layer */
-int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
+BIGC_API int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                        float* pred_logits, float* att);
 /* dlogits (B*Q, ldg) with ldg = num_pred_cats rounded up to 4 and zero pad columns; datt (2*Q*NT) */
-int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
+BIGC_API int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                         const float* dlogits, int ldg, const float* datt);
 
 /* ------------------------------------------------------------------------------------
@@ -420,14 +424,14 @@ int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch* b, void* 
 /* depth-wise Conv1d(groups=C, kernel ks, padding ks/2, stride 1) over n_seq sequences of length T stored as
  *   rows (n_seq*T, d): y[s,t,c] = b[c] + sum_j w[c,j] * x[s, t+j-ks/2, c]  (models/grd_model_v5.py:44,54).
  *   w is the torch (d,1,ks) weight; d % 4 == 0; ks odd <= 7. */
-int bigc_dwconv_f32(void* stream, const float* x, const float* w, const float* b, float* y, int n_seq, int T, int d, int ks);
+BIGC_API int bigc_dwconv_f32(void* stream, const float* x, const float* w, const float* b, float* y, int n_seq, int T, int d, int ks);
 
 /* Video <-> query co-attention and feature fusion (models/grd_model_v5.py:346-365) for n queries of 3 words:
  *   sim[i,t,l] = proj[t,:] . query[i,l,:]; sim_r = softmax_l, sim_c = softmax_t;
  *   A = sim_r @ query_i, B = (sim_r sim_c^T) @ video evaluated as sim_r @ (sim_c^T @ video);
  *   out[i,t,:] = [video[t], A, A*video[t], B*video[t]]  (4d wide).
  *   video, proj (T,d); query (n*3,d); out (n*T, 4d). T <= 2048, d % 4 == 0, d <= 256. */
-int grd_coattention_f32(void* stream, const float* video, const float* proj, const float* query, float* out, int n, int T, int d);
+BIGC_API int grd_coattention_f32(void* stream, const float* video, const float* proj, const float* query, float* out, int n, int T, int d);
 
 /* Multi-bin post-processing of the three heads (models/grd_model_v5.py:533-572 with temporal_pooling :697-737
  *   and temporal_nms :667-695): scores = sigmoid(conf)*sigmoid(cls); per (query, bin) the spans
@@ -438,7 +442,7 @@ int grd_coattention_f32(void* stream, const float* video, const float* proj, con
  *   exceeds bins_th.  regrs (n,T,2k) already passed through the sigmoid; conf, cls (n,T,k) logits;
  *   clip (T) = linspace(0,1,T); info (n,2). Outputs pooled_se (n,k+1,2), bins_probs (n,k+1), bins_mask (n,k+1) u8.
  *   k <= 16. status[0] is set to 1 if some (query,bin) had an empty pooling set (the reference raises there, :726). */
-int grd_postprocess(void* stream, const float* regrs, const float* conf, const float* cls, const float* clip, const float* info,
+BIGC_API int grd_postprocess(void* stream, const float* regrs, const float* conf, const float* cls, const float* clip, const float* info,
                     int n, int T, int k, float score_th, float tiou_th, float bins_th, float nms_th,
                     float* pooled_se, float* bins_probs, uint8_t* bins_mask, int32_t* status);
 
@@ -449,13 +453,13 @@ typedef struct {
 
 typedef struct grd_model grd_model;
 
-int grd_create(const grd_config* cfg, grd_model** out);
-void grd_destroy(grd_model* m);
-int grd_set_param(grd_model* m, const char* key, const float* ptr, int64_t numel);
-int grd_finalize(grd_model* m, void* stream);
+BIGC_API int grd_create(const grd_config* cfg, grd_model** out);
+BIGC_API void grd_destroy(grd_model* m);
+BIGC_API int grd_set_param(grd_model* m, const char* key, const float* ptr, int64_t numel);
+BIGC_API int grd_finalize(grd_model* m, void* stream);
 /* as bigc_set_mode, for the grounding scorer's handle (grd_forward*, grd_train_*) */
-int grd_set_mode(grd_model* m, int exact, int fast);
-size_t grd_workspace_bytes(const grd_model* m, int T, int n);
+BIGC_API int grd_set_mode(grd_model* m, int exact, int fast);
+BIGC_API size_t grd_workspace_bytes(const grd_model* m, int T, int n);
 
 typedef struct {
     float* pooled_se;     /* (n, k+1, 2) normalised [0,1] */
@@ -473,7 +477,7 @@ typedef struct {
 /* quint (n,5) int32 [pred, s_cat, o_cat, s_tid, o_tid] and dura (n,2) int32 as produced by bigc_forward;
  * pos_video (T,d), pos_query (3,d): PosEncoder tables (models/grd_model_v5.py:58-78) evaluated by the host
  * exactly as the reference does; clip (T) = linspace(0,1,T). */
-int grd_forward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, const int32_t* dura, int n,
+BIGC_API int grd_forward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, const int32_t* dura, int n,
                 float video_len, const float* pos_video, const float* pos_query, const float* clip,
                 float score_th, float tiou_th, float bins_th, float nms_th,
                 void* workspace, size_t workspace_bytes, const grd_outputs* out);
@@ -491,11 +495,11 @@ typedef struct {
     const int32_t* q_row_off;     /* (n_query + 1) first combined row of every query */
     const float* vid_len;         /* (n_vid) video_len in frames */
 } grd_batch;
-size_t grd_batch_workspace_bytes(const grd_model* m, const grd_batch* b);
+BIGC_API size_t grd_batch_workspace_bytes(const grd_model* m, const grd_batch* b);
 /* video_feat (total_T, dim_feat), quint (n_query, 5), dura (n_query, 2); pos_video (>= max_T, d), pos_query (3, d); clip (total_T) =
  * the videos' linspace(0, 1, T_v) tables back to back; outputs as grd_outputs with n = n_query and n*T -> total_rows, T -> total_T;
  * status (1 + n_vid): [any, per video] set to 1 where temporal pooling selected no clip (the reference raises there). */
-int grd_forward_batch(grd_model* m, void* stream, const float* video_feat, const grd_batch* b, const int32_t* quint, const int32_t* dura,
+BIGC_API int grd_forward_batch(grd_model* m, void* stream, const float* video_feat, const grd_batch* b, const int32_t* quint, const int32_t* dura,
                       const float* pos_video, const float* pos_query, const float* clip,
                       float score_th, float tiou_th, float bins_th, float nms_th,
                       void* workspace, size_t workspace_bytes, const grd_outputs* out);
@@ -518,19 +522,19 @@ int grd_forward_batch(grd_model* m, void* stream, const float* video_feat, const
  *                     scaled by gs_host[5] (upstream gradient of each term).  count_* are the denominators of the
  *                     batch-wide means: positive elements, negative elements, elements with centerness > 0.
  * grd_train_backward  backward pass from those three gradient arrays through the network. */
-int grd_set_grad(grd_model* m, const char* key, float* ptr);
+BIGC_API int grd_set_grad(grd_model* m, const char* key, float* ptr);
 /* training-mode dropout of the three QANet layers (models/grd_model_v5.py:123-136; base p = 0.1, 0.05 after conv block 1),
  * counter-based masks as bigc_set_dropout; the host passes a different seed for every video of a batch. 0 = off. */
-int grd_set_dropout(grd_model* m, float p, uint32_t seed);
-size_t grd_train_workspace_bytes(const grd_model* m, int T, int n);
-int grd_train_forward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, const int32_t* dura, int n,
+BIGC_API int grd_set_dropout(grd_model* m, float p, uint32_t seed);
+BIGC_API size_t grd_train_workspace_bytes(const grd_model* m, int T, int n);
+BIGC_API int grd_train_forward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, const int32_t* dura, int n,
                       float video_len, const float* pos_video, const float* pos_query, void* workspace, size_t workspace_bytes,
                       float* regrs, float* conf, float* cls);
-int grd_loss_grad(void* stream, const float* regrs, const float* conf, const float* cls, const float* clip, const float* target,
+BIGC_API int grd_loss_grad(void* stream, const float* regrs, const float* conf, const float* cls, const float* clip, const float* target,
                   const int32_t* pos_i, const int32_t* pos_b, const int32_t* pos_j, int n_pos, const int32_t* neg_i,
                   const int32_t* neg_b, int n_neg, int T, int k, float count_pos, float count_neg, float count_mask,
                   float f_cls, float f_ct, float f_regr, const float* gs_host, float* loss, float* dregr, float* dconf, float* dcls);
-int grd_train_backward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, int n,
+BIGC_API int grd_train_backward(grd_model* m, void* stream, const float* video_feat, int T, const int32_t* quint, int n,
                        void* workspace, size_t workspace_bytes, const float* dregr, const float* dconf, const float* dcls);
 
 /* ---- dropout of the training paths --------------------------------------------------------------------------------------
@@ -542,12 +546,12 @@ int grd_train_backward(grd_model* m, void* stream, const float* video_feat, int 
  *   bigc_dropout_f32      in place on the logical (rows, n) matrix x with leading dimension ld, idx = r * n + c
  *   bigc_mha_core_drop_f32 / bigc_mha_bwd_drop_f32   attention core with dropout on the probabilities,
  *                         idx = ((global query row * n_head + head) << 12) + key index inside the sequence */
-int bigc_set_dropout(bigc_model* m, float p, uint32_t seed);
-int bigc_dropout_f32(void* stream, float* x, long rows, int n, int ld, float p, uint32_t seed, uint32_t site);
-int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+BIGC_API int bigc_set_dropout(bigc_model* m, float p, uint32_t seed);
+BIGC_API int bigc_dropout_f32(void* stream, float* x, long rows, int n, int ld, float p, uint32_t seed, uint32_t site);
+BIGC_API int bigc_mha_core_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                            float* o, int ldo, const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q,
                            int n_head, int hd, float* lse, float drop_p, uint32_t drop_seed, uint32_t drop_site);
-int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+BIGC_API int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                           const float* o, int ldo, const float* dO, int lddo, const float* lse, float* delta_scratch,
                           float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                           const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
@@ -558,8 +562,8 @@ int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, const float* k,
  * the reference's state_dict).  bigc_pair_forward runs the front-end and scores EVERY ordered tracklet pair (s, o), s != o:
  * pair p of video v (row-major over the N_v x N_v grid without its diagonal, trajid2pairid :105-112) is row
  * vid_pair_off[v] + p of pair_logits (n_pairs, num_pred_cats).  enti2enco (n_trk, dim_enti) is optional. */
-size_t bigc_pair_workspace_bytes(const bigc_model* m, const bigc_batch* b, long n_pairs);
-int bigc_pair_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* vid_pair_off, long n_pairs, void* workspace,
+BIGC_API size_t bigc_pair_workspace_bytes(const bigc_model* m, const bigc_batch* b, long n_pairs);
+BIGC_API int bigc_pair_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* vid_pair_off, long n_pairs, void* workspace,
                       size_t workspace_bytes, float* enti2enco, float* pair_logits);
 
 /* ---- Base_C training step (models/model_pairwise_baseline.py:276-312; loop body tools/train_vidor.py:305-330) ---------------
@@ -569,12 +573,12 @@ int bigc_pair_forward(bigc_model* m, void* stream, const bigc_batch* b, const in
  * bigc_bce_logits_f32 is F.binary_cross_entropy_with_logits(x, y, reduction='mean') over a (rows, cols) block: *loss +=
  * the mean, dx = gscale * d mean / dx (either may be NULL); bigc_pair_train_backward takes dlogits (n_pairs, ldg) with
  * ldg = num_pred_cats rounded up to 4 (zero pad columns) and accumulates into the bigc_set_grad destinations. */
-size_t bigc_pair_train_workspace_bytes(const bigc_model* m, const bigc_batch* b, long n_pairs);
-int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
+BIGC_API size_t bigc_pair_train_workspace_bytes(const bigc_model* m, const bigc_batch* b, long n_pairs);
+BIGC_API int bigc_pair_train_forward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
                             size_t workspace_bytes, float* pair_logits);
-int bigc_pair_train_backward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
+BIGC_API int bigc_pair_train_backward(bigc_model* m, void* stream, const bigc_batch* b, const int32_t* pair_so, long n_pairs, void* workspace,
                              size_t workspace_bytes, const float* dlogits, int ldg);
-int bigc_bce_logits_f32(void* stream, const float* x, int ldx, const float* y, int ldy, long rows, int cols, float gscale, float* loss,
+BIGC_API int bigc_bce_logits_f32(void* stream, const float* x, int ldx, const float* y, int ldy, long rows, int cols, float gscale, float* loss,
                         float* dx, int lddx);
 
 /* ---- tracking-result ingest (dataloaders/dataloader_vidvrd.py:585-700, utils/utils_func.py:273-317) ---------------------
@@ -584,7 +588,7 @@ int bigc_bce_logits_f32(void* stream, const float* x, int ldx, const float* y, i
  * otherwise the row numpy.linspace(row src_a[r], row src_b[r], num = step_div[r] + 1, axis=0)[step_i[r]] evaluated in
  * float64 with numpy's arithmetic (incl. its any-step-zero branch) and rounded to float32, a negative index standing
  * for the zero vector.  Bit-identical to the reference's host interpolation. */
-int bigc_assemble_rows_f32(void* stream, const float* raw, int ld_raw, int col0, int width, const float* raw2, int ld_raw2,
+BIGC_API int bigc_assemble_rows_f32(void* stream, const float* raw, int ld_raw, int col0, int width, const float* raw2, int ld_raw2,
                            int col02, int width2, const int32_t* src_a, const int32_t* src_b, const int32_t* step_i,
                            const int32_t* step_div, float* out, int ld_out, int n_rows);
 
@@ -596,29 +600,29 @@ int bigc_assemble_rows_f32(void* stream, const float* raw, int ld_raw, int col0,
  * ld_feats; feats_hr8: columns [0, dim_feat) in the split form of bigc_gemm_ps at pitch ld_hr8_bytes (range_flag is or-ed with 1
  * when an element is outside its range); extra: columns [dim_feat, width) f32 at pitch ld_extra; boxes (R, 4).  feat_src may
  * be NULL (boxes only).  vectorized = 1 promises 16-byte aligned sources / pitches (16-byte loads), 0 = any alignment. */
-int bigc_pack_tracklets(void* stream, const uint64_t* feat_src, const int32_t* feat_ld, const uint64_t* box_src,
+BIGC_API int bigc_pack_tracklets(void* stream, const uint64_t* feat_src, const int32_t* feat_ld, const uint64_t* box_src,
                         const int32_t* trk_row_off, int n_trk, long n_rows, int width, int dim_feat, int vectorized, float* feats, long ld_feats,
                         void* feats_hr8, long ld_hr8_bytes, float* extra, long ld_extra, float* boxes, int32_t* range_flag);
 /* row_ptr[trk_row_off[t] + i] = feat_src[t] + 4 * i * (feat_ld ? feat_ld[t] : width): the per-row address table of bigc_batch.feat_row_ptr */
-int bigc_row_pointers(void* stream, const uint64_t* feat_src, const int32_t* feat_ld, int width, const int32_t* trk_row_off, int n_trk,
+BIGC_API int bigc_row_pointers(void* stream, const uint64_t* feat_src, const int32_t* feat_ld, int width, const int32_t* trk_row_off, int n_trk,
                       uint64_t* row_ptr);
 /* bigc_stretched_mean over rows given by address: columns [col0, col0 + w) of row r at row_ptr[r] (16-byte aligned; col0, w multiples of 4) */
-int bigc_stretched_mean_rows(void* stream, const uint64_t* row_ptr, int col0, int w, const int32_t* trk_row_off, const int32_t* trk_vid,
+BIGC_API int bigc_stretched_mean_rows(void* stream, const uint64_t* row_ptr, int col0, int w, const int32_t* trk_row_off, const int32_t* trk_vid,
                              const int32_t* vid_tmax, float* out, int n_trk);
 /* per-video metadata of the same containers: cat_ids (N_v) int64, scores (N_v) f32, traj_durations (N_v, 2) int64 at the
  * addresses cat_src[v] / score_src[v] / dura_src[v] -> trk_cat int32, trk_score f32, trk_dura int32 of bigc_batch */
-int bigc_pack_video_meta(void* stream, const uint64_t* cat_src, const uint64_t* score_src, const uint64_t* dura_src,
+BIGC_API int bigc_pack_video_meta(void* stream, const uint64_t* cat_src, const uint64_t* score_src, const uint64_t* dura_src,
                          const int32_t* vid_trk_off, int n_vid, int32_t* trk_cat, float* trk_score, int32_t* trk_dura);
 /* host -> device copy by a kernel on `stream`: src_mapped is page-locked host memory mapped into the device's address space
  * (torch pin_memory() / hipHostMalloc); ordered like any other launch, no use of the runtime's copy queues */
-int bigc_copy_mapped(void* stream, void* dst, const void* src_mapped, long nbytes);
+BIGC_API int bigc_copy_mapped(void* stream, void* dst, const void* src_mapped, long nbytes);
 /* progress mark: mapped_word[0] = value (8-byte aligned page-locked host memory, mapped) once everything queued on `stream` before
  * the call has run; when or_flag (device int, may be NULL) is non-zero, mapped_word[1] = value as well.  The host polls the word. */
-int bigc_stamp(void* stream, void* mapped_word, unsigned long long value, const int* or_flag);
+BIGC_API int bigc_stamp(void* stream, void* mapped_word, unsigned long long value, const int* or_flag);
 /* padded outputs of bigc_construct_triplets / bigc_forward -> the reference's return types back to back
  * (models/model_0v10.py:776-785: int64 quintuples, f32 scores, int64 duration intersections, int64 query ids per video):
  * video v's n_out[v] rows at rows [out_off[v], out_off[v+1]) of the compact arrays (each sized for n_vid * cap rows) */
-int bigc_compact_triplets(void* stream, const int32_t* quint, const float* scores, const int32_t* dura, const int32_t* qid,
+BIGC_API int bigc_compact_triplets(void* stream, const int32_t* quint, const float* scores, const int32_t* dura, const int32_t* qid,
                           const int32_t* n_out, int n_vid, int cap, int64_t* out_quint, float* out_scores, int64_t* out_dura,
                           int64_t* out_qid, int32_t* out_off);
 
@@ -632,8 +636,8 @@ int bigc_compact_triplets(void* stream, const int32_t* quint, const float* score
  * score, descending: quint_top (B, rt_topk, 5), scores_top, dura_top, n_top (B).
  * bm_off (B) int64 / bm_words (B): offset (in 32-bit words) of video v's bitmap in the scratch region and its words per
  * predicate class, ceil(N_v^2 / 32); bitmap_words_total = sum_v n_pred * bm_words[v]. */
-size_t bigc_pair_triplets_workspace_bytes(int n_vid, int n_trk, long n_pairs, int topk, long bitmap_words_total);
-int bigc_pair_triplets(void* stream, const float* pair_logits, int n_pred, int topk, const int32_t* vid_trk_off,
+BIGC_API size_t bigc_pair_triplets_workspace_bytes(int n_vid, int n_trk, long n_pairs, int topk, long bitmap_words_total);
+BIGC_API int bigc_pair_triplets(void* stream, const float* pair_logits, int n_pred, int topk, const int32_t* vid_trk_off,
                        const int32_t* vid_pair_off, const int32_t* trk_dura, const int32_t* trk_cat, const float* trk_score,
                        int n_vid, int n_trk, long n_pairs, const long* bm_off, const int32_t* bm_words, long bitmap_words_total,
                        void* workspace, size_t workspace_bytes, int32_t* quint, float* scores, int32_t* dura, int32_t* n_rows,
@@ -647,7 +651,7 @@ int bigc_pair_triplets(void* stream, const float* pair_logits, int n_pred, int t
  * a_idx (M, nseg), -1 = zero row, K = nseg segments).  Outputs: f32 C and / or hr8 Cs (at least one).  K % 32 == 0, N % 8 == 0.
  * range_flag (device int, may be null) is OR-ed with 1 when an element being split is >= 32768 in magnitude, NaN or Inf: the
  * result is then invalid and the caller must redo the computation on the exact path (bigc_linear_set_exact(1)). */
-int bigc_gemm_ps(void* stream, const void* A, long lda_bytes, int a_fmt, const int32_t* a_idx, int nseg, const float* W, int ldw,
+BIGC_API int bigc_gemm_ps(void* stream, const void* A, long lda_bytes, int a_fmt, const int32_t* a_idx, int nseg, const float* W, int ldw,
                  const float* bias, const float* residual, long ldr, float* C, long ldc, void* Cs, long ldcs_bytes,
                  int M, int N, int K, int act, int* range_flag);
 /* The same product with the rows of A given by ADDRESS (row_ptr[m] -> K floats, 16-byte aligned): the first visual-feature layer
@@ -657,21 +661,21 @@ int bigc_gemm_ps(void* stream, const void* A, long lda_bytes, int a_fmt, const i
  * second accumulator (the rounding behaviour of the library's in-loop-split GEMM); 2 = blocked accumulation (partial sums over K = 128
  * folded into a running total; needs K % 128 == 0, else as 0): rounds no coarser than a blocked CPU GEMM.  1 and 2 run on 128-row tiles.
  * C and / or Cs as above. */
-int bigc_gemm_ps_rows(void* stream, const uint64_t* row_ptr, const float* W, int ldw, const float* bias, float* C, long ldc, void* Cs,
+BIGC_API int bigc_gemm_ps_rows(void* stream, const uint64_t* row_ptr, const float* W, int ldw, const float* bias, float* C, long ldc, void* Cs,
                       long ldcs_bytes, int M, int N, int K, int act, int accum, int* range_flag);
 /* the same product with nn.LayerNorm over the N = 512 output features taken in the epilogue (models/model_0v10.py:188,211,223: the three
  * norms of a decoder layer follow a GEMM + residual): C = LayerNorm(act(A W^T + bias) + residual) * gamma + beta (+ add[m % add_period],
  * e.g. `+ pos_embedding`), Cs = the split form of the normalised rows (without the added table).  A must be in the split form. */
-int bigc_gemm_ps_ln(void* stream, const void* A, long lda_bytes, const float* W, int ldw, const float* bias, const float* residual, long ldr,
+BIGC_API int bigc_gemm_ps_ln(void* stream, const void* A, long lda_bytes, const float* W, int ldw, const float* bias, const float* residual, long ldr,
                     const float* gamma, const float* beta, float eps, const float* add, int add_period, float* C, long ldc, void* Cs,
                     long ldcs_bytes, int M, int N, int K, int act, int* range_flag);
 /* f32 rows (rows, K) -> hr8 rows; K % 8 == 0 */
-int bigc_split_rows_f32(void* stream, const float* X, long ldx, void* Y, long ldy_bytes, long rows, int K, int* range_flag);
+BIGC_API int bigc_split_rows_f32(void* stream, const float* X, long ldx, void* Y, long ldy_bytes, long rows, int K, int* range_flag);
 /* act(A W^T + bias) + residual on the default split-operand GEMM (f32 A, as bigc_linear_f32) with the result written in the split
  * form "hr8" (Cs, pitch ldcs_bytes; N % 8 == 0) and / or as f32 (C may be NULL): the producer side of a GEMM -> GEMM chain whose
  * second GEMM is bigc_gemm_ps (models/model_0v10.py:446-448 fc_feat2enti.0 -> .2 -> conv, FFN pairs :113, :220).  K == 8 runs
  * the store-bound FMA kernel.  An element the split form cannot hold sets *range_flag. */
-int bigc_linear_hr8out_f32(void* stream, const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
+BIGC_API int bigc_linear_hr8out_f32(void* stream, const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
                            float* C, int ldc, void* Cs, long ldcs_bytes, int M, int N, int K, int act, int* range_flag);
 
 #ifdef __cplusplus

@@ -270,3 +270,37 @@ def test_eval_loop_over_reference_style_containers_does_not_retain_gpu_features(
     # the first video once more on the GPU: fresh allocations, the stale table (other addresses) must not be used
     got = model([vids[0].to(DEV)], topk=3)[0]
     assert all(torch.equal(u.cpu(), v) for u, v in zip(got, want0))
+
+
+def test_source_table_cache_is_validated_item_by_item():
+    """a cache hit used to be decided by the lists' length and the addresses of their FIRST and LAST tensors.  After a
+    to(GPU) -> forward -> to(cpu) -> to(GPU) cycle the caching allocator may hand back the old blocks for the ends and other blocks for
+    the middle: the stale addresses were then read.  The cache holds a weak reference per source tensor now; a hit needs every one alive
+    and identical to the list's current item.  (CPU tensors: the table logic is device-independent.)"""
+    from bigc_hip.packed import tracklet_table
+    dev = torch.device("cpu")
+    p = _RefStyleProposal(synthetic_proposal(811, n_trajs=9, feat_width=16, len_range=(4, 9)))
+    t1 = tracklet_table(p, dev)
+    assert t1["fptr"].tolist() == [f.data_ptr() for f in p.features_list]
+    t2 = tracklet_table(p, dev)
+    assert t2["_cached"] is p._bigc_pack and t2["fptr"] is t1["fptr"]                     # unchanged lists: a hit
+    # same ends (the very same tensor objects), middle tracklets replaced by tensors elsewhere in memory
+    keep_old = [p.features_list[i] for i in range(2, 6)]                                   # (keeps the old blocks from being re-used for the clones)
+    for i in range(2, 6):
+        p.features_list[i] = p.features_list[i].clone()
+    t3 = tracklet_table(p, dev)
+    assert t3["fptr"].tolist() == [f.data_ptr() for f in p.features_list] and t3["fptr"].tolist() != t1["fptr"].tolist()
+    # the same ADDRESS everywhere but other tensor objects (what allocator re-use looks like): not a hit either -- the table is rebuilt
+    # from the lists as they are, which costs time, never correctness
+    p.features_list = [f[:] for f in p.features_list]
+    t4 = tracklet_table(p, dev)
+    assert t4["fptr"] is not t3["fptr"] and t4["fptr"].tolist() == t3["fptr"].tolist()
+    # a source tensor that died (its list item replaced and nothing else holding it): the weak reference is dead, no hit
+    p.bboxes_list[4] = p.bboxes_list[4].clone()
+    t5 = tracklet_table(p, dev)
+    assert t5["bptr"].tolist() == [b.data_ptr() for b in p.bboxes_list]
+    # what PackedBatch derives from the table is kept on the proposal's cached dict, not on the per-call copy (ADVICE r05, low)
+    from bigc_hip.packed import PackedBatch
+    PackedBatch([p], "cpu")
+    assert p._bigc_pack["tmax"] == max(b.shape[0] for b in p.bboxes_list)
+    del keep_old

@@ -488,8 +488,8 @@ def test_two_forwards_before_one_backward_accumulate_like_autograd():
 
 def test_gradients_are_bit_reproducible_run_to_run():
     """The split-M weight-gradient GEMM sums its partial tiles in split order (csrc/backward.hip: dw_reduce_kernel, or the
-    last-arriving workgroup under BIGC_DW_REDUCE=inline) and no weight gradient goes through float atomics: two runs of the same
-    step give identical bits for every weight matrix."""
+    last-arriving workgroup under BIGC_DW_REDUCE=inline), and since round 6 no reduction of the step goes through float atomics: two runs
+    of the same step give identical bits for EVERY gradient and the loss (five runs, three models: tests/test_hip_determinism.py)."""
     runs = []
     for _ in range(2):
         cfg, variant, sd, props, gts = cases.make_train_case("bigc_train_v")
@@ -498,7 +498,8 @@ def test_gradients_are_bit_reproducible_run_to_run():
         total, _ = model(props, gts)
         total.backward()
         torch.cuda.synchronize()
-        runs.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None and k.endswith(".weight") and p.dim() == 2})
+        runs.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        runs[-1]["loss"] = total.detach().clone()
     diff = [k for k in runs[0] if not torch.equal(runs[0][k], runs[1][k])]
     assert not diff, diff[:10]
 

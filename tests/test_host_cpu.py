@@ -38,11 +38,14 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert n in _lib._SIGS, "no ctypes signature for " + n
     assert b"gfx950" in _lib.load().bigc_build_info()
-    # and the other way round: no undocumented C entry point (every exported bigc_* / grd_* function is declared in the header)
+    # and the other way round: the dynamic symbol table holds the header's functions and NOTHING else -- no mangled launcher, no
+    # template instantiation, no data symbol (-fvisibility=hidden + csrc/exports.map; BIGC_API marks the entry points in the header)
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
-    exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-2] in "Tt" and l.split()[-1].startswith(("bigc_", "grd_"))}
-    assert exported and not (exported - set(names)), sorted(exported - set(names))
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.split())
+    assert exported == names, (sorted(set(exported) - set(names)), sorted(set(names) - set(exported)))
+    text = open(os.path.join(ROOT, "include", "bigc_hip.h")).read()
+    assert len(re.findall(r"^BIGC_API ", text, flags=re.M)) == len(names)
 
 
 def test_packed_batch_offsets_cpu():

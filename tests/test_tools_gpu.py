@@ -86,36 +86,66 @@ def test_vidor_cli_pairwise_baseline_training_then_eval():
     assert "detection recall" in log
 
 
-def _bench(args, env=None):
+def _bench(args, env=None, detail=False):
+    """-> the object of bench.py's LAST stdout line, parsed strictly (the driver reads that line); with detail=True also bench_detail.json"""
     import json
     e = dict(os.environ)
     e.update(env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, capture_output=True, text=True, timeout=900, env=e)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert lines and lines[-1].startswith("{"), r.stdout[-2000:]
+    assert sum(1 for l in lines if l.startswith("{")) == 1, "one JSON line on stdout (the detail goes to bench_detail.json)"
+
+    def strict(c):
+        raise ValueError("not strict JSON: " + c)
+    d = json.loads(lines[-1], parse_constant=strict)          # NaN / Infinity are not JSON
+    if "legs" in d:                                            # the eval line's compact form
+        assert len(lines[-1]) < 4096, len(lines[-1])
+
+        def keys(o):
+            if isinstance(o, dict):
+                for k, v in o.items():
+                    yield k
+                    yield from keys(v)
+        assert max(len(k) for k in keys(d)) <= 32
+    if detail:
+        return d, json.load(open(os.path.join(ROOT, "bench_detail.json")))
+    return d
 
 
 def test_bench_json_contract():
-    """bench.py prints ONE JSON line with the keys the driver and the judge read (small workload, one GPU)"""
-    d = _bench(["--videos", "8", "--steps", "2", "--warmup", "1", "--cpu-videos", "4", "--exact-steps", "1", "--legs", "grounding,train,batch512",
-                "--vidor-videos", "2", "--recall-steps", "150", "--recall-videos", "6"])
+    """bench.py's last stdout line is ONE compact JSON object (< 4 KB, short keys) with the keys the driver and the judge read; the
+    long form goes to bench_detail.json (small workload, one GPU)"""
+    c, d = _bench(["--videos", "8", "--steps", "2", "--warmup", "1", "--cpu-videos", "4", "--exact-steps", "1", "--legs", "grounding,train,batch512",
+                   "--vidor-videos", "2", "--recall-steps", "150", "--recall-videos", "6", "--budget-s", "800"], detail=True)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline", "oracle_parity"):
-        assert k in d, k
-    assert d["metric"] == "tracklet_pairs_per_sec" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
-    assert d["value"] > 0 and abs(d["value"] - d["config"]["pairs_per_gpu_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+              "config", "roofline", "cpu_baseline", "parity", "legs", "skipped"):
+        assert k in c, k
+    assert c["metric"] == "tracklet_pairs_per_sec" and c["n_gpus"] == 1 and c["steps"] == 2 and c["warmup"] == 1 and c["higher_is_better"] is True
+    assert c["scaling"] == "weak" and c["vs_baseline"] is None and c["dtype"] == "f32" and c["data"] == "synthetic" and "workload" in c["config"]
+    assert c["value"] > 0 and abs(c["value"] - c["config"]["pairs_per_gpu"] / (c["ms_per_step"] * 1e-3)) < 1e-3 * c["value"]
+    assert c["config"]["timed_call"].startswith("model(proposal_list, topk)") and c["skipped"] == []
+    r = c["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    assert r["algorithmic_bytes_per_launch"] > 0 and "step_traffic_ratio" in r
+    cb = c["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    pa = c["parity"]
+    n_same, n_all = [int(x) for x in pa["rows"].split(" of ")]
+    assert pa["videos"] == 4 and n_all > 0 and n_same == n_all and pa["rows_off_both_oracles"] == 0 and pa["hip_vs_f64_max"] <= 1e-4
+    lg = c["legs"]
+    for k in ("resident", "pipelined", "plain_accum", "exact_f32", "fast_f16", "fast_bf16", "batch_x2", "grounding", "train_8", "train_64", "recall"):
+        assert k in lg, k
+    assert lg["grounding"]["unit"] == "queries/s" and lg["grounding"]["value"] > 0 and 0 < lg["grounding"]["mfma_frac"] < 1
+    assert lg["train_8"]["value"] > 0 and lg["train_64"]["value"] > 0 and lg["recall"]["gate"] is True
+    # ---- the long form
+    assert d["value"] == c["value"] and d["ms_per_step"] == c["ms_per_step"] and d["roofline"]["frac"] == r["frac"]
     # the timed call is the drop-in signature (pack + forward + results inside); the resident-batch forward rides beside it
     assert d["timed_call"].startswith("model(proposal_list, topk)") and d["forward_api"]["value"] == d["value"]
     assert d["resident_packed_batch"]["roofline"]["bound"] == "mfma" and d["resident_packed_batch"]["value"] > 0 and len(d["timed_steps_ms"]) == 2 and d["modes"]["resident_batch_holds_split_features"] is True
     assert d["kernel_families_ms_per_step"]["pack"] >= 0
     assert d["forward_api_pipelined"]["value"] > 0 and d["forward_api_pipelined"]["results_identical_to_the_synchronous_call"] is True
-    r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
-    c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["exact_f32_gemm_mode"]["triplet_indices_identical_to_default_mode"] in (True, False)
     # the opt-in reduced-precision mode rides along with its Recall@50 gate (SURVEY.md 8d) -- and is a different arithmetic
     f = d["fast_f16_gemm_mode"]
@@ -128,22 +158,28 @@ def test_bench_json_contract():
     # the literal bf16 arithmetic of BASELINE configs[1] rides along too, with the same gate
     assert f["bf16"]["value"] > 0 and f["bf16"]["max_logit_diff_rel_vs_parity_mode"] > 1e-5
     assert "bf16_gate_passed" in rc and rc["abs_diff_recall50_bf16_vs_parity_mode"] <= 0.05
-    assert r["sustained_mfma_peak"]["three_mfma_gemm_ceiling"] > 0
+    assert d["roofline"]["sustained_mfma_peak"]["three_mfma_gemm_ceiling"] > 0
     # the oracle outputs of the CPU-baseline sample are compared row for row with the HIP outputs of the same videos
     op = d["oracle_parity"]
-    n_same, n_all = [int(x) for x in op["identical_triplet_rows"].split(" of ")]
-    assert op["videos"] == 4 and n_all > 0 and n_same == n_all and op["videos_fully_identical"] == 4
+    assert op["videos"] == 4 and op["videos_fully_identical"] == 4
     # per video: within 1e-4 of the f32 oracle, or of a float64 evaluation, or inside the video's own f32 noise floor (oracle/accuracy.py)
     assert op["videos_outside_1e_4_and_their_f32_noise_floor"] == 0 and len(op["videos_over_1e_4"]) <= 1
-    # the other BASELINE configs ride in the same line, and the headline workload at twice the videos per step
+    # the other BASELINE configs ride in the same run, and the headline workload at twice the videos per step
     assert d["batch_x2"]["videos_per_step"] == 16 and d["batch_x2"]["value"] > 0 and d["batch_x2"]["roofline"]["bound"] == "mfma"
     g, t = d["grounding"], d["train"]
-    assert g["unit"] == "triplet-queries/s" and g["value"] > 0
+    assert g["unit"] == "triplet-queries/s" and g["value"] > 0 and g["roofline_mfma"]["bound"] == "mfma"
     # who took part: one rank on one device here; at N > 1 the same object lists every rank's device UUID and its own step time
     rk = d["ranks"]
     assert rk["world"] == 1 and rk["ranks_seen"] == [0] and rk["distinct_devices"] == 1 and rk["devices"][0]["uuid"] and rk["devices"][0]["name"]
     assert abs(rk["ms_per_step_max"] - d["ms_per_step"]) < 1e-2 and rk["ms_per_step_min"] == rk["ms_per_step_max"]
     assert t["videos_8"]["value"] > 0 and t["videos_64"]["value"] > 0
+
+
+def test_bench_time_budget_skips_optional_legs_and_keeps_the_required_objects():
+    """past --budget-s the optional legs are skipped and named in `skipped`; roofline, cpu_baseline and parity are still there"""
+    c = _bench(["--videos", "4", "--steps", "2", "--warmup", "1", "--cpu-videos", "2", "--budget-s", "0"])
+    assert c["roofline"]["frac"] > 0 and c["cpu_baseline"]["value"] > 0 and c["parity"]["videos"] == 2
+    assert {"recall", "vidor+grounding", "train", "batch_x2"} <= set(c["skipped"]) and "train_8" not in c["legs"]
 
 
 def test_bench_train_mode_runs_rccl_allreduce_on_one_rank():
@@ -165,4 +201,6 @@ def test_bench_eval_mode_with_rccl_group_and_self_launch():
     d = _bench(["--videos", "4", "--steps", "2", "--warmup", "1", "--cpu-videos", "0", "--exact-steps", "0", "--legs", "", "--no-prof", "--recall-steps", "0"],
                env={"BIGC_BENCH_FORCE_DIST": "1", "BIGC_BENCH_SELF_LAUNCH": "1"})
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
-    assert d["ranks"]["backend"] == "nccl" and d["ranks"]["world"] == 1 and d["ranks"]["distinct_devices"] == 1
+    import json
+    rk = json.load(open(os.path.join(ROOT, "bench_detail.json")))["ranks"]
+    assert rk["backend"] == "nccl" and rk["world"] == 1 and rk["distinct_devices"] == 1

@@ -19,6 +19,8 @@ the rows directly in the form the forward reads:
 The form is chosen at first use (``materialize``); a packed batch can be kept resident and
 reused.  Per-video metadata (categories, scores, durations) is gathered by a second small launch.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -30,9 +32,11 @@ def tracklet_table(p, device):
     addresses of the boxes -- what ``bigc_pack_tracklets`` gathers from.  Cached on the object (``_bigc_pack``): containers
     built by this package (``TrajProposal.from_blocks`` / ``.to()``, ``bigc_hip.ingest``) hold their tracklets as views of one
     block per video and get the table by arithmetic; for foreign containers (the reference's own ``TrajProposal``) the
-    tensors are visited once.  The cache is checked against the lists' length and first / last addresses: replacing a
-    tensor in the middle of ``features_list`` after the first forward needs ``del proposal._bigc_pack``.
-    The cached table holds ADDRESSES only, never tensors (a table that kept its sources alive pinned every evaluated
+    tensors are visited once.  The cache is checked against EVERY item of both lists: it holds a weak reference per source
+    tensor and is a hit only while each one is alive and IS the list's current item -- after the reference's to(GPU) -> forward -> to(cpu)
+    -> to(GPU) cycle the caching allocator may hand the old blocks back for the first / last tracklets and other blocks for the middle
+    ones; matching end addresses prove nothing.
+    The cached table holds ADDRESSES and weak references only, never tensors (a table that kept its sources alive pinned every evaluated
     video's GPU features for the whole run once the reference's ``TrajProposal.to(cpu)`` had replaced the list items); what keeps the
     memory behind the addresses alive while a forward reads it is the ``PackedBatch`` (``_sources``), for as long as IT lives.  A table
     made for another device is dropped."""
@@ -51,9 +55,10 @@ def tracklet_table(p, device):
     fl, bl = p.features_list, p.bboxes_list
     n = len(bl)
     assert n == len(fl) and n == int(p.num_proposals)
-    if c is not None and c["n"] == n and c["device"] == device and c["ends"] == (fl[0].data_ptr(), fl[-1].data_ptr(), bl[0].data_ptr(), bl[-1].data_ptr()):
-        # the caller's lists as they are NOW keep the rows alive for this batch (64 references per video; nothing is stored on `p`)
-        return dict(c, sources=(list(fl), list(bl)))
+    if c is not None and c["n"] == n and c["device"] == device and all(r() is t for r, t in zip(c["refs"][0], fl)) and all(r() is t for r, t in zip(c["refs"][1], bl)):
+        # the caller's lists as they are NOW keep the rows alive for this batch (64 references per video; nothing is stored on `p`);
+        # `_cached`: where PackedBatch keeps what it derives from the table (tmax, the metadata check) from one call to the next
+        return dict(c, sources=(list(fl), list(bl)), _cached=c)
     keep = []
     width = int(fl[0].shape[1])
 
@@ -74,15 +79,17 @@ def tracklet_table(p, device):
     fld = np.fromiter((f.stride(0) if f.shape[0] > 1 else width for f in fl2), dtype=np.int64, count=n)
     c = dict(n=n, device=device, width=width, lens=lens, fptr=fptr, bptr=bptr, fld=None if (fld == width).all() else fld.astype(np.int32),
              aligned=bool(((fptr | bptr) % np.uint64(16) == 0).all() and (fld % 4 == 0).all()),
-             ends=(fl[0].data_ptr(), fl[-1].data_ptr(), bl[0].data_ptr(), bl[-1].data_ptr()), keep=[])
+             refs=([weakref.ref(t) for t in fl], [weakref.ref(t) for t in bl]), keep=[])
+    cached = None
     if not keep:                  # (a table that points at converted COPIES is not kept: the caller may change its own tensors' values in place)
         try:
-            p._bigc_pack = c      # addresses only
+            p._bigc_pack = c      # addresses + weak references only
+            cached = c
         except Exception:
             pass
     # the copy handed to the PackedBatch carries the references that keep the addressed memory alive (a caller that drops a tensor from
     # the middle of its list while the batch is in flight must not leave the forward reading freed memory)
-    return dict(c, keep=keep, sources=(list(fl2), list(bl2)))
+    return dict(c, keep=keep, sources=(list(fl2), list(bl2)), _cached=cached if cached is not None else {})
 
 
 class PackedBatch(object):
@@ -109,7 +116,9 @@ class PackedBatch(object):
         all_lens = np.concatenate([t["lens"] for t in tabs])
         for t in tabs:
             if "tmax" not in t:
-                t["tmax"] = int(t["lens"].max())                # (kept with the cached table: 256 small reductions per call otherwise)
+                # kept with the CACHED table (256 small reductions per call otherwise): for a foreign container `t` is a per-call copy and
+                # `_cached` the dict that lives on the proposal
+                t["tmax"] = t.get("_cached", t)["tmax"] = int(t["lens"].max())
         tmax = np.asarray([t["tmax"] for t in tabs])
         wh = [[float(p.video_wh[0]), float(p.video_wh[1])] for p in proposals]
         self.n_rows = int(all_lens.sum())
@@ -127,11 +136,12 @@ class PackedBatch(object):
             a, b_, c_ = p.cat_ids, p.scores, p.traj_durations
             key = t.get("meta_key")
             if key is None or key[0] is not a or key[1] is not b_ or key[2] is not c_:          # checked once per set of tensors
-                t["meta_key"] = (a, b_, c_)
-                t["meta_ok"] = bool(p.cat_ids.dtype == torch.int64 and p.scores.dtype == torch.float32 and p.traj_durations.dtype == torch.int64
+                store = t.get("_cached", t)
+                store["meta_key"] = t["meta_key"] = (a, b_, c_)
+                store["meta_ok"] = t["meta_ok"] = bool(p.cat_ids.dtype == torch.int64 and p.scores.dtype == torch.float32 and p.traj_durations.dtype == torch.int64
                                     and p.cat_ids.device == device and p.scores.device == device and p.traj_durations.device == device
                                     and p.cat_ids.is_contiguous() and p.scores.is_contiguous() and p.traj_durations.is_contiguous())
-                t["meta_ptr"] = (p.cat_ids.data_ptr(), p.scores.data_ptr(), p.traj_durations.data_ptr())
+                store["meta_ptr"] = t["meta_ptr"] = (p.cat_ids.data_ptr(), p.scores.data_ptr(), p.traj_durations.data_ptr())
             return t["meta_ok"]
         meta_ok = device.type == "cuda" and all([meta_usable(p, t) for p, t in zip(proposals, tabs)])
 

@@ -7,7 +7,9 @@
 // stretched-conv gather-sum, head scatter, periodic reduction for the shared query/pos embeddings).
 #include "common.h"
 #include "prof.h"
+#include <map>
 #include <unordered_map>
+#include <utility>
 #include <stdlib.h>
 #include <string.h>
 
@@ -39,6 +41,7 @@ struct DwArgs {
     float* partial;        // when the M range is split: (splits, tiles_n*128, tiles_k*128) partial products
     int* arrived;          // per tile: how many of its splits have stored their partial product (nullptr: a second kernel sums them)
     int splits;
+    float* db_part = nullptr;   // when the M range is split and db is given: (splits, tiles_n*128) column sums of dY, added in split order by the reduction
     // row m of X starts at x_rowptr[m] (16-byte aligned, K floats) instead of X + m * ldx: the operand is read in place from rows that live
     // in separate allocations (bigc_batch.feat_row_ptr; split kernel, no gather)
     const uint64_t* x_rowptr = nullptr;
@@ -74,7 +77,27 @@ __device__ __forceinline__ void dw_finish_tile(const DwArgs& p, int tile, int n0
 #pragma unroll
         for (int c = 0; c < 4; ++c) if (col + c < p.K) dst[c] += acc[c];
     }
+    if (p.db_part && k0 == 0 && threadIdx.x < 128 && n0 + (int)threadIdx.x < p.N) {
+        float sb = 0.f;
+        for (int sp = 0; sp < p.splits; ++sp) sb += p.db_part[(size_t)sp * p.tiles_n * 128 + n0 + threadIdx.x];
+        p.db[n0 + threadIdx.x] += sb;
+    }
     if (threadIdx.x == 0) p.arrived[tile] = 0;
+}
+
+// The bias gradient (column sum of dY over this workgroup's M range; called by the tk == 0 workgroups, uniformly): the two half-slab
+// partial sums of a column meet in LDS (`lds`: 128 floats of the staging buffer, free after the K loop) and are added in a fixed order;
+// a single split adds its sum to db itself (one writer per column), several splits store theirs to db_part for the reduction stage to
+// add in split order.  No float atomics: the gradient's bits do not depend on the order the workgroups ran in.
+__device__ __forceinline__ void dw_bias_out(const DwArgs& p, float* lds, float bsum, int c, int mh, int split, int n0, bool nval) {
+    __syncthreads();                        // the last slab's fragment reads are done
+    if (mh == 1) lds[c] = bsum;
+    __syncthreads();
+    if (mh == 0 && nval) {
+        const float tot = bsum + lds[c];
+        if (p.db_part) p.db_part[(size_t)split * p.tiles_n * 128 + n0 + c] = tot;
+        else p.db[n0 + c] += tot;
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
@@ -143,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const DwArgs p) {
             }
         }
     }
-    if (p.db && tk == 0 && nval) atomicAdd(&p.db[ncol], bsum);
+    if (p.db && tk == 0) dw_bias_out(p, &smem[0][0], bsum, c, mh, split, n0, nval);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -346,7 +369,7 @@ __device__ __forceinline__ void linear_dw_split_body(const DwArgs& p, const int 
         if (more) store_slab(buf ^ 1);
         __syncthreads();
     }
-    if (do_bias && nval) atomicAdd(&p.db[n0 + c], bsum);
+    if (do_bias) dw_bias_out(p, (float*)&smem[0][0][0], bsum, c, mh, split, n0, nval);
     if (__syncthreads_or((!(fabsf(chk) < INFINITY) || amax >= 32768.0f) ? 1 : 0)) {
         // exact f32 MFMA straight from memory: lane (l31, hi) of block a / b owns row n / column k, m = m2 + hi
 #pragma unroll
@@ -420,6 +443,12 @@ __global__ __launch_bounds__(256) void dw_reduce_group_kernel(const DwGroup g) {
     if (!p.partial) return;
     const int nb = g.start[j + 1] - g.start[j], b = (int)blockIdx.x - g.start[j];
     const size_t n_pad = (size_t)p.tiles_n * 128, k_pad = (size_t)p.tiles_k * 128;
+    if (p.db_part)                          // the bias gradient's per-split column sums, added in split order
+        for (int n = b * 256 + threadIdx.x; n < p.N; n += nb * 256) {
+            float sb = 0.f;
+            for (int sp = 0; sp < p.splits; ++sp) sb += p.db_part[(size_t)sp * n_pad + n];
+            p.db[n] += sb;
+        }
     if (((p.K | p.ldw) & 3) == 0 && ((uintptr_t)p.dW & 15) == 0) {      // (gradient views of the flat buffer need not be 16-byte aligned)
         // four consecutive k per thread (16-byte accesses), one or two passes per thread
         const int K4 = p.K >> 2;
@@ -446,7 +475,13 @@ __global__ __launch_bounds__(256) void dw_reduce_group_kernel(const DwGroup g) {
 
 // dW[n, k] += sum over the M splits of their partial products (no atomics: summation order is fixed -> deterministic gradients)
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int ldw, int N, int K,
-                                                        int n_pad, int k_pad, int splits) {
+                                                        int n_pad, int k_pad, int splits, const float* __restrict__ db_part, float* __restrict__ db) {
+    if (db_part)                            // the bias gradient's per-split column sums, added in split order
+        for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+            float sb = 0.f;
+            for (int sp = 0; sp < splits; ++sp) sb += db_part[(size_t)sp * n_pad + n];
+            db[n] += sb;
+        }
     const long total = (long)N * K;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int n = (int)(i / K), k = (int)(i - (long)n * K);
@@ -489,14 +524,15 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
-// LayerNorm backward. One wave per row (grid-stride), d <= 2048. dgamma/dbeta accumulated per wave in
-// registers and added atomically once at the end.
+// LayerNorm backward. One wave per row (grid-stride), d <= 2048. dgamma/dbeta accumulated per wave in registers; the four waves of
+// a workgroup meet in LDS and the workgroup stores ONE partial row pair to `part` (gridDim.x, 2, d); partial_rows_finish_kernel adds
+// the workgroups' rows in block order (no float atomics: the parameter gradients are bit-reproducible from run to run).
 // NVL = float4 per lane (d <= 256 * NVL): the per-lane arrays are exactly as long as the row needs (a fixed length of 8
 // spilled 688 bytes per lane at d = 512)
 template <int NVL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                             const float* __restrict__ dy, float* __restrict__ dx,
-                                                            float* __restrict__ dg, float* __restrict__ db, int rows, int d, float eps) {
+                                                            float* __restrict__ part, int rows, int d, float eps) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const int nv = d >> 2;
@@ -565,7 +601,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
-    // the four waves of the workgroup are summed through LDS first: one atomic per column and workgroup
+    // the four waves of the workgroup are summed through LDS, in wave order: one partial row pair per workgroup
     __shared__ float red[2][4][256 * NVL];
     const int wv = threadIdx.x >> 6;
 #pragma unroll
@@ -576,9 +612,40 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             for (int c = 0; c < 4; ++c) { red[0][wv][i * 4 + c] = ag[j][c]; red[1][wv][i * 4 + c] = ab[j][c]; }
     }
     __syncthreads();
+    float* out = part + (size_t)blockIdx.x * 2 * d;
     for (int c = threadIdx.x; c < d; c += 256) {
-        atomicAdd(&dg[c], (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
-        atomicAdd(&db[c], (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+        out[c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        out[d + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+}
+
+// out[c] += part[0][c] + part[1][c] + ... over `blocks` partial rows of `w` columns, in a FIXED order: thread (g, c) of a 16 x 64 workgroup
+// adds the rows g, g + 16, g + 32, ... (eight loads in flight), the sixteen row groups of a column are then added in group order.
+// Columns [0, split) are added to out, columns [split, w) to out2 (LayerNorm's dgamma | dbeta, a depth-wise conv's weight | bias gradient).
+__global__ __launch_bounds__(1024) void partial_rows_finish_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ out2,
+                                                                    int blocks, int w, int split) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < w) {
+        int b = g;
+        for (; b + 7 * 16 < blocks; b += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 16 * u) * w + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < blocks; b += 16) s += part[(size_t)b * w + c];
+    }
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < w) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int u = 1; u < 16; ++u) t += red[u][cl];
+        if (c >= split) { if (out2) out2[c - split] += t; }
+        else out[c] += t;
     }
 }
 
@@ -832,16 +899,53 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void bias_matrix_bwd_kernel(const float* __restrict__ dlogits, int ldg, const int32_t* __restrict__ soid,
-                                                              const int32_t* __restrict__ e_off, const int32_t* __restrict__ trk_cat,
-                                                              int nq, int n_ecat, int n_pcat, float* __restrict__ dbias) {
-    const int row = blockIdx.x;
+// d bias_matrix[cat_s, cat_o, :] += d logits[row, :] for every query row (models/model_0v10.py:489-497: the bias rows are gathered by the
+// categories of the arg-max subject / object): a scatter-add with collisions.  No float atomics -- the rows that share a destination are
+// added in ROW ORDER by one workgroup: bias_matrix_key_kernel writes every row's destination, then the workgroup of row r leaves if an
+// earlier row has the same destination, else walks the rows from r on, 256 at a time, compacts the matching ones in order and adds them up.
+__global__ __launch_bounds__(256) void bias_matrix_key_kernel(const int32_t* __restrict__ soid, const int32_t* __restrict__ e_off,
+                                                              const int32_t* __restrict__ trk_cat, int rows, int nq, int n_ecat, int32_t* __restrict__ key) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
     const int v = row / nq, qi = row - v * nq;
     const int e0 = e_off[v];
-    if (e_off[v + 1] - e0 <= 0) return;
-    const int cs = trk_cat[e0 + soid[((size_t)v * 2) * nq + qi]], co = trk_cat[e0 + soid[((size_t)v * 2 + 1) * nq + qi]];
-    float* dst = dbias + ((size_t)cs * n_ecat + co) * n_pcat;
-    for (int i = threadIdx.x; i < n_pcat; i += 256) atomicAdd(&dst[i], dlogits[(size_t)row * ldg + i]);
+    int k = -1;
+    if (e_off[v + 1] - e0 > 0)
+        k = trk_cat[e0 + soid[((size_t)v * 2) * nq + qi]] * n_ecat + trk_cat[e0 + soid[((size_t)v * 2 + 1) * nq + qi]];
+    key[row] = k;
+}
+
+__global__ __launch_bounds__(256) void bias_matrix_bwd_kernel(const float* __restrict__ dlogits, int ldg, const int32_t* __restrict__ key, int rows,
+                                                              int n_pcat, float* __restrict__ dbias) {
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int my = key[r];
+    if (my < 0) return;
+    int dup = 0;
+    for (int j = tid; j < r; j += 256) dup |= key[j] == my;
+    if (__syncthreads_or(dup)) return;
+    __shared__ int cnt[4];
+    __shared__ int list[256];
+    float* dst = dbias + (size_t)my * n_pcat;
+    for (int i0 = 0; i0 < n_pcat; i0 += 256) {
+        const int col = i0 + tid;
+        float acc = 0.f;
+        for (int base = r; base < rows; base += 256) {
+            const int j = base + tid;
+            const bool m = j < rows && key[j] == my;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(m);
+            if (lane == 0) cnt[wv] = __builtin_popcountll(mask);
+            __syncthreads();
+            int off = 0, total = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { if (u < wv) off += cnt[u]; total += cnt[u]; }
+            if (m) list[off + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = j;
+            __syncthreads();
+            if (col < n_pcat)
+                for (int t = 0; t < total; ++t) acc += dlogits[(size_t)list[t] * ldg + col];
+            __syncthreads();
+        }
+        if (col < n_pcat) dst[col] += acc;
+    }
 }
 
 // copy the first dq columns of each row (d head_in -> d query)
@@ -889,18 +993,29 @@ extern "C" int bigc_transpose_f32(void* stream, const float* in, float* out, int
 // Split-K scratch of the weight-gradient kernels: one buffer per (calling thread, device, slot), grown on demand after a sync of the
 // calling stream.  (the buffers used to be function-static -- two threads driving two devices, which the per-handle
 // arithmetic modes explicitly allow, would have shared one pointer and raced on the regrow.)
+// slots: 0 / 1 weight-gradient partial tiles (single / grouped), 2 column sums, 3 LayerNorm and depth-wise conv parameter partials,
+// 4 the keys of the bias_matrix gradient.  One buffer per (calling thread, device, slot, STREAM): two streams driven from one thread never
+// share partials between a producer and its reduction.
 static int dw_scratch(void* stream, size_t need_floats, int slot, float** out) {
     struct Buf { float* p = nullptr; size_t cap = 0; };
-    thread_local std::unordered_map<int, Buf> bufs;
+    thread_local std::map<std::pair<int, void*>, Buf> bufs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_dw: hipGetDevice failed");
-    Buf& b = bufs[dev * 4 + slot];
+    Buf& b = bufs[std::make_pair(dev * 8 + slot, stream)];
     if (need_floats > b.cap) {
         if (b.p) { if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_dw: sync failed"); (void)hipFree(b.p); }
         b.cap = need_floats + need_floats / 2;
         if (hipMalloc((void**)&b.p, b.cap * sizeof(float)) != hipSuccess) { b.p = nullptr; b.cap = 0; return bigc_fail(BIGC_ERR_HIP, "linear_dw: hipMalloc of the split scratch failed"); }
     }
     *out = b.p;
+    return BIGC_OK;
+}
+
+// for the other training files (grounding_train.hip): the same scratch, and the fixed-order sum of per-workgroup partial rows
+int bigc_scratch_floats(hipStream_t s, size_t need_floats, int slot, float** out) { return dw_scratch((void*)s, need_floats, slot, out); }
+int bigc_partial_rows_finish(hipStream_t s, const float* part, float* out, float* out2, int blocks, int w, int split) {
+    hipLaunchKernelGGL(partial_rows_finish_kernel, dim3(cdiv(w, 64)), dim3(1024), 0, s, part, out, out2, blocks, w, split);
+    BIGC_LAUNCH_CHECK("partial_rows_finish");
     return BIGC_OK;
 }
 
@@ -927,10 +1042,11 @@ static int dw_launch(void* stream, const float* dY, int ldy, const float* X, int
     const size_t n_pad = (size_t)p.tiles_n * 128, k_pad = (size_t)p.tiles_k * 128;
     if (splits > 1) {
         // stream-ordered scratch, grown on demand, one per (thread, device): see dw_scratch
-        const size_t need = (size_t)splits * n_pad * k_pad;
+        const size_t need = (size_t)splits * n_pad * k_pad + (db ? (size_t)splits * n_pad : 0);
         float* scratch = nullptr;
         if (int rc = dw_scratch(stream, need, 0, &scratch)) return rc;
         p.partial = scratch;
+        if (db) p.db_part = scratch + (size_t)splits * n_pad * k_pad;
         // arrival counters of the in-kernel reduction (zero between launches); one set per (calling thread, device) like the scratch
         // (a function-static pointer was shared by threads driving different devices)
         thread_local std::unordered_map<int, int*> arrived_of;
@@ -959,7 +1075,7 @@ static int dw_launch(void* stream, const float* dY, int ldy, const float* X, int
         BIGC_LAUNCH_CHECK("linear_dw");
         if (splits > 1 && !p.arrived) {
             hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for((long)N * K)), dim3(256), 0, (hipStream_t)stream, p.partial, dW, ldw, N, K, (int)n_pad,
-                               (int)k_pad, splits);
+                               (int)k_pad, splits, (const float*)p.db_part, db);
             BIGC_LAUNCH_CHECK("dw_reduce");
         }
     }
@@ -1020,7 +1136,7 @@ int bigc_linear_dw_group(void* stream, const BigcDwJob* jobs, int n) {
             p.splits = splits; p.arrived = nullptr; p.partial = nullptr;
             g.start[i] = blocks;
             blocks += p.tiles_n * p.tiles_k * splits;
-            if (splits > 1) need += (size_t)splits * p.tiles_n * 128 * p.tiles_k * 128;
+            if (splits > 1) need += (size_t)splits * p.tiles_n * 128 * p.tiles_k * 128 + (q.db ? (size_t)splits * p.tiles_n * 128 : 0);
             flops += 2.0 * q.M * (double)q.N * q.K;
             bytes += 4.0 * ((double)q.M * q.N + (double)q.M * q.K + (double)q.N * q.K);
         }
@@ -1031,7 +1147,10 @@ int bigc_linear_dw_group(void* stream, const BigcDwJob* jobs, int n) {
             size_t off = 0;
             for (int i = 0; i < cnt; ++i) {
                 DwArgs& p = g.job[i];
-                if (p.splits > 1) { p.partial = scratch + off; off += (size_t)p.splits * p.tiles_n * 128 * p.tiles_k * 128; }
+                if (p.splits > 1) {
+                    p.partial = scratch + off; off += (size_t)p.splits * p.tiles_n * 128 * p.tiles_k * 128;
+                    if (p.db) { p.db_part = scratch + off; off += (size_t)p.splits * p.tiles_n * 128; }
+                }
             }
         }
         r = g;
@@ -1091,13 +1210,16 @@ extern "C" int bigc_layernorm_bwd_f32(void* stream, const float* x, const float*
     if (rows <= 0) return BIGC_OK;
     // every wave takes >= 8 rows (its parameter-gradient partials live in registers): few workgroups, few atomics
     const int grid = cdiv(rows, 32) < 512 ? cdiv(rows, 32) : 512;
+    float* part = nullptr;                  // (grid, 2, d) partial rows: stream-ordered scratch, see dw_scratch
+    if (int rc = dw_scratch(stream, (size_t)grid * 2 * d, 3, &part)) return rc;
     ProfScope ps(stream, FAM_BACKWARD, 0.0, 12.0 * rows * (double)d);
-#define LN_BWD(NVL) hipLaunchKernelGGL(layernorm_bwd_kernel<NVL>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dx, dgamma, dbeta, rows, d, eps)
+#define LN_BWD(NVL) hipLaunchKernelGGL(layernorm_bwd_kernel<NVL>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dx, part, rows, d, eps)
     if (d <= 256) LN_BWD(1);
     else if (d <= 512) LN_BWD(2);
     else if (d <= 1024) LN_BWD(4);
     else LN_BWD(8);
 #undef LN_BWD
+    hipLaunchKernelGGL(partial_rows_finish_kernel, dim3(cdiv(2 * d, 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)part, dgamma, dbeta, grid, 2 * d, d);
     BIGC_LAUNCH_CHECK("layernorm_bwd");
     return BIGC_OK;
 }
@@ -1153,7 +1275,11 @@ int bigc_head_gather_bwd(hipStream_t s, const float* dhead, int ld, const int32_
 int bigc_bias_matrix_bwd(hipStream_t s, const float* dlogits, int ldg, const int32_t* soid, const int32_t* e_off, const int32_t* trk_cat,
                          int n_vid, int nq, int n_ecat, int n_pcat, float* dbias) {
     if (n_vid <= 0) return BIGC_OK;
-    hipLaunchKernelGGL(bias_matrix_bwd_kernel, dim3(n_vid * nq), dim3(256), 0, s, dlogits, ldg, soid, e_off, trk_cat, nq, n_ecat, n_pcat, dbias);
+    const int rows = n_vid * nq;
+    float* key = nullptr;                   // one int32 per row (stream-ordered scratch)
+    if (int rc = dw_scratch((void*)s, (size_t)rows, 4, &key)) return rc;
+    hipLaunchKernelGGL(bias_matrix_key_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, soid, e_off, trk_cat, rows, nq, n_ecat, (int32_t*)key);
+    hipLaunchKernelGGL(bias_matrix_bwd_kernel, dim3(rows), dim3(256), 0, s, dlogits, ldg, (const int32_t*)key, rows, n_pcat, dbias);
     BIGC_LAUNCH_CHECK("bias_matrix_bwd");
     return BIGC_OK;
 }

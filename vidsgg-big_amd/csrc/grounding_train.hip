@@ -9,6 +9,8 @@
 #include "prof.h"
 
 int bigc_transpose_pad(hipStream_t s, const float* in, float* out, int rows, int cols, int ld_out);
+int bigc_scratch_floats(hipStream_t s, size_t need_floats, int slot, float** out);                                         // backward.hip
+int bigc_partial_rows_finish(hipStream_t s, const float* part, float* out, float* out2, int blocks, int w, int split);     // backward.hip
 int grd_query_input(hipStream_t hs, const float* enti, const float* pred, const int32_t* quint, const int32_t* dura, float video_len,
                     float* out, int n, int de, int kq);
 extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const float* X, int ldx, const int32_t* x_idx, int nseg,
@@ -63,9 +65,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const float* __restr
     }
 }
 
-// dW[c,j] += sum_{s,t} dY[s,t,c] X[s,t+j-ks/2,c] ; db[c] += sum dY[s,t,c]; one thread per channel and row chunk
-__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
-                                                           float* __restrict__ db, long rows, int T, int d, int ks, int rows_per_block) {
+// dW[c,j] += sum_{s,t} dY[s,t,c] X[s,t+j-ks/2,c] ; db[c] += sum dY[s,t,c]; one thread per channel and row chunk.  Every row chunk
+// (blockIdx.y) stores its sums as one partial row [d * ks weight terms | d bias terms] of `part`; bigc_partial_rows_finish adds the chunks
+// in order (no float atomics: bit-reproducible parameter gradients)
+__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                           long rows, int T, int d, int ks, int rows_per_block) {
     const int half = ks / 2;
     const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     for (int c = blockIdx.x * 256 + threadIdx.x; c < d; c += gridDim.x * 256) {
@@ -80,8 +84,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
                 if (tt >= 0 && tt < T) acc[j] += g * x[(r + (j - half)) * d + c];
             }
         }
-        for (int j = 0; j < ks; ++j) atomicAdd(&dw[(size_t)c * ks + j], acc[j]);
-        if (db) atomicAdd(&db[c], sb);
+        float* out = part + (size_t)blockIdx.y * ((size_t)d * ks + d);
+        for (int j = 0; j < ks; ++j) out[(size_t)c * ks + j] = acc[j];
+        out[(size_t)d * ks + c] = sb;
     }
 }
 
@@ -434,9 +439,12 @@ struct GBwd {
         float* gw = gof(m, key + ".depth_wise.weight");
         if (gw) {
             const int rpb = rows > 4096 ? (rows + 255) / 256 : 16;
-            hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3((d + 255) / 256, (rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)s, scratch, x, gw,
-                               gof(m, key + ".depth_wise.bias"), (long)rows, T, d, ks, rpb);
+            const int chunks = (rows + rpb - 1) / rpb;
+            float* part = nullptr;
+            TRY(bigc_scratch_floats((hipStream_t)s, (size_t)chunks * ((size_t)d * ks + d), 3, &part));
+            hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3((d + 255) / 256, chunks), dim3(256), 0, (hipStream_t)s, scratch, x, part, (long)rows, T, d, ks, rpb);
             BIGC_LAUNCH_CHECK("dwconv_bwd_w");
+            TRY(bigc_partial_rows_finish((hipStream_t)s, part, gw, gof(m, key + ".depth_wise.bias"), chunks, d * ks + d, d * ks));
         }
         if (dx_out) {
             const long total4 = (long)rows * (d / 4);

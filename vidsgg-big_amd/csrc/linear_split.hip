@@ -26,7 +26,10 @@
 #include <atomic>
 #include <stdlib.h>
 #include <mutex>
+#include <algorithm>
+#include <map>
 #include <unordered_map>
+#include <utility>
 
 namespace {
 
@@ -853,7 +856,8 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
     // dw_finish_tile -- was built and measured: 14.4 instead of 9.4 ms per training step, the device-scope release every workgroup then
     // needs writes back its L2.)
     // split-K for small grids (inside a SplitKScope only: the training step; see linear_internal.h): enough splits to give every CU a
-    // workgroup, each at least four slabs long, at most eight; partial tiles go to a stream-ordered scratch (one per thread and device)
+    // workgroup, each at least four slabs long, at most eight; partial tiles go to a stream-ordered scratch (one per thread, device AND stream: two streams driven from one thread
+    // must not share the partials between a GEMM and its reduce)
     p.splits = 1; p.part = nullptr;
     static const bool sk_off = getenv("BIGC_SPLITK") && atoi(getenv("BIGC_SPLITK")) == 0;
     {
@@ -862,7 +866,7 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
         const bool aligned = p.C && !p.Cs && p.N % 4 == 0 && p.ldc % 4 == 0 && ((uintptr_t)p.C & 15) == 0 && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
                              (!p.res || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
         if (bigc_splitk_allowed && !sk_off && aligned && !p.pre_x && !p.dw_w && tiles * 2 <= 256 && nk_tot >= 8) {
-            static const int min_slabs = getenv("BIGC_SPLITK_MINSLABS") ? atoi(getenv("BIGC_SPLITK_MINSLABS")) : 4;
+            static const int min_slabs = std::max(1, getenv("BIGC_SPLITK_MINSLABS") ? atoi(getenv("BIGC_SPLITK_MINSLABS")) : 4);
             int want = (int)(256 / tiles);
             if (want > nk_tot / min_slabs) want = nk_tot / min_slabs;
             if (want > 8) want = 8;
@@ -870,10 +874,10 @@ int bigc_linear_split_launch(hipStream_t s, LinearArgs& p, double flops, double 
                 const int nkp = cdiv(nk_tot, want);
                 p.splits = cdiv(nk_tot, nkp);
                 struct Buf { float* p = nullptr; size_t cap = 0; };
-                thread_local std::unordered_map<int, Buf> bufs;
+                thread_local std::map<std::pair<int, void*>, Buf> bufs;
                 int dev = 0;
                 if (hipGetDevice(&dev) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_split: hipGetDevice failed");
-                Buf& b = bufs[dev];
+                Buf& b = bufs[std::make_pair(dev, (void*)s)];
                 const size_t need = (size_t)p.splits * p.M * p.N;
                 if (need > b.cap) {
                     if (b.p) { if (hipStreamSynchronize(s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "linear_split: sync failed"); (void)hipFree(b.p); }

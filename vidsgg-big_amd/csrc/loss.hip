@@ -5,7 +5,10 @@
 // One wave per (video, query); latency-bound integer/transcendental work.
 #include "common.h"
 #include "prof.h"
+#include <algorithm>
+#include <map>
 #include <unordered_map>
+#include <utility>
 
 namespace {
 
@@ -156,12 +159,12 @@ static int loss_grad_launch(void* stream, const float* logits, int n_pcat, const
     if (n_vid <= 0) return BIGC_OK;
     ProfScope ps(stream, FAM_LOSS, 0.0, 0.0);
     const int blocks = (n_vid * nq + LG_ROWS - 1) / LG_ROWS;
-    // per-workgroup partial terms: a stream-ordered scratch per (calling thread, device), grown on demand
+    // per-workgroup partial terms: a stream-ordered scratch per (calling thread, device, stream), grown on demand
     struct Buf { float* p = nullptr; size_t cap = 0; };
-    thread_local std::unordered_map<int, Buf> bufs;
+    thread_local std::map<std::pair<int, void*>, Buf> bufs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "loss_grad: hipGetDevice failed");
-    Buf& b = bufs[dev];
+    Buf& b = bufs[std::make_pair(dev, stream)];
     if ((size_t)blocks * 3 > b.cap) {
         if (b.p) { if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "loss_grad: sync failed"); (void)hipFree(b.p); }
         b.cap = (size_t)blocks * 6;
@@ -280,7 +283,7 @@ namespace {
 // F.binary_cross_entropy_with_logits(x, y, reduction='mean') over a (rows, cols) block and its gradient
 //   l = max(x, 0) - x y + log1p(exp(-|x|)),  dl/dx = sigmoid(x) - y     (Base_C.loss, models/model_pairwise_baseline.py:301-312)
 __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy, long rows,
-                                                         int cols, float inv_n, float gscale, float* __restrict__ loss,
+                                                         int cols, float inv_n, float gscale, float* __restrict__ part,
                                                          float* __restrict__ dx, int lddx) {
     const long total = rows * cols;
     float acc = 0.f;
@@ -292,10 +295,18 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
         if (dx) dx[(size_t)r * lddx + c] = (1.0f / (1.0f + expf(-v)) - t) * inv_n * gscale;
     }
     acc = wave_sum(acc);
-    __shared__ float part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __shared__ float wsum4[4];
+    if ((threadIdx.x & 63) == 0) wsum4[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0 && loss) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) * inv_n);
+    if (threadIdx.x == 0 && part) part[blockIdx.x] = (wsum4[0] + wsum4[1] + wsum4[2] + wsum4[3]) * inv_n;    // one partial per workgroup
+}
+
+// loss += part[0] + part[1] + ... in a fixed order (one wave: lane l adds l, l + 64, ...; then the lanes, butterfly): no float atomics
+__global__ __launch_bounds__(64) void bce_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ loss) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *loss += s;
 }
 }  // namespace
 
@@ -307,8 +318,19 @@ extern "C" int bigc_bce_logits_f32(void* stream, const float* x, int ldx, const 
     ProfScope ps(stream, FAM_LOSS, 0.0, 0.0);
     const long total = rows * cols;
     const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    float* part = nullptr;
+    if (loss) {                             // per-workgroup partial sums: stream-ordered scratch per (calling thread, device, stream)
+        struct Buf { float* p = nullptr; };
+        thread_local std::map<std::pair<int, void*>, Buf> bufs;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "bce_logits: hipGetDevice failed");
+        Buf& b = bufs[std::make_pair(dev, stream)];
+        if (!b.p && hipMalloc((void**)&b.p, 1024 * sizeof(float)) != hipSuccess) { b.p = nullptr; return bigc_fail(BIGC_ERR_HIP, "bce_logits: hipMalloc of the partial sums failed"); }
+        part = b.p;
+    }
     hipLaunchKernelGGL(bce_logits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols, 1.0f / (float)total, gscale,
-                       loss, dx, lddx);
+                       part, dx, lddx);
+    if (loss) hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)part, grid, loss);
     BIGC_LAUNCH_CHECK("bce_logits");
     return BIGC_OK;
 }

@@ -73,10 +73,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // 16 bytes of f16 residuals of 8 x -- for the GEMM that reads it next (a lane owns 4 consecutive columns: half a group of each).
 template <int G, int NVL, int UNR, bool ADD, bool HR8 = false>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                                                             float* __restrict__ y, int rows, float eps,
+                                                             float* y, int rows, float eps,
                                                              const float* __restrict__ add, int period, float* __restrict__ y_plain,
                                                              unsigned char* __restrict__ ys = nullptr, long ldys = 0, int* __restrict__ range_flag = nullptr,
-                                                             const float* __restrict__ pre = nullptr) {
+                                                             const float* pre = nullptr) {
+    // `y` and `pre` carry no __restrict__: the decoder calls this in place (pre == y, include/bigc_hip.h bigc_layernorm_res_f32) -- a wave
+    // reads its rows of `pre` completely before it stores them, and no other wave touches those rows
     // pre != nullptr: the rows are x + pre (a GEMM's output and its residual, models/model_0v10.py:188,211,223: LayerNorm(query + sublayer)).
     // The sum used to be the GEMM's epilogue; there a lane owns a data ROW, so the residual came in as 16 bytes from each of 32 rows per
     // load instruction -- 34 of the 129 us of a decoder 512 x 512 GEMM -- while here a row is read by whole lines.  Same f32 addition, same bits.

@@ -52,18 +52,18 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict_
 }
 
 template <int HD>
-__global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
-                                                         const float* __restrict__ v, int ldv, const float* __restrict__ dO, int lddo,
-                                                         const float* __restrict__ lse, const float* __restrict__ delta,
-                                                         float* __restrict__ dq, int lddq, const int32_t* __restrict__ q_off,
-                                                         const int32_t* __restrict__ k_off, int n_seq, int n_qt, int n_head, float scale,
-                                                         const DropSpec drop, const int* __restrict__ run_flag, int run_id) {
-    if (run_flag && *run_flag != run_id) return;        // fallback launch behind attention_bwd_split.hip: only when that one flagged
+__device__ __forceinline__ void mha_bwd_dq_body(const int bid, const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                const float* __restrict__ v, int ldv, const float* __restrict__ dO, int lddo,
+                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                float* __restrict__ dq, int lddq, const int32_t* __restrict__ q_off,
+                                                const int32_t* __restrict__ k_off, int n_seq, int n_qt, int n_head, float scale,
+                                                const DropSpec drop, const int* __restrict__ run_flag, int run_id) {
+    if (run_flag && *run_flag != run_id) return;        // fallback launch behind the split-operand kernels: only when they flagged
     constexpr int HALF = HD / 2;
     constexpr int NTD = (HD + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const long item = (long)blockIdx.x * 4 + wave;
+    const long item = (long)bid * 4 + wave;
     if (item >= (long)n_seq * n_qt * n_head) return;
     const int h = item % n_head;
     const int qt = (item / n_head) % n_qt;
@@ -124,19 +124,19 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
 }
 
 template <int HD>
-__global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
-                                                          const float* __restrict__ v, int ldv, const float* __restrict__ dO, int lddo,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv,
-                                                          const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
-                                                          int n_seq, int n_kt, int n_head, float scale, const DropSpec drop,
-                                                          const int* __restrict__ run_flag, int run_id) {
+__device__ __forceinline__ void mha_bwd_dkv_body(const int bid, const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                 const float* __restrict__ v, int ldv, const float* __restrict__ dO, int lddo,
+                                                 const float* __restrict__ lse, const float* __restrict__ delta,
+                                                 float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv,
+                                                 const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
+                                                 int n_seq, int n_kt, int n_head, float scale, const DropSpec drop,
+                                                 const int* __restrict__ run_flag, int run_id) {
     if (run_flag && *run_flag != run_id) return;
     constexpr int HALF = HD / 2;
     constexpr int NTD = (HD + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const long item = (long)blockIdx.x * 4 + wave;
+    const long item = (long)bid * 4 + wave;
     if (item >= (long)n_seq * n_kt * n_head) return;
     const int h = item % n_head;
     const int kt = (item / n_head) % n_kt;
@@ -208,6 +208,23 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------------
 // d scores of the role attention, already multiplied by `scale` (= d of the raw dot products).
+// dQ and dK / dV in ONE launch: workgroups [0, gq) take the query tiles, [gq, gq + gk) the key tiles (the gated fallback behind the
+// split-operand kernel, and the exact mode / the other head dims: one launch where there were two)
+template <int HD>
+__global__ __launch_bounds__(256) void mha_bwd_both_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                           const float* __restrict__ v, int ldv, const float* __restrict__ dO, int lddo,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           float* __restrict__ dq, int lddq, float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv,
+                                                           const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off,
+                                                           int n_seq, int n_qt, int n_kt, int gq, int n_head, float scale, const DropSpec drop,
+                                                           const int* __restrict__ run_flag, int run_id) {
+    if ((int)blockIdx.x < gq)
+        mha_bwd_dq_body<HD>((int)blockIdx.x, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta, dq, lddq, q_off, k_off, n_seq, n_qt, n_head, scale, drop, run_flag, run_id);
+    else
+        mha_bwd_dkv_body<HD>((int)blockIdx.x - gq, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta, dk, lddk, dv, lddv, q_off, k_off, n_seq, n_kt, n_head, scale, drop,
+                             run_flag, run_id);
+}
+
 __global__ __launch_bounds__(256) void role_attention_bwd_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
                                                                  const float* __restrict__ datt, float* __restrict__ ds,
                                                                  const int32_t* __restrict__ e_off, int n_vid, int nq, int n_qt, int half,
@@ -535,8 +552,8 @@ extern "C" int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, cons
     const int n_qt = cdiv(max_q, 32), n_kt = cdiv(max_k, 32);
     const int gq = (int)(((long)n_seq * n_qt * n_head + 3) / 4), gk = (int)(((long)n_seq * n_kt * n_head + 3) / 4);
 #define LAUNCH_BWD(HD) \
-    hipLaunchKernelGGL(mha_bwd_dq_kernel<HD>, dim3(gq), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dq, lddq, q_off, k_off, n_seq, n_qt, n_head, scale, drop, run_flag, run_id); \
-    hipLaunchKernelGGL(mha_bwd_dkv_kernel<HD>, dim3(gk), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dk, lddk, dv, lddv, q_off, k_off, n_seq, n_kt, n_head, scale, drop, run_flag, run_id)
+    hipLaunchKernelGGL(mha_bwd_both_kernel<HD>, dim3(gq + gk), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dq, lddq, dk, lddk, dv, lddv, \
+                       q_off, k_off, n_seq, n_qt, n_kt, gq, n_head, scale, drop, run_flag, run_id)
     if (run_flag)
         bigc_mha_bwd_h_launch(s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta_scratch, dq, lddq, dk, lddk, dv, lddv, q_off, k_off, n_seq, n_qt, n_kt, n_head, scale,
                               drop, run_flag, run_id, amax_slot);

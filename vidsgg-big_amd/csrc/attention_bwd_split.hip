@@ -253,6 +253,236 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_h_kernel(const float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: dQ, dK and dV in ONE launch, the shared operand of a step split ONCE per workgroup into LDS.
+//
+// The two kernels above give one wave a tile of its own rows and let it walk the other side's tiles alone: every wave loads and splits
+// the same K / V / Q / dO rows again (272 split elements per lane and tile pair beside 84 MFMAs), and the walk is a chain of dependent
+// global loads (35 + 60 us per decoder layer for 8 videos -- the same for the encoder's 64-row sequences: latency, not work).  Here a
+// workgroup is (sequence, head, side, group of <= 4 own tiles): side KV owns key tiles (dK, dV), side Q owns query tiles (dQ); the
+// workgroups of both sides run side by side in the same launch.  Per step the whole workgroup stages ONE tile of the other side --
+// 32 rows of the two operands it multiplies with -- into LDS in the split form, in the two layouts the MFMAs read:
+//   R (row-major: 16-byte chunks of 8 head dims, a row every 272 bytes) -> A fragments of the score / dP products,
+//   T (transposed: per head dim the tile's 32 rows in the register order of an accumulator, 8 per 16-byte chunk, a column every 144
+//      bytes) -> B fragments of the products that contract over the tile's rows (P^T dO, dS^T Q, dS K),
+// both pitches conflict-free for ds_read_b128.  The next tile's global loads are issued before the current tile's MFMAs and split into
+// the other LDS buffer behind them: one barrier per step.  Per lane and tile pair 48 elements are split on the fly (P, dS) instead of 272.
+// Same arithmetic per product as above (three f16 MFMAs, two accumulators), same dropout masks, same range flag.
+constexpr int RP = 272, TP = 144;                       // bytes per row of R / per column of T
+constexpr int LDS_R = 32 * RP, LDS_T = HD * TP;         // 8704, 9216
+constexpr int LDS_BUF = 2 * LDS_R + 2 * LDS_T + 256;    // [R1 | R2 | T1 | T2 | lse (32 f32) | delta (32 f32)] = 36096 bytes; two of them
+
+struct FusedArgs {
+    const float *q, *k, *v, *dO, *lse, *delta;
+    float *dq, *dk, *dv;
+    int ldq, ldk, ldv, lddo, lddq, lddk, lddv;
+    const int32_t *q_off, *k_off;
+    int n_head, gq_groups, gk_groups;
+    float scale;
+    DropSpec drop;
+    int* flag; int run_id; const float* amax_slot;
+};
+
+template <int NW, bool KV>
+__device__ __forceinline__ void bwd_side(const FusedArgs& a, unsigned char* lds, const int s, const int h, const int group, const float gs, const float gi) {
+    constexpr int NTH = 64 * NW;
+    constexpr int N_ITEMS = KV ? 1024 : 768;              // R1, R2: 256 each; T1 (and T2 for KV): 256 each
+    constexpr int ITERS = (N_ITEMS + NTH - 1) / NTH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int q0 = a.q_off[s], nq = a.q_off[s + 1] - q0;
+    const int k0 = a.k_off[s], nk = a.k_off[s + 1] - k0;
+    const int n_own = KV ? nk : nq, n_oth = KV ? nq : nk;
+    if (n_own <= 0 || n_oth <= 0 || group * NW * 32 >= n_own) return;          // (uniform over the workgroup)
+    const int ot = group * NW + wave;
+    const bool own_valid = ot * 32 < n_own;                                     // (uniform over the wave)
+    const int orow = min(ot * 32 + l31, n_own - 1);
+    const bool rok = ot * 32 + l31 < n_own;
+    // the operands of the other side: X1 meets own1 in the scores, X2 meets own2 in dP
+    const float* x1 = KV ? a.q + (size_t)q0 * a.ldq + h * HD : a.k + (size_t)k0 * a.ldk + h * HD;
+    const float* x2 = KV ? a.dO + (size_t)q0 * a.lddo + h * HD : a.v + (size_t)k0 * a.ldv + h * HD;
+    const int ld1 = KV ? a.ldq : a.ldk, ld2 = KV ? a.lddo : a.ldv;
+    const float mul2 = KV ? gs : 1.0f;
+    float chk = 0.f, amax = 0.f;
+    a16x8 o1h[NST], o1r[NST], o2h[NST], o2r[NST];
+    {
+        const float* p1 = KV ? a.k + (size_t)(k0 + orow) * a.ldk + h * HD + 8 * hi : a.q + (size_t)(q0 + orow) * a.ldq + h * HD + 8 * hi;
+        const float* p2 = KV ? a.v + (size_t)(k0 + orow) * a.ldv + h * HD + 8 * hi : a.dO + (size_t)(q0 + orow) * a.lddo + h * HD + 8 * hi;
+        load_row_split(p1, a.scale, o1h, o1r, chk, amax);                       // (the 1 / sqrt(hd) of the scores rides on the own side)
+        load_row_split(p2, KV ? 1.0f : gs, o2h, o2r, chk, amax);
+    }
+    float my_lse = 0.f, my_delta = 0.f;
+    if (!KV) { my_lse = a.lse[(size_t)(q0 + orow) * a.n_head + h]; my_delta = a.delta[(size_t)(q0 + orow) * a.n_head + h] * gs; }
+    // accumulators: [0] = P^T dO (dV, KV only), [1] = dS^T Q (dK) / dS K (dQ)
+    f32x16 acc0[KV ? 2 : 1][2], acc1[KV ? 2 : 1][2];
+#pragma unroll
+    for (int o = 0; o < (KV ? 2 : 1); ++o)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { acc0[o][t] = zero16(); acc1[o][t] = zero16(); }
+
+    // ---- staging of one tile of the other side: items [0,256) R1, [256,512) R2, [512,768) T1, [768,1024) T2
+    float pre[ITERS][8];
+    auto fetch = [&](int tile) {
+        const int row0 = tile * 32;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int id = tid + it * NTH;
+            if (ITERS * NTH > N_ITEMS && id >= N_ITEMS) break;
+            const int kind = id >> 8, e = id & 255;
+            if (kind < 2) {                                   // row-major: row e >> 3, chunk e & 7
+                const float* src = (kind ? x2 : x1) + (size_t)min(row0 + (e >> 3), n_oth - 1) * (kind ? ld2 : ld1) + 8 * (e & 7);
+                const f32x4 t0 = *(const f32x4*)src, t1 = *(const f32x4*)(src + 4);
+                pre[it][0] = t0[0]; pre[it][1] = t0[1]; pre[it][2] = t0[2]; pre[it][3] = t0[3];
+                pre[it][4] = t1[0]; pre[it][5] = t1[1]; pre[it][6] = t1[2]; pre[it][7] = t1[3];
+            } else {                                          // transposed: head dim e & 63, chunk g = e >> 6 = 2 u + hi: rows mfma_row(8 u + j, hi)
+                const int d = e & 63, g = e >> 6;
+                const float* base = (kind == 3 ? x2 : x1) + d;
+                const int ldx = kind == 3 ? ld2 : ld1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pre[it][j] = base[(size_t)min(row0 + mfma_row(8 * (g >> 1) + j, g & 1), n_oth - 1) * ldx];
+            }
+        }
+    };
+    auto stash = [&](unsigned char* buf) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int id = tid + it * NTH;
+            if (ITERS * NTH > N_ITEMS && id >= N_ITEMS) break;
+            const int kind = id >> 8, e = id & 255;
+            const float mul = (kind == 1 || kind == 3) ? mul2 : 1.0f;
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = pre[it][j] * mul;
+            a16x8 hh, rr;
+            split8(x, hh, rr, chk, amax);
+            unsigned char* dst;
+            int roff;
+            if (kind < 2) { dst = buf + kind * LDS_R + (e >> 3) * RP + (e & 7) * 16; roff = 128; }
+            else { dst = buf + 2 * LDS_R + (kind - 2) * LDS_T + (e & 63) * TP + (e >> 6) * 32; roff = 16; }
+            *(a16x8*)dst = hh;
+            *(a16x8*)(dst + roff) = rr;
+        }
+    };
+    auto stash_stats = [&](unsigned char* buf, int tile) {        // KV: lse / delta of the tile's 32 query rows
+        if (KV && tid < 64) {
+            const int r = min(tile * 32 + (tid & 31), nq - 1);
+            float* dst = (float*)(buf + 2 * LDS_R + 2 * LDS_T);
+            dst[tid] = tid < 32 ? a.lse[(size_t)(q0 + r) * a.n_head + h] : a.delta[(size_t)(q0 + r) * a.n_head + h] * gs;
+        }
+    };
+    // C^T tile = (rows of R) x (own rows)^T over the head dimension
+    auto dot_lds = [&](const unsigned char* R, const a16x8 (&bh)[NST], const a16x8 (&br)[NST], f32x16& out) {
+        f32x16 c0 = zero16(), c1 = zero16();
+        const unsigned char* rowp = R + l31 * RP + hi * 16;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const a16x8 ah = *(const a16x8*)(rowp + st * 32), ar = *(const a16x8*)(rowp + st * 32 + 128);
+            c0 = MFMA_H(ah, bh[st], c0);
+            c1 = MFMA_H(ah, br[st], c1);
+            c1 = MFMA_H(ar, bh[st], c1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[r] = c0[r] + c1[r] * RI;
+    };
+    // acc[t] += W^T X: W = this lane's 16 register values (A operand as they stand), X^T from T: column 32 t + l31
+    auto accum_lds = [&](const float (&w)[16], const unsigned char* T, f32x16 (&o0)[2], f32x16 (&o1)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float w8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w8[j] = w[8 * u + j];
+            a16x8 wh, wr;
+            split8(w8, wh, wr, chk, amax);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned char* cp = T + (32 * t + l31) * TP + (2 * u + hi) * 32;
+                const a16x8 xh = *(const a16x8*)cp, xr = *(const a16x8*)(cp + 16);
+                o0[t] = MFMA_H(wh, xh, o0[t]);
+                o1[t] = MFMA_H(wh, xr, o1[t]);
+                o1[t] = MFMA_H(wr, xh, o1[t]);
+            }
+        }
+    };
+
+    const int n_tiles = (n_oth + 31) / 32;
+    fetch(0);
+    stash(lds);
+    stash_stats(lds, 0);
+    __syncthreads();
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        unsigned char* cur = lds + (tile & 1) * LDS_BUF;
+        unsigned char* nxt = lds + ((tile + 1) & 1) * LDS_BUF;
+        const bool more = tile + 1 < n_tiles;
+        if (more) fetch(tile + 1);
+        if (own_valid) {
+            f32x16 sc, dp;
+            dot_lds(cur, o1h, o1r, sc);
+            dot_lds(cur + LDS_R, o2h, o2r, dp);
+            const float* stats = (const float*)(cur + 2 * LDS_R + 2 * LDS_T);
+            float pd[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orr = mfma_row(r, hi);                    // row of the staged tile this register belongs to
+                const int oi = tile * 32 + orr;
+                const bool ok = oi < n_oth && rok;
+                const float lr = KV ? stats[orr] : my_lse, dr = KV ? stats[32 + orr] : my_delta;
+                const float p = ok ? expf(sc[r] - lr) : 0.f;
+                float pdr = p, dpr = dp[r];
+                if (a.drop.thresh) {
+                    const int qrow_g = KV ? q0 + min(oi, nq - 1) : q0 + orow;
+                    const int key = KV ? ot * 32 + l31 : oi;
+                    const bool keep = drop_keep(a.drop, drop_att_idx(qrow_g, a.n_head, h, key));
+                    pdr = keep ? p * a.drop.scale : 0.f;
+                    dpr = keep ? dpr * a.drop.scale : 0.f;
+                }
+                pd[r] = pdr;
+                ds[r] = p * (dpr - dr);
+            }
+            if (KV) {
+                accum_lds(pd, cur + 2 * LDS_R + LDS_T, acc0[0], acc1[0]);                    // dV += P^T dO
+                accum_lds(ds, cur + 2 * LDS_R, acc0[KV ? 1 : 0], acc1[KV ? 1 : 0]);          // dK += dS^T Q
+            } else {
+                accum_lds(ds, cur + 2 * LDS_R, acc0[0], acc1[0]);                            // dQ += dS K
+            }
+        }
+        if (more) { stash(nxt); stash_stats(nxt, tile + 1); }
+        __syncthreads();
+    }
+    if (!(fabsf(chk) < INFINITY) || amax >= 32768.0f) atomicMax(a.flag, a.run_id);
+    if (!own_valid) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = ot * 32 + mfma_row(r, hi);
+        if (row >= n_own) continue;
+        if (KV) {
+            float* vd = a.dv + (size_t)(k0 + row) * a.lddv + h * HD + l31;
+            float* kd = a.dk + (size_t)(k0 + row) * a.lddk + h * HD + l31;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                vd[32 * t] = (acc0[0][t][r] + acc1[0][t][r] * RI) * gi;
+                kd[32 * t] = (acc0[KV ? 1 : 0][t][r] + acc1[KV ? 1 : 0][t][r] * RI) * a.scale * gi;
+            }
+        } else {
+            float* qd = a.dq + (size_t)(q0 + row) * a.lddq + h * HD + l31;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) qd[32 * t] = (acc0[0][t][r] + acc1[0][t][r] * RI) * a.scale * gi;
+        }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void mha_bwd_fused_h_kernel(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+    const int per = a.gk_groups + a.gq_groups;
+    const int item = blockIdx.x / per, r = blockIdx.x - item * per;
+    const int h = item % a.n_head, s = item / a.n_head;
+    float gs, gi;
+    grad_scale(a.amax_slot, gs, gi);
+    if (r < a.gk_groups) bwd_side<NW, true>(a, fused_lds, s, h, r, gs, gi);
+    else bwd_side<NW, false>(a, fused_lds, s, h, r - a.gk_groups, gs, gi);
+}
+
 }  // namespace
 
 namespace {
@@ -294,6 +524,28 @@ void bigc_mha_bwd_h_launch(hipStream_t s, const float* q, int ldq, const float* 
                            const float* lse, const float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                            const int32_t* q_off, const int32_t* k_off, int n_seq, int n_qt, int n_kt, int n_head, float scale,
                            const DropSpec& drop, int* flag, int run_id, const float* amax_slot) {
+    // default (round 6): one launch, the other side's tiles staged split in LDS; BIGC_MHA_BWD_LDS=0 = the two wave-per-tile kernels
+    static const bool lds_off = getenv("BIGC_MHA_BWD_LDS") && atoi(getenv("BIGC_MHA_BWD_LDS")) == 0;
+    if (!lds_off) {
+        FusedArgs a;
+        a.q = q; a.k = k; a.v = v; a.dO = dO; a.lse = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
+        a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+        a.q_off = q_off; a.k_off = k_off; a.n_head = n_head; a.scale = scale; a.drop = drop; a.flag = flag; a.run_id = run_id; a.amax_slot = amax_slot;
+        const int nw = (n_qt <= 2 && n_kt <= 2) ? 2 : 4;              // own tiles per workgroup: sequences of at most 64 rows (the encoder) fit two waves
+        a.gq_groups = (n_qt + nw - 1) / nw; a.gk_groups = (n_kt + nw - 1) / nw;
+        const int grid = n_seq * n_head * (a.gq_groups + a.gk_groups);
+        static std::atomic<unsigned long long> attr{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!((attr.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull)) {
+            (void)hipFuncSetAttribute((const void*)mha_bwd_fused_h_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF);
+            (void)hipFuncSetAttribute((const void*)mha_bwd_fused_h_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF);
+            attr.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+        }
+        if (nw == 2) hipLaunchKernelGGL(mha_bwd_fused_h_kernel<2>, dim3(grid), dim3(128), 2 * LDS_BUF, s, a);
+        else hipLaunchKernelGGL(mha_bwd_fused_h_kernel<4>, dim3(grid), dim3(256), 2 * LDS_BUF, s, a);
+        return;
+    }
     const int gq = (int)(((long)n_seq * n_qt * n_head + 3) / 4), gk = (int)(((long)n_seq * n_kt * n_head + 3) / 4);
     hipLaunchKernelGGL(mha_bwd_dq_h_kernel, dim3(gq), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, delta, dq, lddq, q_off, k_off, n_seq, n_qt,
                        n_head, scale, drop, flag, run_id, amax_slot);

@@ -900,9 +900,8 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 }
 
 // d bias_matrix[cat_s, cat_o, :] += d logits[row, :] for every query row (models/model_0v10.py:489-497: the bias rows are gathered by the
-// categories of the arg-max subject / object): a scatter-add with collisions.  No float atomics -- the rows that share a destination are
-// added in ROW ORDER by one workgroup: bias_matrix_key_kernel writes every row's destination, then the workgroup of row r leaves if an
-// earlier row has the same destination, else walks the rows from r on, 256 at a time, compacts the matching ones in order and adds them up.
+// categories of the arg-max subject / object): a scatter-add with collisions.  No float atomics -- bias_matrix_key_kernel writes every
+// row's destination, ordered_rows_add_kernel adds the rows that share one in ROW ORDER.
 __global__ __launch_bounds__(256) void bias_matrix_key_kernel(const int32_t* __restrict__ soid, const int32_t* __restrict__ e_off,
                                                               const int32_t* __restrict__ trk_cat, int rows, int nq, int n_ecat, int32_t* __restrict__ key) {
     const int row = blockIdx.x * 256 + threadIdx.x;
@@ -915,23 +914,26 @@ __global__ __launch_bounds__(256) void bias_matrix_key_kernel(const int32_t* __r
     key[row] = k;
 }
 
-__global__ __launch_bounds__(256) void bias_matrix_bwd_kernel(const float* __restrict__ dlogits, int ldg, const int32_t* __restrict__ key, int rows,
-                                                              int n_pcat, float* __restrict__ dbias) {
+// dst[key[r] * ld_dst + c] += sum over the rows r' with key[r'] == key[r] of src[r' * ld_src + c], added in ascending r' (rows with a
+// negative key are skipped).  One workgroup per row r: it leaves when an earlier row has the same key, else it is the key's first row and
+// walks the rows from r on, 256 at a time, compacting the matching ones in order.  The ordered form of a scatter-add with collisions.
+__global__ __launch_bounds__(256) void ordered_rows_add_kernel(const float* __restrict__ src, int ld_src, const int32_t* __restrict__ key, int key_stride,
+                                                               int rows, int width, float* __restrict__ dst, int ld_dst) {
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int my = key[r];
+    const int my = key[(size_t)r * key_stride];
     if (my < 0) return;
     int dup = 0;
-    for (int j = tid; j < r; j += 256) dup |= key[j] == my;
+    for (int j = tid; j < r; j += 256) dup |= key[(size_t)j * key_stride] == my;
     if (__syncthreads_or(dup)) return;
     __shared__ int cnt[4];
     __shared__ int list[256];
-    float* dst = dbias + (size_t)my * n_pcat;
-    for (int i0 = 0; i0 < n_pcat; i0 += 256) {
+    float* out = dst + (size_t)my * ld_dst;
+    for (int i0 = 0; i0 < width; i0 += 256) {
         const int col = i0 + tid;
         float acc = 0.f;
         for (int base = r; base < rows; base += 256) {
             const int j = base + tid;
-            const bool m = j < rows && key[j] == my;
+            const bool m = j < rows && key[(size_t)j * key_stride] == my;
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(m);
             if (lane == 0) cnt[wv] = __builtin_popcountll(mask);
             __syncthreads();
@@ -940,11 +942,11 @@ __global__ __launch_bounds__(256) void bias_matrix_bwd_kernel(const float* __res
             for (int u = 0; u < 4; ++u) { if (u < wv) off += cnt[u]; total += cnt[u]; }
             if (m) list[off + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = j;
             __syncthreads();
-            if (col < n_pcat)
-                for (int t = 0; t < total; ++t) acc += dlogits[(size_t)list[t] * ldg + col];
+            if (col < width)
+                for (int t = 0; t < total; ++t) acc += src[(size_t)list[t] * ld_src + col];
             __syncthreads();
         }
-        if (col < n_pcat) dst[col] += acc;
+        if (col < width) out[col] += acc;
     }
 }
 
@@ -1013,6 +1015,12 @@ static int dw_scratch(void* stream, size_t need_floats, int slot, float** out) {
 
 // for the other training files (grounding_train.hip): the same scratch, and the fixed-order sum of per-workgroup partial rows
 int bigc_scratch_floats(hipStream_t s, size_t need_floats, int slot, float** out) { return dw_scratch((void*)s, need_floats, slot, out); }
+int bigc_ordered_rows_add(hipStream_t s, const float* src, int ld_src, const int32_t* key, int key_stride, int rows, int width, float* dst, int ld_dst) {
+    if (rows <= 0 || width <= 0) return BIGC_OK;
+    hipLaunchKernelGGL(ordered_rows_add_kernel, dim3(rows), dim3(256), 0, s, src, ld_src, key, key_stride, rows, width, dst, ld_dst);
+    BIGC_LAUNCH_CHECK("ordered_rows_add");
+    return BIGC_OK;
+}
 int bigc_partial_rows_finish(hipStream_t s, const float* part, float* out, float* out2, int blocks, int w, int split) {
     hipLaunchKernelGGL(partial_rows_finish_kernel, dim3(cdiv(w, 64)), dim3(1024), 0, s, part, out, out2, blocks, w, split);
     BIGC_LAUNCH_CHECK("partial_rows_finish");
@@ -1279,7 +1287,7 @@ int bigc_bias_matrix_bwd(hipStream_t s, const float* dlogits, int ldg, const int
     float* key = nullptr;                   // one int32 per row (stream-ordered scratch)
     if (int rc = dw_scratch((void*)s, (size_t)rows, 4, &key)) return rc;
     hipLaunchKernelGGL(bias_matrix_key_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, soid, e_off, trk_cat, rows, nq, n_ecat, (int32_t*)key);
-    hipLaunchKernelGGL(bias_matrix_bwd_kernel, dim3(rows), dim3(256), 0, s, dlogits, ldg, (const int32_t*)key, rows, n_pcat, dbias);
+    hipLaunchKernelGGL(ordered_rows_add_kernel, dim3(rows), dim3(256), 0, s, dlogits, ldg, (const int32_t*)key, 1, rows, n_pcat, dbias, n_pcat);
     BIGC_LAUNCH_CHECK("bias_matrix_bwd");
     return BIGC_OK;
 }

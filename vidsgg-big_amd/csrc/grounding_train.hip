@@ -11,6 +11,7 @@
 int bigc_transpose_pad(hipStream_t s, const float* in, float* out, int rows, int cols, int ld_out);
 int bigc_scratch_floats(hipStream_t s, size_t need_floats, int slot, float** out);                                         // backward.hip
 int bigc_partial_rows_finish(hipStream_t s, const float* part, float* out, float* out2, int blocks, int w, int split);     // backward.hip
+int bigc_ordered_rows_add(hipStream_t s, const float* src, int ld_src, const int32_t* key, int key_stride, int rows, int width, float* dst, int ld_dst);   // backward.hip
 int grd_query_input(hipStream_t hs, const float* enti, const float* pred, const int32_t* quint, const int32_t* dura, float video_len,
                     float* out, int n, int de, int kq);
 extern "C" int bigc_linear_dw_f32(void* stream, const float* dY, int ldy, const float* X, int ldx, const int32_t* x_idx, int nseg,
@@ -107,8 +108,10 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) 
 
 __global__ __launch_bounds__(256) void coattention_bwd_kernel(const float* __restrict__ video, const float* __restrict__ proj,
                                                               const float* __restrict__ query, const float* __restrict__ dout,
-                                                              float* __restrict__ g_video, float* __restrict__ g_proj,
+                                                              float* __restrict__ part,
                                                               float* __restrict__ g_query, int T, int d) {
+    // part: (n, 2 T d) -- this query's contribution to [d video | d proj]; bigc_partial_rows_finish adds the queries in order (the two
+    // gradients are sums over the queries of the video: float atomics here made the step's bits depend on the order the blocks ran in)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* q = lds;                  // 3d
     float* s2 = q + 3 * d;           // 3d
@@ -216,22 +219,8 @@ __global__ __launch_bounds__(256) void coattention_bwd_kernel(const float* __res
         const float A = r0 * q[c] + r1 * q[d + c] + r2 * q[2 * d + c];
         const float Bv = r0 * s2[c] + r1 * s2[d + c] + r2 * s2[2 * d + c];
         const float dv = g[c] + g[2 * d + c] * A + g[3 * d + c] * Bv + Cc[t] * ds2[c] + Cc[T + t] * ds2[d + c] + Cc[2 * T + t] * ds2[2 * d + c];
-        atomicAdd(&g_video[e], dv);
-        atomicAdd(&g_proj[e], dR[t] * q[c] + dR[T + t] * q[d + c] + dR[2 * T + t] * q[2 * d + c]);
-    }
-}
-
-// d of the query input rows (3n, kq): the first de columns are embedding rows -> scatter-add into the two tables
-__global__ __launch_bounds__(256) void emb_scatter_kernel(const float* __restrict__ g_qin, int kq, const int32_t* __restrict__ quint,
-                                                          float* __restrict__ g_enti, float* __restrict__ g_pred, int n, int de) {
-    const long total = (long)3 * n * de;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long row = i / de;
-        const int c = (int)(i - row * de);
-        const int qi = (int)(row / 3), l = (int)(row - 3 * (long)qi);
-        const int id = quint[qi * 5 + (l == 0 ? 1 : (l == 1 ? 0 : 2))];
-        float* dst = (l == 1) ? g_pred : g_enti;
-        if (dst) atomicAdd(&dst[(size_t)id * de + c], g_qin[row * kq + c]);
+        part[(size_t)i * 2 * T * d + e] = dv;
+        part[(size_t)i * 2 * T * d + (size_t)T * d + e] = dR[t] * q[c] + dR[T + t] * q[d + c] + dR[2 * T + t] * q[2 * d + c];
     }
 }
 
@@ -247,8 +236,12 @@ struct GrdLossArgs {
     float f_cls, f_ct, f_regr;
     float gs[5];                                         // upstream gradients of [pos_cls, neg_cls, pos_ct, neg_ct, regr]
     float *loss, *dregr, *dconf, *dcls;                  // loss[5] accumulated; gradients accumulated (pre-sigmoid for regr)
+    float* part;                                         // (gridDim.x, 5) loss terms per workgroup, added in block order by the finish launch
 };
 
+// Positive entries are (query i, bin b, GT j); two GT members of a query may fall into the same bin, i.e. write the same gradient
+// elements.  No float atomics: the FIRST entry of a (query, bin) pair owns its elements and adds the later entries of the same pair in
+// entry order (entries of a query are few and adjacent); negative entries are unique (query, bin) pairs that no positive entry uses.
 __global__ __launch_bounds__(256) void grd_loss_grad_kernel(const GrdLossArgs p) {
     const int T = p.T, k = p.k;
     float part[5] = {0, 0, 0, 0, 0};
@@ -256,30 +249,41 @@ __global__ __launch_bounds__(256) void grd_loss_grad_kernel(const GrdLossArgs p)
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int ent = (int)(e / T), t = (int)(e - (long)ent * T);
         if (ent < p.n_pos) {
-            const int i = p.pos_i[ent], b = p.pos_b[ent], j = p.pos_j[ent];
+            const int i = p.pos_i[ent], b = p.pos_b[ent];
+            bool first = true;
+            for (int o = 0; o < ent; ++o) first = first && !(p.pos_i[o] == i && p.pos_b[o] == b);
+            if (!first) continue;
             const size_t ck = ((size_t)i * T + t) * k + b, rk = ((size_t)i * T + t) * 2 * k + b;
             const size_t gck = ((size_t)i * T + t) * p.ldc + b, grk = ((size_t)i * T + t) * p.ldr + b;
-            const float left = p.clip[t] - p.target[2 * j], right = p.target[2 * j + 1] - p.clip[t];
-            const bool outside = left <= 0.f || right <= 0.f;
-            const float score = outside ? 0.f : 1.f;
-            const float y = p.cls[ck];
-            part[0] += bce_logits(y, score) * p.inv_pos * p.f_cls;
-            atomicAdd(&p.dcls[gck], (sigm(y) - score) * p.inv_pos * p.f_cls * p.gs[0]);
-            const float ct = outside ? 0.f : sqrtf(fminf(left, right) / fmaxf(left, right));
-            if (ct > 0.f) {
-                const float x = p.conf[ck];
-                part[2] += bce_logits(x, ct) * p.inv_mask * p.f_ct;
-                atomicAdd(&p.dconf[gck], (sigm(x) - ct) * p.inv_mask * p.f_ct * p.gs[2]);
-                const float rl = p.regrs[rk], rr = p.regrs[rk + k];
-                const float num = fminf(rr, right) + fminf(rl, left), den = fmaxf(rr, right) + fmaxf(rl, left);
-                const float tiou = num / den;
-                part[4] += -logf(tiou + 1e-6f) * p.inv_mask * p.f_regr;
-                const float gt_ = -1.f / (tiou + 1e-6f) * p.inv_mask * p.f_regr * p.gs[4];
-                const float dl = gt_ * ((rl < left ? 1.f : 0.f) / den - (rl > left ? num / (den * den) : 0.f));
-                const float dr = gt_ * ((rr < right ? 1.f : 0.f) / den - (rr > right ? num / (den * den) : 0.f));
-                atomicAdd(&p.dregr[grk], dl * rl * (1.f - rl));
-                atomicAdd(&p.dregr[grk + k], dr * rr * (1.f - rr));
+            const float y = p.cls[ck], x = p.conf[ck];
+            const float rl = p.regrs[rk], rr = p.regrs[rk + k];
+            float g_cls = 0.f, g_conf = 0.f, g_l = 0.f, g_r = 0.f;
+            for (int o = ent; o < p.n_pos; ++o) {
+                if (p.pos_i[o] != i || p.pos_b[o] != b) continue;
+                const int j = p.pos_j[o];
+                const float left = p.clip[t] - p.target[2 * j], right = p.target[2 * j + 1] - p.clip[t];
+                const bool outside = left <= 0.f || right <= 0.f;
+                const float score = outside ? 0.f : 1.f;
+                part[0] += bce_logits(y, score) * p.inv_pos * p.f_cls;
+                g_cls += (sigm(y) - score) * p.inv_pos * p.f_cls * p.gs[0];
+                const float ct = outside ? 0.f : sqrtf(fminf(left, right) / fmaxf(left, right));
+                if (ct > 0.f) {
+                    part[2] += bce_logits(x, ct) * p.inv_mask * p.f_ct;
+                    g_conf += (sigm(x) - ct) * p.inv_mask * p.f_ct * p.gs[2];
+                    const float num = fminf(rr, right) + fminf(rl, left), den = fmaxf(rr, right) + fmaxf(rl, left);
+                    const float tiou = num / den;
+                    part[4] += -logf(tiou + 1e-6f) * p.inv_mask * p.f_regr;
+                    const float gt_ = -1.f / (tiou + 1e-6f) * p.inv_mask * p.f_regr * p.gs[4];
+                    const float dl = gt_ * ((rl < left ? 1.f : 0.f) / den - (rl > left ? num / (den * den) : 0.f));
+                    const float dr = gt_ * ((rr < right ? 1.f : 0.f) / den - (rr > right ? num / (den * den) : 0.f));
+                    g_l += dl * rl * (1.f - rl);
+                    g_r += dr * rr * (1.f - rr);
+                }
             }
+            p.dcls[gck] += g_cls;
+            p.dconf[gck] += g_conf;
+            p.dregr[grk] += g_l;
+            p.dregr[grk + k] += g_r;
         } else {
             const int m = ent - p.n_pos;
             const int i = p.neg_i[m], b = p.neg_b[m];
@@ -287,17 +291,20 @@ __global__ __launch_bounds__(256) void grd_loss_grad_kernel(const GrdLossArgs p)
             const float x = p.conf[ck], y = p.cls[ck];
             part[1] += bce_logits(y, 0.f) * p.inv_neg * p.f_cls;
             part[3] += bce_logits(x, 0.f) * p.inv_neg * p.f_ct;
-            atomicAdd(&p.dcls[gck], sigm(y) * p.inv_neg * p.f_cls * p.gs[1]);
-            atomicAdd(&p.dconf[gck], sigm(x) * p.inv_neg * p.f_ct * p.gs[3]);
+            p.dcls[gck] += sigm(y) * p.inv_neg * p.f_cls * p.gs[1];
+            p.dconf[gck] += sigm(x) * p.inv_neg * p.f_ct * p.gs[3];
         }
     }
+    __shared__ float red[4][5];
 #pragma unroll
     for (int a = 0; a < 5; ++a) {
         float v = part[a];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-        if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&p.loss[a], v);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][a] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < 5) p.part[(size_t)blockIdx.x * 5 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ---- workspace ------------------------------------------------------------------------------------------------
@@ -577,9 +584,11 @@ extern "C" int grd_loss_grad(void* stream, const float* regrs, const float* conf
     for (int a = 0; a < 5; ++a) p.gs[a] = gs_host[a];
     p.loss = loss; p.dregr = dregr; p.dconf = dconf; p.dcls = dcls;
     ProfScope ps(stream, FAM_LOSS, 0.0, 0.0);
-    hipLaunchKernelGGL(grd_loss_grad_kernel, dim3(grid_for((long)(n_pos + n_neg) * T, 1024)), dim3(256), 0, (hipStream_t)stream, p);
+    const int grid = grid_for((long)(n_pos + n_neg) * T, 1024);
+    if (int rc = bigc_scratch_floats((hipStream_t)stream, (size_t)grid * 5, 2, &p.part)) return rc;
+    hipLaunchKernelGGL(grd_loss_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     BIGC_LAUNCH_CHECK("grd_loss_grad");
-    return BIGC_OK;
+    return bigc_partial_rows_finish((hipStream_t)stream, p.part, loss, nullptr, grid, 5, 5);
 }
 
 #define GZERO(ptr, count) do { hipError_t e_ = hipMemsetAsync((ptr), 0, sizeof(float) * (size_t)(count), hs); \
@@ -616,8 +625,11 @@ extern "C" int grd_train_backward(grd_model* m, void* stream, const float* video
     {
         const size_t lds = sizeof(float) * (12 * (size_t)d + 12 * (size_t)T + 4);
         ProfScope ps(stream, FAM_GROUNDING, 0.0, 0.0);
-        hipLaunchKernelGGL(coattention_bwd_kernel, dim3(n), dim3(256), lds, hs, w.venc, w.proj, w.qenc, w.gcomb, w.gvenc, w.gproj, w.gqenc, T, d);
+        float* part = nullptr;
+        TRY(bigc_scratch_floats(hs, (size_t)n * 2 * T * d, 3, &part));
+        hipLaunchKernelGGL(coattention_bwd_kernel, dim3(n), dim3(256), lds, hs, w.venc, w.proj, w.qenc, w.gcomb, part, w.gqenc, T, d);
         BIGC_LAUNCH_CHECK("coattention_bwd");
+        TRY(bigc_partial_rows_finish(hs, part, w.gvenc, w.gproj, n, 2 * T * d, T * d));
     }
     TRY(B.lin("proj2sim", m->proj2sim, w.gproj, d, w.venc, d, T, d, d, w.gvenc, d, true, false));
     // video branch
@@ -635,8 +647,12 @@ extern "C" int grd_train_backward(grd_model* m, void* stream, const float* video
         float* gp = gof(m, "PredNameEmb");
         if (ge || gp) {
             TRY(B.dx(m->wq, w.g0, d, 3 * n, d, m->kq, w.gqin, m->kq, false));
-            hipLaunchKernelGGL(emb_scatter_kernel, dim3(grid_for((long)3 * n * c.dim_clsme)), dim3(256), 0, hs, w.gqin, m->kq, quint, ge, gp, n, c.dim_clsme);
-            BIGC_LAUNCH_CHECK("emb_scatter");
+            // d of the query input rows (3n, kq): the first dim_clsme columns are embedding rows (word l of query qi: subject = quint column 1,
+            // predicate = column 0, object = column 2) -> added to the two tables in query order per table row (no float atomics)
+            const int de = c.dim_clsme;
+            if (ge) TRY(bigc_ordered_rows_add(hs, w.gqin, 3 * m->kq, quint + 1, 5, n, de, ge, de));
+            if (gp) TRY(bigc_ordered_rows_add(hs, w.gqin + m->kq, 3 * m->kq, quint + 0, 5, n, de, gp, de));
+            if (ge) TRY(bigc_ordered_rows_add(hs, w.gqin + 2 * m->kq, 3 * m->kq, quint + 2, 5, n, de, ge, de));
         }
     }
     return BIGC_OK;

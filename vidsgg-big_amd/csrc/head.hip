@@ -5,6 +5,9 @@
 #include "common.h"
 #include "prof.h"
 
+int bigc_scratch_floats(hipStream_t s, size_t need_floats, int slot, float** out);                                                                    // backward.hip
+int bigc_ordered_rows_add(hipStream_t s, const float* src, int ld_src, const int32_t* key, int key_stride, int rows, int width, float* dst, int ld_dst);   // backward.hip
+
 namespace {
 
 struct HeadSegs {
@@ -216,30 +219,11 @@ __global__ __launch_bounds__(256) void pair_bias_idx_kernel(const float* __restr
     }
 }
 
-// dU[s_p] += dH[p], dV[o_p] += dH[p]: a tracklet takes part in few labelled pairs, float atomics
-__global__ __launch_bounds__(256) void pair_scatter_add_kernel(const float* __restrict__ dH, const int32_t* __restrict__ pair_so,
-                                                               float* __restrict__ dU, float* __restrict__ dV, long n_pairs, int d) {
-    const long total = n_pairs * d;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long p = i / d;
-        const int c = (int)(i - p * d);
-        const float g = dH[i];
-        if (g != 0.f) {
-            atomicAdd(&dU[(size_t)pair_so[2 * p] * d + c], g);
-            atomicAdd(&dV[(size_t)pair_so[2 * p + 1] * d + c], g);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void pair_bias_bwd_kernel(const float* __restrict__ dlogits, int ldg, const int32_t* __restrict__ trk_cat,
-                                                            const int32_t* __restrict__ pair_so, float* __restrict__ dbias, long n_pairs,
-                                                            int n_cat, int n_pred) {
-    const long total = n_pairs * n_pred;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long p = i / n_pred;
-        const int c = (int)(i - p * n_pred);
-        atomicAdd(&dbias[((size_t)trk_cat[pair_so[2 * p]] * n_cat + trk_cat[pair_so[2 * p + 1]]) * n_pred + c], dlogits[(size_t)p * ldg + c]);
-    }
+// destination row of pair p in d bias_matrix: (category of its subject) * n_cat + (category of its object)
+__global__ __launch_bounds__(256) void pair_bias_key_kernel(const int32_t* __restrict__ trk_cat, const int32_t* __restrict__ pair_so, long n_pairs, int n_cat,
+                                                            int32_t* __restrict__ key) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p < n_pairs) key[p] = trk_cat[pair_so[2 * p]] * n_cat + trk_cat[pair_so[2 * p + 1]];
 }
 
 int grid_of(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
@@ -282,16 +266,19 @@ int bigc_pair_bias_idx(hipStream_t s, const float* bias_matrix, const int32_t* t
     return BIGC_OK;
 }
 
+// dU[s_p] += dH[p], dV[o_p] += dH[p] and d bias_matrix[cat_s, cat_o] += d logits[p]: scatter-adds with collisions, added in PAIR ORDER per
+// destination (bigc_ordered_rows_add, backward.hip) -- no float atomics, the training step's gradients are bit-reproducible
 int bigc_pair_scatter_add(hipStream_t s, const float* dH, const int32_t* pair_so, float* dU, float* dV, long n_pairs, int d) {
-    hipLaunchKernelGGL(pair_scatter_add_kernel, dim3(grid_of(n_pairs * d)), dim3(256), 0, s, dH, pair_so, dU, dV, n_pairs, d);
-    BIGC_LAUNCH_CHECK("pair_scatter_add");
-    return BIGC_OK;
+    if (int rc = bigc_ordered_rows_add(s, dH, d, pair_so, 2, (int)n_pairs, d, dU, d)) return rc;
+    return bigc_ordered_rows_add(s, dH, d, pair_so + 1, 2, (int)n_pairs, d, dV, d);
 }
 
 int bigc_pair_bias_bwd(hipStream_t s, const float* dlogits, int ldg, const int32_t* trk_cat, const int32_t* pair_so, float* dbias, long n_pairs,
                        int n_cat, int n_pred) {
-    hipLaunchKernelGGL(pair_bias_bwd_kernel, dim3(grid_of(n_pairs * n_pred)), dim3(256), 0, s, dlogits, ldg, trk_cat, pair_so, dbias, n_pairs, n_cat,
-                       n_pred);
-    BIGC_LAUNCH_CHECK("pair_bias_bwd");
-    return BIGC_OK;
+    if (n_pairs <= 0) return BIGC_OK;
+    float* key = nullptr;
+    if (int rc = bigc_scratch_floats(s, (size_t)n_pairs, 4, &key)) return rc;
+    hipLaunchKernelGGL(pair_bias_key_kernel, dim3((int)((n_pairs + 255) / 256)), dim3(256), 0, s, trk_cat, pair_so, n_pairs, n_cat, (int32_t*)key);
+    BIGC_LAUNCH_CHECK("pair_bias_key");
+    return bigc_ordered_rows_add(s, dlogits, ldg, (const int32_t*)key, 1, (int)n_pairs, n_pred, dbias, n_pred);
 }

@@ -309,8 +309,12 @@ def make_ingest_case(name):
     """-> (track_res (n_box, 12+dim_box) float32, i3d rows (n_box, 12+dim_i3d) float32 or None, case dict).
     Tracklets with gaps (to be interpolated), undetected boxes (cat <= 0: tracker box only, zero features), mixed
     categories (majority vote), one short tracklet (filtered) and one all-background tracklet."""
+    return make_pku_rows(INGEST_CASES[name])
+
+
+def make_pku_rows(case):
+    """the generator of make_ingest_case for any case dict (tests/test_tools_gpu.py writes full-width PKU files with it)"""
     import numpy as np
-    case = INGEST_CASES[name]
     rs = np.random.RandomState(case["seed"])
     rows = []
     for t in range(case["n_traj"]):
@@ -336,6 +340,52 @@ def make_ingest_case(name):
     if case["with_i3d"]:
         i3d = np.concatenate([track[:, :12], np.maximum(rs.standard_normal((track.shape[0], case["dim_i3d"])), 0)], 1).astype(np.float32)
     return track, i3d, case
+
+
+# VidOR tracking results (dataloaders/dataloader_vidor_v3.py:389-485): rows of length 12 + dim_box or of length 6 (tracker-only boxes,
+# skipped by the loader), a classeme row per file row, score clipping before the top-N cut.
+VIDOR_INGEST_CASES = {
+    # ragged file (6-column rows inside tracklets and one tracklet made of them only), gaps, score threshold that removes some
+    "ingest_vidor": dict(seed=911, n_traj=10, dim_box=16, dim_clsme=12, min_frames_th=5, max_proposal=6, score_th=0.55, ragged=True),
+    # dense 2-D file, more tracklets than max_proposal, a threshold below every score
+    "ingest_vidor_b": dict(seed=912, n_traj=14, dim_box=24, dim_clsme=300, min_frames_th=7, max_proposal=5, score_th=0.2, ragged=False),
+    # high threshold: few survive (fewer than max_proposal), long gaps
+    "ingest_vidor_c": dict(seed=913, n_traj=8, dim_box=8, dim_clsme=20, min_frames_th=3, max_proposal=40, score_th=0.68, ragged=True),
+}
+
+
+def make_vidor_ingest_case(name):
+    """-> (track_res: list of rows (Python lists; fid / tid / category are ints as in the reference's pickled object arrays),
+            classeme (n_file_rows, dim_clsme) float32, case dict)."""
+    import numpy as np
+    case = VIDOR_INGEST_CASES[name]
+    rs = np.random.RandomState(case["seed"])
+    rows = []
+    for t in range(case["n_traj"]):
+        tid = 5 * t + 2
+        start = rs.randint(0, 25)
+        n = rs.randint(6, 20) if t != 2 else 3                    # tracklet 2 is shorter than min_frames_th
+        fids = start + np.sort(rs.choice(np.arange(n + 8), size=n, replace=False))
+        main_cat = rs.randint(1, 80)
+        base_conf = rs.uniform(0.35, 0.95)                         # per-tracklet confidence level: the score threshold separates tracklets
+        for fid in fids:
+            xy, wh = rs.uniform(0, 500, 2), rs.uniform(20, 120, 2)
+            conf = float(np.clip(base_conf + rs.uniform(-0.1, 0.1), 0.01, 0.99))
+            cat = main_cat if rs.rand() < 0.8 else rs.randint(1, 80)
+            if t == 4:
+                cat = 0                                            # majority category 0: background tracklet
+            short = case["ragged"] and (t == 6 or rs.rand() < 0.12)     # tracklet 6: tracker-only boxes only; elsewhere: a gap
+            if short:
+                rows.append([int(fid), int(tid)] + [float(np.float32(v)) for v in np.concatenate([xy, wh])])
+                continue
+            dxy, dwh = xy + rs.uniform(-5, 5, 2), wh + rs.uniform(-5, 5, 2)
+            feat = np.maximum(rs.standard_normal(case["dim_box"]), 0)
+            vals = [float(np.float32(v)) for v in np.concatenate([xy, wh, [conf]])]
+            rows.append([int(fid), int(tid)] + vals[:4] + [vals[4], int(cat)] + [float(np.float32(v)) for v in np.concatenate([dxy, dwh, feat])])
+    order = np.argsort([r[0] for r in rows], kind="stable")       # file order: by frame, tracklets interleaved
+    track = [rows[i] for i in order]
+    classeme = rs.standard_normal((len(track), case["dim_clsme"])).astype(np.float32)
+    return track, classeme, case
 
 
 # --------------------------------------------------------------------------------------------------------------------

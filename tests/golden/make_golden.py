@@ -289,6 +289,50 @@ def run_ingest_case(name):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "proposals", prop.num_proposals, "rows", out["bboxes"].shape[0])
 
 
+def run_vidor_ingest_case(name):
+    """The reference's VidOR ``Dataset._get_proposal`` (dataloaders/dataloader_vidor_v3.py:389-485; its ``TrajProposal`` :19-69 does the
+    score clipping and the top-N cut) on synthetic tracking results + classemes written to a temp dir; the Dataset constructor
+    (annotations, caches) is bypassed with a stand-in ``self``."""
+    import types as _t
+    for m in ("cv2", "torchvision", "torchvision.ops"):
+        if m not in sys.modules:
+            sys.modules[m] = types.ModuleType(m)
+    for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k == "dataloaders" or k.startswith("dataloaders.")]:
+        del sys.modules[k]
+    sys.path.insert(0, REFERENCE)
+    np.float, np.int = float, int
+    from dataloaders import dataloader_vidor_v3 as D
+    import utils.utils_func as U
+    sys.path.remove(REFERENCE)
+    U.fill_zeropadding = lambda vectors: None            # see run_ingest_case
+    D.linear_interpolation.__globals__["fill_zeropadding"] = U.fill_zeropadding
+    track, classeme, case = cases.make_vidor_ingest_case(name)
+    d = tempfile.mkdtemp()
+    os.makedirs(d + "/prop"); os.makedirs(d + "/clsme")
+    if case["ragged"]:
+        arr = np.empty(len(track), dtype=object)
+        for i, r in enumerate(track):
+            arr[i] = r
+    else:
+        arr = np.asarray(track, dtype=object)
+    np.save(d + "/prop/video_x.npy", arr, allow_pickle=True)
+    np.save(d + "/clsme/video_x_clsme.npy", classeme)
+    fake = _t.SimpleNamespace(classeme_dir=d + "/clsme", dim_boxfeature=case["dim_box"], min_frames_th=case["min_frames_th"],
+                              max_proposal=case["max_proposal"], score_th=case["score_th"],
+                              videoname2trackres=lambda video_name: d + "/prop/" + video_name + ".npy")
+    prop = D.Dataset._get_proposal(fake, "video_x")
+    if prop.num_proposals == 0:
+        out = dict(num_proposals=np.array(0))
+    else:
+        out = dict(num_proposals=np.array(prop.num_proposals), cat_ids=prop.cat_ids.numpy(), scores=prop.scores.numpy(),
+                   traj_durations=prop.traj_durations.numpy(), bboxes=torch.cat(prop.bboxes_list, 0).numpy(),
+                   features=torch.cat(prop.features_list, 0).numpy(), lens=np.array([b.shape[0] for b in prop.bboxes_list]))
+    out["versions"] = np.array([torch.__version__, np.__version__])
+    path = os.path.join(cases.GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "proposals", prop.num_proposals, "rows", out.get("bboxes", np.zeros((0, 4))).shape[0])
+
+
 def run_basec_case(name):
     """The reference's Base_C (models/model_pairwise_baseline.py) eval forward on the seeded case."""
     sys.path.insert(0, REFERENCE)
@@ -420,7 +464,7 @@ def main():
     torch.manual_seed(0)
     m10, m07, grd = import_reference()
     names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + list(cases.GRD_TRAIN_CASES) + ["evaluator", "categories", "evalfmt", "ties"] +
-                             list(cases.INGEST_CASES) + list(cases.BASEC_CASES) + list(cases.BASEC_TRAIN_CASES))
+                             list(cases.INGEST_CASES) + list(cases.VIDOR_INGEST_CASES) + list(cases.BASEC_CASES) + list(cases.BASEC_TRAIN_CASES))
     for n in names:
         if n == "evaluator":
             run_evaluator_golden()
@@ -436,6 +480,9 @@ def main():
             continue
         if n in cases.INGEST_CASES:
             run_ingest_case(n)
+            continue
+        if n in cases.VIDOR_INGEST_CASES:
+            run_vidor_ingest_case(n)
             continue
         if n in cases.BASEC_CASES:
             run_basec_case(n)

@@ -304,3 +304,78 @@ def test_source_table_cache_is_validated_item_by_item():
     PackedBatch([p], "cpu")
     assert p._bigc_pack["tmax"] == max(b.shape[0] for b in p.bboxes_list)
     del keep_old
+
+
+def _same_results(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert all(torch.equal(u, v) for u, v in zip(x, y))
+
+
+@pytest.mark.gpu
+def test_same_list_again_reuses_the_tables_and_sees_values_written_in_place():
+    """``forward(proposal_list)`` keeps its last batch; when the same containers come back with the same tensors
+    (identity, element by element) the address / offset tables are not rebuilt -- but everything the batch COPIES (boxes, scores,
+    categories, durations) is gathered again, so that values written in place between the calls are seen, as the feature rows (read in
+    place) are.  Replaced tensors, a replaced container or another device drop the kept batch."""
+    cfg, model = _model("CONFIG_V")
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    mk = lambda s: synthetic_proposal(s, n_trajs=12, feat_width=width, num_enti_cats=cfg["num_enti_cats"], len_range=(10, 30))
+    props = [mk(900 + i).to(DEV) for i in range(5)]
+    first = model(props, topk=3)
+    kept = model._last_pack[3]
+    assert kept is not None and kept.proposals is None                      # weak references only: the batch does not hold the containers
+    _same_results(model(props, topk=3), first)
+    assert model._last_pack[3] is kept                                      # ... the very same batch object served the second call
+    _same_results(model(list(props), topk=3), first)                        # another list object with the same containers: still a hit
+    assert model._last_pack[3] is kept
+    # values written IN PLACE: features (read in place), scores and boxes (gathered again)
+    with torch.no_grad():
+        props[1].features_list[0].mul_(1.5)
+        props[2].scores.mul_(0.5)
+        props[3].bboxes_list[2].add_(3.0)
+    got = model(props, topk=3)
+    assert model._last_pack[3] is kept
+    fresh_cfg, fresh = _model("CONFIG_V")
+    want = fresh([p for p in props], topk=3)                                # a model that has never seen the list
+    _same_results(got, want)
+    assert not all(torch.equal(a[1], b[1]) for a, b in zip(got, first) if a is not None and b is not None)
+    # a container whose tensors were replaced (to(cpu) -> to(GPU)): rebuilt
+    props[0].to("cpu").to(DEV)
+    _same_results(model(props, topk=3), want)
+    assert model._last_pack[3] is not kept
+    kept = model._last_pack[3]
+    # a metadata tensor replaced by another object
+    props[4].scores = props[4].scores.clone()
+    _same_results(model(props, topk=3), want)
+    assert model._last_pack[3] is not kept
+    # a shorter list, then a foreign container in the list: no reuse, no stale batch kept
+    _same_results(model(props[:3], topk=3), want[:3])
+    mixed = props[:4] + [_foreign(mk(904), DEV)]
+    r = model(mixed, topk=3)
+    _same_results(r[:4], want[:4])
+    assert model.__dict__.get("_last_pack") is None
+
+
+@pytest.mark.gpu
+def test_lazy_result_list_behaves_like_the_reference_list():
+    """the eval result of a one-class batch is a ``list`` whose entries are cut out of the compacted arrays when first read"""
+    cfg, model = _model("CONFIG_V")
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    props = [synthetic_proposal(950 + i, n_trajs=9, feat_width=width, num_enti_cats=cfg["num_enti_cats"], len_range=(10, 30)).to(DEV) for i in range(4)]
+    res = model(props, topk=3)
+    assert isinstance(res, list) and len(res) == 4
+    eager = model.unpack_results(4, [0, 1, 2, 3], model.forward_checked(PackedBatch(props, DEV, "lazy"), 3))
+    assert type(eager) is list
+    _same_results(res, eager)                      # iteration
+    _same_results([res[i] for i in range(4)], eager)
+    _same_results(res[1:3], eager[1:3])
+    _same_results([res[-1]], [eager[-1]])
+    q, s, d, i = res[0]                            # tuple unpacking of an entry
+    assert q.dtype == torch.int64 and s.dtype == torch.float32 and d.dtype == torch.int64 and i.dtype == torch.int64 and q.shape[1] == 5
+    import copy
+    import pickle
+    assert type(pickle.loads(pickle.dumps([None if r is None else tuple(t.cpu() for t in r) for r in res]))) is list
+    assert len(copy.copy(res)) == 4 and len(res + [None]) == 5

@@ -62,3 +62,62 @@ def test_ingested_proposal_runs_through_the_model():
                                   dim_i3d=case["dim_i3d"], device="cuda:0").to("cuda:0")
     res = model([p], topk=3)[0]
     assert res is None or (res[0].shape[1] == 5 and res[0].shape[0] == res[1].shape[0])
+
+
+# ---- VidOR (dataloaders/dataloader_vidor_v3.py:389-485 + :19-69): ragged files, classeme rows, score clipping before the top-N cut ------
+
+def _ragged(track, ragged):
+    if not ragged:
+        return np.asarray(track, dtype=np.float32)
+    arr = np.empty(len(track), dtype=object)
+    for i, r in enumerate(track):
+        arr[i] = r
+    return arr
+
+
+@pytest.mark.parametrize("name", list(cases.VIDOR_INGEST_CASES))
+def test_vidor_plan_matches_reference_dataloader(name):
+    g = np.load(cases.GOLDEN_DIR + "/" + name + ".npz")
+    track, classeme, case = cases.make_vidor_ingest_case(name)
+    plan, dense = ingest.plan_vidor_tracklets(_ragged(track, case["ragged"]), case["dim_box"], case["min_frames_th"], case["max_proposal"], case["score_th"])
+    assert len(plan["cat_ids"]) == int(g["num_proposals"])
+    assert np.array_equal(np.array(plan["cat_ids"]), g["cat_ids"])
+    assert np.array_equal(plan["scores"].numpy(), g["scores"])                                  # bit-exact, in the reference's order
+    assert (plan["scores"] > case["score_th"]).all() and len(plan["cat_ids"]) <= case["max_proposal"]
+    assert np.array_equal(np.array(plan["durations"]), g["traj_durations"])
+    assert np.array_equal(np.array([b.shape[0] for b in plan["boxes"]]), g["lens"])
+    assert np.array_equal(torch.cat(plan["boxes"], 0).numpy(), g["bboxes"])                     # bit-exact (tracker boxes, interpolated across gaps)
+    assert (plan["src_b"] != -2).sum() > 0                                                      # the case has gaps
+    # the list-of-lists form (what numpy.load(allow_pickle=True) of the reference's files gives after .tolist()) plans the same
+    plan2, _ = ingest.plan_vidor_tracklets(track, case["dim_box"], case["min_frames_th"], case["max_proposal"], case["score_th"])
+    assert np.array_equal(plan2["src_a"], plan["src_a"]) and np.array_equal(plan2["scores"].numpy(), plan["scores"].numpy())
+    assert dense.shape[1] == 12 + case["dim_box"] and len(plan["file_rows"]) == dense.shape[0]
+
+
+def test_vidor_score_clipping_comes_before_the_top_n_cut_and_empty_results():
+    track, classeme, case = cases.make_vidor_ingest_case("ingest_vidor_b")
+    loose, _ = ingest.plan_vidor_tracklets(np.asarray(track, dtype=np.float32), case["dim_box"], case["min_frames_th"], 100, 0.0)
+    mid = float(loose["scores"][len(loose["scores"]) // 2])
+    tight, _ = ingest.plan_vidor_tracklets(np.asarray(track, dtype=np.float32), case["dim_box"], case["min_frames_th"], 3, mid)
+    want = [float(s) for s in loose["scores"] if float(s) > mid][:3]
+    assert [float(s) for s in tight["scores"]] == want
+    assert ingest.plan_vidor_tracklets(np.asarray(track, dtype=np.float32), case["dim_box"], case["min_frames_th"], 10, 0.999) == (None, None)
+    assert ingest.plan_vidor_tracklets(np.asarray(track, dtype=np.float32)[:, :6], case["dim_box"], 1, 10, 0.0) == (None, None)      # tracker-only file
+    with pytest.raises(AssertionError):
+        ingest.plan_vidor_tracklets(np.asarray(track, dtype=np.float32)[:, :9], case["dim_box"], 1, 10, 0.0)                        # (:406)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(cases.VIDOR_INGEST_CASES))
+def test_vidor_feature_rows_match_reference_dataloader(name):
+    g = np.load(cases.GOLDEN_DIR + "/" + name + ".npz")
+    track, classeme, case = cases.make_vidor_ingest_case(name)
+    p = ingest.load_vidor_tracklets("video_x", _ragged(track, case["ragged"]), classeme, case["dim_box"], case["min_frames_th"], case["max_proposal"],
+                                    case["score_th"], device="cuda:0")
+    assert p.num_proposals == int(g["num_proposals"])
+    feats = torch.cat(p.features_list, 0)
+    assert feats.is_cuda and feats.shape == g["features"].shape and feats.shape[1] == case["dim_box"] + case["dim_clsme"]
+    assert np.array_equal(feats.cpu().numpy(), g["features"])                                    # [RoI | classeme], bit-exact incl. interpolated rows
+    assert np.array_equal(torch.cat(p.bboxes_list, 0).cpu().numpy(), g["bboxes"])
+    assert np.array_equal(p.traj_durations.cpu().numpy(), g["traj_durations"]) and np.array_equal(p.cat_ids.cpu().numpy(), g["cat_ids"])
+    assert np.array_equal(p.scores.cpu().numpy(), g["scores"])

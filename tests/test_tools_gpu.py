@@ -204,3 +204,92 @@ def test_bench_eval_mode_with_rccl_group_and_self_launch():
     import json
     rk = json.load(open(os.path.join(ROOT, "bench_detail.json")))["ranks"]
     assert rk["backend"] == "nccl" and rk["world"] == 1 and rk["distinct_devices"] == 1
+
+
+def _gt_from_predictions(pred_json_path, per_video=3):
+    """a ground-truth JSON in the evaluator's format made of each video's best-scored predictions (so that recall is > 0 by construction:
+    the CLI tests check the plumbing, parity with the reference's evaluator is tests/test_evaluator.py)"""
+    import json
+    pred = json.load(open(pred_json_path))
+    gt = {}
+    for name, rel in pred.items():
+        best = sorted(rel, key=lambda x: -x["score"])[:per_video]
+        gt[name] = [{k: r[k] for k in ("triplet", "duration", "sub_traj", "obj_traj")} for r in best]
+    return gt
+
+
+def test_eval_vidvrd_cli_on_raw_tracking_results():
+    """BASELINE configs[0] as worded: a 10-video subset through ``tools/eval_vidvrd.py`` -- here from raw PKU tracking results
+    (``--tracking_dir`` / ``--i3d_dir``: per-box rows of 12 + 2048 and 12 + 832 columns), ingested by this package (no reference
+    dataloader on PYTHONPATH), scored by the HIP forward, converted and evaluated."""
+    import json
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases
+    d = tempfile.mkdtemp()
+    os.makedirs(d + "/track"); os.makedirs(d + "/i3d")
+    for v in range(10):
+        track, i3d, _ = cases.make_pku_rows(dict(seed=7000 + v, n_traj=8, dim_box=2048, dim_i3d=832, with_i3d=True))
+        np.save(d + "/track/video_%02d.npy" % v, track)
+        np.save(d + "/i3d/video_%02d.npy" % v, i3d)
+    json.dump({"video_00": {"video_len": 60, "video_wh": [640, 360]}}, open(d + "/info.json", "w"))
+    json.dump({"video_%02d" % v: [] for v in range(10)}, open(d + "/gt0.json", "w"))
+    common = [os.path.join(TOOLS, "eval_vidvrd.py"), "--cfg_path", CFG, "--output_dir", d, "--use_pku", "--tracking_dir", d + "/track", "--i3d_dir", d + "/i3d",
+              "--video_info_path", d + "/info.json"]
+    log = run(common + ["--save_tag", "raw0", "--gt_json_path", d + "/gt0.json", "--json_results_path", d + "/pred.json"])
+    assert "inference: 10 videos" in log and "detection recall" in log
+    pred = json.load(open(d + "/pred.json"))
+    assert len(pred) == 10 and sum(len(r) for r in pred.values()) > 0
+    json.dump(_gt_from_predictions(d + "/pred.json"), open(d + "/gt1.json", "w"))
+    log = run(common + ["--save_tag", "raw1", "--gt_json_path", d + "/gt1.json"])
+    rec = [l for l in log.splitlines() if l.startswith("detection recall")][0]
+    assert float(rec.split("{")[1].split(":")[1].split(",")[0]) > 0.5, rec          # recall@50 of ground truth taken from the predictions' top 3
+    assert os.path.exists(d + "/VidVRDtest_infer_result_raw1.pkl")
+
+
+def test_eval_vidor_cli_on_raw_tracking_results_then_grounding():
+    """BASELINE configs[3] (VidOR full pipeline) from raw files: ``tools/eval_vidor.py --tracking_dir --classeme_dir`` (ragged per-box rows of
+    12 + 1024 or 6 columns + a classeme row per box, dataloaders/dataloader_vidor_v3.py:389-485) for the classification stage, then
+    ``--video_feature_dir`` for the grounding stage on the saved results."""
+    import json
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases
+    cfg5 = os.path.join(ROOT, "vidsgg-big_amd", "experiments", "exp5", "config_.py")
+    cfgg = os.path.join(ROOT, "vidsgg-big_amd", "experiments", "grounding_weights", "config_.py")
+    d = tempfile.mkdtemp()
+    for sub in ("track", "clsme", "clip"):
+        os.makedirs(os.path.join(d, sub))
+    rs = np.random.RandomState(5)
+    info = {}
+    for v in range(4):
+        cases.VIDOR_INGEST_CASES["_cli"] = dict(seed=7100 + v, n_traj=9, dim_box=1024, dim_clsme=300, min_frames_th=15, max_proposal=180, score_th=0.4, ragged=True)
+        track, classeme, _ = cases.make_vidor_ingest_case("_cli")
+        arr = np.empty(len(track), dtype=object)
+        for i, r in enumerate(track):
+            arr[i] = r
+        name = "%04d_%d" % (v, 1000 + v)
+        np.save(os.path.join(d, "track", name + ".npy"), arr, allow_pickle=True)
+        np.save(os.path.join(d, "clsme", name + "_clsme.npy"), classeme)
+        vlen = int(max(r[0] for r in track)) + 1
+        info[name] = {"video_len": vlen, "video_wh": [640, 360]}
+        np.save(os.path.join(d, "clip", name + ".npy"), (0.1 * rs.standard_normal((-(-vlen // 8), 1024))).astype(np.float32))
+    del cases.VIDOR_INGEST_CASES["_cli"]
+    json.dump(info, open(d + "/info.json", "w"))
+    json.dump({}, open(d + "/gt0.json", "w"))
+    # exp5 asks for min_frames_th = 15; the generated tracklets have 6..19 boxes: a config copy with the threshold of the golden cases
+    # (the same for the grounding config: both stages must ingest the same proposals)
+    open(d + "/config_.py", "w").write(open(cfg5).read().replace("min_frames_th=15", "min_frames_th=5"))
+    os.makedirs(d + "/grd")
+    open(d + "/grd/config_.py", "w").write(open(cfgg).read().replace("min_frames_th=15", "min_frames_th=5"))
+    raw = ["--tracking_dir", d + "/track", "--classeme_dir", d + "/clsme", "--video_info_path", d + "/info.json", "--gt_json_path", d + "/gt0.json"]
+    log = run([os.path.join(TOOLS, "eval_vidor.py"), "--eval_cls_only", "--cfg_path", d + "/config_.py", "--output_dir", d, "--save_tag", "raw", "--save_json_results"] + raw)
+    assert "inference: 4 videos" in log and "detection recall" in log
+    pkl = os.path.join(d, "VidORval_infer_results_topk3_raw.pkl")
+    pred = json.load(open(os.path.join(d, "VidORval_predict_relations_topk3_raw.json")))
+    assert os.path.exists(pkl) and sum(len(r) for r in pred.values()) > 0
+    json.dump(_gt_from_predictions(os.path.join(d, "VidORval_predict_relations_topk3_raw.json")), open(d + "/gt0.json", "w"))
+    log = run([os.path.join(TOOLS, "eval_vidor.py"), "--cfg_path", d + "/grd/config_.py", "--cls_stage_result_path", pkl, "--output_dir", d, "--save_tag", "raw",
+               "--video_feature_dir", d + "/clip", "--save_json_results"] + raw[:4] + ["--video_info_path", d + "/info.json", "--gt_json_path", d + "/gt0.json"])
+    assert "grounding: 4 videos" in log and "detection recall" in log
+    assert os.path.exists(os.path.join(d, "VidORval_predict_relations_aft_grd_raw.json"))

@@ -84,19 +84,21 @@ def plan_tracklets(track_res, dim_boxfeature, min_frames_th, max_proposal):
                 **{key: np.concatenate([k[key] for k in kept]).astype(np.int32) for key in ("src_a", "src_b", "step_i", "step_div")})
 
 
-def assemble_features(plan, track_res, dim_boxfeature, i3d_res=None, dim_i3d=0, device="cuda:0"):
-    """Device side: the (n_rows, dim_boxfeature + dim_i3d) float32 feature rows of the kept tracklets."""
+def assemble_features(plan, track_res, dim_boxfeature, i3d_res=None, dim_i3d=0, device="cuda:0", col2=12):
+    """Device side: the (n_rows, dim_boxfeature + dim_i3d) float32 feature rows of the kept tracklets.  ``i3d_res``: the second per-box
+    file whose columns [col2, col2 + dim_i3d) ride behind the box features (VidVRD: the I3D rows, 12 head columns; VidOR: the classeme
+    rows, no head columns)."""
     lib = _lib.load()
     raw = torch.from_numpy(np.ascontiguousarray(np.asarray(track_res, dtype=np.float32))).to(device)     # one H2D copy of the file
     raw2 = None
     if i3d_res is not None and dim_i3d:
         raw2 = torch.from_numpy(np.ascontiguousarray(np.asarray(i3d_res, dtype=np.float32))).to(device)
-        assert raw2.shape == (raw.shape[0], 12 + dim_i3d)
+        assert raw2.shape == (raw.shape[0], col2 + dim_i3d)
     t = {k: torch.from_numpy(plan[k]).to(device) for k in ("src_a", "src_b", "step_i", "step_div")}
     n_rows = int(plan["src_a"].shape[0])
     out = torch.empty((n_rows, dim_boxfeature + dim_i3d), dtype=torch.float32, device=device)
     _lib.check(lib.bigc_assemble_rows_f32(_lib.current_stream(), raw.data_ptr(), raw.shape[1], 12, dim_boxfeature,
-                                          _lib.ptr(raw2), raw2.shape[1] if raw2 is not None else 0, 12, dim_i3d if raw2 is not None else 0,
+                                          _lib.ptr(raw2), raw2.shape[1] if raw2 is not None else 0, col2, dim_i3d if raw2 is not None else 0,
                                           t["src_a"].data_ptr(), t["src_b"].data_ptr(), t["step_i"].data_ptr(), t["step_div"].data_ptr(),
                                           out.data_ptr(), out.shape[1], n_rows))
     return out
@@ -115,3 +117,117 @@ def load_pku_tracklets(video_name, track_res, dim_boxfeature, min_frames_th, max
     boxes = torch.cat(plan["boxes"], 0).to(feats.device)
     return TrajProposal.from_blocks(video_name, video_len or (max(d[1] for d in plan["durations"]) + 1), video_wh, plan["cat_ids"], plan["scores"],
                                     plan["durations"], lens, boxes, feats)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# VidOR (dataloaders/dataloader_vidor_v3.py:389-485 ``_get_proposal``, :19-69 ``TrajProposal``, :265-277 ``load_video_features``)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+
+def plan_vidor_tracklets(track_res, dim_boxfeature, min_frames_th, max_proposal, score_th):
+    """Host bookkeeping of the VidOR tracking results.  ``track_res``: per-box rows ``[fid, tid, x, y, w, h (tracker), conf, cat,
+    x, y, w, h (detector), feat...]`` of length ``12 + dim_boxfeature``, or of length 6 (a tracker-only box: skipped, :408-409, so its
+    frame becomes a gap) -- a 2-D array, or the reference's object array / list of ragged rows.  Differences from the VidVRD loader
+    (``plan_tracklets``): the box is the TRACKER box with the detector's confidence (:411-418, no averaging with the detector box),
+    every full row carries features, the classeme row of a box is picked by its index in the FILE (:428), a tracklet without full rows
+    or shorter than ``min_frames_th`` is background (:431-445), and the proposals whose mean confidence is not above ``score_th`` go
+    BEFORE the top-``max_proposal`` cut (:39-53).
+    -> (plan as ``plan_tracklets``' with ``file_rows``: the file index of every dense row, or None when nothing is left;
+        dense (n_full, 12 + dim_boxfeature) float32 rows)"""
+    if isinstance(track_res, np.ndarray) and track_res.dtype != object and track_res.ndim == 2:
+        assert track_res.shape[1] in (6, 12 + dim_boxfeature), "len(box_info)=={}".format(track_res.shape[1])
+        if track_res.shape[1] == 6:
+            return None, None
+        file_rows = np.arange(track_res.shape[0])
+        dense = np.ascontiguousarray(track_res, dtype=np.float32)
+        tid_all = track_res[:, 1].astype(np.int64)
+    else:
+        rows = [r if isinstance(r, list) else np.asarray(r).tolist() for r in track_res]
+        for r in rows:
+            assert len(r) == 6 or len(r) == 12 + dim_boxfeature, "len(box_info)=={}".format(len(r))
+        file_rows = np.asarray([i for i, r in enumerate(rows) if len(r) != 6], dtype=np.int64)
+        tid_all = np.asarray([int(r[1]) for r in rows], dtype=np.int64)
+        if len(file_rows) == 0:
+            return None, None
+        dense = np.asarray([rows[i] for i in file_rows], dtype=np.float32)
+    head = dense[:, :12].astype(np.float64)
+    fid, tid, cat = head[:, 0].astype(np.int64), head[:, 1].astype(np.int64), head[:, 7].astype(np.int64)
+    _, first = np.unique(tid_all, return_index=True)             # tracklets in order of first appearance over ALL rows (:395)
+    order = tid_all[np.sort(first)]
+    box5 = np.stack([head[:, 2], head[:, 3], head[:, 2] + head[:, 4], head[:, 3] + head[:, 5], head[:, 6]], 1)
+    kept = []
+    for t in order:
+        rows_t = np.nonzero(tid == t)[0]                        # dense rows of the tracklet, file order
+        if len(rows_t) == 0:
+            continue                                           # only tracker-only boxes: category 0 (:431-432)
+        category = int(np.argmax(np.bincount(cat[rows_t])))    # (:435)
+        if len(rows_t) < min_frames_th or category == 0:
+            continue
+        f = fid[rows_t]
+        start, end = int(f.min()), int(f.max()) + 1
+        b5 = box5[rows_t]
+        a = rows_t.astype(np.int32)
+        if len(rows_t) != end - start:                         # gaps -> interpolate (:458-460, utils/utils_func.py:292-317)
+            cut = np.nonzero(np.diff(f) > 1)[0] + 1
+            seg_f, seg_b, seg_a = np.split(f, cut), np.split(b5, cut, axis=0), np.split(a, cut)
+            parts_b, src_a, src_b, step_i, step_div = [], [], [], [], []
+            for i in range(1, len(seg_f)):
+                left, right = int(seg_f[i - 1][-1]), int(seg_f[i][0])
+                n_in = right - left - 1
+                parts_b += [seg_b[i - 1], np.linspace(seg_b[i - 1][-1], seg_b[i][0], num=n_in + 2, axis=0)[1:-1]]
+                src_a += [seg_a[i - 1], np.full(n_in, seg_a[i - 1][-1], np.int32)]
+                src_b += [np.full(len(seg_a[i - 1]), -2, np.int32), np.full(n_in, seg_a[i][0], np.int32)]
+                step_i += [np.zeros(len(seg_a[i - 1]), np.int32), np.arange(1, n_in + 1, dtype=np.int32)]
+                step_div += [np.ones(len(seg_a[i - 1]), np.int32), np.full(n_in, n_in + 1, np.int32)]
+            parts_b.append(seg_b[-1])
+            src_a.append(seg_a[-1])
+            n_last = len(seg_a[-1])
+            src_b.append(np.full(n_last, -2, np.int32)); step_i.append(np.zeros(n_last, np.int32)); step_div.append(np.ones(n_last, np.int32))
+            b5 = np.concatenate(parts_b, 0)
+        else:
+            n = len(rows_t)
+            src_a, src_b, step_i, step_div = [a], [np.full(n, -2, np.int32)], [np.zeros(n, np.int32)], [np.ones(n, np.int32)]
+        assert len(b5) == end - start
+        score = sum(float(x) for x in b5[:, 4]) / len(b5)       # Python-float running sum as the reference (:79-81)
+        kept.append(dict(cat=category, score=score, dura=(start, end - 1), boxes=b5[:, :4],
+                         src_a=np.concatenate(src_a), src_b=np.concatenate(src_b), step_i=np.concatenate(step_i),
+                         step_div=np.concatenate(step_div)))
+    if not kept:
+        return None, None
+    scores = torch.FloatTensor([k["score"] for k in kept])
+    above = torch.where(scores > score_th)[0]                    # score clipping first (:39-50) ...
+    if len(above) == 0:
+        return None, None
+    scores = scores[above]
+    order2 = torch.argsort(scores, descending=True)[:max_proposal]       # ... then the top-N cut (:53-55)
+    kept = [kept[int(above[i])] for i in order2.tolist()]
+    plan = dict(cat_ids=[k["cat"] for k in kept], scores=scores[order2], durations=[k["dura"] for k in kept],
+                boxes=[torch.FloatTensor(k["boxes"]) for k in kept], file_rows=file_rows,
+                **{key: np.concatenate([k[key] for k in kept]).astype(np.int32) for key in ("src_a", "src_b", "step_i", "step_div")})
+    return plan, dense
+
+
+def load_vidor_tracklets(video_name, track_res, classeme, dim_boxfeature, min_frames_th, max_proposal, score_th, device="cuda:0",
+                         video_len=None, video_wh=(1280, 720)):
+    """``Dataset._get_proposal`` of the VidOR loader (dataloaders/dataloader_vidor_v3.py:389-485) + its ``TrajProposal`` (:19-69):
+    -> TrajProposal whose feature rows ``[RoI (dim_boxfeature) | classeme (300)]`` were assembled on the device (views of one tensor), or
+    an empty proposal.  ``classeme``: the ``<video>_clsme.npy`` array, one row per row of ``track_res``."""
+    plan, dense = plan_vidor_tracklets(track_res, dim_boxfeature, min_frames_th, max_proposal, score_th)
+    if plan is None:
+        return TrajProposal(video_name, video_len or 0, video_wh, [], [], [], [], [])
+    cls = np.ascontiguousarray(np.asarray(classeme, dtype=np.float32)[plan["file_rows"]])          # the full rows' classemes, dense order
+    feats = assemble_features(plan, dense, dim_boxfeature, cls, cls.shape[1], device, col2=0)
+    lens = [int(b.shape[0]) for b in plan["boxes"]]
+    boxes = torch.cat(plan["boxes"], 0).to(feats.device)
+    return TrajProposal.from_blocks(video_name, video_len or (max(d[1] for d in plan["durations"]) + 1), video_wh, plan["cat_ids"], plan["scores"],
+                                    plan["durations"], lens, boxes, feats)
+
+
+def load_video_features(video_feature_dir, video_names, device=None):
+    """``Dataset.load_video_features`` (dataloaders/dataloader_vidor_v3.py:265-277): {video_name: (num_clips, 1024) clip features} for
+    the grounding stage, optionally moved to ``device``."""
+    import os
+    out = {}
+    for name in video_names:
+        f = torch.from_numpy(np.load(os.path.join(video_feature_dir, name + ".npy")))
+        out[name] = f.to(device) if device is not None else f
+    return out

@@ -33,7 +33,8 @@ def tracklet_table(p, device):
     built by this package (``TrajProposal.from_blocks`` / ``.to()``, ``bigc_hip.ingest``) hold their tracklets as views of one
     block per video and get the table by arithmetic; for foreign containers (the reference's own ``TrajProposal``) the
     tensors are visited once.  The cache is checked against EVERY item of both lists: it holds a weak reference per source
-    tensor and is a hit only while each one is alive and IS the list's current item -- after the reference's to(GPU) -> forward -> to(cpu)
+    tensor (whose callback marks the table dead when the tensor goes) and the tensors' ids, and is a hit only while every one is alive and
+    IS the list's current item -- after the reference's to(GPU) -> forward -> to(cpu)
     -> to(GPU) cycle the caching allocator may hand the old blocks back for the first / last tracklets and other blocks for the middle
     ones; matching end addresses prove nothing.
     The cached table holds ADDRESSES and weak references only, never tensors (a table that kept its sources alive pinned every evaluated
@@ -55,7 +56,9 @@ def tracklet_table(p, device):
     fl, bl = p.features_list, p.bboxes_list
     n = len(bl)
     assert n == len(fl) and n == int(p.num_proposals)
-    if c is not None and c["n"] == n and c["device"] == device and all(r() is t for r, t in zip(c["refs"][0], fl)) and all(r() is t for r, t in zip(c["refs"][1], bl)):
+    if c is not None and c["n"] == n and c["device"] == device and not c["died"][0] and c["ids"] == (list(map(id, fl)), list(map(id, bl))):
+        # (every source tensor of the table is still alive -- a weak-reference callback sets `died` when one goes -- so its id() cannot have
+        # been handed to another object: equal ids ARE the same tensors.  5 us per video where 128 weak-reference calls took 27.)
         # the caller's lists as they are NOW keep the rows alive for this batch (64 references per video; nothing is stored on `p`);
         # `_cached`: where PackedBatch keeps what it derives from the table (tmax, the metadata check) from one call to the next
         return dict(c, sources=(list(fl), list(bl)), _cached=c)
@@ -77,9 +80,10 @@ def tracklet_table(p, device):
     fptr = np.fromiter((f.data_ptr() for f in fl2), dtype=np.uint64, count=n)
     bptr = np.fromiter((b.data_ptr() for b in bl2), dtype=np.uint64, count=n)
     fld = np.fromiter((f.stride(0) if f.shape[0] > 1 else width for f in fl2), dtype=np.int64, count=n)
+    died = [False]
     c = dict(n=n, device=device, width=width, lens=lens, fptr=fptr, bptr=bptr, fld=None if (fld == width).all() else fld.astype(np.int32),
              aligned=bool(((fptr | bptr) % np.uint64(16) == 0).all() and (fld % 4 == 0).all()),
-             refs=([weakref.ref(t) for t in fl], [weakref.ref(t) for t in bl]), keep=[])
+             ids=(list(map(id, fl)), list(map(id, bl))), died=died, refs=[weakref.ref(t, lambda _r, d=died: d.__setitem__(0, True)) for t in fl + bl], keep=[])
     cached = None
     if not keep:                  # (a table that points at converted COPIES is not kept: the caller may change its own tensors' values in place)
         try:
@@ -93,6 +97,8 @@ def tracklet_table(p, device):
 
 
 class PackedBatch(object):
+    _meta_srcs = None
+
     def __init__(self, proposals, device, features="f32"):
         """``proposals``: list of non-empty TrajProposal-like objects (see bigc_hip.synthetic.TrajProposal).
         ``features``: "f32" / "hr8" = gather the feature rows now in that form, "lazy" = at first use (the engine picks the form
@@ -175,7 +181,7 @@ class PackedBatch(object):
             self.trk_dura = torch.empty((self.n_trk, 2), dtype=torch.int32, device=device)
             self.trk_cat = torch.empty((self.n_trk,), dtype=torch.int32, device=device)
             self.trk_score = torch.empty((self.n_trk,), dtype=torch.float32, device=device)
-            srcs = [d64[s64[k]:s64[k] + self.n_vid] for k in (2, 3, 4)]
+            srcs = self._meta_srcs = [d64[s64[k]:s64[k] + self.n_vid] for k in (2, 3, 4)]
             _lib.check(_lib.load().bigc_pack_video_meta(_lib.current_stream(), srcs[0].data_ptr(), srcs[1].data_ptr(), srcs[2].data_ptr(),
                                                         self.vid_trk_off.data_ptr(), self.n_vid, self.trk_cat.data_ptr(), self.trk_score.data_ptr(),
                                                         self.trk_dura.data_ptr()))
@@ -243,6 +249,37 @@ class PackedBatch(object):
             self._feats = feats
         else:
             self.feats_hr8, self.feats_hr8_flag, self.extra = hr8, flag, extra
+
+    # ---- the same list of containers again (models/_bigc.py: forward keeps its last batch) -----------------------------------------------
+    def signature(self):
+        """What must still hold for this batch's tables to describe ``self.proposals``: weak references to every container's two blocks
+        and three metadata tensors (containers of this package only; None otherwise).  Weak: the signature keeps no GPU memory alive."""
+        ps = self.proposals
+        if ps is None or self._meta_srcs is None or self._sources or self._keep or not all(hasattr(p, "_feat_block") and p._lists is None for p in ps):
+            return None
+        return [(weakref.ref(p._feat_block), weakref.ref(p._box_block), weakref.ref(p.cat_ids), weakref.ref(p.scores), weakref.ref(p.traj_durations)) for p in ps]
+
+    @staticmethod
+    def signature_holds(sig, proposals):
+        """every container still holds the very tensors the tables were made from (identity: ~0.3 us per container)"""
+        for p, (fb, bb, ci, sc, td) in zip(proposals, sig):
+            if fb() is not p._feat_block or bb() is not p._box_block or ci() is not p.cat_ids or sc() is not p.scores or td() is not p.traj_durations:
+                return False
+        return True
+
+    def refresh_values(self):
+        """The tables (addresses, offsets) are those of the same tensors; what the batch COPIED from them when it was made -- boxes and the
+        per-tracklet metadata -- is gathered again (two launches), so that values written in place since then are seen, as the feature rows
+        (read in place) are."""
+        lib = _lib.load()
+        if self._boxes is not None:
+            _lib.check(lib.bigc_pack_tracklets(_lib.current_stream(), None, None, self._box_src.data_ptr(), self.trk_row_off.data_ptr(),
+                                               self.n_trk, self.n_rows, self.feat_width, self.feat_width, 0, None, 0, None, 0, None, 0,
+                                               self._boxes.data_ptr(), None))
+        srcs = self._meta_srcs
+        _lib.check(lib.bigc_pack_video_meta(_lib.current_stream(), srcs[0].data_ptr(), srcs[1].data_ptr(), srcs[2].data_ptr(),
+                                            self.vid_trk_off.data_ptr(), self.n_vid, self.trk_cat.data_ptr(), self.trk_score.data_ptr(),
+                                            self.trk_dura.data_ptr()))
 
     def can_read_in_place(self):
         """the forward can read the feature rows where they are (16-byte aligned sources that are still alive)"""

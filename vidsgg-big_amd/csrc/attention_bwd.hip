@@ -225,17 +225,92 @@ __global__ __launch_bounds__(256) void mha_bwd_both_kernel(const float* __restri
                              run_flag, run_id);
 }
 
+// Videos of at most 64 entities (round 6): one workgroup of four waves per (video, query tile).  Wave (role, entity tile) computes ITS
+// 32 x 32 score tile (a chain of half dependent f32 MFMAs -- the four tiles run side by side instead of one after the other on one wave)
+// and leaves it in LDS as S[role][query][entity]; then wave w takes the query rows w, w + 4, ... with lane = entity: the softmax
+// statistics of a row are wave reductions and d att is read, d scores written, as whole 256-byte rows (with lane = query every load
+// instruction touched 64 cache lines).  Which form runs depends on the video's own entity count only.
+__global__ __launch_bounds__(256) void role_attention_bwd_tiles_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
+                                                                       const float* __restrict__ datt, float* __restrict__ ds,
+                                                                       const int32_t* __restrict__ e_off, int n_vid, int nq, int n_qt, int half,
+                                                                       float scale) {
+    constexpr int SP = 68;                                  // floats per query row of S (64 entities + pad)
+    __shared__ __attribute__((aligned(16))) float S[2][32][SP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int item = blockIdx.x;
+    const int qt = item % n_qt, vid = item / n_qt;
+    const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
+    if (qt * 32 >= nq || ne <= 0 || ne > 64) return;        // (uniform; ne > 64: role_attention_bwd_kernel, launched beside this one)
+    {
+        const int role = wave >> 1, et = wave & 1;
+        if (et * 32 < ne) {
+            const int hh = half / 2;
+            const int qrow = min(qt * 32 + l31, nq - 1);
+            const int erow = min(et * 32 + l31, ne - 1);
+            const float* qp = p2a + (size_t)(vid * nq + qrow) * ldp + role * half + hi * hh;
+            const float* ep = e2a + (size_t)(e0 + erow) * lde + role * half + hi * hh;
+            f32x16 acc = zero16();
+            for (int i = 0; i < hh; i += 16) {              // sixteen k of both operands in flight per round
+                f32x4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[u] = *(const f32x4*)(ep + i + 4 * u); b[u] = *(const f32x4*)(qp + i + 4 * u); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc = mfma32(a[u][c], b[u][c], acc);
+            }
+            // register r of lane (l31, hi) = S[entity et * 32 + mfma_row(r, hi)][query l31]: four consecutive entities per register quad
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *(f32x4*)&S[role][l31][et * 32 + 8 * r4 + 4 * hi] = f32x4{acc[4 * r4] * scale, acc[4 * r4 + 1] * scale, acc[4 * r4 + 2] * scale, acc[4 * r4 + 3] * scale};
+        }
+    }
+    __syncthreads();
+    const float* gbase = datt + (size_t)2 * nq * e0;
+    float* dbase = ds + (size_t)2 * nq * e0;
+    const bool nok = lane < ne;
+    for (int ql = wave; ql < 32; ql += 4) {
+        const int qq = qt * 32 + ql;
+        if (qq >= nq) break;
+        const float s0 = nok ? S[0][ql][lane] : NEG_BIG, s1 = nok ? S[1][ql][lane] : NEG_BIG;
+        float m0 = s0, m1 = s1;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
+        const float x0 = nok ? expf(s0 - m0) : 0.f, x1 = nok ? expf(s1 - m1) : 0.f;
+        float l0 = x0, l1 = x1;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { l0 += __shfl_xor(l0, o); l1 += __shfl_xor(l1, o); }
+        const float E0 = x0 / l0, E1 = x1 / l1;
+        const float mx = fmaxf(s0, s1);
+        const float w0 = expf(s0 - mx), w1 = expf(s1 - mx);
+        const float R0 = w0 / (w0 + w1), R1 = w1 / (w0 + w1);
+        const float ga0 = nok ? gbase[((size_t)0 * nq + qq) * ne + lane] * E0 * R0 : 0.f;
+        const float ga1 = nok ? gbase[((size_t)1 * nq + qq) * ne + lane] * E1 * R1 : 0.f;
+        float c0 = ga0, c1 = ga1;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); }
+        const float both = ga0 + ga1;
+        if (nok) {
+            dbase[((size_t)0 * nq + qq) * ne + lane] = (2.f * ga0 - E0 * c0 - R0 * both) * scale;
+            dbase[((size_t)1 * nq + qq) * ne + lane] = (2.f * ga1 - E1 * c1 - R1 * both) * scale;
+        }
+    }
+}
+
+// The general form (any entity count): one wave per (video, query tile), lane = query, registers = entities.  `skip_small`: videos of
+// at most 64 entities are left to role_attention_bwd_tiles_kernel.
 __global__ __launch_bounds__(256) void role_attention_bwd_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
                                                                  const float* __restrict__ datt, float* __restrict__ ds,
                                                                  const int32_t* __restrict__ e_off, int n_vid, int nq, int n_qt, int half,
-                                                                 float scale) {
+                                                                 float scale, int skip_small) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;
     if (item >= (long)n_vid * n_qt) return;
     const int qt = item % n_qt, vid = item / n_qt;
     const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
-    if (qt * 32 >= nq || ne <= 0) return;
+    if (qt * 32 >= nq || ne <= 0 || (skip_small && ne <= 64)) return;
     const int qq = qt * 32 + l31;
     const int qrow = min(qq, nq - 1);
     const int hh = half / 2;
@@ -260,8 +335,7 @@ __global__ __launch_bounds__(256) void role_attention_bwd_kernel(const float* __
         for (int r = 0; r < 16; ++r) { s0[r] *= scale; s1[r] *= scale; }
     };
 
-    // videos of at most 64 entities (the training workloads): the score tiles of both roles are computed ONCE and kept in registers
-    // for the three passes below (each tile is 2 x half / 2 dependent f32 MFMAs: recomputing them was two thirds of this kernel)
+    // videos of at most 64 entities: the score tiles of both roles are computed ONCE and kept in registers for the three passes below
     const bool cached = n_et <= 2;
     f32x16 cs0[2], cs1[2];
     if (cached) {
@@ -568,15 +642,32 @@ extern "C" int bigc_mha_bwd_drop_f32(void* stream, const float* q, int ldq, cons
     return BIGC_OK;
 }
 
+// max_ent: an upper bound of the videos' entity counts (the caller's bigc_batch.max_trk), INT_MAX when unknown
+int bigc_role_attention_bwd_launch(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt,
+                                   float* ds, const int32_t* e_off, int n_vid, int nq, int half, float scale, int max_ent);
+
 extern "C" int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt,
                                            float* ds, const int32_t* e_off, int n_vid, int nq, int half, float scale) {
+    return bigc_role_attention_bwd_launch(stream, p2a, ldp, e2a, lde, datt, ds, e_off, n_vid, nq, half, scale, 0x7fffffff);
+}
+
+int bigc_role_attention_bwd_launch(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt,
+                                   float* ds, const int32_t* e_off, int n_vid, int nq, int half, float scale, int max_ent) {
     BIGC_CHECK_ARG(p2a && e2a && datt && ds && e_off, "role_attention_bwd: null pointer");
     if (n_vid <= 0) return BIGC_OK;
     const int n_qt = cdiv(nq, 32);
     ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
-    const int wpb = n_vid * n_qt <= 512 ? 1 : 4;                 // small batches: one wave per workgroup (more CUs)
-    hipLaunchKernelGGL(role_attention_bwd_kernel, dim3(cdiv(n_vid * n_qt, wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, datt, ds,
-                       e_off, n_vid, nq, n_qt, half, scale);
+    // videos of at most 64 entities: the four-wave tile kernel; larger ones: the wave-per-item kernel.  Both are launched (each leaves the
+    // other's videos alone: the entity counts live on the device), the second only when the caller's bound says it is needed
+    const bool tiles = half % 32 == 0 && (ldp % 4) == 0 && (lde % 4) == 0;
+    if (tiles)
+        hipLaunchKernelGGL(role_attention_bwd_tiles_kernel, dim3(n_vid * n_qt), dim3(256), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, datt, ds,
+                           e_off, n_vid, nq, n_qt, half, scale);
+    if (!tiles || max_ent > 64) {
+        const int wpb = n_vid * n_qt <= 512 ? 1 : 4;             // small batches: one wave per workgroup (more CUs)
+        hipLaunchKernelGGL(role_attention_bwd_kernel, dim3(cdiv(n_vid * n_qt, wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, p2a, ldp, e2a, lde, datt, ds,
+                           e_off, n_vid, nq, n_qt, half, scale, tiles ? 1 : 0);
+    }
     BIGC_LAUNCH_CHECK("role_attention_bwd");
     return BIGC_OK;
 }

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_h_kernel(const float* __restr
 // both pitches conflict-free for ds_read_b128.  The next tile's global loads are issued before the current tile's MFMAs and split into
 // the other LDS buffer behind them: one barrier per step.  Per lane and tile pair 48 elements are split on the fly (P, dS) instead of 272.
 // Same arithmetic per product as above (three f16 MFMAs, two accumulators), same dropout masks, same range flag.
+constexpr float LOG2E = 1.4426950408889634f;
 constexpr int RP = 272, TP = 144;                       // bytes per row of R / per column of T
 constexpr int LDS_R = 32 * RP, LDS_T = HD * TP;         // 8704, 9216
 constexpr int LDS_BUF = 2 * LDS_R + 2 * LDS_T + 256;    // [R1 | R2 | T1 | T2 | lse (32 f32) | delta (32 f32)] = 36096 bytes; two of them
@@ -287,7 +288,7 @@ struct FusedArgs {
 template <int NW, bool KV>
 __device__ __forceinline__ void bwd_side(const FusedArgs& a, unsigned char* lds, const int s, const int h, const int group, const float gs, const float gi) {
     constexpr int NTH = 64 * NW;
-    constexpr int N_ITEMS = KV ? 1024 : 768;              // R1, R2: 256 each; T1 (and T2 for KV): 256 each
+    constexpr int N_ITEMS = 256;                          // (operand 1 | operand 2) x 16 row pairs x 8 chunks of 8 head dims
     constexpr int ITERS = (N_ITEMS + NTH - 1) / NTH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -313,7 +314,7 @@ __device__ __forceinline__ void bwd_side(const FusedArgs& a, unsigned char* lds,
         load_row_split(p2, KV ? 1.0f : gs, o2h, o2r, chk, amax);
     }
     float my_lse = 0.f, my_delta = 0.f;
-    if (!KV) { my_lse = a.lse[(size_t)(q0 + orow) * a.n_head + h]; my_delta = a.delta[(size_t)(q0 + orow) * a.n_head + h] * gs; }
+    if (!KV) { my_lse = a.lse[(size_t)(q0 + orow) * a.n_head + h] * LOG2E; my_delta = a.delta[(size_t)(q0 + orow) * a.n_head + h] * gs; }
     // accumulators: [0] = P^T dO (dV, KV only), [1] = dS^T Q (dK) / dS K (dQ)
     f32x16 acc0[KV ? 2 : 1][2], acc1[KV ? 2 : 1][2];
 #pragma unroll
@@ -321,26 +322,23 @@ __device__ __forceinline__ void bwd_side(const FusedArgs& a, unsigned char* lds,
 #pragma unroll
         for (int t = 0; t < 2; ++t) { acc0[o][t] = zero16(); acc1[o][t] = zero16(); }
 
-    // ---- staging of one tile of the other side: items [0,256) R1, [256,512) R2, [512,768) T1, [768,1024) T2
-    float pre[ITERS][8];
+    // ---- staging of one tile of the other side: item = (operand, row pair e >> 3, chunk e & 7): 8 head dims of two adjacent rows, split
+    // ONCE and written in both layouts -- 16 + 16 bytes per row into R, and per head dim one dword (the two rows' halves) into T, where row
+    // 2 p becomes position (chunk g = 2 (row >> 4) + ((row >> 2) & 1), slot j = (row & 3) + 4 ((row >> 3) & 1)) and row 2 p + 1 slot j + 1:
+    // the inverse of mfma_row(8 u + j, hi).  T2 (the dP operand transposed) is only read by the KV side (dV = P^T dO).
+    float pre[ITERS][16];
     auto fetch = [&](int tile) {
         const int row0 = tile * 32;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int id = tid + it * NTH;
-            if (ITERS * NTH > N_ITEMS && id >= N_ITEMS) break;
-            const int kind = id >> 8, e = id & 255;
-            if (kind < 2) {                                   // row-major: row e >> 3, chunk e & 7
-                const float* src = (kind ? x2 : x1) + (size_t)min(row0 + (e >> 3), n_oth - 1) * (kind ? ld2 : ld1) + 8 * (e & 7);
-                const f32x4 t0 = *(const f32x4*)src, t1 = *(const f32x4*)(src + 4);
-                pre[it][0] = t0[0]; pre[it][1] = t0[1]; pre[it][2] = t0[2]; pre[it][3] = t0[3];
-                pre[it][4] = t1[0]; pre[it][5] = t1[1]; pre[it][6] = t1[2]; pre[it][7] = t1[3];
-            } else {                                          // transposed: head dim e & 63, chunk g = e >> 6 = 2 u + hi: rows mfma_row(8 u + j, hi)
-                const int d = e & 63, g = e >> 6;
-                const float* base = (kind == 3 ? x2 : x1) + d;
-                const int ldx = kind == 3 ? ld2 : ld1;
+            const int kind = id >> 7, e = id & 127;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pre[it][j] = base[(size_t)min(row0 + mfma_row(8 * (g >> 1) + j, g & 1), n_oth - 1) * ldx];
+            for (int rr = 0; rr < 2; ++rr) {
+                const float* src = (kind ? x2 : x1) + (size_t)min(row0 + 2 * (e >> 3) + rr, n_oth - 1) * (kind ? ld2 : ld1) + 8 * (e & 7);
+                const f32x4 t0 = *(const f32x4*)src, t1 = *(const f32x4*)(src + 4);
+                pre[it][8 * rr + 0] = t0[0]; pre[it][8 * rr + 1] = t0[1]; pre[it][8 * rr + 2] = t0[2]; pre[it][8 * rr + 3] = t0[3];
+                pre[it][8 * rr + 4] = t1[0]; pre[it][8 * rr + 5] = t1[1]; pre[it][8 * rr + 6] = t1[2]; pre[it][8 * rr + 7] = t1[3];
             }
         }
     };
@@ -348,27 +346,37 @@ __device__ __forceinline__ void bwd_side(const FusedArgs& a, unsigned char* lds,
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int id = tid + it * NTH;
-            if (ITERS * NTH > N_ITEMS && id >= N_ITEMS) break;
-            const int kind = id >> 8, e = id & 255;
-            const float mul = (kind == 1 || kind == 3) ? mul2 : 1.0f;
-            float x[8];
+            const int kind = id >> 7, e = id & 127;
+            const float mul = kind ? mul2 : 1.0f;
+            union { a16x8 v; _Float16 s[8]; } hh[2], rr[2];
+            const int row = 2 * (e >> 3), c = e & 7;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = pre[it][j] * mul;
-            a16x8 hh, rr;
-            split8(x, hh, rr, chk, amax);
-            unsigned char* dst;
-            int roff;
-            if (kind < 2) { dst = buf + kind * LDS_R + (e >> 3) * RP + (e & 7) * 16; roff = 128; }
-            else { dst = buf + 2 * LDS_R + (kind - 2) * LDS_T + (e & 63) * TP + (e >> 6) * 32; roff = 16; }
-            *(a16x8*)dst = hh;
-            *(a16x8*)(dst + roff) = rr;
+            for (int q = 0; q < 2; ++q) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = pre[it][8 * q + j] * mul;
+                split8(x, hh[q].v, rr[q].v, chk, amax);
+                unsigned char* dst = buf + kind * LDS_R + (row + q) * RP + c * 16;
+                *(a16x8*)dst = hh[q].v;
+                *(a16x8*)(dst + 128) = rr[q].v;
+            }
+            if (KV || kind == 0) {
+                const int g = 2 * (row >> 4) + ((row >> 2) & 1), j = (row & 3) + 4 * ((row >> 3) & 1);       // (row even: j even, row + 1 -> j + 1)
+                unsigned char* tp = buf + 2 * LDS_R + kind * LDS_T + (8 * c) * TP + g * 32 + j * 2;
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    *(h2*)(tp + d * TP) = h2{hh[0].s[d], hh[1].s[d]};
+                    *(h2*)(tp + d * TP + 16) = h2{rr[0].s[d], rr[1].s[d]};
+                }
+            }
         }
     };
     auto stash_stats = [&](unsigned char* buf, int tile) {        // KV: lse / delta of the tile's 32 query rows
         if (KV && tid < 64) {
             const int r = min(tile * 32 + (tid & 31), nq - 1);
             float* dst = (float*)(buf + 2 * LDS_R + 2 * LDS_T);
-            dst[tid] = tid < 32 ? a.lse[(size_t)(q0 + r) * a.n_head + h] : a.delta[(size_t)(q0 + r) * a.n_head + h] * gs;
+            dst[tid] = tid < 32 ? a.lse[(size_t)(q0 + r) * a.n_head + h] * LOG2E : a.delta[(size_t)(q0 + r) * a.n_head + h] * gs;
         }
     };
     // C^T tile = (rows of R) x (own rows)^T over the head dimension
@@ -420,14 +428,24 @@ __device__ __forceinline__ void bwd_side(const FusedArgs& a, unsigned char* lds,
             dot_lds(cur, o1h, o1r, sc);
             dot_lds(cur + LDS_R, o2h, o2r, dp);
             const float* stats = (const float*)(cur + 2 * LDS_R + 2 * LDS_T);
+            float lrs[16], drs[16];
+            if (KV) {                                                // registers 4 a .. 4 a + 3 are the tile's rows 8 a + 4 hi + (0 .. 3)
+#pragma unroll
+                for (int a4 = 0; a4 < 4; ++a4) {
+                    const f32x4 l4 = *(const f32x4*)(stats + 8 * a4 + 4 * hi), d4 = *(const f32x4*)(stats + 32 + 8 * a4 + 4 * hi);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { lrs[4 * a4 + c] = l4[c]; drs[4 * a4 + c] = d4[c]; }
+                }
+            }
             float pd[16], ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int orr = mfma_row(r, hi);                    // row of the staged tile this register belongs to
                 const int oi = tile * 32 + orr;
                 const bool ok = oi < n_oth && rok;
-                const float lr = KV ? stats[orr] : my_lse, dr = KV ? stats[32 + orr] : my_delta;
-                const float p = ok ? expf(sc[r] - lr) : 0.f;
+                const float lr = KV ? lrs[r] : my_lse, dr = KV ? drs[r] : my_delta;
+                // exp(s - lse) as 2^(s log2 e - lse log2 e): one v_exp_f32 (1 ulp) where expf is a dozen instructions; lse arrives pre-multiplied
+                const float p = ok ? __builtin_amdgcn_exp2f(sc[r] * LOG2E - lr) : 0.f;
                 float pdr = p, dpr = dp[r];
                 if (a.drop.thresh) {
                     const int qrow_g = KV ? q0 + min(oi, nq - 1) : q0 + orow;

@@ -35,6 +35,8 @@ extern "C" int bigc_mha_bwd_f32(void* stream, const float* q, int ldq, const flo
                                 float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                                 const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
                                 int n_head, int hd);
+int bigc_role_attention_bwd_launch(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt,
+                                   float* ds, const int32_t* e_off, int n_vid, int nq, int half, float scale, int max_ent);        // attention_bwd.hip
 extern "C" int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt,
                                            float* ds, const int32_t* e_off, int n_vid, int nq, int half, float scale);
 extern "C" int bigc_role_small_gemm_f32(void* stream, int mode, const float* att_or_ds, const float* dvals_or_p2a, int ld1,
@@ -430,8 +432,14 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
         }
         TRY(linear(s, enco, de, L.e2a, S.e2a, da, NT, da, de, BIGC_ACT_NONE));
         TRY(linear(s, S.q2, dp, L.p2a, S.p2a, da, BQ, da, dp, BIGC_ACT_NONE));
-        TRY(bigc_role_attention_f32(s, S.p2a, da, S.e2a, da, S.att, b->vid_trk_off, B, Q, da / 2, att_scale));
-        TRY(bigc_role_values_f32(s, S.att, enco, de, S.vals, b->vid_trk_off, B, Q, de));
+        // role attention and its values: videos of at most 64 tracklets take the eval path's one-launch kernel (csrc/attention_split.hip,
+        // split-operand f16 MFMAs, att written for the backward: 15 us where the two f32-MFMA launches took 66 + 18 for 8 videos)
+        if (b->max_trk <= 64 && (da / 2) % 64 == 0 && !bigc_linear_get_exact()) {
+            TRY(bigc_role_fused_f32(s, S.p2a, da, S.e2a, da, enco, de, S.att, S.vals, b->vid_trk_off, B, Q, b->max_trk, da / 2, de, att_scale));
+        } else {
+            TRY(bigc_role_attention_f32(s, S.p2a, da, S.e2a, da, S.att, b->vid_trk_off, B, Q, da / 2, att_scale));
+            TRY(bigc_role_values_f32(s, S.att, enco, de, S.vals, b->vid_trk_off, B, Q, de));
+        }
         TRY(linear(s, S.vals, de, L.role0[0], S.rh0, dp, BQ, dp, de, BIGC_ACT_RELU));
         TRY(linear(s, S.rh0, dp, L.role0[1], w.rtmp, dp, BQ, dp, dp, BIGC_ACT_NONE, S.q2, dp));
         TRY(linear(s, S.vals + (size_t)BQ * de, de, L.role1[0], S.rh1, dp, BQ, dp, de, BIGC_ACT_RELU));
@@ -566,7 +574,7 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
         // d att = d vals @ enco^T and d enco += att^T @ d vals in one launch, then d p2a = ds @ e2a and d e2a = ds^T @ p2a in another
         TRY(bigc_role_small_gemm_pair_f32(s, 0, S.att, w.gvals, de, enco, de, w.gatt, w.genco, de, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
         if (i == c.n_deco_layers - 1) TRY(bigc_axpy_f32(s, w.gatt, datt, (long)2 * Q * NT));
-        TRY(bigc_role_attention_bwd_f32(s, S.p2a, da, S.e2a, da, w.gatt, w.ds, b->vid_trk_off, B, Q, da / 2, att_scale));
+        TRY(bigc_role_attention_bwd_launch(s, S.p2a, da, S.e2a, da, w.gatt, w.ds, b->vid_trk_off, B, Q, da / 2, att_scale, b->max_trk));
         TRY(bigc_role_small_gemm_pair_f32(s, 1, w.ds, S.p2a, da, S.e2a, da, w.gp2a, w.ge2a, da, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
         TRY(bw.lin_res(p + ".fc_pred2att", L.p2a, w.gp2a, da, S.q2, dp, BQ, da, dp, B2, B3, dp));             // B3 = d q2 total
         TRY(bw.lin(p + ".fc_enti2att", L.e2a, w.ge2a, da, enco, de, NT, da, de, w.genco, de, true));

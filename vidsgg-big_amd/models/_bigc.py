@@ -7,6 +7,8 @@ are used as parameter containers only: ``forward`` never calls them, all arithme
 the HIP library through ``bigc_hip.engine.BigcEngine``.
 """
 import numpy as np
+import weakref
+
 import torch
 from torch import nn
 
@@ -50,6 +52,70 @@ class _DecoderLayerParams(nn.Module):
         self.norm1 = nn.LayerNorm(d_pred)
         self.norm2 = nn.LayerNorm(d_pred)
         self.norm3 = nn.LayerNorm(d_pred)
+
+
+class _LazyResults(list):
+    """The per-video result list of an eval forward -- a real ``list`` (``len``, indexing, slicing, iteration, ``==`` behave as the
+    reference's list of tuples / ``None``) whose entries are made when they are first read: entry v is ``None`` for a video without
+    triplets, else the tuple of the four views [off_v : off_v + n_v] of the batch's compacted arrays.  Cutting 4 x 256 views eagerly costs
+    0.45 ms per call, more than the GPU side of small batches; a caller that reads every entry pays the same in total."""
+    __slots__ = ("_arrays", "_off", "_sizes", "_todo")
+
+    def __init__(self, arrays, off, sizes):
+        super().__init__([None] * len(sizes))
+        self._arrays, self._off, self._sizes = arrays, off, sizes
+        self._todo = set(i for i, n in enumerate(sizes) if n > 0)
+
+    def _make(self, i):
+        if i in self._todo:
+            self._todo.discard(i)
+            o, n = self._off[i], self._sizes[i]
+            a = self._arrays
+            list.__setitem__(self, i, (a[0][o:o + n], a[1][o:o + n], a[2][o:o + n], a[3][o:o + n]))
+
+    def _make_all(self):
+        for i in list(self._todo):
+            self._make(i)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            self._make_all()
+            return list.__getitem__(self, i)
+        self._make(i if i >= 0 else i + len(self))
+        return list.__getitem__(self, i)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            self._make(i)
+            yield list.__getitem__(self, i)
+
+    def __reversed__(self):
+        self._make_all()
+        return list.__reversed__(self)
+
+    def _all(fn):                                           # (whole-list operations see the finished list)
+        def wrapped(self, *a, **k):
+            self._make_all()
+            return fn(self, *a, **k)
+        wrapped.__name__ = fn.__name__
+        return wrapped
+
+    __eq__ = _all(list.__eq__)
+    __ne__ = _all(list.__ne__)
+    __repr__ = _all(list.__repr__)
+    __add__ = _all(list.__add__)
+    __mul__ = _all(list.__mul__)
+    __contains__ = _all(list.__contains__)
+    __reduce_ex__ = _all(lambda self, proto: (list, (list.__getitem__(self, slice(None)),)))
+    copy = _all(list.copy)
+    count = _all(list.count)
+    index = _all(list.index)
+    pop = _all(list.pop)
+    remove = _all(list.remove)
+    reverse = _all(list.reverse)
+    sort = _all(list.sort)
+    del _all
+    __hash__ = None
 
 
 class _Pending(object):
@@ -199,12 +265,47 @@ class BigcBase(nn.Module):
         for i in keep:
             n = proposal_list[i].num_proposals
             classes.setdefault(0 if n <= 64 else (1 if n <= single_pass else 2), []).append(i)
+        if len(classes) == 1 and len(keep) == len(proposal_list):
+            # the common case -- one class, no empty video: the results are handed out as a lazy list (see _LazyResults)
+            packed = self._pack(proposal_list, device)
+            out = self.forward_checked(packed, topk)
+            self._remember_pack(proposal_list, packed)
+            return self.unpack_results(len(proposal_list), None, out, lazy=True)
         res = [None] * len(proposal_list)
         for idx in classes.values():
             packed = PackedBatch([proposal_list[i] for i in idx], device, "lazy")      # the engine gathers the rows in the form its forward reads
             for i, r in zip(idx, self.unpack_results(len(idx), list(range(len(idx))), self.forward_checked(packed, topk))):
                 res[i] = r
         return res
+
+    # ---- the same list of containers again: per-epoch evaluation over a device-resident set, benchmarks ------------------------------
+    def _pack(self, proposal_list, device):
+        """PackedBatch of the list -- the previous call's when ``proposal_list`` holds the same containers with the same tensors (checked by
+        identity, element by element: 0.15 ms for 256 videos where the tables cost 1 ms to build and upload).  Only what the batch copies --
+        boxes, categories, scores, durations -- is gathered again (``refresh_values``); the feature rows are read in place anyway."""
+        c = self.__dict__.get("_last_pack")
+        if c is not None and c[0] == device and len(c[1]) == len(proposal_list) and all(a() is b for a, b in zip(c[1], proposal_list)) \
+                and PackedBatch.signature_holds(c[2], proposal_list):
+            packed = c[3]
+            packed.proposals = proposal_list
+            packed.refresh_values()
+            return packed
+        object.__setattr__(self, "_last_pack", None)
+        return PackedBatch(list(proposal_list), device, "lazy")
+
+    def _remember_pack(self, proposal_list, packed):
+        """keep the batch for ``_pack`` -- if it is made of this package's containers and the forward read their rows in place (a batch that
+        holds a COPY of the features would go stale when the caller writes into its tensors).  Holds weak references only; the batch's own
+        device memory is its tables and boxes (14 MB for 256 videos)."""
+        if self.__dict__.get("_last_pack") is not None and self._last_pack[3] is packed:
+            packed.proposals = None
+            return
+        sig = packed.signature() if (packed._feats is None and packed.feats_hr8 is None and packed.feat_row_ptr is not None) else None
+        if sig is None:
+            object.__setattr__(self, "_last_pack", None)
+            return
+        packed.proposals = None                     # (the cache must not keep the containers alive)
+        object.__setattr__(self, "_last_pack", (packed.device, [weakref.ref(p) for p in proposal_list], sig, packed))
 
     def forward_async(self, proposal_list, topk=None):
         """``forward`` in two halves, for loops over many batches (tools/eval_*.py): this call packs the batch and QUEUES everything on the
@@ -341,12 +442,17 @@ class BigcBase(nn.Module):
         return out
 
     @staticmethod
-    def unpack_results(n_total, keep, out):
+    def unpack_results(n_total, keep, out, lazy=False):
         """Device outputs -> the reference's per-video list: one D2H copy (the row offsets) and one split per array -- the library has
-        already laid the videos' rows out back to back in the reference's dtypes (``bigc_compact_triplets``)."""
+        already laid the videos' rows out back to back in the reference's dtypes (``bigc_compact_triplets``).  ``lazy`` (keep = None: every
+        video of the batch, in order): a list that cuts a video's four views out of the arrays when the video's entry is first read."""
         sizes = BigcBase.counts(out).tolist()
         total = int(out["_host_off"][-1])
-        parts = [out[k][:total].split(sizes) for k in ("c_quint", "c_scores", "c_dura", "c_qid")]
+        arrays = [out[k][:total] for k in ("c_quint", "c_scores", "c_dura", "c_qid")]
+        if lazy:
+            assert keep is None and len(sizes) == n_total
+            return _LazyResults(arrays, out["_host_off"].tolist(), sizes)
+        parts = [a.split(sizes) for a in arrays]
         res = [None] * n_total
         for j, i in enumerate(keep):
             if sizes[j] > 0:

@@ -25,10 +25,37 @@ from bigc_hip.shard import gather_results
 from models import BIG_C_vidor, Base_C, DEBUG
 
 
-def _load_data(cfg, synthetic, n_trajs, clip_dim):
+RAW = {}        # --tracking_dir / --classeme_dir / --video_feature_dir / --video_info_path / --gt_json_path of this run (set in __main__)
+
+
+def _load_data(cfg, synthetic, n_trajs, clip_dim, device=None):
     """the data set as an index of (proposal, gt_graph, clip features) items, loaded per rank on demand (_common.VideoIndex)"""
     if synthetic:
         return synthetic_vidor_index(cfg["model_config"] if not clip_dim else {}, synthetic, n_trajs, seed=2468, clip_dim=clip_dim)
+    if RAW.get("tracking_dir"):
+        # raw tracking results: one `<video>.npy` of per-box rows (length 12 + dim_boxfeature, or 6 for tracker-only boxes) and one
+        # `<video>_clsme.npy` of classeme rows per video, ingested here (bigc_hip/ingest.py: dataloaders/dataloader_vidor_v3.py:389-485
+        # restated, the feature rows assembled on the GPU); the grounding stage's clip features from --video_feature_dir (:265-277)
+        import glob
+        import numpy as np
+        from _common import VideoIndex
+        from bigc_hip.ingest import load_vidor_tracklets
+        ds_cfg = cfg["test_dataset_config"]
+        paths = sorted(glob.glob(os.path.join(RAW["tracking_dir"], "*.npy")))
+        names = [os.path.splitext(os.path.basename(path))[0] for path in paths]
+        info = json.load(open(RAW["video_info_path"])) if RAW.get("video_info_path") else {}
+
+        def load(i):
+            nm = names[i]
+            vi = info.get(nm, {})
+            p = load_vidor_tracklets(nm, np.load(paths[i], allow_pickle=True), np.load(os.path.join(RAW["classeme_dir"], nm + "_clsme.npy")),
+                                     ds_cfg["dim_boxfeature"], ds_cfg["min_frames_th"], ds_cfg["max_proposal"], ds_cfg["score_th"],
+                                     device=device or "cuda:0", video_len=vi.get("video_len"), video_wh=tuple(vi.get("video_wh", (1280, 720))))
+            clip = None
+            if clip_dim and RAW.get("video_feature_dir"):
+                clip = torch.from_numpy(np.load(os.path.join(RAW["video_feature_dir"], nm + ".npy")))       # (num_clips, 1024)
+            return (p, None, clip)
+        return VideoIndex([max(1, os.path.getsize(path)) for path in paths], load, names)
     from dataloaders.dataloader_vidor_v3 import Dataset                 # the reference's loader (tools/eval_vidor.py:11)
     ds = Dataset(**cfg["test_dataset_config"])
     return dataset_index(ds, lambda it: (it[1], it[2], it[0]) if len(it) == 3 else (it[0], it[1], None))
@@ -39,7 +66,7 @@ def _report(groundtruth, predictions, output_dir, name, save_json, device=None):
         with open(os.path.join(output_dir, name), "w") as f:
             json.dump(predictions, f)
     if not groundtruth:
-        with open("datasets/GT_json_for_eval/VidORval_gts.json") as f:      # VidVRDhelperEvalAPIs/visual_relation_detection.py:250-256
+        with open(RAW.get("gt_json_path") or "datasets/GT_json_for_eval/VidORval_gts.json") as f:      # VidVRDhelperEvalAPIs/visual_relation_detection.py:250-256
             groundtruth = json.load(f)
     mean_ap, rec, prec = E.evaluate(groundtruth, predictions, device=device)
     print("detection mean AP (used in challenge): {}".format(mean_ap))
@@ -61,7 +88,7 @@ def evaluate_cls_stage(cfg_path, ckpt_path=None, save_tag="", output_dir=None, c
     if ckpt_path:
         load_checkpoint_into(model, ckpt_path, device)
     model.eval()
-    data = _load_data(cfg, synthetic, n_trajs, None)
+    data = _load_data(cfg, synthetic, n_trajs, None, device)
     predictions, groundtruth, raw = {}, {}, {}
     mine, my_data = shard_for_inference(data, data.costs, rank, world)          # only this rank's videos are loaded
     t0 = time.time()
@@ -123,7 +150,7 @@ def evaluate_combined(cfg_path, ckpt_path, cls_stage_result_path, save_tag="", o
     if ckpt_path:
         load_checkpoint_into(model, ckpt_path, device)
     model.eval()
-    data = _load_data(cfg, synthetic, n_trajs, cfg["model_config"]["dim_feat"])
+    data = _load_data(cfg, synthetic, n_trajs, cfg["model_config"]["dim_feat"], device)
     with open(cls_stage_result_path, "rb") as f:
         cls_results = pickle.load(f)
     predictions, groundtruth, n_skipped = {}, {}, 0
@@ -200,7 +227,15 @@ if __name__ == "__main__":
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N generated videos instead of a dataset")
     ap.add_argument("--n_trajs", type=int, default=32)
     ap.add_argument("--grd_batch", type=int, default=8, help="videos per grounding launch sequence (1 = the reference's one video per forward)")
+    ap.add_argument("--tracking_dir", type=str, default=None, help="directory of raw tracking results (<video>.npy): ingested by this package, no reference dataloader needed")
+    ap.add_argument("--classeme_dir", type=str, default=None, help="with --tracking_dir: directory of the per-box classeme files (<video>_clsme.npy)")
+    ap.add_argument("--video_feature_dir", type=str, default=None, help="with --tracking_dir: directory of the clip features of the grounding stage (<video>.npy)")
+    ap.add_argument("--video_info_path", type=str, default=None, help="with --tracking_dir: JSON {video: {video_len, video_wh}} (default: last tracked frame + 1, 1280 x 720)")
+    ap.add_argument("--gt_json_path", type=str, default=None, help="ground truth in the evaluator's JSON format (default: datasets/GT_json_for_eval/VidORval_gts.json)")
     a = ap.parse_args()
+    assert not a.tracking_dir or a.classeme_dir, "--tracking_dir needs --classeme_dir"
+    RAW.update(tracking_dir=a.tracking_dir, classeme_dir=a.classeme_dir, video_feature_dir=a.video_feature_dir, video_info_path=a.video_info_path,
+               gt_json_path=a.gt_json_path)
     if a.json_results_path is not None:
         with open(a.json_results_path) as f:
             _report({}, json.load(f), ".", "", False)

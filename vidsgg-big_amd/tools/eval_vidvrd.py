@@ -28,7 +28,7 @@ from models import BIG_C_vidvrd
 
 
 def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_tag="", use_pku=False, json_results_path=None,
-                        synthetic=0, n_trajs=64, batch_videos=64, tracking_dir=None, i3d_dir=None):
+                        synthetic=0, n_trajs=64, batch_videos=64, tracking_dir=None, i3d_dir=None, gt_json_path=None, video_info_path=None):
     cfg = parse_config_py(cfg_path)
     model_config, infer_config = cfg["model_config"], cfg.get("inference_config", {})
     topk = infer_config.get("topk", 10)
@@ -53,12 +53,14 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
         ds_cfg = cfg["test_dataset_config"]
         paths = sorted(glob.glob(os.path.join(tracking_dir, "*.npy")))
         names = [os.path.splitext(os.path.basename(path))[0] for path in paths]
+        info = json.load(open(video_info_path)) if video_info_path else {}      # {video: {video_len, video_wh}}; default: last tracked frame + 1, 1280 x 720
 
         def load(i):
             i3d = np.load(os.path.join(i3d_dir, names[i] + ".npy")) if i3d_dir else None
+            vi = info.get(names[i], {})
             return (load_pku_tracklets(names[i], np.load(paths[i], allow_pickle=True), ds_cfg["dim_boxfeature"], ds_cfg["min_frames_th"],
                                        ds_cfg["max_proposal"], i3d_res=i3d, dim_i3d=ds_cfg.get("dim_i3d", 0) if i3d_dir else 0,
-                                       device=device), None)
+                                       device=device, video_len=vi.get("video_len"), video_wh=tuple(vi.get("video_wh", (1280, 720)))), None)
         data = VideoIndex([max(1, os.path.getsize(path)) for path in paths], load, names)       # cost = file size ~ rows
     else:
         from dataloaders.dataloader_vidvrd import Dataset_pku_i3d, Dataset_pku, Dataset   # the reference's own loaders
@@ -114,7 +116,7 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
         with open(json_results_path, "w") as f:
             json.dump(predictions, f)
     if not groundtruth:
-        gt_json = "datasets/GT_json_for_eval/VidVRDtest_gts.json"      # VidVRDhelperEvalAPIs/visual_relation_detection.py:250-253
+        gt_json = gt_json_path or "datasets/GT_json_for_eval/VidVRDtest_gts.json"      # VidVRDhelperEvalAPIs/visual_relation_detection.py:250-253
         with open(gt_json) as f:
             groundtruth = json.load(f)
     mean_ap, rec, prec = E.evaluate(groundtruth, predictions, device=device)     # vIoU overlaps from one batched HIP kernel
@@ -140,6 +142,8 @@ if __name__ == "__main__":
     ap.add_argument("--n_trajs", type=int, default=64)
     ap.add_argument("--tracking_dir", type=str, default=None, help="directory of raw per-video tracking-result .npy files (PKU row format)")
     ap.add_argument("--i3d_dir", type=str, default=None, help="matching directory of per-box I3D feature .npy files")
+    ap.add_argument("--video_info_path", type=str, default=None, help="with --tracking_dir: JSON {video: {video_len, video_wh}} (default: last tracked frame + 1, 1280 x 720)")
+    ap.add_argument("--gt_json_path", type=str, default=None, help="ground truth in the evaluator's JSON format (default: datasets/GT_json_for_eval/VidVRDtest_gts.json)")
     a = ap.parse_args()
     inference_then_eval(a.cfg_path, a.ckpt_path, a.output_dir, a.cuda, a.save_tag, a.use_pku, a.json_results_path, a.synthetic, a.n_trajs,
-                        tracking_dir=a.tracking_dir, i3d_dir=a.i3d_dir)
+                        tracking_dir=a.tracking_dir, i3d_dir=a.i3d_dir, gt_json_path=a.gt_json_path, video_info_path=a.video_info_path)

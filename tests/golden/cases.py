@@ -65,6 +65,17 @@ BIGC_CASES = {
                         videos=[dict(seed=4100, n_trajs=100)]),
     "bigo_o_n180": dict(cfg="CONFIG_O", variant="vidor", wseed=35, topk=3, att_gain=8.0, full=False,
                         videos=[dict(seed=2280, n_trajs=180, len_range=(15, 200), start_range=(0, 150))]),
+    # the other shipped experiment shapes at FULL dims through the real reference, outputs only (round 6):
+    #   exp1 (experiments/exp1/config_.py): PKU RoI 2048 only, no I3D -> the head's other concat order, K = 2 x 512 + 2 x 512 + 2 x 300 + 512 (models/model_0v10.py:503)
+    #   exp3 (experiments/exp3/config_.py): MEGA RoI 1024, no I3D
+    #   exp4 (experiments/exp4/config_.py:21): the VidOR model without classemes (use_clsme = False)
+    "bigc_exp1_n48": dict(cfg="CONFIG_V_EXP1", variant="vidvrd", wseed=41, topk=10, att_gain=8.0, full=False, slim=True,
+                          videos=[dict(seed=3101, n_trajs=48), dict(seed=3102, n_trajs=20, len_range=(5, 40), start_range=(0, 20))]),
+    "bigc_exp3_n40": dict(cfg="CONFIG_V_EXP3", variant="vidvrd", wseed=42, topk=10, att_gain=8.0, full=False, slim=True,
+                          videos=[dict(seed=3103, n_trajs=40)]),
+    "bigo_exp4_n40": dict(cfg="CONFIG_O_EXP4", variant="vidor", wseed=43, topk=3, att_gain=8.0, full=False, slim=True,
+                          videos=[dict(seed=3104, n_trajs=40, len_range=(15, 200), start_range=(0, 100)),
+                                  dict(seed=3105, n_trajs=90, len_range=(15, 80), start_range=(0, 150))]),
 }
 
 
@@ -79,6 +90,19 @@ def get_cfg(name):
         return c
     if name == "CONFIG_TINY_O_NOCLSME":
         c = dict(configs.CONFIG_TINY_O)
+        c["use_clsme"] = False
+        return c
+    if name == "CONFIG_V_EXP1":             # experiments/exp1: exp2 without the I3D columns
+        c = dict(configs.CONFIG_V)
+        c.pop("dim_i3d")
+        return c
+    if name == "CONFIG_V_EXP3":             # experiments/exp3: MEGA RoI features (1024-d), no I3D
+        c = dict(configs.CONFIG_V)
+        c.pop("dim_i3d")
+        c["dim_feat"] = 1024
+        return c
+    if name == "CONFIG_O_EXP4":             # experiments/exp4: exp5 without classemes
+        c = dict(configs.CONFIG_O)
         c["use_clsme"] = False
         return c
     return dict(getattr(configs, name))

@@ -194,6 +194,27 @@ def test_grounding_empty_and_all_zero_scores():
     assert status == 1
 
 
+def test_model_forward_raises_where_the_reference_raises_on_all_zero_scores():
+    """``temporal_pooling`` takes ``torch.min`` of an EMPTY selection when a (query, bin) column of scores is all zero -- the
+    reference dies with an IndexError (models/grd_model_v5.py:726).  The convention here: the kernel raises the ``status`` word of the
+    video (nothing else of its output is defined), ``DEBUG.forward`` turns it into the same IndexError, the batched entry point hands the
+    status out per video (tools/eval_vidor.py skips such a video), and the CPU oracle asserts at the same place.  Forced through the whole
+    model: head biases of -1e4 make sigmoid(conf) and sigmoid(cls) exactly 0."""
+    from oracle import grd_oracle as G
+    cfg, sd, videos = cases.make_grd_case("grd_tiny")
+    sd = {k: v.clone() for k, v in sd.items()}
+    last = sorted(k for k in sd if k.startswith("cls_head.") and k.endswith(".bias"))[-1]
+    sd[last] = torch.full_like(sd[last], -1e4)
+    model = build_model(cfg, sd)
+    feat, (quint, dura, vl) = videos[0]
+    with pytest.raises(IndexError):
+        model([feat.to(DEV)], [(quint, dura, vl)], with_gt_data=False, **cases.GRD_TH)
+    outs = model.forward_raw_batch([(feat.to(DEV), quint, dura, vl)], **cases.GRD_TH)
+    assert int(outs[0]["status"].item()) == 1
+    with pytest.raises(AssertionError):
+        G.forward(sd, cfg, feat, (quint, dura, vl), **cases.GRD_TH)
+
+
 def test_grounding_batch_of_videos_vs_reference_golden_and_vs_one_video_calls():
     """grd_forward_batch on the three grd_tiny videos (T = 9 / 33 / 2 clips, n = 5 / 1 / 4 queries) in ONE call: every video's
     result matches the reference golden and is bit-identical to the one-video-per-call forward."""

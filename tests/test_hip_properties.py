@@ -205,7 +205,9 @@ def test_benchmark_videos_vs_oracle_row_for_row():
     on video 29), and so was the HIP path while its GEMMs summed K in one accumulator (1.65e-4 on video 117, 1.59e-4 on 172).  With blocked
     accumulation in every GEMM (csrc/gemm_ps.hip) the maximum over all 256 benchmark videos is 6.7e-5 to 7.8e-5.  Where HIP and the f32
     oracle differ by more than 1e-4 the f32 oracle must be the farther one from float64.
-    Over the SET, HIP's mean distance to float64 must not exceed 1.1 x the f32 oracle's (measured 0.7 - 0.8 x)."""
+    Over the SET, HIP's mean distance to float64 must not exceed 1.1 x the f32 oracle's (measured 0.7 - 0.8 x).
+    PER QUERY ROW (round 6): the same bound with every query's own largest logit as the scale (6.0e-5 on these 32 videos, 8.7e-5 over
+    all 256)."""
     from oracle import accuracy as A
     from oracle import bigc_oracle as O
     n_vid = 32
@@ -224,7 +226,7 @@ def test_benchmark_videos_vs_oracle_row_for_row():
     soid = out["soid"].cpu().numpy()
     torch.set_num_threads(min(16, torch.get_num_threads()))
     rows, arbitrated = 0, []
-    e_hips, e_refs = [], []
+    e_hips, e_refs, row_errs = [], [], []
     with torch.no_grad():
         for v, p in enumerate(host):
             o = O.encode2decode(sd, cfg, p)
@@ -240,6 +242,10 @@ def test_benchmark_videos_vs_oracle_row_for_row():
             # evaluation on EVERY video -- no noise-floor criterion.  Where two f32 evaluations are more than 1e-4 apart it is then the f32
             # oracle that sits far from float64 (video 29 of this set: 2.1e-4), which is recorded, not excused.
             assert e_hips[-1] <= 1e-4, "video %d: HIP logits %.2e from the float64 oracle (f32 oracle: %.2e)" % (v, e_hips[-1], e_refs[-1])
+            # ... and PER QUERY ROW ("1e-4 rel" read row by row): max_c |delta| / max_c |logit of that query| against float64
+            row_err = float((np.abs(logits[v].astype(np.float64) - ref64).max(1) / np.abs(ref64).max(1)).max())
+            row_errs.append(row_err)
+            assert row_err <= 1e-4, "video %d: a query row of the HIP logits is %.2e (relative to that row's largest logit) from float64" % (v, row_err)
             if np.abs(logits[v] - ref).max() / np.abs(ref).max() > 1e-4:
                 arbitrated.append((v, dict(hip_vs_f64=e_hips[-1], f32_oracle_vs_f64=e_refs[-1])))
                 assert e_refs[-1] > e_hips[-1], "video %d: HIP and the f32 oracle differ by more than 1e-4 and HIP is the farther from float64" % v
@@ -252,3 +258,32 @@ def test_benchmark_videos_vs_oracle_row_for_row():
     assert rows > 32 * 50 and len(arbitrated) <= 2, arbitrated
     assert max(e_hips) <= 1e-4 and np.mean(e_hips) <= 1.1 * np.mean(e_refs), "distance to float64: hip max %.2e mean %.2e, f32 oracle mean %.2e" % (
         max(e_hips), np.mean(e_hips), np.mean(e_refs))
+
+
+def test_the_one_benchmark_row_that_differs_from_the_f32_oracle_is_the_float64_oracles():
+    """Of the 51 306 triplet rows of the 256-video benchmark set ONE differs between the HIP path and the f32 oracle (video 156: a top-k
+    decision between two class probabilities within round-off of each other).  Two f32 evaluations may disagree there; the float64
+    evaluation of the oracle decides, and it sides with the HIP rows: every row of the HIP output that is not in the f32 oracle's output is
+    in the float64 oracle's, at the same position.  (A video's bits do not depend on its company: scored alone here.)"""
+    from oracle import accuracy as A
+    from oracle import bigc_oracle as O
+    cfg = dict(configs.CONFIG_V)
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 7, att_gain=8.0)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    model = build_model(cfg, "vidvrd", sd)
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    v = 156
+    p = synthetic_proposal(1234 + v, n_trajs=64, feat_width=width, num_enti_cats=cfg["num_enti_cats"])
+    got = as_np(model([synthetic_proposal(1234 + v, n_trajs=64, feat_width=width, num_enti_cats=cfg["num_enti_cats"]).to(DEV)], topk=10)[0])
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        o = O.encode2decode(sd, cfg, p)
+        want32 = O.construct_triplet(p, o["pred_logits"], o["att"], 10)
+        _, p64 = A.to_f64({}, p)
+        o64 = O.encode2decode(sd64, cfg, p64)
+        want64 = O.construct_triplet(p64, o64["pred_logits"], o64["att"], 10)
+    assert got[0].shape == tuple(want64[0].shape) == tuple(want32[0].shape)
+    same32 = (got[0] == want32[0].numpy()).all(1) & (got[2] == want32[2].numpy()).all(1) & (got[3] == want32[3].numpy())
+    same64 = (got[0] == want64[0].numpy()).all(1) & (got[2] == want64[2].numpy()).all(1) & (got[3] == want64[3].numpy())
+    assert same64.all(), "rows %s of the HIP output differ from the float64 oracle's" % np.nonzero(~same64)[0].tolist()
+    assert (~same32).sum() <= 1                      # (the f32 oracle's one tie that falls the other way; 0 if a library update moves it)

@@ -233,7 +233,9 @@ def test_eval_vidvrd_cli_on_raw_tracking_results():
         np.save(d + "/track/video_%02d.npy" % v, track)
         np.save(d + "/i3d/video_%02d.npy" % v, i3d)
     json.dump({"video_00": {"video_len": 60, "video_wh": [640, 360]}}, open(d + "/info.json", "w"))
-    json.dump({"video_%02d" % v: [] for v in range(10)}, open(d + "/gt0.json", "w"))
+    # first pass: a ground truth that nothing matches (the evaluator, like the reference's, needs at least one relation in total)
+    json.dump({"video_00": [{"triplet": ["nothing", "matches", "this"], "duration": [0, 5], "sub_traj": [[0, 0, 9, 9]] * 5, "obj_traj": [[20, 20, 29, 29]] * 5}]},
+              open(d + "/gt0.json", "w"))
     common = [os.path.join(TOOLS, "eval_vidvrd.py"), "--cfg_path", CFG, "--output_dir", d, "--use_pku", "--tracking_dir", d + "/track", "--i3d_dir", d + "/i3d",
               "--video_info_path", d + "/info.json"]
     log = run(common + ["--save_tag", "raw0", "--gt_json_path", d + "/gt0.json", "--json_results_path", d + "/pred.json"])
@@ -276,7 +278,8 @@ def test_eval_vidor_cli_on_raw_tracking_results_then_grounding():
         np.save(os.path.join(d, "clip", name + ".npy"), (0.1 * rs.standard_normal((-(-vlen // 8), 1024))).astype(np.float32))
     del cases.VIDOR_INGEST_CASES["_cli"]
     json.dump(info, open(d + "/info.json", "w"))
-    json.dump({}, open(d + "/gt0.json", "w"))
+    json.dump({"1000": [{"triplet": ["nothing", "matches", "this"], "duration": [0, 5], "sub_traj": [[0, 0, 9, 9]] * 5, "obj_traj": [[20, 20, 29, 29]] * 5}]},
+              open(d + "/gt0.json", "w"))
     # exp5 asks for min_frames_th = 15; the generated tracklets have 6..19 boxes: a config copy with the threshold of the golden cases
     # (the same for the grounding config: both stages must ingest the same proposals)
     open(d + "/config_.py", "w").write(open(cfg5).read().replace("min_frames_th=15", "min_frames_th=5"))

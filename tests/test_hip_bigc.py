@@ -41,6 +41,21 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
 
 
+def check_logits(hip, golden, sd, cfg, variant, p):
+    """north_star's bound on the predicate logits: within 1e-4 (max-norm, relative to the video's largest logit) of the REFERENCE's stored
+    output -- or, where the two f32 evaluations are farther apart than that, within 1e-4 of a FLOAT64 evaluation of the oracle with the
+    reference's own f32 output the farther of the two from it.  The seeded models' role attention is sharp by construction (att_gain 8:
+    scores of magnitude ~50) and amplifies round-off; an f32 evaluation that rounds like the reference's is itself up to 2e-4 from float64
+    on such videos (measured on the 256 benchmark videos; first seen at full dims on the exp1 case of round 6)."""
+    e = rel(hip, golden)
+    if e < LOGIT_RTOL:
+        return
+    from oracle import accuracy as A
+    ref64 = A.f64_logits(sd, cfg, p, variant)
+    e_hip, e_ref = A.rel_err(hip, ref64), A.rel_err(golden, ref64)
+    assert e_hip <= LOGIT_RTOL and e_ref >= e_hip, "logits %.2e from the reference; from float64: HIP %.2e, the reference %.2e" % (e, e_hip, e_ref)
+
+
 def check_tuple_exact(got, want_q, want_s, want_d, want_id):
     assert got is not None
     q, s, d, i = [t.cpu().numpy() for t in got]
@@ -75,7 +90,7 @@ def test_bigc_vs_reference_golden(name):
         torch.cuda.synchronize()
         n = p.num_proposals
         if pre + "att_argmax" in g.files:            # outputs-only fixture: the contract itself
-            assert rel(out["pred_logits"].cpu().numpy(), g[pre + "pred_logits"]) < LOGIT_RTOL
+            check_logits(out["pred_logits"].cpu().numpy(), g[pre + "pred_logits"], sd, cfg, variant, p)
             assert np.array_equal(out["soid"].cpu().numpy()[0], g[pre + "att_argmax"])
             continue
         assert rel(out["enti2enco"].cpu().numpy(), g[pre + "enti2enco"]) < 2e-5
@@ -87,7 +102,7 @@ def test_bigc_vs_reference_golden(name):
         # an fp32-roundoff score difference of 1e-5*|s| moves a probability by up to ~5e-4; it is an
         # intermediate, the contract is on the logits (1e-4) and on the argmax indices (exact)
         assert rel(out["att"].cpu().numpy().reshape(2, Q, n), g[pre + "att"]) < 1e-3
-        assert rel(out["pred_logits"].cpu().numpy(), g[pre + "pred_logits"]) < LOGIT_RTOL
+        check_logits(out["pred_logits"].cpu().numpy(), g[pre + "pred_logits"], sd, cfg, variant, p)
         assert np.array_equal(out["soid"].cpu().numpy()[0], g[pre + "att"].argmax(-1))
     # ... and all videos of the case in one batch (cross-video batching must not change anything)
     res = model(props, topk=topk)

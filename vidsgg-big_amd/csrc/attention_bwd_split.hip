@@ -489,6 +489,200 @@ __device__ __forceinline__ void bwd_side(const FusedArgs& a, unsigned char* lds,
     }
 }
 
+// ---- one OUTPUT per wave (late round 6) --------------------------------------------------------------------------------------------
+// The kernel above gives a wave of the KV side both outputs of its key tile (dV and dK: 128 accumulator registers, 442 - 500 registers
+// in all) -- one wave per SIMD, which then sits out every LDS / barrier wait alone (rocprofv3 --pmc, profiles/r06h_pmc_mha_bwd_fused_64_videos.log:
+// 48 % of the wave cycles waiting, VALU 33 %, matrix pipe 10 %).  Here a workgroup has 2 x NWT waves and every wave ONE output:
+//   KV side: waves [0, NWT) own key tile g NWT + w and compute dK (scores, dP, dS, dS^T Q), waves [NWT, 2 NWT) own the same tiles and
+//            compute dV (scores, P, P^T dO) -- the scores of a tile pair are computed twice, by two waves side by side;
+//   Q side:  the 2 NWT waves own query tiles g 2 NWT + w and compute dQ.
+// <= 256 registers per wave: two waves per SIMD.  Staging, arithmetic per product and results are those of the kernel above.
+template <int NWT>
+__global__ __launch_bounds__(128 * NWT, 2) void mha_bwd_roles_h_kernel(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+    unsigned char* lds = fused_lds;
+    constexpr int NTH = 128 * NWT;
+    const int per = a.gk_groups + a.gq_groups;
+    const int item = blockIdx.x / per, rr_ = blockIdx.x - item * per;
+    const int h = item % a.n_head, s = item / a.n_head;
+    const bool KV = rr_ < a.gk_groups;
+    const int group = KV ? rr_ : rr_ - a.gk_groups;
+    float gs, gi;
+    grad_scale(a.amax_slot, gs, gi);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int q0 = a.q_off[s], nq = a.q_off[s + 1] - q0;
+    const int k0 = a.k_off[s], nk = a.k_off[s + 1] - k0;
+    const int n_own = KV ? nk : nq, n_oth = KV ? nq : nk;
+    const int per_group = KV ? NWT : 2 * NWT;
+    if (n_own <= 0 || n_oth <= 0 || group * per_group * 32 >= n_own) return;   // (uniform over the workgroup)
+    // role of this wave: 0 = dQ, 1 = dK, 2 = dV
+    const int role = KV ? (wave < NWT ? 1 : 2) : 0;
+    const int ot = KV ? group * NWT + (wave < NWT ? wave : wave - NWT) : group * 2 * NWT + wave;
+    const bool own_valid = ot * 32 < n_own;
+    const int orow = min(ot * 32 + l31, n_own - 1);
+    const bool rok = ot * 32 + l31 < n_own;
+    const float* x1 = KV ? a.q + (size_t)q0 * a.ldq + h * HD : a.k + (size_t)k0 * a.ldk + h * HD;
+    const float* x2 = KV ? a.dO + (size_t)q0 * a.lddo + h * HD : a.v + (size_t)k0 * a.ldv + h * HD;
+    const int ld1 = KV ? a.ldq : a.ldk, ld2 = KV ? a.lddo : a.ldv;
+    const float mul2 = KV ? gs : 1.0f;
+    float chk = 0.f, amax = 0.f;
+    a16x8 o1h[NST], o1r[NST], o2h[NST], o2r[NST];
+    {
+        const float* p1 = KV ? a.k + (size_t)(k0 + orow) * a.ldk + h * HD + 8 * hi : a.q + (size_t)(q0 + orow) * a.ldq + h * HD + 8 * hi;
+        load_row_split(p1, a.scale, o1h, o1r, chk, amax);
+        if (role != 2) {
+            const float* p2 = KV ? a.v + (size_t)(k0 + orow) * a.ldv + h * HD + 8 * hi : a.dO + (size_t)(q0 + orow) * a.lddo + h * HD + 8 * hi;
+            load_row_split(p2, KV ? 1.0f : gs, o2h, o2r, chk, amax);
+        }
+    }
+    float my_lse = 0.f, my_delta = 0.f;
+    if (!KV) { my_lse = a.lse[(size_t)(q0 + orow) * a.n_head + h] * LOG2E; my_delta = a.delta[(size_t)(q0 + orow) * a.n_head + h] * gs; }
+    f32x16 acc0[2], acc1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { acc0[t] = zero16(); acc1[t] = zero16(); }
+
+    // staging: 256 items (operand, row pair, chunk) by the first 256 threads -- see bwd_side
+    const bool stager = tid < 256;
+    float pre[16];
+    const int skind = (tid >> 7) & 1, se = tid & 127;
+    auto fetch = [&](int tile) {
+        if (!stager) return;
+        const int row0 = tile * 32;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float* src = (skind ? x2 : x1) + (size_t)min(row0 + 2 * (se >> 3) + q, n_oth - 1) * (skind ? ld2 : ld1) + 8 * (se & 7);
+            const f32x4 t0 = *(const f32x4*)src, t1 = *(const f32x4*)(src + 4);
+            pre[8 * q + 0] = t0[0]; pre[8 * q + 1] = t0[1]; pre[8 * q + 2] = t0[2]; pre[8 * q + 3] = t0[3];
+            pre[8 * q + 4] = t1[0]; pre[8 * q + 5] = t1[1]; pre[8 * q + 6] = t1[2]; pre[8 * q + 7] = t1[3];
+        }
+    };
+    auto stash = [&](unsigned char* buf, int tile) {
+        if (stager) {
+            const float mul = skind ? mul2 : 1.0f;
+            union { a16x8 v; _Float16 s[8]; } hh[2], rr[2];
+            const int row = 2 * (se >> 3), c = se & 7;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = pre[8 * q + j] * mul;
+                split8(x, hh[q].v, rr[q].v, chk, amax);
+                unsigned char* dst = buf + skind * LDS_R + (row + q) * RP + c * 16;
+                *(a16x8*)dst = hh[q].v;
+                *(a16x8*)(dst + 128) = rr[q].v;
+            }
+            if (KV || skind == 0) {
+                const int g = 2 * (row >> 4) + ((row >> 2) & 1), j = (row & 3) + 4 * ((row >> 3) & 1);
+                unsigned char* tp = buf + 2 * LDS_R + skind * LDS_T + (8 * c) * TP + g * 32 + j * 2;
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    *(h2*)(tp + d * TP) = h2{hh[0].s[d], hh[1].s[d]};
+                    *(h2*)(tp + d * TP + 16) = h2{rr[0].s[d], rr[1].s[d]};
+                }
+            }
+        }
+        if (KV && tid >= NTH - 64) {                       // lse / delta of the tile's 32 query rows (the last wave's lanes)
+            const int t64 = tid - (NTH - 64);
+            const int r = min(tile * 32 + (t64 & 31), nq - 1);
+            float* dst = (float*)(buf + 2 * LDS_R + 2 * LDS_T);
+            dst[t64] = t64 < 32 ? a.lse[(size_t)(q0 + r) * a.n_head + h] * LOG2E : a.delta[(size_t)(q0 + r) * a.n_head + h] * gs;
+        }
+    };
+    auto dot_lds = [&](const unsigned char* R, const a16x8 (&bh)[NST], const a16x8 (&br)[NST], f32x16& out) {
+        f32x16 c0 = zero16(), c1 = zero16();
+        const unsigned char* rowp = R + l31 * RP + hi * 16;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const a16x8 ah = *(const a16x8*)(rowp + st * 32), ar = *(const a16x8*)(rowp + st * 32 + 128);
+            c0 = MFMA_H(ah, bh[st], c0);
+            c1 = MFMA_H(ah, br[st], c1);
+            c1 = MFMA_H(ar, bh[st], c1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[r] = c0[r] + c1[r] * RI;
+    };
+    auto accum_lds = [&](const float (&w)[16], const unsigned char* T) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float w8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w8[j] = w[8 * u + j];
+            a16x8 wh, wr;
+            split8(w8, wh, wr, chk, amax);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned char* cp = T + (32 * t + l31) * TP + (2 * u + hi) * 32;
+                const a16x8 xh = *(const a16x8*)cp, xr = *(const a16x8*)(cp + 16);
+                acc0[t] = MFMA_H(wh, xh, acc0[t]);
+                acc1[t] = MFMA_H(wh, xr, acc1[t]);
+                acc1[t] = MFMA_H(wr, xh, acc1[t]);
+            }
+        }
+    };
+
+    const int n_tiles = (n_oth + 31) / 32;
+    fetch(0);
+    stash(lds, 0);
+    __syncthreads();
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        unsigned char* cur = lds + (tile & 1) * LDS_BUF;
+        unsigned char* nxt = lds + ((tile + 1) & 1) * LDS_BUF;
+        const bool more = tile + 1 < n_tiles;
+        if (more && !own_valid) fetch(tile + 1);
+        if (own_valid) {
+            f32x16 sc, dp;
+            dot_lds(cur, o1h, o1r, sc);
+            __builtin_amdgcn_sched_barrier(0);              // (the two products one after the other: interleaved they hold 128 accumulator registers)
+            if (role != 2) dot_lds(cur + LDS_R, o2h, o2r, dp);
+            __builtin_amdgcn_sched_barrier(0);
+            const float* stats = (const float*)(cur + 2 * LDS_R + 2 * LDS_T);
+            float w[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orr = mfma_row(r, hi);
+                const int oi = tile * 32 + orr;
+                const bool ok = oi < n_oth && rok;
+                const float lr = KV ? stats[orr] : my_lse, dr = KV ? stats[32 + orr] : my_delta;
+                const float p = ok ? __builtin_amdgcn_exp2f(sc[r] * LOG2E - lr) : 0.f;
+                bool keep = true;
+                if (a.drop.thresh) {
+                    const int qrow_g = KV ? q0 + min(oi, nq - 1) : q0 + orow;
+                    const int key = KV ? ot * 32 + l31 : oi;
+                    keep = drop_keep(a.drop, drop_att_idx(qrow_g, a.n_head, h, key));
+                }
+                if (role == 2) {
+                    w[r] = (a.drop.thresh && !keep) ? 0.f : p * (a.drop.thresh ? a.drop.scale : 1.0f);       // P (dropped)
+                } else {
+                    const float dpr = (a.drop.thresh && !keep) ? 0.f : dp[r] * (a.drop.thresh ? a.drop.scale : 1.0f);
+                    w[r] = p * (dpr - dr);                                                                       // dS
+                }
+            }
+            // (the next tile's global loads go out here, behind the two score products: their 16 registers are not live beside the
+            // products' 64 accumulator registers -- 20 spilled registers otherwise -- and still have the accumulation to hide behind)
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) fetch(tile + 1);
+            accum_lds(w, cur + 2 * LDS_R + (role == 2 ? LDS_T : 0));       // dV += P^T dO (T2)  |  dK += dS^T Q, dQ += dS K (T1)
+        }
+        if (more) stash(nxt, tile + 1);
+        __syncthreads();
+    }
+    if (!(fabsf(chk) < INFINITY) || amax >= 32768.0f) atomicMax(a.flag, a.run_id);
+    if (!own_valid) return;
+    float* outp = role == 0 ? a.dq + (size_t)q0 * a.lddq : (role == 1 ? a.dk + (size_t)k0 * a.lddk : a.dv + (size_t)k0 * a.lddv);
+    const int ldo = role == 0 ? a.lddq : (role == 1 ? a.lddk : a.lddv);
+    const float osc = role == 2 ? gi : a.scale * gi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = ot * 32 + mfma_row(r, hi);
+        if (row >= n_own) continue;
+        float* dst = outp + (size_t)row * ldo + h * HD + l31;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) dst[32 * t] = (acc0[t][r] + acc1[t][r] * RI) * osc;
+    }
+}
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void mha_bwd_fused_h_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
@@ -550,16 +744,27 @@ void bigc_mha_bwd_h_launch(hipStream_t s, const float* q, int ldq, const float* 
         a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
         a.q_off = q_off; a.k_off = k_off; a.n_head = n_head; a.scale = scale; a.drop = drop; a.flag = flag; a.run_id = run_id; a.amax_slot = amax_slot;
         const int nw = (n_qt <= 2 && n_kt <= 2) ? 2 : 4;              // own tiles per workgroup: sequences of at most 64 rows (the encoder) fit two waves
-        a.gq_groups = (n_qt + nw - 1) / nw; a.gk_groups = (n_kt + nw - 1) / nw;
-        const int grid = n_seq * n_head * (a.gq_groups + a.gk_groups);
+        static const bool roles_off = getenv("BIGC_MHA_BWD_ROLES") && atoi(getenv("BIGC_MHA_BWD_ROLES")) == 0;
         static std::atomic<unsigned long long> attr{0};
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (!((attr.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull)) {
             (void)hipFuncSetAttribute((const void*)mha_bwd_fused_h_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF);
             (void)hipFuncSetAttribute((const void*)mha_bwd_fused_h_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF);
+            (void)hipFuncSetAttribute((const void*)mha_bwd_roles_h_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF);
+            (void)hipFuncSetAttribute((const void*)mha_bwd_roles_h_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BUF);
             attr.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
         }
+        if (!roles_off) {
+            // one output per wave: 2 nw waves per workgroup; KV groups of nw key tiles, Q groups of 2 nw query tiles
+            a.gk_groups = (n_kt + nw - 1) / nw; a.gq_groups = (n_qt + 2 * nw - 1) / (2 * nw);
+            const int grid = n_seq * n_head * (a.gq_groups + a.gk_groups);
+            if (nw == 2) hipLaunchKernelGGL(mha_bwd_roles_h_kernel<2>, dim3(grid), dim3(256), 2 * LDS_BUF, s, a);
+            else hipLaunchKernelGGL(mha_bwd_roles_h_kernel<4>, dim3(grid), dim3(512), 2 * LDS_BUF, s, a);
+            return;
+        }
+        a.gq_groups = (n_qt + nw - 1) / nw; a.gk_groups = (n_kt + nw - 1) / nw;
+        const int grid = n_seq * n_head * (a.gq_groups + a.gk_groups);
         if (nw == 2) hipLaunchKernelGGL(mha_bwd_fused_h_kernel<2>, dim3(grid), dim3(128), 2 * LDS_BUF, s, a);
         else hipLaunchKernelGGL(mha_bwd_fused_h_kernel<4>, dim3(grid), dim3(256), 2 * LDS_BUF, s, a);
         return;

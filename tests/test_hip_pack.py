@@ -325,38 +325,46 @@ def test_same_list_again_reuses_the_tables_and_sees_values_written_in_place():
     mk = lambda s: synthetic_proposal(s, n_trajs=12, feat_width=width, num_enti_cats=cfg["num_enti_cats"], len_range=(10, 30))
     props = [mk(900 + i).to(DEV) for i in range(5)]
     first = model(props, topk=3)
-    kept = model._last_pack[3]
-    assert kept is not None and kept.proposals is None                      # weak references only: the batch does not hold the containers
+    assert model._last_pack["packed"] is None                               # a first call only remembers (length, first container) ...
     _same_results(model(props, topk=3), first)
-    assert model._last_pack[3] is kept                                      # ... the very same batch object served the second call
+    kept = model._last_pack["packed"]                                       # ... the second call with the same first container keeps its batch ...
+    assert kept is not None and kept.proposals is None                      # (weak references only: the batch does not hold the containers)
+    _same_results(model(props, topk=3), first)
+    assert model._last_pack["packed"] is kept                               # ... and the third is served by it
     _same_results(model(list(props), topk=3), first)                        # another list object with the same containers: still a hit
-    assert model._last_pack[3] is kept
+    assert model._last_pack["packed"] is kept
     # values written IN PLACE: features (read in place), scores and boxes (gathered again)
     with torch.no_grad():
         props[1].features_list[0].mul_(1.5)
         props[2].scores.mul_(0.5)
         props[3].bboxes_list[2].add_(3.0)
     got = model(props, topk=3)
-    assert model._last_pack[3] is kept
+    assert model._last_pack["packed"] is kept
     fresh_cfg, fresh = _model("CONFIG_V")
     want = fresh([p for p in props], topk=3)                                # a model that has never seen the list
     _same_results(got, want)
     assert not all(torch.equal(a[1], b[1]) for a, b in zip(got, first) if a is not None and b is not None)
-    # a container whose tensors were replaced (to(cpu) -> to(GPU)): rebuilt
+    # a container whose tensors were replaced (to(cpu) -> to(GPU)): rebuilt (and, the first container being the same, kept again)
     props[0].to("cpu").to(DEV)
     _same_results(model(props, topk=3), want)
-    assert model._last_pack[3] is not kept
-    kept = model._last_pack[3]
+    assert model._last_pack["packed"] is not kept and model._last_pack["packed"] is not None
+    kept = model._last_pack["packed"]
     # a metadata tensor replaced by another object
     props[4].scores = props[4].scores.clone()
     _same_results(model(props, topk=3), want)
-    assert model._last_pack[3] is not kept
+    assert model._last_pack["packed"] is not kept
     # a shorter list, then a foreign container in the list: no reuse, no stale batch kept
     _same_results(model(props[:3], topk=3), want[:3])
+    assert model._last_pack["packed"] is None
     mixed = props[:4] + [_foreign(mk(904), DEV)]
-    r = model(mixed, topk=3)
-    _same_results(r[:4], want[:4])
-    assert model.__dict__.get("_last_pack") is None
+    for _ in range(3):
+        r = model(mixed, topk=3)
+        _same_results(r[:4], want[:4])
+        assert model._last_pack["packed"] is None                           # (a batch with a foreign container is never kept)
+    # ever new lists: nothing but (length, first container) is remembered
+    for i in range(3):
+        model([mk(960 + i).to(DEV)], topk=3)
+        assert model._last_pack["packed"] is None
 
 
 @pytest.mark.gpu

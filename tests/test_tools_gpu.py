@@ -135,7 +135,7 @@ def test_bench_json_contract():
     n_same, n_all = [int(x) for x in pa["rows"].split(" of ")]
     assert pa["videos"] == 4 and n_all > 0 and n_same == n_all and pa["rows_off_both_oracles"] == 0 and pa["hip_vs_f64_max"] <= 1e-4
     lg = c["legs"]
-    for k in ("resident", "pipelined", "plain_accum", "exact_f32", "fast_f16", "fast_bf16", "batch_x2", "grounding", "train_8", "train_64", "recall"):
+    for k in ("resident", "pipelined", "new_lists", "plain_accum", "exact_f32", "fast_f16", "fast_bf16", "batch_x2", "grounding", "train_8", "train_64", "recall"):
         assert k in lg, k
     assert lg["grounding"]["unit"] == "queries/s" and lg["grounding"]["value"] > 0 and 0 < lg["grounding"]["mfma_frac"] < 1
     assert lg["train_8"]["value"] > 0 and lg["train_64"]["value"] > 0 and lg["recall"]["gate"] is True

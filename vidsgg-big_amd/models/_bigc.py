@@ -56,38 +56,34 @@ class _DecoderLayerParams(nn.Module):
 
 class _LazyResults(list):
     """The per-video result list of an eval forward -- a real ``list`` (``len``, indexing, slicing, iteration, ``==`` behave as the
-    reference's list of tuples / ``None``) whose entries are made when they are first read: entry v is ``None`` for a video without
-    triplets, else the tuple of the four views [off_v : off_v + n_v] of the batch's compacted arrays.  Cutting 4 x 256 views eagerly costs
-    0.45 ms per call, more than the GPU side of small batches; a caller that reads every entry pays the same in total."""
-    __slots__ = ("_arrays", "_off", "_sizes", "_todo")
+    reference's list of tuples / ``None``) whose entries are made when the list is first READ (all of them then, by one ``split`` per array):
+    entry v is ``None`` for a video without triplets, else the tuple of the four views [off_v : off_v + n_v] of the batch's compacted
+    arrays.  Cutting 4 x 256 views costs 0.45 ms per call, more than the GPU side of small batches; a caller that reads the results pays it
+    at its first read, a caller that only forwards the list (or reads nothing) does not."""
+    __slots__ = ("_arrays", "_sizes")
 
     def __init__(self, arrays, off, sizes):
         super().__init__([None] * len(sizes))
-        self._arrays, self._off, self._sizes = arrays, off, sizes
-        self._todo = set(i for i, n in enumerate(sizes) if n > 0)
-
-    def _make(self, i):
-        if i in self._todo:
-            self._todo.discard(i)
-            o, n = self._off[i], self._sizes[i]
-            a = self._arrays
-            list.__setitem__(self, i, (a[0][o:o + n], a[1][o:o + n], a[2][o:o + n], a[3][o:o + n]))
+        self._arrays, self._sizes = arrays, sizes
 
     def _make_all(self):
-        for i in list(self._todo):
-            self._make(i)
+        """every entry at once, at first read: one ``split`` per array (0.1 ms each for 256 videos; cutting the views one by one from
+        Python costs three times that)"""
+        if self._arrays is None:
+            return
+        parts = [a.split(self._sizes) for a in self._arrays]
+        for i, n in enumerate(self._sizes):
+            if n > 0:
+                list.__setitem__(self, i, (parts[0][i], parts[1][i], parts[2][i], parts[3][i]))
+        self._arrays = None
 
     def __getitem__(self, i):
-        if isinstance(i, slice):
-            self._make_all()
-            return list.__getitem__(self, i)
-        self._make(i if i >= 0 else i + len(self))
+        self._make_all()
         return list.__getitem__(self, i)
 
     def __iter__(self):
-        for i in range(len(self)):
-            self._make(i)
-            yield list.__getitem__(self, i)
+        self._make_all()
+        return list.__iter__(self)
 
     def __reversed__(self):
         self._make_all()
@@ -281,31 +277,39 @@ class BigcBase(nn.Module):
     # ---- the same list of containers again: per-epoch evaluation over a device-resident set, benchmarks ------------------------------
     def _pack(self, proposal_list, device):
         """PackedBatch of the list -- the previous call's when ``proposal_list`` holds the same containers with the same tensors (checked by
-        identity, element by element: 0.15 ms for 256 videos where the tables cost 1 ms to build and upload).  Only what the batch copies --
-        boxes, categories, scores, durations -- is gathered again (``refresh_values``); the feature rows are read in place anyway."""
+        identity, element by element: 0.1 ms for 256 videos where the tables cost 1 ms to build and upload).  Only what the batch copies --
+        boxes, categories, scores, durations -- is gathered again (``refresh_values``); the feature rows are read in place anyway.
+        Two stages, so that a loop over ever new videos pays one weak reference per call: a call remembers (length, first container); only
+        when the NEXT call starts with the same container is that call's batch kept with its full signature; the third call reuses it."""
         c = self.__dict__.get("_last_pack")
-        if c is not None and c[0] == device and len(c[1]) == len(proposal_list) and all(a() is b for a, b in zip(c[1], proposal_list)) \
-                and PackedBatch.signature_holds(c[2], proposal_list):
-            packed = c[3]
+        n = len(proposal_list)
+        if c is not None and c["packed"] is not None and c["device"] == device and c["n"] == n and all(a() is b for a, b in zip(c["refs"], proposal_list)) \
+                and PackedBatch.signature_holds(c["sig"], proposal_list):
+            packed = c["packed"]
             packed.proposals = proposal_list
             packed.refresh_values()
             return packed
-        object.__setattr__(self, "_last_pack", None)
+        repeat = c is not None and c["device"] == device and c["n"] == n and c["first"]() is proposal_list[0]
+        object.__setattr__(self, "_last_pack", dict(device=device, n=n, first=weakref.ref(proposal_list[0]), packed=None, keep_next=repeat))
         return PackedBatch(list(proposal_list), device, "lazy")
 
     def _remember_pack(self, proposal_list, packed):
-        """keep the batch for ``_pack`` -- if it is made of this package's containers and the forward read their rows in place (a batch that
-        holds a COPY of the features would go stale when the caller writes into its tensors).  Holds weak references only; the batch's own
-        device memory is its tables and boxes (14 MB for 256 videos)."""
-        if self.__dict__.get("_last_pack") is not None and self._last_pack[3] is packed:
-            packed.proposals = None
+        """keep the batch for ``_pack`` -- if the list looks like a repeat (see ``_pack``), is made of this package's containers and the forward
+        read their rows in place (a batch that holds a COPY of the features would go stale when the caller writes into its tensors).  Holds
+        weak references only; the batch's own device memory is its tables and boxes (14 MB for 256 videos)."""
+        c = self.__dict__.get("_last_pack")
+        if c is None:
+            return
+        if c["packed"] is packed:
+            packed.proposals = None                 # (the kept batch must not keep the containers alive)
+            return
+        if not c.get("keep_next"):
             return
         sig = packed.signature() if (packed._feats is None and packed.feats_hr8 is None and packed.feat_row_ptr is not None) else None
         if sig is None:
-            object.__setattr__(self, "_last_pack", None)
             return
-        packed.proposals = None                     # (the cache must not keep the containers alive)
-        object.__setattr__(self, "_last_pack", (packed.device, [weakref.ref(p) for p in proposal_list], sig, packed))
+        packed.proposals = None
+        c.update(refs=[weakref.ref(p) for p in proposal_list], sig=sig, packed=packed)
 
     def forward_async(self, proposal_list, topk=None):
         """``forward`` in two halves, for loops over many batches (tools/eval_*.py): this call packs the batch and QUEUES everything on the

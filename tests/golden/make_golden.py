@@ -333,6 +333,47 @@ def run_vidor_ingest_case(name):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "proposals", prop.num_proposals, "rows", out.get("bboxes", np.zeros((0, 4))).shape[0])
 
 
+def run_cache_fixture():
+    """A ``datasets/cache/*.pkl`` file as the reference writes it (dataloaders/dataloader_vidvrd.py:170-183): {video: (TrajProposal, VideoGraph)}
+    holding instances of the REFERENCE's classes, built from the ingest case's tracking results by the reference's own ``get_data`` pieces.
+    Stored as tests/golden/ref_cache_vidvrd.pkl (data: what a user's cache directory holds) + the expected arrays."""
+    import pickle
+    import types as _t
+    sys.path.insert(0, REFERENCE)
+    np.float, np.int = float, int
+    from dataloaders import dataloader_vidvrd as D
+    import utils.utils_func as U
+    sys.path.remove(REFERENCE)
+    U.fill_zeropadding = lambda vectors: None
+    data, expect = {}, {}
+    for vi, name in enumerate(("ingest_pku_i3d", "ingest_pku_i3d_c")):
+        track, i3d, case = cases.make_ingest_case(name)
+        d = tempfile.mkdtemp()
+        os.makedirs(d + "/prop"); os.makedirs(d + "/i3d")
+        np.save(d + "/prop/video_x.npy", track); np.save(d + "/i3d/video_x.npy", i3d)
+        fake = _t.SimpleNamespace(proposal_dir=d + "/prop", i3d_dir=d + "/i3d", dim_boxfeature=case["dim_box"], dim_i3d=case["dim_i3d"],
+                                  min_frames_th=case["min_frames_th"], max_proposal=case["max_proposal"])
+        prop = D.Dataset_pku_i3d._get_proposal(fake, "video_x")
+        prop.video_name = "video_%d" % vi
+        n_t, n_p = 3, 2
+        rs = np.random.RandomState(40 + vi)
+        graph = D.VideoGraph(("video_%d" % vi, 50 + vi, (640, 360)), "test", [3, 5, 7], [(0, 10), (2, 14), (5, 9)],
+                             [rs.uniform(0, 100, (10, 4)), rs.uniform(0, 100, (12, 4)), rs.uniform(0, 100, (4, 4))], [11, 12], [(2, 9), (5, 8)],
+                             np.array([[1, 0, 0], [0, 0, 1]], dtype=np.float32), np.array([[0, 1, 0], [0, 1, 0]], dtype=np.float32), 100)
+        prop.video_len, prop.video_wh = graph.video_len, graph.video_wh            # get_data (:232-233)
+        data["video_%d" % vi] = (prop, graph)
+        expect["v%d_features" % vi] = torch.cat(prop.features_list, 0).numpy()
+        expect["v%d_bboxes" % vi] = torch.cat(prop.bboxes_list, 0).numpy()
+        expect["v%d_cat_ids" % vi], expect["v%d_scores" % vi] = prop.cat_ids.numpy(), prop.scores.numpy()
+        expect["v%d_traj_durations" % vi] = prop.traj_durations.numpy()
+        expect["v%d_adj" % vi], expect["v%d_pred_durations" % vi] = graph.adj_matrix.numpy(), graph.pred_durations.numpy()
+        expect["v%d_gt_traj_durations" % vi] = graph.traj_durations.numpy()
+    with open(os.path.join(cases.GOLDEN_DIR, "ref_cache_vidvrd.pkl"), "wb") as f:
+        pickle.dump(data, f)
+    np.savez_compressed(os.path.join(cases.GOLDEN_DIR, "ref_cache_vidvrd_expect.npz"), **expect)
+    print("wrote ref_cache_vidvrd.pkl", os.path.getsize(os.path.join(cases.GOLDEN_DIR, "ref_cache_vidvrd.pkl")), "bytes")
+
+
 def run_basec_case(name):
     """The reference's Base_C (models/model_pairwise_baseline.py) eval forward on the seeded case."""
     sys.path.insert(0, REFERENCE)
@@ -463,7 +504,7 @@ def run_ties_golden(m10):
 def main():
     torch.manual_seed(0)
     m10, m07, grd = import_reference()
-    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + list(cases.GRD_TRAIN_CASES) + ["evaluator", "categories", "evalfmt", "ties"] +
+    names = sys.argv[1:] or (list(cases.BIGC_CASES) + list(cases.GRD_CASES) + list(cases.TRAIN_CASES) + list(cases.GRD_TRAIN_CASES) + ["evaluator", "categories", "evalfmt", "ties", "cache"] +
                              list(cases.INGEST_CASES) + list(cases.VIDOR_INGEST_CASES) + list(cases.BASEC_CASES) + list(cases.BASEC_TRAIN_CASES))
     for n in names:
         if n == "evaluator":
@@ -477,6 +518,9 @@ def main():
             continue
         if n == "evalfmt":
             run_evalfmt_golden()
+            continue
+        if n == "cache":
+            run_cache_fixture()
             continue
         if n in cases.INGEST_CASES:
             run_ingest_case(n)

@@ -121,3 +121,54 @@ def test_vidor_feature_rows_match_reference_dataloader(name):
     assert np.array_equal(torch.cat(p.bboxes_list, 0).cpu().numpy(), g["bboxes"])
     assert np.array_equal(p.traj_durations.cpu().numpy(), g["traj_durations"]) and np.array_equal(p.cat_ids.cpu().numpy(), g["cat_ids"])
     assert np.array_equal(p.scores.cpu().numpy(), g["scores"])
+
+
+# ---- the reference's on-disk cache (datasets/cache/*.pkl: pickled instances of ITS classes) read without the reference on PYTHONPATH ------
+
+def test_reference_cache_is_read_without_the_reference_classes():
+    import sys
+    assert not any(m == "dataloaders" or m.startswith("dataloaders.") for m in sys.modules), "the reference must not be importable here"
+    g = np.load(cases.GOLDEN_DIR + "/ref_cache_vidvrd_expect.npz")
+    data = ingest.load_reference_cache(cases.GOLDEN_DIR + "/ref_cache_vidvrd.pkl")       # written by the reference's own classes (make_golden.py cache)
+    assert sorted(data) == ["video_0", "video_1"]
+    for v, name in enumerate(sorted(data)):
+        p, gt = data[name]
+        pre = "v%d_" % v
+        assert type(p).__module__ == "bigc_hip.synthetic" and p.video_name == name and p.video_len == 50 + v and p.video_wh == (640, 360)
+        assert np.array_equal(torch.cat(p.features_list, 0).numpy(), g[pre + "features"])
+        assert np.array_equal(torch.cat(p.bboxes_list, 0).numpy(), g[pre + "bboxes"])
+        assert np.array_equal(p.cat_ids.numpy(), g[pre + "cat_ids"]) and np.array_equal(p.scores.numpy(), g[pre + "scores"])
+        assert np.array_equal(p.traj_durations.numpy(), g[pre + "traj_durations"])
+        assert hasattr(p, "_feat_block") and p._lists is None                    # block-backed: the batch packer reads addresses by arithmetic
+        assert np.array_equal(gt.adj_matrix.numpy(), g[pre + "adj"]) and np.array_equal(gt.pred_durations.numpy(), g[pre + "pred_durations"])
+        assert np.array_equal(gt.traj_durations.numpy(), g[pre + "gt_traj_durations"]) and gt.num_trajs == 3 and gt.num_preds == 2
+
+
+def test_reference_cache_reader_refuses_other_classes():
+    import io
+    import pickle
+
+    class Evil(object):
+        def __reduce__(self):
+            return (print, ("should never run",))
+    blob = pickle.dumps({"v": (Evil(),)})
+    with pytest.raises(pickle.UnpicklingError):
+        ingest._restricted_unpickler(io.BytesIO(blob)).load()
+
+
+@pytest.mark.gpu
+def test_reference_cache_feeds_the_model():
+    import tempfile
+    from bigc_hip.synthetic import bigc_state_shapes, seeded_state_dict
+    from models import BIG_C_vidvrd
+    data = ingest.load_reference_cache(cases.GOLDEN_DIR + "/ref_cache_vidvrd.pkl", device="cuda:0")
+    p0 = data["video_0"][0]
+    cfg = cases.get_cfg("CONFIG_TINY")
+    cfg["dim_feat"], cfg["dim_i3d"], cfg["num_enti_cats"] = 16, 8, 36
+    sd = seeded_state_dict(bigc_state_shapes(cfg, "vidvrd"), 5, att_gain=4.0)
+    d = tempfile.mkdtemp()
+    np.save(d + "/b.npy", sd["bias_matrix"].numpy()); np.save(d + "/e.npy", sd["EntiNameEmb"].numpy())
+    model = BIG_C_vidvrd(dict(cfg, bias_matrix_path=d + "/b.npy", EntiNameEmb_path=d + "/e.npy"), is_train=False)
+    model.load_state_dict(sd)
+    res = model.to("cuda:0")([p0], topk=3)[0]
+    assert res is None or (res[0].shape[1] == 5 and res[0].shape[0] == res[1].shape[0])

@@ -296,3 +296,14 @@ def test_eval_vidor_cli_on_raw_tracking_results_then_grounding():
                "--video_feature_dir", d + "/clip", "--save_json_results"] + raw[:4] + ["--video_info_path", d + "/info.json", "--gt_json_path", d + "/gt0.json"])
     assert "grounding: 4 videos" in log and "detection recall" in log
     assert os.path.exists(os.path.join(d, "VidORval_predict_relations_aft_grd_raw.json"))
+
+
+def test_eval_vidvrd_cli_on_a_reference_cache_file():
+    """the on-disk cache a user of the reference already has (datasets/cache/*.pkl: pickled instances of the reference's TrajProposal /
+    VideoGraph) through ``tools/eval_vidvrd.py --cache_path``: proposals AND ground truth come from the file, no reference code is imported"""
+    cfg_txt = open(CFG).read().replace("dim_feat=2048", "dim_feat=16").replace("dim_i3d=832", "dim_i3d=8")
+    d = tempfile.mkdtemp()
+    open(d + "/config_.py", "w").write(cfg_txt)
+    log = run([os.path.join(TOOLS, "eval_vidvrd.py"), "--cfg_path", d + "/config_.py", "--output_dir", d, "--save_tag", "c",
+               "--cache_path", os.path.join(ROOT, "tests", "golden", "ref_cache_vidvrd.pkl")])
+    assert "inference: 2 videos" in log and "detection recall" in log

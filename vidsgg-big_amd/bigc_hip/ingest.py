@@ -231,3 +231,74 @@ def load_video_features(video_feature_dir, video_names, device=None):
         f = torch.from_numpy(np.load(os.path.join(video_feature_dir, name + ".npy")))
         out[name] = f.to(device) if device is not None else f
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The on-disk cache users of the reference already have (dataloaders/dataloader_vidvrd.py:170-183, dataloader_vidor_v3.py:229-246):
+# ``datasets/cache/<tag>_VidVRD<split>_th_<m>-<p>-<q>.pkl`` = pickle of {video_name: (TrajProposal, VideoGraph)} holding INSTANCES of the
+# reference's classes.  Read here without the reference on PYTHONPATH: a restricted unpickler maps those class names to plain holders
+# (pickle restores an instance's __dict__ without calling __init__) and nothing else but torch / numpy / builtins is allowed to load.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+
+class _Holder(object):
+    """plain attribute bag a pickled reference object is restored into"""
+
+
+def _restricted_unpickler(f):
+    import pickle
+
+    class U(pickle.Unpickler):
+        def find_class(self, module, name):
+            if name in ("TrajProposal", "VideoGraph") and (module.startswith("dataloaders.") or module in ("__main__", "dataloader_vidvrd", "dataloader_vidor", "dataloader_vidor_v3")):
+                return _Holder
+            root = module.split(".")[0]
+            if root in ("torch", "numpy", "collections", "_codecs") or (root == "builtins" and name in ("dict", "list", "tuple", "set", "frozenset", "int", "float", "str", "bytes", "bool", "complex", "slice", "range", "bytearray", "object")):
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError("the cache holds a %s.%s object: only the reference's TrajProposal / VideoGraph, tensors and arrays are read" % (module, name))
+    return U(f)
+
+
+def proposal_from_reference(h, device=None):
+    """a restored reference ``TrajProposal`` (dataloaders/dataloader_vidvrd.py:14-77, dataloader_vidor_v3.py:19-98) -> this package's
+    block-backed container (one box block + one feature block per video; ``TrajProposal.from_blocks``), optionally on ``device``"""
+    name = getattr(h, "video_name", None)
+    wh = tuple(getattr(h, "video_wh", (1280, 720)))
+    n = int(getattr(h, "num_proposals", 0))
+    if n == 0:
+        return TrajProposal(name, int(getattr(h, "video_len", 0) or 0), wh, [], [], [], [], [])
+    boxes = [torch.as_tensor(b, dtype=torch.float32) for b in h.bboxes_list[:n]]
+    feats = [torch.as_tensor(f, dtype=torch.float32) for f in h.features_list[:n]]
+    dura = torch.as_tensor(h.traj_durations, dtype=torch.long)[:n]
+    lens = [int(b.shape[0]) for b in boxes]
+    assert all(int(f.shape[0]) == l for f, l in zip(feats, lens)) and all(int(dura[i, 1] - dura[i, 0] + 1) == lens[i] for i in range(n))
+    bb, fb = torch.cat(boxes, 0).contiguous(), torch.cat(feats, 0).contiguous()
+    if device is not None:
+        bb, fb = bb.to(device), fb.to(device)
+    video_len = getattr(h, "video_len", None)
+    return TrajProposal.from_blocks(name, int(video_len) if video_len is not None else int(dura[:, 1].max()) + 1, wh, torch.as_tensor(h.cat_ids)[:n],
+                                    torch.as_tensor(h.scores)[:n], dura, lens, bb, fb)
+
+
+def graph_from_reference(h):
+    """a restored reference ``VideoGraph`` (dataloaders/dataloader_vidvrd.py:84-140) -> ``bigc_hip.synthetic.VideoGraph`` (same fields, already
+    in closed-interval form as the reference's constructor left them)"""
+    from .synthetic import VideoGraph
+    return VideoGraph(h.video_name, h.video_len, h.video_wh, h.traj_cat_ids, h.traj_durations, h.traj_bboxes, h.pred_cat_ids, h.pred_durations, h.adj_matrix)
+
+
+def load_reference_cache(path, device=None, with_gt=True):
+    """``datasets/cache/*.pkl`` of the reference -> {video_name: (TrajProposal, VideoGraph or None)} in this package's containers.  VidOR caches
+    made with video features hold 3-tuples (video_feature, proposal, graph) per video: returned as (proposal, graph, video_feature)."""
+    with open(path, "rb") as f:
+        data = _restricted_unpickler(f).load()
+    out = {}
+    for name, item in data.items():
+        item = tuple(item) if isinstance(item, (tuple, list)) else (item,)
+        props = [x for x in item if isinstance(x, _Holder) and hasattr(x, "bboxes_list") or (isinstance(x, _Holder) and getattr(x, "num_proposals", None) == 0)]
+        graphs = [x for x in item if isinstance(x, _Holder) and hasattr(x, "adj_matrix")]
+        feats = [x for x in item if isinstance(x, torch.Tensor)]
+        assert len(props) == 1, "video %s: expected one TrajProposal in the cache entry" % name
+        p = proposal_from_reference(props[0], device)
+        g = graph_from_reference(graphs[0]) if (with_gt and graphs) else None
+        out[name] = (p, g) + ((feats[0],) if feats else ())
+    return out

@@ -28,7 +28,7 @@ from models import BIG_C_vidvrd
 
 
 def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_tag="", use_pku=False, json_results_path=None,
-                        synthetic=0, n_trajs=64, batch_videos=64, tracking_dir=None, i3d_dir=None, gt_json_path=None, video_info_path=None):
+                        synthetic=0, n_trajs=64, batch_videos=64, tracking_dir=None, i3d_dir=None, gt_json_path=None, video_info_path=None, cache_path=None):
     cfg = parse_config_py(cfg_path)
     model_config, infer_config = cfg["model_config"], cfg.get("inference_config", {})
     topk = infer_config.get("topk", 10)
@@ -45,6 +45,13 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
     # its own share (the reference iterates a DataLoader, tools/eval_vidvrd.py:91-121; an 8-GPU node reads the data set once, not 8 times)
     if synthetic:
         data = synthetic_index(model_config, synthetic, n_trajs, seed=1234)
+    elif cache_path:
+        # the reference's own on-disk cache (datasets/cache/*.pkl, dataloaders/dataloader_vidvrd.py:170-183: pickled instances of ITS classes),
+        # read by a restricted unpickler into this package's containers -- no reference code needed
+        from bigc_hip.ingest import load_reference_cache
+        cached = load_reference_cache(cache_path)
+        names = sorted(cached)
+        data = VideoIndex([max(1, sum(cached[n][0]._lens) if cached[n][0].num_proposals else 1) for n in names], lambda i: cached[names[i]][:2], names)
     elif tracking_dir:
         # raw tracking results (one `.npy` of per-box rows per video, PKU format): ingested here, feature rows assembled on the GPU
         import glob
@@ -73,6 +80,7 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
     # does.  Synthetic videos have no JSON: their ground truth comes from the generated graphs, which share the proposals'
     # numbering, so both sides use the standard table.
     pku_names = use_pku and not synthetic
+    cache_gt = bool(cache_path) and not gt_json_path          # a cache carries the videos' ground-truth graphs: used unless a JSON is given
     # this rank's share of the videos, balanced by the number of feature rows (sum of the tracklet lengths), loaded now
     mine, my_data = shard_for_inference(data, data.costs, rank, world)
     t0 = time.time()
@@ -97,7 +105,7 @@ def inference_then_eval(cfg_path, ckpt_path=None, output_dir=None, cuda=0, save_
             # (raw result, prediction entry, ground-truth entry) and never needs the other ranks' proposals
             r = None if r is None else tuple(t.cpu() for t in r)
             pred = E.to_eval_format(p.to(torch.device("cpu")), r, dataset_type="vidvrd", use_pku=pku_names)
-            gt = E.gt_to_eval_format(g, dataset_type="vidvrd") if (g is not None and synthetic) else None
+            gt = E.gt_to_eval_format(g, dataset_type="vidvrd") if (g is not None and (synthetic or cache_gt)) else None
             my_results.append((p.video_name, r, pred, gt))
     torch.cuda.synchronize()
     all_results = gather_results(my_results, mine, len(data), dist)
@@ -142,8 +150,9 @@ if __name__ == "__main__":
     ap.add_argument("--n_trajs", type=int, default=64)
     ap.add_argument("--tracking_dir", type=str, default=None, help="directory of raw per-video tracking-result .npy files (PKU row format)")
     ap.add_argument("--i3d_dir", type=str, default=None, help="matching directory of per-box I3D feature .npy files")
+    ap.add_argument("--cache_path", type=str, default=None, help="a datasets/cache/*.pkl file written by the reference's Dataset (read without the reference on PYTHONPATH)")
     ap.add_argument("--video_info_path", type=str, default=None, help="with --tracking_dir: JSON {video: {video_len, video_wh}} (default: last tracked frame + 1, 1280 x 720)")
     ap.add_argument("--gt_json_path", type=str, default=None, help="ground truth in the evaluator's JSON format (default: datasets/GT_json_for_eval/VidVRDtest_gts.json)")
     a = ap.parse_args()
     inference_then_eval(a.cfg_path, a.ckpt_path, a.output_dir, a.cuda, a.save_tag, a.use_pku, a.json_results_path, a.synthetic, a.n_trajs,
-                        tracking_dir=a.tracking_dir, i3d_dir=a.i3d_dir, gt_json_path=a.gt_json_path, video_info_path=a.video_info_path)
+                        tracking_dir=a.tracking_dir, i3d_dir=a.i3d_dir, gt_json_path=a.gt_json_path, video_info_path=a.video_info_path, cache_path=a.cache_path)

@@ -346,8 +346,8 @@ def run_cache_fixture():
     sys.path.remove(REFERENCE)
     U.fill_zeropadding = lambda vectors: None
     data, expect = {}, {}
-    for vi, name in enumerate(("ingest_pku_i3d", "ingest_pku_i3d_c")):
-        track, i3d, case = cases.make_ingest_case(name)
+    for vi, case in enumerate((cases.INGEST_CASES["ingest_pku_i3d"], dict(cases.INGEST_CASES["ingest_pku_i3d"], seed=907, n_traj=7))):
+        track, i3d, case = cases.make_pku_rows(case)
         d = tempfile.mkdtemp()
         os.makedirs(d + "/prop"); os.makedirs(d + "/i3d")
         np.save(d + "/prop/video_x.npy", track); np.save(d + "/i3d/video_x.npy", i3d)

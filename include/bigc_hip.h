@@ -88,6 +88,11 @@ BIGC_API int bigc_linear_f32(void* stream, const float* A, int lda, const int32_
  * 1 = the exact f32 MFMA kernels.  Initial value from the environment variable
  * BIGC_LINEAR_EXACT.  bigc_linear_set_exact returns the previous mode. */
 BIGC_API int bigc_linear_set_exact(int exact);
+/* Split-K of small-grid GEMMs (csrc/linear_split.hip): allowed on the calling thread while `on` != 0 -- what the training entry points do
+ * for the duration of a step (a launch of at most 128 tiles then splits K over up to eight workgroups per tile and adds the partial tiles
+ * in split order); the eval forwards never allow it, a GEMM's result there must not depend on how many rows share the launch.  Exposed so
+ * that the split and the unsplit form of bigc_linear_f32 can be compared shape by shape (tests/test_hip_ops.py).  Returns the previous state. */
+BIGC_API int bigc_linear_splitk_allow(int on);
 BIGC_API int bigc_linear_get_exact(void);
 /* Opt-in reduced-precision modes of the GEMMs (never the default; also env BIGC_FAST = 1 | f16 | 2 | bf16): fast = 1: operands rounded
  * to ONE f16 each (11-bit mantissa), one f16 MFMA per product instead of three, f32 accumulation; fast = 2: the literal bf16

@@ -107,6 +107,54 @@ def test_linear_gather_segments(lib):
     assert rel_err(got, F.linear(src2[idx1[:, 0]], W2)) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,act,use_res,gather", [
+    (1536, 512, 512, 0, True, False),       # the decoder GEMM of an 8-video training step (48 tiles: splits)
+    (1536, 512, 1024, 1, False, False),     # ReLU applied by the reduction
+    (515, 512, 3160, 0, True, False),       # K tail (3160 = 98 slabs + 24), M not a tile multiple
+    (130, 260, 777, 1, True, False),        # N, M, K all ragged (N % 4 == 0 as the split form needs)
+    (333, 48, 576, 0, False, True),         # gathered operand (3 segments of 192)
+    (64, 1536, 512, 0, False, False),
+])
+def test_linear_split_k_equals_the_unsplit_form_up_to_reassociation(lib, M, N, K, act, use_res, gather):
+    """the split-K path (training steps only: bigc_linear_splitk_allow) had no test of its own.  Same operands through
+    bigc_linear_f32 with and without the scope: equal up to the reassociation of K (partial tiles added in split order), bias / activation /
+    residual applied once by the reduction; and both within 2e-6 of torch."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g) if use_res else None
+    if gather:
+        nseg, seg = 3, K // 3
+        src = torch.randn(90, seg, generator=g)
+        idx = torch.randint(-1, 90, (M, nseg), generator=g)
+        Ag = torch.zeros(M, nseg, seg)
+        for s_ in range(nseg):
+            ok = idx[:, s_] >= 0
+            Ag[ok, s_] = src[idx[ok, s_]]
+        A_full = Ag.reshape(M, -1)
+        kw = dict(idx=i32(idx.numpy()), nseg=nseg, seg_len=seg, M=M)
+        A_dev = dev(src)
+    else:
+        A_full = torch.randn(M, K, generator=g)
+        kw = {}
+        A_dev = dev(A_full)
+    want = F.linear(A_full, W, b)
+    if use_res:
+        want = want + res
+    if act:
+        want = torch.relu(want)
+    plain = run_linear(lib, A_dev, dev(W), dev(b), None if res is None else dev(res), act, **kw)
+    prev = lib.bigc_linear_splitk_allow(1)
+    try:
+        split = run_linear(lib, A_dev, dev(W), dev(b), None if res is None else dev(res), act, **kw)
+    finally:
+        lib.bigc_linear_splitk_allow(prev)
+    assert prev == 0
+    assert rel_err(plain, want) < 2e-6 and rel_err(split, want) < 2e-6
+    assert rel_err(split, plain) < 1e-6
+    assert not torch.isnan(split).any()
+
+
 def test_linear_rejects_bad_shapes(lib):
     A = torch.zeros(4, 6, device=DEV)
     W = torch.zeros(4, 6, device=DEV)

@@ -81,6 +81,7 @@ _SIGS = {
     "bigc_set_accum_policy": (c_int, [c_int]),
     "bigc_get_accum_policy": (c_int, []),
     "bigc_linear_set_exact": (c_int, [c_int]),
+    "bigc_linear_splitk_allow": (c_int, [c_int]),
     "bigc_linear_get_exact": (c_int, []),
     "bigc_linear_set_fast": (c_int, [c_int]),
     "bigc_linear_get_fast": (c_int, []),

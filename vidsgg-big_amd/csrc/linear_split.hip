@@ -776,6 +776,7 @@ void bigc_weight_cache_forget(const float* w) {
 
 thread_local unsigned long long bigc_static_weights_epoch = 0;
 thread_local int bigc_splitk_allowed = 0;
+extern "C" int bigc_linear_splitk_allow(int on) { const int prev = bigc_splitk_allowed; bigc_splitk_allowed = on ? 1 : 0; return prev; }
 unsigned long long bigc_next_weights_epoch() { return ++g_epoch_seq; }
 thread_local std::vector<SplitJob>* bigc_split_recorder = nullptr;
 

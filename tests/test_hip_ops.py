@@ -139,10 +139,10 @@ def test_linear_split_k_equals_the_unsplit_form_up_to_reassociation(lib, M, N, K
         kw = {}
         A_dev = dev(A_full)
     want = F.linear(A_full, W, b)
-    if use_res:
-        want = want + res
     if act:
         want = torch.relu(want)
+    if use_res:
+        want = want + res                       # (the residual is added behind the activation, as in test_linear)
     plain = run_linear(lib, A_dev, dev(W), dev(b), None if res is None else dev(res), act, **kw)
     prev = lib.bigc_linear_splitk_allow(1)
     try:

@@ -387,3 +387,26 @@ def test_lazy_result_list_behaves_like_the_reference_list():
     import pickle
     assert type(pickle.loads(pickle.dumps([None if r is None else tuple(t.cpu() for t in r) for r in res]))) is list
     assert len(copy.copy(res)) == 4 and len(res + [None]) == 5
+
+
+@pytest.mark.gpu
+def test_kept_batch_is_dropped_when_a_step_had_to_be_repeated_on_the_exact_kernels():
+    """a value written in place that leaves the split form's range raises the step's range flag: ``forward`` repeats the step on the exact f32
+    kernels, which read a gathered COPY of the feature rows -- a kept batch that holds such a copy must not serve the next call"""
+    cfg, model = _model("CONFIG_V")
+    width = cfg["dim_feat"] + cfg["dim_i3d"]
+    props = [synthetic_proposal(980 + i, n_trajs=10, feat_width=width, num_enti_cats=cfg["num_enti_cats"], len_range=(10, 30)).to(DEV) for i in range(3)]
+    for _ in range(3):
+        base = model(props, topk=3)
+    kept = model._last_pack["packed"]
+    assert kept is not None and kept._feats is None
+    with torch.no_grad():
+        props[1].features_list[2][0, 5] = 3.0e6                      # outside the f16 pair's range
+    got = model(props, topk=3)
+    assert model.__dict__.get("_last_pack") is None                  # the repeated step gathered f32 rows: batch not kept
+    cfg2, fresh = _model("CONFIG_V")
+    _same_results(got, fresh([p for p in props], topk=3))
+    with torch.no_grad():
+        props[1].features_list[2][0, 5] = 0.25
+    again = model(props, topk=3)                                       # reads the callers' tensors again, not a stale copy
+    _same_results(again, fresh([p for p in props], topk=3))

@@ -110,6 +110,14 @@ class _LazyResults(list):
     remove = _all(list.remove)
     reverse = _all(list.reverse)
     sort = _all(list.sort)
+    append = _all(list.append)                              # (mutators too: entries are placed by index when the list is first read)
+    extend = _all(list.extend)
+    insert = _all(list.insert)
+    clear = _all(list.clear)
+    __setitem__ = _all(list.__setitem__)
+    __delitem__ = _all(list.__delitem__)
+    __iadd__ = _all(list.__iadd__)
+    __imul__ = _all(list.__imul__)
     del _all
     __hash__ = None
 
@@ -302,6 +310,10 @@ class BigcBase(nn.Module):
             return
         if c["packed"] is packed:
             packed.proposals = None                 # (the kept batch must not keep the containers alive)
+            if packed._feats is not None or packed.feats_hr8 is not None:
+                # the step was repeated on the exact kernels (range flag): the batch now holds a COPY of the feature rows, which the next
+                # call would read instead of the callers' tensors -- not kept
+                object.__setattr__(self, "_last_pack", None)
             return
         if not c.get("keep_next"):
             return

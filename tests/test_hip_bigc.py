@@ -93,15 +93,15 @@ def test_bigc_vs_reference_golden(name):
             check_logits(out["pred_logits"].cpu().numpy(), g[pre + "pred_logits"], sd, cfg, variant, p)
             assert np.array_equal(out["soid"].cpu().numpy()[0], g[pre + "att_argmax"])
             continue
-        assert rel(out["enti2enco"].cpu().numpy(), g[pre + "enti2enco"]) < 2e-5
-        assert rel(out["enco_output"].cpu().numpy(), g[pre + "enco_output"]) < 5e-5
-        # pred_query (the last LayerNorm's output) is an intermediate: measured up to 1.2e-4 at N=100 where the logits -- the
-        # contract -- stay within 1e-4
-        assert rel(out["pred_query"].cpu().numpy(), g[pre + "pred_query"]) < 2e-4
-        # att is a double softmax of scores of magnitude ~50 with these seeded weights (att_gain=8):
-        # an fp32-roundoff score difference of 1e-5*|s| moves a probability by up to ~5e-4; it is an
-        # intermediate, the contract is on the logits (1e-4) and on the argmax indices (exact)
-        assert rel(out["att"].cpu().numpy().reshape(2, Q, n), g[pre + "att"]) < 1e-3
+        # intermediates, bounded at ~5 x what is measured (benchmarks/probes/intermediates_vs_golden.py, round 6: the encoder side agrees to
+        # 9e-7 on every case; behind the sharp role attention -- scores of magnitude ~50 with att_gain 8, an f32 round-off of 1e-5 |s| moves a
+        # probability by up to ~5e-4 -- att is within 2.4e-4 and pred_query within 1.05e-4 at full dims (N = 100), 7e-6 / 8e-6 at tiny dims).
+        # The contract is on the logits (1e-4) and on the arg-max indices (exact).
+        tiny = cfg["dim_enti"] <= 64
+        assert rel(out["enti2enco"].cpu().numpy(), g[pre + "enti2enco"]) < 5e-6
+        assert rel(out["enco_output"].cpu().numpy(), g[pre + "enco_output"]) < 5e-6
+        assert rel(out["pred_query"].cpu().numpy(), g[pre + "pred_query"]) < (4e-5 if tiny else 2e-4)
+        assert rel(out["att"].cpu().numpy().reshape(2, Q, n), g[pre + "att"]) < (4e-5 if tiny else 5e-4)
         check_logits(out["pred_logits"].cpu().numpy(), g[pre + "pred_logits"], sd, cfg, variant, p)
         assert np.array_equal(out["soid"].cpu().numpy()[0], g[pre + "att"].argmax(-1))
     # ... and all videos of the case in one batch (cross-video batching must not change anything)

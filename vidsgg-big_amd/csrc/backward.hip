@@ -649,6 +649,39 @@ __global__ __launch_bounds__(1024) void partial_rows_finish_kernel(const float* 
     }
 }
 
+// Several partial-row sets in ONE launch (the LayerNorm parameter gradients of a whole backward pass: 22 finishes of 5 us each otherwise).
+// blockIdx.y = job; same arithmetic per job as partial_rows_finish_kernel.
+constexpr int FINISH_JOBS_MAX = 32;
+struct FinishJob { const float* part; float* out; float* out2; int blocks, w, split; };
+struct FinishJobs { int n; FinishJob job[FINISH_JOBS_MAX]; };
+__global__ __launch_bounds__(1024) void partial_rows_finish_multi_kernel(const FinishJobs js) {
+    const FinishJob& j = js.job[blockIdx.y];
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    if (blockIdx.x * 64 >= j.w) return;                 // (uniform: jobs narrower than the widest)
+    float s = 0.f;
+    if (c < j.w) {
+        int b = g;
+        for (; b + 7 * 16 < j.blocks; b += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = j.part[(size_t)(b + 16 * u) * j.w + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < j.blocks; b += 16) s += j.part[(size_t)b * j.w + c];
+    }
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < j.w) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int u = 1; u < 16; ++u) t += red[u][cl];
+        if (c >= j.split) { if (j.out2) j.out2[c - j.split] += t; }
+        else j.out[c] += t;
+    }
+}
+
 // out[r % period, :] += sum over the rows with that residue (gradients of pos_embedding / pred_query_init)
 __global__ __launch_bounds__(256) void reduce_periodic_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int d, int period) {
     const int total = period * d;
@@ -996,7 +1029,7 @@ extern "C" int bigc_transpose_f32(void* stream, const float* in, float* out, int
 // calling stream.  (the buffers used to be function-static -- two threads driving two devices, which the per-handle
 // arithmetic modes explicitly allow, would have shared one pointer and raced on the regrow.)
 // slots: 0 / 1 weight-gradient partial tiles (single / grouped), 2 column sums, 3 LayerNorm and depth-wise conv parameter partials,
-// 4 the keys of the bias_matrix gradient.  One buffer per (calling thread, device, slot, STREAM): two streams driven from one thread never
+// 4 the keys of the bias_matrix gradient, 5 the deferred LayerNorm partials of a backward pass.  One buffer per (calling thread, device, slot, STREAM): two streams driven from one thread never
 // share partials between a producer and its reduction.
 static int dw_scratch(void* stream, size_t need_floats, int slot, float** out) {
     struct Buf { float* p = nullptr; size_t cap = 0; };
@@ -1021,6 +1054,40 @@ int bigc_ordered_rows_add(hipStream_t s, const float* src, int ld_src, const int
     BIGC_LAUNCH_CHECK("ordered_rows_add");
     return BIGC_OK;
 }
+// Deferred finishes: inside a FinishScope (the BIG-C backward) bigc_layernorm_bwd_f32 does not launch its finish but queues it -- each with its
+// own slice of one scratch -- and bigc_finish_flush adds all queued partial-row sets in one launch (same sums, same order per set).
+namespace {
+struct FinishQueue { bool on = false; FinishJobs jobs; size_t used = 0; float* base = nullptr; size_t cap = 0; };
+thread_local FinishQueue g_fq;
+}
+void bigc_finish_begin(void) { g_fq.on = true; g_fq.jobs.n = 0; g_fq.used = 0; }
+int bigc_finish_flush(hipStream_t s) {
+    FinishQueue& q = g_fq;
+    q.on = false;
+    if (q.jobs.n == 0) return BIGC_OK;
+    int wmax = 0;
+    for (int i = 0; i < q.jobs.n; ++i) wmax = q.jobs.job[i].w > wmax ? q.jobs.job[i].w : wmax;
+    hipLaunchKernelGGL(partial_rows_finish_multi_kernel, dim3(cdiv(wmax, 64), q.jobs.n), dim3(1024), 0, s, q.jobs);
+    q.jobs.n = 0;
+    BIGC_LAUNCH_CHECK("partial_rows_finish_multi");
+    return BIGC_OK;
+}
+// scratch slice for a deferred job (nullptr: not deferring, or the queue / the scratch is full -> the caller finishes at once)
+static float* finish_slice(hipStream_t s, size_t floats) {
+    FinishQueue& q = g_fq;
+    if (!q.on || q.jobs.n >= FINISH_JOBS_MAX) return nullptr;
+    if (!q.base || q.used + floats > q.cap) {
+        if (q.jobs.n > 0 || q.used > 0) return nullptr;          // (never move a scratch that queued jobs point into)
+        float* b = nullptr;
+        const size_t want = floats * 40 > ((size_t)8 << 20) ? floats * 40 : ((size_t)8 << 20);
+        if (dw_scratch((void*)s, want, 5, &b) != BIGC_OK) return nullptr;
+        q.base = b; q.cap = want;
+    }
+    float* p = q.base + q.used;
+    q.used += (floats + 63) & ~(size_t)63;
+    return p;
+}
+
 int bigc_partial_rows_finish(hipStream_t s, const float* part, float* out, float* out2, int blocks, int w, int split) {
     hipLaunchKernelGGL(partial_rows_finish_kernel, dim3(cdiv(w, 64)), dim3(1024), 0, s, part, out, out2, blocks, w, split);
     BIGC_LAUNCH_CHECK("partial_rows_finish");
@@ -1218,8 +1285,10 @@ extern "C" int bigc_layernorm_bwd_f32(void* stream, const float* x, const float*
     if (rows <= 0) return BIGC_OK;
     // every wave takes >= 8 rows (its parameter-gradient partials live in registers): few workgroups, few atomics
     const int grid = cdiv(rows, 32) < 512 ? cdiv(rows, 32) : 512;
-    float* part = nullptr;                  // (grid, 2, d) partial rows: stream-ordered scratch, see dw_scratch
-    if (int rc = dw_scratch(stream, (size_t)grid * 2 * d, 3, &part)) return rc;
+    float* part = finish_slice((hipStream_t)stream, (size_t)grid * 2 * d);      // deferred finish (FinishScope): own slice, one launch for all at the flush
+    const bool deferred = part != nullptr;
+    if (!deferred)                          // (grid, 2, d) partial rows: stream-ordered scratch, see dw_scratch
+        if (int rc = dw_scratch(stream, (size_t)grid * 2 * d, 3, &part)) return rc;
     ProfScope ps(stream, FAM_BACKWARD, 0.0, 12.0 * rows * (double)d);
 #define LN_BWD(NVL) hipLaunchKernelGGL(layernorm_bwd_kernel<NVL>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dx, part, rows, d, eps)
     if (d <= 256) LN_BWD(1);
@@ -1227,7 +1296,12 @@ extern "C" int bigc_layernorm_bwd_f32(void* stream, const float* x, const float*
     else if (d <= 1024) LN_BWD(4);
     else LN_BWD(8);
 #undef LN_BWD
-    hipLaunchKernelGGL(partial_rows_finish_kernel, dim3(cdiv(2 * d, 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)part, dgamma, dbeta, grid, 2 * d, d);
+    if (deferred) {
+        FinishJob& j = g_fq.jobs.job[g_fq.jobs.n++];
+        j.part = part; j.out = dgamma; j.out2 = dbeta; j.blocks = grid; j.w = 2 * d; j.split = d;
+    } else {
+        hipLaunchKernelGGL(partial_rows_finish_kernel, dim3(cdiv(2 * d, 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)part, dgamma, dbeta, grid, 2 * d, d);
+    }
     BIGC_LAUNCH_CHECK("layernorm_bwd");
     return BIGC_OK;
 }

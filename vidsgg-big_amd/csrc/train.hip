@@ -35,6 +35,13 @@ extern "C" int bigc_mha_bwd_f32(void* stream, const float* q, int ldq, const flo
                                 float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                                 const int32_t* q_off, const int32_t* k_off, int n_seq, int max_q, int max_k, long total_q_rows,
                                 int n_head, int hd);
+void bigc_finish_begin(void);                 // backward.hip: deferred partial-row finishes
+int bigc_finish_flush(hipStream_t s);
+struct FinishScope {
+    hipStream_t s;
+    explicit FinishScope(hipStream_t s_) : s(s_) { bigc_finish_begin(); }
+    ~FinishScope() { (void)bigc_finish_flush(s); }
+};
 int bigc_role_attention_bwd_launch(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt,
                                    float* ds, const int32_t* e_off, int n_vid, int nq, int half, float scale, int max_ent);        // attention_bwd.hip
 extern "C" int bigc_role_attention_bwd_f32(void* stream, const float* p2a, int ldp, const float* e2a, int lde, const float* datt,
@@ -495,6 +502,7 @@ extern "C" int bigc_train_forward(bigc_model* m, void* stream, const bigc_batch*
 extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch* b, void* workspace, size_t workspace_bytes,
                                    const float* dlogits, int ldg, const float* datt) {
     SplitKScope splitk;          // small-grid GEMMs of the step may split K (linear_internal.h)
+    FinishScope finishes((hipStream_t)stream);   // the LayerNorm parameter gradients' partial rows are added by ONE launch when the pass is over (backward.hip)
     StaticWeights static_weights(m ? m->epoch : 0);
     ModeScope mode_scope(m ? m->mode_exact : -1, m ? m->mode_fast : -1);
     SplitRecorder recorder(m ? &m->train_jobs : nullptr);

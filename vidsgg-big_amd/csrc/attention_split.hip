@@ -1268,7 +1268,11 @@ __global__ __launch_bounds__(384) void role_fused_lds_kernel(const float* __rest
 // instead of two on two SIMDs and one on the others -- at half the registers.  Same LDS images; score k-slot (g, j) of step s =
 // dimension 32 s + 8 g + j of the role's half; value k-slot (g, j) of step u = entity 32 u + 16 (j >> 2) + 4 g + (j & 3), kept
 // in V^T at position 32 u + 8 g + 4 (j >> 2) + (j & 3).  C[row 4 g + reg][col l15].
-__global__ __launch_bounds__(768) void role_fused_lds16_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
+// NWV = waves per workgroup: 12 (one workgroup per video: every 16-query tile of up to 192 queries) or 4 (three workgroups per video,
+// blockIdx.y picks the tiles 4 y .. 4 y + 3, each workgroup staging the video's entity rows itself: small batches -- at 8 videos eight
+// twelve-wave workgroups left 248 CUs idle for 76 us).  A tile's arithmetic is the same in both forms: a video's bits do not depend on it.
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void role_fused_lds16_kernel(const float* __restrict__ p2a, int ldp, const float* __restrict__ e2a, int lde,
                                                                const float* __restrict__ enco, int ldenc, float* __restrict__ att,
                                                                float* __restrict__ values, const int32_t* __restrict__ e_off,
                                                                int n_vid, int nq, int half, int d, float scale,
@@ -1278,16 +1282,16 @@ __global__ __launch_bounds__(768) void role_fused_lds16_kernel(const float* __re
                                                                unsigned char* __restrict__ vals_s = nullptr, long ldvs = 0, int* __restrict__ range_flag = nullptr) {
     // vals_s != nullptr: the values go out in the split form "hr8" (row pitch ldvs bytes, role r at byte offset 4 r out_role_stride)
     // INSTEAD of f32 -- their only reader is the GEMM of the second role-wise linears -- see mha_core_lds16_kernel
-    constexpr int NTH = 768, PLANE = 32768, DC = 256, NU = 3;      // 2048 staging units of 8 floats over 768 threads
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE + 12 * 1024];      // + 1 KB per wave: the split-form values go out through it
+    constexpr int NTH = 64 * NWV, PLANE = 32768, DC = 256, NU = (2048 + NTH - 1) / NTH;      // 2048 staging units of 8 floats over the workgroup's threads
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE + NWV * 1024];      // + 1 KB per wave: the split-form values go out through it
     unsigned char* const Ph = smem;
     unsigned char* const Pr = smem + PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int vid = blockIdx.x;
     const int e0 = e_off[vid], ne = e_off[vid + 1] - e0;
-    if (ne <= 0) return;
-    const int qt = wave;
+    if (ne <= 0 || (int)blockIdx.y * NWV * 16 >= nq) return;
+    const int qt = (int)blockIdx.y * NWV + wave;
     const bool active = qt * 16 < nq;
     const int qrow = min(qt * 16 + l15, nq - 1);
     const int per_row = half / 8, n_eunits = 64 * per_row, row_bytes = 2 * half, n_step = half / 32;
@@ -1564,8 +1568,14 @@ int bigc_role_fused_h_launch(hipStream_t s, const float* p2a, int ldp, const flo
     const bool projected = role_stride != 0 || vbias0 || relu;      // only the LDS kernel (and the f32 fallback) implement it; the caller checked the shape
     static const int tile16 = getenv("BIGC_ROLE_TILE16") ? atoi(getenv("BIGC_ROLE_TILE16")) : 1;
     if ((use_lds || projected) && n_qt <= 6 && half <= 256 && tile16 && half % 128 == 0) {
-        hipLaunchKernelGGL(role_fused_lds16_kernel, dim3(n_vid), dim3(768), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, half, d,
-                           scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, ldval);
+        // fewer than 128 videos: three four-wave workgroups per video (see the kernel)
+        static const int force_nwv = getenv("BIGC_ROLE_NWV") ? atoi(getenv("BIGC_ROLE_NWV")) : 0;
+        if (force_nwv == 4 || (force_nwv != 12 && n_vid < 128))
+            hipLaunchKernelGGL(role_fused_lds16_kernel<4>, dim3(n_vid, (nq + 63) / 64), dim3(256), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, half, d,
+                               scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, ldval, (unsigned char*)nullptr, 0L, (int*)nullptr);
+        else
+            hipLaunchKernelGGL(role_fused_lds16_kernel<12>, dim3(n_vid), dim3(768), 0, s, p2a, ldp, e2a, lde, enco, ldenc, att, values, e_off, n_vid, nq, half, d,
+                               scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, ldval, (unsigned char*)nullptr, 0L, (int*)nullptr);
         return 1;
     }
     if ((use_lds || projected) && n_qt <= 6 && half <= 256) {
@@ -1647,8 +1657,13 @@ int bigc_role_fused_proj_hr8_launch(hipStream_t s, const float* p2a, int ldp, co
     int* flag = hr8_dummy_flag();
     if (!flag) return 0;
     ProfScope ps((void*)s, FAM_ROLE_ATT, 0.0, 0.0);
-    hipLaunchKernelGGL(role_fused_lds16_kernel, dim3(n_vid), dim3(768), 0, s, p2a, ldp, e2a, lde, rhs, ldrhs, att, (float*)nullptr, e_off, n_vid, nq, half, d,
-                       scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, 0, (unsigned char*)vals_s, ldvs, range_flag);
+    static const int force_nwv = getenv("BIGC_ROLE_NWV") ? atoi(getenv("BIGC_ROLE_NWV")) : 0;
+    if (force_nwv == 4 || (force_nwv != 12 && n_vid < 128))
+        hipLaunchKernelGGL(role_fused_lds16_kernel<4>, dim3(n_vid, (nq + 63) / 64), dim3(256), 0, s, p2a, ldp, e2a, lde, rhs, ldrhs, att, (float*)nullptr, e_off, n_vid, nq, half, d,
+                           scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, 0, (unsigned char*)vals_s, ldvs, range_flag);
+    else
+        hipLaunchKernelGGL(role_fused_lds16_kernel<12>, dim3(n_vid), dim3(768), 0, s, p2a, ldp, e2a, lde, rhs, ldrhs, att, (float*)nullptr, e_off, n_vid, nq, half, d,
+                           scale, flag, run_id, role_stride, vbias0, vbias1, relu, out_role_stride, 0, (unsigned char*)vals_s, ldvs, range_flag);
     return 1;
 }
 

@@ -429,6 +429,7 @@ struct SmallGemmArgs {
     const float* att; const float* dvals; const float* enco; int lde;      // DATT / DENCO
     const float* ds; const float* p2a; int ldp; const float* e2a; int lda;  // DP2A / DE2A
     float* out; int ldo; const int32_t* e_off; int max_rows; int n_cc;
+    int narrow;                                                              // every video has at most 64 columns (role_bgemm_kernel)
 };
 
 // Two of the four products in one launch (blockIdx.y selects): DATT with DENCO and DP2A with DE2A are independent of each other and each
@@ -574,6 +575,211 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallGemmArgs p0,
     }
 }
 
+// ---- the same four per-video products with the operands staged in LDS (round 6) -------------------------------------------------------------
+// small_gemm_kernel above feeds its f32 MFMAs with one 4-byte global load per lane and operand element: 40 load instructions per round of 32
+// MFMAs, a chain of load -> wait -> MFMA rounds on waves that sit alone on their SIMDs (rocprofv3 --pmc at 8 videos: 71 % of the wave cycles
+// waiting, matrix pipe 14 % busy; more loads in flight or more workgroups did not change that).  Here a workgroup (four waves) owns a 32-row x
+// BN-column tile of C and walks K in slabs of KS: the 32 x KS slab of A and the BN x KS slab of B go to LDS through coalesced 16-byte global
+// loads -- along k where k is contiguous in memory (dvals / enco rows in DATT, ds rows in DP2A), along the row index where that is (att^T,
+// ds^T, dvals, e2a, p2a) -- the next slab's loads in flight (registers) while the current one multiplies.  What bounds these launches at training sizes
+// is the chain of global-load round trips of a workgroup that is alone on its CU, so the slabs are deep: 64 k for 128-column tiles (wave w
+// multiplies columns 32 w .. 32 w + 31), 128 k for tiles of at most 64 live columns (DATT: the video's entities; wave pairs split each slab's
+// k and add their halves through LDS at the end).  DATT's K = 512 is four round trips instead of sixteen 32-k rounds.  Exact f32 arithmetic
+// as before (gradients of any magnitude, no range flag); the order of the K sum differs from the wave-split form above.
+constexpr int BG_LDS_FLOATS = (32 + 64) * (128 + 4);     // the largest of the forms below (DATT, 64-column tiles)
+template <int BN, int KS, bool A_KC, bool B_KC>
+__device__ __forceinline__ void role_bgemm_body(const float* A, const float* B, float* C, int m, int n, int kdim, int sa_i, int sa_k, int sb_k,
+                                                int sb_j, int sc_i, int n_pass, size_t a_pass, size_t b_pass, bool accumulate, int i0, int j0,
+                                                float* lds) {
+    // LDS images: an operand whose k is contiguous in memory is kept as rows of KS k (pitch KS + 4 floats: the MFMA loop reads 16 bytes = four k
+    // per lane, lane = row), one whose row index is contiguous as KS rows of 32 / BN row values (the loop reads 4 bytes per
+    // lane and k); either way a staging item is 16 contiguous bytes of memory and of LDS.
+    // (the 4-byte reads take k and k + 1 in the two half-waves: pitches of 32 mod 64 floats keep them on different banks)
+    constexpr int PA = A_KC ? KS + 4 : 32, PB = B_KC ? KS + 4 : BN + 32;
+    constexpr int A_FLOATS = A_KC ? 32 * PA : KS * PA;
+    static_assert(A_FLOATS + (B_KC ? BN : KS) * PB <= BG_LDS_FLOATS, "role_bgemm: LDS");
+    constexpr int NA = 32 * KS / 4 / 256, NB = BN * KS / 4 / 256;          // staging items per thread
+    constexpr int QA = A_KC ? KS / 4 : 8, QB = B_KC ? KS / 4 : BN / 4;     // 16-byte items per LDS row
+    constexpr bool KSPLIT = BN == 64;
+    float* As = lds;
+    float* Bs = lds + A_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ncols = min(BN, n - j0);
+    const int nb = KSPLIT ? (wave & 1) : wave;                // this wave's 32-column block
+    const int kh = KSPLIT ? (wave >> 1) : 0;                  // and (64-column tiles) its half of every slab's k
+    const bool active = nb * 32 < ncols;
+    const bool a_vec = ((A_KC ? sa_i : sa_k) & 3) == 0 && (((uintptr_t)A) & 15) == 0 && (a_pass & 3) == 0;
+    const bool b_vec = ((B_KC ? sb_j : sb_k) & 3) == 0 && (((uintptr_t)B) & 15) == 0 && (b_pass & 3) == 0;
+    const int spp = (kdim + KS - 1) / KS, n_slab = n_pass * spp;
+    f32x4 pa[NA], pb[NB];
+    // 16 bytes of an operand: KC = row `r`, k0 .. k0 + 3; else k = `k`, rows r0 .. r0 + 3 (r_lim rows, stride_o = the other index's stride)
+    auto fetch_kc = [&](const float* base, int r, int r_lim, int stride_r, bool vec, int k0) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r >= r_lim || k0 >= kdim) return v;
+        const float* src = base + (size_t)r * stride_r + k0;
+        if (vec && k0 + 4 <= kdim) {
+            v = *(const f32x4*)src;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (k0 + c < kdim) v[c] = src[c];
+        }
+        return v;
+    };
+    auto fetch_rc = [&](const float* base, int r0, int r_lim, int stride_k, bool vec, int k) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 >= r_lim || k >= kdim) return v;
+        const float* src = base + (size_t)k * stride_k + r0;
+        if (vec && r0 + 4 <= r_lim) {
+            v = *(const f32x4*)src;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (r0 + c < r_lim) v[c] = src[c];
+        }
+        return v;
+    };
+    auto fetch = [&](int sl) {
+        const int pass = sl / spp, k0 = (sl - pass * spp) * KS;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int id = tid + 256 * u;
+            if (A_KC) pa[u] = fetch_kc(A + pass * a_pass, i0 + id / QA, m, sa_i, a_vec, k0 + 4 * (id % QA));
+            else pa[u] = fetch_rc(A + pass * a_pass, i0 + 4 * (id % QA), m, sa_k, a_vec && (i0 & 3) == 0, k0 + id / QA);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int id = tid + 256 * u;
+            if (B_KC) pb[u] = fetch_kc(B + pass * b_pass, j0 + id / QB, n, sb_j, b_vec, k0 + 4 * (id % QB));
+            else pb[u] = fetch_rc(B + pass * b_pass, j0 + 4 * (id % QB), n, sb_k, b_vec, k0 + id / QB);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int id = tid + 256 * u;
+            *(f32x4*)(&As[(id / QA) * PA + 4 * (id % QA)]) = pa[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int id = tid + 256 * u;
+            *(f32x4*)(&Bs[(id / QB) * PB + 4 * (id % QB)]) = pb[u];
+        }
+    };
+    f32x16 acc = zero16();
+    fetch(0);
+    for (int sl = 0; sl < n_slab; ++sl) {
+        stash();
+        __syncthreads();
+        if (sl + 1 < n_slab) fetch(sl + 1);
+        if (active) {
+            constexpr int QW = KSPLIT ? KS / 8 : KS / 4;      // k-quads this wave multiplies per slab
+            const int q0 = kh * QW;
+            const int bc = nb * 32 + l31;
+#pragma unroll
+            for (int qq = 0; qq < QW; ++qq) {
+                const int k = 4 * (q0 + qq);
+                float a0, a1, b0, b1;
+                if (A_KC) {
+                    const f32x4 a4 = *(const f32x4*)(&As[l31 * PA + k]);
+                    a0 = hi ? a4[1] : a4[0]; a1 = hi ? a4[3] : a4[2];
+                } else {
+                    a0 = As[(k + hi) * PA + l31]; a1 = As[(k + 2 + hi) * PA + l31];
+                }
+                if (B_KC) {
+                    const f32x4 b4 = *(const f32x4*)(&Bs[bc * PB + k]);
+                    b0 = hi ? b4[1] : b4[0]; b1 = hi ? b4[3] : b4[2];
+                } else {
+                    b0 = Bs[(k + hi) * PB + bc]; b1 = Bs[(k + 2 + hi) * PB + bc];
+                }
+                acc = mfma32(a0, b0, acc);
+                acc = mfma32(a1, b1, acc);
+            }
+        }
+        __syncthreads();
+    }
+    if (KSPLIT) {                                             // the second k-half's tile through LDS (the staging rows are free now)
+        float* red = lds;                                     // [2 column blocks][16][64]
+        if (kh == 1 && active) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(nb * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (kh == 1 || !active) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[(nb * 16 + r) * 64 + lane];
+    } else if (!active) {
+        return;
+    }
+    const int j = j0 + nb * 32 + l31;
+    if (j >= n) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = i0 + mfma_row(r, hi);
+        if (i >= m) continue;
+        float* cp = C + (size_t)i * sc_i + j;
+        *cp = accumulate ? *cp + acc[r] : acc[r];
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void role_bgemm_kernel(const SmallGemmArgs p0, const SmallGemmArgs p1) {
+    const SmallGemmArgs& p = blockIdx.y ? p1 : p0;
+    __shared__ __attribute__((aligned(16))) float lds[BG_LDS_FLOATS];
+    const int n_role = p.mode == SG_DENCO ? 1 : 2;
+    const int n_rt = (p.max_rows + 31) / 32;
+    const int n_cc = p.n_cc;
+    const long item = blockIdx.x;
+    if (item >= (long)p.n_vid * n_role * n_rt * n_cc) return;
+    const int cc = item % n_cc;
+    const int rt = (item / n_cc) % n_rt;
+    const int role = (item / ((long)n_cc * n_rt)) % n_role;
+    const int vid = item / ((long)n_cc * n_rt * n_role);
+    const int e0 = p.e_off[vid], ne = p.e_off[vid + 1] - e0;
+    if (ne <= 0) return;
+    const int nq = p.nq;
+    const size_t abase = (size_t)2 * nq * e0;
+    // C is m x n, reduction length kdim; element strides of A (i,k), B (k,j) and C rows; pass strides of DENCO's two roles
+    int m, n, kdim, sa_i, sa_k, sb_k, sb_j, sc_i, n_pass = 1;
+    size_t a_pass = 0, b_pass = 0;
+    const float *A, *B;
+    float* C;
+    bool accumulate = false;
+    if (p.mode == SG_DATT) {
+        m = nq; n = ne; kdim = p.d;
+        A = p.dvals + ((size_t)role * p.n_vid * nq + (size_t)vid * nq) * p.lde; sa_i = p.lde; sa_k = 1;
+        B = p.enco + (size_t)e0 * p.lde; sb_k = 1; sb_j = p.lde;
+        C = p.out + abase + (size_t)role * nq * ne; sc_i = ne;
+    } else if (p.mode == SG_DENCO) {
+        m = ne; n = p.d; kdim = nq; n_pass = 2; accumulate = true;
+        A = p.att + abase; sa_i = 1; sa_k = ne; a_pass = (size_t)nq * ne;
+        B = p.dvals + (size_t)vid * nq * p.lde; sb_k = p.lde; sb_j = 1; b_pass = (size_t)p.n_vid * nq * p.lde;
+        C = p.out + (size_t)e0 * p.ldo; sc_i = p.ldo;
+    } else if (p.mode == SG_DP2A) {
+        m = nq; n = p.half; kdim = ne;
+        A = p.ds + abase + (size_t)role * nq * ne; sa_i = ne; sa_k = 1;
+        B = p.e2a + (size_t)e0 * p.lda + role * p.half; sb_k = p.lda; sb_j = 1;
+        C = p.out + (size_t)vid * nq * p.ldo + role * p.half; sc_i = p.ldo;
+    } else {
+        m = ne; n = p.half; kdim = nq;
+        A = p.ds + abase + (size_t)role * nq * ne; sa_i = 1; sa_k = ne;
+        B = p.p2a + (size_t)vid * nq * p.ldp + role * p.half; sb_k = p.ldp; sb_j = 1;
+        C = p.out + (size_t)e0 * p.ldo + role * p.half; sc_i = p.ldo;
+    }
+    const int i0 = rt * 32, j0 = cc * 128;
+    if (i0 >= m || j0 >= n) return;                          // (uniform over the workgroup)
+#define BG_ARGS A, B, C, m, n, kdim, sa_i, sa_k, sb_k, sb_j, sc_i, n_pass, a_pass, b_pass, accumulate, i0, j0, lds
+    if (p.mode == SG_DATT) {
+        if (p.narrow) role_bgemm_body<64, 128, true, true>(BG_ARGS);
+        else role_bgemm_body<128, 64, true, true>(BG_ARGS);
+    } else if (p.mode == SG_DP2A) {
+        role_bgemm_body<128, 64, true, false>(BG_ARGS);
+    } else {
+        role_bgemm_body<128, 64, false, false>(BG_ARGS);
+    }
+#undef BG_ARGS
+}
+
 int grid_for(long n, int cap = 4096) { long g = (n + 255) / 256; return (int)(g < cap ? (g < 1 ? 1 : g) : cap); }
 
 }  // namespace
@@ -686,7 +892,16 @@ long small_gemm_args(SmallGemmArgs& p, int mode, const float* att_or_ds, const f
     else { rows = max_trk; cols = half; n_role = 2; }
     p.max_rows = rows;
     p.n_cc = cdiv(cols, 128);
+    p.narrow = cols <= 64;
     return (long)n_vid * n_role * cdiv(rows, 32) * p.n_cc;
+}
+}  // namespace
+
+namespace {
+void role_bgemm_launch(hipStream_t s, const SmallGemmArgs& p0, const SmallGemmArgs& p1, long items, int ny) {
+    static const bool lds_off = getenv("BIGC_SG_LDS") && atoi(getenv("BIGC_SG_LDS")) == 0;
+    if (lds_off) hipLaunchKernelGGL(small_gemm_kernel, dim3((int)items, ny), dim3(256), 0, s, p0, p1);
+    else hipLaunchKernelGGL(role_bgemm_kernel, dim3((int)items, ny), dim3(256), 0, s, p0, p1);
 }
 }  // namespace
 
@@ -699,7 +914,7 @@ extern "C" int bigc_role_small_gemm_f32(void* stream, int mode, const float* att
     SmallGemmArgs p;
     const long items = small_gemm_args(p, mode, att_or_ds, dvals_or_p2a, ld1, enco_or_e2a, ld2, out, ldo, e_off, n_vid, nq, d, half, max_trk);
     ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((int)items, 1), dim3(256), 0, (hipStream_t)stream, p, p);
+    role_bgemm_launch((hipStream_t)stream, p, p, items, 1);
     BIGC_LAUNCH_CHECK("role_small_gemm");
     return BIGC_OK;
 }
@@ -722,7 +937,7 @@ extern "C" int bigc_role_small_gemm_pair_f32(void* stream, int pair, const float
         i1 = small_gemm_args(p1, SG_DE2A, x, y, ld_y, nullptr, 0, out_b, ldo_b, e_off, n_vid, nq, d, half, max_trk);
     }
     ProfScope ps(stream, FAM_ATTN_BWD, 0.0, 0.0);
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((int)(i0 > i1 ? i0 : i1), 2), dim3(256), 0, (hipStream_t)stream, p0, p1);
+    role_bgemm_launch((hipStream_t)stream, p0, p1, i0 > i1 ? i0 : i1, 2);
     BIGC_LAUNCH_CHECK("role_small_gemm_pair");
     return BIGC_OK;
 }

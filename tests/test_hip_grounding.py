@@ -336,7 +336,9 @@ def test_encoder_chain_out_of_range_operands_fall_back_to_f32():
         for key in ("video_enc", "query_enc", "combined_enc", "regrs", "conf", "cls"):
             g, w = got[key].cpu(), want[key].cpu()
             assert not torch.isnan(g).any() and not torch.isnan(w).any(), (case, key)
-            assert float((g - w).abs().max()) <= 2e-4 * max(float(w.abs().max()), 1e-6), (case, key, float((g - w).abs().max()), float(w.abs().max()))
+            # (3e-4 of the largest magnitude: the out-of-range weight of `huge_weight` amplifies the f32 rounding of two different summation
+            # orders -- the fallback's sequential FMAs against the exact mode's f32 MFMA -- 5e4-fold before the heads' sigmoids)
+            assert float((g - w).abs().max()) <= 3e-4 * max(float(w.abs().max()), 1e-6), (case, key, float((g - w).abs().max()), float(w.abs().max()))
 
 
 def test_encoder_chain_rows_do_not_depend_on_their_tile():
@@ -355,3 +357,42 @@ def test_encoder_chain_rows_do_not_depend_on_their_tile():
         o = outs[order.index(0)]
         for key in ("pooled_se", "bins_probs", "bins_mask"):
             assert torch.equal(o[key], alone[key]), (order, key)
+
+
+_ENV_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.environ["BIGC_REPO"], "tests")); sys.path.insert(0, os.path.join(os.environ["BIGC_REPO"], "tests", "golden"))
+import test_hip_grounding as T, cases
+cfg = dict(cases.GRD_CASES["grd_g_n64"]["cfg"])
+_, sd, _ = cases.make_grd_case("grd_g_n64")
+model = T.build_model(dict(cfg, loss_factor=dict(classification=1.0, centerness=1.0, regression=1.0)), sd)
+out = {}
+for v, (Tn, n) in enumerate([(61, 7), (138, 11), (97, 30)]):
+    feat, (quint, dura, vl) = cases.make_grd_inputs(cfg, dict(seed=800 + v, T=Tn, n=n, video_len=8 * Tn - 3))
+    o = model.forward_raw(feat.to(T.DEV), quint, dura, vl, keep_intermediates=True, **cases.GRD_TH)
+    for k in ("video_enc", "query_enc", "combined_enc", "regrs", "conf", "cls", "pooled_se", "bins_probs", "bins_mask"):
+        out["%d_%s" % (v, k)] = o[k].cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_query_encoder_stream_and_fused_in_proj_against_the_plain_sequence():
+    """Round 6: the query encoder runs on a second stream beside the video encoder (fork / join by events), and the attention's in_proj runs
+    inside the encoder chain kernel.  One stream (BIGC_GRD_STREAMS=0) must give the same BITS; the in_proj as a GEMM of its own
+    (BIGC_ENC_QKV=0: another summation order) the same values to the f32 level."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tempfile.mkdtemp()
+    res = {}
+    for tag, env in (("default", {}), ("one_stream", {"BIGC_GRD_STREAMS": "0"}), ("plain_in_proj", {"BIGC_ENC_QKV": "0"})):
+        path = os.path.join(d, tag + ".npz")
+        e = dict(os.environ, BIGC_REPO=repo, **env)
+        r = subprocess.run([sys.executable, "-c", _ENV_SCRIPT, path], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = dict(np.load(path))
+    for k, v in res["default"].items():
+        assert np.array_equal(v, res["one_stream"][k], equal_nan=True), k
+        if v.dtype == np.bool_:
+            continue
+        assert rel(res["plain_in_proj"][k], v) < 5e-5, (k, rel(res["plain_in_proj"][k], v))

@@ -572,6 +572,7 @@ struct GWork {
     float *b0, *b1, *b2, *b3, *qkv, *att, *venc, *qenc, *proj, *qin, *comb, *regrs, *conf, *cls, *info;
     int32_t* off;
     int2 *vinfo, *cinfo;      // several videos per call: (position, length) of every video row / every combined row
+    float *q_b[4], *q_qkv, *q_att; int32_t* q_off;     // the query encoder's own scratch (3n rows): it runs beside the video encoder on a second stream
 };
 
 // total_T = sum of the videos' clip counts, total_rows = sum over queries of their video's clip count (one video: T and n*T)
@@ -595,6 +596,10 @@ bool glayout(const grd_model* m, long total_T, int n, long total_rows, bool ragg
     w.off = a.take<int32_t>(rows + 2);
     w.vinfo = ragged ? a.take<int2>((size_t)total_T) : nullptr;
     w.cinfo = ragged ? a.take<int2>((size_t)total_rows) : nullptr;
+    for (int i = 0; i < 4; ++i) w.q_b[i] = a.take<float>((size_t)3 * n * d);
+    w.q_qkv = a.take<float>((size_t)3 * n * 3 * d);
+    w.q_att = a.take<float>((size_t)3 * n * d);
+    w.q_off = a.take<int32_t>((size_t)n + 2);
     return !a.overflow;
 }
 
@@ -656,9 +661,11 @@ int qanet(void* s, grd_model* m, int which, const Enc& E, const float* x, const 
         // the convolution stack in one launch and the two GEMMs behind the attention in another (csrc/grounding_encoder.hip)
         if (!m->enc_frag[which] && hipMalloc(&m->enc_frag[which], grd_enc_frag_bytes()) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_forward: hipMalloc failed");
         const bool refresh = m->enc_frag_epoch[which] != m->epoch;
-        GTRY(grd_enc_chain((hipStream_t)s, E, x, pos, q.rows, q.T, q.info, m->enc_frag[which], refresh, res, ln));
+        // (the attention's packed in_proj runs inside the chain kernel on the normalised tile: BIGC_ENC_QKV=0 = as a GEMM of its own)
+        static const bool qkv_off = getenv("BIGC_ENC_QKV") && atoi(getenv("BIGC_ENC_QKV")) == 0;
+        GTRY(grd_enc_chain((hipStream_t)s, E, x, pos, q.rows, q.T, q.info, m->enc_frag[which], refresh, res, ln, qkv_off ? nullptr : w.qkv));
         m->enc_frag_epoch[which] = m->epoch;
-        GTRY(glinear(s, ln, d, E.in_proj, w.qkv, 3 * d, rows, 3 * d, d, BIGC_ACT_NONE));
+        if (qkv_off) GTRY(glinear(s, ln, d, E.in_proj, w.qkv, 3 * d, rows, 3 * d, d, BIGC_ACT_NONE));
         const int32_t* off = q.off;
         if (!q.info) { GTRY(bigc_fill_offsets((hipStream_t)s, w.off, q.n_seq + 1, q.T)); off = w.off; }
         bigc_prof_hint(4.0 * (double)rows * ((double)rows / q.n_seq) * d, 16.0 * rows * (double)d);
@@ -747,35 +754,68 @@ int forward_impl(grd_model* m, void* stream, const float* video_feat, int T, con
         sv.info = w.vinfo; sc.info = w.cinfo;
     }
 
+    // The query side (a12 + the query encoder: 3n rows, ~10 launches that each fill a fraction of the chip) and the video side (video_fc + the
+    // video encoder: total_T rows, the same) do not depend on each other until the co-attention: the query side goes to a second stream of
+    // the model's, forked from and joined back into the caller's stream by events (BIGC_GRD_STREAMS=0: one stream), with its own scratch.
+    static const bool streams_off = getenv("BIGC_GRD_STREAMS") && atoi(getenv("BIGC_GRD_STREAMS")) == 0;
+    bool two = !streams_off;
+    if (two && !m->side_stream) {
+        hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess)
+            return bigc_fail(BIGC_ERR_HIP, "grd_forward: could not create the query encoder's stream");
+        m->side_stream = st; m->ev_fork = e0; m->ev_join = e1;
+    }
+    hipStream_t qhs = two ? (hipStream_t)m->side_stream : hs;
+    void* qs = (void*)qhs;
+    if (two) {
+        if (hipEventRecord((hipEvent_t)m->ev_fork, hs) != hipSuccess || hipStreamWaitEvent(qhs, (hipEvent_t)m->ev_fork, 0) != hipSuccess)
+            return bigc_fail(BIGC_ERR_HIP, "grd_forward: stream fork failed");
+    }
     // a12: prepare_data (:310-328) fused with query_fc + temp_fc (:337-339)
-    hipLaunchKernelGGL(query_input_kernel, dim3(grid_for((long)3 * n * m->kq)), dim3(256), 0, hs, m->enti, m->pred, quint, dura, video_len,
+    hipLaunchKernelGGL(query_input_kernel, dim3(grid_for((long)3 * n * m->kq)), dim3(256), 0, qhs, m->enti, m->pred, quint, dura, video_len,
                        q_vid, vid_len, w.qin, n, c.dim_clsme, m->kq);
     BIGC_LAUNCH_CHECK("query_input");
     hipLaunchKernelGGL(span_info_kernel, dim3(cdiv(2 * n, 256)), dim3(256), 0, hs, dura, video_len, q_vid, vid_len, w.info, 2 * n);
     BIGC_LAUNCH_CHECK("span_info");
     Lin qlin{m->wq, m->bq};
     float* qemb = w.comb;                         // (3n, d) scratch, comb is free until the co-attention
-    GTRY(glinear(s, w.qin, m->kq, qlin, qemb, d, 3 * n, d, m->kq, BIGC_ACT_NONE));
+    GTRY(glinear(qs, w.qin, m->kq, qlin, qemb, d, 3 * n, d, m->kq, BIGC_ACT_NONE));
     float* vemb = w.comb + (size_t)3 * n * d;     // (total_T, d)
     GTRY(glinear(s, video_feat, c.dim_feat, m->video_fc, vemb, d, (int)total_T, d, c.dim_feat, BIGC_ACT_NONE));
 
     // a13: the two encoders, co-attention, fusion, combined encoder, three heads (:341-372)
     float* venc = out->video_enc ? out->video_enc : w.venc;
     float* qenc = out->query_enc ? out->query_enc : w.qenc;
+    GWork wq = w;
+    wq.b0 = w.q_b[0]; wq.b1 = w.q_b[1]; wq.b2 = w.q_b[2]; wq.b3 = w.q_b[3]; wq.qkv = w.q_qkv; wq.att = w.q_att; wq.off = w.q_off;
+    GTRY(qanet(qs, m, 1, m->query_enc, qemb, pos_query, sq, d, wq, qenc));
     GTRY(qanet(s, m, 0, m->video_enc, vemb, pos_video, sv, d, w, venc));
-    GTRY(qanet(s, m, 1, m->query_enc, qemb, pos_query, sq, d, w, qenc));
-    GTRY(glinear(s, venc, d, m->proj2sim, w.proj, d, (int)total_T, d, d, BIGC_ACT_NONE));
-    if (!b) {
-        GTRY(grd_coattention_f32(s, venc, w.proj, qenc, w.comb, n, T, d));
-    } else {
-        BIGC_CHECK_ARG(max_T <= 2048 && d <= 256, "grd_forward_batch: max_T=%d (<=2048) d=%d (<=256)", max_T, d);
-        const size_t lds = sizeof(float) * (6 * (size_t)d + 6 * (size_t)max_T + 4);
-        ProfScope ps(stream, FAM_GROUNDING, 0.0, 16.0 * total_rows * (double)d);
-        hipLaunchKernelGGL(coattention_kernel, dim3(n), dim3(256), lds, hs, venc, w.proj, qenc, w.comb, max_T, d, q_vid, b->vid_row_off, b->q_row_off);
-        BIGC_LAUNCH_CHECK("coattention");
+    if (two) {
+        if (hipEventRecord((hipEvent_t)m->ev_join, qhs) != hipSuccess || hipStreamWaitEvent(hs, (hipEvent_t)m->ev_join, 0) != hipSuccess)
+            return bigc_fail(BIGC_ERR_HIP, "grd_forward: stream join failed");
     }
+    GTRY(glinear(s, venc, d, m->proj2sim, w.proj, d, (int)total_T, d, d, BIGC_ACT_NONE));
     float* cin = w.att;                           // (rows, d) free between qanet calls
-    GTRY(glinear(s, w.comb, 4 * d, m->vq_fc, cin, d, (int)total_rows, d, 4 * d, BIGC_ACT_NONE));
+    if (grd_coatt_fc_supported(d, max_T)) {
+        // co-attention + vq_fc in one launch (csrc/grounding_encoder.hip): the (rows, 4 d) fusion tensor is never written
+        if (!m->vq_frag && hipMalloc(&m->vq_frag, grd_vq_frag_bytes()) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_forward: hipMalloc failed");
+        const bool refresh = m->vq_frag_epoch != m->epoch;
+        GTRY(grd_coatt_fc(hs, venc, w.proj, qenc, m->vq_fc, cin, n, T, max_T, total_rows, q_vid, b ? b->vid_row_off : nullptr, b ? b->q_row_off : nullptr,
+                          m->vq_frag, refresh));
+        m->vq_frag_epoch = m->epoch;
+    } else {
+        if (!b) {
+            GTRY(grd_coattention_f32(s, venc, w.proj, qenc, w.comb, n, T, d));
+        } else {
+            BIGC_CHECK_ARG(max_T <= 2048 && d <= 256, "grd_forward_batch: max_T=%d (<=2048) d=%d (<=256)", max_T, d);
+            const size_t lds = sizeof(float) * (6 * (size_t)d + 6 * (size_t)max_T + 4);
+            ProfScope ps(stream, FAM_GROUNDING, 0.0, 16.0 * total_rows * (double)d);
+            hipLaunchKernelGGL(coattention_kernel, dim3(n), dim3(256), lds, hs, venc, w.proj, qenc, w.comb, max_T, d, q_vid, b->vid_row_off, b->q_row_off);
+            BIGC_LAUNCH_CHECK("coattention");
+        }
+        GTRY(glinear(s, w.comb, 4 * d, m->vq_fc, cin, d, (int)total_rows, d, 4 * d, BIGC_ACT_NONE));
+    }
     float* cenc = out->combined_enc ? out->combined_enc : w.comb;     // comb (rows*4d) is free again
     // qanet reads its input into b0 first, and w.att is only rewritten by the attention step, after
     // the input has been consumed
@@ -834,6 +874,10 @@ extern "C" void grd_destroy(grd_model* m) {
     if (m->wq) (void)hipFree(m->wq);
     if (m->bq) (void)hipFree(m->bq);
     if (m->head_frag) (void)hipFree(m->head_frag);
+    if (m->vq_frag) (void)hipFree(m->vq_frag);
+    if (m->ev_fork) (void)hipEventDestroy((hipEvent_t)m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy((hipEvent_t)m->ev_join);
+    if (m->side_stream) (void)hipStreamDestroy((hipStream_t)m->side_stream);
     for (int i = 0; i < 3; ++i) if (m->enc_frag[i]) (void)hipFree(m->enc_frag[i]);
     delete m;
 }

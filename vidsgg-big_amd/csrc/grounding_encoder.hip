@@ -23,6 +23,7 @@
 #include "prof.h"
 #include <stdlib.h>
 #include <atomic>
+#include <mutex>
 
 typedef _Float16 a16x8 __attribute__((ext_vector_type(8)));
 
@@ -31,7 +32,7 @@ namespace {
 constexpr int EC_D = 128, EC_CR = 64;
 constexpr int EC_XP = 132;                  // pitch (floats) of the f32 activation tile
 constexpr int EC_AP = 272;                  // pitch (bytes) of a row of a split plane: 128 f16 + 16
-constexpr int EC_LAYERS = 6;                // 4 point-wise convolutions, out_proj, fc
+constexpr int EC_LAYERS = 9;                // 4 point-wise convolutions, out_proj, fc, and the attention's in_proj as three 128 x 128 blocks (q, k, v)
 constexpr float EC_RS = 2048.0f, EC_RI = 1.0f / 2048.0f, EC_LIM = 32768.0f;
 constexpr long EC_FRAG_ELEMS = (long)EC_LAYERS * 4 * 8 * 2 * 64;            // a16x8 elements per encoder
 
@@ -43,6 +44,7 @@ struct EncChainArgs {
     const float* dw_w[4]; const float* dw_b[4];
     const float* pw_w[EC_LAYERS]; const float* pw_b[EC_LAYERS];
     float* out; float* ln_out; float eps;
+    float* qkv_out;                                       // (rows, 384): in_proj(LayerNorm_4(out)) instead of ln_out (chain kernel)
 };
 
 __device__ __forceinline__ bool ec_bad4(const f32x4 v) {
@@ -100,13 +102,15 @@ __device__ __forceinline__ void ec_load_w(const a16x8* frag, int layer, int wave
 }
 
 // acc[i] (feature 32 fb + mfma_row(r, hi), data row 32 (rb0 + i) + l31) = sum_k W[feature][k] act[row][k]: NRB 32-row blocks in one sweep over k
-template <int NRB>
+template <int NRB, bool ZERO = true>
 __device__ __forceinline__ void ec_mm(const unsigned char* Ah, const unsigned char* Ar, const a16x8 (&w)[16], int rb0, int l31, int hi,
                                       f32x16 (&acc0)[NRB], f32x16 (&acc1)[NRB]) {
+    if (ZERO) {
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[rb][r] = 0.f; acc1[rb][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { acc0[rb][r] = 0.f; acc1[rb][r] = 0.f; }
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
@@ -300,14 +304,16 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void grd_enc_chain_kernel(const En
             }
         }
         __syncthreads();
-        ec_pointwise<EXACT, NW>(a, S, layer, wcur, layer < 3 ? layer + 1 : -1, tid, [&](int row, int nn0, const f32x4 v) {
+        ec_pointwise<EXACT, NW>(a, S, layer, wcur, layer < 3 ? layer + 1 : (a.qkv_out ? 6 : -1), tid, [&](int row, int nn0, const f32x4 v) {
             f32x4* xp = (f32x4*)(S.X + row * EC_XP + nn0);
             *xp = ec_relu(v) + *xp;                              // relu(conv) + res  (:130-131)
         });
         __syncthreads();
     }
 
-    // ---- the tile's exact rows: `out` and LayerNorm_4(out) (the attention's input, :132)
+    // ---- the tile's exact rows: `out` and LayerNorm_4(out) (the attention's input, :132) -- or, with qkv_out, the attention's in_proj on
+    // the normalised tile right here (:132-133, nn.MultiheadAttention's packed projection): the normalised tensor is neither written nor
+    // read back, q / k / v leave through the tile as whole rows
     ec_stats(S, tid, a.eps);
     __syncthreads();
     {
@@ -316,14 +322,43 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void grd_enc_chain_kernel(const En
         for (int rr = 0; rr < RPG; ++rr) {
             const int row = rg + NG * rr;
             const long g = g0 + row;
-            if (row < HALO || row >= EC_CR - HALO || g < 0 || g >= a.rows) continue;
+            const bool own = !(row < HALO || row >= EC_CR - HALO || g < 0 || g >= a.rows);
+            if (!own && !a.qkv_out) continue;
             const f32x4 v = *(const f32x4*)(S.X + row * EC_XP + 4 * cq);
             const float2 st = S.stat[row];
             f32x4 o;
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = (v[c] - st.x) * st.y * gg[c] + be[c];
-            *(f32x4*)(a.out + g * EC_D + 4 * cq) = v;
-            *(f32x4*)(a.ln_out + g * EC_D + 4 * cq) = o;
+            if (own) *(f32x4*)(a.out + g * EC_D + 4 * cq) = v;
+            if (!a.qkv_out) {
+                *(f32x4*)(a.ln_out + g * EC_D + 4 * cq) = o;
+            } else {
+                if (!own) o = f32x4{0.f, 0.f, 0.f, 0.f};          // (rim rows: computed and dropped)
+                if (!EXACT) {
+                    bad = bad || ec_bad4(o);
+                    ec_store_split(o, Ah, Ar, row, cq);
+                } else {
+                    *(f32x4*)((float*)S.A2 + row * EC_XP + 4 * cq) = o;
+                }
+            }
+        }
+    }
+    if (a.qkv_out) {
+        __syncthreads();
+#pragma unroll 1
+        for (int part = 0; part < 3; ++part) {
+            ec_pointwise<EXACT, NW>(a, S, 6 + part, wcur, part < 2 ? 7 + part : -1, tid, [&](int row, int nn0, const f32x4 v) {
+                *(f32x4*)(S.X + row * EC_XP + nn0) = v;
+            });
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < RPG; ++rr) {
+                const int row = rg + NG * rr;
+                const long g = g0 + row;
+                if (row < HALO || row >= EC_CR - HALO || g < 0 || g >= a.rows) continue;
+                *(f32x4*)(a.qkv_out + g * (3 * EC_D) + part * EC_D + 4 * cq) = *(const f32x4*)(S.X + row * EC_XP + 4 * cq);
+            }
+            __syncthreads();
         }
     }
     if (!EXACT && bad) atomicMax(a.act_bad, a.run_id);
@@ -401,6 +436,253 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void grd_attn_tail_kernel(const En
     if (!EXACT && bad) atomicMax(a.act_bad, a.run_id);
 }
 
+// ---- co-attention + the fusion layer in one kernel (round 6) -----------------------------------------------------------------------------
+// models/grd_model_v5.py:346-366: sim = proj2sim(video) @ query^T, its two softmaxes, A = sim_r @ query, B = sim_r @ (sim_c^T @ video), then
+// vq_fc([video, A, video * A, video * B]) (4 d -> d).  As two launches (coattention_kernel + a GEMM, csrc/grounding.hip) the (rows, 4 d)
+// fusion tensor is written and read back: 470 MB each way on the benchmark's 230 k rows, 0.30 of the leg's 2.2 ms.  Here the workgroup of a
+// query keeps the three softmaxed score rows in LDS as coattention_kernel does (the same statements, except the order of the S2 sum) and then walks
+// its T clips in blocks of 64: the four d-wide pieces of the fusion row are built in registers, split into the two f16 planes of the
+// encoder kernels (one piece = one 128-deep K chunk of vq_fc) and multiplied on the matrix cores into ONE pair of accumulators; the fusion
+// tensor never exists in memory, the output goes out through the tile as whole rows.  Range flag and exact fallback as the encoder kernels.
+struct CoattArgs {
+    const float* video; const float* proj; const float* query; float* out; int T; const int32_t* q_vid; const int32_t* vid_row_off;
+    const int32_t* q_row_off; const a16x8* frag; const int* frag_bad; int* act_bad; int run_id; const float* w; const float* bias;
+};
+
+__device__ __forceinline__ float ca_block_reduce(float v, bool is_max, float* red) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float u = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, u) : v + u;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+// vq_fc.weight (128, 512) as four K chunks in the fragment order of grd_enc_prep_kernel: (chunk, wave, k16 step, plane) x 64 lanes x 16 bytes
+__global__ __launch_bounds__(64) void grd_vq_prep_kernel(const float* __restrict__ W, a16x8* frag, int* frag_bad) {
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    const int s = blockIdx.x & 7, wave = (blockIdx.x >> 3) & 3, chunk = blockIdx.x >> 5;
+    const int n = wave * 32 + l31;
+    float x8[8];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x8[j] = W[(size_t)n * (4 * EC_D) + chunk * EC_D + 16 * s + 8 * hi + j]; bad = bad || !(fabsf(x8[j]) < EC_LIM); }
+    if (bad) atomicOr(frag_bad, 1);
+    union { bigc_fp16x2 p[4]; a16x8 v; } hh, rr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float u = x8[2 * j], v = x8[2 * j + 1];
+        hh.p[j] = bigc_pk_rtn(u, v);
+        rr.p[j] = bigc_pk_rtn((u - (float)hh.p[j][0]) * EC_RS, (v - (float)hh.p[j][1]) * EC_RS);
+    }
+    a16x8* dst = frag + ((((long)chunk * 4 + wave) * 8 + s) * 2) * 64 + lane;
+    dst[0] = hh.v;
+    dst[64] = rr.v;
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(256, 2) void grd_coatt_fc_kernel(const CoattArgs a) {
+    if (EXACT && a.act_bad[0] != a.run_id && a.frag_bad[0] == 0) return;
+    constexpr int d = EC_D;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ca_lds[];
+    unsigned char* Ah = ca_lds;                               // the two split planes of a 64 x 128 operand piece; EXACT: the piece in f32; then the output tile
+    unsigned char* Ar = ca_lds + EC_CR * EC_AP;
+    float* Xt = (float*)ca_lds;                               // (64, EC_XP) f32: 33.8 KB of the planes' 34.8 KB
+    float* q = (float*)(ca_lds + 2 * EC_CR * EC_AP);          // 3 d
+    float* s2 = q + 3 * d;                                    // 3 d
+    float* red = s2 + 3 * d;                                  // 4
+    float* sim_r = red + 4;                                   // 3 T
+    const float* video = a.video;
+    const float* proj = a.proj;
+    int T = a.T;
+    size_t out_row = (size_t)blockIdx.x * T;
+    if (a.q_vid) {
+        const int v = a.q_vid[blockIdx.x], r0 = a.vid_row_off[v];
+        T = a.vid_row_off[v + 1] - r0;
+        video += (size_t)r0 * d;
+        proj += (size_t)r0 * d;
+        out_row = a.q_row_off[blockIdx.x];
+    }
+    float* sim_c = sim_r + 3 * T;                             // 3 T
+    const int i = blockIdx.x, tid = threadIdx.x;
+    // ---- scores and their two softmaxes: coattention_kernel's statements (csrc/grounding.hip)
+    for (int c = tid; c < 3 * d; c += 256) q[c] = a.query[(size_t)i * 3 * d + c];
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) {
+        const f32x4* pr = (const f32x4*)(proj + (size_t)t * d);
+        float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int c4 = 0; c4 < d / 4; ++c4) {
+            const f32x4 p = pr[c4];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const f32x4 qq = *(const f32x4*)(q + l * d + c4 * 4);
+                s[l] += p[0] * qq[0] + p[1] * qq[1] + p[2] * qq[2] + p[3] * qq[3];
+            }
+        }
+        const float m = fmaxf(s[0], fmaxf(s[1], s[2]));
+        const float e0 = expf(s[0] - m), e1 = expf(s[1] - m), e2 = expf(s[2] - m);
+        const float sum = e0 + e1 + e2;
+        sim_r[t] = e0 / sum; sim_r[T + t] = e1 / sum; sim_r[2 * T + t] = e2 / sum;
+        sim_c[t] = s[0]; sim_c[T + t] = s[1]; sim_c[2 * T + t] = s[2];
+    }
+    __syncthreads();
+    for (int l = 0; l < 3; ++l) {
+        float m = -INFINITY;
+        for (int t = tid; t < T; t += 256) m = fmaxf(m, sim_c[l * T + t]);
+        m = ca_block_reduce(m, true, red);
+        float sum = 0.f;
+        for (int t = tid; t < T; t += 256) {
+            const float e = expf(sim_c[l * T + t] - m);
+            sim_c[l * T + t] = e;
+            sum += e;
+        }
+        sum = ca_block_reduce(sum, false, red);
+        for (int t = tid; t < T; t += 256) sim_c[l * T + t] /= sum;
+    }
+    __syncthreads();
+    const int cq = tid & 31, rg = tid >> 5;                   // channels 4 cq .. + 3 of rows rg, rg + 8, ...
+    {   // S2 = sim_c^T @ video (3, d): eight partial sums per element (clips rg, rg + 8, ...: a 512-byte row per 32 lanes and load), added in
+        // a fixed order.  (coattention_kernel walks the T clips of an element one after the other: a chain of T L2 round trips that took half
+        // of its time; the sum's order differs from it, the values agree to f32 rounding.)
+        f32x4 part[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 4
+        for (int t = rg; t < T; t += 8) {
+            const f32x4 v = *(const f32x4*)(video + (size_t)t * d + 4 * cq);
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const float w = sim_c[l * T + t];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) part[l][c] = fmaf(w, v[c], part[l][c]);
+            }
+        }
+        float* ps = (float*)ca_lds;                           // (8, 3 d) in the operand planes, which are not in use yet
+#pragma unroll
+        for (int l = 0; l < 3; ++l) *(f32x4*)(ps + (rg * 3 + l) * d + 4 * cq) = part[l];
+        __syncthreads();
+        for (int e = tid; e < 3 * d; e += 256) {
+            float acc = ps[e];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) acc += ps[g * 3 * d + e];
+            s2[e] = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- the fusion rows, 64 clips at a time, straight into vq_fc
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    bool bad = false;
+    float* ob = a.out + out_row * d;
+#pragma unroll 1
+    for (int t0 = 0; t0 < T; t0 += EC_CR) {
+        f32x16 acc0[2], acc1[2];
+        float ex[EXACT ? 8 : 1][4];                           // EXACT: thread (row tid & 63, features 4 (tid >> 6) + 16 j .. + 3)
+        if (EXACT) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ex[j][c] = 0.f;
+        }
+        if (!EXACT) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[rb][r] = 0.f; acc1[rb][r] = 0.f; }
+        }
+        f32x4 vrow[8];                                        // this thread's video values of the block: the same for the four pieces
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int t = t0 + rg + 8 * rr;
+            vrow[rr] = t < T ? *(const f32x4*)(video + (size_t)t * d + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int piece = 0; piece < 4; ++piece) {
+            a16x8 w[16];
+            if (!EXACT) ec_load_w(a.frag, piece, wave, lane, w);
+            // (pieces 1, 2 combine the query rows, piece 3 the S2 rows: the same three coefficients either way)
+            const float* z = piece == 3 ? s2 : q;
+            const f32x4 z0 = *(const f32x4*)(z + 4 * cq), z1 = *(const f32x4*)(z + d + 4 * cq), z2 = *(const f32x4*)(z + 2 * d + 4 * cq);
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int row = rg + 8 * rr, t = t0 + row;
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (t < T) {
+                    const f32x4 v = vrow[rr];
+                    const float r0 = sim_r[t], r1 = sim_r[T + t], r2 = sim_r[2 * T + t];
+                    // (coattention_kernel's expressions: a = r0 q0 + r1 q1 + r2 q2, b likewise on S2, then a v and b v)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float ab = r0 * z0[c] + r1 * z1[c] + r2 * z2[c];
+                        o[c] = piece == 0 ? v[c] : piece == 1 ? ab : ab * v[c];
+                    }
+                }
+                if (!EXACT) {
+                    bad = bad || ec_bad4(o);
+                    ec_store_split(o, Ah, Ar, row, cq);
+                } else {
+                    *(f32x4*)((float*)ca_lds + row * EC_XP + 4 * cq) = o;
+                }
+            }
+            __syncthreads();
+            if (!EXACT) {
+                ec_mm<2, false>(Ah, Ar, w, 0, l31, hi, acc0, acc1);
+            } else {
+                const float* Dw = (const float*)ca_lds;
+                const int row = tid & 63;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float* wr = a.w + (size_t)(4 * (tid >> 6) + 16 * j + c) * (4 * d) + piece * d;
+                        float acc = ex[j][c];
+#pragma unroll 4
+                        for (int k = 0; k < d; ++k) acc = fmaf(Dw[row * EC_XP + k], wr[k], acc);
+                        ex[j][c] = acc;
+                    }
+            }
+            __syncthreads();
+        }
+        // ---- + bias, through the tile, out by whole rows
+        if (!EXACT) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int nn0 = wave * 32 + 8 * r4 + 4 * hi;
+                const f32x4 bias = *(const f32x4*)(a.bias + nn0);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = (acc0[rb][4 * r4 + c] + acc1[rb][4 * r4 + c] * EC_RI) + bias[c];
+                    *(f32x4*)(Xt + (rb * 32 + l31) * EC_XP + nn0) = v;
+                }
+            }
+        } else {
+            const int row = tid & 63;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int nn0 = 4 * (tid >> 6) + 16 * j;
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = ex[j][c] + a.bias[nn0 + c];
+                *(f32x4*)(Xt + row * EC_XP + nn0) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = rg + 8 * rr, t = t0 + row;
+            if (t < T) *(f32x4*)(ob + (size_t)t * d + 4 * cq) = *(const f32x4*)(Xt + row * EC_XP + 4 * cq);
+        }
+        __syncthreads();
+    }
+    if (!EXACT && bad) atomicMax(a.act_bad, a.run_id);
+}
+
 }  // namespace
 
 bool grd_enc_chain_supported(int d, int ks) {
@@ -427,16 +709,18 @@ void enc_args(const Enc& E, long rows, int T, const int2* info, void* frag, EncC
     }
     a.pw_w[4] = E.out_proj.w; a.pw_b[4] = E.out_proj.b;
     a.pw_w[5] = E.fc.w; a.pw_b[5] = E.fc.b;
+    for (int i = 0; i < 3; ++i) { a.pw_w[6 + i] = E.in_proj.w + (size_t)i * EC_D * EC_D; a.pw_b[6 + i] = E.in_proj.b + i * EC_D; }
+    a.qkv_out = nullptr;
 }
 }  // namespace
 
 // `frag`: grd_enc_frag_bytes() of device memory owned by the model for this encoder; `refresh`: rebuild it (the weights changed since)
 int grd_enc_chain(hipStream_t s, const Enc& E, const float* x, const float* pos, long rows, int T, const int2* info, void* frag, bool refresh,
-                  float* out, float* ln_out) {
+                  float* out, float* ln_out, float* qkv_out) {
     if (rows <= 0) return BIGC_OK;
     EncChainArgs a;
     enc_args(E, rows, T, info, frag, a);
-    a.x = x; a.pos = pos; a.res = nullptr; a.out = out; a.ln_out = ln_out;
+    a.x = x; a.pos = pos; a.res = nullptr; a.out = out; a.ln_out = ln_out; a.qkv_out = qkv_out;
     if (refresh) {                             // (also the first use of the buffer: both flag words start at zero)
         if (hipMemsetAsync((void*)a.frag_bad, 0, 2 * sizeof(int), s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_enc_chain: memset failed");
         hipLaunchKernelGGL(grd_enc_prep_kernel, dim3(EC_LAYERS * 32 + 4), dim3(64), 0, s, a, (a16x8*)frag, (int*)a.frag_bad);
@@ -444,7 +728,7 @@ int grd_enc_chain(hipStream_t s, const Enc& E, const float* x, const float* pos,
     }
     const int tr = EC_CR - 8 * (E.ks / 2);
     const long tiles = (rows + tr - 1) / tr;
-    ProfScope ps((void*)s, FAM_GROUNDING, 2.0 * rows * EC_D * 4.0 * EC_D, 4.0 * rows * 3.0 * EC_D);
+    ProfScope ps((void*)s, FAM_GROUNDING, 2.0 * rows * EC_D * (qkv_out ? 7.0 : 4.0) * EC_D, 4.0 * rows * (qkv_out ? 5.0 : 3.0) * EC_D);
     static const int waves = getenv("BIGC_ENC_WAVES") ? atoi(getenv("BIGC_ENC_WAVES")) : 8;
     if (E.ks == 7) {
         if (waves == 8) hipLaunchKernelGGL((grd_enc_chain_kernel<7, false, 8>), dim3((unsigned)tiles), dim3(512), 0, s, a);
@@ -472,5 +756,41 @@ int grd_attn_tail(hipStream_t s, const Enc& E, const float* att, const float* re
     else hipLaunchKernelGGL((grd_attn_tail_kernel<false, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     hipLaunchKernelGGL((grd_attn_tail_kernel<true, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     BIGC_LAUNCH_CHECK("grd_attn_tail");
+    return BIGC_OK;
+}
+
+bool grd_coatt_fc_supported(int d, int max_T) {
+    static const bool off = getenv("BIGC_COATT_FC") && atoi(getenv("BIGC_COATT_FC")) == 0;
+    return !off && d == EC_D && max_T <= 2048 && !bigc_linear_get_exact() && !bigc_linear_get_fast();
+}
+
+size_t grd_vq_frag_bytes() { return (size_t)4 * 4 * 8 * 2 * 64 * sizeof(a16x8) + 256; }
+
+// out (rows, 128) = vq_fc(fusion rows of the co-attention); one video (q_vid == nullptr: n queries x T clips) or several (ragged descriptors)
+int grd_coatt_fc(hipStream_t s, const float* video, const float* proj, const float* query, const Lin& vq_fc, float* out, int n, int T, int max_T,
+                 long total_rows, const int32_t* q_vid, const int32_t* vid_row_off, const int32_t* q_row_off, void* frag, bool refresh) {
+    if (n <= 0) return BIGC_OK;
+    CoattArgs a;
+    a.video = video; a.proj = proj; a.query = query; a.out = out; a.T = T; a.q_vid = q_vid; a.vid_row_off = vid_row_off; a.q_row_off = q_row_off;
+    a.frag = (const a16x8*)frag; a.w = vq_fc.w; a.bias = vq_fc.b;
+    int* flags = (int*)((char*)frag + (size_t)4 * 4 * 8 * 2 * 64 * sizeof(a16x8));
+    a.frag_bad = flags; a.act_bad = flags + 1;
+    static std::atomic<int> g_run{0};
+    a.run_id = g_run.fetch_add(1, std::memory_order_relaxed) + 1;
+    if (refresh) {
+        if (hipMemsetAsync((void*)flags, 0, 2 * sizeof(int), s) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_coatt_fc: memset failed");
+        hipLaunchKernelGGL(grd_vq_prep_kernel, dim3(4 * 32), dim3(64), 0, s, vq_fc.w, (a16x8*)frag, flags);
+        BIGC_LAUNCH_CHECK("grd_vq_prep");
+    }
+    const size_t lds = (size_t)2 * EC_CR * EC_AP + sizeof(float) * (6 * (size_t)EC_D + 4 + 6 * (size_t)max_T);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)grd_coatt_fc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EC_CR * EC_AP + 4 * (6 * EC_D + 4 + 6 * 2048));
+        (void)hipFuncSetAttribute((const void*)grd_coatt_fc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EC_CR * EC_AP + 4 * (6 * EC_D + 4 + 6 * 2048));
+    });
+    ProfScope ps((void*)s, FAM_GROUNDING, 2.0 * total_rows * 4.0 * EC_D * EC_D, 4.0 * total_rows * 2.0 * EC_D);
+    hipLaunchKernelGGL(grd_coatt_fc_kernel<false>, dim3(n), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(grd_coatt_fc_kernel<true>, dim3(n), dim3(256), lds, s, a);      // gated: returns at once when no flag is up
+    BIGC_LAUNCH_CHECK("grd_coatt_fc");
     return BIGC_OK;
 }

@@ -21,8 +21,10 @@ struct grd_model {
     float* wq = nullptr;   // (d, kq) owned: [query_fc.weight | temp_fc.weight | 0 0]
     float* bq = nullptr;   // (d) owned: query_fc.bias + temp_fc.bias
     int kq = 0;
+    void* side_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;   // the query encoder's own stream beside the video encoder's (grd_forward), created at first use
+    void* vq_frag = nullptr; unsigned long long vq_frag_epoch = 0;       // vq_fc's weight in fragment order (grd_coatt_fc), owned
     void* head_frag = nullptr; unsigned long long head_frag_epoch = 0;   // the heads' point-wise weights in MFMA fragment order (grounding_heads.hip), owned
-    void* enc_frag[3] = {nullptr, nullptr, nullptr}; unsigned long long enc_frag_epoch[3] = {0, 0, 0};   // per encoder (video, query, combined): its six 128 x 128 weights in fragment order (grounding_encoder.hip), owned
+    void* enc_frag[3] = {nullptr, nullptr, nullptr}; unsigned long long enc_frag_epoch[3] = {0, 0, 0};   // per encoder (video, query, combined): its nine 128 x 128 weights in fragment order (grounding_encoder.hip), owned
     std::vector<SplitJob> train_jobs;  // as bigc_model::train_jobs
 };
 
@@ -36,5 +38,10 @@ int grd_head_chain(hipStream_t s, const float* x, long rows, int T, const int2* 
 bool grd_enc_chain_supported(int d, int ks);
 size_t grd_enc_frag_bytes();
 int grd_enc_chain(hipStream_t s, const Enc& E, const float* x, const float* pos, long rows, int T, const int2* info, void* frag, bool refresh,
-                  float* out, float* ln_out);
+                  float* out, float* ln_out, float* qkv_out = nullptr);   // qkv_out: (rows, 384) = in_proj(ln) written instead of ln_out
 int grd_attn_tail(hipStream_t s, const Enc& E, const float* att, const float* res, long rows, void* frag, float* out);
+// the co-attention and the fusion layer vq_fc in one launch: the (rows, 4 d) fusion tensor stays on the chip
+bool grd_coatt_fc_supported(int d, int max_T);
+size_t grd_vq_frag_bytes();
+int grd_coatt_fc(hipStream_t s, const float* video, const float* proj, const float* query, const Lin& vq_fc, float* out, int n, int T, int max_T,
+                 long total_rows, const int32_t* q_vid, const int32_t* vid_row_off, const int32_t* q_row_off, void* frag, bool refresh);

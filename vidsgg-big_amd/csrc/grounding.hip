@@ -573,6 +573,7 @@ struct GWork {
     int32_t* off;
     int2 *vinfo, *cinfo;      // several videos per call: (position, length) of every video row / every combined row
     float *q_b[4], *q_qkv, *q_att; int32_t* q_off;     // the query encoder's own scratch (3n rows): it runs beside the video encoder on a second stream
+    float *vp, *qu;           // vq_fc's clip-only and query-only terms (grd_coatt_fc)
 };
 
 // total_T = sum of the videos' clip counts, total_rows = sum over queries of their video's clip count (one video: T and n*T)
@@ -600,6 +601,8 @@ bool glayout(const grd_model* m, long total_T, int n, long total_rows, bool ragg
     w.q_qkv = a.take<float>((size_t)3 * n * 3 * d);
     w.q_att = a.take<float>((size_t)3 * n * d);
     w.q_off = a.take<int32_t>((size_t)n + 2);
+    w.vp = a.take<float>((size_t)total_T * d);
+    w.qu = a.take<float>((size_t)3 * n * d);
     return !a.overflow;
 }
 
@@ -789,20 +792,25 @@ int forward_impl(grd_model* m, void* stream, const float* video_feat, int T, con
     float* qenc = out->query_enc ? out->query_enc : w.qenc;
     GWork wq = w;
     wq.b0 = w.q_b[0]; wq.b1 = w.q_b[1]; wq.b2 = w.q_b[2]; wq.b3 = w.q_b[3]; wq.qkv = w.q_qkv; wq.att = w.q_att; wq.off = w.q_off;
+    const bool fused_ca = grd_coatt_fc_supported(d, max_T);
     GTRY(qanet(qs, m, 1, m->query_enc, qemb, pos_query, sq, d, wq, qenc));
+    // vq_fc's K chunks 0 and 1 do not need the (query, clip) rows (csrc/grounding_encoder.hip: grd_coatt_fc): two small GEMMs on the
+    // encoders' outputs, each on its encoder's stream
+    if (fused_ca) GTRY(bigc_linear_f32(qs, qenc, d, nullptr, 1, d, m->vq_fc.w + d, 4 * d, nullptr, nullptr, 0, w.qu, d, 3 * n, d, d, BIGC_ACT_NONE));
     GTRY(qanet(s, m, 0, m->video_enc, vemb, pos_video, sv, d, w, venc));
+    GTRY(glinear(s, venc, d, m->proj2sim, w.proj, d, (int)total_T, d, d, BIGC_ACT_NONE));
+    if (fused_ca) GTRY(bigc_linear_f32(s, venc, d, nullptr, 1, d, m->vq_fc.w, 4 * d, m->vq_fc.b, nullptr, 0, w.vp, d, (int)total_T, d, d, BIGC_ACT_NONE));
     if (two) {
         if (hipEventRecord((hipEvent_t)m->ev_join, qhs) != hipSuccess || hipStreamWaitEvent(hs, (hipEvent_t)m->ev_join, 0) != hipSuccess)
             return bigc_fail(BIGC_ERR_HIP, "grd_forward: stream join failed");
     }
-    GTRY(glinear(s, venc, d, m->proj2sim, w.proj, d, (int)total_T, d, d, BIGC_ACT_NONE));
     float* cin = w.att;                           // (rows, d) free between qanet calls
-    if (grd_coatt_fc_supported(d, max_T)) {
-        // co-attention + vq_fc in one launch (csrc/grounding_encoder.hip): the (rows, 4 d) fusion tensor is never written
+    if (fused_ca) {
+        // co-attention + vq_fc in one launch: the (rows, 4 d) fusion tensor is never written
         if (!m->vq_frag && hipMalloc(&m->vq_frag, grd_vq_frag_bytes()) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "grd_forward: hipMalloc failed");
         const bool refresh = m->vq_frag_epoch != m->epoch;
-        GTRY(grd_coatt_fc(hs, venc, w.proj, qenc, m->vq_fc, cin, n, T, max_T, total_rows, q_vid, b ? b->vid_row_off : nullptr, b ? b->q_row_off : nullptr,
-                          m->vq_frag, refresh));
+        GTRY(grd_coatt_fc(hs, venc, w.proj, qenc, m->vq_fc, w.vp, w.qu, cin, n, T, max_T, total_rows, q_vid, b ? b->vid_row_off : nullptr,
+                          b ? b->q_row_off : nullptr, m->vq_frag, refresh));
         m->vq_frag_epoch = m->epoch;
     } else {
         if (!b) {

@@ -440,13 +440,17 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void grd_attn_tail_kernel(const En
 // models/grd_model_v5.py:346-366: sim = proj2sim(video) @ query^T, its two softmaxes, A = sim_r @ query, B = sim_r @ (sim_c^T @ video), then
 // vq_fc([video, A, video * A, video * B]) (4 d -> d).  As two launches (coattention_kernel + a GEMM, csrc/grounding.hip) the (rows, 4 d)
 // fusion tensor is written and read back: 470 MB each way on the benchmark's 230 k rows, 0.30 of the leg's 2.2 ms.  Here the workgroup of a
-// query keeps the three softmaxed score rows in LDS as coattention_kernel does (the same statements, except the order of the S2 sum) and then walks
-// its T clips in blocks of 64: the four d-wide pieces of the fusion row are built in registers, split into the two f16 planes of the
-// encoder kernels (one piece = one 128-deep K chunk of vq_fc) and multiplied on the matrix cores into ONE pair of accumulators; the fusion
-// tensor never exists in memory, the output goes out through the tile as whole rows.  Range flag and exact fallback as the encoder kernels.
+// query keeps the three softmaxed score rows in LDS as coattention_kernel does (the same statements, except the order of the S2 sum) and
+// then walks its T clips in blocks of 64.  Of vq_fc's four d-wide K chunks two do not need the (query, clip) rows at all:
+//     W0 video[t] + bias                   depends on the clip only      -> `vp` (total_T, d), one small GEMM per call
+//     W1 A[t] = sum_l sim_r[l][t] (W1 query_l)  is a rank-3 combination  -> `qu` (3 n, d) = query rows through W1, one small GEMM per call
+// The other two (video * A, video * B) are built in registers block by block, split into the two f16 planes of the encoder kernels and
+// multiplied on the matrix cores into one pair of accumulators; the output row = that + vp[t] + sum_l sim_r[l][t] qu[l] leaves through the
+// tile as whole rows.  The fusion tensor never exists in memory.  Range flag and exact fallback as the encoder kernels.
 struct CoattArgs {
     const float* video; const float* proj; const float* query; float* out; int T; const int32_t* q_vid; const int32_t* vid_row_off;
-    const int32_t* q_row_off; const a16x8* frag; const int* frag_bad; int* act_bad; int run_id; const float* w; const float* bias;
+    const int32_t* q_row_off; const a16x8* frag; const int* frag_bad; int* act_bad; int run_id; const float* w;
+    const float* vp; const float* qu;                     // (total_T, d) = video @ W0^T + bias; (3 n, d) = query @ W1^T
 };
 
 __device__ __forceinline__ float ca_block_reduce(float v, bool is_max, float* red) {
@@ -495,10 +499,12 @@ __global__ __launch_bounds__(256, 2) void grd_coatt_fc_kernel(const CoattArgs a)
     float* Xt = (float*)ca_lds;                               // (64, EC_XP) f32: 33.8 KB of the planes' 34.8 KB
     float* q = (float*)(ca_lds + 2 * EC_CR * EC_AP);          // 3 d
     float* s2 = q + 3 * d;                                    // 3 d
-    float* red = s2 + 3 * d;                                  // 4
+    float* qu = s2 + 3 * d;                                   // 3 d: this query's rows of `qu`
+    float* red = qu + 3 * d;                                  // 4
     float* sim_r = red + 4;                                   // 3 T
     const float* video = a.video;
     const float* proj = a.proj;
+    const float* vp = a.vp;
     int T = a.T;
     size_t out_row = (size_t)blockIdx.x * T;
     if (a.q_vid) {
@@ -506,12 +512,13 @@ __global__ __launch_bounds__(256, 2) void grd_coatt_fc_kernel(const CoattArgs a)
         T = a.vid_row_off[v + 1] - r0;
         video += (size_t)r0 * d;
         proj += (size_t)r0 * d;
+        vp += (size_t)r0 * d;
         out_row = a.q_row_off[blockIdx.x];
     }
     float* sim_c = sim_r + 3 * T;                             // 3 T
     const int i = blockIdx.x, tid = threadIdx.x;
     // ---- scores and their two softmaxes: coattention_kernel's statements (csrc/grounding.hip)
-    for (int c = tid; c < 3 * d; c += 256) q[c] = a.query[(size_t)i * 3 * d + c];
+    for (int c = tid; c < 3 * d; c += 256) { q[c] = a.query[(size_t)i * 3 * d + c]; qu[c] = a.qu[(size_t)i * 3 * d + c]; }
     __syncthreads();
     for (int t = tid; t < T; t += 256) {
         const f32x4* pr = (const f32x4*)(proj + (size_t)t * d);
@@ -578,6 +585,7 @@ __global__ __launch_bounds__(256, 2) void grd_coatt_fc_kernel(const CoattArgs a)
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     bool bad = false;
     float* ob = a.out + out_row * d;
+    const f32x4 u0 = *(const f32x4*)(qu + 4 * cq), u1 = *(const f32x4*)(qu + d + 4 * cq), u2 = *(const f32x4*)(qu + 2 * d + 4 * cq);
 #pragma unroll 1
     for (int t0 = 0; t0 < T; t0 += EC_CR) {
         f32x16 acc0[2], acc1[2];
@@ -601,11 +609,10 @@ __global__ __launch_bounds__(256, 2) void grd_coatt_fc_kernel(const CoattArgs a)
             vrow[rr] = t < T ? *(const f32x4*)(video + (size_t)t * d + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll 1
-        for (int piece = 0; piece < 4; ++piece) {
+        for (int piece = 2; piece < 4; ++piece) {             // (K chunks 0 and 1 of vq_fc: see vp / qu)
             a16x8 w[16];
             if (!EXACT) ec_load_w(a.frag, piece, wave, lane, w);
-            // (pieces 1, 2 combine the query rows, piece 3 the S2 rows: the same three coefficients either way)
-            const float* z = piece == 3 ? s2 : q;
+            const float* z = piece == 3 ? s2 : q;             // video * A combines the query rows, video * B the S2 rows
             const f32x4 z0 = *(const f32x4*)(z + 4 * cq), z1 = *(const f32x4*)(z + d + 4 * cq), z2 = *(const f32x4*)(z + 2 * d + 4 * cq);
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void grd_coatt_fc_kernel(const CoattArgs a)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float ab = r0 * z0[c] + r1 * z1[c] + r2 * z2[c];
-                        o[c] = piece == 0 ? v[c] : piece == 1 ? ab : ab * v[c];
+                        o[c] = ab * v[c];
                     }
                 }
                 if (!EXACT) {
@@ -647,17 +654,16 @@ __global__ __launch_bounds__(256, 2) void grd_coatt_fc_kernel(const CoattArgs a)
             }
             __syncthreads();
         }
-        // ---- + bias, through the tile, out by whole rows
+        // ---- through the tile, + the clip's and the query's terms, out by whole rows
         if (!EXACT) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int nn0 = wave * 32 + 8 * r4 + 4 * hi;
-                const f32x4 bias = *(const f32x4*)(a.bias + nn0);
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) {
                     f32x4 v;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = (acc0[rb][4 * r4 + c] + acc1[rb][4 * r4 + c] * EC_RI) + bias[c];
+                    for (int c = 0; c < 4; ++c) v[c] = acc0[rb][4 * r4 + c] + acc1[rb][4 * r4 + c] * EC_RI;
                     *(f32x4*)(Xt + (rb * 32 + l31) * EC_XP + nn0) = v;
                 }
             }
@@ -668,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void grd_coatt_fc_kernel(const CoattArgs a)
                 const int nn0 = 4 * (tid >> 6) + 16 * j;
                 f32x4 v;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = ex[j][c] + a.bias[nn0 + c];
+                for (int c = 0; c < 4; ++c) v[c] = ex[j][c];
                 *(f32x4*)(Xt + row * EC_XP + nn0) = v;
             }
         }
@@ -676,7 +682,14 @@ __global__ __launch_bounds__(256, 2) void grd_coatt_fc_kernel(const CoattArgs a)
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const int row = rg + 8 * rr, t = t0 + row;
-            if (t < T) *(f32x4*)(ob + (size_t)t * d + 4 * cq) = *(const f32x4*)(Xt + row * EC_XP + 4 * cq);
+            if (t < T) {
+                const f32x4 x = *(const f32x4*)(Xt + row * EC_XP + 4 * cq), pv = *(const f32x4*)(vp + (size_t)t * d + 4 * cq);
+                const float r0 = sim_r[t], r1 = sim_r[T + t], r2 = sim_r[2 * T + t];
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = (x[c] + pv[c]) + (r0 * u0[c] + r1 * u1[c] + r2 * u2[c]);
+                *(f32x4*)(ob + (size_t)t * d + 4 * cq) = o;
+            }
         }
         __syncthreads();
     }
@@ -767,12 +780,13 @@ bool grd_coatt_fc_supported(int d, int max_T) {
 size_t grd_vq_frag_bytes() { return (size_t)4 * 4 * 8 * 2 * 64 * sizeof(a16x8) + 256; }
 
 // out (rows, 128) = vq_fc(fusion rows of the co-attention); one video (q_vid == nullptr: n queries x T clips) or several (ragged descriptors)
-int grd_coatt_fc(hipStream_t s, const float* video, const float* proj, const float* query, const Lin& vq_fc, float* out, int n, int T, int max_T,
-                 long total_rows, const int32_t* q_vid, const int32_t* vid_row_off, const int32_t* q_row_off, void* frag, bool refresh) {
+int grd_coatt_fc(hipStream_t s, const float* video, const float* proj, const float* query, const Lin& vq_fc, const float* vp, const float* qu,
+                 float* out, int n, int T, int max_T, long total_rows, const int32_t* q_vid, const int32_t* vid_row_off, const int32_t* q_row_off,
+                 void* frag, bool refresh) {
     if (n <= 0) return BIGC_OK;
     CoattArgs a;
     a.video = video; a.proj = proj; a.query = query; a.out = out; a.T = T; a.q_vid = q_vid; a.vid_row_off = vid_row_off; a.q_row_off = q_row_off;
-    a.frag = (const a16x8*)frag; a.w = vq_fc.w; a.bias = vq_fc.b;
+    a.frag = (const a16x8*)frag; a.w = vq_fc.w; a.vp = vp; a.qu = qu;
     int* flags = (int*)((char*)frag + (size_t)4 * 4 * 8 * 2 * 64 * sizeof(a16x8));
     a.frag_bad = flags; a.act_bad = flags + 1;
     static std::atomic<int> g_run{0};
@@ -782,13 +796,13 @@ int grd_coatt_fc(hipStream_t s, const float* video, const float* proj, const flo
         hipLaunchKernelGGL(grd_vq_prep_kernel, dim3(4 * 32), dim3(64), 0, s, vq_fc.w, (a16x8*)frag, flags);
         BIGC_LAUNCH_CHECK("grd_vq_prep");
     }
-    const size_t lds = (size_t)2 * EC_CR * EC_AP + sizeof(float) * (6 * (size_t)EC_D + 4 + 6 * (size_t)max_T);
+    const size_t lds = (size_t)2 * EC_CR * EC_AP + sizeof(float) * (9 * (size_t)EC_D + 4 + 6 * (size_t)max_T);
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute((const void*)grd_coatt_fc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EC_CR * EC_AP + 4 * (6 * EC_D + 4 + 6 * 2048));
-        (void)hipFuncSetAttribute((const void*)grd_coatt_fc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EC_CR * EC_AP + 4 * (6 * EC_D + 4 + 6 * 2048));
+        (void)hipFuncSetAttribute((const void*)grd_coatt_fc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EC_CR * EC_AP + 4 * (9 * EC_D + 4 + 6 * 2048));
+        (void)hipFuncSetAttribute((const void*)grd_coatt_fc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * EC_CR * EC_AP + 4 * (9 * EC_D + 4 + 6 * 2048));
     });
-    ProfScope ps((void*)s, FAM_GROUNDING, 2.0 * total_rows * 4.0 * EC_D * EC_D, 4.0 * total_rows * 2.0 * EC_D);
+    ProfScope ps((void*)s, FAM_GROUNDING, 2.0 * total_rows * 2.0 * EC_D * EC_D, 4.0 * total_rows * 2.0 * EC_D);
     hipLaunchKernelGGL(grd_coatt_fc_kernel<false>, dim3(n), dim3(256), lds, s, a);
     hipLaunchKernelGGL(grd_coatt_fc_kernel<true>, dim3(n), dim3(256), lds, s, a);      // gated: returns at once when no flag is up
     BIGC_LAUNCH_CHECK("grd_coatt_fc");

@@ -43,5 +43,7 @@ int grd_attn_tail(hipStream_t s, const Enc& E, const float* att, const float* re
 // the co-attention and the fusion layer vq_fc in one launch: the (rows, 4 d) fusion tensor stays on the chip
 bool grd_coatt_fc_supported(int d, int max_T);
 size_t grd_vq_frag_bytes();
-int grd_coatt_fc(hipStream_t s, const float* video, const float* proj, const float* query, const Lin& vq_fc, float* out, int n, int T, int max_T,
-                 long total_rows, const int32_t* q_vid, const int32_t* vid_row_off, const int32_t* q_row_off, void* frag, bool refresh);
+// (vp (total_T, d) = video @ vq_fc.weight[:, :d]^T + bias and qu (3 n, d) = query @ vq_fc.weight[:, d:2d]^T are the caller's two small GEMMs)
+int grd_coatt_fc(hipStream_t s, const float* video, const float* proj, const float* query, const Lin& vq_fc, const float* vp, const float* qu,
+                 float* out, int n, int T, int max_T, long total_rows, const int32_t* q_vid, const int32_t* vid_row_off, const int32_t* q_row_off,
+                 void* frag, bool refresh);

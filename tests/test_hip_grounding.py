@@ -378,14 +378,16 @@ np.savez(sys.argv[1], **out)
 
 
 def test_query_encoder_stream_and_fused_in_proj_against_the_plain_sequence():
-    """Round 6: the query encoder runs on a second stream beside the video encoder (fork / join by events), and the attention's in_proj runs
-    inside the encoder chain kernel.  One stream (BIGC_GRD_STREAMS=0) must give the same BITS; the in_proj as a GEMM of its own
-    (BIGC_ENC_QKV=0: another summation order) the same values to the f32 level."""
+    """Round 6: the query encoder runs on a second stream beside the video encoder (fork / join by events), the attention's in_proj runs
+    inside the encoder chain kernel, the co-attention carries vq_fc, big k = 7 launches use 128-row tiles.  One stream (BIGC_GRD_STREAMS=0)
+    and the forced tile size must give the same BITS; the in_proj / vq_fc as GEMMs of their own (other summation orders) the same values
+    to the f32 level."""
     import subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = tempfile.mkdtemp()
     res = {}
-    for tag, env in (("default", {}), ("one_stream", {"BIGC_GRD_STREAMS": "0"}), ("plain_in_proj", {"BIGC_ENC_QKV": "0"})):
+    for tag, env in (("default", {}), ("one_stream", {"BIGC_GRD_STREAMS": "0"}), ("plain_in_proj", {"BIGC_ENC_QKV": "0"}),
+                     ("tile128", {"BIGC_ENC_TILE128": "1"}), ("two_kernel_coatt", {"BIGC_COATT_FC": "0"})):
         path = os.path.join(d, tag + ".npz")
         e = dict(os.environ, BIGC_REPO=repo, **env)
         r = subprocess.run([sys.executable, "-c", _ENV_SCRIPT, path], env=e, capture_output=True, text=True, timeout=600)
@@ -393,6 +395,10 @@ def test_query_encoder_stream_and_fused_in_proj_against_the_plain_sequence():
         res[tag] = dict(np.load(path))
     for k, v in res["default"].items():
         assert np.array_equal(v, res["one_stream"][k], equal_nan=True), k
+        # the k = 7 encoders on the 128-row tiles of big launches (forced here): the same arithmetic per row, the same bits
+        assert np.array_equal(v, res["tile128"][k], equal_nan=True), k
         if v.dtype == np.bool_:
             continue
         assert rel(res["plain_in_proj"][k], v) < 5e-5, (k, rel(res["plain_in_proj"][k], v))
+        # co-attention and vq_fc as two launches (the (rows, 4 d) tensor in memory, one GEMM over K = 4 d)
+        assert rel(res["two_kernel_coatt"][k], v) < 5e-5, (k, rel(res["two_kernel_coatt"][k], v))

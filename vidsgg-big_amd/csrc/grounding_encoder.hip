@@ -1,13 +1,15 @@
 // A QANet encoder layer of the grounding scorer (models/grd_model_v5.py:110-137, eval mode) in TWO kernels around its attention core:
 //
-//   grd_enc_chain   out = x + pos;  4 x [ out = relu(point_wise(depth_wise_k(LayerNorm_i(out)))) + out ];  ln = LayerNorm_4(out)
-//                   (:124-131 and the normalisation in front of the attention, :132)       -> `out` and `ln`, (rows, 128) each
+//   grd_enc_chain   out = x + pos;  4 x [ out = relu(point_wise(depth_wise_k(LayerNorm_i(out)))) + out ];  ln = LayerNorm_4(out);
+//                   qkv = in_proj(ln)   (:124-131, the normalisation in front of the attention and its packed projection, :132-133)
+//                                                                                          -> `out` (rows, 128) and `qkv` (rows, 384)
 //   grd_attn_tail   r = out_proj(att) + out;  y = relu(fc(LayerNorm_e(r))) + r                (:133-136)        -> y (rows, 128)
 //
 // Layer by layer (csrc/grounding.hip: qanet) the first part is 1 + 4 x 2 + 1 launches that each read and write the whole (rows, 128)
 // activation -- 10 passes of 123 MB each way on the combined encoder of the benchmark's 241 k rows, 0.65 of the leg's 3.3 ms -- and the
 // second 3.  Here a workgroup keeps a tile of 64 consecutive rows in LDS through all four convolution layers: the activation is read once
-// (1.6 times with the halo), the normalised and the convolved tensors never exist in memory, `out` and `ln` are written once.
+// (1.6 times with the halo; 1.23 times on the 128-row tiles of big launches), the normalised and the convolved tensors never exist in
+// memory, `out` and `qkv` are written once.
 //
 // Tile and halo: rows [g0, g0 + 64) of the row-major activation (sequences back to back).  A k-tap depth-wise convolution needs k / 2
 // neighbours on either side inside the same sequence, so after four layers rows 4 (k / 2) .. 63 - 4 (k / 2) of the tile are exact
@@ -124,12 +126,14 @@ __device__ __forceinline__ void ec_mm(const unsigned char* Ah, const unsigned ch
     }
 }
 
-struct EcSmem {
-    float X[EC_CR * EC_XP];                           // the running activation (`out` of the reference), f32
-    unsigned char A2[2 * EC_CR * EC_AP];              // split planes of the current GEMM operand; EXACT: the same operand in f32
-    int2 rinfo[EC_CR];                                // (position, length of the sequence) of a tile row; length 0 = outside the tensor
-    float2 stat[EC_CR];                               // (mean, 1 / std) of a tile row for the current LayerNorm
+template <int CR = EC_CR>
+struct EcSmemT {
+    float X[CR * EC_XP];                              // the running activation (`out` of the reference), f32
+    unsigned char A2[2 * CR * EC_AP];                 // split planes of the current GEMM operand; EXACT: the same operand in f32
+    int2 rinfo[CR];                                   // (position, length of the sequence) of a tile row; length 0 = outside the tensor
+    float2 stat[CR];                                  // (mean, 1 / std) of a tile row for the current LayerNorm
 };
+typedef EcSmemT<EC_CR> EcSmem;
 
 // sum over the four lanes of a quad, in every lane (two DPP quad permutes: no LDS traffic, no bpermute latency)
 __device__ __forceinline__ float ec_quad_sum(float t) {
@@ -140,8 +144,9 @@ __device__ __forceinline__ float ec_quad_sum(float t) {
 
 // LayerNorm statistics of the tile's 64 rows -> S.stat: four threads per row, 32 channels each, two-pass in f32 (mean, then the squared
 // deviations from it), biased variance, eps inside the root (torch.nn.LayerNorm)
-__device__ __forceinline__ void ec_stats(EcSmem& S, int tid, float eps) {
-    if (tid >= 4 * EC_CR) return;                 // (eight-wave workgroups: the first four waves)
+template <int CR>
+__device__ __forceinline__ void ec_stats(EcSmemT<CR>& S, int tid, float eps) {
+    if (tid >= 4 * CR) return;                    // (eight / sixteen-wave workgroups: the first half of the waves)
     const int row = tid >> 2, q = tid & 3;
     const float* xp = S.X + row * EC_XP + 32 * q;
     f32x4 v[8];
@@ -163,16 +168,16 @@ __device__ __forceinline__ void ec_stats(EcSmem& S, int tid, float eps) {
 // right behind the MFMAs (it lands while the epilogue and the next layer's row-wise stages run: with two waves per SIMD nothing else would
 // hide an L2 round trip per layer).  NW = 8 waves: a wave owns 32 features and ONE 32-row block and fetches its slice where it uses it
 // (64 registers that must not live through the row-wise stages at 128 per wave; the other three waves of the SIMD cover the round trip).
-template <bool EXACT, int NW, typename Epi>
-__device__ __forceinline__ void ec_pointwise(const EncChainArgs& a, EcSmem& S, int layer, a16x8 (&wcur)[16], int next, int tid, Epi epi) {
+template <bool EXACT, int NW, int CR, typename Epi>
+__device__ __forceinline__ void ec_pointwise(const EncChainArgs& a, EcSmemT<CR>& S, int layer, a16x8 (&wcur)[16], int next, int tid, Epi epi) {
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    constexpr int NRB = 8 / NW;
-    const int fb = wave & 3, rb0 = NW == 8 ? wave >> 2 : 0;
+    constexpr int NRB = (CR / 32) * 4 / NW;               // 32-row blocks per wave: 2 at four waves, 1 at eight (64 rows) and sixteen (128 rows)
+    const int fb = wave & 3, rb0 = (wave >> 2) * NRB;
     if (!EXACT) {
         unsigned char* Ah = S.A2;
-        unsigned char* Ar = S.A2 + EC_CR * EC_AP;
+        unsigned char* Ar = S.A2 + CR * EC_AP;
         f32x16 acc0[NRB], acc1[NRB];
-        if (NW == 8) {
+        if (NW >= 8) {
             a16x8 w[16];
             ec_load_w(a.frag, layer, fb, lane, w);
             ec_mm<NRB>(Ah, Ar, w, rb0, l31, hi, acc0, acc1);
@@ -216,14 +221,18 @@ __device__ __forceinline__ f32x4 ec_relu(const f32x4 v) {                    // 
     return o;
 }
 
-template <int KS, bool EXACT, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 2) void grd_enc_chain_kernel(const EncChainArgs a) {
-    constexpr int NG = 2 * NW, RPG = EC_CR / NG;           // 32-lane groups of the row-wise stages; consecutive rows per group
+// CR = rows of the tile: 64 (eight waves, two workgroups per CU), or 128 with sixteen waves (one workgroup per CU, the same four waves per SIMD)
+// for big launches of the k = 7 encoders, whose 24 halo rows are 37 % of a 64-row tile and 19 % of a 128-row one: 480 -> 427 us on the
+// benchmark's combined encoder (eight waves on 128 rows, two row blocks per wave and half the weight fetches: 462).
+template <int KS, bool EXACT, int NW, int CR = EC_CR>
+__global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : NW / 2) void grd_enc_chain_kernel(const EncChainArgs a) {
+    constexpr int NG = 2 * NW, RPG = CR / NG;              // 32-lane groups of the row-wise stages; consecutive rows per group
     if (EXACT && a.act_bad[0] != a.run_id && a.frag_bad[0] == 0) return;
-    constexpr int H = KS / 2, HALO = 4 * H, TR = EC_CR - 2 * HALO;
-    __shared__ __attribute__((aligned(16))) EcSmem S;
+    constexpr int H = KS / 2, HALO = 4 * H, TR = CR - 2 * HALO;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ec_raw[];
+    EcSmemT<CR>& S = *(EcSmemT<CR>*)ec_raw;
     unsigned char* Ah = S.A2;
-    unsigned char* Ar = S.A2 + EC_CR * EC_AP;
+    unsigned char* Ar = S.A2 + CR * EC_AP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cq = tid & 31, rg = tid >> 5;                 // row-wise stages: channels 4 cq .. + 3 of rows RPG rg .. + RPG - 1
     const long g0 = (long)blockIdx.x * TR - HALO;
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void grd_enc_chain_kernel(const En
         {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             auto ln_row = [&](int r) {
-                if (r < 0 || r >= EC_CR) return zero;            // (only the rim rows see these)
+                if (r < 0 || r >= CR) return zero;            // (only the rim rows see these)
                 const f32x4 v = *(const f32x4*)(S.X + r * EC_XP + 4 * cq);
                 const float2 st = S.stat[r];
                 f32x4 o;
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void grd_enc_chain_kernel(const En
             }
         }
         __syncthreads();
-        ec_pointwise<EXACT, NW>(a, S, layer, wcur, layer < 3 ? layer + 1 : (a.qkv_out ? 6 : -1), tid, [&](int row, int nn0, const f32x4 v) {
+        ec_pointwise<EXACT, NW, CR>(a, S, layer, wcur, layer < 3 ? layer + 1 : (a.qkv_out ? 6 : -1), tid, [&](int row, int nn0, const f32x4 v) {
             f32x4* xp = (f32x4*)(S.X + row * EC_XP + nn0);
             *xp = ec_relu(v) + *xp;                              // relu(conv) + res  (:130-131)
         });
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void grd_enc_chain_kernel(const En
         for (int rr = 0; rr < RPG; ++rr) {
             const int row = rg + NG * rr;
             const long g = g0 + row;
-            const bool own = !(row < HALO || row >= EC_CR - HALO || g < 0 || g >= a.rows);
+            const bool own = !(row < HALO || row >= CR - HALO || g < 0 || g >= a.rows);
             if (!own && !a.qkv_out) continue;
             const f32x4 v = *(const f32x4*)(S.X + row * EC_XP + 4 * cq);
             const float2 st = S.stat[row];
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void grd_enc_chain_kernel(const En
         __syncthreads();
 #pragma unroll 1
         for (int part = 0; part < 3; ++part) {
-            ec_pointwise<EXACT, NW>(a, S, 6 + part, wcur, part < 2 ? 7 + part : -1, tid, [&](int row, int nn0, const f32x4 v) {
+            ec_pointwise<EXACT, NW, CR>(a, S, 6 + part, wcur, part < 2 ? 7 + part : -1, tid, [&](int row, int nn0, const f32x4 v) {
                 *(f32x4*)(S.X + row * EC_XP + nn0) = v;
             });
             __syncthreads();
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void grd_enc_chain_kernel(const En
             for (int rr = 0; rr < RPG; ++rr) {
                 const int row = rg + NG * rr;
                 const long g = g0 + row;
-                if (row < HALO || row >= EC_CR - HALO || g < 0 || g >= a.rows) continue;
+                if (row < HALO || row >= CR - HALO || g < 0 || g >= a.rows) continue;
                 *(f32x4*)(a.qkv_out + g * (3 * EC_D) + part * EC_D + 4 * cq) = *(const f32x4*)(S.X + row * EC_XP + 4 * cq);
             }
             __syncthreads();
@@ -394,7 +403,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void grd_attn_tail_kernel(const En
         }
     }
     __syncthreads();
-    ec_pointwise<EXACT, NW>(a, S, 4, wcur, 5, tid, [&](int row, int nn0, const f32x4 v) {
+    ec_pointwise<EXACT, NW, EC_CR>(a, S, 4, wcur, 5, tid, [&](int row, int nn0, const f32x4 v) {
         f32x4* xp = (f32x4*)(S.X + row * EC_XP + nn0);
         *xp = v + *xp;                                           // attn + res (:134)
     });
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void grd_attn_tail_kernel(const En
     }
     __syncthreads();
     // (through the tile, then out by whole rows: stored straight from the accumulator layout every instruction touched 64 different lines)
-    ec_pointwise<EXACT, NW>(a, S, 5, wcur, -1, tid, [&](int row, int nn0, const f32x4 v) {
+    ec_pointwise<EXACT, NW, EC_CR>(a, S, 5, wcur, -1, tid, [&](int row, int nn0, const f32x4 v) {
         f32x4* xp = (f32x4*)(S.X + row * EC_XP + nn0);
         *xp = ec_relu(v) + *xp;                                  // relu(fc) + res (:135-136)
     });
@@ -740,17 +749,34 @@ int grd_enc_chain(hipStream_t s, const Enc& E, const float* x, const float* pos,
         BIGC_LAUNCH_CHECK("grd_enc_prep");
     }
     const int tr = EC_CR - 8 * (E.ks / 2);
-    const long tiles = (rows + tr - 1) / tr;
+    const long tiles = (rows + tr - 1) / tr;                 // 64-row tiles (the gated f32 instantiation always runs on these)
     ProfScope ps((void*)s, FAM_GROUNDING, 2.0 * rows * EC_D * (qkv_out ? 7.0 : 4.0) * EC_D, 4.0 * rows * (qkv_out ? 5.0 : 3.0) * EC_D);
     static const int waves = getenv("BIGC_ENC_WAVES") ? atoi(getenv("BIGC_ENC_WAVES")) : 8;
+    // k = 7, launches of several 128-row tiles per CU: sixteen waves on 128 rows (104 of them exact instead of 40 of 64)
+    static const int big_env = getenv("BIGC_ENC_TILE128") ? atoi(getenv("BIGC_ENC_TILE128")) : -1;
+    const int tr128 = 128 - 8 * (E.ks / 2);
+    const long tiles128 = (rows + tr128 - 1) / tr128;
+    const bool big = E.ks == 7 && waves == 8 && (big_env >= 0 ? big_env != 0 : tiles128 >= 1024);
+    constexpr size_t lds64 = sizeof(EcSmemT<64>), lds128 = sizeof(EcSmemT<128>);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)grd_enc_chain_kernel<7, false, 16, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        (void)hipFuncSetAttribute((const void*)grd_enc_chain_kernel<7, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+        (void)hipFuncSetAttribute((const void*)grd_enc_chain_kernel<7, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+        (void)hipFuncSetAttribute((const void*)grd_enc_chain_kernel<7, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+        (void)hipFuncSetAttribute((const void*)grd_enc_chain_kernel<3, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+        (void)hipFuncSetAttribute((const void*)grd_enc_chain_kernel<3, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+        (void)hipFuncSetAttribute((const void*)grd_enc_chain_kernel<3, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+    });
     if (E.ks == 7) {
-        if (waves == 8) hipLaunchKernelGGL((grd_enc_chain_kernel<7, false, 8>), dim3((unsigned)tiles), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((grd_enc_chain_kernel<7, false, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((grd_enc_chain_kernel<7, true, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);     // gated: returns at once when no flag is up
+        if (big) hipLaunchKernelGGL((grd_enc_chain_kernel<7, false, 16, 128>), dim3((unsigned)tiles128), dim3(1024), lds128, s, a);
+        else if (waves == 8) hipLaunchKernelGGL((grd_enc_chain_kernel<7, false, 8>), dim3((unsigned)tiles), dim3(512), lds64, s, a);
+        else hipLaunchKernelGGL((grd_enc_chain_kernel<7, false, 4>), dim3((unsigned)tiles), dim3(256), lds64, s, a);
+        hipLaunchKernelGGL((grd_enc_chain_kernel<7, true, 4>), dim3((unsigned)tiles), dim3(256), lds64, s, a);     // gated: returns at once when no flag is up
     } else {
-        if (waves == 8) hipLaunchKernelGGL((grd_enc_chain_kernel<3, false, 8>), dim3((unsigned)tiles), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((grd_enc_chain_kernel<3, false, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((grd_enc_chain_kernel<3, true, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+        if (waves == 8) hipLaunchKernelGGL((grd_enc_chain_kernel<3, false, 8>), dim3((unsigned)tiles), dim3(512), lds64, s, a);
+        else hipLaunchKernelGGL((grd_enc_chain_kernel<3, false, 4>), dim3((unsigned)tiles), dim3(256), lds64, s, a);
+        hipLaunchKernelGGL((grd_enc_chain_kernel<3, true, 4>), dim3((unsigned)tiles), dim3(256), lds64, s, a);
     }
     BIGC_LAUNCH_CHECK("grd_enc_chain");
     return BIGC_OK;

@@ -33,6 +33,7 @@ class GrdEngine(object):
         self._keep = None
         self._ws = None
         self._tables = {}
+        self._clip_cat = {}
 
     def __del__(self):
         try:
@@ -173,7 +174,12 @@ class GrdEngine(object):
         vid_row_off, q_vid_d, q_row_off = [blob_d[o:o + len(a)] for a, o in zip(tables, starts)]
         vlen = _lib.upload(np.asarray([float(j[3]) for j in jobs], dtype=np.float32), dev)
         pos_v, pos_q, _ = self.tables(max_T, dev)
-        clip = torch.cat([self.tables(int(t), dev)[2] for t in T])
+        ckey = (tuple(int(t) for t in T), str(dev))          # the clips' normalised positions of this group of videos, back to back
+        clip = self._clip_cat.get(ckey)
+        if clip is None:
+            if len(self._clip_cat) >= 64:
+                self._clip_cat.clear()
+            clip = self._clip_cat[ckey] = torch.cat([self.tables(int(t), dev)[2] for t in T])
         b = _lib.grd_batch()
         b.n_vid, b.n_query, b.max_T, b.total_T, b.total_rows = V, Q, max_T, total_T, total_rows
         b.vid_row_off, b.q_vid, b.q_row_off, b.vid_len = vid_row_off.data_ptr(), q_vid_d.data_ptr(), q_row_off.data_ptr(), vlen.data_ptr()
@@ -181,7 +187,7 @@ class GrdEngine(object):
             "pooled_se": torch.empty((Q, k + 1, 2), dtype=torch.float32, device=dev),
             "bins_probs": torch.empty((Q, k + 1), dtype=torch.float32, device=dev),
             "bins_mask": torch.empty((Q, k + 1), dtype=torch.uint8, device=dev),
-            "status": torch.zeros((1 + V,), dtype=torch.int32, device=dev),
+            "status": torch.empty((1 + V,), dtype=torch.int32, device=dev),          # (zeroed by grd_forward_batch on its stream)
         }
         o = _lib.grd_outputs()
         for name, _ in _lib.grd_outputs._fields_:

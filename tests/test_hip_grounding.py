@@ -402,3 +402,30 @@ def test_query_encoder_stream_and_fused_in_proj_against_the_plain_sequence():
         assert rel(res["plain_in_proj"][k], v) < 5e-5, (k, rel(res["plain_in_proj"][k], v))
         # co-attention and vq_fc as two launches (the (rows, 4 d) tensor in memory, one GEMM over K = 4 d)
         assert rel(res["two_kernel_coatt"][k], v) < 5e-5, (k, rel(res["two_kernel_coatt"][k], v))
+
+
+def test_grounding_forward_repeats_bit_for_bit_across_interleaved_batches():
+    """The query encoder runs on the handle's second stream with its own scratch, joined into the caller's stream before the co-attention:
+    two different batches scored alternately, twenty times, give their first results again every time (a missing dependency between the
+    streams, or scratch shared by them, would show as differing bits)."""
+    cfg = dict(cases.GRD_CASES["grd_g_n64"]["cfg"])
+    _, sd, _ = cases.make_grd_case("grd_g_n64")
+    model = build_model(dict(cfg, loss_factor=dict(classification=1.0, centerness=1.0, regression=1.0)), sd)
+    batches = []
+    for bi, shapes in enumerate([[(61, 7), (138, 11), (97, 30)], [(20, 40), (250, 3)]]):
+        jobs = []
+        for v, (T, n) in enumerate(shapes):
+            feat, (quint, dura, vl) = cases.make_grd_inputs(cfg, dict(seed=1100 + 10 * bi + v, T=T, n=n, video_len=8 * T - 1))
+            jobs.append((feat.to(DEV), quint, dura, vl))
+        batches.append(jobs)
+    first = [None, None]
+    for it in range(20):
+        bi = it & 1
+        outs = model.forward_raw_batch(batches[bi], **cases.GRD_TH)
+        got = [{k: o[k].clone() for k in ("pooled_se", "bins_probs", "bins_mask")} for o in outs]
+        if first[bi] is None:
+            first[bi] = got
+            continue
+        for v, (a, b) in enumerate(zip(first[bi], got)):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (it, v, k)

@@ -81,3 +81,44 @@ def test_grounding_training_step_is_bit_reproducible(name):
         out.update({"loss:" + k: v.detach().clone() for k, v in terms.items()})
         runs.append(out)
     assert not _same(runs), _same(runs)[:10]
+
+
+_DW_STREAM_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+repo = os.environ["BIGC_REPO"]
+sys.path.insert(0, os.path.join(repo, "tests")); sys.path.insert(0, os.path.join(repo, "tests", "golden"))
+import cases
+from test_hip_train import build_train_model
+out = {}
+for name in ("bigc_train_v64", "bigo_train_o"):
+    cfg, variant, sd, props, gts = cases.make_train_case(name)
+    model = build_train_model(cfg, variant, sd)
+    total, terms = model([p.to("cuda:0") for p in props], gts)
+    total.sum().backward()
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            out[name + ":" + k] = p.grad.cpu().numpy()
+    out[name + ":loss"] = total.detach().cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_decoder_weight_gradients_on_their_own_stream_give_the_same_bits():
+    """Round 6: at big batches the decoder layers' grouped weight-gradient launches run on a stream of the handle's beside the next layer's
+    backward chain (two buffer sets, fork / join by events; csrc/train.hip).  Forced on and forced off: every gradient, bit for bit."""
+    import os, subprocess, sys, tempfile
+    import numpy as np
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tempfile.mkdtemp()
+    res = {}
+    for tag in ("0", "1"):
+        path = os.path.join(d, "dw_stream_" + tag + ".npz")
+        r = subprocess.run([sys.executable, "-c", _DW_STREAM_SCRIPT, path], env=dict(os.environ, BIGC_REPO=repo, BIGC_DW_STREAM=tag),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = dict(np.load(path))
+    assert set(res["0"]) == set(res["1"]) and len(res["0"]) > 60
+    for k, v in res["0"].items():
+        assert np.array_equal(v, res["1"][k], equal_nan=True), k

@@ -185,6 +185,8 @@ extern "C" void bigc_destroy(bigc_model* m) {
     if (m->role_cat) (void)hipFree(m->role_cat);
     if (m->enco_cat) (void)hipFree(m->enco_cat);
     if (m->conv_w_bwd) (void)hipFree(m->conv_w_bwd);
+    for (int i = 0; i < 3; ++i) if (m->dw_ev[i]) (void)hipEventDestroy((hipEvent_t)m->dw_ev[i]);
+    if (m->dw_stream) (void)hipStreamDestroy((hipStream_t)m->dw_stream);
     if (m->qkpos) (void)hipFree(m->qkpos);
     delete m;
 }

@@ -28,6 +28,7 @@ struct bigc_model {
     unsigned long long role_cat_epoch = 0;   // weights epoch role_cat was built for (built lazily by the eval forward)
     float* role_cat = nullptr;         // per decoder layer: [W_role0.2 | W_role1.2] (dp, 2 dp) then b_role0.2 + b_role1.2 (dp), owned
     float* conv_w_bwd = nullptr;       // (2de, 3*de), owned (training)
+    void* dw_stream = nullptr; void* dw_ev[3] = {nullptr, nullptr, nullptr};   // the decoder's grouped weight-gradient launches run beside the backward chain (train.hip), created at first use
     unsigned long long enco_cat_epoch = 0;
     float* enco_cat = nullptr;         // all decoder layers: [W_e2a; W_role0.0; W_role1.0] (n_layers (da + 2 dp), de), then the biases [b_e2a | 0] per layer, owned (model.hip: build_enco_cat)
     unsigned long long qkpos_epoch = 0;

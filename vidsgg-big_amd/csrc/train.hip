@@ -82,6 +82,7 @@ struct TrainWork {
     float *gq, *ga, *gb, *gc, *gqk, *gvals, *gp2a, *ghead, *ghh, *gatt, *ds, *genco, *ge2e, *gx, *gy, *gz, *gqkv, *ge2a, *gi3d,
           *gpooled, *delta, *gconv, *G, *genti, *gh, *wT, *gconvw;
     float* gd[8];      // decoder layer: one buffer per gradient that a deferred weight-gradient product reads (see the decoder loop)
+    float* alt[10];    // a second set of the ten buffers such products read (ga gb gc gd1 gd2 gd5 gd6 gqk gp2a ge2a): odd layers, when the products run on their own stream
 };
 
 struct TSizes { size_t R, NT, C, B, Q, BQ; };
@@ -129,6 +130,8 @@ bool train_layout(const bigc_model* m, const TSizes& z, Arena& a, TrainWork& w) 
     // backward scratch
     w.gq = a.take<float>(z.BQ * mx); w.ga = a.take<float>(z.BQ * mx); w.gb = a.take<float>(z.BQ * mx); w.gc = a.take<float>(z.BQ * mx);
     for (int i = 0; i < 8; ++i) w.gd[i] = a.take<float>(z.BQ * mx);
+    for (int i = 0; i < 7; ++i) w.alt[i] = a.take<float>(z.BQ * mx);
+    w.alt[7] = a.take<float>(z.BQ * 2 * dp); w.alt[8] = a.take<float>(z.BQ * da); w.alt[9] = a.take<float>(z.NT * da);
     w.gqk = a.take<float>(z.BQ * 2 * dp);
     w.gvals = a.take<float>(2 * z.BQ * de);
     w.gp2a = a.take<float>(z.BQ * da);
@@ -176,6 +179,29 @@ struct Bwd {
     // the flush (the decoder layer below hands every gradient a buffer of its own).
     bool defer = false;
     std::vector<BigcDwJob> pending;
+    // The grouped launches on a stream of their own (decoder): forked from the caller's stream when the layer's chain has been issued, so
+    // that they run beside the NEXT layer's chain (at the reference's batch of 8 videos neither fills the chip); that layer works on the
+    // other buffer set, and the one after it waits for this launch before it reuses the set (wait_set); join() at the end of the pass.
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_done[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int flush_side(int set) {
+        if (pending.empty()) return BIGC_OK;
+        if (hipEventRecord(ev_fork, (hipStream_t)s) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)
+            return bigc_fail(BIGC_ERR_HIP, "train_backward: stream fork failed");
+        int rc = bigc_linear_dw_group((void*)side, pending.data(), (int)pending.size());
+        pending.clear();
+        if (rc != BIGC_OK) return rc;
+        if (hipEventRecord(ev_done[set], side) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: event record failed");
+        busy[set] = true;
+        return BIGC_OK;
+    }
+    int wait_set(int set) {
+        if (!busy[set]) return BIGC_OK;
+        busy[set] = false;
+        if (hipStreamWaitEvent((hipStream_t)s, ev_done[set], 0) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: stream join failed");
+        return BIGC_OK;
+    }
+    int join() { int rc = wait_set(0); if (rc == BIGC_OK) rc = wait_set(1); return rc; }
     int dw(const float* dY, int ldy, const float* X, int ldx, float* gw, int ldw, float* gb, int M, int N, int K) {
         if (!gw) return BIGC_OK;
         if (defer) { pending.push_back(BigcDwJob{dY, ldy, X, ldx, gw, ldw, gb, M, N, K}); return BIGC_OK; }
@@ -559,12 +585,30 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
     // 224 tiles with the whole B*Q contraction split in two, instead of eleven launches of 16 tiles x 32 splits + eleven reductions).
     static const bool group_off = getenv("BIGC_DW_GROUP") && atoi(getenv("BIGC_DW_GROUP")) == 0;
     bw.defer = !group_off && !bigc_linear_get_exact();
+    // (measured: 64 videos 23.9 -> 23.5 ms per step; at 8 videos the forks and joins cost more than the overlap returns, 8.4 -> 8.7 ms: big
+    // batches only; BIGC_DW_STREAM=0 / 1 forces it off / on)
+    static const int dw_stream_env = getenv("BIGC_DW_STREAM") ? atoi(getenv("BIGC_DW_STREAM")) : -1;
+    const bool dw_side = bw.defer && (dw_stream_env >= 0 ? dw_stream_env != 0 : BQ >= 32 * 192);
+    if (dw_side) {
+        if (!m->dw_stream) {
+            hipStream_t st = nullptr; hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: could not create a stream");
+            for (int j = 0; j < 3; ++j)
+                if (hipEventCreateWithFlags(&e[j], hipEventDisableTiming) != hipSuccess) return bigc_fail(BIGC_ERR_HIP, "train_backward: could not create an event");
+            m->dw_stream = st; for (int j = 0; j < 3; ++j) m->dw_ev[j] = e[j];
+        }
+        bw.side = (hipStream_t)m->dw_stream; bw.ev_fork = (hipEvent_t)m->dw_ev[0]; bw.ev_done[0] = (hipEvent_t)m->dw_ev[1]; bw.ev_done[1] = (hipEvent_t)m->dw_ev[2];
+    }
     for (int i = c.n_deco_layers - 1; i >= 0; --i) {
         const DecLayer& L = m->dec[i];
         DecS& S = w.dec[i];
         const std::string p = "decoder_layers." + std::to_string(i);
+        const int set = dw_side ? ((c.n_deco_layers - 1 - i) & 1) : 0;
+        if (dw_side) TRY(bw.wait_set(set));                  // the products of the layer before last have read this set
         float *A1 = w.ga, *B1 = w.gb, *A2 = w.gd[0], *B2 = w.gd[1], *C1 = w.gc, *C0 = w.gd[2], *B3 = w.gd[3], *C2 = w.gd[4], *A3 = w.gd[5],
               *V1 = w.gd[6], *A4 = w.gd[7];
+        float *gqk = w.gqk, *gp2a = w.gp2a, *ge2a = w.ge2a;
+        if (set) { A1 = w.alt[0]; B1 = w.alt[1]; C1 = w.alt[2]; B2 = w.alt[3]; C0 = w.alt[4]; A3 = w.alt[5]; V1 = w.alt[6]; gqk = w.alt[7]; gp2a = w.alt[8]; ge2a = w.alt[9]; }
         // w.gq = d qout
         TRY(bigc_layernorm_bwd_f32(s, S.t3c, L.n3.g, w.gq, A1, grad_of(m, p + ".norm3.weight"), grad_of(m, p + ".norm3.bias"), BQ, dp, eps));
         // A1 = d t3c ; t3c = f W3^T + b + q3
@@ -583,9 +627,9 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
         TRY(bigc_role_small_gemm_pair_f32(s, 0, S.att, w.gvals, de, enco, de, w.gatt, w.genco, de, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
         if (i == c.n_deco_layers - 1) TRY(bigc_axpy_f32(s, w.gatt, datt, (long)2 * Q * NT));
         TRY(bigc_role_attention_bwd_launch(s, S.p2a, da, S.e2a, da, w.gatt, w.ds, b->vid_trk_off, B, Q, da / 2, att_scale, b->max_trk));
-        TRY(bigc_role_small_gemm_pair_f32(s, 1, w.ds, S.p2a, da, S.e2a, da, w.gp2a, w.ge2a, da, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
-        TRY(bw.lin_res(p + ".fc_pred2att", L.p2a, w.gp2a, da, S.q2, dp, BQ, da, dp, B2, B3, dp));             // B3 = d q2 total
-        TRY(bw.lin(p + ".fc_enti2att", L.e2a, w.ge2a, da, enco, de, NT, da, de, w.genco, de, true));
+        TRY(bigc_role_small_gemm_pair_f32(s, 1, w.ds, S.p2a, da, S.e2a, da, gp2a, ge2a, da, b->vid_trk_off, B, Q, de, da / 2, b->max_trk));
+        TRY(bw.lin_res(p + ".fc_pred2att", L.p2a, gp2a, da, S.q2, dp, BQ, da, dp, B2, B3, dp));             // B3 = d q2 total
+        TRY(bw.lin(p + ".fc_enti2att", L.e2a, ge2a, da, enco, de, NT, da, de, w.genco, de, true));
         // q2 = LN1(t2) + pos
         if (gpos) TRY(bigc_reduce_periodic_f32(s, B3, gpos, BQ, dp, Q));
         const int rows = (i == 0) ? Q : BQ, nseq = (i == 0) ? 1 : B;
@@ -599,23 +643,23 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
         // A3 = d t2 ; t2 = ao2 Wo^T + b + qin
         const float* qin = (i == 0) ? m->qinit : w.dec[i - 1].qout;
         TRY(bw.lin(p + ".self_attn.out_proj", L.out_proj, A3, dp, S.ao2, dp, rows, dp, dp, w.gq, dp, false));   // gq = d ao2 (d qout is consumed)
-        TRY(bigc_mha_bwd_drop_f32(s, S.qk, 2 * dp, S.qk + dp, 2 * dp, S.vv, dp, S.ao2, dp, w.gq, dp, S.lse, w.delta, w.gqk, 2 * dp, w.gqk + dp,
+        TRY(bigc_mha_bwd_drop_f32(s, S.qk, 2 * dp, S.qk + dp, 2 * dp, S.vv, dp, S.ao2, dp, w.gq, dp, S.lse, w.delta, gqk, 2 * dp, gqk + dp,
                                   2 * dp, V1, dp, w.q_off, w.q_off, nseq, Q, Q, rows, H, dp / H, dp_, ds_, dec_site(i, 0)));
         // in_proj: [q;k] rows from qk_in, v rows from qin
         {
             float* gw = grad_of(m, p + ".self_attn.in_proj_weight");
             float* gbias = grad_of(m, p + ".self_attn.in_proj_bias");
             if (gw) {
-                TRY(bw.dw(w.gqk, 2 * dp, S.qk_in, dp, gw, dp, gbias, rows, 2 * dp, dp));
+                TRY(bw.dw(gqk, 2 * dp, S.qk_in, dp, gw, dp, gbias, rows, 2 * dp, dp));
                 TRY(bw.dw(V1, dp, qin, dp, gw + (size_t)2 * dp * dp, dp, gbias ? gbias + 2 * dp : nullptr, rows, dp, dp));
             }
         }
         // d qin = d t2 (residual) + d vv Wv + d qk_in ; d qk_in = d qk Wqk ; d pos += d qk_in
         TRY(bw.dx_res(L.in_proj.w + (size_t)2 * dp * dp, V1, dp, rows, dp, dp, A3, A4, dp));
-        TRY(bw.dx(L.in_proj.w, w.gqk, 2 * dp, rows, 2 * dp, dp, w.gq, dp, false));                         // gq = d qk_in (d ao2 is consumed)
+        TRY(bw.dx(L.in_proj.w, gqk, 2 * dp, rows, 2 * dp, dp, w.gq, dp, false));                         // gq = d qk_in (d ao2 is consumed)
         if (gpos) TRY(bigc_reduce_periodic_f32(s, w.gq, gpos, rows, dp, Q));
         TRY(bigc_axpy_f32(s, A4, w.gq, (long)rows * dp));                                                    // A4 = d qin
-        TRY(bw.flush());                                                                                     // the layer's weight gradients
+        if (dw_side) TRY(bw.flush_side(set)); else TRY(bw.flush());                                           // the layer's weight gradients
         if (i == 0) {
             if (float* gqi = grad_of(m, "pred_query_init")) TRY(bigc_reduce_periodic_f32(s, A4, gqi, Q, dp, Q));
         } else {
@@ -667,6 +711,7 @@ extern "C" int bigc_train_backward(bigc_model* m, void* stream, const bigc_batch
     TRY(bigc_axpy_f32(s, gx, w.ge2e, (long)NT * de));                                                  // + head gather path
 
     TRY(frontend_train_backward(m, s, b, w, bw, gx));
+    TRY(bw.join());              // (the decoder's weight-gradient launches: before the LayerNorm finishes of FinishScope and the caller's optimizer)
     return BIGC_OK;
 }
 

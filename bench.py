@@ -289,9 +289,13 @@ def main():
         lib.bigc_prof_enable(0)
         families = collect_families(lib, args.steps)
 
+    # every rank leaves the process group HERE, at the same point (the legs below are rank 0's alone and use no collective): a teardown on
+    # rank 0 long after its peers have exited is the one asymmetric step of the N > 1 run, and the RCCL banner a rank prints when its
+    # communicator goes away then lands well before the final line
+    if dist is not None:
+        dist.destroy_process_group()
+        dist = None
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
         return
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -500,10 +504,8 @@ def main():
     if "train" in want:
         from legs.train import train_leg
         detail["train"] = run_leg("train", lambda: train_leg(args, lib, device, budget=lambda: over_budget(args)))
-    if dist is not None:
-        dist.destroy_process_group()       # (before the final line: see legs/common.py print_last)
-        if world > 1:
-            time.sleep(1.0)                # the other ranks (whose output the launcher merges into the same stream) have exited by then
+    if world > 1:
+        time.sleep(1.0)                    # the other ranks (whose output the launcher merges into the same stream) have exited by then
     emit(detail, args)
 
 

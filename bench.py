@@ -172,6 +172,9 @@ def compact_line(d):
         if k in t:
             legs["train_" + k[7:]] = {"value": t[k]["value"], "ms": t[k]["ms_per_step"], "gemm_frac": (t[k].get("roofline") or {}).get("frac"),
                                       "attn_bwd_ms": (t[k].get("kernel_families_ms_per_step") or {}).get("attention_bwd")}
+    gt = d.get("grd_train")
+    if gt and "value" in gt:
+        legs["grd_train_8"] = {"value": gt["value"], "ms": gt["ms_per_step"], "unit": "videos/s"}
     rc = d.get("recall")
     if rc and "recall50_hip" in rc:
         legs["recall"] = {"r50_hip": round(rc["recall50_hip"], 4), "r50_oracle": round(rc["recall50_oracle"], 4), "gate": rc["parity_gate_passed"],
@@ -504,6 +507,9 @@ def main():
     if "train" in want:
         from legs.train import train_leg
         detail["train"] = run_leg("train", lambda: train_leg(args, lib, device, budget=lambda: over_budget(args)))
+        if "grounding" in want:
+            from legs.train import grd_train_leg
+            detail["grd_train"] = run_leg("grd_train", lambda: grd_train_leg(args, lib, device))
     if world > 1:
         time.sleep(1.0)                    # the other ranks (whose output the launcher merges into the same stream) have exited by then
     emit(detail, args)

@@ -177,3 +177,53 @@ def train_leg(args, lib, device, budget=None):
                        "backward + clip_grad_norm_ + Adam (tools/train_vidvrd.py:151-164)" % args.n_trajs)
     return out
 
+
+
+def grd_train_leg(args, lib, device):
+    """BASELINE configs[5], grounding stage: the training step of the temporal grounding scorer (models/grd_model_v5.py:224-306,375-527;
+    tools/train_vidor.py:497-636) at the reference's batch of 8 videos (experiments/grounding_weights/config_.py:66), config G dims:
+    zero_grad + forward (GT queries + drawn negatives) + the three losses + backward + Adam, on synthetic clip features and GT graphs."""
+    import tempfile
+    from models import DEBUG
+    from bigc_hip.synthetic import grd_state_shapes, synthetic_gt_graph
+    gcfg = dict(configs.CONFIG_G)
+    gcfg["loss_factor"] = dict(classification=1.0, centerness=1.0, regression=1.0)
+    gsd = seeded_state_dict(grd_state_shapes(gcfg), 12, 2.0)
+    d = tempfile.mkdtemp()
+    np.save(d + "/ge.npy", gsd["EntiNameEmb"].numpy())
+    np.save(d + "/gp.npy", gsd["PredNameEmb"].numpy())
+    model = DEBUG(dict(gcfg, EntiNameEmb_path=d + "/ge.npy", PredNameEmb_path=d + "/gp.npy"), is_train=True)
+    model.load_state_dict(gsd)
+    model = model.to(device)
+    rs = np.random.RandomState(4711)
+    feats, gts, n_pred = [], [], 0
+    for v, L in enumerate([480, 800, 1100, 1400, 1800, 2200, 2700, 3200]):          # video lengths of the eval grounding leg: T = ceil(L / 8) in [60, 400]
+        p = synthetic_proposal(9100 + v, n_trajs=16, feat_width=4, num_enti_cats=gcfg.get("num_enti_cats", 81), len_range=(L // 4, L // 2), start_range=(0, L // 2))
+        g = synthetic_gt_graph(p, 9200 + v, n_gt_trajs=8, n_preds=10, num_pred_cats=gcfg.get("num_pred_cats", 51))
+        T = -(-int(p.video_len) // 8)
+        feats.append(torch.from_numpy((0.1 * rs.standard_normal((T, gcfg["dim_feat"]))).astype(np.float32)).to(device))
+        gts.append(g)
+        n_pred += int(g.num_preds)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-5, fused=True)
+
+    def step():
+        opt.zero_grad()
+        torch.manual_seed(1000)                      # (the negative predicates are drawn from the global RNG, models/grd_model_v5.py:285-303)
+        total, terms = model(feats, gts)
+        total.backward()
+        opt.step()
+        return total.detach()
+
+    steps = 8
+    el, el_prof, fam = timed_with_events(lib, step, 4, steps)
+    kern_ms = sum(v["ms"] for v in fam.values()) / steps
+    out = dict(value=round(len(feats) * steps / el, 1), unit="videos/s", ms_per_step=round(1e3 * el / steps, 3), steps=steps,
+               ms_per_step_of_each_repeat=timed_with_events.last_repeats_ms, videos=len(feats), gt_predicates=n_pred,
+               clips=[int(f.shape[0]) for f in feats], kernel_ms_per_step=round(kern_ms, 3),
+               kernel_families_ms_per_step={k: round(v["ms"] / steps, 3) for k, v in fam.items()},
+               launches_per_step={k: v["launches"] // steps for k, v in fam.items()},
+               workload="grounding scorer training step (BASELINE configs[5], grd_model_v5 DEBUG config G, batch 8 as experiments/grounding_weights/config_.py:66): "
+                        "zero_grad + forward on the GT queries and drawn negatives + classification / centerness / regression losses + backward + Adam")
+    del model, opt
+    torch.cuda.empty_cache()
+    return out

@@ -126,3 +126,59 @@ def test_grd_train_with_dropout_matches_oracle_with_same_masks():
             continue
         err = float((p.grad.cpu() - ref).abs().max())
         assert err <= 1e-3 * max(float(ref.abs().max()), 1e-12), (k, err, float(ref.abs().max()))
+
+
+_STREAMS_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+repo = os.environ["BIGC_REPO"]
+sys.path.insert(0, os.path.join(repo, "tests")); sys.path.insert(0, os.path.join(repo, "tests", "golden"))
+import cases
+from test_hip_grd_train import build_model, DEV
+from bigc_hip.synthetic import synthetic_gt_graph
+from cases import synthetic_proposal
+cfg, sd, _, _, seed = cases.make_grd_train_case("grd_train_g")
+model = build_model(cfg, sd)
+rs = np.random.RandomState(5)
+feats, gts = [], []
+for v, T in enumerate([40, 23, 61, 9, 33]):
+    p = synthetic_proposal(3100 + v, n_trajs=10, feat_width=4, num_enti_cats=81, len_range=(30, 64), start_range=(0, 20))
+    gts.append(synthetic_gt_graph(p, 3200 + v, n_gt_trajs=6, n_preds=7, num_pred_cats=51))
+    feats.append(torch.from_numpy((0.1 * rs.standard_normal((T, cfg["dim_feat"]))).astype(np.float32)).to(DEV))
+out = {}
+for step in range(3):                      # the first step of a model runs on one stream (it records the weights a step prepares)
+    model.zero_grad()
+    torch.manual_seed(seed)
+    total, terms = model(feats, gts)
+    total.backward()
+    torch.cuda.synchronize()
+    if step:
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                out["s%d:%s" % (step, k)] = p.grad.cpu().numpy()
+        out["s%d:loss" % step] = np.asarray([float(total)] + [float(terms[k]) for k in sorted(terms)])
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_videos_of_a_training_batch_on_their_own_streams():
+    """Round 6: from a model's second step on, the videos of a batch run on streams of the engine's (forward: video 0 on the caller's
+    stream, where the step's weights are prepared, the others forked behind it; backward: one flat gradient buffer per stream, added in a
+    fixed order).  Two runs give the same bits; one stream (BIGC_GRD_TRAIN_STREAMS=1: the sums in another order) the same values to f32
+    rounding; steps 2 and 3 of a run (same weights, same seed) the same bits."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tempfile.mkdtemp()
+    res = {}
+    for tag, env in (("a", {}), ("b", {}), ("one", {"BIGC_GRD_TRAIN_STREAMS": "1"})):
+        path = os.path.join(d, tag + ".npz")
+        r = subprocess.run([sys.executable, "-c", _STREAMS_SCRIPT, path], env=dict(os.environ, BIGC_REPO=repo, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = dict(np.load(path))
+    assert len(res["a"]) > 100
+    for k, v in res["a"].items():
+        assert np.array_equal(v, res["b"][k], equal_nan=True), k
+        if k.startswith("s1:"):
+            assert np.array_equal(v, res["a"]["s2:" + k[3:]], equal_nan=True), k
+        w = res["one"][k]
+        assert np.abs(v - w).max() <= 2e-5 * max(np.abs(w).max(), 1e-12), (k, float(np.abs(v - w).max()), float(np.abs(w).max()))

@@ -83,6 +83,18 @@ class _Video(object):
     pass
 
 
+def _side_streams(engine, dev):
+    """streams of the engine for the videos of a training batch (BIGC_GRD_TRAIN_STREAMS, default 8 = the reference's batch size; 0 or 1 = the caller's stream only)"""
+    import os
+    n = int(os.environ.get("BIGC_GRD_TRAIN_STREAMS", "8"))
+    if n <= 1:
+        return []
+    st = getattr(engine, "_train_streams", None)
+    if st is None or len(st) != n or st[0].device != dev:
+        st = engine._train_streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return st
+
+
 def forward(model, engine, video_feature_list, gt_graph_list):
     """-> (loss terms (5,) device tensor in LOSS_KEYS order, context for ``backward``)"""
     lib, c = engine.lib, engine.c
@@ -116,14 +128,38 @@ def forward(model, engine, video_feature_list, gt_graph_list):
         v.ws = torch.empty((need,), dtype=torch.uint8, device=dev)             # activations live until the backward
         v.pos_v, v.pos_q, v.clip = engine.tables(v.T, dev)
         v.drop = (drop_p, int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0)
-        _lib.check(lib.grd_set_dropout(engine.handle, v.drop[0], v.drop[1]))
-        _lib.check(lib.grd_train_forward(engine.handle, stream, v.feat.data_ptr(), v.T, v.quint.data_ptr(), v.dura.data_ptr(), v.n,
-                                         v.video_len, v.pos_v.data_ptr(), v.pos_q.data_ptr(), v.ws.data_ptr(), v.ws.numel(),
-                                         v.regrs.data_ptr(), v.conf.data_ptr(), v.cls.data_ptr()))
         v.dregr = torch.zeros((v.n * v.T, ldr), dtype=torch.float32, device=dev)
         v.dconf = torch.zeros((v.n * v.T, ldc), dtype=torch.float32, device=dev)
         v.dcls = torch.zeros((v.n * v.T, ldc), dtype=torch.float32, device=dev)
         vids.append(v)
+
+    def launch(v):
+        _lib.check(lib.grd_set_dropout(engine.handle, v.drop[0], v.drop[1]))
+        _lib.check(lib.grd_train_forward(engine.handle, _lib.current_stream(), v.feat.data_ptr(), v.T, v.quint.data_ptr(), v.dura.data_ptr(), v.n,
+                                         v.video_len, v.pos_v.data_ptr(), v.pos_q.data_ptr(), v.ws.data_ptr(), v.ws.numel(),
+                                         v.regrs.data_ptr(), v.conf.data_ptr(), v.cls.data_ptr()))
+
+    # The videos of a batch are independent until the loss (the reference runs them one after the other, models/grd_model_v5.py:377) and
+    # each is a few hundred launches that fill a fraction of the chip: from the second step on -- the first records which weights the step
+    # prepares (split forms, transposed copies) -- video 0 runs on the caller's stream, where that preparation is launched, and the others
+    # on a few streams of the engine's, forked behind it and joined before the loss.  Every tensor is allocated on the caller's stream.
+    side = _side_streams(engine, vids[0].feat.device) if (len(vids) > 1 and getattr(engine, "_train_steps", 0) >= 1) else []
+    launch(vids[0])
+    if side:
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for i, v in enumerate(vids[1:]):
+            st = side[i % len(side)]
+            if i < len(side):
+                st.wait_event(ready)
+            with torch.cuda.stream(st):
+                launch(v)
+        for st in side[:len(vids) - 1]:
+            main.wait_stream(st)
+    else:
+        for v in vids[1:]:
+            launch(v)
     ctx = _Video()
     ctx.vids = vids
     ctx.count_pos = float(sum(v.n_pos * v.T for v in vids))
@@ -159,22 +195,47 @@ def backward(model, engine, ctx, grad_terms, named_params):
     dev = ctx.vids[0].feat.device
     trainable = [(k, p) for k, p in named_params if p.requires_grad]
     sizes = [(p.numel() + 3) // 4 * 4 for _, p in trainable]
-    flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)
-    views, off = {}, 0
-    for (k, p), sz in zip(trainable, sizes):
-        views[k] = flat[off:off + p.numel()].view_as(p)
-        _lib.check(engine.lib.grd_set_grad(engine.handle, k.encode(), views[k].data_ptr()))
-        off += sz
+    # (as in the forward: not in a model's first step, whose backward is where the transposed weight copies are made and recorded)
+    side = _side_streams(engine, dev) if (len(ctx.vids) > 1 and getattr(engine, "_train_steps", 0) >= 1) else []
+    n_slot = max(1, min(len(side), len(ctx.vids)))
+    # one flat gradient buffer per stream: the videos of a stream add into it in order, the buffers are added in order at the end
+    flats = [torch.zeros((sum(sizes),), dtype=torch.float32, device=dev) for _ in range(n_slot)]
     for k, p in named_params:
         if not p.requires_grad:
             _lib.check(engine.lib.grd_set_grad(engine.handle, k.encode(), None))
-    stream = _lib.current_stream()
-    for v in ctx.vids:
-        _lib.check(engine.lib.grd_set_dropout(engine.handle, v.drop[0], v.drop[1]))       # the masks of this video's forward
-        _lib.check(engine.lib.grd_train_backward(engine.handle, stream, v.feat.data_ptr(), v.T, v.quint.data_ptr(), v.n, v.ws.data_ptr(),
-                                                 v.ws.numel(), v.dregr.data_ptr(), v.dconf.data_ptr(), v.dcls.data_ptr()))
+
+    def run(slot):
+        off = 0
+        for (k, p), sz in zip(trainable, sizes):
+            _lib.check(engine.lib.grd_set_grad(engine.handle, k.encode(), flats[slot][off:off + p.numel()].data_ptr()))
+            off += sz
+        for v in ctx.vids[slot::n_slot]:
+            _lib.check(engine.lib.grd_set_dropout(engine.handle, v.drop[0], v.drop[1]))       # the masks of this video's forward
+            _lib.check(engine.lib.grd_train_backward(engine.handle, _lib.current_stream(), v.feat.data_ptr(), v.T, v.quint.data_ptr(), v.n,
+                                                     v.ws.data_ptr(), v.ws.numel(), v.dregr.data_ptr(), v.dconf.data_ptr(), v.dcls.data_ptr()))
+
+    if side:
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for slot in range(n_slot):
+            side[slot].wait_event(ready)
+            with torch.cuda.stream(side[slot]):
+                run(slot)
+        for slot in range(n_slot):
+            main.wait_stream(side[slot])
+    else:
+        run(0)
+    flat = flats[0]
+    for other in flats[1:]:
+        flat.add_(other)
+    views, off = {}, 0
+    for (k, p), sz in zip(trainable, sizes):
+        views[k] = flat[off:off + p.numel()].view_as(p)
+        off += sz
     if scale != 1.0:
         flat.mul_(1.0 / scale)
+    engine._train_steps = getattr(engine, "_train_steps", 0) + 1
     engine.last_flat_grad = flat
     return [views.get(k) for k, _ in named_params]
 

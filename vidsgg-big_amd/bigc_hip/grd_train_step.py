@@ -115,11 +115,12 @@ def forward(model, engine, video_feature_list, gt_graph_list):
         v.n = int(quint.shape[0])
         pos, neg, v.n_mask = bin_entries(target, index_map, v.n, k, v.T)
         v.n_pos, v.n_neg = len(pos), len(neg)
-        v.quint = quint.to(device=dev, dtype=torch.int32).contiguous()
-        v.dura = dura.to(device=dev, dtype=torch.int32).contiguous()
-        v.target = target.contiguous().to(dev)
-        v.pos = torch.from_numpy(np.ascontiguousarray(pos.T)).to(dev)          # (3, n_pos) rows: query, bin, gt
-        v.neg = torch.from_numpy(np.ascontiguousarray(neg.T)).to(dev)          # (2, n_neg)
+        # (host arrays now, ONE upload of all the videos' integer tables and one of their float targets behind the loop: six small
+        # pageable copies per video each cost the host ~25 us and wait for the stream)
+        v.host_i = [quint.to(torch.int32).numpy().reshape(-1), dura.to(torch.int32).numpy().reshape(-1),
+                    np.ascontiguousarray(pos.T).reshape(-1), np.ascontiguousarray(neg.T).reshape(-1)]
+        v.host_f = target.contiguous().numpy().reshape(-1)
+        v.tshape = tuple(target.shape)
         v.video_len = float(g.video_len)
         v.regrs = torch.empty((v.n * v.T, 2 * k), dtype=torch.float32, device=dev)
         v.conf = torch.empty((v.n * v.T, k), dtype=torch.float32, device=dev)
@@ -128,10 +129,39 @@ def forward(model, engine, video_feature_list, gt_graph_list):
         v.ws = torch.empty((need,), dtype=torch.uint8, device=dev)             # activations live until the backward
         v.pos_v, v.pos_q, v.clip = engine.tables(v.T, dev)
         v.drop = (drop_p, int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0)
-        v.dregr = torch.zeros((v.n * v.T, ldr), dtype=torch.float32, device=dev)
-        v.dconf = torch.zeros((v.n * v.T, ldc), dtype=torch.float32, device=dev)
-        v.dcls = torch.zeros((v.n * v.T, ldc), dtype=torch.float32, device=dev)
         vids.append(v)
+    # ---- the batch's tables in two uploads, the seed-gradient buffers in one allocation (pieces padded to 16 bytes)
+    dev = vids[0].feat.device
+    pad4 = lambda n: (n + 3) // 4 * 4
+    i_sizes = [[pad4(a.size) for a in v.host_i] for v in vids]
+    f_sizes = [pad4(v.host_f.size) for v in vids]
+    blob_i = np.zeros((sum(sum(x) for x in i_sizes),), dtype=np.int32)
+    blob_f = np.zeros((max(1, sum(f_sizes)),), dtype=np.float32)
+    oi = of = 0
+    spans = []
+    for v, isz, fsz in zip(vids, i_sizes, f_sizes):
+        sp = []
+        for a, z in zip(v.host_i, isz):
+            blob_i[oi:oi + a.size] = a
+            sp.append((oi, a.size))
+            oi += z
+        blob_f[of:of + v.host_f.size] = v.host_f
+        spans.append((sp, (of, v.host_f.size)))
+        of += fsz
+    dev_i, dev_f = _lib.upload(blob_i, dev), _lib.upload(blob_f, dev)
+    g_sizes = [(v.n * v.T * ldr, v.n * v.T * ldc, v.n * v.T * ldc) for v in vids]
+    seeds = torch.zeros((sum(sum(x) for x in g_sizes),), dtype=torch.float32, device=dev)
+    og = 0
+    for v, (sp, (fo, fn)), gs_ in zip(vids, spans, g_sizes):
+        cut = lambda k: dev_i[sp[k][0]:sp[k][0] + sp[k][1]]
+        v.quint, v.dura = cut(0).view(v.n, 5), cut(1).view(v.n, 2)
+        v.pos, v.neg = cut(2).view(3, v.n_pos), cut(3).view(2, v.n_neg)
+        v.target = dev_f[fo:fo + fn].view(v.tshape)
+        v.dregr = seeds[og:og + gs_[0]].view(v.n * v.T, ldr); og += gs_[0]
+        v.dconf = seeds[og:og + gs_[1]].view(v.n * v.T, ldc); og += gs_[1]
+        v.dcls = seeds[og:og + gs_[2]].view(v.n * v.T, ldc); og += gs_[2]
+        v.host_i = v.host_f = None
+    ctx_keep = (dev_i, dev_f, seeds)
 
     def launch(v):
         _lib.check(lib.grd_set_dropout(engine.handle, v.drop[0], v.drop[1]))
@@ -162,6 +192,7 @@ def forward(model, engine, video_feature_list, gt_graph_list):
             launch(v)
     ctx = _Video()
     ctx.vids = vids
+    ctx.keep = ctx_keep
     ctx.count_pos = float(sum(v.n_pos * v.T for v in vids))
     ctx.count_neg = float(sum(v.n_neg * v.T for v in vids))
     ctx.count_mask = float(sum(v.n_mask for v in vids))
@@ -174,8 +205,8 @@ def loss_grad(model, engine, ctx, gs):
     f = model.loss_factor
     gs_arr = (ctypes.c_float * 5)(*[float(x) for x in gs])
     ctx.loss.zero_()
+    ctx.keep[2].zero_()                      # every video's dregr / dconf / dcls (one buffer)
     for v in ctx.vids:
-        v.dregr.zero_(); v.dconf.zero_(); v.dcls.zero_()
         _lib.check(engine.lib.grd_loss_grad(
             _lib.current_stream(), v.regrs.data_ptr(), v.conf.data_ptr(), v.cls.data_ptr(), v.clip.data_ptr(), v.target.data_ptr(),
             v.pos[0].data_ptr(), v.pos[1].data_ptr(), v.pos[2].data_ptr(), v.n_pos, v.neg[0].data_ptr(), v.neg[1].data_ptr(), v.n_neg,
@@ -187,11 +218,10 @@ def backward(model, engine, ctx, grad_terms, named_params):
     """HIP backward of every video; returns one gradient per entry of ``named_params`` (views of one flat buffer)."""
     loss_grad(model, engine, ctx, grad_terms.detach().cpu().tolist())
     # power-of-two scaling of the seed gradients for the split-operand backward GEMMs (see train_step.backward)
-    seeds = [t for v in ctx.vids for t in (v.dregr, v.dconf, v.dcls)]
-    scale = grad_scale(*seeds)
+    seeds = ctx.keep[2]                      # every video's seed gradients, one buffer
+    scale = grad_scale(seeds)
     if scale != 1.0:
-        for t in seeds:
-            t.mul_(scale)
+        seeds.mul_(scale)
     dev = ctx.vids[0].feat.device
     trainable = [(k, p) for k, p in named_params if p.requires_grad]
     sizes = [(p.numel() + 3) // 4 * 4 for _, p in trainable]
